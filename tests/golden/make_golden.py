@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REAL reference (oracle/_ref, built by `make -C oracle ref ref-native`).
+
+Runs only where /root/reference exists (this build container).  The reference itself never travels:
+what is committed is data (inputs, expected floats / bytes / hashes) plus this script.
+
+The reference latches APPROX_MODE once per process (rans_interface.cpp:100-115), so each mode runs in a
+child process (`--worker MODE`).  Before anything is written, the x86-64-v3 build that travels to the GPU
+box and the -march=native build (the reference's own setup.py flags) are checked to agree bit-for-bit.
+
+Fixtures:
+  g1_cdf.npz        G1/G2  4096 seeded rows x 3 modes: float32 CDF pairs of _fast_gmm_cdf<4> (bit patterns)
+                           + the (start,range) they imply
+  g3_small.json     G3     encode_with_indexes_gmm bytes, verbatim hex: n in {0,1,17,1000}, forced-bypass rows
+                           with positive and negative symbols, plus decoder outputs
+  ka1.json          KA-1   Kodak-half [1,192,32,24] cases (seeds 1234, 0..3): len + md5 + bypass count, 3 modes
+  g4_api.json       G4     Python-API level: the reference's own GaussianMixtureConditional.compress /
+                           decompress imported IN PLACE from /root/reference (un-clamped sigma, >=10 % zero
+                           channels): md5(bytes), len, abs_max, zero_bitmap, sha256(y_q), decompress == y_q
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from flashgmm_amd import testing as T  # noqa: E402
+
+MODE_NAMES = ["polya", "as", "logistic"]
+
+
+def g1_inputs():
+    rng = np.random.default_rng(20251003)
+    n = 4096
+    e = np.exp(rng.uniform(-3, 2.5, n)).astype(np.float32)
+    mu = (rng.standard_normal((n, 4)) * e[:, None]).astype(np.float32)
+    sg = np.clip((rng.uniform(0, 2, (n, 4)) + 0.05) * e[:, None], 0.11, 256).astype(np.float32)
+    lg = rng.standard_normal((n, 4))
+    pi = (np.exp(lg) / np.exp(lg).sum(1, keepdims=True)).astype(np.float32)
+    v = np.round(rng.standard_normal(n) * 1.5 * e + rng.standard_normal(n) * 2).astype(np.int32)
+    return v, sg, mu, pi
+
+
+def g3_cases():
+    """name -> (symbols, scales, means, weights) small explicit cases."""
+    cases = {}
+    rng = np.random.default_rng(33)
+
+    def rows(n, bypass_every=0):
+        e = np.exp(rng.uniform(-2, 2, n)).astype(np.float32)
+        mu = (rng.standard_normal((n, 4)) * e[:, None]).astype(np.float32)
+        sg = np.clip((rng.uniform(0, 2, (n, 4)) + 0.05) * e[:, None], 0.11, 256).astype(np.float32)
+        lg = rng.standard_normal((n, 4))
+        pi = (np.exp(lg) / np.exp(lg).sum(1, keepdims=True)).astype(np.float32)
+        v = np.round(rng.standard_normal(n) * 1.5 * e).astype(np.int32)
+        if bypass_every:
+            # forced bypass: sigma = 0.11 and |v - mu| >> sigma  => pmf == 0 (rans_interface.cpp:513)
+            idx = np.arange(0, n, bypass_every)
+            sg[idx] = 0.11
+            mu[idx] = 0.0
+            far = np.array([37, -37, 5, -5, 300, -300, 70000, -70000, 2**30, -(2**31)], np.int64)
+            v[idx] = far[np.arange(len(idx)) % len(far)].astype(np.int32)
+        return v, sg, mu, pi
+
+    cases["n0"] = rows(0)
+    cases["n1"] = rows(1)
+    cases["n1_bypass_neg"] = (np.array([-9], np.int32), np.full((1, 4), 0.11, np.float32),
+                              np.zeros((1, 4), np.float32), np.full((1, 4), 0.25, np.float32))
+    cases["n17"] = rows(17, bypass_every=4)
+    cases["n1000"] = rows(1000, bypass_every=97)
+    return cases
+
+
+def ka1_case(seed):
+    y, sg, mu, pi = T.make_latent(seed)
+    return T.to_coder_inputs(y, sg, mu, pi)
+
+
+def import_reference_entropy_models(ans_mod):
+    """Import /root/reference/compressai/entropy_models/entropy_models.py IN PLACE.
+
+    `import compressai` fails here with ModuleNotFoundError (torch_geometric / torchvision / pytorch_msssim are
+    not installed), so a bare package object with the right __path__ stands in for compressai/__init__.py and
+    the two compiled extensions come from oracle/_ref."""
+    import importlib.util
+    import sysconfig
+
+    pkg = types.ModuleType("compressai")
+    pkg.__path__ = ["/root/reference/compressai"]
+    pkg.available_entropy_coders = lambda: ["ans"]
+    pkg.get_entropy_coder = lambda: "ans"
+    pkg.ans = ans_mod
+    sys.modules["compressai"] = pkg
+    sys.modules["compressai.ans"] = ans_mod
+    cxx_path = os.path.join(O.REF_DIR, "_CXX" + sysconfig.get_config_var("EXT_SUFFIX"))
+    spec = importlib.util.spec_from_file_location("compressai._CXX", cxx_path)
+    cxx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cxx)
+    sys.modules["compressai._CXX"] = cxx
+    from compressai.entropy_models.entropy_models import GaussianMixtureConditional
+
+    return GaussianMixtureConditional
+
+
+def worker(mode: int, flavour: str):
+    import torch
+
+    os.environ["APPROX_MODE"] = str(mode)
+    ans = O.ref_ans(flavour)
+    probe = O.ref_probe(flavour)
+    assert probe.ref_probe_mode() == (mode | 0x100)
+    ts = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    out = {}
+
+    v, sg, mu, pi = g1_inputs()
+    c1, c2 = O.ref_gmm_cdf(probe, v, sg, mu, pi)
+    out["g1_c1_bits"] = c1.view(np.uint32).tolist()
+    out["g1_c2_bits"] = c2.view(np.uint32).tolist()
+
+    g3 = {}
+    for name, (sym, s, m, w) in g3_cases().items():
+        b = ans.RansEncoder().encode_with_indexes_gmm(ts(sym), ts(s), ts(m), ts(w), 0)
+        max_bs = int(np.abs(sym.astype(np.int64)).max() + 2) if len(sym) else 1
+        max_bs = min(max_bs, 400)  # bisection half-width; bypass symbols do not use it
+        d = ans.RansDecoder().decode_with_indexes_gmm(b, ts(s), ts(m), ts(w), max_bs).numpy()
+        g3[name] = {"hex": b.hex(), "max_bs": max_bs, "decoded": d.tolist()}
+    out["g3"] = g3
+
+    ka = {}
+    for seed in (1234, 0, 1, 2, 3):
+        sym, s, m, w, abs_max, zb, yq = ka1_case(seed)
+        b = ans.RansEncoder().encode_with_indexes_gmm(ts(sym), ts(s), ts(m), ts(w), abs_max + 1)
+        d = ans.RansDecoder().decode_with_indexes_gmm(b, ts(s), ts(m), ts(w), abs_max + 1).numpy()
+        ka[str(seed)] = {"n": int(len(sym)), "nz_channels": int(zb.sum()), "abs_max": int(abs_max), "len": len(b),
+                         "md5": hashlib.md5(b).hexdigest(), "roundtrip": bool((d == sym).all())}
+    out["ka1"] = ka
+
+    if flavour == "":
+        GMC = import_reference_entropy_models(ans)
+        g4 = {}
+        for seed, shape in ((4321, (192, 32, 24)), (77, (192, 16, 8)), (5, (320, 8, 12))):
+            M, h, w_ = shape
+            y, sg4, mu4, pi4 = T.make_latent(seed, M=M, h=h, w=w_, clamp=False, zero_frac=0.15)
+            gmc = GMC(K=4)
+            (b, abs_max, zb), yq = gmc.compress(ts(y), ts(sg4), ts(mu4), ts(pi4))
+            y_hat = gmc.decompress(b, abs_max, zb, ts(sg4), ts(mu4), ts(pi4))
+            g4[str(seed)] = {
+                "M": M, "h": h, "w": w_, "len": len(b), "md5": hashlib.md5(b).hexdigest(), "abs_max": int(abs_max),
+                "zero_bitmap": zb.tolist(), "yq_sha256": hashlib.sha256(yq.numpy().tobytes()).hexdigest(),
+                "decompress_equals_yq": bool(torch.equal(y_hat, yq)),
+                "y_hat_dtype": str(y_hat.dtype), "y_hat_shape": list(y_hat.shape),
+            }
+        out["g4"] = g4
+    json.dump(out, sys.stdout)
+
+
+def run_worker(mode, flavour):
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(mode), "--flavour", flavour],
+                       check=True, capture_output=True, text=True)
+    return json.loads(r.stdout[r.stdout.index("{"):])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--worker", type=int, default=None)
+    ap.add_argument("--flavour", default="")
+    a = ap.parse_args()
+    if a.worker is not None:
+        return worker(a.worker, a.flavour)
+
+    assert os.path.isdir("/root/reference"), "the reference is only present in the build container"
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"])
+    have_native = O.ref_available("native")
+    res = {}
+    for mode, name in enumerate(MODE_NAMES):
+        r = run_worker(mode, "")
+        if have_native:
+            rn = run_worker(mode, "native")
+            for key in ("g1_c1_bits", "g1_c2_bits", "g3", "ka1"):
+                assert r[key] == rn[key], f"x86-64-v3 and native reference builds differ: {name}/{key}"
+        res[name] = r
+        print(f"[{name}] reference run ok" + (" (v3 == native)" if have_native else ""))
+
+    # --- cross-check this repo's C restatement against the reference outputs before writing anything ---
+    v, sg, mu, pi = g1_inputs()
+    npz = {"v": v, "scales": sg, "means": mu, "weights": pi}
+    for mode, name in enumerate(MODE_NAMES):
+        c1 = np.array(res[name]["g1_c1_bits"], np.uint32)
+        c2 = np.array(res[name]["g1_c2_bits"], np.uint32)
+        o1, o2 = O.gmm_cdf(mode, v, sg, mu, pi)
+        assert (o1.view(np.uint32) == c1).all() and (o2.view(np.uint32) == c2).all(), f"oracle float mismatch {name}"
+        npz[f"c1_{name}"] = c1
+        npz[f"c2_{name}"] = c2
+        # G2: (start, range) implied by the reference floats (rans_interface.cpp:509-512)
+        lo = (c1.view(np.float32) * np.float32(65535.0)).astype(np.int64) & 0xFFFF
+        hi = (c2.view(np.float32) * np.float32(65535.0)).astype(np.int64) & 0xFFFF
+        npz[f"start_{name}"] = lo.astype(np.uint16)
+        npz[f"range_{name}"] = ((hi - lo) & 0xFFFF).astype(np.uint16)
+        for cname, (sym, s, m, w) in g3_cases().items():
+            assert O.encode_gmm(mode, sym, s, m, w).hex() == res[name]["g3"][cname]["hex"], (name, cname)
+        for seed, ent in res[name]["ka1"].items():
+            sym, s, m, w, abs_max, zb, yq = ka1_case(int(seed))
+            b = O.encode_gmm(mode, sym, s, m, w)
+            assert hashlib.md5(b).hexdigest() == ent["md5"] and ent["roundtrip"], (name, seed)
+    np.savez_compressed(os.path.join(HERE, "g1_cdf.npz"), **npz)
+
+    g3_out = {"note": "inputs are regenerated by make_golden.g3_cases(); hex = RansEncoder.encode_with_indexes_gmm output",
+              "cases": {}}
+    for cname, (sym, s, m, w) in g3_cases().items():
+        ent = {"symbols": sym.tolist()}
+        if len(sym) <= 17:
+            ent.update(scales=s.tolist(), means=m.tolist(), weights=w.tolist())
+        for name in MODE_NAMES:
+            ent[name] = res[name]["g3"][cname]
+        g3_out["cases"][cname] = ent
+    json.dump(g3_out, open(os.path.join(HERE, "g3_small.json"), "w"), indent=1)
+    json.dump({name: res[name]["ka1"] for name in MODE_NAMES}, open(os.path.join(HERE, "ka1.json"), "w"), indent=1)
+    json.dump({name: res[name]["g4"] for name in MODE_NAMES}, open(os.path.join(HERE, "g4_api.json"), "w"), indent=1)
+    # the survey's KA-1 must be what we just reproduced
+    assert res["polya"]["ka1"]["1234"]["md5"] == "e759909d27406fbc0168c33b4509772d"
+    assert res["as"]["ka1"]["1234"]["md5"] == "9283e03480f545471e6245b21aa61af5"
+    assert res["logistic"]["ka1"]["1234"]["md5"] == "ecbe33ac17fe297803909b32db54d1f6"
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
