@@ -1,0 +1,133 @@
+"""ctypes binding of libflashgmm_amd.so (include/flashgmm_amd.h).
+
+The library is built in-tree by ``flashgmm_amd/csrc/build.sh`` (``__graft_entry__.build()``).  There is no
+Python or CPU fallback for it: if the shared object is missing or no HIP device is usable, every entry point
+raises — loudly — instead of silently doing the work some other way.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libflashgmm_amd.so")
+
+FGMM_OK = 0
+FGMM_HOST, FGMM_DEVICE = 0, 1
+FGMM_K = 4
+MODES = {"polya": 0, "as": 1, "logistic": 2}  # numbering of the reference CODE (rans_interface.cpp:224-232)
+
+STATUS_NAMES = {1: "FGMM_ERR_INVALID", 2: "FGMM_ERR_NO_DEVICE", 3: "FGMM_ERR_HIP", 4: "FGMM_ERR_NOMEM",
+                5: "FGMM_ERR_STREAM", 6: "FGMM_ERR_UNSUPPORTED"}
+
+
+class FgmmError(RuntimeError):
+    """Raised for every non-zero fgmm_status (the reference raises RuntimeError through pybind11 as well)."""
+
+
+class fgmm_params(C.Structure):
+    _fields_ = [("scales", C.c_void_p), ("means", C.c_void_p), ("weights", C.c_void_p),
+                ("stride_k", C.c_int64), ("stride_c", C.c_int64)]
+
+
+class fgmm_item(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("params", fgmm_params), ("M", C.c_int32), ("K", C.c_int32), ("hw", C.c_int64),
+                ("yq_out", C.c_void_p), ("zero_bitmap", C.c_void_p), ("abs_max", C.c_int32),
+                ("bytes", C.c_void_p), ("bytes_len", C.c_size_t), ("status", C.c_int32)]
+
+
+# every symbol include/flashgmm_amd.h declares: (restype, argtypes)
+_p, _i, _i32, _i64, _sz = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_size_t
+_pp, _psz = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
+SIGNATURES = {
+    "fgmm_abi_version": (_i, []),
+    "fgmm_last_error": (C.c_char_p, []),
+    "fgmm_ctx_create": (_i, [_i, _i, _pp]),
+    "fgmm_ctx_destroy": (None, [_p]),
+    "fgmm_ctx_device": (_i, [_p]),
+    "fgmm_ctx_threads": (_i, [_p]),
+    "fgmm_free": (None, [_p]),
+    "fgmm_encode_with_indexes_gmm": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _i32, _pp, _psz]),
+    "fgmm_decode_with_indexes_gmm": (_i, [_p, _p, _sz, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _i32, _p]),
+    "fgmm_gmc_compress": (_i, [_p, _p, _p, C.POINTER(fgmm_params), _i, _i, _i64, _i, _i, _p, C.POINTER(_i32), _p, _pp, _psz]),
+    "fgmm_gmc_decompress": (_i, [_p, _p, _p, _sz, _i32, _p, C.POINTER(fgmm_params), _i, _i, _i64, _i, _i, _p]),
+    "fgmm_gmc_compress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
+    "fgmm_gmc_decompress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
+    "fgmm_gmm_cdf_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p, _p]),
+    "fgmm_build_symtab_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "fgmm_build_cdftab_hip": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i32, _p, _p, C.c_uint64, _p]),
+    "fgmm_rans_encode_symtab": (_i, [_p, _p, _i64, _pp, _psz]),
+    "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, _i64, _i32, _p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_ctxs = {}
+
+
+def lib() -> C.CDLL:
+    """Load the shared object (no GPU needed for this step) and bind every declared symbol."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise FgmmError(
+                    f"{LIB_PATH} is missing: build it with flashgmm_amd/csrc/build.sh (or __graft_entry__.build()). "
+                    "flashgmm_amd has no CPU / pure-Python fallback for the GMM entropy-coding path."
+                )
+            L = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)  # AttributeError here = header and library out of sync
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != FGMM_OK:
+        msg = lib().fgmm_last_error().decode(errors="replace")
+        raise FgmmError(f"{what or 'libflashgmm_amd'}: {STATUS_NAMES.get(rc, rc)}: {msg}")
+
+
+def ctx(device: int = -1, n_threads: int = 0) -> C.c_void_p:
+    """Process-wide context of a GPU (created on first use; needs a real HIP device)."""
+    L = lib()
+    key = int(device)
+    with _lock:
+        h = _ctxs.get(key)
+    if h is None:
+        out = C.c_void_p()
+        check(L.fgmm_ctx_create(key, int(n_threads), C.byref(out)), "fgmm_ctx_create")
+        with _lock:
+            if key in _ctxs:  # lost a race: keep the first
+                L.fgmm_ctx_destroy(out)
+            else:
+                _ctxs[key] = out
+            h = _ctxs[key]
+    return h
+
+
+def take_bytes(ptr: C.c_void_p, length: int) -> bytes:
+    data = C.string_at(ptr, length)
+    lib().fgmm_free(ptr)
+    return data
+
+
+def mode_id(mode) -> int:
+    if isinstance(mode, str):
+        return MODES[mode.lower()]
+    m = int(mode)
+    if m not in (0, 1, 2):
+        raise ValueError(f"mode {mode!r}")
+    return m
+
+
+def default_mode() -> int:
+    """APPROX_MODE env var, parsed as the reference does (rans_interface.cpp:99-115): 0/1/2, anything else -> 0."""
+    try:
+        m = int(os.environ.get("APPROX_MODE", "0"))
+    except ValueError:
+        return 0
+    return m if 0 <= m <= 2 else 0

@@ -1,0 +1,13 @@
+#!/usr/bin/env bash
+# Build libflashgmm_amd.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+#   -ffp-contract=off                         : the only fused ops are the explicit FMAs of fgmm_math.h
+#   -fhip-fp32-correctly-rounded-divide-sqrt  : IEEE '/' and sqrt on the device (bit-exact CDFs)
+#   -march=x86-64-v3                          : host rANS code may use AVX2/BMI2, stays portable across hosts
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../libflashgmm_amd.so
+COMMON="-O3 -fPIC -std=c++17 -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math"
+$HIPCC $COMMON --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc \
+    -march=x86-64-v3 -shared -o $OUT fgmm_kernels.hip fgmm_rans.cpp fgmm_capi.cpp -lpthread "$@"
+echo "built $(realpath $OUT)"

@@ -1,0 +1,841 @@
+// fgmm_capi.cpp — the C ABI of libflashgmm_amd.so (include/flashgmm_amd.h): context, staging, orchestration.
+//
+// One fgmm_ctx per process per GPU owns
+//   * a device workspace and a pinned host staging area (both grow on demand and are then reused),
+//   * HIP events used to hand finished tables to the host coder item by item,
+//   * a pool of host worker threads, one rANS state machine per bitstream.
+// The float work is enqueued for ALL items of a call first (batched kernels, blockIdx.z = item), the tables
+// come back by pinned hipMemcpyAsync, and the workers start on item i as soon as its copy has landed, so the
+// PCIe transfer of item i+1 overlaps the host coding of item i.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <queue>
+#include <thread>
+#include <vector>
+
+#include "../../include/flashgmm_amd.h"
+#include "fgmm_internal.h"
+
+using namespace fgmm;
+
+namespace {
+
+thread_local char t_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(t_err, sizeof t_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess) return fail(FGMM_ERR_HIP, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define LAUNCH_TRY(expr)                                                                                    \
+  do {                                                                                                      \
+    int e_ = (expr);                                                                                        \
+    if (e_ != 0) return fail(FGMM_ERR_HIP, "%s -> %s", #expr, hipGetErrorString((hipError_t)e_));          \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- host worker pool ----------------------------------------------------------------------------------
+class Pool {
+public:
+  explicit Pool(int n) {
+    for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  int size() const { return (int)th_.size(); }
+  void submit(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      q_.push(std::move(f));
+      ++pending_;
+    }
+    cv_.notify_one();
+  }
+  void wait_all() {
+    std::unique_lock<std::mutex> l(m_);
+    done_cv_.wait(l, [this] { return pending_ == 0; });
+  }
+
+private:
+  void run() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return stop_ || !q_.empty(); });
+        if (stop_ && q_.empty()) return;
+        f = std::move(q_.front());
+        q_.pop();
+      }
+      f();
+      {
+        std::lock_guard<std::mutex> l(m_);
+        if (--pending_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  std::queue<std::function<void()>> q_;
+  int pending_ = 0;
+  bool stop_ = false;
+};
+
+// bump allocator over one device buffer + one pinned host buffer with identical offsets
+struct Arena {
+  size_t off = 0;
+  size_t take(size_t bytes, size_t align = 256) {
+    off = align_up(off, align);
+    const size_t o = off;
+    off += bytes;
+    return o;
+  }
+};
+
+} // namespace
+
+struct fgmm_ctx {
+  int device = 0;
+  std::mutex mu; // one call at a time per context
+  Pool *pool = nullptr;
+  char *d_ws = nullptr;
+  size_t d_cap = 0;
+  char *h_ws = nullptr; // pinned
+  size_t h_cap = 0;
+  std::vector<hipEvent_t> events;
+
+  int ensure_device(size_t bytes) {
+    if (bytes <= d_cap) return FGMM_OK;
+    if (d_ws) HIP_TRY(hipFree(d_ws));
+    d_ws = nullptr;
+    d_cap = 0;
+    const size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    HIP_TRY(hipMalloc((void **)&d_ws, want));
+    d_cap = want;
+    return FGMM_OK;
+  }
+  int ensure_host(size_t bytes) {
+    if (bytes <= h_cap) return FGMM_OK;
+    if (h_ws) HIP_TRY(hipHostFree(h_ws));
+    h_ws = nullptr;
+    h_cap = 0;
+    const size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    HIP_TRY(hipHostMalloc((void **)&h_ws, want, hipHostMallocDefault));
+    h_cap = want;
+    return FGMM_OK;
+  }
+  int ensure_events(size_t n) {
+    while (events.size() < n) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      events.push_back(e);
+    }
+    return FGMM_OK;
+  }
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess)) ok = true;
+  }
+  ~DeviceGuard() {
+    int cur;
+    if (ok && prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+bool mode_ok(int mode) { return mode >= 0 && mode <= 2; }
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// can item use the 16-B-per-lane symtab kernel?
+bool enc_vec4_ok(const EncDesc &d) {
+  return d.stride_p == 1 && (d.hw & 3) == 0 && (d.stride_c & 3) == 0 && (d.stride_k & 3) == 0 && aligned16(d.scales) &&
+         aligned16(d.means) && aligned16(d.weights) && (d.y ? aligned16(d.y) : aligned16(d.sym)) && aligned16(d.packed);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// encode, batched.  Items are described in the latent-codec layout (fgmm_item) or as raw (n,K) rows.
+// ---------------------------------------------------------------------------------------------------------
+struct EncItem {
+  // inputs
+  const float *y = nullptr;      // device
+  const int32_t *sym_dev = nullptr; // device (raw boundary)
+  const int32_t *sym_host = nullptr; // host copy of the raw symbols when the caller has one
+  fgmm_params prm{};
+  int64_t stride_p = 1;
+  int32_t M = 0;
+  int64_t hw = 0;
+  int clamp = 0;
+  float *yq = nullptr; // device out
+  // outputs
+  int64_t *zero_bitmap = nullptr; // host [M] or null
+  int32_t abs_max = 0;
+  uint8_t *bytes = nullptr;
+  size_t bytes_len = 0;
+  int status = FGMM_OK;
+  // workspace offsets
+  size_t o_min = 0, o_max = 0, o_nz = 0, o_meta = 0, o_packed = 0;
+};
+
+int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items, int mode) {
+  const int count = (int)items.size();
+  if (count == 0) return FGMM_OK;
+  // ---- plan the workspace: [descs][small: per item min|max|nz|meta][tables: per item packed] -------
+  Arena ar;
+  const size_t o_descs = ar.take(sizeof(EncDesc) * count);
+  const size_t o_small = ar.take(0);
+  int M_max = 0;
+  int64_t hw_max = 0;
+  for (auto &it : items) {
+    it.o_min = ar.take(sizeof(float) * it.M, 16);
+    it.o_max = ar.take(sizeof(float) * it.M, 16);
+    it.o_nz = ar.take(sizeof(int32_t) * it.M, 16);
+    it.o_meta = ar.take(16, 16);
+    M_max = std::max(M_max, it.M);
+    hw_max = std::max(hw_max, it.hw);
+  }
+  const size_t small_bytes = ar.off - o_small;
+  for (auto &it : items) it.o_packed = ar.take(sizeof(uint32_t) * (size_t)it.M * (size_t)it.hw + 64);
+  const size_t total = ar.off;
+  int rc;
+  if ((rc = ctx->ensure_device(total)) || (rc = ctx->ensure_host(total)) || (rc = ctx->ensure_events(count + 1))) return rc;
+
+  // ---- descriptors ------------------------------------------------------------------------------
+  EncDesc *hd = reinterpret_cast<EncDesc *>(ctx->h_ws + o_descs);
+  bool vec4 = true, any_y = false;
+  for (int i = 0; i < count; ++i) {
+    const EncItem &it = items[i];
+    EncDesc &d = hd[i];
+    memset(&d, 0, sizeof d);
+    d.y = it.y;
+    d.sym = it.sym_dev;
+    d.scales = it.prm.scales;
+    d.means = it.prm.means;
+    d.weights = it.prm.weights;
+    d.stride_k = it.prm.stride_k;
+    d.stride_c = it.prm.stride_c;
+    d.stride_p = it.stride_p;
+    d.hw = it.hw;
+    d.M = it.M;
+    d.clamp = it.clamp;
+    d.yq = it.yq;
+    d.chan_min = reinterpret_cast<float *>(ctx->d_ws + it.o_min);
+    d.chan_max = reinterpret_cast<float *>(ctx->d_ws + it.o_max);
+    d.chan_nz = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_nz) : nullptr;
+    d.packed = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_packed);
+    d.meta = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_meta);
+    vec4 = vec4 && enc_vec4_ok(d);
+    any_y = any_y || it.y;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs, hd, sizeof(EncDesc) * count, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + o_small, 0, small_bytes, stream));
+  const EncDesc *dd = reinterpret_cast<const EncDesc *>(ctx->d_ws + o_descs);
+  // a batch is homogeneous by construction: all latent-layout items (y given) or one raw (n,K) item
+  if (any_y) LAUNCH_TRY(launch_quant_stats(dd, count, M_max, stream));
+  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4, stream));
+  // ---- tables back to the host: small region first, then one copy + event per item ----------------
+  HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_small, ctx->d_ws + o_small, small_bytes, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipEventRecord(ctx->events[count], stream));
+  for (int i = 0; i < count; ++i) {
+    const EncItem &it = items[i];
+    const size_t bytes = sizeof(uint32_t) * (size_t)it.M * (size_t)it.hw;
+    if (bytes) HIP_TRY(hipMemcpyAsync(ctx->h_ws + it.o_packed, ctx->d_ws + it.o_packed, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(ctx->events[i], stream));
+  }
+  HIP_TRY(hipEventSynchronize(ctx->events[count]));
+
+  // ---- host side: per item side information, then one rANS job per item -----------------------------
+  std::vector<std::vector<int32_t>> wide_syms(count); // only for bypass symbols beyond int16 (rare)
+  for (int i = 0; i < count; ++i) {
+    EncItem &it = items[i];
+    int64_t n = (int64_t)it.M * it.hw;
+    const unsigned long long n_bypass = *reinterpret_cast<unsigned long long *>(ctx->h_ws + it.o_meta);
+    const int32_t *syms_for_bypass = it.sym_host;
+    if (it.y) {
+      const float *mn = reinterpret_cast<const float *>(ctx->h_ws + it.o_min);
+      const float *mx = reinterpret_cast<const float *>(ctx->h_ws + it.o_max);
+      const int32_t *nz = reinterpret_cast<const int32_t *>(ctx->h_ws + it.o_nz);
+      float gmin = INFINITY, gmax = -INFINITY;
+      int n_nz = 0;
+      for (int c = 0; c < it.M; ++c) {
+        gmin = fminf(gmin, mn[c]);
+        gmax = fmaxf(gmax, mx[c]);
+        n_nz += nz[c] != 0;
+        if (it.zero_bitmap) it.zero_bitmap[c] = nz[c] != 0;
+      }
+      // max(torch.abs(y.max()).int(), torch.abs(y.min()).int()) + 1, floored at 1   (entropy_models.py:834-837)
+      auto trunc_abs = [](float v) -> int64_t {
+        const float a = fabsf(v);
+        if (!(a < 2147483648.0f)) return INT32_MIN; // torch .int() of an out-of-range float: x86 cvttss2si
+        return (int64_t)(int32_t)a;
+      };
+      int64_t am = (it.M * it.hw) ? std::max(trunc_abs(gmax), trunc_abs(gmin)) + 1 : 1;
+      if (am < 1) am = 1;
+      it.abs_max = (int32_t)am;
+      n = (int64_t)n_nz * it.hw;
+      if (n_bypass && am > 32767) {
+        // a bypassed symbol may not fit the 16 bits the table carries: fetch y and rebuild the int32 symbols
+        // (integer conversion only; y is complete — the kernels that read it have finished)
+        std::vector<float> yraw((size_t)it.M * it.hw);
+        HIP_TRY(hipMemcpy(yraw.data(), it.y, sizeof(float) * yraw.size(), hipMemcpyDeviceToHost));
+        wide_syms[i].reserve((size_t)n);
+        for (int c = 0; c < it.M; ++c)
+          if (nz[c])
+            for (int64_t p = 0; p < it.hw; ++p) wide_syms[i].push_back((int32_t)nearbyintf(yraw[(size_t)c * it.hw + p]));
+        syms_for_bypass = wide_syms[i].data();
+      }
+    } else if (n_bypass && !it.sym_host) {
+      wide_syms[i].resize((size_t)n);
+      HIP_TRY(hipMemcpy(wide_syms[i].data(), it.sym_dev, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+      syms_for_bypass = wide_syms[i].data();
+    }
+    HIP_TRY(hipEventSynchronize(ctx->events[i]));
+    const uint32_t *packed = reinterpret_cast<const uint32_t *>(ctx->h_ws + it.o_packed);
+    EncItem *pit = &it;
+    auto job = [pit, packed, syms_for_bypass, n, n_bypass] {
+      pit->status = rans_encode_symtab(packed, syms_for_bypass, n, (int64_t)n_bypass, &pit->bytes, &pit->bytes_len);
+    };
+    if (count == 1) job(); else ctx->pool->submit(job);
+  }
+  if (count > 1) ctx->pool->wait_all();
+  for (auto &it : items)
+    if (it.status) return fail(it.status, "host rANS encode failed (%d)", it.status);
+  return FGMM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decode, batched
+// ---------------------------------------------------------------------------------------------------------
+struct DecItem {
+  const uint8_t *enc = nullptr;
+  size_t enc_len = 0;
+  fgmm_params prm{};
+  int64_t stride_p = 1;
+  int32_t M = 0;
+  int64_t hw = 0;
+  int clamp = 0;
+  int32_t max_bs = 1;
+  const int64_t *zero_bitmap = nullptr; // host [M] or null (= all channels coded)
+  float *y_hat = nullptr;               // device [M*hw] or null
+  int32_t *sym_host_out = nullptr;      // host [n] or null
+  int status = FGMM_OK;
+  // derived
+  int32_t n_ch = 0;
+  int64_t n = 0;
+  size_t o_list = 0, o_rank = 0, o_hdr = 0, o_pool = 0, o_used = 0, o_sym = 0;
+  size_t ho_hdr = 0, ho_pool = 0, ho_sym = 0;
+  uint64_t pool_cap = 0, pool_used = 0;
+};
+
+int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items, int mode) {
+  const int count = (int)items.size();
+  if (count == 0) return FGMM_OK;
+  Arena ar;
+  // device: [descs | scat descs | chan lists & ranks] (mirrored on the host for one H2D) [used counters] then big buffers
+  const size_t o_descs = ar.take(sizeof(DecDesc) * count);
+  const size_t o_sdescs = ar.take(sizeof(ScatDesc) * count);
+  int n_ch_max = 0, M_max = 0;
+  int64_t hw_max = 0;
+  for (auto &it : items) {
+    if (it.max_bs < 0 || it.max_bs > FGMM_MAX_BS) return fail(FGMM_ERR_UNSUPPORTED, "max_bs_value %d outside [0, %d]", it.max_bs, FGMM_MAX_BS);
+    it.n_ch = 0;
+    for (int c = 0; c < it.M; ++c) it.n_ch += it.zero_bitmap ? (it.zero_bitmap[c] != 0) : 1;
+    it.n = (int64_t)it.n_ch * it.hw;
+    it.o_list = ar.take(sizeof(int32_t) * std::max(it.n_ch, 1), 16);
+    it.o_rank = ar.take(sizeof(int32_t) * std::max(it.M, 1), 16);
+    n_ch_max = std::max(n_ch_max, it.n_ch);
+    M_max = std::max(M_max, it.M);
+    hw_max = std::max(hw_max, it.hw);
+  }
+  const size_t o_used = ar.take(16 * (size_t)count, 256);
+  const size_t upload_bytes = o_used; // everything before the counters is uploaded
+  for (int i = 0; i < count; ++i) items[i].o_used = o_used + 16 * (size_t)i;
+  const size_t host_fixed = ar.off;
+  for (auto &it : items) {
+    const uint64_t rowcap = ((uint64_t)(2 * (int64_t)it.max_bs + 2) + 3) & ~3ull;
+    it.pool_cap = (uint64_t)it.n * rowcap;
+    it.o_hdr = ar.take(sizeof(uint64_t) * (size_t)it.n + 64);
+    it.o_pool = ar.take(sizeof(uint16_t) * it.pool_cap + 64);
+    it.o_sym = ar.take(sizeof(int32_t) * (size_t)it.n + 64);
+  }
+  int rc;
+  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(host_fixed)) || (rc = ctx->ensure_events(count + 1))) return rc;
+
+  DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_descs);
+  ScatDesc *hs = reinterpret_cast<ScatDesc *>(ctx->h_ws + o_sdescs);
+  for (int i = 0; i < count; ++i) {
+    DecItem &it = items[i];
+    int32_t *list = reinterpret_cast<int32_t *>(ctx->h_ws + it.o_list);
+    int32_t *rank = reinterpret_cast<int32_t *>(ctx->h_ws + it.o_rank);
+    int r = 0;
+    for (int c = 0; c < it.M; ++c) {
+      const bool nzc = it.zero_bitmap ? (it.zero_bitmap[c] != 0) : true;
+      rank[c] = nzc ? r : -1;
+      if (nzc) list[r++] = c;
+    }
+    DecDesc &d = hd[i];
+    memset(&d, 0, sizeof d);
+    d.scales = it.prm.scales;
+    d.means = it.prm.means;
+    d.weights = it.prm.weights;
+    d.stride_k = it.prm.stride_k;
+    d.stride_c = it.prm.stride_c;
+    d.stride_p = it.stride_p;
+    d.hw = it.hw;
+    d.chan_list = reinterpret_cast<const int32_t *>(ctx->d_ws + it.o_list);
+    d.n_ch = it.n_ch;
+    d.max_bs = it.max_bs;
+    d.clamp = it.clamp;
+    d.hdr = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_hdr);
+    d.pool = reinterpret_cast<uint16_t *>(ctx->d_ws + it.o_pool);
+    d.pool_cap = it.pool_cap;
+    d.pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_used);
+    ScatDesc &s = hs[i];
+    memset(&s, 0, sizeof s);
+    s.sym = reinterpret_cast<const int32_t *>(ctx->d_ws + it.o_sym);
+    s.chan_rank = reinterpret_cast<const int32_t *>(ctx->d_ws + it.o_rank);
+    s.y_hat = it.y_hat;
+    s.hw = it.hw;
+    s.M = it.M;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + o_used, 0, 16 * (size_t)count, stream));
+  LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs), count, n_ch_max, hw_max, mode, stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_used, ctx->d_ws + o_used, 16 * (size_t)count, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+
+  // ---- now the pool sizes are known: lay out the pinned receive area -------------------------------
+  Arena har;
+  har.off = host_fixed;
+  for (int i = 0; i < count; ++i) {
+    DecItem &it = items[i];
+    const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
+    if (u[1]) return fail(FGMM_ERR_HIP, "edge-table pool overflow on item %d (internal sizing error)", i);
+    it.pool_used = u[0];
+    it.ho_hdr = har.take(sizeof(uint64_t) * (size_t)it.n + 64);
+    it.ho_pool = har.take(sizeof(uint16_t) * it.pool_used + 128);
+    it.ho_sym = har.take(sizeof(int32_t) * (size_t)it.n + 64);
+  }
+  {
+    // growing the pinned buffer would invalidate what was just read; everything needed is already in `items`
+    std::vector<char> keep(ctx->h_ws, ctx->h_ws + host_fixed);
+    if ((rc = ctx->ensure_host(har.off))) return rc;
+    memcpy(ctx->h_ws, keep.data(), host_fixed);
+  }
+  for (int i = 0; i < count; ++i) {
+    DecItem &it = items[i];
+    if (it.n) {
+      HIP_TRY(hipMemcpyAsync(ctx->h_ws + it.ho_hdr, ctx->d_ws + it.o_hdr, sizeof(uint64_t) * (size_t)it.n, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(ctx->h_ws + it.ho_pool, ctx->d_ws + it.o_pool, sizeof(uint16_t) * it.pool_used, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipEventRecord(ctx->events[i], stream));
+  }
+  for (int i = 0; i < count; ++i) {
+    DecItem *pit = &items[i];
+    HIP_TRY(hipEventSynchronize(ctx->events[i]));
+    char *hws = ctx->h_ws;
+    auto job = [pit, hws] {
+      int32_t *out = reinterpret_cast<int32_t *>(hws + pit->ho_sym);
+      memset(hws + pit->ho_pool + sizeof(uint16_t) * pit->pool_used, 0, 64); // defined bytes for the SIMD over-read
+      pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, reinterpret_cast<const uint64_t *>(hws + pit->ho_hdr),
+                                       reinterpret_cast<const uint16_t *>(hws + pit->ho_pool), pit->n, pit->max_bs, out);
+      if (pit->status == FGMM_OK && pit->sym_host_out) memcpy(pit->sym_host_out, out, sizeof(int32_t) * (size_t)pit->n);
+    };
+    if (count == 1) job(); else ctx->pool->submit(job);
+  }
+  if (count > 1) ctx->pool->wait_all();
+  for (auto &it : items)
+    if (it.status) return fail(it.status, "host rANS decode failed (%d)%s", it.status, it.status == FGMM_ERR_STREAM ? ": bitstream too short" : "");
+
+  // ---- symbols back to the GPU and into y_hat --------------------------------------------------------
+  bool any_scatter = false;
+  for (auto &it : items) {
+    if (!it.y_hat) continue;
+    any_scatter = true;
+    if (it.n) HIP_TRY(hipMemcpyAsync(ctx->d_ws + it.o_sym, ctx->h_ws + it.ho_sym, sizeof(int32_t) * (size_t)it.n, hipMemcpyHostToDevice, stream));
+  }
+  if (any_scatter) {
+    bool all = true;
+    for (auto &it : items) all = all && it.y_hat;
+    if (!all) return fail(FGMM_ERR_INVALID, "mixed y_hat / symbol outputs in one batch");
+    LAUNCH_TRY(launch_scatter(reinterpret_cast<const ScatDesc *>(ctx->d_ws + o_sdescs), count, M_max, hw_max, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return FGMM_OK;
+}
+
+// stage an (n,K) host parameter triple on the device; returns device pointers + strides to use
+struct StagedRows {
+  const float *s = nullptr, *m = nullptr, *w = nullptr;
+  int64_t stride_n = 0, stride_k = 0;
+};
+
+} // namespace
+
+// ===========================================================================================================
+// extern "C"
+// ===========================================================================================================
+extern "C" {
+
+int fgmm_abi_version(void) { return FGMM_ABI_VERSION; }
+const char *fgmm_last_error(void) { return t_err; }
+
+int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {
+  if (!out) return fail(FGMM_ERR_INVALID, "out == NULL");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FGMM_ERR_NO_DEVICE, "no HIP device: libflashgmm_amd has no CPU path for the float work");
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return fail(FGMM_ERR_NO_DEVICE, "hipGetDevice failed");
+  if (device >= ndev) return fail(FGMM_ERR_INVALID, "device %d of %d", device, ndev);
+  DeviceGuard g(device);
+  if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+  if (n_threads <= 0) {
+    n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 4;
+    n_threads = std::min(n_threads, 16);
+  }
+  fgmm_ctx *c = new (std::nothrow) fgmm_ctx;
+  if (!c) return fail(FGMM_ERR_NOMEM, "ctx");
+  c->device = device;
+  c->pool = new Pool(n_threads);
+  *out = c;
+  return FGMM_OK;
+}
+
+void fgmm_ctx_destroy(fgmm_ctx *ctx) {
+  if (!ctx) return;
+  {
+    DeviceGuard g(ctx->device);
+    delete ctx->pool;
+    for (auto e : ctx->events) (void)hipEventDestroy(e);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->h_ws) (void)hipHostFree(ctx->h_ws);
+  }
+  delete ctx;
+}
+
+int fgmm_ctx_device(const fgmm_ctx *ctx) { return ctx ? ctx->device : -1; }
+int fgmm_ctx_threads(const fgmm_ctx *ctx) { return ctx && ctx->pool ? ctx->pool->size() : 0; }
+
+// ---- section 2: entropy-model level ---------------------------------------------------------------------
+
+int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales) {
+  if (!ctx || count < 0 || (count && !items) || !mode_ok(mode)) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+  std::vector<EncItem> v((size_t)count);
+  for (int i = 0; i < count; ++i) {
+    const fgmm_item &s = items[i];
+    if (s.K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", s.K);
+    if (s.M < 0 || s.hw < 0 || (s.M * s.hw && (!s.y || !s.params.scales || !s.params.means || !s.params.weights)))
+      return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
+    EncItem &e = v[i];
+    e.y = s.y;
+    e.prm = s.params;
+    e.M = s.M;
+    e.hw = s.hw;
+    e.clamp = clamp_scales;
+    e.yq = s.yq_out;
+    e.zero_bitmap = s.zero_bitmap;
+  }
+  const int rc = encode_batch(ctx, (hipStream_t)stream, v, mode);
+  for (int i = 0; i < count; ++i) {
+    items[i].abs_max = v[i].abs_max;
+    items[i].bytes = v[i].bytes;
+    items[i].bytes_len = v[i].bytes_len;
+    items[i].status = v[i].status;
+  }
+  return rc;
+}
+
+int fgmm_gmc_compress(fgmm_ctx *ctx, void *stream, const float *y, const fgmm_params *params, int M, int K,
+                      int64_t hw, int mode, int clamp_scales, float *yq_out, int32_t *abs_max_out,
+                      int64_t *zero_bitmap_out, uint8_t **out, size_t *out_len) {
+  if (!params || !out || !out_len) return fail(FGMM_ERR_INVALID, "null argument");
+  fgmm_item it;
+  memset(&it, 0, sizeof it);
+  it.y = y;
+  it.params = *params;
+  it.M = M;
+  it.K = K;
+  it.hw = hw;
+  it.yq_out = yq_out;
+  it.zero_bitmap = zero_bitmap_out;
+  const int rc = fgmm_gmc_compress_batch(ctx, stream, &it, 1, mode, clamp_scales);
+  if (rc) return rc;
+  if (abs_max_out) *abs_max_out = it.abs_max;
+  *out = it.bytes;
+  *out_len = it.bytes_len;
+  return FGMM_OK;
+}
+
+int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales) {
+  if (!ctx || count < 0 || (count && !items) || !mode_ok(mode)) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+  std::vector<DecItem> v((size_t)count);
+  for (int i = 0; i < count; ++i) {
+    const fgmm_item &s = items[i];
+    if (s.K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", s.K);
+    if (s.M < 0 || s.hw < 0 || !s.bytes || !s.zero_bitmap || !s.yq_out ||
+        (s.M * s.hw && (!s.params.scales || !s.params.means || !s.params.weights)))
+      return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
+    DecItem &d = v[i];
+    d.enc = s.bytes;
+    d.enc_len = s.bytes_len;
+    d.prm = s.params;
+    d.M = s.M;
+    d.hw = s.hw;
+    d.clamp = clamp_scales;
+    d.max_bs = s.abs_max + 1; // entropy_models.py:888
+    d.zero_bitmap = s.zero_bitmap;
+    d.y_hat = s.yq_out;
+  }
+  const int rc = decode_batch(ctx, (hipStream_t)stream, v, mode);
+  for (int i = 0; i < count; ++i) items[i].status = v[i].status;
+  return rc;
+}
+
+int fgmm_gmc_decompress(fgmm_ctx *ctx, void *stream, const uint8_t *encoded, size_t encoded_len, int32_t abs_max,
+                        const int64_t *zero_bitmap, const fgmm_params *params, int M, int K, int64_t hw, int mode,
+                        int clamp_scales, float *y_hat_out) {
+  if (!params) return fail(FGMM_ERR_INVALID, "null argument");
+  fgmm_item it;
+  memset(&it, 0, sizeof it);
+  it.params = *params;
+  it.M = M;
+  it.K = K;
+  it.hw = hw;
+  it.yq_out = y_hat_out;
+  it.zero_bitmap = const_cast<int64_t *>(zero_bitmap);
+  it.abs_max = abs_max;
+  it.bytes = const_cast<uint8_t *>(encoded);
+  it.bytes_len = encoded_len;
+  return fgmm_gmc_decompress_batch(ctx, stream, &it, 1, mode, clamp_scales);
+}
+
+// ---- section 1: the reference's native boundary ------------------------------------------------------------
+
+namespace {
+
+// Host (n,K) rows -> device.  The three arrays are copied as the smallest span covering every addressed element
+// when that span is dense enough; otherwise they are gathered into (n,4) row-major staging first (a copy, no
+// arithmetic).  Device rows are used in place.
+int stage_rows(fgmm_ctx *ctx, hipStream_t stream, const float *scales, const float *means, const float *weights,
+               int64_t n, int64_t stride_n, int64_t stride_k, int memspace, std::vector<void *> &to_free, StagedRows *out) {
+  if (memspace == FGMM_DEVICE || n == 0) {
+    *out = {scales, means, weights, stride_n, stride_k};
+    return FGMM_OK;
+  }
+  (void)ctx;
+  const float *src[3] = {scales, means, weights};
+  const float *dst[3];
+  const bool dense = stride_n >= 0 && stride_k >= 0 && ((n - 1) * stride_n + 3 * stride_k + 1) <= 8 * n;
+  const size_t span = dense ? (size_t)((n - 1) * stride_n + 3 * stride_k + 1) : (size_t)n * 4;
+  for (int a = 0; a < 3; ++a) {
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, span * sizeof(float) + 64));
+    to_free.push_back(d);
+    if (dense) {
+      HIP_TRY(hipMemcpyAsync(d, src[a], span * sizeof(float), hipMemcpyHostToDevice, stream));
+    } else {
+      std::vector<float> tmp((size_t)n * 4);
+      for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 4; ++k) tmp[(size_t)i * 4 + k] = src[a][i * stride_n + k * stride_k];
+      HIP_TRY(hipMemcpy(d, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    dst[a] = d;
+  }
+  *out = {dst[0], dst[1], dst[2], dense ? stride_n : 4, dense ? stride_k : 1};
+  return FGMM_OK;
+}
+
+struct FreeList {
+  std::vector<void *> v;
+  ~FreeList() {
+    for (void *p : v) (void)hipFree(p);
+  }
+};
+
+} // namespace
+
+int fgmm_encode_with_indexes_gmm(fgmm_ctx *ctx, const int32_t *symbols, const float *scales, const float *means,
+                                 const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int K,
+                                 int mode, int memspace, int32_t max_value, uint8_t **out, size_t *out_len) {
+  (void)max_value; // ignored by the reference too (rans_interface.cpp:462)
+  if (!ctx || !out || !out_len || n < 0 || !mode_ok(mode)) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", K);
+  if (n && (!symbols || !scales || !means || !weights)) return fail(FGMM_ERR_INVALID, "null tensor");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+  hipStream_t stream = nullptr;
+  FreeList fl;
+  StagedRows r;
+  int rc = stage_rows(ctx, stream, scales, means, weights, n, stride_n, stride_k, memspace, fl.v, &r);
+  if (rc) return rc;
+  const int32_t *sym_dev = symbols;
+  if (memspace == FGMM_HOST && n) {
+    int32_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(int32_t) * (size_t)n + 64));
+    fl.v.push_back(d);
+    HIP_TRY(hipMemcpyAsync(d, symbols, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
+    sym_dev = d;
+  }
+  std::vector<EncItem> v(1);
+  EncItem &e = v[0];
+  e.sym_dev = sym_dev;
+  e.sym_host = memspace == FGMM_HOST ? symbols : nullptr;
+  e.prm = {r.s, r.m, r.w, r.stride_k, 0};
+  e.stride_p = r.stride_n;
+  e.M = 1;
+  e.hw = n;
+  e.clamp = 0;
+  rc = encode_batch(ctx, stream, v, mode);
+  if (rc) return rc;
+  *out = e.bytes;
+  *out_len = e.bytes_len;
+  return FGMM_OK;
+}
+
+int fgmm_decode_with_indexes_gmm(fgmm_ctx *ctx, const uint8_t *encoded, size_t encoded_len, const float *scales,
+                                 const float *means, const float *weights, int64_t n, int64_t stride_n,
+                                 int64_t stride_k, int K, int mode, int memspace, int32_t max_bs_value,
+                                 int32_t *out_symbols) {
+  if (!ctx || !encoded || n < 0 || !mode_ok(mode) || (n && !out_symbols)) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", K);
+  if (n && (!scales || !means || !weights)) return fail(FGMM_ERR_INVALID, "null tensor");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+  hipStream_t stream = nullptr;
+  FreeList fl;
+  StagedRows r;
+  int rc = stage_rows(ctx, stream, scales, means, weights, n, stride_n, stride_k, memspace, fl.v, &r);
+  if (rc) return rc;
+  std::vector<DecItem> v(1);
+  DecItem &d = v[0];
+  d.enc = encoded;
+  d.enc_len = encoded_len;
+  d.prm = {r.s, r.m, r.w, r.stride_k, 0};
+  d.stride_p = r.stride_n;
+  d.M = 1;
+  d.hw = n;
+  d.max_bs = max_bs_value;
+  d.sym_host_out = out_symbols;
+  return decode_batch(ctx, stream, v, mode);
+}
+
+// ---- section 3: building blocks ---------------------------------------------------------------------------
+
+int fgmm_gmm_cdf_hip(fgmm_ctx *ctx, void *stream, const int32_t *v, const float *scales, const float *means,
+                     const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode, float *c1,
+                     float *c2) {
+  if (!ctx || n < 0 || !mode_ok(mode)) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  LAUNCH_TRY(launch_cdf_pair(v, scales, means, weights, n, stride_n, stride_k, mode, c1, c2, stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return FGMM_OK;
+}
+
+int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, const float *scales,
+                          const float *means, const float *weights, int64_t n, int64_t stride_n, int64_t stride_k,
+                          int mode, uint32_t *packed) {
+  if (!ctx || n < 0 || !mode_ok(mode)) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (n == 0) return FGMM_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  int rc;
+  if ((rc = ctx->ensure_device(4096)) || (rc = ctx->ensure_host(4096))) return rc;
+  EncDesc *hd = reinterpret_cast<EncDesc *>(ctx->h_ws);
+  memset(hd, 0, sizeof *hd);
+  hd->sym = symbols;
+  hd->scales = scales;
+  hd->means = means;
+  hd->weights = weights;
+  hd->stride_k = stride_k;
+  hd->stride_p = stride_n;
+  hd->hw = n;
+  hd->M = 1;
+  hd->packed = packed;
+  hd->meta = reinterpret_cast<unsigned long long *>(ctx->d_ws + 1024);
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
+  LAUNCH_TRY(launch_symtab(reinterpret_cast<const EncDesc *>(ctx->d_ws), 1, 1, n, mode, enc_vec4_ok(*hd), s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return FGMM_OK;
+}
+
+int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
+                          const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode,
+                          int32_t max_bs, uint64_t *hdr, uint16_t *pool, uint64_t pool_cap, uint64_t *pool_used) {
+  if (!ctx || n < 0 || !mode_ok(mode) || !pool_used) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (max_bs < 0 || max_bs > FGMM_MAX_BS) return fail(FGMM_ERR_UNSUPPORTED, "max_bs %d outside [0, %d]", max_bs, FGMM_MAX_BS);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  int rc;
+  if ((rc = ctx->ensure_device(4096)) || (rc = ctx->ensure_host(4096))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws);
+  memset(hd, 0, sizeof *hd);
+  hd->scales = scales;
+  hd->means = means;
+  hd->weights = weights;
+  hd->stride_k = stride_k;
+  hd->stride_p = stride_n;
+  hd->hw = n;
+  hd->n_ch = 1;
+  hd->max_bs = max_bs;
+  hd->hdr = reinterpret_cast<unsigned long long *>(hdr);
+  hd->pool = pool;
+  hd->pool_cap = pool_cap;
+  hd->pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + 1024);
+  HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
+  if (n) LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, 1, n, mode, s));
+  unsigned long long used[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(used, ctx->d_ws + 1024, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMemcpy(pool_used, used, sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (used[1]) return fail(FGMM_ERR_NOMEM, "pool_cap %llu too small", (unsigned long long)pool_cap);
+  return FGMM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,84 @@
+// fgmm_internal.h — structures shared by the HIP kernels (fgmm_kernels.hip), the host rANS coder
+// (fgmm_rans.cpp) and the C-ABI glue (fgmm_capi.cpp).  Not part of the public ABI.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FGMM_HD __host__ __device__
+#else
+#define FGMM_HD
+#endif
+
+namespace fgmm {
+
+// ---- per-item descriptors of the batched kernels (one item = one bitstream: an image half / a channel group) --
+
+struct EncDesc {
+  // inputs (device)
+  const float *y;        // [M*hw] latents, rounded by the kernel;   null when `sym` is given
+  const int32_t *sym;    // raw-boundary form: symbols given, [hw] with M == 1
+  const float *scales, *means, *weights;
+  int64_t stride_k, stride_c, stride_p; // elements
+  int64_t hw;
+  int32_t M;
+  int32_t clamp;
+  // outputs (device)
+  float *yq;             // [M*hw] round(y), or null
+  float *chan_min;       // [M]  min over the channel of y
+  float *chan_max;       // [M]
+  int32_t *chan_nz;      // [M]  any round(y) != 0
+  uint32_t *packed;      // [n_nz*hw] start | range<<16, channels compacted
+  unsigned long long *meta; // [0] = number of bypass symbols
+};
+
+struct DecDesc {
+  const float *scales, *means, *weights;
+  int64_t stride_k, stride_c, stride_p;
+  int64_t hw;
+  const int32_t *chan_list; // device [n_ch] source channel of compact channel j; null: identity
+  int32_t n_ch;
+  int32_t max_bs;
+  int32_t clamp;
+  int32_t pad_;
+  unsigned long long *hdr;       // [n_ch*hw]
+  uint16_t *pool;
+  unsigned long long pool_cap;   // entries
+  unsigned long long *pool_used; // [0] entries used, [1] overflow flag
+};
+
+struct ScatDesc {
+  const int32_t *sym;       // device [n_ch*hw] decoded symbols, compact channel order
+  const int32_t *chan_rank; // device [M]: compact index of channel c, or -1 (all-zero channel)
+  float *y_hat;             // device [M*hw]
+  int64_t hw;
+  int32_t M;
+  int32_t pad_;
+};
+
+// edge-table header (8 bytes): int16 a | (uint16 cnt | nonmono<<15) << 16 | (uint32 off/4) << 32
+FGMM_HD static inline uint64_t hdr_pack(int32_t a, uint32_t cnt, uint32_t nonmono, uint64_t off_entries) {
+  return (uint64_t)(uint16_t)(int16_t)a | ((uint64_t)((cnt & 0x7FFFu) | (nonmono << 15)) << 16) |
+         ((off_entries >> 2) << 32);
+}
+FGMM_HD static inline int32_t hdr_a(uint64_t h) { return (int32_t)(int16_t)(uint16_t)(h & 0xFFFFu); }
+FGMM_HD static inline uint32_t hdr_cnt(uint64_t h) { return (uint32_t)(h >> 16) & 0x7FFFu; }
+FGMM_HD static inline uint32_t hdr_nonmono(uint64_t h) { return (uint32_t)(h >> 31) & 1u; }
+FGMM_HD static inline uint64_t hdr_off(uint64_t h) { return (h >> 32) << 2; }
+
+// ---- kernel launchers (fgmm_kernels.hip); stream is a hipStream_t; all return hipError_t as int ----------
+int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *stream);
+int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, bool vec4, void *stream);
+int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
+                    int64_t stride_n, int64_t stride_k, int mode, float *c1, float *c2, void *stream);
+int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, void *stream);
+int launch_scatter(const ScatDesc *d_descs, int count, int M_max, int64_t hw_max, void *stream);
+
+// ---- host rANS (fgmm_rans.cpp), integer only --------------------------------------------------------------
+// returns 0 or an fgmm_status; *out malloc'ed
+int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint,
+                       uint8_t **out, size_t *out_len);
+int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint64_t *hdr, const uint16_t *pool, int64_t n,
+                       int32_t max_bs, int32_t *out);
+
+} // namespace fgmm

@@ -1,0 +1,391 @@
+// fgmm_kernels.hip — hand-written HIP kernels of the GMM entropy-coding path for CDNA4 / gfx950 (MI355X).
+//
+//   quant_stats_kernel   y -> round(y), per-channel {min, max, any-nonzero}            (entropy_models.py:834-842)
+//   symtab_kernel        (y | symbols, sigma, mu, pi) -> packed start|range<<16         (rans_interface.cpp:487-517)
+//   cdf_pair_kernel      float CDF pair probe                                           (rans_interface.cpp:250-292)
+//   cdftab_kernel        (sigma, mu, pi, max_bs) -> trimmed per-latent edge tables      (rans_interface.cpp:826-862)
+//   scatter_kernel       decoded symbols -> y_hat with zero channels restored           (entropy_models.py:903-908)
+//
+// All kernels are batched over `count` independent bitstreams (blockIdx.z = item) through a device array of
+// descriptors, because one Kodak-sized half (<= 147 456 latents) is far too small to fill 256 CUs on its own.
+// They are HBM-streaming / transcendental-VALU kernels: no MFMA, no data reuse, so no LDS tiling — mixture
+// parameters are read exactly once, straight to VGPRs, as 16-byte-per-lane coalesced loads of the planar
+// (k, c, p) layout.  Wave = 64 lanes throughout.
+#include <hip/hip_runtime.h>
+
+#include "fgmm_internal.h"
+#include "fgmm_math.h"
+
+namespace fgmm {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------------------
+// wave / block helpers (wave64)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// quant_stats_kernel: one block per (channel, item).  8 B/latent of traffic (4 in, 4 out).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void quant_stats_kernel(const EncDesc *__restrict__ descs) {
+  const EncDesc &d = descs[blockIdx.z];
+  const int c = blockIdx.x;
+  if (c >= d.M) return;
+  const float *__restrict__ y = d.y + (int64_t)c * d.hw;
+  float *__restrict__ yq = d.yq ? d.yq + (int64_t)c * d.hw : nullptr;
+  float mn = INFINITY, mx = -INFINITY;
+  int nz = 0;
+  const int64_t hw = d.hw;
+  const bool vec = ((hw & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                   (!yq || (reinterpret_cast<uintptr_t>(yq) & 15) == 0);
+  if (vec) {
+    for (int64_t p = (int64_t)threadIdx.x * 4; p < hw; p += (int64_t)kBlock * 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(y + p);
+      float4 q;
+      q.x = __builtin_rintf(v.x); q.y = __builtin_rintf(v.y); q.z = __builtin_rintf(v.z); q.w = __builtin_rintf(v.w);
+      mn = fminf(fminf(mn, v.x), fminf(fminf(v.y, v.z), v.w));
+      mx = fmaxf(fmaxf(mx, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+      nz |= (q.x != 0.0f) | (q.y != 0.0f) | (q.z != 0.0f) | (q.w != 0.0f);
+      if (yq) *reinterpret_cast<float4 *>(yq + p) = q;
+    }
+  } else {
+    for (int64_t p = threadIdx.x; p < hw; p += kBlock) {
+      const float v = y[p];
+      const float q = __builtin_rintf(v); // round-half-even == torch.round
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+      nz |= (q != 0.0f);
+      if (yq) yq[p] = q;
+    }
+  }
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  nz = __any(nz) ? 1 : 0;
+  __shared__ float s_mn[kBlock / 64], s_mx[kBlock / 64];
+  __shared__ int s_nz[kBlock / 64];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_mn[w] = mn; s_mx[w] = mx; s_nz[w] = nz;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < kBlock / 64; ++i) {
+      mn = fminf(mn, s_mn[i]); mx = fmaxf(mx, s_mx[i]); nz |= s_nz[i];
+    }
+    d.chan_min[c] = mn;
+    d.chan_max[c] = mx;
+    d.chan_nz[c] = nz;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// symtab_kernel — THE encode-side CDF kernel.  Algorithmic traffic 56 B/latent at K = 4:
+//   4 (y or symbol) + 3*4*4 (sigma, mu, pi planes) in, 4 out (start | range << 16).
+// grid = (tiles over hw, channel, item); a block whose channel is all-zero exits at once; otherwise its output
+// row is the rank of the channel among the non-zero ones (entropy_models.py:844-845 channel compaction), found
+// from chan_nz without a host round trip.
+// VEC = 4: each lane owns 4 consecutive positions, every plane read is one 16-B load (1 KiB per wave-instr).
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE> __device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu)[4], const float (&sg)[4],
+                                                                 const float (&pi)[4], int &bypass) {
+  const float x1 = vq - 0.5f;          // static_cast<float>(value) - offset             (:499)
+  const float x2 = vq - 0.5f + 1.0f;   // static_cast<float>(value) - offset + 1.0f
+  const uint32_t lo = quant16(mix4<MODE>(x1, mu, sg, pi));
+  const uint32_t hi = quant16(mix4<MODE>(x2, mu, sg, pi));
+  const uint32_t pmf = (hi - lo) & 0xFFFFu; // uint16_t pmf = next - value                (:512)
+  bypass = (pmf == 0);
+  return pmf ? (lo | (pmf << 16)) : ((uint32_t)vi & 0xFFFFu); // bypass: low 16 bits of the int32 symbol
+}
+
+template <int MODE, int VEC> __global__ __launch_bounds__(kBlock) void symtab_kernel(const EncDesc *__restrict__ descs) {
+  const EncDesc &d = descs[blockIdx.z];
+  const int c = blockIdx.y;
+  if (c >= d.M) return;
+  const int64_t hw = d.hw;
+  const int64_t p0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  if ((int64_t)blockIdx.x * kBlock * VEC >= hw) return;
+
+  int rank = c;
+  if (d.chan_nz) {
+    if (d.chan_nz[c] == 0) return; // wave-uniform: the whole block leaves
+    // rank of channel c among the non-zero channels (M is a few hundred at most)
+    int cnt = 0;
+    for (int i = threadIdx.x; i < c; i += kBlock) cnt += d.chan_nz[i] != 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    __shared__ int s_cnt[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    rank = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; ++i) rank += s_cnt[i];
+  }
+  const bool active = p0 < hw; // lanes past the end stay for the wave reduction below
+
+  const int clampf = d.clamp;
+  int nbypass = 0;
+  if (!active) {
+  } else if constexpr (VEC == 4) {
+    // planar, 16-B aligned (checked by the host): one float4 per plane per lane
+    const int64_t base = (int64_t)c * d.stride_c + p0;
+    float4 vq4;
+    int4 vi4;
+    if (d.sym) {
+      vi4 = *reinterpret_cast<const int4 *>(d.sym + (int64_t)c * hw + p0);
+      vq4 = make_float4((float)vi4.x, (float)vi4.y, (float)vi4.z, (float)vi4.w);
+    } else {
+      const float4 yv = *reinterpret_cast<const float4 *>(d.y + (int64_t)c * hw + p0);
+      vq4 = make_float4(__builtin_rintf(yv.x), __builtin_rintf(yv.y), __builtin_rintf(yv.z), __builtin_rintf(yv.w));
+      vi4 = make_int4((int)vq4.x, (int)vq4.y, (int)vq4.z, (int)vq4.w);
+    }
+    float4 S[4], Mu[4], Pi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      S[k] = *reinterpret_cast<const float4 *>(d.scales + base + k * d.stride_k);
+      Mu[k] = *reinterpret_cast<const float4 *>(d.means + base + k * d.stride_k);
+      Pi[k] = *reinterpret_cast<const float4 *>(d.weights + base + k * d.stride_k);
+    }
+    uint32_t out[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float mu[4], sg[4], pi[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float s = (&S[k].x)[e];
+        sg[k] = clampf ? clamp_scale(s) : s;
+        mu[k] = (&Mu[k].x)[e];
+        pi[k] = (&Pi[k].x)[e];
+      }
+      int bp;
+      out[e] = sym_entry<MODE>((&vq4.x)[e], (&vi4.x)[e], mu, sg, pi, bp);
+      nbypass += bp;
+    }
+    *reinterpret_cast<uint4 *>(d.packed + (int64_t)rank * hw + p0) = make_uint4(out[0], out[1], out[2], out[3]);
+  } else {
+    const int64_t base = (int64_t)c * d.stride_c + p0 * d.stride_p;
+    float vq;
+    int vi;
+    if (d.sym) {
+      vi = d.sym[(int64_t)c * hw + p0];
+      vq = (float)vi;
+    } else {
+      vq = __builtin_rintf(d.y[(int64_t)c * hw + p0]);
+      vi = (int)vq;
+    }
+    float mu[4], sg[4], pi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float s = d.scales[base + k * d.stride_k];
+      sg[k] = clampf ? clamp_scale(s) : s;
+      mu[k] = d.means[base + k * d.stride_k];
+      pi[k] = d.weights[base + k * d.stride_k];
+    }
+    int bp;
+    d.packed[(int64_t)rank * hw + p0] = sym_entry<MODE>(vq, vi, mu, sg, pi, bp);
+    nbypass = bp;
+  }
+  // bypass census: one atomic per wave that saw any (the host sizes its output buffer from it)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nbypass += __shfl_xor(nbypass, o, 64);
+  if ((threadIdx.x & 63) == 0 && nbypass) atomicAdd(d.meta, (unsigned long long)nbypass);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cdf_pair_kernel: float probe of the mixture CDF at both edges of v (parity tests: 1e-5 bar, in fact bit-exact)
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void cdf_pair_kernel(const int32_t *__restrict__ v, const float *__restrict__ scales,
+                                                          const float *__restrict__ means, const float *__restrict__ weights,
+                                                          int64_t n, int64_t sn, int64_t sk, float *__restrict__ c1,
+                                                          float *__restrict__ c2) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float mu[4], sg[4], pi[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sg[k] = scales[i * sn + k * sk];
+    mu[k] = means[i * sn + k * sk];
+    pi[k] = weights[i * sn + k * sk];
+  }
+  const float vq = (float)v[i];
+  c1[i] = mix4<MODE>(vq - 0.5f, mu, sg, pi);
+  c2[i] = mix4<MODE>(vq - 0.5f + 1.0f, mu, sg, pi);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cdftab_kernel — decode-side edge tables.  Lane = latent.
+//   pass 1: evaluate F[v] = quant16(cdf(v - 0.5)) over the whole range the reference's bisection can probe,
+//           v in [-max_bs, max_bs+1] (W = 2*max_bs + 2 values), tracking the leading run of zeros, the trailing
+//           constant run and whether the sequence ever decreases — so the stored window is exact by
+//           construction, whatever the parameters are;
+//   alloc : wave-wide prefix sum of the (4-padded) row lengths, ONE atomicAdd per wave on the item's pool head;
+//   pass 2: re-evaluate only the window and store it (8 B per store), then the 8-byte header.
+// Transcendental-VALU bound (about 200 VALU ops per edge), not HBM bound: 48 B in per latent.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE> __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restrict__ descs) {
+  const DecDesc &d = descs[blockIdx.z];
+  const int cj = blockIdx.y;
+  if (cj >= d.n_ch) return;
+  const int64_t hw = d.hw;
+  if ((int64_t)blockIdx.x * kBlock >= hw) return;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = p < hw;
+  const int c = d.chan_list ? d.chan_list[cj] : cj;
+
+  float mu[4], sg[4], pi[4];
+  {
+    const int64_t base = (int64_t)c * d.stride_c + (active ? p : 0) * d.stride_p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float s = d.scales[base + k * d.stride_k];
+      sg[k] = d.clamp ? clamp_scale(s) : s;
+      mu[k] = d.means[base + k * d.stride_k];
+      pi[k] = d.weights[base + k * d.stride_k];
+    }
+  }
+  const int max_bs = d.max_bs;
+  const int W = 2 * max_bs + 2;
+
+  // ---- pass 1 -------------------------------------------------------------------------------------
+  int lead = -1, run_start = 0;
+  bool allzero = true, nonmono = false;
+  uint32_t prev = 0;
+  for (int j = 0; j < W; ++j) {
+    const float x = (float)(j - max_bs) - 0.5f;
+    const uint32_t E = quant16(mix4<MODE>(x, mu, sg, pi));
+    if (allzero) {
+      if (E == 0) lead = j; else allzero = false;
+    }
+    if (j == 0 || E != prev) run_start = j;
+    nonmono |= (j > 0) && (E < prev);
+    prev = E;
+  }
+  int a_idx = lead < 0 ? 0 : lead;
+  if (a_idx > run_start) a_idx = run_start;
+  const int cnt = run_start - a_idx + 1;
+  const uint32_t len4 = active ? (uint32_t)((cnt + 3) & ~3) : 0u;
+
+  // ---- wave allocation ----------------------------------------------------------------------------
+  const int lane = threadIdx.x & 63;
+  uint32_t incl = len4;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const uint32_t total = __shfl(incl, 63, 64);
+  unsigned long long base = 0;
+  if (lane == 63 && total) base = atomicAdd(d.pool_used, (unsigned long long)total);
+  base = __shfl(base, 63, 64);
+  if (base + total > d.pool_cap) { // wave-uniform
+    if (lane == 0) d.pool_used[1] = 1;
+    return;
+  }
+  if (!active) return;
+  const unsigned long long off = base + (incl - len4);
+
+  // ---- pass 2 -------------------------------------------------------------------------------------
+  uint16_t *__restrict__ row = d.pool + off;
+  uint32_t last = 0;
+  for (uint32_t j0 = 0; j0 < len4; j0 += 4) {
+    uint32_t e[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = (int)(j0 + t);
+      if (j < cnt) {
+        const float x = (float)(a_idx + j - max_bs) - 0.5f;
+        last = quant16(mix4<MODE>(x, mu, sg, pi));
+      }
+      e[t] = last; // pad with the row's last value (= the trailing constant)
+    }
+    *reinterpret_cast<uint2 *>(row + j0) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+  }
+  d.hdr[(int64_t)cj * hw + p] = hdr_pack(a_idx - max_bs, (uint32_t)cnt, nonmono ? 1u : 0u, off);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scatter_kernel: y_hat[:, nonzero] = symbols.float(), zeros elsewhere (entropy_models.py:903-908)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void scatter_kernel(const ScatDesc *__restrict__ descs) {
+  const ScatDesc &d = descs[blockIdx.z];
+  const int c = blockIdx.y;
+  if (c >= d.M) return;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= d.hw) return;
+  const int r = d.chan_rank[c];
+  d.y_hat[(int64_t)c * d.hw + p] = r < 0 ? 0.0f : (float)d.sym[(int64_t)r * d.hw + p];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+static inline int launch_err() { return (int)hipGetLastError(); }
+
+int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *stream) {
+  if (count <= 0 || M_max <= 0) return 0;
+  dim3 grid((unsigned)M_max, 1, (unsigned)count);
+  hipLaunchKernelGGL(quant_stats_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, d_descs);
+  return launch_err();
+}
+
+template <int VEC> static int launch_symtab_v(const EncDesc *d, int count, int M_max, int64_t hw_max, int mode, hipStream_t s) {
+  const int64_t per_block = (int64_t)kBlock * VEC;
+  dim3 grid((unsigned)((hw_max + per_block - 1) / per_block), (unsigned)M_max, (unsigned)count);
+  switch (mode) {
+  case MODE_AS: hipLaunchKernelGGL((symtab_kernel<MODE_AS, VEC>), grid, dim3(kBlock), 0, s, d); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((symtab_kernel<MODE_LOGISTIC, VEC>), grid, dim3(kBlock), 0, s, d); break;
+  default: hipLaunchKernelGGL((symtab_kernel<MODE_POLYA, VEC>), grid, dim3(kBlock), 0, s, d); break;
+  }
+  return launch_err();
+}
+
+int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, bool vec4, void *stream) {
+  if (count <= 0 || M_max <= 0 || hw_max <= 0) return 0;
+  return vec4 ? launch_symtab_v<4>(d_descs, count, M_max, hw_max, mode, (hipStream_t)stream)
+              : launch_symtab_v<1>(d_descs, count, M_max, hw_max, mode, (hipStream_t)stream);
+}
+
+int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
+                    int64_t stride_n, int64_t stride_k, int mode, float *c1, float *c2, void *stream) {
+  if (n <= 0) return 0;
+  dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  hipStream_t s = (hipStream_t)stream;
+  switch (mode) {
+  case MODE_AS: hipLaunchKernelGGL((cdf_pair_kernel<MODE_AS>), grid, dim3(kBlock), 0, s, v, scales, means, weights, n, stride_n, stride_k, c1, c2); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((cdf_pair_kernel<MODE_LOGISTIC>), grid, dim3(kBlock), 0, s, v, scales, means, weights, n, stride_n, stride_k, c1, c2); break;
+  default: hipLaunchKernelGGL((cdf_pair_kernel<MODE_POLYA>), grid, dim3(kBlock), 0, s, v, scales, means, weights, n, stride_n, stride_k, c1, c2); break;
+  }
+  return launch_err();
+}
+
+int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, void *stream) {
+  if (count <= 0 || n_ch_max <= 0 || hw_max <= 0) return 0;
+  dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)n_ch_max, (unsigned)count);
+  hipStream_t s = (hipStream_t)stream;
+  switch (mode) {
+  case MODE_AS: hipLaunchKernelGGL((cdftab_kernel<MODE_AS>), grid, dim3(kBlock), 0, s, d_descs); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((cdftab_kernel<MODE_LOGISTIC>), grid, dim3(kBlock), 0, s, d_descs); break;
+  default: hipLaunchKernelGGL((cdftab_kernel<MODE_POLYA>), grid, dim3(kBlock), 0, s, d_descs); break;
+  }
+  return launch_err();
+}
+
+int launch_scatter(const ScatDesc *d_descs, int count, int M_max, int64_t hw_max, void *stream) {
+  if (count <= 0 || M_max <= 0 || hw_max <= 0) return 0;
+  dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)M_max, (unsigned)count);
+  hipLaunchKernelGGL(scatter_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, d_descs);
+  return launch_err();
+}
+
+} // namespace fgmm

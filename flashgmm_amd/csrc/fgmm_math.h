@@ -1,0 +1,102 @@
+// fgmm_math.h — device-side fp32 arithmetic of the GMM CDF, CDNA4 (gfx950).
+//
+// Every function is a fixed sequence of single IEEE-754 binary32 round-to-nearest-even operations that
+// reproduces, bit for bit, what the reference's default (AVX, K == 4) path computes after GCC's FMA
+// contraction (SURVEY.md §8a'; reference: compressai/cpp_exts/rans/rans_interface.cpp:133-292,
+// compressai/cpp_exts/rans/avx_mathfun.h:250-304).  Consequences for how this file must be built and written:
+//   * compile with -ffp-contract=off: the ONLY fused operations are the explicit __builtin_fmaf calls;
+//   * '/' and __builtin_sqrtf must be correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt, hipcc's
+//     default) — never __fdividef / v_rcp_f32 / v_exp_f32 fast paths;
+//   * f32 denormals stay enabled (hipcc's default float mode on gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fgmm {
+
+enum : int { MODE_POLYA = 0, MODE_AS = 1, MODE_LOGISTIC = 2 };
+
+__device__ __forceinline__ float bits2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2bits(float f) { return __float_as_uint(f); }
+
+// exp256_ps as compiled (avx_mathfun.h:250-304): clamp, n = floor(x*log2e + 0.5) by one FMA, two-constant
+// Cody-Waite by FMAs, degree-5 Horner by FMAs, y = fma(y, x*x, x) + 1, times the BIT PATTERN 2^n
+// ((n+127)<<23: n = -127 -> +0.0, n = 128 -> +inf; this is not ldexp).
+__device__ __forceinline__ float exp_ref(float x) {
+  x = (x < 88.3762626647949f) ? x : 88.3762626647949f;   // _mm256_min_ps(x, hi): hi when x is NaN
+  x = (x > -88.3762626647949f) ? x : -88.3762626647949f; // _mm256_max_ps(x, lo)
+  float fx = __builtin_fmaf(x, 1.44269504088896341f, 0.5f);
+  fx = __builtin_floorf(fx);
+  x = __builtin_fmaf(-fx, 0.693359375f, x);
+  x = __builtin_fmaf(-fx, -2.12194440e-4f, x);
+  const float z = x * x;
+  float y = 1.9875691500E-4f;
+  y = __builtin_fmaf(y, x, 1.3981999507E-3f);
+  y = __builtin_fmaf(y, x, 8.3334519073E-3f);
+  y = __builtin_fmaf(y, x, 4.1665795894E-2f);
+  y = __builtin_fmaf(y, x, 1.6666665459E-1f);
+  y = __builtin_fmaf(y, x, 5.0000001201E-1f);
+  y = __builtin_fmaf(y, z, x);
+  y = y + 1.0f;
+  const int n = (int)fx; // |fx| <= 128 after the clamps
+  return y * bits2f((uint32_t)(n + 127) << 23);
+}
+
+template <int MODE> __device__ __forceinline__ float phi(float z);
+
+// Polya/Watterson, rans_interface.cpp:135-146
+template <> __device__ __forceinline__ float phi<MODE_POLYA>(float z) {
+  const float c = -2.0f / 3.14159265358979323846f; // folded in binary32, as the reference's constant is
+  const float e = exp_ref(c * (z * z));
+  float s = __builtin_sqrtf(1.0f - e);
+  s = bits2f((f2bits(z) & 0x80000000u) | (f2bits(s) & 0x7fffffffu)); // copysign_ps(z, s)
+  return 0.5f * (1.0f + s);
+}
+
+// Abramowitz & Stegun 26.2.17, rans_interface.cpp:154-186
+template <> __device__ __forceinline__ float phi<MODE_AS>(float z) {
+  const float az = bits2f(f2bits(z) & 0x7fffffffu);
+  const float zx = 0.3989422804014327f * exp_ref((z * z) * -0.5f);
+  const float t = 1.0f / __builtin_fmaf(0.2316419f, az, 1.0f);
+  float poly = __builtin_fmaf(1.330274429f, t, -1.821255978f);
+  poly = __builtin_fmaf(poly, t, 1.781477937f);
+  poly = __builtin_fmaf(poly, t, -0.356563782f);
+  poly = __builtin_fmaf(poly, t, 0.319381530f);
+  poly = poly * t;
+  const float res_pos = __builtin_fmaf(-zx, poly, 1.0f);
+  const float res_neg = 1.0f - res_pos;
+  return (f2bits(z) & 0x80000000u) ? res_neg : res_pos; // blendv on the sign BIT (so -0.0 -> res_neg)
+}
+
+// logistic, rans_interface.cpp:208-214
+template <> __device__ __forceinline__ float phi<MODE_LOGISTIC>(float z) {
+  const float e = exp_ref(-1.0f * (1.702f * z));
+  return 1.0f / (1.0f + e);
+}
+
+// _fast_gmm_cdf<4>, AVX branch (rans_interface.cpp:259-283): (p0 + p1) + (p2 + p3)
+template <int MODE>
+__device__ __forceinline__ float mix4(float x, const float (&mu)[4], const float (&sg)[4], const float (&pi)[4]) {
+  float p[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) p[k] = pi[k] * phi<MODE>((x - mu[k]) / sg[k]);
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+// static_cast<uint16_t>(float) as x86-64 GCC emits it (cvttss2si r32 ; movzwl), rans_interface.cpp:509-510.
+// cvttss2si yields 0x80000000 for NaN / out-of-range, v_cvt_i32_f32 saturates: make the x86 answer explicit.
+__device__ __forceinline__ uint32_t quant16(float cdf) {
+  const float f = cdf * 65535.0f;
+  const bool in_range = (f >= -2147483648.0f) && (f < 2147483648.0f);
+  const int t = in_range ? (int)f : (int)0x80000000;
+  return (uint32_t)t & 0xFFFFu;
+}
+
+// sigma clamp of reshape_entropy_parameters (entropy_models.py:817): torch.clamp(x, 0.11, 256) keeps NaN
+__device__ __forceinline__ float clamp_scale(float s) {
+  s = (s < 0.11f) ? 0.11f : s;
+  s = (s > 256.0f) ? 256.0f : s;
+  return s;
+}
+
+} // namespace fgmm

@@ -1,0 +1,297 @@
+// fgmm_rans.cpp — host side of the path: the integer rANS state machine, fed by GPU-built tables.
+//
+// Nothing in this file touches floating point.  It consumes
+//   * the encode-side symbol table (uint32 start | range<<16 per symbol, range == 0 = bypass escape) and
+//   * the decode-side trimmed edge tables (8-byte header + uint16 window per latent)
+// produced by fgmm_kernels.hip and reproduces, bit for bit, the streams / symbols of
+//   BufferedRansEncoder::flush            compressai/cpp_exts/rans/rans_interface.cpp:557-585
+//   the bypass escape                     compressai/cpp_exts/rans/rans_interface.cpp:513-552, :808-824
+//   RansDecoder::decode_with_indexes_gmm  compressai/cpp_exts/rans/rans_interface.cpp:798-881 (bisection on F)
+//   Rans64Enc/Dec primitives              third_party/ryg_rans/rans64.h:65-142, bit put/get rans_interface.cpp:295-331
+//
+// Encoder: the per-symbol 64-bit division of Rans64EncPut is replaced by a multiply with an exact
+// Alverson reciprocal from a 65 536-entry table (state-identical by construction for every state the
+// encoder can reach; the same identity ryg's Rans64EncPutSymbol relies on).
+// Decoder: rows flagged monotone are searched with one or two AVX2 compares; everything else (flagged
+// non-monotone rows, a cum_freq no interval contains) goes through a literal replay of the reference's
+// bisection over the virtual table, so the result is the reference's result in every case.
+#include <immintrin.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "../../include/flashgmm_amd.h"
+#include "fgmm_internal.h"
+
+namespace fgmm {
+
+namespace {
+
+constexpr uint64_t kRansL = 1ull << 31; // rans64.h:59
+constexpr uint32_t kPrec = 16;          // rans_interface.cpp:55
+constexpr uint32_t kMaxCdf = 65535;     // rans_interface.cpp:56
+constexpr uint32_t kBypassBits = 4;     // rans_interface.cpp:58
+constexpr uint32_t kMaxBypassVal = 15;  // rans_interface.cpp:59
+
+struct Rcp {
+  uint64_t rcp;      // fixed-point reciprocal
+  uint32_t shift;    // post-shift
+  uint32_t bias_add; // 65535 for freq == 1 (see below), else 0
+};
+Rcp g_rcp[65536];
+std::once_flag g_rcp_once;
+
+// Alverson, "Integer division using reciprocals": for 2 <= freq < 2^16 and x < 2^63,
+//   floor(x / freq) == mulhi(x, rcp) >> shift   with shift = ceil(log2 freq) - 1,
+//   rcp = ceil(2^(shift+64) / freq).
+// freq == 1 cannot be expressed (reciprocal 1.0); with rcp = 2^64-1, shift = 0 the quotient comes out as
+// x - 1, which the update x + bias + q*(2^16 - freq) absorbs by bias += 2^16 - 1.
+void init_rcp() {
+  g_rcp[0] = {0, 0, 0};
+  g_rcp[1] = {~0ull, 0, 65535};
+  for (uint32_t freq = 2; freq < 65536; ++freq) {
+    uint32_t shift = 0;
+    while (freq > (1u << shift)) shift++;
+    // ceil(2^(shift+63) / freq) by a 128/64 division
+    const unsigned __int128 num = ((unsigned __int128)1 << (shift + 63)) + freq - 1;
+    g_rcp[freq] = {(uint64_t)(num / freq), shift - 1, 0};
+  }
+}
+
+inline uint64_t mulhi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+
+struct Enc {
+  uint64_t x;
+  uint32_t *ptr;
+  inline void put(uint32_t start, uint32_t freq) { // Rans64EncPut(start, freq, 16)
+    const uint64_t x_max = (uint64_t)freq << 47;   // ((RANS64_L >> 16) << 32) * freq
+    uint64_t xx = x;
+    if (xx >= x_max) {
+      *--ptr = (uint32_t)xx;
+      xx >>= 32;
+    }
+    const Rcp &r = g_rcp[freq];
+    const uint64_t q = mulhi(xx, r.rcp) >> r.shift;
+    x = xx + start + r.bias_add + q * (65536u - freq); // == ((xx / freq) << 16) + xx % freq + start
+  }
+  inline void put_bits(uint32_t val) {             // Rans64EncPutBits(val, 4)
+    const uint64_t x_max = 1ull << 59;             // ((RANS64_L >> 16) << 32) * (1 << 12)
+    uint64_t xx = x;
+    if (xx >= x_max) {
+      *--ptr = (uint32_t)xx;
+      xx >>= 32;
+    }
+    x = (xx << kBypassBits) | val;
+  }
+};
+
+} // namespace
+
+int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n, int64_t n_bypass_hint,
+                       uint8_t **out, size_t *out_len) {
+  std::call_once(g_rcp_once, init_rcp);
+  if (n < 0 || !out || !out_len || (n > 0 && !packed)) return FGMM_ERR_INVALID;
+  int64_t nb = n_bypass_hint;
+  if (nb < 0) {
+    nb = 0;
+    for (int64_t i = 0; i < n; ++i) nb += (packed[i] >> 16) == 0;
+  }
+  // every entry of the reference's _syms emits at most one 32-bit word; a bypassed symbol is 1 + 1 + <=8 entries
+  const size_t nwords = (size_t)n + (size_t)nb * 10 + 16;
+  uint32_t *buf = (uint32_t *)malloc(nwords * sizeof(uint32_t));
+  if (!buf) return FGMM_ERR_NOMEM;
+  uint32_t *const end = buf + nwords;
+  Enc e{kRansL, end}; // Rans64EncInit
+
+  for (int64_t i = n - 1; i >= 0; --i) { // reversed _syms (rans_interface.cpp:569)
+    const uint32_t ent = packed[i];
+    const uint32_t freq = ent >> 16;
+    if (__builtin_expect(freq != 0, 1)) {
+      e.put(ent & 0xFFFFu, freq);
+      continue;
+    }
+    // bypass escape; forward order was [sentinel {65535,1}] [count] [nibble 0 .. nibble k-1]  (:519-551)
+    const int32_t value = symbols ? symbols[i] : (int32_t)(int16_t)(uint16_t)(ent & 0xFFFFu);
+    const uint32_t raw = (uint32_t)value;
+    int nn = 0;
+    for (uint32_t t = raw; t != 0; t >>= kBypassBits) ++nn; // <= 8
+    for (int j = nn - 1; j >= 0; --j) e.put_bits((raw >> (j * kBypassBits)) & kMaxBypassVal);
+    e.put_bits((uint32_t)nn); // nn <= 8 < 15: the count is always a single nibble (:538-543)
+    e.put(kMaxCdf, 1);
+  }
+  // Rans64EncFlush
+  e.ptr -= 2;
+  e.ptr[0] = (uint32_t)(e.x >> 0);
+  e.ptr[1] = (uint32_t)(e.x >> 32);
+  const size_t nbytes = (size_t)(end - e.ptr) * sizeof(uint32_t);
+  uint8_t *o = (uint8_t *)malloc(nbytes);
+  if (!o) {
+    free(buf);
+    return FGMM_ERR_NOMEM;
+  }
+  memcpy(o, e.ptr, nbytes);
+  free(buf);
+  *out = o;
+  *out_len = nbytes;
+  return FGMM_OK;
+}
+
+namespace {
+
+struct Dec {
+  uint64_t x;
+  const uint32_t *ptr;
+  const uint32_t *end;
+  bool underrun = false;
+  inline uint32_t next_word() {
+    if (__builtin_expect(ptr >= end, 0)) {
+      underrun = true;
+      return 0;
+    }
+    return *ptr++;
+  }
+  inline void advance(uint32_t start, uint32_t freq) { // Rans64DecAdvance(start, freq, 16)
+    uint64_t xx = (uint64_t)freq * (x >> kPrec) + (x & 0xFFFFu) - start;
+    if (xx < kRansL) xx = (xx << 32) | next_word();
+    x = xx;
+  }
+  inline uint32_t get_bits() { // Rans64DecGetBits(4)
+    const uint32_t val = (uint32_t)(x & kMaxBypassVal);
+    uint64_t xx = x >> kBypassBits;
+    if (xx < kRansL) xx = (xx << 32) | next_word();
+    x = xx;
+    return val;
+  }
+  inline int32_t bypass() { // rans_interface.cpp:809-824
+    advance(kMaxCdf, 1);
+    int32_t val = (int32_t)get_bits();
+    int32_t nn = val;
+    while (val == (int32_t)kMaxBypassVal && !underrun) {
+      val = (int32_t)get_bits();
+      nn += val;
+    }
+    uint32_t raw = 0;
+    for (int j = 0; j < nn && !underrun; ++j) raw |= get_bits() << ((j * kBypassBits) & 31);
+    return (int32_t)raw;
+  }
+};
+
+// virtual full table F[v], v in [-max_bs, max_bs+1], rebuilt from the trimmed row
+struct Row {
+  const uint16_t *row;
+  int32_t a;
+  int32_t cnt;
+  inline uint32_t F(int32_t v) const {
+    const int32_t idx = v - a;
+    if (idx < 0) return 0;
+    return row[idx >= cnt ? cnt - 1 : idx];
+  }
+};
+
+// literal replay of rans_interface.cpp:826-877 on F
+inline int32_t bisect_reference(const Row &r, uint32_t cum_freq, int32_t max_bs, uint32_t *start, uint32_t *freq) {
+  int32_t s_bs = -max_bs, e_bs = max_bs, mid = 0;
+  uint32_t c1 = 0, c2 = 0;
+  while (s_bs <= e_bs) {
+    mid = s_bs + (e_bs - s_bs) / 2;
+    c1 = r.F(mid);
+    c2 = r.F(mid + 1);
+    if (c1 <= cum_freq && c2 > cum_freq) break;
+    else if (c1 > cum_freq) e_bs = mid - 1;
+    else s_bs = mid + 1;
+  }
+  c1 = r.F(mid);
+  c2 = r.F(mid + 1);
+  uint32_t pmf = (c2 - c1) & 0xFFFFu;
+  if (pmf == 0) pmf = 1; // :866-868 (the start adjustment at :869 cannot trigger: c1 <= 65535)
+  *start = c1;
+  *freq = pmf;
+  return mid;
+}
+
+// first index j in [0, cnt) with row[j] > cf, or cnt; row is non-decreasing; reads up to 30 bytes past the row
+__attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *row, int32_t cnt, uint32_t cf) {
+  const __m256i bias = _mm256_set1_epi16((short)0x8000);
+  const __m256i key = _mm256_set1_epi16((short)(cf ^ 0x8000u));
+  for (int32_t k = 0; k < cnt; k += 16) {
+    const __m256i v = _mm256_xor_si256(_mm256_loadu_si256((const __m256i *)(row + k)), bias);
+    const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi16(v, key));
+    if (m) {
+      const int32_t j = k + (int32_t)(__builtin_ctz(m) >> 1);
+      return j < cnt ? j : cnt;
+    }
+  }
+  return cnt;
+}
+
+} // namespace
+
+int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint64_t *hdr, const uint16_t *pool, int64_t n,
+                       int32_t max_bs, int32_t *out) {
+  if (n < 0 || (n > 0 && (!hdr || !pool || !out)) || !enc) return FGMM_ERR_INVALID;
+  if (enc_len < 8 || (enc_len & 3)) return FGMM_ERR_STREAM;
+  const uint32_t *words;
+  uint32_t *copy = nullptr;
+  if (reinterpret_cast<uintptr_t>(enc) & 3) { // Python bytes are aligned in practice; stay safe
+    copy = (uint32_t *)malloc(enc_len);
+    if (!copy) return FGMM_ERR_NOMEM;
+    memcpy(copy, enc, enc_len);
+    words = copy;
+  } else {
+    words = reinterpret_cast<const uint32_t *>(enc);
+  }
+  Dec d;
+  d.x = (uint64_t)words[0] | ((uint64_t)words[1] << 32); // Rans64DecInit
+  d.ptr = words + 2;
+  d.end = words + enc_len / 4;
+
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t h = hdr[i];
+    const uint32_t cf = (uint32_t)(d.x & 0xFFFFu); // Rans64DecGet
+    int32_t value;
+    if (__builtin_expect(cf == kMaxCdf, 0)) {
+      value = d.bypass();
+    } else {
+      Row r{pool + hdr_off(h), hdr_a(h), (int32_t)hdr_cnt(h)};
+      uint32_t start, freq;
+      bool done = false;
+      if (__builtin_expect(!hdr_nonmono(h), 1)) {
+        const int32_t j = upper_bound_u16(r.row, r.cnt, cf);
+        if (__builtin_expect(j >= 1 && j < r.cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
+          start = r.row[j - 1];
+          freq = r.row[j] - start;
+          value = r.a + j - 1;
+          done = true;
+        }
+      }
+      if (!done) value = bisect_reference(r, cf, max_bs, &start, &freq);
+      d.advance(start, freq);
+    }
+    out[i] = value;
+    if (__builtin_expect(d.underrun, 0)) {
+      free(copy);
+      return FGMM_ERR_STREAM;
+    }
+  }
+  free(copy);
+  return FGMM_OK;
+}
+
+} // namespace fgmm
+
+extern "C" {
+
+int fgmm_rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, uint8_t **out,
+                            size_t *out_len) {
+  return fgmm::rans_encode_symtab(packed, symbols_or_null, n, -1, out, out_len);
+}
+
+int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint64_t *hdr, const uint16_t *pool,
+                            int64_t n, int32_t max_bs, int32_t *out_symbols) {
+  return fgmm::rans_decode_cdftab(encoded, encoded_len, hdr, pool, n, max_bs, out_symbols);
+}
+
+void fgmm_free(void *p) { free(p); }
+
+} // extern "C"

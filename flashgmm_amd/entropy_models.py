@@ -1,0 +1,176 @@
+"""``GaussianMixtureConditional`` — the Python boundary of the path, same API as the reference's class
+(compressai/entropy_models/entropy_models.py:762-910), running on MI355X.
+
+    gmc = GaussianMixtureConditional(K=4)
+    (strings, abs_max, zero_bitmap), y_q = gmc.compress(y, scales, means, weights)
+    y_hat = gmc.decompress(strings, abs_max, zero_bitmap, scales, means, weights)
+
+``y`` is ``[1, M, h, w]``; ``scales / means / weights`` are ``[1, K*M, h, w]`` with channel ``k*M + c``
+(latent_codecs/gaussian_mixture_conditional.py:193-202).  What the reference does on the host between these
+tensors and its C++ coder — abs-max, round, zero-channel bitmap, channel gather, the (n,K) re-layout with the
+sigma clamp, four ``.to("cpu")`` copies — is fused into the HIP kernels: parameters are read in place from the
+planar layout and only the 4 B/symbol table crosses PCIe.  Returned values and bitstreams are identical to the
+reference's for identical inputs.
+
+Intended deviation: ``decompress`` returns ``y_hat`` on the parameters' device (the reference builds it on the
+CPU, entropy_models.py:905-908, and lets the caller's assignment copy it back).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib
+
+__all__ = ["GaussianMixtureConditional"]
+
+
+def _plane_view(t: Tensor, K: int) -> Tuple[Tensor, int, int]:
+    """-> (tensor kept alive, stride_k, stride_c) for a [1, K*M, h, w] parameter tensor whose (h, w) planes are
+    dense; anything else is made contiguous first.  chunk(3, 1) views of the parameter head qualify as they are."""
+    if t.dim() != 4 or t.size(0) != 1:
+        raise RuntimeError("entropy parameters must be [1, K*M, h, w] (the reference squeezes batch 1 too, entropy_models.py:841)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"entropy parameters must be float32, got {t.dtype}")
+    h, w = t.size(2), t.size(3)
+    if not (t.stride(3) == 1 and t.stride(2) == w) and h * w > 1:
+        t = t.contiguous()
+    sc = t.stride(1) if t.size(1) > 1 else h * w
+    M = t.size(1) // K
+    return t, M * sc, sc
+
+
+class GaussianMixtureConditional(nn.Module):
+    """Entropy model of a K-component Gaussian mixture conditional; ``compress`` / ``decompress`` only need K = 4
+    (the reference's coder is bound for K = 4 only, rans_interface.cpp:60,982)."""
+
+    def __init__(self, K: int = 4, mode=None, clamp_scales: bool = True):
+        super().__init__()
+        self.K = int(K)
+        self.mode = mode  # None -> APPROX_MODE env var at call time
+        self.clamp_scales = bool(clamp_scales)  # entropy_models.py:817 clamp(0.11, 256)
+
+    # ------------------------------------------------------------------------------------------------
+    def _mode(self) -> int:
+        return _lib.default_mode() if self.mode is None else _lib.mode_id(self.mode)
+
+    def reshape_entropy_parameters(self, scales, means, weights, nonzero):
+        """Same result as the reference (entropy_models.py:810-828): three (n, K) views with strides (1, n), sigma
+        clamped.  The HIP path never materialises these; kept for callers and tests that want the coder inputs."""
+        reshape_size = (scales.size(0), self.K, scales.size(1) // self.K, -1)
+
+        def rs(t):
+            return t.reshape(*reshape_size)[:, :, nonzero].permute(1, 0, 2, 3).reshape(self.K, -1).permute(1, 0)
+
+        return rs(scales).clamp(0.11, 256), rs(means), rs(weights)
+
+    # ------------------------------------------------------------------------------------------------
+    def _item(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor, keep: list):
+        if not scales.is_cuda:
+            raise RuntimeError(
+                "flashgmm_amd runs the GMM entropy-coding path on the GPU only: tensors must be on a HIP device "
+                "(there is deliberately no CPU fallback)")
+        s, sk, sc = _plane_view(scales, self.K)
+        m, mk, mc = _plane_view(means, self.K)
+        w, wk, wc = _plane_view(weights, self.K)
+        if (mk, mc) != (sk, sc) or (wk, wc) != (sk, sc):
+            s, m, w = s.contiguous(), m.contiguous(), w.contiguous()
+            hw_ = s.size(2) * s.size(3)
+            sc, sk = hw_, (s.size(1) // self.K) * hw_
+        M = s.size(1) // self.K
+        hw = s.size(2) * s.size(3)
+        it = _lib.fgmm_item()
+        it.params = _lib.fgmm_params(s.data_ptr(), m.data_ptr(), w.data_ptr(), sk, sc)
+        it.M, it.K, it.hw = M, self.K, hw
+        keep += [s, m, w]
+        if y is not None:
+            if y.dim() != 4 or y.size(0) != 1 or y.size(1) != M or y.size(2) * y.size(3) != hw:
+                raise RuntimeError(f"y must be [1, {M}, h, w] matching the parameters; got {tuple(y.shape)}")
+            if y.dtype != torch.float32 or y.device != s.device:
+                raise RuntimeError("y must be float32 on the parameters' device")
+            yc = y.contiguous()
+            it.y = yc.data_ptr()
+            keep.append(yc)
+        return it, M, hw, s.device
+
+    def compress_batch(self, ys: Sequence[Tensor], scales: Sequence[Tensor], means: Sequence[Tensor],
+                       weights: Sequence[Tensor]):
+        """N independent ``compress`` calls in one native call (kernels batched over items, one host rANS worker
+        per bitstream).  Returns a list of ``((bytes, abs_max, zero_bitmap_cpu), y_q)``."""
+        if self.K != _lib.FGMM_K:
+            raise RuntimeError(f"K = {self.K}: the coder is bound for K = 4 only (as the reference's)")
+        n_items = len(ys)
+        items = (_lib.fgmm_item * n_items)()
+        keep: list = []
+        outs, bitmaps = [], []
+        dev = None
+        for i in range(n_items):
+            it, M, hw, d = self._item(ys[i], scales[i], means[i], weights[i], keep)
+            dev = dev or d
+            if d != dev:
+                raise RuntimeError("all items of a batch must be on one device")
+            yq = torch.empty_like(keep[-1])
+            zb = torch.empty(M, dtype=torch.int64)
+            it.yq_out, it.zero_bitmap = yq.data_ptr(), zb.data_ptr()
+            items[i] = it
+            outs.append(yq)
+            bitmaps.append(zb)
+        if n_items == 0:
+            return []
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = _lib.lib().fgmm_gmc_compress_batch(_lib.ctx(dev.index if dev.index is not None else -1), stream, items,
+                                                n_items, self._mode(), int(self.clamp_scales))
+        _lib.check(rc, "GaussianMixtureConditional.compress")
+        res = []
+        for i in range(n_items):
+            data = _lib.take_bytes(items[i].bytes, items[i].bytes_len)
+            res.append(((data, int(items[i].abs_max), bitmaps[i]), outs[i].view_as(ys[i])))
+        return res
+
+    def compress(self, y: Tensor, scales: Tensor, means: Tensor, weights: Tensor):
+        """-> ((bytes, abs_max, zero_bitmap), y_quantized)     (entropy_models.py:833-867)"""
+        ((data, abs_max, zb), yq), = self.compress_batch([y], [scales], [means], [weights])
+        return (data, abs_max, zb.to(y.device)), yq
+
+    def decompress_batch(self, strings: Sequence[bytes], abs_maxes: Sequence[int], zero_bitmaps: Sequence[Tensor],
+                         scales: Sequence[Tensor], means: Sequence[Tensor], weights: Sequence[Tensor]) -> List[Tensor]:
+        if self.K != _lib.FGMM_K:
+            raise RuntimeError(f"K = {self.K}: the coder is bound for K = 4 only (as the reference's)")
+        n_items = len(strings)
+        items = (_lib.fgmm_item * n_items)()
+        keep: list = []
+        outs = []
+        dev = None
+        for i in range(n_items):
+            it, M, hw, d = self._item(None, scales[i], means[i], weights[i], keep)
+            dev = dev or d
+            if d != dev:
+                raise RuntimeError("all items of a batch must be on one device")
+            zb = zero_bitmaps[i].to("cpu", torch.int64).contiguous()
+            if zb.numel() != M:
+                raise RuntimeError(f"zero_bitmap has {zb.numel()} entries, expected {M}")
+            data = bytes(strings[i])
+            buf = C.create_string_buffer(data, len(data))
+            y_hat = torch.empty((1, M, scales[i].size(2), scales[i].size(3)), dtype=torch.float32, device=d)
+            it.yq_out, it.zero_bitmap = y_hat.data_ptr(), zb.data_ptr()
+            it.abs_max = int(abs_maxes[i])
+            it.bytes, it.bytes_len = C.cast(buf, C.c_void_p), len(data)
+            items[i] = it
+            keep += [zb, buf]
+            outs.append(y_hat)
+        if n_items == 0:
+            return []
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = _lib.lib().fgmm_gmc_decompress_batch(_lib.ctx(dev.index if dev.index is not None else -1), stream, items,
+                                                  n_items, self._mode(), int(self.clamp_scales))
+        _lib.check(rc, "GaussianMixtureConditional.decompress")
+        return outs
+
+    def decompress(self, strings: bytes, abs_max: int, zero_bitmap: Tensor, scales: Tensor, means: Tensor,
+                   weights: Tensor) -> Tensor:
+        """-> y_hat [1, M, h, w] float32     (entropy_models.py:872-910)"""
+        return self.decompress_batch([strings], [abs_max], [zero_bitmap], [scales], [means], [weights])[0]

@@ -1,0 +1,184 @@
+/*
+ * flashgmm_amd.h — C ABI of libflashgmm_amd.so, the MI355X (gfx950) GMM entropy-coding path.
+ *
+ * This is the drop-in boundary for ONE path of tokkiwa/FlashGMM: what its pybind11 module `compressai.ans`
+ * exposes for Gaussian-mixture conditionals, and the tensor preparation its Python entropy model does right
+ * above that call.  Plain pointers and sizes only; no torch / pybind types.  All functions return an
+ * fgmm_status (0 = OK) and never throw across the ABI.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   - RansEncoder::encode_with_indexes_gmm<4>   compressai/cpp_exts/rans/rans_interface.cpp:609-617 (-> :458-554, :557-585)
+ *   - RansDecoder::decode_with_indexes_gmm<4>   compressai/cpp_exts/rans/rans_interface.cpp:766-883
+ *   - pybind signatures / keyword names         compressai/cpp_exts/rans/rans_interface.cpp:977-1004, :1026-1035
+ *   - GaussianMixtureConditional.compress       compressai/entropy_models/entropy_models.py:833-867
+ *   - GaussianMixtureConditional.decompress     compressai/entropy_models/entropy_models.py:872-910
+ *   - reshape_entropy_parameters (+clamp)       compressai/entropy_models/entropy_models.py:810-828
+ *   - APPROX_MODE numbering                     compressai/cpp_exts/rans/rans_interface.cpp:224-232
+ *
+ * Division of labour (BASELINE.json north_star): every floating-point operation — the K=4 mixture CDF in one
+ * of three Phi approximations, 16-bit quantisation, bypass detection, the decode-side per-latent edge tables —
+ * runs in hand-written HIP kernels; the integer rANS state machine runs on host threads fed by pinned
+ * hipMemcpyAsync copies of the GPU-built tables.  There is NO CPU implementation of the float work in this
+ * library: with no usable HIP device every entry point that needs one returns FGMM_ERR_NO_DEVICE.
+ *
+ * Parameter addressing.  A mixture parameter of latent (channel c, position p), component k lives at
+ *     base[k*stride_k + c*stride_c + p*stride_p]           (strides in ELEMENTS)
+ *   - latent-codec layout [1, K*M, h, w] (channel = k*M + c): stride_k = M*h*w, stride_c = h*w, stride_p = 1
+ *   - the reference's (n, K) accessor views:                 one channel, stride_p = stride(0), stride_k = stride(1)
+ * `memspace` says where the parameter / symbol pointers live: FGMM_DEVICE pointers are used in place,
+ * FGMM_HOST buffers are staged through pinned memory and copied to the GPU first (PCIe-inclusive path).
+ */
+#ifndef FLASHGMM_AMD_H
+#define FLASHGMM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGMM_ABI_VERSION 1
+
+typedef enum {
+  FGMM_OK = 0,
+  FGMM_ERR_INVALID = 1,     /* bad argument (null pointer, K != 4, negative size, unknown mode ...) */
+  FGMM_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime error at context creation */
+  FGMM_ERR_HIP = 3,         /* a HIP call failed; fgmm_last_error() has the text */
+  FGMM_ERR_NOMEM = 4,
+  FGMM_ERR_STREAM = 5,      /* bitstream shorter than the symbols it is asked to yield (corrupt input) */
+  FGMM_ERR_UNSUPPORTED = 6  /* outside the built envelope (e.g. max_bs_value > FGMM_MAX_BS) */
+} fgmm_status;
+
+/* Phi approximation, numbered as the reference CODE numbers APPROX_MODE (the README swaps 1 and 2). */
+typedef enum { FGMM_MODE_POLYA = 0, FGMM_MODE_AS = 1, FGMM_MODE_LOGISTIC = 2 } fgmm_mode;
+
+typedef enum { FGMM_HOST = 0, FGMM_DEVICE = 1 } fgmm_memspace;
+
+#define FGMM_K 4              /* the reference binds K = 4 only (rans_interface.cpp:60,982,1003,1033) */
+#define FGMM_MAX_BS 16382     /* largest decoder half-width (abs_max + 1) the edge-table header can carry */
+
+typedef struct fgmm_ctx fgmm_ctx; /* one per process per GPU: streams, pinned staging, workspaces, host threads */
+
+int fgmm_abi_version(void);
+const char *fgmm_last_error(void); /* thread-local text of the last failure on this thread */
+
+/* device < 0: current HIP device.  n_threads <= 0: min(hardware threads, 16) host rANS workers. */
+int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out);
+void fgmm_ctx_destroy(fgmm_ctx *ctx);
+int fgmm_ctx_device(const fgmm_ctx *ctx);
+int fgmm_ctx_threads(const fgmm_ctx *ctx);
+
+void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 1. The reference's native boundary (compressai.ans), same argument meaning and order.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* RansEncoder.encode_with_indexes_gmm(symbols, scales, means, weights, max_value) -> bytes
+ * symbols: int32[n] contiguous.  scales/means/weights: (n, 4) float32 at [i*stride_n + k*stride_k].
+ * max_value is accepted and ignored, as in the reference (rans_interface.cpp:462).
+ * *out is malloc'ed by the library (fgmm_free); empty input yields the 8-byte flushed state. */
+int fgmm_encode_with_indexes_gmm(fgmm_ctx *ctx, const int32_t *symbols, const float *scales, const float *means,
+                                 const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int K,
+                                 int mode, int memspace, int32_t max_value, uint8_t **out, size_t *out_len);
+
+/* RansDecoder.decode_with_indexes_gmm(encoded, scales, means, weights, max_bs_value) -> int32[n]
+ * out_symbols: HOST int32[n].  Yields exactly what the reference's float bisection yields, including on
+ * non-monotone tables and on its pmf==0 fallback (rans_interface.cpp:865-875). */
+int fgmm_decode_with_indexes_gmm(fgmm_ctx *ctx, const uint8_t *encoded, size_t encoded_len, const float *scales,
+                                 const float *means, const float *weights, int64_t n, int64_t stride_n,
+                                 int64_t stride_k, int K, int mode, int memspace, int32_t max_bs_value,
+                                 int32_t *out_symbols);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 2. Entropy-model level, fused on the GPU: GaussianMixtureConditional.compress / .decompress for B = 1.
+ *    All tensor pointers are DEVICE pointers in the latent codec's layout:
+ *      y [M, h*w] float32;   scales/means/weights [K, M, h*w] via (stride_k, stride_c), position stride 1.
+ *    `stream` is the hipStream_t the caller's producer kernels were enqueued on (NULL = default stream);
+ *    the library orders its own work after it and returns with all outputs complete.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+typedef struct {
+  const float *scales, *means, *weights; /* device */
+  int64_t stride_k, stride_c;            /* elements */
+} fgmm_params;
+
+/* compress(y, scales, means, weights) -> ((bytes, abs_max, zero_bitmap), y_quantized)
+ *   yq_out        device float32[M*hw]  = round(y) (round-half-even)                    entropy_models.py:839
+ *   abs_max_out   max(int|max y|, int|min y|) + 1, floored at 1                         entropy_models.py:834-837
+ *   zero_bitmap   HOST int64[M]: 1 where the channel has any non-zero quantised latent  entropy_models.py:840-842
+ *   scales are clamped to [0.11, 256] when clamp_scales != 0                            entropy_models.py:817
+ *   symbols are coded in (non-zero channel, h, w) order                                 entropy_models.py:844-845 */
+int fgmm_gmc_compress(fgmm_ctx *ctx, void *stream, const float *y, const fgmm_params *params, int M, int K,
+                      int64_t hw, int mode, int clamp_scales, float *yq_out, int32_t *abs_max_out,
+                      int64_t *zero_bitmap_out, uint8_t **out, size_t *out_len);
+
+/* decompress(strings, abs_max, zero_bitmap, scales, means, weights) -> y_hat
+ *   y_hat_out     device float32[M*hw]: decoded symbols at the non-zero channels, 0 elsewhere (:903-908) */
+int fgmm_gmc_decompress(fgmm_ctx *ctx, void *stream, const uint8_t *encoded, size_t encoded_len, int32_t abs_max,
+                        const int64_t *zero_bitmap, const fgmm_params *params, int M, int K, int64_t hw, int mode,
+                        int clamp_scales, float *y_hat_out);
+
+/* Batched forms: `count` independent streams (images / checkerboard halves) in one call.  Kernels for all
+ * items are enqueued first on the context's HIP streams, tables come back by pinned async copies, and the host
+ * worker threads run one rANS state machine per item.  Item i uses y[i], params[i], ... ; outputs as above. */
+typedef struct {
+  const float *y;          /* device [M*hw] (compress only) */
+  fgmm_params params;
+  int32_t M, K;
+  int64_t hw;
+  float *yq_out;           /* compress: device [M*hw];  decompress: y_hat device [M*hw] */
+  int64_t *zero_bitmap;    /* HOST int64[M]: compress out / decompress in */
+  int32_t abs_max;         /* compress out / decompress in */
+  uint8_t *bytes;          /* compress: out (fgmm_free);  decompress: in */
+  size_t bytes_len;
+  int32_t status;          /* per-item fgmm_status */
+} fgmm_item;
+
+int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
+int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 3. Building blocks ("same tables => same bytes" surfaces; also what the parity tests probe).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* GPU: float mixture-CDF pair per symbol, c1 = cdf(v - 0.5), c2 = cdf(v - 0.5 + 1.0)  (rans_interface.cpp:498-501).
+ * v: device int32[n]; params (n,4) device via (stride_n, stride_k); c1/c2: device float32[n]. */
+int fgmm_gmm_cdf_hip(fgmm_ctx *ctx, void *stream, const int32_t *v, const float *scales, const float *means,
+                     const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode, float *c1,
+                     float *c2);
+
+/* GPU: encode-side symbol table.  packed[i] = start | range << 16 with start = (uint16)(c1*65535),
+ * range = (uint16)(end - start); range == 0 marks the reference's bypass escape (rans_interface.cpp:512-517) and
+ * the low half then carries the low 16 bits of the symbol.  All pointers device. */
+int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, const float *scales,
+                          const float *means, const float *weights, int64_t n, int64_t stride_n, int64_t stride_k,
+                          int mode, uint32_t *packed);
+
+/* GPU: decode-side edge tables.  For latent i the reference's bisection can only ever look at
+ *   F_i[v] = (uint16)(cdf_i(v - 0.5) * 65535),  v in [-max_bs, max_bs + 1]      (rans_interface.cpp:826-862).
+ * The kernel evaluates all of F_i and stores the window outside which it is constant:
+ *   hdr[i]  = { int16 a; uint16 cnt | nonmono << 15; uint32 off }   (8 bytes)
+ *   pool[off .. off+cnt) = F_i[a .. a+cnt),   F_i[v < a] = 0,  F_i[v >= a+cnt] = pool[off+cnt-1]
+ * rows are padded to a multiple of 4 entries with their last value.  `nonmono` is set when the stored row
+ * decreases somewhere.  hdr: device uint64[n]; pool: device uint16[pool_cap]; pool_used: device uint64[1],
+ * zeroed by the call.  pool_cap >= n * (2*max_bs + 5) always suffices. */
+int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
+                          const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode,
+                          int32_t max_bs, uint64_t *hdr, uint16_t *pool, uint64_t pool_cap, uint64_t *pool_used);
+
+/* Host, integer only: symbol table (+ raw symbols, needed only where range == 0 and abs(symbol) >= 32768)
+ * -> bitstream.  BufferedRansEncoder::flush semantics (rans_interface.cpp:557-585). */
+int fgmm_rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, uint8_t **out,
+                            size_t *out_len);
+
+/* Host, integer only: edge tables -> symbols; the reference's bisection with every float evaluation replaced
+ * by a look-up in F_i. */
+int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint64_t *hdr, const uint16_t *pool,
+                            int64_t n, int32_t max_bs, int32_t *out_symbols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASHGMM_AMD_H */

@@ -1,0 +1,318 @@
+"""GPU (-m gpu): parity of the HIP path with the oracle / golden vectors, called through the C ABI.
+
+Bars: bit-exact for every integer / byte / index result; float CDFs within 1e-5 of the reference (north_star) —
+and, since the arithmetic is restated op for op, asserted bit-exact as well.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from flashgmm_amd import GaussianMixtureConditional, _lib, ans, testing as T
+from helpers import expand_trimmed
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+MODES = ["polya", "as", "logistic"]
+DEV = "cuda:0"
+
+
+def _mg():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg
+
+
+def dv(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def gpu_cdf(mode, v, s, m, w):
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    v, s, m, w = dv(v.astype(np.int32)), dv(s), dv(m), dv(w)
+    n = v.numel()
+    c1 = torch.empty(n, dtype=torch.float32, device=DEV)
+    c2 = torch.empty_like(c1)
+    torch.cuda.synchronize()
+    _lib.check(L.fgmm_gmm_cdf_hip(ctx, None, v.data_ptr(), s.data_ptr(), m.data_ptr(), w.data_ptr(), n, s.stride(0),
+                                  s.stride(1), _lib.mode_id(mode), c1.data_ptr(), c2.data_ptr()))
+    return c1.cpu().numpy(), c2.cpu().numpy()
+
+
+def gpu_symtab(mode, v, s, m, w):
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    v, s, m, w = dv(v.astype(np.int32)), dv(s), dv(m), dv(w)
+    n = v.numel()
+    out = torch.empty(n, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
+    _lib.check(L.fgmm_build_symtab_hip(ctx, None, v.data_ptr(), s.data_ptr(), m.data_ptr(), w.data_ptr(), n, s.stride(0),
+                                       s.stride(1), _lib.mode_id(mode), out.data_ptr()))
+    return out.cpu().numpy().view(np.uint32)
+
+
+def gpu_cdftab(mode, s, m, w, max_bs):
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    s, m, w = dv(s), dv(m), dv(w)
+    n = s.size(0)
+    cap = n * (2 * max_bs + 6)
+    hdr = torch.zeros(n, dtype=torch.int64, device=DEV)
+    pool = torch.zeros(cap + 64, dtype=torch.int16, device=DEV)
+    used = torch.zeros(2, dtype=torch.int64, device=DEV)
+    torch.cuda.synchronize()
+    _lib.check(L.fgmm_build_cdftab_hip(ctx, None, s.data_ptr(), m.data_ptr(), w.data_ptr(), n, s.stride(0), s.stride(1),
+                                       _lib.mode_id(mode), max_bs, hdr.data_ptr(), pool.data_ptr(), cap, used.data_ptr()))
+    return hdr.cpu().numpy().view(np.uint64), pool.cpu().numpy().view(np.uint16), int(used[0].item())
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", MODES)
+def test_g1_float_cdf(mode):
+    g = np.load(os.path.join(GOLD, "g1_cdf.npz"))
+    c1, c2 = gpu_cdf(mode, g["v"], g["scales"], g["means"], g["weights"])
+    r1, r2 = g[f"c1_{mode}"].view(np.float32), g[f"c2_{mode}"].view(np.float32)
+    assert np.abs(c1 - r1).max() <= 1e-5 and np.abs(c2 - r2).max() <= 1e-5  # the stated tolerance
+    assert np.array_equal(c1.view(np.uint32), g[f"c1_{mode}"])  # and in fact bit for bit
+    assert np.array_equal(c2.view(np.uint32), g[f"c2_{mode}"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_float_cdf_bit_exact_wide_sweep(oracle, mode):
+    """2M rows incl. extreme sigma (1e-5 .. 3e3), far tails, both sides of every clamp."""
+    rng = np.random.default_rng(2024)
+    n = 2_000_000
+    e = np.exp(rng.uniform(-3, 2.5, n)).astype(np.float32)
+    mu = (rng.standard_normal((n, 4)) * e[:, None]).astype(np.float32)
+    sg = np.exp(rng.uniform(-12, 8, (n, 4))).astype(np.float32)
+    sg[: n // 2] = np.clip((rng.uniform(0, 2, (n // 2, 4)) + 0.05) * e[: n // 2, None], 0.11, 256)
+    lg = rng.standard_normal((n, 4))
+    pi = (np.exp(lg) / np.exp(lg).sum(1, keepdims=True)).astype(np.float32)
+    v = np.round(rng.standard_normal(n) * 40).astype(np.int32)
+    c1, c2 = gpu_cdf(mode, v, sg, mu, pi)
+    o1, o2 = oracle.gmm_cdf(mode, v, sg, mu, pi)
+    assert np.array_equal(c1.view(np.uint32), o1.view(np.uint32))
+    assert np.array_equal(c2.view(np.uint32), o2.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_g2_symtab(oracle, mode):
+    g = np.load(os.path.join(GOLD, "g1_cdf.npz"))
+    packed = gpu_symtab(mode, g["v"], g["scales"], g["means"], g["weights"])
+    assert np.array_equal(packed >> 16, g[f"range_{mode}"].astype(np.uint32))
+    nb = (packed >> 16) != 0
+    assert np.array_equal((packed & 0xFFFF)[nb], g[f"start_{mode}"].astype(np.uint32)[nb])
+    assert np.array_equal(packed, oracle.symtab(mode, g["v"], g["scales"], g["means"], g["weights"]))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_symtab_strided_and_ragged(oracle, mode):
+    """(n,4) row-major, (1,n) planar views, n not a multiple of 4 -> scalar and 16-B kernels agree with the oracle."""
+    for seed, n in ((1, 1), (2, 3), (3, 1021), (4, 4096)):
+        rng = np.random.default_rng(seed)
+        e = np.exp(rng.uniform(-2, 2, n)).astype(np.float32)
+        mu = (rng.standard_normal((n, 4)) * e[:, None]).astype(np.float32)
+        sg = ((rng.uniform(0, 2, (n, 4)) + 0.11) * e[:, None]).astype(np.float32)
+        pi = rng.dirichlet(np.ones(4), n).astype(np.float32)
+        v = np.round(rng.standard_normal(n) * 2 * e).astype(np.int32)
+        want = oracle.symtab(mode, v, sg, mu, pi)
+        assert np.array_equal(gpu_symtab(mode, v, sg, mu, pi), want)
+        # planar: strides (1, n)
+        L, ctx = _lib.lib(), _lib.ctx(0)
+        sp, mp, wp = (dv(np.ascontiguousarray(a.T)) for a in (sg, mu, pi))
+        vd = dv(v)
+        out = torch.empty(n, dtype=torch.int32, device=DEV)
+        torch.cuda.synchronize()
+        _lib.check(L.fgmm_build_symtab_hip(ctx, None, vd.data_ptr(), sp.data_ptr(), mp.data_ptr(), wp.data_ptr(), n, 1, n,
+                                           _lib.mode_id(mode), out.data_ptr()))
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_g3_small_streams_through_ans_mirror(mode):
+    gold = json.load(open(os.path.join(GOLD, "g3_small.json")))["cases"]
+    for name, (sym, s, m, w) in _mg().g3_cases().items():
+        ent = gold[name][mode]
+        for dev in ("cpu", DEV):  # the reference hands CPU tensors; GPU tensors are this repo's fast path
+            t = [torch.from_numpy(a).to(dev) for a in (sym, s, m, w)]
+            b = ans.RansEncoder().encode_with_indexes_gmm(*t, 0, mode=mode)
+            assert b.hex() == ent["hex"], (name, dev)
+            d = ans.RansDecoder().decode_with_indexes_gmm(b, *t[1:], ent["max_bs"], mode=mode)
+            assert d.dtype == torch.int32 and d.device.type == "cpu"
+            assert d.tolist() == ent["decoded"], (name, dev)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_ka1_boundary_level(mode):
+    """KA-1 through the reference's own boundary signature, with the reference's (n,4) strides-(1,n) views."""
+    ent = json.load(open(os.path.join(GOLD, "ka1.json")))[mode]
+    for seed in ("1234", "0"):
+        y, sg, mu, pi = T.make_latent(int(seed))
+        sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+        t = [torch.from_numpy(np.ascontiguousarray(a.T)).to(DEV).T for a in (s, m, w)]  # strides (1, n)
+        assert t[0].stride() == (1, len(sym))
+        b = ans.RansEncoder().encode_with_indexes_gmm(torch.from_numpy(sym).to(DEV), *t, abs_max + 1, mode=mode)
+        assert (len(b), hashlib.md5(b).hexdigest()) == (ent[seed]["len"], ent[seed]["md5"])
+        d = ans.RansDecoder().decode_with_indexes_gmm(b, *t, abs_max + 1, mode=mode)
+        assert np.array_equal(d.numpy(), sym)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_g4_api_level(mode):
+    """GaussianMixtureConditional.compress / decompress == the reference's own class (un-clamped sigma, zero channels)."""
+    gold = json.load(open(os.path.join(GOLD, "g4_api.json")))[mode]
+    gmc = GaussianMixtureConditional(K=4, mode=mode)
+    for seed, ent in gold.items():
+        y, sg, mu, pi = T.make_latent(int(seed), M=ent["M"], h=ent["h"], w=ent["w"], clamp=False, zero_frac=0.15)
+        t = [dv(a) for a in (y, sg, mu, pi)]
+        (b, abs_max, zb), yq = gmc.compress(*t)
+        assert isinstance(b, bytes) and isinstance(abs_max, int)
+        assert zb.dtype == torch.int64 and zb.device == t[0].device and zb.tolist() == ent["zero_bitmap"]
+        assert (len(b), hashlib.md5(b).hexdigest(), abs_max) == (ent["len"], ent["md5"], ent["abs_max"])
+        assert yq.shape == t[0].shape and hashlib.sha256(yq.cpu().numpy().tobytes()).hexdigest() == ent["yq_sha256"]
+        y_hat = gmc.decompress(b, abs_max, zb, *t[1:])
+        assert y_hat.dtype == torch.float32 and list(y_hat.shape) == ent["y_hat_shape"]
+        assert torch.equal(y_hat, yq)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_chunked_parameter_views(oracle, mode):
+    """params handed as chunk(3, 1) views of one [1, 3*K*M, h, w] head output (latent codec :193-195)."""
+    M, h, w = 24, 12, 10  # hw = 120: 16-B path;  M*hw strides stay multiples of 4
+    y, sg, mu, pi = T.make_latent(8, M=M, h=h, w=w, clamp=False)
+    head = dv(np.concatenate([sg, mu, pi], axis=1))
+    s_, m_, w_ = head.chunk(3, 1)
+    gmc = GaussianMixtureConditional(K=4, mode=mode)
+    (b, abs_max, zb), yq = gmc.compress(dv(y), s_, m_, w_)
+    sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi)
+    assert b == oracle.encode_gmm(mode, sym, s, m, wt) and abs_max == am
+    assert torch.equal(gmc.decompress(b, abs_max, zb, s_, m_, w_), yq)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_ragged_shapes_and_edge_cases(oracle, mode):
+    gmc = GaussianMixtureConditional(K=4, mode=mode)
+    for seed, (M, h, w), zf in ((1, (3, 5, 7), 0.0), (2, (17, 1, 1), 0.3), (3, (192, 16, 8), 0.5), (4, (5, 3, 3), 1.0)):
+        y, sg, mu, pi = T.make_latent(seed, M=M, h=h, w=w, clamp=False, zero_frac=zf)
+        t = [dv(a) for a in (y, sg, mu, pi)]
+        (b, abs_max, zb), yq = gmc.compress(*t)
+        sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi)
+        assert b == oracle.encode_gmm(mode, sym, s, m, wt), (seed, M, h, w)
+        assert abs_max == am and zb.cpu().numpy().tolist() == zbm.tolist()
+        assert np.array_equal(yq.cpu().numpy(), yqn)
+        if zf == 1.0:
+            assert b == bytes.fromhex("0000008000000000")  # every channel zero: empty stream
+        assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq)
+
+
+def test_wide_bypass_symbols(oracle):
+    """latents far outside int16 with tiny sigma: bypass nibbles must carry the full int32 (rans_interface.cpp:525)."""
+    M, h, w = 4, 4, 4
+    y, sg, mu, pi = T.make_latent(21, M=M, h=h, w=w)
+    y = y.copy()
+    y[0, 1, 2, 3] = 70000.3
+    y[0, 2, 0, 0] = -123456.7
+    y[0, 3, 1, 1] = 40000.0
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    t = [dv(a) for a in (y, sg, mu, pi)]
+    (b, abs_max, zb), yq = gmc.compress(*t)
+    sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi)
+    assert abs_max == am == 123457
+    assert b == oracle.encode_gmm("polya", sym, s, m, wt)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):  # decoder half-width beyond the built envelope: loud
+        gmc.decompress(b, abs_max, zb, *t[1:])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_cdftab_equals_oracle_full_table(oracle, mode):
+    y, sg, mu, pi = T.make_latent(31, M=24, h=16, w=8)
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    max_bs = abs_max + 1
+    hdr, pool, used = gpu_cdftab(mode, s, m, w, max_bs)
+    full = oracle.cdftab(mode, s, m, w, max_bs)
+    assert np.array_equal(expand_trimmed(hdr, pool, max_bs), full)
+    assert used < 0.6 * full.size  # trimmed for real
+    # un-normalised / wild parameters: still exact (the window is found by evaluation, not by assumption)
+    rng = np.random.default_rng(3)
+    n = 3000
+    sgw = np.exp(rng.uniform(-6, 6, (n, 4))).astype(np.float32)
+    muw = (rng.standard_normal((n, 4)) * 20).astype(np.float32)
+    piw = rng.uniform(0, 0.6, (n, 4)).astype(np.float32)
+    hdr, pool, used = gpu_cdftab(mode, sgw, muw, piw, 37)
+    assert np.array_equal(expand_trimmed(hdr, pool, 37), oracle.cdftab(mode, sgw, muw, piw, 37))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_decoder_equals_reference_on_garbage_streams(oracle, mode):
+    """Desynchronised input: the result must still be the reference's (its bisection fallbacks included)."""
+    rng = np.random.default_rng(17)
+    n, max_bs = 5000, 12
+    e = np.exp(rng.uniform(-2, 1.5, n)).astype(np.float32)
+    mu = (rng.standard_normal((n, 4)) * e[:, None]).astype(np.float32)
+    sg = ((rng.uniform(0, 2, (n, 4)) + 0.11) * e[:, None]).astype(np.float32)
+    pi = rng.dirichlet(np.ones(4), n).astype(np.float32)
+    enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+    want = oracle.decode_gmm(mode, enc, sg, mu, pi, max_bs)
+    got = ans.RansDecoder().decode_with_indexes_gmm(enc, dv(sg), dv(mu), dv(pi), max_bs, mode=mode)
+    assert np.array_equal(got.numpy(), want)
+    with pytest.raises(RuntimeError, match="STREAM"):
+        ans.RansDecoder().decode_with_indexes_gmm(enc[:64], dv(sg), dv(mu), dv(pi), max_bs, mode=mode)
+
+
+def test_input_validation_is_loud():
+    s = torch.rand(8, 4, device=DEV) + 0.2
+    v = torch.zeros(8, dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):
+        ans.RansEncoder().encode_with_indexes_gmm(v.long(), s, s, s, 1)
+    with pytest.raises(RuntimeError):
+        ans.RansEncoder().encode_with_indexes_gmm(v, s[:, :3], s, s, 1)
+    with pytest.raises(RuntimeError):
+        ans.RansEncoder().encode_with_indexes_gmm(v, s.double(), s, s, 1)
+    with pytest.raises(RuntimeError):
+        GaussianMixtureConditional(K=3).compress(torch.zeros(1, 2, 2, 2, device=DEV), *(torch.ones(1, 6, 2, 2, device=DEV),) * 3)
+
+
+def test_buffered_encoder_concatenates(oracle):
+    rng = np.random.default_rng(9)
+    parts = []
+    for n in (100, 37):
+        e = np.ones(n, np.float32)
+        mu = rng.standard_normal((n, 4)).astype(np.float32)
+        sg = (rng.uniform(0.2, 2, (n, 4))).astype(np.float32)
+        pi = rng.dirichlet(np.ones(4), n).astype(np.float32)
+        v = np.round(rng.standard_normal(n) * 2).astype(np.int32)
+        parts.append((v, sg, mu, pi))
+    enc = ans.BufferedRansEncoder()
+    for v, sg, mu, pi in parts:
+        enc.encode_with_indexes_gmm(dv(v), dv(sg), dv(mu), dv(pi), 0, mode="as")
+    b = enc.flush()
+    cat = [np.concatenate([p[i] for p in parts]) for i in range(4)]
+    assert b == oracle.encode_gmm("as", *cat)
+    assert enc.flush() == bytes.fromhex("0000008000000000")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_batch_of_kodak_halves_full_size(mode):
+    """BASELINE configs[1] shape: 24 images x 2 halves of [1,192,32,24], one native call each way.
+    Checked against the reference through its golden md5s (seeds 0..3 are in ka1.json) and, for the whole batch,
+    through the size-independent property decode(encode(y)) == round(y)."""
+    ka = json.load(open(os.path.join(GOLD, "ka1.json")))[mode]
+    gmc = GaussianMixtureConditional(K=4, mode=mode)
+    ys, ss, ms, ws = [], [], [], []
+    for seed in range(48):
+        y, sg, mu, pi = T.make_latent(seed)
+        ys.append(dv(y)); ss.append(dv(sg)); ms.append(dv(mu)); ws.append(dv(pi))
+    res = gmc.compress_batch(ys, ss, ms, ws)
+    for seed in range(4):
+        (b, abs_max, zb), yq = res[seed]
+        assert (len(b), hashlib.md5(b).hexdigest(), abs_max) == (ka[str(seed)]["len"], ka[str(seed)]["md5"], ka[str(seed)]["abs_max"])
+    outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+    for seed in range(48):
+        assert torch.equal(outs[seed], res[seed][1]), seed
+        assert torch.equal(res[seed][1], torch.round(ys[seed]))

@@ -1,0 +1,144 @@
+"""CPU (-m "not gpu"): the product's HOST logic and ABI surface, no GPU compute.
+
+  * libflashgmm_amd.so loads and exports every symbol include/flashgmm_amd.h declares;
+  * with no HIP device the GPU entry points fail loudly (no CPU fallback exists);
+  * the integer-only host rANS coder (fgmm_rans_encode_symtab / fgmm_rans_decode_cdftab) reproduces the
+    reference's streams / symbols from tables — tables here come from the oracle, formatted by tests/helpers.py.
+"""
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from flashgmm_amd import _lib, testing as T
+from helpers import expand_trimmed, host_decode_cdftab, host_encode_symtab, trim_full_table
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODES = ["polya", "as", "logistic"]
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "flashgmm_amd.h")).read()
+    declared = set(re.findall(r"\b(fgmm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fgmm_status", "fgmm_mode", "fgmm_memspace"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert L.fgmm_abi_version() == 1
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.FgmmError, match="NO_DEVICE"):
+        _lib.ctx(-1)
+    from flashgmm_amd import GaussianMixtureConditional
+
+    y, sg, mu, pi = (torch.from_numpy(a) for a in T.make_latent(3, M=8, h=4, w=4))
+    with pytest.raises(RuntimeError, match="GPU only|NO_DEVICE"):
+        GaussianMixtureConditional(K=4).compress(y, sg, mu, pi)
+    from flashgmm_amd import ans
+
+    s = torch.rand(5, 4) + 0.2
+    with pytest.raises(RuntimeError):
+        ans.RansEncoder().encode_with_indexes_gmm(torch.zeros(5, dtype=torch.int32), s, s, s, 1)
+
+
+def test_product_does_not_import_the_oracle():
+    """the product path may not route through oracle/ (grep-level guard)"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "flashgmm_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".sh")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "fgmm_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_host_encoder_from_oracle_tables(oracle, mode):
+    L = _lib.lib()
+    # KA-1 Kodak half: md5 of the reference
+    ent = json.load(open(os.path.join(GOLD, "ka1.json")))[mode]["1234"]
+    y, sg, mu, pi = T.make_latent(1234)
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    packed = oracle.symtab(mode, sym, s, m, w)
+    b = host_encode_symtab(L, packed, None)  # |symbols| < 32768: bypass values come from the table
+    assert (len(b), hashlib.md5(b).hexdigest()) == (ent["len"], ent["md5"])
+    assert host_encode_symtab(L, packed, sym) == b
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_host_encoder_small_and_wide_bypass(oracle, mode):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = json.load(open(os.path.join(GOLD, "g3_small.json")))["cases"]
+    L = _lib.lib()
+    for name, (sym, s, m, w) in mg.g3_cases().items():
+        packed = oracle.symtab(mode, sym, s, m, w)
+        assert host_encode_symtab(L, packed, sym).hex() == gold[name][mode]["hex"], name  # incl. 2^30, -2^31 bypass
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_host_decoder_from_oracle_tables(oracle, mode):
+    L = _lib.lib()
+    y, sg, mu, pi = T.make_latent(11, M=48, h=16, w=8)
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    enc = oracle.encode_gmm(mode, sym, s, m, w)
+    max_bs = abs_max + 1
+    tab = oracle.cdftab(mode, s, m, w, max_bs)
+    hdr, pool, used = trim_full_table(tab, max_bs)
+    assert np.array_equal(expand_trimmed(hdr, pool, max_bs), tab)  # the format is lossless
+    rc, out = host_decode_cdftab(L, enc, hdr, pool, max_bs)
+    assert rc == 0 and np.array_equal(out, sym)
+    assert used < tab.size  # and it is a real trim
+
+
+def test_host_decoder_matches_reference_bisection_on_hostile_tables(oracle):
+    """Non-monotone rows, zero-width brackets and cum_freq values no interval contains: the host decoder must
+    return what the reference's bisection returns (oracle.rans_decode_cdftab is its literal replay)."""
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    n, max_bs = 4000, 9
+    W = 2 * max_bs + 2
+    tab = np.sort(rng.integers(0, 65536, (n, W)), axis=1).astype(np.uint16)
+    tab[: n // 2, :3] = 0
+    tab[n // 4: n // 2, -4:] = tab[n // 4: n // 2, -5:-4]
+    # hostile: swap two entries in a third of the rows (non-monotone), flat rows, rows not starting at 0
+    for i in range(0, n, 3):
+        j = rng.integers(1, W - 1)
+        tab[i, j], tab[i, j - 1] = tab[i, j - 1], tab[i, j]
+    tab[5::50] = 1234
+    tab[7::50] = 0
+    enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()  # garbage stream: exercises every fallback
+    hdr, pool, _ = trim_full_table(tab, max_bs)
+    assert np.array_equal(expand_trimmed(hdr, pool, max_bs), tab)
+    want = oracle.rans_decode_cdftab(enc, tab, max_bs)
+    rc, out = host_decode_cdftab(L, enc, hdr, pool, max_bs)
+    assert rc == 0
+    assert np.array_equal(out, want)
+
+
+def test_host_decoder_short_stream_is_an_error(oracle):
+    L = _lib.lib()
+    y, sg, mu, pi = T.make_latent(12, M=8, h=8, w=8)
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    enc = oracle.encode_gmm("polya", sym, s, m, w)
+    hdr, pool, _ = trim_full_table(oracle.cdftab("polya", s, m, w, abs_max + 1), abs_max + 1)
+    rc, _ = host_decode_cdftab(L, enc[: len(enc) // 2 // 4 * 4], hdr, pool, abs_max + 1)
+    assert rc == 5  # FGMM_ERR_STREAM
+    rc, _ = host_decode_cdftab(L, b"\0\0\0", hdr, pool, abs_max + 1)
+    assert rc == 5
+
+
+def test_empty_table_flushes_initial_state():
+    assert host_encode_symtab(_lib.lib(), np.zeros(0, np.uint32), None) == bytes.fromhex("0000008000000000")
