@@ -48,6 +48,8 @@ SIGNATURES = {
     "fgmm_ctx_device": (_i, [_p]),
     "fgmm_ctx_threads": (_i, [_p]),
     "fgmm_free": (None, [_p]),
+    "fgmm_ctx_set_profiling": (_i, [_p, _i]),
+    "fgmm_ctx_kernel_ms": (_i, [_p, _i, C.POINTER(C.c_float)]),
     "fgmm_encode_with_indexes_gmm": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _i32, _pp, _psz]),
     "fgmm_decode_with_indexes_gmm": (_i, [_p, _p, _sz, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _i32, _p]),
     "fgmm_gmc_compress": (_i, [_p, _p, _p, C.POINTER(fgmm_params), _i, _i, _i64, _i, _i, _p, C.POINTER(_i32), _p, _pp, _psz]),
@@ -131,3 +133,15 @@ def default_mode() -> int:
     except ValueError:
         return 0
     return m if 0 <= m <= 2 else 0
+
+
+def set_profiling(device: int, enable: bool) -> None:
+    check(lib().fgmm_ctx_set_profiling(ctx(device), int(enable)), "fgmm_ctx_set_profiling")
+
+
+def kernel_ms(device: int, which: int) -> float:
+    """Duration (ms) of the most recent launch of kernel `which` (0 symtab, 1 cdftab, 2 quant_stats), from HIP
+    events recorded on the stream the kernel ran on."""
+    out = C.c_float()
+    check(lib().fgmm_ctx_kernel_ms(ctx(device), which, C.byref(out)), "fgmm_ctx_kernel_ms")
+    return float(out.value)

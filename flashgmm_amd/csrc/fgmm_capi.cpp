@@ -130,6 +130,21 @@ struct fgmm_ctx {
   char *h_ws = nullptr; // pinned
   size_t h_cap = 0;
   std::vector<hipEvent_t> events;
+  bool profiling = false;
+  hipEvent_t prof[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  bool prof_valid[3] = {false, false, false};
+
+  int prof_begin(int which, hipStream_t s) {
+    if (!profiling) return FGMM_OK;
+    HIP_TRY(hipEventRecord(prof[which][0], s));
+    return FGMM_OK;
+  }
+  int prof_end(int which, hipStream_t s) {
+    if (!profiling) return FGMM_OK;
+    HIP_TRY(hipEventRecord(prof[which][1], s));
+    prof_valid[which] = true;
+    return FGMM_OK;
+  }
 
   int ensure_device(size_t bytes) {
     if (bytes <= d_cap) return FGMM_OK;
@@ -263,8 +278,14 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   HIP_TRY(hipMemsetAsync(ctx->d_ws + o_small, 0, small_bytes, stream));
   const EncDesc *dd = reinterpret_cast<const EncDesc *>(ctx->d_ws + o_descs);
   // a batch is homogeneous by construction: all latent-layout items (y given) or one raw (n,K) item
-  if (any_y) LAUNCH_TRY(launch_quant_stats(dd, count, M_max, stream));
+  if (any_y) {
+    if ((rc = ctx->prof_begin(2, stream))) return rc;
+    LAUNCH_TRY(launch_quant_stats(dd, count, M_max, stream));
+    if ((rc = ctx->prof_end(2, stream))) return rc;
+  }
+  if ((rc = ctx->prof_begin(0, stream))) return rc;
   LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4, stream));
+  if ((rc = ctx->prof_end(0, stream))) return rc;
   // ---- tables back to the host: small region first, then one copy + event per item ----------------
   HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_small, ctx->d_ws + o_small, small_bytes, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipEventRecord(ctx->events[count], stream));
@@ -432,7 +453,9 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + o_used, 0, 16 * (size_t)count, stream));
+  if ((rc = ctx->prof_begin(1, stream))) return rc;
   LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs), count, n_ch_max, hw_max, mode, stream));
+  if ((rc = ctx->prof_end(1, stream))) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_used, ctx->d_ws + o_used, 16 * (size_t)count, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
 
@@ -541,10 +564,35 @@ void fgmm_ctx_destroy(fgmm_ctx *ctx) {
     DeviceGuard g(ctx->device);
     delete ctx->pool;
     for (auto e : ctx->events) (void)hipEventDestroy(e);
+    for (auto &pr : ctx->prof)
+      for (auto e : pr)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_ws) (void)hipHostFree(ctx->h_ws);
   }
   delete ctx;
+}
+
+int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable) {
+  if (!ctx) return fail(FGMM_ERR_INVALID, "ctx == NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  if (enable)
+    for (auto &pr : ctx->prof)
+      for (auto &e : pr)
+        if (!e) HIP_TRY(hipEventCreate(&e));
+  ctx->profiling = enable != 0;
+  return FGMM_OK;
+}
+
+int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out) {
+  if (!ctx || which < 0 || which > 2 || !ms_out) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!ctx->profiling || !ctx->prof_valid[which]) return fail(FGMM_ERR_INVALID, "no profiled launch of kernel %d yet", which);
+  DeviceGuard g(ctx->device);
+  HIP_TRY(hipEventSynchronize(ctx->prof[which][1]));
+  HIP_TRY(hipEventElapsedTime(ms_out, ctx->prof[which][0], ctx->prof[which][1]));
+  return FGMM_OK;
 }
 
 int fgmm_ctx_device(const fgmm_ctx *ctx) { return ctx ? ctx->device : -1; }

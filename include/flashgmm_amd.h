@@ -71,6 +71,12 @@ int fgmm_ctx_threads(const fgmm_ctx *ctx);
 
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
 
+/* Measurement aid (bench.py): when enabled, timing HIP events bracket each table kernel ON THE STREAM IT IS
+ * LAUNCHED ON; fgmm_ctx_kernel_ms returns the duration of the most recent launch of
+ * which = 0: symtab kernel (encode-side CDF), 1: cdftab kernel (decode-side tables), 2: quant_stats kernel. */
+int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable);
+int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out);
+
 /* ------------------------------------------------------------------------------------------------------------
  * 1. The reference's native boundary (compressai.ans), same argument meaning and order.
  * ---------------------------------------------------------------------------------------------------------- */
