@@ -58,7 +58,8 @@ SIGNATURES = {
     "fgmm_gmc_decompress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
     "fgmm_gmm_cdf_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p, _p]),
     "fgmm_build_symtab_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
-    "fgmm_build_cdftab_hip": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i32, _p, _p, C.c_uint64, _p]),
+    "fgmm_build_cdftab_hip": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i32, _i, _p, _p, C.c_uint64, _p]),
+    "fgmm_selftest_saturation": (_i, [_p, _i, C.POINTER(C.c_uint64)]),
     "fgmm_rans_encode_symtab": (_i, [_p, _p, _i64, _pp, _psz]),
     "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, _i64, _i32, _p]),
 }

@@ -439,6 +439,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.n_ch = it.n_ch;
     d.max_bs = it.max_bs;
     d.clamp = it.clamp;
+    d.prune = 1;
     d.hdr = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_hdr);
     d.pool = reinterpret_cast<uint16_t *>(ctx->d_ws + it.o_pool);
     d.pool_cap = it.pool_cap;
@@ -853,7 +854,8 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
 
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
                           const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode,
-                          int32_t max_bs, uint64_t *hdr, uint16_t *pool, uint64_t pool_cap, uint64_t *pool_used) {
+                          int32_t max_bs, int flags, uint64_t *hdr, uint16_t *pool, uint64_t pool_cap,
+                          uint64_t *pool_used) {
   if (!ctx || n < 0 || !mode_ok(mode) || !pool_used) return fail(FGMM_ERR_INVALID, "bad argument");
   if (max_bs < 0 || max_bs > FGMM_MAX_BS) return fail(FGMM_ERR_UNSUPPORTED, "max_bs %d outside [0, %d]", max_bs, FGMM_MAX_BS);
   std::lock_guard<std::mutex> lock(ctx->mu);
@@ -871,6 +873,7 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   hd->hw = n;
   hd->n_ch = 1;
   hd->max_bs = max_bs;
+  hd->prune = (flags & FGMM_TAB_NO_PRUNE) ? 0 : 1;
   hd->hdr = reinterpret_cast<unsigned long long *>(hdr);
   hd->pool = pool;
   hd->pool_cap = pool_cap;
@@ -883,6 +886,21 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipMemcpy(pool_used, used, sizeof(uint64_t), hipMemcpyHostToDevice));
   if (used[1]) return fail(FGMM_ERR_NOMEM, "pool_cap %llu too small", (unsigned long long)pool_cap);
+  return FGMM_OK;
+}
+
+int fgmm_selftest_saturation(fgmm_ctx *ctx, int mode, uint64_t *n_bad_out) {
+  if (!ctx || !mode_ok(mode) || !n_bad_out) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  int rc;
+  if ((rc = ctx->ensure_device(4096))) return rc;
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(ctx->d_ws);
+  HIP_TRY(hipMemsetAsync(d, 0, 8, nullptr));
+  LAUNCH_TRY(launch_saturation_selftest(mode, d, nullptr));
+  unsigned long long bad = 0;
+  HIP_TRY(hipMemcpy(&bad, d, 8, hipMemcpyDeviceToHost));
+  *n_bad_out = bad;
   return FGMM_OK;
 }
 

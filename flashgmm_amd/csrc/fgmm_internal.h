@@ -40,7 +40,7 @@ struct DecDesc {
   int32_t n_ch;
   int32_t max_bs;
   int32_t clamp;
-  int32_t pad_;
+  int32_t prune;                 // 1: skip the saturated tails (exact, see cdftab_kernel); 0: evaluate all of F
   unsigned long long *hdr;       // [n_ch*hw]
   uint16_t *pool;
   unsigned long long pool_cap;   // entries
@@ -72,6 +72,8 @@ int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, 
 int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
                     int64_t stride_n, int64_t stride_k, int mode, float *c1, float *c2, void *stream);
 int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, void *stream);
+// exhaustive check of the saturation lemmas behind the pruning; *n_bad (device) receives the number of violations
+int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream);
 int launch_scatter(const ScatDesc *d_descs, int count, int M_max, int64_t hw_max, void *stream);
 
 // ---- host rANS (fgmm_rans.cpp), integer only --------------------------------------------------------------

@@ -257,11 +257,47 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void cdftab_kernel(cons
   const int max_bs = d.max_bs;
   const int W = 2 * max_bs + 2;
 
+  // ---- evaluation window: skip the part of [-max_bs, max_bs+1] where every component is saturated ---------
+  // Saturation lemmas (fgmm_math.h Sat<MODE>, proved by exhaustive scan: fgmm_selftest_saturation):
+  //   all z_k <= -ZL  =>  F[v] == 0          all z_k >= +ZR  =>  F[v] == quant16((pi0+pi1)+(pi2+pi3))
+  // z_k(v) = ((float)v - 0.5f - mu_k) / sg_k is non-decreasing in v for finite mu and 0 < sg < inf (every IEEE
+  // operation is monotone), so it is enough to VERIFY the condition, with the kernel's own arithmetic, at one v:
+  // it then holds for every v beyond it.  Any latent whose parameters fall outside the lemmas' domain is
+  // evaluated over the full range instead.
+  int j_lo = 0, j_hi = W;
+  uint32_t T_sat = 0;
+  if (d.prune) {
+    bool ok = true;
+    float tl = INFINITY, tr = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ok = ok && (sg[k] > 0.0f) && (sg[k] < INFINITY) && (fabsf(mu[k]) < INFINITY) && Sat<MODE>::weight_ok(pi[k]);
+      tl = fminf(tl, __builtin_fmaf(-Sat<MODE>::ZL, sg[k], mu[k]));
+      tr = fmaxf(tr, __builtin_fmaf(Sat<MODE>::ZR, sg[k], mu[k]));
+    }
+    if (ok) {
+      const float lim = (float)max_bs + 4.0f;
+      // left: largest candidate v with v - 0.5 <= tl, minus one for the rounding of tl itself
+      int vL = (int)fminf(fmaxf(floorf(tl + 0.5f) - 1.0f, -lim), lim);
+      int vR = (int)fminf(fmaxf(ceilf(tr + 0.5f) + 1.0f, -lim), lim);
+      bool okL = true, okR = true;
+      const float xl = (float)vL - 0.5f, xr = (float)vR - 0.5f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        okL = okL && ((xl - mu[k]) / sg[k] <= -Sat<MODE>::ZL);
+        okR = okR && ((xr - mu[k]) / sg[k] >= Sat<MODE>::ZR);
+      }
+      if (okL) j_lo = min(max(vL + max_bs + 1, 0), W); // indices < j_lo are v <= vL: all zero
+      if (okR) j_hi = min(max(vR + max_bs, j_lo), W);  // indices >= j_hi are v >= vR: all T_sat
+      T_sat = quant16((pi[0] + pi[1]) + (pi[2] + pi[3]));
+    }
+  }
+
   // ---- pass 1 -------------------------------------------------------------------------------------
-  int lead = -1, run_start = 0;
+  int lead = j_lo - 1, run_start = 0;
   bool allzero = true, nonmono = false;
   uint32_t prev = 0;
-  for (int j = 0; j < W; ++j) {
+  for (int j = j_lo; j < j_hi; ++j) {
     const float x = (float)(j - max_bs) - 0.5f;
     const uint32_t E = quant16(mix4<MODE>(x, mu, sg, pi));
     if (allzero) {
@@ -270,6 +306,13 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void cdftab_kernel(cons
     if (j == 0 || E != prev) run_start = j;
     nonmono |= (j > 0) && (E < prev);
     prev = E;
+  }
+  if (j_hi < W) { // the saturated right part, one virtual step: F[j_hi .. W-1] == T_sat
+    if (allzero) {
+      if (T_sat == 0) lead = W - 1; else allzero = false;
+    }
+    if (j_hi == 0 || T_sat != prev) run_start = j_hi;
+    nonmono |= (j_hi > 0) && (T_sat < prev);
   }
   int a_idx = lead < 0 ? 0 : lead;
   if (a_idx > run_start) a_idx = run_start;
@@ -312,6 +355,31 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void cdftab_kernel(cons
     *reinterpret_cast<uint2 *>(row + j0) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
   }
   d.hdr[(int64_t)cj * hw + p] = hdr_pack(a_idx - max_bs, (uint32_t)cnt, nonmono ? 1u : 0u, off);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// saturation_selftest_kernel: exhaustive proof-by-enumeration of the lemmas in fgmm_math.h (Sat<MODE>):
+// every binary32 z >= ZR (up to and including +inf) must give phi(z) == 1, every z <= -ZL must give
+// 0 <= phi(z) <= LEFT_MAX.  ~2.1e9 evaluations per mode; a few milliseconds.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE> __global__ __launch_bounds__(kBlock) void saturation_selftest_kernel(unsigned long long *n_bad) {
+  const uint32_t inf_bits = 0x7F800000u;
+  const uint32_t r0 = f2bits(Sat<MODE>::ZR), l0 = f2bits(Sat<MODE>::ZL);
+  const uint64_t nr = (uint64_t)inf_bits - r0 + 1, nl = (uint64_t)inf_bits - l0 + 1;
+  unsigned long long bad = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nr + nl; i += (uint64_t)gridDim.x * kBlock) {
+    if (i < nr) {
+      const float z = bits2f(r0 + (uint32_t)i);
+      bad += !(phi<MODE>(z) == 1.0f);
+    } else {
+      const float z = -bits2f(l0 + (uint32_t)(i - nr));
+      const float v = phi<MODE>(z);
+      bad += !(v >= 0.0f && v <= Sat<MODE>::LEFT_MAX);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(n_bad, bad);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -377,6 +445,17 @@ int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_ma
   case MODE_AS: hipLaunchKernelGGL((cdftab_kernel<MODE_AS>), grid, dim3(kBlock), 0, s, d_descs); break;
   case MODE_LOGISTIC: hipLaunchKernelGGL((cdftab_kernel<MODE_LOGISTIC>), grid, dim3(kBlock), 0, s, d_descs); break;
   default: hipLaunchKernelGGL((cdftab_kernel<MODE_POLYA>), grid, dim3(kBlock), 0, s, d_descs); break;
+  }
+  return launch_err();
+}
+
+int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream) {
+  dim3 grid(256 * 16);
+  hipStream_t s = (hipStream_t)stream;
+  switch (mode) {
+  case MODE_AS: hipLaunchKernelGGL((saturation_selftest_kernel<MODE_AS>), grid, dim3(kBlock), 0, s, n_bad); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((saturation_selftest_kernel<MODE_LOGISTIC>), grid, dim3(kBlock), 0, s, n_bad); break;
+  default: hipLaunchKernelGGL((saturation_selftest_kernel<MODE_POLYA>), grid, dim3(kBlock), 0, s, n_bad); break;
   }
   return launch_err();
 }

@@ -99,4 +99,30 @@ __device__ __forceinline__ float clamp_scale(float s) {
   return s;
 }
 
+// Saturation thresholds of the three Phi sequences above, used to prune the decode-side table evaluation.
+// For every binary32 z (exhaustively scanned on the GPU by fgmm_selftest_saturation, tests/test_gpu_parity.py):
+//   z <= -ZL  =>  phi(z) == +0.0f exactly           (logistic: phi(z) <= 2^-20)
+//   z >= +ZR  =>  phi(z) == 1.0f exactly
+// Measured last non-saturated |z| (CPU scan of the oracle): Polya 5.2172623 / 4.969077, A&S 5.4203954 both,
+// logistic 8.145089 (2^-20 bound) / 9.774107.
+// weight_ok: what a mixture weight must satisfy for the lemma to give F == 0 / F == quant16(sum pi):
+//   exact 0/1 saturation only needs finite weights; the logistic left tail is a bound, so it needs 0 <= pi <= 1
+//   (then cdf*65535 <= 4 * 2^-20 * 65535 * (1 + eps) < 1).
+template <int MODE> struct Sat;
+template <> struct Sat<MODE_POLYA> {
+  static constexpr float ZL = 5.25f, ZR = 5.0f;
+  static constexpr float LEFT_MAX = 0.0f;
+  __device__ static __forceinline__ bool weight_ok(float w) { return fabsf(w) < INFINITY; }
+};
+template <> struct Sat<MODE_AS> {
+  static constexpr float ZL = 5.45f, ZR = 5.45f;
+  static constexpr float LEFT_MAX = 0.0f;
+  __device__ static __forceinline__ bool weight_ok(float w) { return fabsf(w) < INFINITY; }
+};
+template <> struct Sat<MODE_LOGISTIC> {
+  static constexpr float ZL = 8.2f, ZR = 9.8f;
+  static constexpr float LEFT_MAX = 9.5367431640625e-07f; // 2^-20
+  __device__ static __forceinline__ bool weight_ok(float w) { return w >= 0.0f && w <= 1.0f; }
+};
+
 } // namespace fgmm

@@ -164,15 +164,22 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
 
 /* GPU: decode-side edge tables.  For latent i the reference's bisection can only ever look at
  *   F_i[v] = (uint16)(cdf_i(v - 0.5) * 65535),  v in [-max_bs, max_bs + 1]      (rans_interface.cpp:826-862).
- * The kernel evaluates all of F_i and stores the window outside which it is constant:
+ * The kernel finds, exactly, the window outside which F_i is constant (evaluating F_i everywhere except where
+ * every mixture component is provably saturated — fgmm_selftest_saturation) and stores it:
  *   hdr[i]  = { int16 a; uint16 cnt | nonmono << 15; uint32 off }   (8 bytes)
  *   pool[off .. off+cnt) = F_i[a .. a+cnt),   F_i[v < a] = 0,  F_i[v >= a+cnt] = pool[off+cnt-1]
  * rows are padded to a multiple of 4 entries with their last value.  `nonmono` is set when the stored row
  * decreases somewhere.  hdr: device uint64[n]; pool: device uint16[pool_cap]; pool_used: device uint64[1],
  * zeroed by the call.  pool_cap >= n * (2*max_bs + 5) always suffices. */
+#define FGMM_TAB_NO_PRUNE 1 /* flags: evaluate all of F_i instead of skipping its saturated tails (A/B testing) */
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
                           const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode,
-                          int32_t max_bs, uint64_t *hdr, uint16_t *pool, uint64_t pool_cap, uint64_t *pool_used);
+                          int32_t max_bs, int flags, uint64_t *hdr, uint16_t *pool, uint64_t pool_cap,
+                          uint64_t *pool_used);
+
+/* GPU self-test: exhaustive scan (every binary32 beyond the thresholds) of the saturation lemmas that let the
+ * table kernel skip the tails of F_i.  *n_bad_out = number of violating inputs (must be 0). */
+int fgmm_selftest_saturation(fgmm_ctx *ctx, int mode, uint64_t *n_bad_out);
 
 /* Host, integer only: symbol table (+ raw symbols, needed only where range == 0 and abs(symbol) >= 32768)
  * -> bitstream.  BufferedRansEncoder::flush semantics (rans_interface.cpp:557-585). */

@@ -58,7 +58,7 @@ def gpu_symtab(mode, v, s, m, w):
     return out.cpu().numpy().view(np.uint32)
 
 
-def gpu_cdftab(mode, s, m, w, max_bs):
+def gpu_cdftab(mode, s, m, w, max_bs, flags=0):
     L, ctx = _lib.lib(), _lib.ctx(0)
     s, m, w = dv(s), dv(m), dv(w)
     n = s.size(0)
@@ -68,7 +68,8 @@ def gpu_cdftab(mode, s, m, w, max_bs):
     used = torch.zeros(2, dtype=torch.int64, device=DEV)
     torch.cuda.synchronize()
     _lib.check(L.fgmm_build_cdftab_hip(ctx, None, s.data_ptr(), m.data_ptr(), w.data_ptr(), n, s.stride(0), s.stride(1),
-                                       _lib.mode_id(mode), max_bs, hdr.data_ptr(), pool.data_ptr(), cap, used.data_ptr()))
+                                       _lib.mode_id(mode), max_bs, flags, hdr.data_ptr(), pool.data_ptr(), cap,
+                                       used.data_ptr()))
     return hdr.cpu().numpy().view(np.uint64), pool.cpu().numpy().view(np.uint16), int(used[0].item())
 
 
@@ -246,6 +247,40 @@ def test_cdftab_equals_oracle_full_table(oracle, mode):
     piw = rng.uniform(0, 0.6, (n, 4)).astype(np.float32)
     hdr, pool, used = gpu_cdftab(mode, sgw, muw, piw, 37)
     assert np.array_equal(expand_trimmed(hdr, pool, 37), oracle.cdftab(mode, sgw, muw, piw, 37))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_saturation_lemmas_exhaustive(mode):
+    """every binary32 beyond the pruning thresholds saturates as fgmm_math.h claims (2e9 values per mode)"""
+    bad = C.c_uint64(123)
+    _lib.check(_lib.lib().fgmm_selftest_saturation(_lib.ctx(0), _lib.mode_id(mode), C.byref(bad)))
+    assert bad.value == 0
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_cdftab_pruned_equals_unpruned(oracle, mode):
+    """wide half-widths, tiny and huge sigma, far-off means, weights outside [0,1], NaN/inf/zero sigma: the pruned
+    kernel must reproduce the full evaluation exactly (and both the oracle where the oracle is affordable)."""
+    rng = np.random.default_rng(77)
+    n = 20000
+    sg = np.exp(rng.uniform(-4, 6, (n, 4))).astype(np.float32)
+    mu = (rng.standard_normal((n, 4)) * np.exp(rng.uniform(-2, 7, (n, 1)))).astype(np.float32)
+    pi = rng.dirichlet(np.ones(4), n).astype(np.float32)
+    pi[::7] = rng.uniform(-0.5, 1.5, (len(pi[::7]), 4)).astype(np.float32)
+    sg[5::101, 1] = 0.0
+    sg[6::101, 2] = np.inf
+    sg[7::101, 0] = np.nan
+    sg[8::101, 3] = -1.0
+    mu[9::101, 0] = np.inf
+    pi[10::101, 2] = np.nan
+    for max_bs in (0, 1, 40, 700):
+        h0, p0, u0 = gpu_cdftab(mode, sg, mu, pi, max_bs, flags=1)
+        h1, p1, u1 = gpu_cdftab(mode, sg, mu, pi, max_bs, flags=0)
+        f0, f1 = expand_trimmed(h0, p0, max_bs), expand_trimmed(h1, p1, max_bs)
+        assert np.array_equal(f0, f1), max_bs
+        assert np.array_equal((h0 >> np.uint64(16)) & np.uint64(0xFFFF), (h1 >> np.uint64(16)) & np.uint64(0xFFFF))
+        if max_bs <= 40:
+            assert np.array_equal(f1, oracle.cdftab(mode, sg, mu, pi, max_bs)), max_bs
 
 
 @pytest.mark.parametrize("mode", MODES)
