@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -53,6 +54,26 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// FGMM_TRACE=1: phase timestamps of every batched call on stderr (development aid)
+struct Trace {
+  bool on;
+  std::chrono::steady_clock::time_point t0, last;
+  const char *what;
+  explicit Trace(const char *w) : what(w) {
+    static const bool enabled = getenv("FGMM_TRACE") && atoi(getenv("FGMM_TRACE")) > 0;
+    on = enabled;
+    if (on) t0 = last = std::chrono::steady_clock::now();
+  }
+  void mark(const char *phase) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[fgmm %s] %-28s +%8.3f ms  (t=%8.3f)\n", what, phase,
+            std::chrono::duration<double, std::milli>(now - last).count(),
+            std::chrono::duration<double, std::milli>(now - t0).count());
+    last = now;
+  }
+};
 
 // ---- host worker pool ----------------------------------------------------------------------------------
 class Pool {
@@ -108,6 +129,12 @@ private:
   bool stop_ = false;
 };
 
+// waits for every submitted job before the enclosing scope is left (jobs reference locals of that scope)
+struct PoolDrain {
+  Pool *p;
+  ~PoolDrain() { p->wait_all(); }
+};
+
 // bump allocator over one device buffer + one pinned host buffer with identical offsets
 struct Arena {
   size_t off = 0;
@@ -130,6 +157,38 @@ struct fgmm_ctx {
   char *h_ws = nullptr; // pinned
   size_t h_cap = 0;
   std::vector<hipEvent_t> events;
+  hipStream_t copy_stream = nullptr; // bulk D2H of the decode tables (overlaps the table kernels of later groups)
+  hipStream_t aux_stream = nullptr;  // the few bytes of per-group pool counters
+  // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while
+  // copies are in flight (sizes are only known group by group)
+  struct Chunk {
+    char *p;
+    size_t cap, used;
+  };
+  std::vector<Chunk> chunks;
+  void chunks_reset() {
+    for (auto &c : chunks) c.used = 0;
+  }
+  int chunk_alloc(size_t bytes, char **out) {
+    bytes = align_up(bytes, 256);
+    for (auto &c : chunks)
+      if (c.cap - c.used >= bytes) {
+        *out = c.p + c.used;
+        c.used += bytes;
+        return FGMM_OK;
+      }
+    Chunk c{nullptr, std::max(bytes, (size_t)256 << 20), 0};
+    HIP_TRY(hipHostMalloc((void **)&c.p, c.cap, hipHostMallocDefault));
+    c.used = bytes;
+    chunks.push_back(c);
+    *out = c.p;
+    return FGMM_OK;
+  }
+  int ensure_streams() {
+    if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    if (!aux_stream) HIP_TRY(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+    return FGMM_OK;
+  }
   bool profiling = false;
   hipEvent_t prof[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool prof_valid[3] = {false, false, false};
@@ -227,6 +286,7 @@ struct EncItem {
 int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items, int mode) {
   const int count = (int)items.size();
   if (count == 0) return FGMM_OK;
+  Trace tr("encode");
   // ---- plan the workspace: [descs][small: per item min|max|nz|meta][tables: per item packed] -------
   Arena ar;
   const size_t o_descs = ar.take(sizeof(EncDesc) * count);
@@ -289,16 +349,25 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   // ---- tables back to the host: small region first, then one copy + event per item ----------------
   HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_small, ctx->d_ws + o_small, small_bytes, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipEventRecord(ctx->events[count], stream));
-  for (int i = 0; i < count; ++i) {
-    const EncItem &it = items[i];
-    const size_t bytes = sizeof(uint32_t) * (size_t)it.M * (size_t)it.hw;
-    if (bytes) HIP_TRY(hipMemcpyAsync(ctx->h_ws + it.o_packed, ctx->d_ws + it.o_packed, bytes, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(ctx->events[i], stream));
+  // the per-item tables are contiguous in the workspace: a handful of large copies instead of one per item
+  const int group_size = count >= 16 ? std::max(2, count / 6) : 1;
+  std::vector<int> group_of(count);
+  int n_groups = 0;
+  for (int i0 = 0; i0 < count; i0 += group_size, ++n_groups) {
+    const int i1 = std::min(count, i0 + group_size);
+    const size_t beg = items[i0].o_packed;
+    const size_t end = items[i1 - 1].o_packed + sizeof(uint32_t) * (size_t)items[i1 - 1].M * (size_t)items[i1 - 1].hw;
+    if (end > beg) HIP_TRY(hipMemcpyAsync(ctx->h_ws + beg, ctx->d_ws + beg, end - beg, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(ctx->events[n_groups], stream));
+    for (int i = i0; i < i1; ++i) group_of[i] = n_groups;
   }
+  tr.mark("enqueued");
   HIP_TRY(hipEventSynchronize(ctx->events[count]));
+  tr.mark("kernels + meta landed");
 
   // ---- host side: per item side information, then one rANS job per item -----------------------------
   std::vector<std::vector<int32_t>> wide_syms(count); // only for bypass symbols beyond int16 (rare)
+  PoolDrain drain{ctx->pool};
   for (int i = 0; i < count; ++i) {
     EncItem &it = items[i];
     int64_t n = (int64_t)it.M * it.hw;
@@ -342,7 +411,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
       HIP_TRY(hipMemcpy(wide_syms[i].data(), it.sym_dev, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
       syms_for_bypass = wide_syms[i].data();
     }
-    HIP_TRY(hipEventSynchronize(ctx->events[i]));
+    HIP_TRY(hipEventSynchronize(ctx->events[group_of[i]]));
     const uint32_t *packed = reinterpret_cast<const uint32_t *>(ctx->h_ws + it.o_packed);
     EncItem *pit = &it;
     auto job = [pit, packed, syms_for_bypass, n, n_bypass] {
@@ -350,7 +419,9 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     };
     if (count == 1) job(); else ctx->pool->submit(job);
   }
+  tr.mark("all tables landed, jobs out");
   if (count > 1) ctx->pool->wait_all();
+  tr.mark("host rANS done");
   for (auto &it : items)
     if (it.status) return fail(it.status, "host rANS encode failed (%d)", it.status);
   return FGMM_OK;
@@ -375,33 +446,42 @@ struct DecItem {
   // derived
   int32_t n_ch = 0;
   int64_t n = 0;
-  size_t o_list = 0, o_rank = 0, o_hdr = 0, o_pool = 0, o_used = 0, o_sym = 0;
-  size_t ho_hdr = 0, ho_pool = 0, ho_sym = 0;
+  size_t o_list = 0, o_hdr = 0, o_pool = 0, o_used = 0;
+  char *h_hdr = nullptr, *h_pool = nullptr, *h_out = nullptr; // pinned
   uint64_t pool_cap = 0, pool_used = 0;
+  std::atomic<int> done{0};
+  DecItem() = default;
+  DecItem(const DecItem &) = delete;
 };
 
+// Decode, batched and pipelined.  Items are cut into groups; per group one cdftab launch on the caller's stream.
+//   caller stream : [H2D descs][memset counters][cdftab g0][cdftab g1] ... later [H2D y_hat item by item]
+//   aux stream    : after cdftab g -> D2H of group g's pool counters (sizes of the variable-length tables)
+//   copy stream   : per item of a group whose counters have landed: D2H hdr, D2H pool, event
+//   host workers  : item i starts when its event fires; writes y_hat (zero channels restored) into pinned memory
+// so the PCIe transfer of the tables — the longest leg — overlaps both the table kernels of later groups and
+// the host coding of earlier items.
 int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items, int mode) {
   const int count = (int)items.size();
   if (count == 0) return FGMM_OK;
-  Arena ar;
-  // device: [descs | scat descs | chan lists & ranks] (mirrored on the host for one H2D) [used counters] then big buffers
+  Trace tr("decode");
+  int rc;
+  if ((rc = ctx->ensure_streams())) return rc;
+  const int group_size = count >= 16 ? std::max(2, count / 8) : count;
+  const int n_groups = (count + group_size - 1) / group_size;
+
+  Arena ar; // device workspace; the part before the counters is mirrored in h_ws and uploaded in one copy
   const size_t o_descs = ar.take(sizeof(DecDesc) * count);
-  const size_t o_sdescs = ar.take(sizeof(ScatDesc) * count);
-  int n_ch_max = 0, M_max = 0;
-  int64_t hw_max = 0;
   for (auto &it : items) {
-    if (it.max_bs < 0 || it.max_bs > FGMM_MAX_BS) return fail(FGMM_ERR_UNSUPPORTED, "max_bs_value %d outside [0, %d]", it.max_bs, FGMM_MAX_BS);
+    if (it.max_bs < 0 || it.max_bs > FGMM_MAX_BS)
+      return fail(FGMM_ERR_UNSUPPORTED, "max_bs_value %d outside [0, %d]", it.max_bs, FGMM_MAX_BS);
     it.n_ch = 0;
     for (int c = 0; c < it.M; ++c) it.n_ch += it.zero_bitmap ? (it.zero_bitmap[c] != 0) : 1;
     it.n = (int64_t)it.n_ch * it.hw;
     it.o_list = ar.take(sizeof(int32_t) * std::max(it.n_ch, 1), 16);
-    it.o_rank = ar.take(sizeof(int32_t) * std::max(it.M, 1), 16);
-    n_ch_max = std::max(n_ch_max, it.n_ch);
-    M_max = std::max(M_max, it.M);
-    hw_max = std::max(hw_max, it.hw);
   }
   const size_t o_used = ar.take(16 * (size_t)count, 256);
-  const size_t upload_bytes = o_used; // everything before the counters is uploaded
+  const size_t upload_bytes = o_used;
   for (int i = 0; i < count; ++i) items[i].o_used = o_used + 16 * (size_t)i;
   const size_t host_fixed = ar.off;
   for (auto &it : items) {
@@ -409,23 +489,21 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.pool_cap = (uint64_t)it.n * rowcap;
     it.o_hdr = ar.take(sizeof(uint64_t) * (size_t)it.n + 64);
     it.o_pool = ar.take(sizeof(uint16_t) * it.pool_cap + 64);
-    it.o_sym = ar.take(sizeof(int32_t) * (size_t)it.n + 64);
   }
-  int rc;
-  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(host_fixed)) || (rc = ctx->ensure_events(count + 1))) return rc;
+  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(host_fixed)) ||
+      (rc = ctx->ensure_events((size_t)count + 2 * (size_t)n_groups)))
+    return rc;
+  ctx->chunks_reset();
+  hipEvent_t *ev_item = ctx->events.data();
+  hipEvent_t *ev_kernel = ev_item + count, *ev_counters = ev_kernel + n_groups;
 
   DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_descs);
-  ScatDesc *hs = reinterpret_cast<ScatDesc *>(ctx->h_ws + o_sdescs);
   for (int i = 0; i < count; ++i) {
     DecItem &it = items[i];
     int32_t *list = reinterpret_cast<int32_t *>(ctx->h_ws + it.o_list);
-    int32_t *rank = reinterpret_cast<int32_t *>(ctx->h_ws + it.o_rank);
     int r = 0;
-    for (int c = 0; c < it.M; ++c) {
-      const bool nzc = it.zero_bitmap ? (it.zero_bitmap[c] != 0) : true;
-      rank[c] = nzc ? r : -1;
-      if (nzc) list[r++] = c;
-    }
+    for (int c = 0; c < it.M; ++c)
+      if (!it.zero_bitmap || it.zero_bitmap[c] != 0) list[r++] = c;
     DecDesc &d = hd[i];
     memset(&d, 0, sizeof d);
     d.scales = it.prm.scales;
@@ -444,79 +522,110 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.pool = reinterpret_cast<uint16_t *>(ctx->d_ws + it.o_pool);
     d.pool_cap = it.pool_cap;
     d.pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_used);
-    ScatDesc &s = hs[i];
-    memset(&s, 0, sizeof s);
-    s.sym = reinterpret_cast<const int32_t *>(ctx->d_ws + it.o_sym);
-    s.chan_rank = reinterpret_cast<const int32_t *>(ctx->d_ws + it.o_rank);
-    s.y_hat = it.y_hat;
-    s.hw = it.hw;
-    s.M = it.M;
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + o_used, 0, 16 * (size_t)count, stream));
   if ((rc = ctx->prof_begin(1, stream))) return rc;
-  LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs), count, n_ch_max, hw_max, mode, stream));
-  if ((rc = ctx->prof_end(1, stream))) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_used, ctx->d_ws + o_used, 16 * (size_t)count, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-
-  // ---- now the pool sizes are known: lay out the pinned receive area -------------------------------
-  Arena har;
-  har.off = host_fixed;
-  for (int i = 0; i < count; ++i) {
-    DecItem &it = items[i];
-    const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
-    if (u[1]) return fail(FGMM_ERR_HIP, "edge-table pool overflow on item %d (internal sizing error)", i);
-    it.pool_used = u[0];
-    it.ho_hdr = har.take(sizeof(uint64_t) * (size_t)it.n + 64);
-    it.ho_pool = har.take(sizeof(uint16_t) * it.pool_used + 128);
-    it.ho_sym = har.take(sizeof(int32_t) * (size_t)it.n + 64);
-  }
-  {
-    // growing the pinned buffer would invalidate what was just read; everything needed is already in `items`
-    std::vector<char> keep(ctx->h_ws, ctx->h_ws + host_fixed);
-    if ((rc = ctx->ensure_host(har.off))) return rc;
-    memcpy(ctx->h_ws, keep.data(), host_fixed);
-  }
-  for (int i = 0; i < count; ++i) {
-    DecItem &it = items[i];
-    if (it.n) {
-      HIP_TRY(hipMemcpyAsync(ctx->h_ws + it.ho_hdr, ctx->d_ws + it.o_hdr, sizeof(uint64_t) * (size_t)it.n, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipMemcpyAsync(ctx->h_ws + it.ho_pool, ctx->d_ws + it.o_pool, sizeof(uint16_t) * it.pool_used, hipMemcpyDeviceToHost, stream));
+  for (int g = 0; g < n_groups; ++g) {
+    const int i0 = g * group_size, i1 = std::min(count, i0 + group_size);
+    int n_ch_max = 0;
+    int64_t hw_max = 0;
+    for (int i = i0; i < i1; ++i) {
+      n_ch_max = std::max(n_ch_max, items[i].n_ch);
+      hw_max = std::max(hw_max, items[i].hw);
     }
-    HIP_TRY(hipEventRecord(ctx->events[i], stream));
+    LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs) + i0, i1 - i0, n_ch_max, hw_max, mode, stream));
+    HIP_TRY(hipEventRecord(ev_kernel[g], stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_kernel[g], 0));
+    HIP_TRY(hipMemcpyAsync(ctx->h_ws + items[i0].o_used, ctx->d_ws + items[i0].o_used, 16 * (size_t)(i1 - i0),
+                           hipMemcpyDeviceToHost, ctx->aux_stream));
+    HIP_TRY(hipEventRecord(ev_counters[g], ctx->aux_stream));
   }
+  if ((rc = ctx->prof_end(1, stream))) return rc; // brackets all groups' launches
+  tr.mark("enqueued");
+
+  // ---- as each group's sizes arrive, queue its table copies --------------------------------------------
+  for (int g = 0; g < n_groups; ++g) {
+    const int i0 = g * group_size, i1 = std::min(count, i0 + group_size);
+    HIP_TRY(hipEventSynchronize(ev_counters[g]));
+    for (int i = i0; i < i1; ++i) {
+      DecItem &it = items[i];
+      const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
+      if (u[1]) return fail(FGMM_ERR_HIP, "edge-table pool overflow on item %d (internal sizing error)", i);
+      it.pool_used = u[0];
+      const size_t out_bytes = it.y_hat ? sizeof(float) * (size_t)it.M * (size_t)it.hw : sizeof(int32_t) * (size_t)it.n;
+      if ((rc = ctx->chunk_alloc(sizeof(uint64_t) * (size_t)it.n + 64, &it.h_hdr)) ||
+          (rc = ctx->chunk_alloc(sizeof(uint16_t) * it.pool_used + 128, &it.h_pool)) ||
+          (rc = ctx->chunk_alloc(out_bytes + 64, &it.h_out)))
+        return rc;
+      if (it.n) {
+        HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, sizeof(uint64_t) * (size_t)it.n, hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIP_TRY(hipMemcpyAsync(it.h_pool, ctx->d_ws + it.o_pool, sizeof(uint16_t) * it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
+      }
+      HIP_TRY(hipEventRecord(ev_item[i], ctx->copy_stream));
+    }
+  }
+  tr.mark("table kernels done, copies queued");
+
+  // ---- one host rANS job per item, started as its tables land ------------------------------------------
+  std::mutex done_mu;
+  std::condition_variable done_cv;
+  PoolDrain drain{ctx->pool}; // declared after the objects the jobs reference: destroyed (= drained) before them
+  const char *h_ws = ctx->h_ws;
   for (int i = 0; i < count; ++i) {
     DecItem *pit = &items[i];
-    HIP_TRY(hipEventSynchronize(ctx->events[i]));
-    char *hws = ctx->h_ws;
-    auto job = [pit, hws] {
-      int32_t *out = reinterpret_cast<int32_t *>(hws + pit->ho_sym);
-      memset(hws + pit->ho_pool + sizeof(uint16_t) * pit->pool_used, 0, 64); // defined bytes for the SIMD over-read
-      pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, reinterpret_cast<const uint64_t *>(hws + pit->ho_hdr),
-                                       reinterpret_cast<const uint16_t *>(hws + pit->ho_pool), pit->n, pit->max_bs, out);
-      if (pit->status == FGMM_OK && pit->sym_host_out) memcpy(pit->sym_host_out, out, sizeof(int32_t) * (size_t)pit->n);
+    HIP_TRY(hipEventSynchronize(ev_item[i]));
+    const int32_t *list = reinterpret_cast<const int32_t *>(h_ws + pit->o_list);
+    auto job = [pit, list, &done_mu, &done_cv] {
+      memset(pit->h_pool + sizeof(uint16_t) * pit->pool_used, 0, 64); // defined bytes for the SIMD over-read
+      int32_t *sym = pit->y_hat ? (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(pit->n, 1))
+                                : reinterpret_cast<int32_t *>(pit->h_out);
+      if (!sym) {
+        pit->status = FGMM_ERR_NOMEM;
+      } else {
+        pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, reinterpret_cast<const uint64_t *>(pit->h_hdr),
+                                         reinterpret_cast<const uint16_t *>(pit->h_pool), pit->n, pit->max_bs, sym);
+        if (pit->status == FGMM_OK && pit->y_hat) {
+          // y_hat[:, nonzero] = symbols.float(), zeros elsewhere   (entropy_models.py:903-908)
+          float *yh = reinterpret_cast<float *>(pit->h_out);
+          memset(yh, 0, sizeof(float) * (size_t)pit->M * (size_t)pit->hw);
+          for (int r = 0; r < pit->n_ch; ++r) {
+            float *dst = yh + (size_t)list[r] * pit->hw;
+            const int32_t *src = sym + (size_t)r * pit->hw;
+            for (int64_t p = 0; p < pit->hw; ++p) dst[p] = (float)src[p];
+          }
+        } else if (pit->status == FGMM_OK && pit->sym_host_out) {
+          memcpy(pit->sym_host_out, sym, sizeof(int32_t) * (size_t)pit->n);
+        }
+        if (pit->y_hat) free(sym);
+      }
+      {
+        std::lock_guard<std::mutex> l(done_mu);
+        pit->done.store(1);
+      }
+      done_cv.notify_all();
     };
     if (count == 1) job(); else ctx->pool->submit(job);
   }
-  if (count > 1) ctx->pool->wait_all();
-  for (auto &it : items)
-    if (it.status) return fail(it.status, "host rANS decode failed (%d)%s", it.status, it.status == FGMM_ERR_STREAM ? ": bitstream too short" : "");
+  tr.mark("all tables landed, jobs out");
 
-  // ---- symbols back to the GPU and into y_hat --------------------------------------------------------
-  bool any_scatter = false;
-  for (auto &it : items) {
-    if (!it.y_hat) continue;
-    any_scatter = true;
-    if (it.n) HIP_TRY(hipMemcpyAsync(ctx->d_ws + it.o_sym, ctx->h_ws + it.ho_sym, sizeof(int32_t) * (size_t)it.n, hipMemcpyHostToDevice, stream));
+  // ---- y_hat back to the GPU item by item, on the caller's stream ----------------------------------------
+  int first_err = FGMM_OK;
+  for (int i = 0; i < count; ++i) {
+    DecItem &it = items[i];
+    {
+      std::unique_lock<std::mutex> l(done_mu);
+      done_cv.wait(l, [&it] { return it.done.load() != 0; });
+    }
+    if (it.status && !first_err) first_err = it.status;
+    if (it.status == FGMM_OK && it.y_hat && it.M * it.hw)
+      HIP_TRY(hipMemcpyAsync(it.y_hat, it.h_out, sizeof(float) * (size_t)it.M * (size_t)it.hw, hipMemcpyHostToDevice, stream));
   }
-  if (any_scatter) {
-    bool all = true;
-    for (auto &it : items) all = all && it.y_hat;
-    if (!all) return fail(FGMM_ERR_INVALID, "mixed y_hat / symbol outputs in one batch");
-    LAUNCH_TRY(launch_scatter(reinterpret_cast<const ScatDesc *>(ctx->d_ws + o_sdescs), count, M_max, hw_max, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-  }
+  tr.mark("host rANS done");
+  HIP_TRY(hipStreamSynchronize(stream));
+  tr.mark("y_hat uploaded");
+  if (first_err)
+    return fail(first_err, "host rANS decode failed (%d)%s", first_err, first_err == FGMM_ERR_STREAM ? ": bitstream too short" : "");
   return FGMM_OK;
 }
 
@@ -570,6 +679,9 @@ void fgmm_ctx_destroy(fgmm_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_ws) (void)hipHostFree(ctx->h_ws);
+    for (auto &c : ctx->chunks) (void)hipHostFree(c.p);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   }
   delete ctx;
 }

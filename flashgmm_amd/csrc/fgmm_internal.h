@@ -47,15 +47,6 @@ struct DecDesc {
   unsigned long long *pool_used; // [0] entries used, [1] overflow flag
 };
 
-struct ScatDesc {
-  const int32_t *sym;       // device [n_ch*hw] decoded symbols, compact channel order
-  const int32_t *chan_rank; // device [M]: compact index of channel c, or -1 (all-zero channel)
-  float *y_hat;             // device [M*hw]
-  int64_t hw;
-  int32_t M;
-  int32_t pad_;
-};
-
 // edge-table header (8 bytes): int16 a | (uint16 cnt | nonmono<<15) << 16 | (uint32 off/4) << 32
 FGMM_HD static inline uint64_t hdr_pack(int32_t a, uint32_t cnt, uint32_t nonmono, uint64_t off_entries) {
   return (uint64_t)(uint16_t)(int16_t)a | ((uint64_t)((cnt & 0x7FFFu) | (nonmono << 15)) << 16) |
@@ -74,7 +65,6 @@ int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, c
 int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, void *stream);
 // exhaustive check of the saturation lemmas behind the pruning; *n_bad (device) receives the number of violations
 int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream);
-int launch_scatter(const ScatDesc *d_descs, int count, int M_max, int64_t hw_max, void *stream);
 
 // ---- host rANS (fgmm_rans.cpp), integer only --------------------------------------------------------------
 // returns 0 or an fgmm_status; *out malloc'ed

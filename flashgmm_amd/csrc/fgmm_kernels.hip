@@ -4,7 +4,6 @@
 //   symtab_kernel        (y | symbols, sigma, mu, pi) -> packed start|range<<16         (rans_interface.cpp:487-517)
 //   cdf_pair_kernel      float CDF pair probe                                           (rans_interface.cpp:250-292)
 //   cdftab_kernel        (sigma, mu, pi, max_bs) -> trimmed per-latent edge tables      (rans_interface.cpp:826-862)
-//   scatter_kernel       decoded symbols -> y_hat with zero channels restored           (entropy_models.py:903-908)
 //
 // All kernels are batched over `count` independent bitstreams (blockIdx.z = item) through a device array of
 // descriptors, because one Kodak-sized half (<= 147 456 latents) is far too small to fill 256 CUs on its own.
@@ -383,19 +382,6 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void saturation_selftes
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// scatter_kernel: y_hat[:, nonzero] = symbols.float(), zeros elsewhere (entropy_models.py:903-908)
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void scatter_kernel(const ScatDesc *__restrict__ descs) {
-  const ScatDesc &d = descs[blockIdx.z];
-  const int c = blockIdx.y;
-  if (c >= d.M) return;
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= d.hw) return;
-  const int r = d.chan_rank[c];
-  d.y_hat[(int64_t)c * d.hw + p] = r < 0 ? 0.0f : (float)d.sym[(int64_t)r * d.hw + p];
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 static inline int launch_err() { return (int)hipGetLastError(); }
@@ -457,13 +443,6 @@ int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream
   case MODE_LOGISTIC: hipLaunchKernelGGL((saturation_selftest_kernel<MODE_LOGISTIC>), grid, dim3(kBlock), 0, s, n_bad); break;
   default: hipLaunchKernelGGL((saturation_selftest_kernel<MODE_POLYA>), grid, dim3(kBlock), 0, s, n_bad); break;
   }
-  return launch_err();
-}
-
-int launch_scatter(const ScatDesc *d_descs, int count, int M_max, int64_t hw_max, void *stream) {
-  if (count <= 0 || M_max <= 0 || hw_max <= 0) return 0;
-  dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)M_max, (unsigned)count);
-  hipLaunchKernelGGL(scatter_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, d_descs);
   return launch_err();
 }
 
