@@ -146,8 +146,8 @@ def main():
     ws = [t[3] for t in devt]
     gmc = GaussianMixtureConditional(K=4, mode=a.mode)
     _lib.set_profiling(local_rank, True)
-    lens_dev = torch.zeros(len(ys), dtype=torch.int64, device=dev)
-    gathered = [torch.zeros_like(lens_dev) for _ in range(world)] if world > 1 else None
+    from flashgmm_amd import parallel as P
+
     k_sym, k_tab, k_qs = [], [], []
 
     def step(record=False):
@@ -155,9 +155,8 @@ def main():
         if record:
             k_sym.append(_lib.kernel_ms(local_rank, 0))
             k_qs.append(_lib.kernel_ms(local_rank, 2))
-        if world > 1:  # the path's one exchange: per-stream bitstream lengths
-            lens_dev.copy_(torch.tensor([len(r[0][0]) for r in res], dtype=torch.int64))
-            dist.all_gather(gathered, lens_dev)
+        if world > 1:  # the path's one exchange: per-stream bitstream lengths, RCCL all-gather
+            P.all_gather_stream_lengths([len(r[0][0]) for r in res], len(res), device=dev)
         outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
         if record:
             k_tab.append(_lib.kernel_ms(local_rank, 1))

@@ -1,0 +1,55 @@
+"""Multi-GPU sharding of the path: independent units, one exchange.
+
+Images (and, on encode, checkerboard halves) are independent bitstreams, so they are dealt to ranks round-robin and
+coded with no data-path collective.  The one exchange is an all-gather of the per-stream byte lengths
+(``int64[streams_per_rank]`` per rank — tens of bytes; latency-bound, so xGMI link bandwidth is irrelevant), from
+which every rank derives the same stream index / byte offsets of the assembled container.  Backend "nccl" is RCCL
+on ROCm; "gloo" runs the same code on CPU tensors (tests/test_parallel_cpu.py, world_size 2).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["shard_units", "owner_of", "all_gather_stream_lengths", "container_index"]
+
+
+def shard_units(n_units: int, rank: int, world: int) -> List[int]:
+    """unit i -> rank i mod world  (image i -> GPU i mod G)."""
+    return list(range(rank, n_units, world))
+
+
+def owner_of(unit: int, world: int) -> int:
+    return unit % world
+
+
+def all_gather_stream_lengths(local_lengths: Sequence[int], streams_per_rank: int, device=None, group=None) -> torch.Tensor:
+    """-> int64 [world, streams_per_rank]; ranks with fewer streams pad with -1."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    buf = torch.full((streams_per_rank,), -1, dtype=torch.int64)
+    buf[: len(local_lengths)] = torch.tensor(list(local_lengths), dtype=torch.int64)
+    if device is not None:
+        buf = buf.to(device)
+    if world == 1:
+        return buf.unsqueeze(0)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return torch.stack(out)
+
+
+def container_index(lengths: torch.Tensor, n_units: int, streams_per_unit: int) -> List[Tuple[int, int, int, int]]:
+    """From the gathered [world, streams_per_rank] lengths: (unit, stream, byte offset, byte length) in unit order —
+    identical on every rank, so any rank can place its payloads without further communication."""
+    world = lengths.size(0)
+    L = lengths.cpu().tolist()
+    out, off = [], 0
+    for u in range(n_units):
+        r, j = u % world, u // world
+        for s in range(streams_per_unit):
+            ln = L[r][j * streams_per_unit + s]
+            assert ln >= 0, f"unit {u} stream {s}: length missing"
+            out.append((u, s, off, ln))
+            off += ln
+    return out
