@@ -60,6 +60,7 @@ SIGNATURES = {
     "fgmm_build_symtab_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "fgmm_build_cdftab_hip": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i32, _i, _p, _p, C.c_uint64, _p]),
     "fgmm_selftest_saturation": (_i, [_p, _i, C.POINTER(C.c_uint64)]),
+    "fgmm_selftest_fastmath": (_i, [_p, _i, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "fgmm_rans_encode_symtab": (_i, [_p, _p, _i64, _pp, _psz]),
     "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, _i64, _i32, _p]),
 }

@@ -344,7 +344,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     if ((rc = ctx->prof_end(2, stream))) return rc;
   }
   if ((rc = ctx->prof_begin(0, stream))) return rc;
-  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4, stream));
+  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4, items[0].clamp != 0, stream));
   if ((rc = ctx->prof_end(0, stream))) return rc;
   // ---- tables back to the host: small region first, then one copy + event per item ----------------
   HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_small, ctx->d_ws + o_small, small_bytes, hipMemcpyDeviceToHost, stream));
@@ -534,7 +534,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       n_ch_max = std::max(n_ch_max, items[i].n_ch);
       hw_max = std::max(hw_max, items[i].hw);
     }
-    LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs) + i0, i1 - i0, n_ch_max, hw_max, mode, stream));
+    LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs) + i0, i1 - i0, n_ch_max, hw_max, mode,
+                             items[0].clamp != 0, stream));
     HIP_TRY(hipEventRecord(ev_kernel[g], stream));
     HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_kernel[g], 0));
     HIP_TRY(hipMemcpyAsync(ctx->h_ws + items[i0].o_used, ctx->d_ws + items[i0].o_used, 16 * (size_t)(i1 - i0),
@@ -959,7 +960,7 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
-  LAUNCH_TRY(launch_symtab(reinterpret_cast<const EncDesc *>(ctx->d_ws), 1, 1, n, mode, enc_vec4_ok(*hd), s));
+  LAUNCH_TRY(launch_symtab(reinterpret_cast<const EncDesc *>(ctx->d_ws), 1, 1, n, mode, enc_vec4_ok(*hd), false, s));
   HIP_TRY(hipStreamSynchronize(s));
   return FGMM_OK;
 }
@@ -986,18 +987,34 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   hd->n_ch = 1;
   hd->max_bs = max_bs;
   hd->prune = (flags & FGMM_TAB_NO_PRUNE) ? 0 : 1;
+  hd->clamp = (flags & FGMM_TAB_CLAMP) ? 1 : 0;
   hd->hdr = reinterpret_cast<unsigned long long *>(hdr);
   hd->pool = pool;
   hd->pool_cap = pool_cap;
   hd->pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + 1024);
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
-  if (n) LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, 1, n, mode, s));
+  if (n) LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, 1, n, mode, (flags & FGMM_TAB_CLAMP) != 0, s));
   unsigned long long used[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(used, ctx->d_ws + 1024, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipMemcpy(pool_used, used, sizeof(uint64_t), hipMemcpyHostToDevice));
   if (used[1]) return fail(FGMM_ERR_NOMEM, "pool_cap %llu too small", (unsigned long long)pool_cap);
+  return FGMM_OK;
+}
+
+int fgmm_selftest_fastmath(fgmm_ctx *ctx, int which, uint64_t n, uint64_t seed, uint64_t *n_bad_out) {
+  if (!ctx || which < 0 || which > 2 || !n_bad_out) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  int rc;
+  if ((rc = ctx->ensure_device(4096))) return rc;
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(ctx->d_ws);
+  HIP_TRY(hipMemsetAsync(d, 0, 8, nullptr));
+  LAUNCH_TRY(launch_fastmath_selftest(which, n, seed, d, nullptr));
+  unsigned long long bad = 0;
+  HIP_TRY(hipMemcpy(&bad, d, 8, hipMemcpyDeviceToHost));
+  *n_bad_out = bad;
   return FGMM_OK;
 }
 

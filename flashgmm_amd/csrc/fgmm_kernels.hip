@@ -96,18 +96,32 @@ __global__ __launch_bounds__(kBlock) void quant_stats_kernel(const EncDesc *__re
 // from chan_nz without a host round trip.
 // VEC = 4: each lane owns 4 consecutive positions, every plane read is one 16-B load (1 KiB per wave-instr).
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE> __device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu)[4], const float (&sg)[4],
-                                                                 const float (&pi)[4], int &bypass) {
+template <int MODE, bool CLAMPED>
+__device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu)[4], float (&sg)[4], const float (&pi)[4],
+                                              int &bypass) {
   const float x1 = vq - 0.5f;          // static_cast<float>(value) - offset             (:499)
   const float x2 = vq - 0.5f + 1.0f;   // static_cast<float>(value) - offset + 1.0f
-  const uint32_t lo = quant16(mix4<MODE>(x1, mu, sg, pi));
-  const uint32_t hi = quant16(mix4<MODE>(x2, mu, sg, pi));
+  uint32_t lo, hi;
+  if constexpr (CLAMPED) {
+    float rs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sg[k] = clamp_scale(sg[k]);
+      rs[k] = rcp_refined(sg[k]); // shared by both edges
+    }
+    lo = quant16(mix4_clamped<MODE>(x1, mu, sg, rs, pi));
+    hi = quant16(mix4_clamped<MODE>(x2, mu, sg, rs, pi));
+  } else {
+    lo = quant16(mix4<MODE>(x1, mu, sg, pi));
+    hi = quant16(mix4<MODE>(x2, mu, sg, pi));
+  }
   const uint32_t pmf = (hi - lo) & 0xFFFFu; // uint16_t pmf = next - value                (:512)
   bypass = (pmf == 0);
   return pmf ? (lo | (pmf << 16)) : ((uint32_t)vi & 0xFFFFu); // bypass: low 16 bits of the int32 symbol
 }
 
-template <int MODE, int VEC> __global__ __launch_bounds__(kBlock) void symtab_kernel(const EncDesc *__restrict__ descs) {
+template <int MODE, int VEC, bool CLAMPED>
+__global__ __launch_bounds__(kBlock) void symtab_kernel(const EncDesc *__restrict__ descs) {
   const EncDesc &d = descs[blockIdx.z];
   const int c = blockIdx.y;
   if (c >= d.M) return;
@@ -132,7 +146,6 @@ template <int MODE, int VEC> __global__ __launch_bounds__(kBlock) void symtab_ke
   }
   const bool active = p0 < hw; // lanes past the end stay for the wave reduction below
 
-  const int clampf = d.clamp;
   int nbypass = 0;
   if (!active) {
   } else if constexpr (VEC == 4) {
@@ -161,13 +174,12 @@ template <int MODE, int VEC> __global__ __launch_bounds__(kBlock) void symtab_ke
       float mu[4], sg[4], pi[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float s = (&S[k].x)[e];
-        sg[k] = clampf ? clamp_scale(s) : s;
+        sg[k] = (&S[k].x)[e];
         mu[k] = (&Mu[k].x)[e];
         pi[k] = (&Pi[k].x)[e];
       }
       int bp;
-      out[e] = sym_entry<MODE>((&vq4.x)[e], (&vi4.x)[e], mu, sg, pi, bp);
+      out[e] = sym_entry<MODE, CLAMPED>((&vq4.x)[e], (&vi4.x)[e], mu, sg, pi, bp);
       nbypass += bp;
     }
     *reinterpret_cast<uint4 *>(d.packed + (int64_t)rank * hw + p0) = make_uint4(out[0], out[1], out[2], out[3]);
@@ -185,13 +197,12 @@ template <int MODE, int VEC> __global__ __launch_bounds__(kBlock) void symtab_ke
     float mu[4], sg[4], pi[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float s = d.scales[base + k * d.stride_k];
-      sg[k] = clampf ? clamp_scale(s) : s;
+      sg[k] = d.scales[base + k * d.stride_k];
       mu[k] = d.means[base + k * d.stride_k];
       pi[k] = d.weights[base + k * d.stride_k];
     }
     int bp;
-    d.packed[(int64_t)rank * hw + p0] = sym_entry<MODE>(vq, vi, mu, sg, pi, bp);
+    d.packed[(int64_t)rank * hw + p0] = sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp);
     nbypass = bp;
   }
   // bypass census: one atomic per wave that saw any (the host sizes its output buffer from it)
@@ -232,7 +243,8 @@ __global__ __launch_bounds__(kBlock) void cdf_pair_kernel(const int32_t *__restr
 //   pass 2: re-evaluate only the window and store it (8 B per store), then the 8-byte header.
 // Transcendental-VALU bound (about 200 VALU ops per edge), not HBM bound: 48 B in per latent.
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE> __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restrict__ descs) {
+template <int MODE, bool CLAMPED>
+__global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restrict__ descs) {
   const DecDesc &d = descs[blockIdx.z];
   const int cj = blockIdx.y;
   if (cj >= d.n_ch) return;
@@ -242,17 +254,23 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void cdftab_kernel(cons
   const bool active = p < hw;
   const int c = d.chan_list ? d.chan_list[cj] : cj;
 
-  float mu[4], sg[4], pi[4];
+  float mu[4], sg[4], pi[4], rs[4];
   {
     const int64_t base = (int64_t)c * d.stride_c + (active ? p : 0) * d.stride_p;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float s = d.scales[base + k * d.stride_k];
-      sg[k] = d.clamp ? clamp_scale(s) : s;
+      sg[k] = CLAMPED ? clamp_scale(s) : s;
+      rs[k] = CLAMPED ? rcp_refined(sg[k]) : 0.0f; // one refined reciprocal per component for the whole row
       mu[k] = d.means[base + k * d.stride_k];
       pi[k] = d.weights[base + k * d.stride_k];
     }
   }
+  auto edge = [&](int j) -> uint32_t { // F[v = j - max_bs]
+    const float x = (float)(j - d.max_bs) - 0.5f;
+    if constexpr (CLAMPED) return quant16(mix4_clamped<MODE>(x, mu, sg, rs, pi));
+    else return quant16(mix4<MODE>(x, mu, sg, pi));
+  };
   const int max_bs = d.max_bs;
   const int W = 2 * max_bs + 2;
 
@@ -297,8 +315,7 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void cdftab_kernel(cons
   bool allzero = true, nonmono = false;
   uint32_t prev = 0;
   for (int j = j_lo; j < j_hi; ++j) {
-    const float x = (float)(j - max_bs) - 0.5f;
-    const uint32_t E = quant16(mix4<MODE>(x, mu, sg, pi));
+    const uint32_t E = edge(j);
     if (allzero) {
       if (E == 0) lead = j; else allzero = false;
     }
@@ -345,10 +362,7 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void cdftab_kernel(cons
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int j = (int)(j0 + t);
-      if (j < cnt) {
-        const float x = (float)(a_idx + j - max_bs) - 0.5f;
-        last = quant16(mix4<MODE>(x, mu, sg, pi));
-      }
+      if (j < cnt) last = edge(a_idx + j);
       e[t] = last; // pad with the row's last value (= the trailing constant)
     }
     *reinterpret_cast<uint2 *>(row + j0) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
@@ -382,6 +396,58 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void saturation_selftes
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// fastmath_selftest_kernel: the hand-expanded cores of fgmm_math.h against the compiler's IEEE '/' and sqrtf.
+//   which = 0: sqrt_core(x) == sqrtf(x) for EVERY binary32 x in [0, 2] (plus -1, NaN)          (exhaustive)
+//   which = 1: div_clamped(a, s, rcp_refined(s)) == a / s   for n hashed pairs, a over every magnitude incl. 0,
+//              inf, NaN, s over [0.11, 256] with the end points and powers of two over-represented
+//   which = 2: rcp_ge1(d) == 1 / d for EVERY binary32 d in [1, +inf] and NaN                   (exhaustive)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash32(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ bool same_f32(float a, float b) { return f2bits(a) == f2bits(b) || (a != a && b != b); }
+
+__global__ __launch_bounds__(kBlock) void fastmath_selftest_kernel(int which, unsigned long long n, unsigned long long seed,
+                                                                   unsigned long long *n_bad) {
+  unsigned long long bad = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const uint64_t t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (which == 0) {
+    const uint32_t top = f2bits(2.0f);
+    for (uint64_t i = t0; i <= (uint64_t)top + 2; i += stride) {
+      const float x = i <= top ? bits2f((uint32_t)i) : (i == (uint64_t)top + 1 ? -1.0f : bits2f(0x7FC00000u));
+      bad += !same_f32(sqrt_core(x), __builtin_sqrtf(x));
+    }
+  } else if (which == 2) {
+    const uint32_t lo = f2bits(1.0f), hi = 0x7F800000u;
+    for (uint64_t i = t0; i <= (uint64_t)(hi - lo) + 1; i += stride) {
+      const float d = i <= (uint64_t)(hi - lo) ? bits2f(lo + (uint32_t)i) : bits2f(0x7FC00000u);
+      bad += !same_f32(rcp_ge1(d), 1.0f / d);
+    }
+  } else {
+    for (uint64_t i = t0; i < n; i += stride) {
+      const uint32_t h1 = hash32(i * 2 + seed), h2 = hash32(i * 2 + 1 + seed * 0x9E3779B97F4A7C15ULL);
+      float a = bits2f(h1); // every exponent, both signs, NaN/inf/denormal included
+      if ((h2 & 7u) == 0) a = (float)(int)(h1 >> 20) * 0.5f - bits2f((h1 & 0x007FFFFFu) | 0x3F000000u); // x - mu like
+      float s;
+      switch ((h2 >> 3) & 7u) {
+      case 0: s = 0.11f; break;
+      case 1: s = 256.0f; break;
+      case 2: s = bits2f(((h2 >> 8) % 12u + 124u) << 23); break;                 // powers of two 2^-3 .. 2^8
+      case 3: s = bits2f((((h2 >> 8) % 12u + 124u) << 23) | 0x007FFFFFu); break; // all-ones mantissas
+      default: s = bits2f((((h2 >> 8) % 12u + 123u) << 23) | (hash32(h2 + i) & 0x007FFFFFu)); break;
+      }
+      s = clamp_scale(s);
+      bad += !same_f32(div_clamped(a, s, rcp_refined(s)), a / s);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(n_bad, bad);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 static inline int launch_err() { return (int)hipGetLastError(); }
@@ -393,21 +459,26 @@ int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *strea
   return launch_err();
 }
 
-template <int VEC> static int launch_symtab_v(const EncDesc *d, int count, int M_max, int64_t hw_max, int mode, hipStream_t s) {
+template <int VEC, bool CLAMPED>
+static int launch_symtab_v(const EncDesc *d, int count, int M_max, int64_t hw_max, int mode, hipStream_t s) {
   const int64_t per_block = (int64_t)kBlock * VEC;
   dim3 grid((unsigned)((hw_max + per_block - 1) / per_block), (unsigned)M_max, (unsigned)count);
   switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((symtab_kernel<MODE_AS, VEC>), grid, dim3(kBlock), 0, s, d); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((symtab_kernel<MODE_LOGISTIC, VEC>), grid, dim3(kBlock), 0, s, d); break;
-  default: hipLaunchKernelGGL((symtab_kernel<MODE_POLYA, VEC>), grid, dim3(kBlock), 0, s, d); break;
+  case MODE_AS: hipLaunchKernelGGL((symtab_kernel<MODE_AS, VEC, CLAMPED>), grid, dim3(kBlock), 0, s, d); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((symtab_kernel<MODE_LOGISTIC, VEC, CLAMPED>), grid, dim3(kBlock), 0, s, d); break;
+  default: hipLaunchKernelGGL((symtab_kernel<MODE_POLYA, VEC, CLAMPED>), grid, dim3(kBlock), 0, s, d); break;
   }
   return launch_err();
 }
 
-int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, bool vec4, void *stream) {
+int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, bool vec4, bool clamped,
+                  void *stream) {
   if (count <= 0 || M_max <= 0 || hw_max <= 0) return 0;
-  return vec4 ? launch_symtab_v<4>(d_descs, count, M_max, hw_max, mode, (hipStream_t)stream)
-              : launch_symtab_v<1>(d_descs, count, M_max, hw_max, mode, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec4) return clamped ? launch_symtab_v<4, true>(d_descs, count, M_max, hw_max, mode, s)
+                           : launch_symtab_v<4, false>(d_descs, count, M_max, hw_max, mode, s);
+  return clamped ? launch_symtab_v<1, true>(d_descs, count, M_max, hw_max, mode, s)
+                 : launch_symtab_v<1, false>(d_descs, count, M_max, hw_max, mode, s);
 }
 
 int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
@@ -423,15 +494,25 @@ int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, c
   return launch_err();
 }
 
-int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, void *stream) {
-  if (count <= 0 || n_ch_max <= 0 || hw_max <= 0) return 0;
+template <bool CLAMPED>
+static int launch_cdftab_c(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, hipStream_t s) {
   dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)n_ch_max, (unsigned)count);
-  hipStream_t s = (hipStream_t)stream;
   switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((cdftab_kernel<MODE_AS>), grid, dim3(kBlock), 0, s, d_descs); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((cdftab_kernel<MODE_LOGISTIC>), grid, dim3(kBlock), 0, s, d_descs); break;
-  default: hipLaunchKernelGGL((cdftab_kernel<MODE_POLYA>), grid, dim3(kBlock), 0, s, d_descs); break;
+  case MODE_AS: hipLaunchKernelGGL((cdftab_kernel<MODE_AS, CLAMPED>), grid, dim3(kBlock), 0, s, d_descs); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((cdftab_kernel<MODE_LOGISTIC, CLAMPED>), grid, dim3(kBlock), 0, s, d_descs); break;
+  default: hipLaunchKernelGGL((cdftab_kernel<MODE_POLYA, CLAMPED>), grid, dim3(kBlock), 0, s, d_descs); break;
   }
+  return launch_err();
+}
+
+int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, void *stream) {
+  if (count <= 0 || n_ch_max <= 0 || hw_max <= 0) return 0;
+  return clamped ? launch_cdftab_c<true>(d_descs, count, n_ch_max, hw_max, mode, (hipStream_t)stream)
+                 : launch_cdftab_c<false>(d_descs, count, n_ch_max, hw_max, mode, (hipStream_t)stream);
+}
+
+int launch_fastmath_selftest(int which, unsigned long long n, unsigned long long seed, unsigned long long *n_bad, void *stream) {
+  hipLaunchKernelGGL(fastmath_selftest_kernel, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, which, n, seed, n_bad);
   return launch_err();
 }
 

@@ -42,37 +42,98 @@ __device__ __forceinline__ float exp_ref(float x) {
   return y * bits2f((uint32_t)(n + 127) << 23);
 }
 
-template <int MODE> __device__ __forceinline__ float phi(float z);
+// ---------------------------------------------------------------------------------------------------------
+// Correctly-rounded division and square root, hand-expanded.
+//
+// hipcc lowers an IEEE f32 '/' to  v_div_scale x2, v_rcp, 4 fma, mul, v_div_fmas, v_div_fixup  (and f32 sqrt to
+// v_sqrt + two fma probes + scaling + class fix-ups).  The scale / fix-up steps only act when an exponent is
+// extreme or an operand is 0/inf/NaN.  Where the operands are known to be tame the core below computes the SAME
+// sequence of operations — hence the same, correctly rounded, bits — in 5 instructions per quotient once the
+// refined reciprocal of the denominator exists; and the denominator (sigma_k) is shared by every abscissa that
+// is evaluated for a latent.  Callers guard the domain and fall back to '/' outside it.
+// Equality with '/' and sqrtf is checked on the GPU by fgmm_selftest_fastmath (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rcp_refined(float d) { // Fma1 of the lowering: rcp + one Newton step
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r0, 1.0f);
+  return __builtin_fmaf(e, r0, r0);
+}
+// a / d given r = rcp_refined(d); exact for |a| in {0} U [2^-60, 2^60), d in [2^-10, 2^60) (no scaling needed)
+__device__ __forceinline__ float div_core(float a, float d, float r) {
+  const float q0 = a * r;
+  const float e2 = __builtin_fmaf(-d, q0, a);
+  const float q1 = __builtin_fmaf(e2, r, q0);
+  const float e3 = __builtin_fmaf(-d, q1, a);
+  return __builtin_fmaf(e3, r, q1);
+}
+__device__ __forceinline__ bool tame(float a) { return __builtin_fabsf(a) < 0x1p60f; } // false for NaN / inf
+
+// a / d for a clamped denominator (sigma in [0.11, 256], or NaN which propagates either way)
+__device__ __forceinline__ float div_clamped(float a, float d, float r) {
+  float q = div_core(a, d, r);
+  if (__builtin_expect(!tame(a), 0)) q = a / d;
+  return q;
+}
+// 1 / d for d >= 1 (d = 1 + something non-negative), any magnitude, NaN
+__device__ __forceinline__ float rcp_ge1(float d) {
+  float q = div_core(1.0f, d, rcp_refined(d));
+  if (__builtin_expect(!tame(d), 0)) q = 1.0f / d;
+  return q;
+}
+// sqrt for x in {+0} U [2^-96, 2^96], negative or NaN (-> NaN): v_sqrt_f32 is within 1 ulp, the two fma probes
+// pick the correctly rounded neighbour (the un-scaled core of hipcc's own lowering)
+__device__ __forceinline__ float sqrt_core(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = bits2f(f2bits(s) - 1u), su = bits2f(f2bits(s) + 1u);
+  const float vp = __builtin_fmaf(-sd, s, x), vs = __builtin_fmaf(-su, s, x);
+  s = (vp <= 0.0f) ? sd : s;
+  s = (vs > 0.0f) ? su : s;
+  return s;
+}
+
+// FAST = false: plain IEEE '/' and sqrtf, any input.  FAST = true: the cores above (identical results).
+template <int MODE, bool FAST> struct Phi;
 
 // Polya/Watterson, rans_interface.cpp:135-146
-template <> __device__ __forceinline__ float phi<MODE_POLYA>(float z) {
-  const float c = -2.0f / 3.14159265358979323846f; // folded in binary32, as the reference's constant is
-  const float e = exp_ref(c * (z * z));
-  float s = __builtin_sqrtf(1.0f - e);
-  s = bits2f((f2bits(z) & 0x80000000u) | (f2bits(s) & 0x7fffffffu)); // copysign_ps(z, s)
-  return 0.5f * (1.0f + s);
-}
+template <bool FAST> struct Phi<MODE_POLYA, FAST> {
+  static __device__ __forceinline__ float eval(float z) {
+    const float c = -2.0f / 3.14159265358979323846f; // folded in binary32, as the reference's constant is
+    const float e = exp_ref(c * (z * z));
+    // 1 - e is +0, >= 2^-24, or (NaN path: e = exp(+88.4)) hugely negative -> NaN: always in sqrt_core's domain
+    float s = FAST ? sqrt_core(1.0f - e) : __builtin_sqrtf(1.0f - e);
+    s = bits2f((f2bits(z) & 0x80000000u) | (f2bits(s) & 0x7fffffffu)); // copysign_ps(z, s)
+    return 0.5f * (1.0f + s);
+  }
+};
 
 // Abramowitz & Stegun 26.2.17, rans_interface.cpp:154-186
-template <> __device__ __forceinline__ float phi<MODE_AS>(float z) {
-  const float az = bits2f(f2bits(z) & 0x7fffffffu);
-  const float zx = 0.3989422804014327f * exp_ref((z * z) * -0.5f);
-  const float t = 1.0f / __builtin_fmaf(0.2316419f, az, 1.0f);
-  float poly = __builtin_fmaf(1.330274429f, t, -1.821255978f);
-  poly = __builtin_fmaf(poly, t, 1.781477937f);
-  poly = __builtin_fmaf(poly, t, -0.356563782f);
-  poly = __builtin_fmaf(poly, t, 0.319381530f);
-  poly = poly * t;
-  const float res_pos = __builtin_fmaf(-zx, poly, 1.0f);
-  const float res_neg = 1.0f - res_pos;
-  return (f2bits(z) & 0x80000000u) ? res_neg : res_pos; // blendv on the sign BIT (so -0.0 -> res_neg)
-}
+template <bool FAST> struct Phi<MODE_AS, FAST> {
+  static __device__ __forceinline__ float eval(float z) {
+    const float az = bits2f(f2bits(z) & 0x7fffffffu);
+    const float zx = 0.3989422804014327f * exp_ref((z * z) * -0.5f);
+    const float d = __builtin_fmaf(0.2316419f, az, 1.0f);
+    const float t = FAST ? rcp_ge1(d) : 1.0f / d;
+    float poly = __builtin_fmaf(1.330274429f, t, -1.821255978f);
+    poly = __builtin_fmaf(poly, t, 1.781477937f);
+    poly = __builtin_fmaf(poly, t, -0.356563782f);
+    poly = __builtin_fmaf(poly, t, 0.319381530f);
+    poly = poly * t;
+    const float res_pos = __builtin_fmaf(-zx, poly, 1.0f);
+    const float res_neg = 1.0f - res_pos;
+    return (f2bits(z) & 0x80000000u) ? res_neg : res_pos; // blendv on the sign BIT (so -0.0 -> res_neg)
+  }
+};
 
 // logistic, rans_interface.cpp:208-214
-template <> __device__ __forceinline__ float phi<MODE_LOGISTIC>(float z) {
-  const float e = exp_ref(-1.0f * (1.702f * z));
-  return 1.0f / (1.0f + e);
-}
+template <bool FAST> struct Phi<MODE_LOGISTIC, FAST> {
+  static __device__ __forceinline__ float eval(float z) {
+    const float e = exp_ref(-1.0f * (1.702f * z));
+    const float d = 1.0f + e;
+    return FAST ? rcp_ge1(d) : 1.0f / d;
+  }
+};
+
+template <int MODE> __device__ __forceinline__ float phi(float z) { return Phi<MODE, false>::eval(z); }
 
 // _fast_gmm_cdf<4>, AVX branch (rans_interface.cpp:259-283): (p0 + p1) + (p2 + p3)
 template <int MODE>
@@ -80,6 +141,17 @@ __device__ __forceinline__ float mix4(float x, const float (&mu)[4], const float
   float p[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) p[k] = pi[k] * phi<MODE>((x - mu[k]) / sg[k]);
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+// Same value, for CLAMPED sigma (entropy-model path), with the refined reciprocals rs[k] = rcp_refined(sg[k])
+// computed once per latent and reused for every abscissa.
+template <int MODE>
+__device__ __forceinline__ float mix4_clamped(float x, const float (&mu)[4], const float (&sg)[4], const float (&rs)[4],
+                                              const float (&pi)[4]) {
+  float p[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) p[k] = pi[k] * Phi<MODE, true>::eval(div_clamped(x - mu[k], sg[k], rs[k]));
   return (p[0] + p[1]) + (p[2] + p[3]);
 }
 

@@ -172,6 +172,7 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
  * decreases somewhere.  hdr: device uint64[n]; pool: device uint16[pool_cap]; pool_used: device uint64[1],
  * zeroed by the call.  pool_cap >= n * (2*max_bs + 5) always suffices. */
 #define FGMM_TAB_NO_PRUNE 1 /* flags: evaluate all of F_i instead of skipping its saturated tails (A/B testing) */
+#define FGMM_TAB_CLAMP 2    /* flags: clamp sigma to [0.11, 256] first (the entropy-model path's kernel variant) */
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
                           const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode,
                           int32_t max_bs, int flags, uint64_t *hdr, uint16_t *pool, uint64_t pool_cap,
@@ -180,6 +181,11 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
 /* GPU self-test: exhaustive scan (every binary32 beyond the thresholds) of the saturation lemmas that let the
  * table kernel skip the tails of F_i.  *n_bad_out = number of violating inputs (must be 0). */
 int fgmm_selftest_saturation(fgmm_ctx *ctx, int mode, uint64_t *n_bad_out);
+
+/* GPU self-test of the hand-expanded correctly-rounded cores (fgmm_math.h) against the compiler's IEEE '/' and
+ * sqrtf: which = 0 sqrt (every binary32 in [0,2]), 1 division by a clamped sigma (n hashed pairs from `seed`),
+ * 2 reciprocal of d >= 1 (every binary32 in [1,+inf]).  *n_bad_out must come back 0. */
+int fgmm_selftest_fastmath(fgmm_ctx *ctx, int which, uint64_t n, uint64_t seed, uint64_t *n_bad_out);
 
 /* Host, integer only: symbol table (+ raw symbols, needed only where range == 0 and abs(symbol) >= 32768)
  * -> bitstream.  BufferedRansEncoder::flush semantics (rans_interface.cpp:557-585). */

@@ -257,6 +257,43 @@ def test_saturation_lemmas_exhaustive(mode):
     assert bad.value == 0
 
 
+def test_fastmath_cores_equal_ieee():
+    """the hand-expanded division / reciprocal / sqrt cores give the compiler's correctly-rounded bits:
+    sqrt and reciprocal exhaustively over their domains, division on 4e9 hashed pairs"""
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    for which, n in ((0, 0), (2, 0), (1, 1 << 32)):
+        for seed in ((1, 2) if which == 1 else (0,)):
+            bad = C.c_uint64(99)
+            _lib.check(L.fgmm_selftest_fastmath(ctx, which, n, seed, C.byref(bad)))
+            assert bad.value == 0, (which, seed, bad.value)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_cdftab_clamped_variant(oracle, mode):
+    """the entropy-model kernel variant (sigma clamp + shared refined reciprocals) == oracle on clamped sigma,
+    including NaN / inf / huge means and sigma far outside the clamp"""
+    rng = np.random.default_rng(123)
+    n = 6000
+    sg = np.exp(rng.uniform(-6, 8, (n, 4))).astype(np.float32)
+    mu = (rng.standard_normal((n, 4)) * np.exp(rng.uniform(-2, 5, (n, 1)))).astype(np.float32)
+    pi = rng.dirichlet(np.ones(4), n).astype(np.float32)
+    mu[3::97, 1] = np.inf
+    mu[4::97, 2] = -np.inf
+    mu[5::97, 0] = 3e38
+    mu[6::97, 3] = np.nan
+    sg[7::97, 0] = np.nan
+    sg[8::97, 1] = 0.0
+    sg[9::97, 2] = -5.0
+    sg[10::97, 3] = np.inf
+    sgc = np.minimum(np.maximum(sg, np.float32(0.11)), np.float32(256))  # torch.clamp semantics (NaN stays)
+    sgc[np.isnan(sg)] = np.nan
+    for max_bs in (3, 60):
+        want = oracle.cdftab(mode, sgc, mu, pi, max_bs)
+        for flags in (2, 3):
+            h, p_, u = gpu_cdftab(mode, sg, mu, pi, max_bs, flags=flags)
+            assert np.array_equal(expand_trimmed(h, p_, max_bs), want), (max_bs, flags)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_cdftab_pruned_equals_unpruned(oracle, mode):
     """wide half-widths, tiny and huge sigma, far-off means, weights outside [0,1], NaN/inf/zero sigma: the pruned
