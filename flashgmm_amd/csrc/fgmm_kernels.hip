@@ -397,9 +397,11 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void saturation_selftes
 
 // ---------------------------------------------------------------------------------------------------------
 // fastmath_selftest_kernel: the hand-expanded cores of fgmm_math.h against the compiler's IEEE '/' and sqrtf.
-//   which = 0: sqrt_core(x) == sqrtf(x) for EVERY binary32 x in [0, 2] (plus -1, NaN)          (exhaustive)
-//   which = 1: div_clamped(a, s, rcp_refined(s)) == a / s   for n hashed pairs, a over every magnitude incl. 0,
-//              inf, NaN, s over [0.11, 256] with the end points and powers of two over-represented
+//   which = 0: sqrt_core(x) == sqrtf(x) for EVERY binary32 x in {0} U [2^-96, 2] (plus -1, NaN)  (exhaustive;
+//              the kernels only ever take sqrt(1 - e) with e in [0,1]: 0 or >= 2^-24)
+//   which = 1: div_clamped(a, s, rcp_refined(s)) == a / s   for n hashed pairs; a = 0, or any magnitude >= 2^-60
+//              incl. inf and NaN (a = x - mu with |x| >= 0.5 is 0 or >= 2^-26 by Sterbenz), s over [0.11, 256]
+//              with the end points, powers of two and all-ones mantissas over-represented
 //   which = 2: rcp_ge1(d) == 1 / d for EVERY binary32 d in [1, +inf] and NaN                   (exhaustive)
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t hash32(uint64_t x) {
@@ -414,9 +416,10 @@ __global__ __launch_bounds__(kBlock) void fastmath_selftest_kernel(int which, un
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   const uint64_t t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (which == 0) {
-    const uint32_t top = f2bits(2.0f);
-    for (uint64_t i = t0; i <= (uint64_t)top + 2; i += stride) {
-      const float x = i <= top ? bits2f((uint32_t)i) : (i == (uint64_t)top + 1 ? -1.0f : bits2f(0x7FC00000u));
+    const uint32_t bot = f2bits(0x1p-96f), top = f2bits(2.0f);
+    for (uint64_t i = t0; i <= (uint64_t)(top - bot) + 3; i += stride) {
+      const uint64_t k = i + bot;
+      const float x = k <= top ? bits2f((uint32_t)k) : (k == (uint64_t)top + 1 ? -1.0f : (k == (uint64_t)top + 2 ? 0.0f : bits2f(0x7FC00000u)));
       bad += !same_f32(sqrt_core(x), __builtin_sqrtf(x));
     }
   } else if (which == 2) {
@@ -428,7 +431,8 @@ __global__ __launch_bounds__(kBlock) void fastmath_selftest_kernel(int which, un
   } else {
     for (uint64_t i = t0; i < n; i += stride) {
       const uint32_t h1 = hash32(i * 2 + seed), h2 = hash32(i * 2 + 1 + seed * 0x9E3779B97F4A7C15ULL);
-      float a = bits2f(h1); // every exponent, both signs, NaN/inf/denormal included
+      float a = bits2f(h1); // both signs, NaN/inf included
+      if (__builtin_fabsf(a) < 0x1p-60f) a = (h1 & 1u) ? 0.0f : a * 0x1p80f; // domain: 0 or >= 2^-60
       if ((h2 & 7u) == 0) a = (float)(int)(h1 >> 20) * 0.5f - bits2f((h1 & 0x007FFFFFu) | 0x3F000000u); // x - mu like
       float s;
       switch ((h2 >> 3) & 7u) {
