@@ -1010,11 +1010,12 @@ int fgmm_selftest_fastmath(fgmm_ctx *ctx, int which, uint64_t n, uint64_t seed, 
   int rc;
   if ((rc = ctx->ensure_device(4096))) return rc;
   unsigned long long *d = reinterpret_cast<unsigned long long *>(ctx->d_ws);
-  HIP_TRY(hipMemsetAsync(d, 0, 8, nullptr));
+  HIP_TRY(hipMemsetAsync(d, 0, 24, nullptr));
   LAUNCH_TRY(launch_fastmath_selftest(which, n, seed, d, nullptr));
-  unsigned long long bad = 0;
-  HIP_TRY(hipMemcpy(&bad, d, 8, hipMemcpyDeviceToHost));
-  *n_bad_out = bad;
+  unsigned long long bad[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpy(bad, d, 24, hipMemcpyDeviceToHost));
+  *n_bad_out = bad[0];
+  if (bad[0]) snprintf(t_err, sizeof t_err, "fastmath selftest %d: %llu mismatches, witness a=0x%08llx s=0x%08llx", which, bad[0], bad[1], bad[2]);
   return FGMM_OK;
 }
 

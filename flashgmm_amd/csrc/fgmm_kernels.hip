@@ -400,7 +400,8 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void saturation_selftes
 //   which = 0: sqrt_core(x) == sqrtf(x) for EVERY binary32 x in {0} U [2^-96, 2] (plus -1, NaN)  (exhaustive;
 //              the kernels only ever take sqrt(1 - e) with e in [0,1]: 0 or >= 2^-24)
 //   which = 1: div_clamped(a, s, rcp_refined(s)) == a / s   for n hashed pairs; a = 0, or any magnitude >= 2^-60
-//              incl. inf and NaN (a = x - mu with |x| >= 0.5 is 0 or >= 2^-26 by Sterbenz), s over [0.11, 256]
+//              incl. inf and NaN (a = x - mu with |x| >= 0.5 is +0 or >= 2^-26 by Sterbenz, never -0: the core
+//              would return +0 where IEEE returns -0), s over [0.11, 256]
 //              with the end points, powers of two and all-ones mantissas over-represented
 //   which = 2: rcp_ge1(d) == 1 / d for EVERY binary32 d in [1, +inf] and NaN                   (exhaustive)
 // ---------------------------------------------------------------------------------------------------------
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(kBlock) void fastmath_selftest_kernel(int which, un
     for (uint64_t i = t0; i < n; i += stride) {
       const uint32_t h1 = hash32(i * 2 + seed), h2 = hash32(i * 2 + 1 + seed * 0x9E3779B97F4A7C15ULL);
       float a = bits2f(h1); // both signs, NaN/inf included
-      if (__builtin_fabsf(a) < 0x1p-60f) a = (h1 & 1u) ? 0.0f : a * 0x1p80f; // domain: 0 or >= 2^-60
+      if (__builtin_fabsf(a) < 0x1p-60f) a = (h1 & 1u) ? 0.0f : a * 0x1p80f; // domain: +0 or >= 2^-60
+      if (a == 0.0f) a = 0.0f; // a = x - mu is never -0 (x != 0; x - x = +0 in round-to-nearest)
       if ((h2 & 7u) == 0) a = (float)(int)(h1 >> 20) * 0.5f - bits2f((h1 & 0x007FFFFFu) | 0x3F000000u); // x - mu like
       float s;
       switch ((h2 >> 3) & 7u) {
@@ -443,7 +445,9 @@ __global__ __launch_bounds__(kBlock) void fastmath_selftest_kernel(int which, un
       default: s = bits2f((((h2 >> 8) % 12u + 123u) << 23) | (hash32(h2 + i) & 0x007FFFFFu)); break;
       }
       s = clamp_scale(s);
-      bad += !same_f32(div_clamped(a, s, rcp_refined(s)), a / s);
+      const bool ok = same_f32(div_clamped(a, s, rcp_refined(s)), a / s);
+      if (!ok) { n_bad[1] = f2bits(a); n_bad[2] = f2bits(s); } // a witness for the report
+      bad += !ok;
     }
   }
 #pragma unroll

@@ -58,7 +58,8 @@ __device__ __forceinline__ float rcp_refined(float d) { // Fma1 of the lowering:
   const float e = __builtin_fmaf(-d, r0, 1.0f);
   return __builtin_fmaf(e, r0, r0);
 }
-// a / d given r = rcp_refined(d); exact for |a| in {0} U [2^-60, 2^60), d in [2^-10, 2^60) (no scaling needed)
+// a / d given r = rcp_refined(d); exact for a in {+0} U +-[2^-60, 2^60), d in [2^-10, 2^60) (no scaling needed).
+// (a = -0 would give +0 instead of -0; a = x - mu with x = v -+ 0.5 is never -0.)
 __device__ __forceinline__ float div_core(float a, float d, float r) {
   const float q0 = a * r;
   const float e2 = __builtin_fmaf(-d, q0, a);
