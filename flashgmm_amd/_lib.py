@@ -11,7 +11,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libflashgmm_amd.so")
+LIB_PATH = os.environ.get("FGMM_LIB") or os.path.join(HERE, "libflashgmm_amd.so")  # FGMM_LIB: A/B builds (dev)
 
 FGMM_OK = 0
 FGMM_HOST, FGMM_DEVICE = 0, 1

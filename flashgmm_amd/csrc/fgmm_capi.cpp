@@ -344,7 +344,8 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     if ((rc = ctx->prof_end(2, stream))) return rc;
   }
   if ((rc = ctx->prof_begin(0, stream))) return rc;
-  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4, items[0].clamp != 0, stream));
+  static const int force_vec = getenv("FGMM_VEC") ? atoi(getenv("FGMM_VEC")) : 0; // dev: A/B the load width
+  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4 ? (force_vec ? force_vec : 4) : 1, items[0].clamp != 0, stream));
   if ((rc = ctx->prof_end(0, stream))) return rc;
   // ---- tables back to the host: small region first, then one copy + event per item ----------------
   HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_small, ctx->d_ws + o_small, small_bytes, hipMemcpyDeviceToHost, stream));
@@ -960,7 +961,7 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
-  LAUNCH_TRY(launch_symtab(reinterpret_cast<const EncDesc *>(ctx->d_ws), 1, 1, n, mode, enc_vec4_ok(*hd), false, s));
+  LAUNCH_TRY(launch_symtab(reinterpret_cast<const EncDesc *>(ctx->d_ws), 1, 1, n, mode, enc_vec4_ok(*hd) ? 4 : 1, false, s));
   HIP_TRY(hipStreamSynchronize(s));
   return FGMM_OK;
 }

@@ -59,7 +59,7 @@ FGMM_HD static inline uint64_t hdr_off(uint64_t h) { return (h >> 32) << 2; }
 
 // ---- kernel launchers (fgmm_kernels.hip); stream is a hipStream_t; all return hipError_t as int ----------
 int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *stream);
-int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, bool vec4, bool clamped,
+int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, int vec, bool clamped,
                   void *stream);
 int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
                     int64_t stride_n, int64_t stride_k, int mode, float *c1, float *c2, void *stream);

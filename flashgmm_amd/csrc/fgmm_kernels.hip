@@ -12,6 +12,8 @@
 // (k, c, p) layout.  Wave = 64 lanes throughout.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fgmm_internal.h"
 #include "fgmm_math.h"
 
@@ -109,8 +111,15 @@ __device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu
       sg[k] = clamp_scale(sg[k]);
       rs[k] = rcp_refined(sg[k]); // shared by both edges
     }
-    lo = quant16(mix4_clamped<MODE>(x1, mu, sg, rs, pi));
-    hi = quant16(mix4_clamped<MODE>(x2, mu, sg, rs, pi));
+    bool ok = true;
+    float c1 = mix4_clamped<MODE>(x1, mu, sg, rs, pi, ok);
+    float c2 = mix4_clamped<MODE>(x2, mu, sg, rs, pi, ok);
+    if (__builtin_expect(!ok, 0)) { // huge / non-finite mean: one rare out-of-line IEEE evaluation
+      c1 = mix4_slow<MODE>(x1, mu[0], mu[1], mu[2], mu[3], sg[0], sg[1], sg[2], sg[3], pi[0], pi[1], pi[2], pi[3]);
+      c2 = mix4_slow<MODE>(x2, mu[0], mu[1], mu[2], mu[3], sg[0], sg[1], sg[2], sg[3], pi[0], pi[1], pi[2], pi[3]);
+    }
+    lo = quant16(c1);
+    hi = quant16(c2);
   } else {
     lo = quant16(mix4<MODE>(x1, mu, sg, pi));
     hi = quant16(mix4<MODE>(x2, mu, sg, pi));
@@ -120,8 +129,11 @@ __device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu
   return pmf ? (lo | (pmf << 16)) : ((uint32_t)vi & 0xFFFFu); // bypass: low 16 bits of the int32 symbol
 }
 
+#ifndef FGMM_SYMTAB_WAVES
+#define FGMM_SYMTAB_WAVES 5 // min waves per SIMD the register allocator must leave room for (<= 96 VGPRs)
+#endif
 template <int MODE, int VEC, bool CLAMPED>
-__global__ __launch_bounds__(kBlock) void symtab_kernel(const EncDesc *__restrict__ descs) {
+__global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const EncDesc *__restrict__ descs) {
   const EncDesc &d = descs[blockIdx.z];
   const int c = blockIdx.y;
   if (c >= d.M) return;
@@ -148,29 +160,39 @@ __global__ __launch_bounds__(kBlock) void symtab_kernel(const EncDesc *__restric
 
   int nbypass = 0;
   if (!active) {
-  } else if constexpr (VEC == 4) {
-    // planar, 16-B aligned (checked by the host): one float4 per plane per lane
+  } else if constexpr (VEC == 4 || VEC == 2) {
+    // planar, 4*VEC-byte aligned (checked by the host): one VEC-wide load per plane per lane
+    using fv = typename std::conditional<VEC == 4, float4, float2>::type;
+    using iv = typename std::conditional<VEC == 4, int4, int2>::type;
+    using uv = typename std::conditional<VEC == 4, uint4, uint2>::type;
     const int64_t base = (int64_t)c * d.stride_c + p0;
-    float4 vq4;
-    int4 vi4;
+    float vq[VEC];
+    int vi[VEC];
     if (d.sym) {
-      vi4 = *reinterpret_cast<const int4 *>(d.sym + (int64_t)c * hw + p0);
-      vq4 = make_float4((float)vi4.x, (float)vi4.y, (float)vi4.z, (float)vi4.w);
+      const iv t = *reinterpret_cast<const iv *>(d.sym + (int64_t)c * hw + p0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        vi[e] = (&t.x)[e];
+        vq[e] = (float)vi[e];
+      }
     } else {
-      const float4 yv = *reinterpret_cast<const float4 *>(d.y + (int64_t)c * hw + p0);
-      vq4 = make_float4(__builtin_rintf(yv.x), __builtin_rintf(yv.y), __builtin_rintf(yv.z), __builtin_rintf(yv.w));
-      vi4 = make_int4((int)vq4.x, (int)vq4.y, (int)vq4.z, (int)vq4.w);
+      const fv t = *reinterpret_cast<const fv *>(d.y + (int64_t)c * hw + p0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        vq[e] = __builtin_rintf((&t.x)[e]);
+        vi[e] = (int)vq[e];
+      }
     }
-    float4 S[4], Mu[4], Pi[4];
+    fv S[4], Mu[4], Pi[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      S[k] = *reinterpret_cast<const float4 *>(d.scales + base + k * d.stride_k);
-      Mu[k] = *reinterpret_cast<const float4 *>(d.means + base + k * d.stride_k);
-      Pi[k] = *reinterpret_cast<const float4 *>(d.weights + base + k * d.stride_k);
+      S[k] = *reinterpret_cast<const fv *>(d.scales + base + k * d.stride_k);
+      Mu[k] = *reinterpret_cast<const fv *>(d.means + base + k * d.stride_k);
+      Pi[k] = *reinterpret_cast<const fv *>(d.weights + base + k * d.stride_k);
     }
-    uint32_t out[4];
+    uv out;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < VEC; ++e) {
       float mu[4], sg[4], pi[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -179,10 +201,10 @@ __global__ __launch_bounds__(kBlock) void symtab_kernel(const EncDesc *__restric
         pi[k] = (&Pi[k].x)[e];
       }
       int bp;
-      out[e] = sym_entry<MODE, CLAMPED>((&vq4.x)[e], (&vi4.x)[e], mu, sg, pi, bp);
+      (&out.x)[e] = sym_entry<MODE, CLAMPED>(vq[e], vi[e], mu, sg, pi, bp);
       nbypass += bp;
     }
-    *reinterpret_cast<uint4 *>(d.packed + (int64_t)rank * hw + p0) = make_uint4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<uv *>(d.packed + (int64_t)rank * hw + p0) = out;
   } else {
     const int64_t base = (int64_t)c * d.stride_c + p0 * d.stride_p;
     float vq;
@@ -268,8 +290,15 @@ __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restric
   }
   auto edge = [&](int j) -> uint32_t { // F[v = j - max_bs]
     const float x = (float)(j - d.max_bs) - 0.5f;
-    if constexpr (CLAMPED) return quant16(mix4_clamped<MODE>(x, mu, sg, rs, pi));
-    else return quant16(mix4<MODE>(x, mu, sg, pi));
+    if constexpr (CLAMPED) {
+      bool ok = true;
+      float c = mix4_clamped<MODE>(x, mu, sg, rs, pi, ok);
+      if (__builtin_expect(!ok, 0))
+        c = mix4_slow<MODE>(x, mu[0], mu[1], mu[2], mu[3], sg[0], sg[1], sg[2], sg[3], pi[0], pi[1], pi[2], pi[3]);
+      return quant16(c);
+    } else {
+      return quant16(mix4<MODE>(x, mu, sg, pi));
+    }
   };
   const int max_bs = d.max_bs;
   const int W = 2 * max_bs + 2;
@@ -479,12 +508,14 @@ static int launch_symtab_v(const EncDesc *d, int count, int M_max, int64_t hw_ma
   return launch_err();
 }
 
-int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, bool vec4, bool clamped,
+int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, int vec, bool clamped,
                   void *stream) {
   if (count <= 0 || M_max <= 0 || hw_max <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (vec4) return clamped ? launch_symtab_v<4, true>(d_descs, count, M_max, hw_max, mode, s)
-                           : launch_symtab_v<4, false>(d_descs, count, M_max, hw_max, mode, s);
+  if (vec == 4) return clamped ? launch_symtab_v<4, true>(d_descs, count, M_max, hw_max, mode, s)
+                               : launch_symtab_v<4, false>(d_descs, count, M_max, hw_max, mode, s);
+  if (vec == 2) return clamped ? launch_symtab_v<2, true>(d_descs, count, M_max, hw_max, mode, s)
+                               : launch_symtab_v<2, false>(d_descs, count, M_max, hw_max, mode, s);
   return clamped ? launch_symtab_v<1, true>(d_descs, count, M_max, hw_max, mode, s)
                  : launch_symtab_v<1, false>(d_descs, count, M_max, hw_max, mode, s);
 }

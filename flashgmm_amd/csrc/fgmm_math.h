@@ -69,18 +69,20 @@ __device__ __forceinline__ float div_core(float a, float d, float r) {
 }
 __device__ __forceinline__ bool tame(float a) { return __builtin_fabsf(a) < 0x1p60f; } // false for NaN / inf
 
-// a / d for a clamped denominator (sigma in [0.11, 256], or NaN which propagates either way)
+// a / d for a clamped denominator (sigma in [0.11, 256], or NaN which propagates either way) — guarded form
 __device__ __forceinline__ float div_clamped(float a, float d, float r) {
   float q = div_core(a, d, r);
   if (__builtin_expect(!tame(a), 0)) q = a / d;
   return q;
 }
-// 1 / d for d >= 1 (d = 1 + something non-negative), any magnitude, NaN
+// 1 / d for d >= 1 (d = 1 + something non-negative), any magnitude, NaN — guarded form
 __device__ __forceinline__ float rcp_ge1(float d) {
   float q = div_core(1.0f, d, rcp_refined(d));
   if (__builtin_expect(!tame(d), 0)) q = 1.0f / d;
   return q;
 }
+// 1 / d for 1 <= d < 2^60 — unguarded (the caller has established the bound)
+__device__ __forceinline__ float rcp_ge1_tame(float d) { return div_core(1.0f, d, rcp_refined(d)); }
 // sqrt for x in {+0} U [2^-96, 2^96], negative or NaN (-> NaN): v_sqrt_f32 is within 1 ulp, the two fma probes
 // pick the correctly rounded neighbour (the un-scaled core of hipcc's own lowering)
 __device__ __forceinline__ float sqrt_core(float x) {
@@ -113,7 +115,8 @@ template <bool FAST> struct Phi<MODE_AS, FAST> {
     const float az = bits2f(f2bits(z) & 0x7fffffffu);
     const float zx = 0.3989422804014327f * exp_ref((z * z) * -0.5f);
     const float d = __builtin_fmaf(0.2316419f, az, 1.0f);
-    const float t = FAST ? rcp_ge1(d) : 1.0f / d;
+    // FAST callers guarantee |z| < 2^48 (|x - mu| < 2^40, sigma >= 0.11), hence d < 2^60
+    const float t = FAST ? rcp_ge1_tame(d) : 1.0f / d;
     float poly = __builtin_fmaf(1.330274429f, t, -1.821255978f);
     poly = __builtin_fmaf(poly, t, 1.781477937f);
     poly = __builtin_fmaf(poly, t, -0.356563782f);
@@ -146,14 +149,26 @@ __device__ __forceinline__ float mix4(float x, const float (&mu)[4], const float
 }
 
 // Same value, for CLAMPED sigma (entropy-model path), with the refined reciprocals rs[k] = rcp_refined(sg[k])
-// computed once per latent and reused for every abscissa.
+// computed once per latent and reused for every abscissa.  Branch-free: `ok` comes back false when some
+// |x - mu_k| is not < 2^40 (huge / inf / NaN mean) — the caller then discards the value and takes mix4_slow.
 template <int MODE>
 __device__ __forceinline__ float mix4_clamped(float x, const float (&mu)[4], const float (&sg)[4], const float (&rs)[4],
-                                              const float (&pi)[4]) {
+                                              const float (&pi)[4], bool &ok) {
   float p[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) p[k] = pi[k] * Phi<MODE, true>::eval(div_clamped(x - mu[k], sg[k], rs[k]));
+  for (int k = 0; k < 4; ++k) {
+    const float a = x - mu[k];
+    ok = ok && (__builtin_fabsf(a) < 0x1p40f);
+    p[k] = pi[k] * Phi<MODE, true>::eval(div_core(a, sg[k], rs[k]));
+  }
   return (p[0] + p[1]) + (p[2] + p[3]);
+}
+// out-of-line IEEE evaluation for the rare latent the fast cores do not cover
+template <int MODE>
+__device__ __noinline__ float mix4_slow(float x, float m0, float m1, float m2, float m3, float s0, float s1, float s2, float s3,
+                                        float w0, float w1, float w2, float w3) {
+  const float mu[4] = {m0, m1, m2, m3}, sg[4] = {s0, s1, s2, s3}, pi[4] = {w0, w1, w2, w3};
+  return mix4<MODE>(x, mu, sg, pi);
 }
 
 // static_cast<uint16_t>(float) as x86-64 GCC emits it (cvttss2si r32 ; movzwl), rans_interface.cpp:509-510.
