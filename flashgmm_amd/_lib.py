@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("FGMM_LIB") or os.path.join(HERE, "libflashgmm_amd.so"
 FGMM_OK = 0
 FGMM_HOST, FGMM_DEVICE = 0, 1
 FGMM_K = 4
+FGMM_F32, FGMM_F16 = 0, 1
 MODES = {"polya": 0, "as": 1, "logistic": 2}  # numbering of the reference CODE (rans_interface.cpp:224-232)
 
 STATUS_NAMES = {1: "FGMM_ERR_INVALID", 2: "FGMM_ERR_NO_DEVICE", 3: "FGMM_ERR_HIP", 4: "FGMM_ERR_NOMEM",
@@ -28,7 +29,7 @@ class FgmmError(RuntimeError):
 
 class fgmm_params(C.Structure):
     _fields_ = [("scales", C.c_void_p), ("means", C.c_void_p), ("weights", C.c_void_p),
-                ("stride_k", C.c_int64), ("stride_c", C.c_int64)]
+                ("stride_k", C.c_int64), ("stride_c", C.c_int64), ("dtype", C.c_int32), ("reserved", C.c_int32)]
 
 
 class fgmm_item(C.Structure):

@@ -254,9 +254,11 @@ bool mode_ok(int mode) { return mode >= 0 && mode <= 2; }
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // can item use the 16-B-per-lane symtab kernel?
-bool enc_vec4_ok(const EncDesc &d) {
-  return d.stride_p == 1 && (d.hw & 3) == 0 && (d.stride_c & 3) == 0 && (d.stride_k & 3) == 0 && aligned16(d.scales) &&
-         aligned16(d.means) && aligned16(d.weights) && (d.y ? aligned16(d.y) : aligned16(d.sym)) && aligned16(d.packed);
+bool enc_vec4_ok(const EncDesc &d, bool f16) {
+  const uintptr_t pm = f16 ? 7 : 15; // 4 parameters per load: 8 B (fp16) or 16 B (fp32)
+  auto al = [pm](const void *p) { return (reinterpret_cast<uintptr_t>(p) & pm) == 0; };
+  return d.stride_p == 1 && (d.hw & 3) == 0 && (d.stride_c & 3) == 0 && (d.stride_k & 3) == 0 && al(d.scales) &&
+         al(d.means) && al(d.weights) && (d.y ? aligned16(d.y) : aligned16(d.sym)) && aligned16(d.packed);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -331,7 +333,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     d.chan_nz = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_nz) : nullptr;
     d.packed = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_packed);
     d.meta = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_meta);
-    vec4 = vec4 && enc_vec4_ok(d);
+    vec4 = vec4 && enc_vec4_ok(d, it.prm.dtype == FGMM_F16);
     any_y = any_y || it.y;
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs, hd, sizeof(EncDesc) * count, hipMemcpyHostToDevice, stream));
@@ -345,7 +347,8 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   }
   if ((rc = ctx->prof_begin(0, stream))) return rc;
   static const int force_vec = getenv("FGMM_VEC") ? atoi(getenv("FGMM_VEC")) : 0; // dev: A/B the load width
-  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4 ? (force_vec ? force_vec : 4) : 1, items[0].clamp != 0, stream));
+  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4 ? (force_vec ? force_vec : 4) : 1, items[0].clamp != 0,
+                           items[0].prm.dtype == FGMM_F16, stream));
   if ((rc = ctx->prof_end(0, stream))) return rc;
   // ---- tables back to the host: small region first, then one copy + event per item ----------------
   HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_small, ctx->d_ws + o_small, small_bytes, hipMemcpyDeviceToHost, stream));
@@ -536,7 +539,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       hw_max = std::max(hw_max, items[i].hw);
     }
     LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs) + i0, i1 - i0, n_ch_max, hw_max, mode,
-                             items[0].clamp != 0, stream));
+                             items[0].clamp != 0, items[0].prm.dtype == FGMM_F16, stream));
     HIP_TRY(hipEventRecord(ev_kernel[g], stream));
     HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_kernel[g], 0));
     HIP_TRY(hipMemcpyAsync(ctx->h_ws + items[i0].o_used, ctx->d_ws + items[i0].o_used, 16 * (size_t)(i1 - i0),
@@ -726,6 +729,8 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
     if (s.K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", s.K);
     if (s.M < 0 || s.hw < 0 || (s.M * s.hw && (!s.y || !s.params.scales || !s.params.means || !s.params.weights)))
       return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
+    if (s.params.dtype != items[0].params.dtype || (s.params.dtype != FGMM_F32 && s.params.dtype != FGMM_F16))
+      return fail(FGMM_ERR_INVALID, "item %d: parameter dtype must be FGMM_F32 or FGMM_F16 and the same for a whole batch", i);
     EncItem &e = v[i];
     e.y = s.y;
     e.prm = s.params;
@@ -778,6 +783,8 @@ int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int
     if (s.M < 0 || s.hw < 0 || !s.bytes || !s.zero_bitmap || !s.yq_out ||
         (s.M * s.hw && (!s.params.scales || !s.params.means || !s.params.weights)))
       return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
+    if (s.params.dtype != items[0].params.dtype || (s.params.dtype != FGMM_F32 && s.params.dtype != FGMM_F16))
+      return fail(FGMM_ERR_INVALID, "item %d: parameter dtype must be FGMM_F32 or FGMM_F16 and the same for a whole batch", i);
     DecItem &d = v[i];
     d.enc = s.bytes;
     d.enc_len = s.bytes_len;
@@ -884,7 +891,7 @@ int fgmm_encode_with_indexes_gmm(fgmm_ctx *ctx, const int32_t *symbols, const fl
   EncItem &e = v[0];
   e.sym_dev = sym_dev;
   e.sym_host = memspace == FGMM_HOST ? symbols : nullptr;
-  e.prm = {r.s, r.m, r.w, r.stride_k, 0};
+  e.prm = {r.s, r.m, r.w, r.stride_k, 0, FGMM_F32, 0};
   e.stride_p = r.stride_n;
   e.M = 1;
   e.hw = n;
@@ -915,7 +922,7 @@ int fgmm_decode_with_indexes_gmm(fgmm_ctx *ctx, const uint8_t *encoded, size_t e
   DecItem &d = v[0];
   d.enc = encoded;
   d.enc_len = encoded_len;
-  d.prm = {r.s, r.m, r.w, r.stride_k, 0};
+  d.prm = {r.s, r.m, r.w, r.stride_k, 0, FGMM_F32, 0};
   d.stride_p = r.stride_n;
   d.M = 1;
   d.hw = n;
@@ -961,7 +968,7 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
-  LAUNCH_TRY(launch_symtab(reinterpret_cast<const EncDesc *>(ctx->d_ws), 1, 1, n, mode, enc_vec4_ok(*hd) ? 4 : 1, false, s));
+  LAUNCH_TRY(launch_symtab(reinterpret_cast<const EncDesc *>(ctx->d_ws), 1, 1, n, mode, enc_vec4_ok(*hd, false) ? 4 : 1, false, false, s));
   HIP_TRY(hipStreamSynchronize(s));
   return FGMM_OK;
 }
@@ -995,7 +1002,7 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   hd->pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + 1024);
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
-  if (n) LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, 1, n, mode, (flags & FGMM_TAB_CLAMP) != 0, s));
+  if (n) LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, 1, n, mode, (flags & FGMM_TAB_CLAMP) != 0, false, s));
   unsigned long long used[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(used, ctx->d_ws + 1024, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));

@@ -18,7 +18,7 @@ struct EncDesc {
   // inputs (device)
   const float *y;        // [M*hw] latents, rounded by the kernel;   null when `sym` is given
   const int32_t *sym;    // raw-boundary form: symbols given, [hw] with M == 1
-  const float *scales, *means, *weights;
+  const void *scales, *means, *weights; // float32 or float16 planes (the launcher picks the kernel)
   int64_t stride_k, stride_c, stride_p; // elements
   int64_t hw;
   int32_t M;
@@ -33,7 +33,7 @@ struct EncDesc {
 };
 
 struct DecDesc {
-  const float *scales, *means, *weights;
+  const void *scales, *means, *weights; // float32 or float16 planes
   int64_t stride_k, stride_c, stride_p;
   int64_t hw;
   const int32_t *chan_list; // device [n_ch] source channel of compact channel j; null: identity
@@ -60,10 +60,11 @@ FGMM_HD static inline uint64_t hdr_off(uint64_t h) { return (h >> 32) << 2; }
 // ---- kernel launchers (fgmm_kernels.hip); stream is a hipStream_t; all return hipError_t as int ----------
 int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *stream);
 int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, int vec, bool clamped,
-                  void *stream);
+                  bool f16, void *stream);
 int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
                     int64_t stride_n, int64_t stride_k, int mode, float *c1, float *c2, void *stream);
-int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, void *stream);
+int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                  void *stream);
 int launch_fastmath_selftest(int which, unsigned long long n, unsigned long long seed, unsigned long long *n_bad, void *stream);
 // exhaustive check of the saturation lemmas behind the pruning; *n_bad (device) receives the number of violations
 int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream);

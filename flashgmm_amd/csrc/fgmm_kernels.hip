@@ -12,8 +12,6 @@
 // (k, c, p) layout.  Wave = 64 lanes throughout.
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "fgmm_internal.h"
 #include "fgmm_math.h"
 
@@ -33,6 +31,22 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// parameter planes are float32, or float16 converted on load (BASELINE configs[4]: "fp16 (mu,sigma,pi) with fp32 CDF
+// accumulate"): every value is widened exactly, then the fp32 path runs unchanged
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+template <typename PT> __device__ __forceinline__ float ld1(const void *base, int64_t idx) {
+  return (float)static_cast<const PT *>(base)[idx];
+}
+template <typename PT> __device__ __forceinline__ void ld4(const void *base, int64_t idx, float (&out)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const void *base, int64_t idx, float (&out)[4]) {
+  const float4 v = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + idx); // 16 B / lane
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <> __device__ __forceinline__ void ld4<_Float16>(const void *base, int64_t idx, float (&out)[4]) {
+  const half4_t v = *reinterpret_cast<const half4_t *>(static_cast<const _Float16 *>(base) + idx); // 8 B / lane
+  out[0] = (float)v[0]; out[1] = (float)v[1]; out[2] = (float)v[2]; out[3] = (float)v[3];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -132,7 +146,7 @@ __device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu
 #ifndef FGMM_SYMTAB_WAVES
 #define FGMM_SYMTAB_WAVES 5 // min waves per SIMD the register allocator must leave room for (<= 96 VGPRs)
 #endif
-template <int MODE, int VEC, bool CLAMPED>
+template <int MODE, int VEC, bool CLAMPED, typename PT>
 __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const EncDesc *__restrict__ descs) {
   const EncDesc &d = descs[blockIdx.z];
   const int c = blockIdx.y;
@@ -160,51 +174,48 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
 
   int nbypass = 0;
   if (!active) {
-  } else if constexpr (VEC == 4 || VEC == 2) {
-    // planar, 4*VEC-byte aligned (checked by the host): one VEC-wide load per plane per lane
-    using fv = typename std::conditional<VEC == 4, float4, float2>::type;
-    using iv = typename std::conditional<VEC == 4, int4, int2>::type;
-    using uv = typename std::conditional<VEC == 4, uint4, uint2>::type;
+  } else if constexpr (VEC == 4) {
+    // planar, aligned (checked by the host): one 4-wide load per plane per lane (16 B fp32 / 8 B fp16)
     const int64_t base = (int64_t)c * d.stride_c + p0;
-    float vq[VEC];
-    int vi[VEC];
+    float vq[4];
+    int vi[4];
     if (d.sym) {
-      const iv t = *reinterpret_cast<const iv *>(d.sym + (int64_t)c * hw + p0);
+      const int4 t = *reinterpret_cast<const int4 *>(d.sym + (int64_t)c * hw + p0);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
+      for (int e = 0; e < 4; ++e) {
         vi[e] = (&t.x)[e];
         vq[e] = (float)vi[e];
       }
     } else {
-      const fv t = *reinterpret_cast<const fv *>(d.y + (int64_t)c * hw + p0);
+      const float4 t = *reinterpret_cast<const float4 *>(d.y + (int64_t)c * hw + p0);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
+      for (int e = 0; e < 4; ++e) {
         vq[e] = __builtin_rintf((&t.x)[e]);
         vi[e] = (int)vq[e];
       }
     }
-    fv S[4], Mu[4], Pi[4];
+    float S[4][4], Mu[4][4], Pi[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      S[k] = *reinterpret_cast<const fv *>(d.scales + base + k * d.stride_k);
-      Mu[k] = *reinterpret_cast<const fv *>(d.means + base + k * d.stride_k);
-      Pi[k] = *reinterpret_cast<const fv *>(d.weights + base + k * d.stride_k);
+      ld4<PT>(d.scales, base + k * d.stride_k, S[k]);
+      ld4<PT>(d.means, base + k * d.stride_k, Mu[k]);
+      ld4<PT>(d.weights, base + k * d.stride_k, Pi[k]);
     }
-    uv out;
+    uint4 out;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
+    for (int e = 0; e < 4; ++e) {
       float mu[4], sg[4], pi[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        sg[k] = (&S[k].x)[e];
-        mu[k] = (&Mu[k].x)[e];
-        pi[k] = (&Pi[k].x)[e];
+        sg[k] = S[k][e];
+        mu[k] = Mu[k][e];
+        pi[k] = Pi[k][e];
       }
       int bp;
       (&out.x)[e] = sym_entry<MODE, CLAMPED>(vq[e], vi[e], mu, sg, pi, bp);
       nbypass += bp;
     }
-    *reinterpret_cast<uv *>(d.packed + (int64_t)rank * hw + p0) = out;
+    *reinterpret_cast<uint4 *>(d.packed + (int64_t)rank * hw + p0) = out;
   } else {
     const int64_t base = (int64_t)c * d.stride_c + p0 * d.stride_p;
     float vq;
@@ -219,9 +230,9 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
     float mu[4], sg[4], pi[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      sg[k] = d.scales[base + k * d.stride_k];
-      mu[k] = d.means[base + k * d.stride_k];
-      pi[k] = d.weights[base + k * d.stride_k];
+      sg[k] = ld1<PT>(d.scales, base + k * d.stride_k);
+      mu[k] = ld1<PT>(d.means, base + k * d.stride_k);
+      pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
     }
     int bp;
     d.packed[(int64_t)rank * hw + p0] = sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp);
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void cdf_pair_kernel(const int32_t *__restr
 //   pass 2: re-evaluate only the window and store it (8 B per store), then the 8-byte header.
 // Transcendental-VALU bound (about 200 VALU ops per edge), not HBM bound: 48 B in per latent.
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE, bool CLAMPED>
+template <int MODE, bool CLAMPED, typename PT>
 __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restrict__ descs) {
   const DecDesc &d = descs[blockIdx.z];
   const int cj = blockIdx.y;
@@ -281,11 +292,11 @@ __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restric
     const int64_t base = (int64_t)c * d.stride_c + (active ? p : 0) * d.stride_p;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float s = d.scales[base + k * d.stride_k];
+      const float s = ld1<PT>(d.scales, base + k * d.stride_k);
       sg[k] = CLAMPED ? clamp_scale(s) : s;
       rs[k] = CLAMPED ? rcp_refined(sg[k]) : 0.0f; // one refined reciprocal per component for the whole row
-      mu[k] = d.means[base + k * d.stride_k];
-      pi[k] = d.weights[base + k * d.stride_k];
+      mu[k] = ld1<PT>(d.means, base + k * d.stride_k);
+      pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
     }
   }
   auto edge = [&](int j) -> uint32_t { // F[v = j - max_bs]
@@ -496,28 +507,31 @@ int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *strea
   return launch_err();
 }
 
-template <int VEC, bool CLAMPED>
+template <int VEC, bool CLAMPED, typename PT>
 static int launch_symtab_v(const EncDesc *d, int count, int M_max, int64_t hw_max, int mode, hipStream_t s) {
   const int64_t per_block = (int64_t)kBlock * VEC;
   dim3 grid((unsigned)((hw_max + per_block - 1) / per_block), (unsigned)M_max, (unsigned)count);
   switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((symtab_kernel<MODE_AS, VEC, CLAMPED>), grid, dim3(kBlock), 0, s, d); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((symtab_kernel<MODE_LOGISTIC, VEC, CLAMPED>), grid, dim3(kBlock), 0, s, d); break;
-  default: hipLaunchKernelGGL((symtab_kernel<MODE_POLYA, VEC, CLAMPED>), grid, dim3(kBlock), 0, s, d); break;
+  case MODE_AS: hipLaunchKernelGGL((symtab_kernel<MODE_AS, VEC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((symtab_kernel<MODE_LOGISTIC, VEC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d); break;
+  default: hipLaunchKernelGGL((symtab_kernel<MODE_POLYA, VEC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d); break;
   }
   return launch_err();
 }
+template <typename PT>
+static int launch_symtab_t(const EncDesc *d, int count, int M_max, int64_t hw_max, int mode, int vec, bool clamped, hipStream_t s) {
+  if (vec == 4) return clamped ? launch_symtab_v<4, true, PT>(d, count, M_max, hw_max, mode, s)
+                               : launch_symtab_v<4, false, PT>(d, count, M_max, hw_max, mode, s);
+  return clamped ? launch_symtab_v<1, true, PT>(d, count, M_max, hw_max, mode, s)
+                 : launch_symtab_v<1, false, PT>(d, count, M_max, hw_max, mode, s);
+}
 
 int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, int vec, bool clamped,
-                  void *stream) {
+                  bool f16, void *stream) {
   if (count <= 0 || M_max <= 0 || hw_max <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (vec == 4) return clamped ? launch_symtab_v<4, true>(d_descs, count, M_max, hw_max, mode, s)
-                               : launch_symtab_v<4, false>(d_descs, count, M_max, hw_max, mode, s);
-  if (vec == 2) return clamped ? launch_symtab_v<2, true>(d_descs, count, M_max, hw_max, mode, s)
-                               : launch_symtab_v<2, false>(d_descs, count, M_max, hw_max, mode, s);
-  return clamped ? launch_symtab_v<1, true>(d_descs, count, M_max, hw_max, mode, s)
-                 : launch_symtab_v<1, false>(d_descs, count, M_max, hw_max, mode, s);
+  return f16 ? launch_symtab_t<_Float16>(d_descs, count, M_max, hw_max, mode, vec, clamped, s)
+             : launch_symtab_t<float>(d_descs, count, M_max, hw_max, mode, vec, clamped, s);
 }
 
 int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
@@ -533,21 +547,25 @@ int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, c
   return launch_err();
 }
 
-template <bool CLAMPED>
+template <bool CLAMPED, typename PT>
 static int launch_cdftab_c(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, hipStream_t s) {
   dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)n_ch_max, (unsigned)count);
   switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((cdftab_kernel<MODE_AS, CLAMPED>), grid, dim3(kBlock), 0, s, d_descs); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((cdftab_kernel<MODE_LOGISTIC, CLAMPED>), grid, dim3(kBlock), 0, s, d_descs); break;
-  default: hipLaunchKernelGGL((cdftab_kernel<MODE_POLYA, CLAMPED>), grid, dim3(kBlock), 0, s, d_descs); break;
+  case MODE_AS: hipLaunchKernelGGL((cdftab_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((cdftab_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs); break;
+  default: hipLaunchKernelGGL((cdftab_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs); break;
   }
   return launch_err();
 }
 
-int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, void *stream) {
+int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                  void *stream) {
   if (count <= 0 || n_ch_max <= 0 || hw_max <= 0) return 0;
-  return clamped ? launch_cdftab_c<true>(d_descs, count, n_ch_max, hw_max, mode, (hipStream_t)stream)
-                 : launch_cdftab_c<false>(d_descs, count, n_ch_max, hw_max, mode, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (f16) return clamped ? launch_cdftab_c<true, _Float16>(d_descs, count, n_ch_max, hw_max, mode, s)
+                          : launch_cdftab_c<false, _Float16>(d_descs, count, n_ch_max, hw_max, mode, s);
+  return clamped ? launch_cdftab_c<true, float>(d_descs, count, n_ch_max, hw_max, mode, s)
+                 : launch_cdftab_c<false, float>(d_descs, count, n_ch_max, hw_max, mode, s);
 }
 
 int launch_fastmath_selftest(int which, unsigned long long n, unsigned long long seed, unsigned long long *n_bad, void *stream) {

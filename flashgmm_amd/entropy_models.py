@@ -34,8 +34,8 @@ def _plane_view(t: Tensor, K: int) -> Tuple[Tensor, int, int]:
     dense; anything else is made contiguous first.  chunk(3, 1) views of the parameter head qualify as they are."""
     if t.dim() != 4 or t.size(0) != 1:
         raise RuntimeError("entropy parameters must be [1, K*M, h, w] (the reference squeezes batch 1 too, entropy_models.py:841)")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"entropy parameters must be float32, got {t.dtype}")
+    if t.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f"entropy parameters must be float32 or float16, got {t.dtype}")
     h, w = t.size(2), t.size(3)
     if not (t.stride(3) == 1 and t.stride(2) == w) and h * w > 1:
         t = t.contiguous()
@@ -84,13 +84,16 @@ class GaussianMixtureConditional(nn.Module):
         M = s.size(1) // self.K
         hw = s.size(2) * s.size(3)
         it = _lib.fgmm_item()
-        it.params = _lib.fgmm_params(s.data_ptr(), m.data_ptr(), w.data_ptr(), sk, sc)
+        if not (s.dtype == m.dtype == w.dtype):
+            raise RuntimeError("scales, means and weights must share one dtype")
+        it.params = _lib.fgmm_params(s.data_ptr(), m.data_ptr(), w.data_ptr(), sk, sc,
+                                     _lib.FGMM_F16 if s.dtype == torch.float16 else _lib.FGMM_F32, 0)
         it.M, it.K, it.hw = M, self.K, hw
         keep += [s, m, w]
         if y is not None:
             if y.dim() != 4 or y.size(0) != 1 or y.size(1) != M or y.size(2) * y.size(3) != hw:
                 raise RuntimeError(f"y must be [1, {M}, h, w] matching the parameters; got {tuple(y.shape)}")
-            if y.dtype != torch.float32 or y.device != s.device:
+            if y.dtype != torch.float32 or y.device != s.device:  # latents stay float32 (32 B/symbol with fp16 planes)
                 raise RuntimeError("y must be float32 on the parameters' device")
             yc = y.contiguous()
             it.y = yc.data_ptr()

@@ -105,9 +105,16 @@ int fgmm_decode_with_indexes_gmm(fgmm_ctx *ctx, const uint8_t *encoded, size_t e
  *    the library orders its own work after it and returns with all outputs complete.
  * ---------------------------------------------------------------------------------------------------------- */
 
+typedef enum { FGMM_F32 = 0, FGMM_F16 = 1 } fgmm_dtype;
+
 typedef struct {
-  const float *scales, *means, *weights; /* device */
+  const void *scales, *means, *weights;  /* device; float32 or IEEE float16 planes, see dtype */
   int64_t stride_k, stride_c;            /* elements */
+  int32_t dtype;                         /* fgmm_dtype.  FGMM_F16 (BASELINE configs[4]): each value is widened to
+                                            float32 exactly on load, then the float32 path runs unchanged — the result
+                                            is that of the reference fed the widened values (the reference itself
+                                            rejects half tensors: accessor<float,2>, rans_interface.cpp:478-480) */
+  int32_t reserved;
 } fgmm_params;
 
 /* compress(y, scales, means, weights) -> ((bytes, abs_max, zero_bitmap), y_quantized)

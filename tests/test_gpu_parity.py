@@ -388,3 +388,51 @@ def test_batch_of_kodak_halves_full_size(mode):
     for seed in range(48):
         assert torch.equal(outs[seed], res[seed][1]), seed
         assert torch.equal(res[seed][1], torch.round(ys[seed]))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_fp16_parameter_planes(oracle, mode):
+    """BASELINE configs[4]: fp16 (mu, sigma, pi), fp32 CDF.  Result == the reference path fed the widened values."""
+    for seed, (M, h, w) in ((41, (32, 16, 12)), (42, (7, 5, 3))):  # 8-B vector loads, and the scalar kernel
+        y, sg, mu, pi = T.make_latent(seed, M=M, h=h, w=w, clamp=False, zero_frac=0.1)
+        sg16, mu16, pi16 = (a.astype(np.float16) for a in (sg, mu, pi))
+        gmc = GaussianMixtureConditional(K=4, mode=mode)
+        t16 = [dv(a) for a in (sg16, mu16, pi16)]
+        assert t16[0].dtype == torch.float16
+        (b, abs_max, zb), yq = gmc.compress(dv(y), *t16)
+        sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, *(a.astype(np.float32) for a in (sg16, mu16, pi16)))
+        assert b == oracle.encode_gmm(mode, sym, s, m, wt) and abs_max == am
+        assert torch.equal(gmc.decompress(b, abs_max, zb, *t16), yq)
+
+
+def test_elic_channel_group_shapes(oracle):
+    """BASELINE configs[4] geometry: ELIC groups of 16/16/32 channels of a 4K latent (h*w = 136*120 per half);
+    the 64- and 192-channel groups go through the same code and are covered by the round-trip property."""
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    ys, ss, ms, ws, host = [], [], [], [], []
+    for seed, M in ((51, 16), (52, 16), (53, 32), (54, 64), (55, 192)):
+        y, sg, mu, pi = T.make_latent(seed, M=M, h=136, w=120, clamp=False)
+        host.append((y, sg, mu, pi))
+        ys.append(dv(y)); ss.append(dv(sg)); ms.append(dv(mu)); ws.append(dv(pi))
+    res = gmc.compress_batch(ys, ss, ms, ws)  # ragged batch: M differs per item
+    for i in range(3):
+        sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(*host[i])
+        (b, abs_max, zb), yq = res[i]
+        assert b == oracle.encode_gmm("polya", sym, s, m, wt) and abs_max == am and zb.tolist() == zbm.tolist()
+    outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+    for i in range(len(res)):
+        assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(ys[i]))
+
+
+def test_config0_256x256_plumbing(oracle):
+    """BASELINE configs[0]: one 256x256 image -> y [1,192,16,16], halves [1,192,16,8]; all three modes."""
+    for mode in MODES:
+        gmc = GaussianMixtureConditional(K=4, mode=mode)
+        for half in range(2):
+            y, sg, mu, pi = T.make_latent(1234 + half, M=192, h=16, w=8)
+            t = [dv(a) for a in (y, sg, mu, pi)]
+            (b, abs_max, zb), yq = gmc.compress(*t)
+            sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi)
+            assert b == oracle.encode_gmm(mode, sym, s, m, wt)
+            assert np.array_equal(oracle.decode_gmm(mode, b, s, m, wt, am + 1), sym)  # the reference's own decoder agrees
+            assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq)
