@@ -67,3 +67,13 @@ def to_coder_inputs(y, scales, means, weights, K: int = 4, clamp: bool = True):
     if clamp:
         s = np.clip(s, np.float32(0.11), np.float32(256))
     return symbols, s, m, wt, abs_max, zero_bitmap, yq
+
+
+def to_float16_planes(scales, means, weights):
+    """fp16 copies of the parameter planes for BASELINE configs[4].  Weights are rounded TOWARD ZERO: the reference
+    algorithm needs sum_k pi_k <= 1 after widening (a quantised CDF edge above 65535 wraps, rans_interface.cpp:509-512,
+    and the stream desynchronises — in the reference exactly as here); round-to-nearest fp16 weights can sum to more."""
+    w16 = weights.astype(np.float16)
+    over = w16.astype(np.float32) > weights
+    w16[over] = np.nextafter(w16[over], np.float16(0))
+    return scales.astype(np.float16), means.astype(np.float16), w16
