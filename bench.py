@@ -33,30 +33,44 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PIX_PER_IMAGE = 768 * 512
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-BYTES_PER_SYMBOL = 56  # 4 (y) + 3*4*4 (sigma, mu, pi) in + 4 out
+# algorithmic bytes per coded symbol of the symtab kernel: 4 (y) + 3*4*{4|2} (sigma, mu, pi) in + 4 out
 
 
-def make_workload(rank: int, images: int, dev):
+ELIC_GROUPS = (16, 16, 32, 64, 192)  # elic_gmm.py:92-96
+
+
+def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: bool = False):
+    """-> (host arrays per stream, device tensors per stream, pixels per image).
+    kodak24: 2 streams per image, [1,192,32,24]; elic4k: 10 streams per image (5 channel groups x 2 halves of a
+    3840x2160 image padded to 2176 rows -> y [1,320,136,240], SURVEY.md §8 sizes)."""
     from flashgmm_amd import testing as T
 
     host, devt = [], []
-    for i in range(images * 2):
-        arrs = T.make_latent(1000 * rank + i)  # [1,192,32,24] + 3 x [1,768,32,24]; sigma pre-clamped as KA-1
-        host.append(arrs)
-        devt.append([torch.from_numpy(a).to(dev) for a in arrs])
-    return host, devt
+    if workload == "kodak24":
+        shapes = [(192, 32, 24)] * 2
+        pix = 768 * 512
+    else:
+        shapes = [(g, 136, 120) for g in ELIC_GROUPS for _ in range(2)]
+        pix = 3840 * 2160
+    for i in range(images):
+        for j, (M, h, w) in enumerate(shapes):
+            y, sg, mu, pi = T.make_latent(1000 * rank + i * len(shapes) + j, M=M, h=h, w=w)  # sigma pre-clamped as KA-1
+            if f16:
+                sg, mu, pi = T.to_float16_planes(sg, mu, pi)
+            host.append((y, sg, mu, pi))
+            devt.append([torch.from_numpy(a).to(dev) for a in (y, sg, mu, pi)])
+    return host, devt, pix
 
 
-def cpu_baseline(host, budget_s: float = 12.0):
+def cpu_baseline(host, pix_per_image: int, streams_per_image: int, budget_s: float = 12.0):
     """Time the reference's own coder on ONE core of this box on the same images (bounded sample)."""
     from flashgmm_amd import testing as T
     from oracle import oracle as O
 
     prepared = []
     for y, sg, mu, pi in host:
-        sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+        sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, *(a.astype(np.float32) for a in (sg, mu, pi)))
         prepared.append((sym, s, m, w, abs_max))
     kind = "port"
     enc = dec = None
@@ -101,14 +115,14 @@ def cpu_baseline(host, budget_s: float = 12.0):
         assert np.array_equal(d, prepared[-1][0])
         best = dt if best is None else min(best, dt)
         passes += 1
-    n_img = len(prepared) // 2
+    n_img = len(prepared) // streams_per_image
     n_sym = sum(len(p[0]) for p in prepared)
     return {
-        "value": round(n_img * PIX_PER_IMAGE / best / 1e6, 3),
+        "value": round(n_img * pix_per_image / best / 1e6, 3),
         "unit": "Mpixels/s",
         "cores": 1,
         "kind": kind,
-        "sample": f"{n_img} Kodak-sized images x 2 halves ({n_sym} symbols), encode+decode, best of {passes} passes, "
+        "sample": f"{n_img} image(s) x {streams_per_image} streams ({n_sym} symbols), encode+decode, best of {passes} passes, "
                   f"{best * 1e3:.0f} ms/pass = {best / n_sym * 1e9:.0f} ns/symbol",
     }
 
@@ -118,7 +132,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--images", type=int, default=24)
+    ap.add_argument("--workload", default="kodak24", choices=["kodak24", "elic4k"])
+    ap.add_argument("--images", type=int, default=None, help="images per GPU (default 24 for kodak24, 1 for elic4k)")
+    ap.add_argument("--param-dtype", default=None, choices=["f32", "f16"], help="default f32 (kodak24) / f16 (elic4k)")
     ap.add_argument("--mode", default="polya", choices=["polya", "as", "logistic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -139,7 +155,12 @@ def main():
 
     from flashgmm_amd import GaussianMixtureConditional, _lib
 
-    host, devt = make_workload(rank, a.images, dev)
+    if a.images is None:
+        a.images = 24 if a.workload == "kodak24" else 1
+    f16 = (a.param_dtype or ("f32" if a.workload == "kodak24" else "f16")) == "f16"
+    host, devt, pix_per_image = make_workload(rank, a.images, dev, a.workload, f16)
+    streams_per_image = len(devt) // a.images
+    bytes_per_symbol = 32 if f16 else 56
     ys = [t[0] for t in devt]
     ss = [t[1] for t in devt]
     ms = [t[2] for t in devt]
@@ -167,7 +188,7 @@ def main():
     # correctness of what is being timed: decode(encode(y)) == round(y) for every stream of this rank
     for i in range(len(ys)):
         assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(ys[i])), f"stream {i} mismatch"
-    n_coded = sum(int(r[0][2].sum()) * ys[0].shape[2] * ys[0].shape[3] for r in res)
+    n_coded = sum(int(r[0][2].sum()) * y.shape[2] * y.shape[3] for r, y in zip(res, ys))
     total_bytes = sum(len(r[0][0]) for r in res)
 
     # a generational GC pass of the interpreter (tens of ms with torch loaded) is not part of the path
@@ -194,11 +215,12 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
-        value = world * a.images * PIX_PER_IMAGE * a.steps / dt / 1e6
+        value = world * a.images * pix_per_image * a.steps / dt / 1e6
         sym_ms = float(np.mean(k_sym))
-        achieved = n_coded * BYTES_PER_SYMBOL / (sym_ms * 1e-3) / 1e9
+        achieved = n_coded * bytes_per_symbol / (sym_ms * 1e-3) / 1e9
         out = {
-            "metric": "encode+decode Mpixels/s (Kodak, K=4 N=192)",
+            "metric": "encode+decode Mpixels/s (Kodak, K=4 N=192)" if a.workload == "kodak24"
+            else "encode+decode Mpixels/s (ELIC 4K, K=4, fp16 params)",
             "value": round(value, 2),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -208,22 +230,24 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",  # the CDF arithmetic; parameter planes: config.param_dtype
             "data": "synthetic",
-            "config": {"workload": "kodak24", "images_per_gpu": a.images, "streams_per_gpu": 2 * a.images,
-                       "latent_half": [1, 192, 32, 24], "K": 4, "approx_mode": a.mode,
+            "config": {"workload": a.workload, "images_per_gpu": a.images, "streams_per_gpu": len(ys),
+                       "stream_shapes": sorted({tuple(y.shape) for y in ys}), "K": 4, "approx_mode": a.mode,
+                       "param_dtype": "f16" if f16 else "f32",
                        "coded_symbols_per_gpu": n_coded, "bitstream_bytes_per_gpu": total_bytes,
                        "host_threads_per_gpu": _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank)),
                        "parallelism": f"images sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "symtab_kernel (encode-side GMM-CDF)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "launch_ms": round(sym_ms, 4), "bytes_per_launch": n_coded * BYTES_PER_SYMBOL},
+                         "launch_ms": round(sym_ms, 4), "bytes_per_launch": n_coded * bytes_per_symbol,
+                         "bytes_per_symbol": bytes_per_symbol},
             "kernels_ms": {"symtab": round(sym_ms, 4), "cdftab": round(float(np.mean(k_tab)), 4),
                            "quant_stats": round(float(np.mean(k_qs)), 4)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host)
+            out["cpu_baseline"] = cpu_baseline(host, pix_per_image, streams_per_image)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
