@@ -282,7 +282,7 @@ struct EncItem {
   size_t bytes_len = 0;
   int status = FGMM_OK;
   // workspace offsets
-  size_t o_min = 0, o_max = 0, o_nz = 0, o_meta = 0, o_packed = 0;
+  size_t o_min = 0, o_max = 0, o_nz = 0, o_list = 0, o_meta = 0, o_packed = 0;
 };
 
 int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items, int mode) {
@@ -299,6 +299,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     it.o_min = ar.take(sizeof(float) * it.M, 16);
     it.o_max = ar.take(sizeof(float) * it.M, 16);
     it.o_nz = ar.take(sizeof(int32_t) * it.M, 16);
+    it.o_list = ar.take(sizeof(int32_t) * ((size_t)it.M + 1), 16);
     it.o_meta = ar.take(16, 16);
     M_max = std::max(M_max, it.M);
     hw_max = std::max(hw_max, it.hw);
@@ -331,6 +332,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     d.chan_min = reinterpret_cast<float *>(ctx->d_ws + it.o_min);
     d.chan_max = reinterpret_cast<float *>(ctx->d_ws + it.o_max);
     d.chan_nz = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_nz) : nullptr;
+    d.chan_list = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_list) : nullptr;
     d.packed = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_packed);
     d.meta = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_meta);
     vec4 = vec4 && enc_vec4_ok(d, it.prm.dtype == FGMM_F16);

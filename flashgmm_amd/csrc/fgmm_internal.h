@@ -28,6 +28,7 @@ struct EncDesc {
   float *chan_min;       // [M]  min over the channel of y
   float *chan_max;       // [M]
   int32_t *chan_nz;      // [M]  any round(y) != 0
+  int32_t *chan_list;    // [M+1] compact index -> channel; [M] = number of non-zero channels (null: identity)
   uint32_t *packed;      // [n_nz*hw] start | range<<16, channels compacted
   unsigned long long *meta; // [0] = number of bypass symbols
 };

@@ -105,11 +105,44 @@ __global__ __launch_bounds__(kBlock) void quant_stats_kernel(const EncDesc *__re
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// chan_compact_kernel: one block per item; chan_nz[M] -> chan_list[j] = j-th non-zero channel, chan_list[M] = count.
+// (entropy_models.py:844 `nonzero`.)  Lets the CDF kernel find its channel with ONE wave-uniform scalar load
+// instead of a dependent global-load + block reduction in front of its parameter loads.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void chan_compact_kernel(const EncDesc *__restrict__ descs) {
+  const EncDesc &d = descs[blockIdx.x];
+  if (!d.chan_nz) return;
+  __shared__ int s_base;
+  __shared__ int s_wave[kBlock / 64];
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < d.M; c0 += kBlock) {
+    const int c = c0 + threadIdx.x;
+    const bool nz = c < d.M && d.chan_nz[c] != 0;
+    const unsigned long long m = __ballot(nz);
+    if (lane == 0) s_wave[w] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int i = 0; i < w; ++i) off += s_wave[i];
+    if (nz) d.chan_list[off + __popcll(m & ((1ull << lane) - 1ull))] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int i = 0; i < kBlock / 64; ++i) t += s_wave[i];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) d.chan_list[d.M] = s_base;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // symtab_kernel — THE encode-side CDF kernel.  Algorithmic traffic 56 B/latent at K = 4:
 //   4 (y or symbol) + 3*4*4 (sigma, mu, pi planes) in, 4 out (start | range << 16).
-// grid = (tiles over hw, channel, item); a block whose channel is all-zero exits at once; otherwise its output
-// row is the rank of the channel among the non-zero ones (entropy_models.py:844-845 channel compaction), found
-// from chan_nz without a host round trip.
+// grid = (tiles over hw, compact channel j, item): block j codes the j-th NON-ZERO channel (chan_list, built on the
+// device by chan_compact_kernel — entropy_models.py:844-845 channel compaction with no host round trip) and writes
+// row j of the table; blocks with j >= count leave after one scalar load.
 // VEC = 4: each lane owns 4 consecutive positions, every plane read is one 16-B load (1 KiB per wave-instr).
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE, bool CLAMPED>
@@ -149,26 +182,15 @@ __device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu
 template <int MODE, int VEC, bool CLAMPED, typename PT>
 __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const EncDesc *__restrict__ descs) {
   const EncDesc &d = descs[blockIdx.z];
-  const int c = blockIdx.y;
-  if (c >= d.M) return;
+  const int rank = blockIdx.y;
+  if (rank >= d.M) return;
   const int64_t hw = d.hw;
   const int64_t p0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
   if ((int64_t)blockIdx.x * kBlock * VEC >= hw) return;
-
-  int rank = c;
-  if (d.chan_nz) {
-    if (d.chan_nz[c] == 0) return; // wave-uniform: the whole block leaves
-    // rank of channel c among the non-zero channels (M is a few hundred at most)
-    int cnt = 0;
-    for (int i = threadIdx.x; i < c; i += kBlock) cnt += d.chan_nz[i] != 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    __shared__ int s_cnt[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    rank = 0;
-#pragma unroll
-    for (int i = 0; i < kBlock / 64; ++i) rank += s_cnt[i];
+  int c = rank;
+  if (d.chan_list) { // wave-uniform scalar loads
+    if (rank >= d.chan_list[d.M]) return;
+    c = d.chan_list[rank];
   }
   const bool active = p0 < hw; // lanes past the end stay for the wave reduction below
 
@@ -504,6 +526,9 @@ int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *strea
   if (count <= 0 || M_max <= 0) return 0;
   dim3 grid((unsigned)M_max, 1, (unsigned)count);
   hipLaunchKernelGGL(quant_stats_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, d_descs);
+  int e = launch_err();
+  if (e) return e;
+  hipLaunchKernelGGL(chan_compact_kernel, dim3((unsigned)count), dim3(kBlock), 0, (hipStream_t)stream, d_descs);
   return launch_err();
 }
 
