@@ -246,7 +246,14 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint64_t *hdr, 
   d.ptr = words + 2;
   d.end = words + enc_len / 4;
 
+  constexpr int64_t kAhead = 12; // rows are found through hdr only (state-independent): fetch them early
   for (int64_t i = 0; i < n; ++i) {
+    {
+      const uint64_t hp = hdr[i + kAhead < n ? i + kAhead : n - 1];
+      const char *rp = reinterpret_cast<const char *>(pool + hdr_off(hp));
+      __builtin_prefetch(rp);
+      __builtin_prefetch(rp + 64);
+    }
     const uint64_t h = hdr[i];
     const uint32_t cf = (uint32_t)(d.x & 0xFFFFu); // Rans64DecGet
     int32_t value;
