@@ -452,7 +452,8 @@ struct DecItem {
   // derived
   int32_t n_ch = 0;
   int64_t n = 0;
-  size_t o_list = 0, o_hdr = 0, o_pool = 0, o_used = 0;
+  size_t o_list = 0, o_hdr = 0, o_pool = 0, o_used = 0, o_bsum = 0, o_boff = 0;
+  int32_t tiles = 0;
   char *h_hdr = nullptr, *h_pool = nullptr, *h_out = nullptr; // pinned
   uint64_t pool_cap = 0, pool_used = 0;
   std::atomic<int> done{0};
@@ -491,10 +492,14 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   for (int i = 0; i < count; ++i) items[i].o_used = o_used + 16 * (size_t)i;
   const size_t host_fixed = ar.off;
   for (auto &it : items) {
-    const uint64_t rowcap = ((uint64_t)(2 * (int64_t)it.max_bs + 2) + 3) & ~3ull;
+    const uint64_t rowcap = 2 * (((uint64_t)(2 * (int64_t)it.max_bs + 2) + 3) & ~3ull); // widest row, raw form, bytes
     it.pool_cap = (uint64_t)it.n * rowcap;
-    it.o_hdr = ar.take(sizeof(uint64_t) * (size_t)it.n + 64);
-    it.o_pool = ar.take(sizeof(uint16_t) * it.pool_cap + 64);
+    it.tiles = (int32_t)((it.hw + 255) / 256);
+    const size_t nblk = (size_t)it.n_ch * (size_t)it.tiles;
+    it.o_hdr = ar.take(sizeof(uint32_t) * (size_t)it.n + 64);
+    it.o_pool = ar.take(it.pool_cap + 128);
+    it.o_bsum = ar.take(sizeof(uint32_t) * nblk + 64);
+    it.o_boff = ar.take(sizeof(uint64_t) * nblk + 64);
   }
   if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(host_fixed)) ||
       (rc = ctx->ensure_events((size_t)count + 2 * (size_t)n_groups)))
@@ -524,10 +529,13 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.max_bs = it.max_bs;
     d.clamp = it.clamp;
     d.prune = 1;
-    d.hdr = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_hdr);
-    d.pool = reinterpret_cast<uint16_t *>(ctx->d_ws + it.o_pool);
+    d.tiles = it.tiles;
+    d.hdr = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_hdr);
+    d.pool = reinterpret_cast<uint8_t *>(ctx->d_ws + it.o_pool);
     d.pool_cap = it.pool_cap;
     d.pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_used);
+    d.blk_sums = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_bsum);
+    d.blk_off = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_boff);
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + o_used, 0, 16 * (size_t)count, stream));
@@ -561,13 +569,14 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       if (u[1]) return fail(FGMM_ERR_HIP, "edge-table pool overflow on item %d (internal sizing error)", i);
       it.pool_used = u[0];
       const size_t out_bytes = it.y_hat ? sizeof(float) * (size_t)it.M * (size_t)it.hw : sizeof(int32_t) * (size_t)it.n;
-      if ((rc = ctx->chunk_alloc(sizeof(uint64_t) * (size_t)it.n + 64, &it.h_hdr)) ||
-          (rc = ctx->chunk_alloc(sizeof(uint16_t) * it.pool_used + 128, &it.h_pool)) ||
+      if ((rc = ctx->chunk_alloc(sizeof(uint32_t) * (size_t)it.n + 64, &it.h_hdr)) ||
+          (rc = ctx->chunk_alloc(it.pool_used + 1024, &it.h_pool)) ||
           (rc = ctx->chunk_alloc(out_bytes + 64, &it.h_out)))
         return rc;
       if (it.n) {
-        HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, sizeof(uint64_t) * (size_t)it.n, hipMemcpyDeviceToHost, ctx->copy_stream));
-        HIP_TRY(hipMemcpyAsync(it.h_pool, ctx->d_ws + it.o_pool, sizeof(uint16_t) * it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, sizeof(uint32_t) * (size_t)it.n, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (it.pool_used)
+          HIP_TRY(hipMemcpyAsync(it.h_pool, ctx->d_ws + it.o_pool, it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
       }
       HIP_TRY(hipEventRecord(ev_item[i], ctx->copy_stream));
     }
@@ -584,14 +593,14 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     HIP_TRY(hipEventSynchronize(ev_item[i]));
     const int32_t *list = reinterpret_cast<const int32_t *>(h_ws + pit->o_list);
     auto job = [pit, list, &done_mu, &done_cv] {
-      memset(pit->h_pool + sizeof(uint16_t) * pit->pool_used, 0, 64); // defined bytes for the SIMD over-read
+      memset(pit->h_pool + pit->pool_used, 0, 64); // defined bytes for the SIMD over-read
       int32_t *sym = pit->y_hat ? (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(pit->n, 1))
                                 : reinterpret_cast<int32_t *>(pit->h_out);
       if (!sym) {
         pit->status = FGMM_ERR_NOMEM;
       } else {
-        pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, reinterpret_cast<const uint64_t *>(pit->h_hdr),
-                                         reinterpret_cast<const uint16_t *>(pit->h_pool), pit->n, pit->max_bs, sym);
+        pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, reinterpret_cast<const uint32_t *>(pit->h_hdr),
+                                         reinterpret_cast<const uint8_t *>(pit->h_pool), pit->n, pit->max_bs, sym);
         if (pit->status == FGMM_OK && pit->y_hat) {
           // y_hat[:, nonzero] = symbols.float(), zeros elsewhere   (entropy_models.py:903-908)
           float *yh = reinterpret_cast<float *>(pit->h_out);
@@ -977,14 +986,16 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
 
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
                           const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode,
-                          int32_t max_bs, int flags, uint64_t *hdr, uint16_t *pool, uint64_t pool_cap,
+                          int32_t max_bs, int flags, uint32_t *hdr, uint8_t *pool, uint64_t pool_cap,
                           uint64_t *pool_used) {
   if (!ctx || n < 0 || !mode_ok(mode) || !pool_used) return fail(FGMM_ERR_INVALID, "bad argument");
   if (max_bs < 0 || max_bs > FGMM_MAX_BS) return fail(FGMM_ERR_UNSUPPORTED, "max_bs %d outside [0, %d]", max_bs, FGMM_MAX_BS);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
+  const int32_t tiles = (int32_t)((n + 255) / 256);
+  const size_t o_bsum = 2048, o_boff = o_bsum + align_up(sizeof(uint32_t) * (size_t)tiles + 64, 256);
   int rc;
-  if ((rc = ctx->ensure_device(4096)) || (rc = ctx->ensure_host(4096))) return rc;
+  if ((rc = ctx->ensure_device(o_boff + sizeof(uint64_t) * (size_t)tiles + 64)) || (rc = ctx->ensure_host(4096))) return rc;
   hipStream_t s = (hipStream_t)stream;
   DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws);
   memset(hd, 0, sizeof *hd);
@@ -998,10 +1009,13 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   hd->max_bs = max_bs;
   hd->prune = (flags & FGMM_TAB_NO_PRUNE) ? 0 : 1;
   hd->clamp = (flags & FGMM_TAB_CLAMP) ? 1 : 0;
-  hd->hdr = reinterpret_cast<unsigned long long *>(hdr);
+  hd->tiles = tiles;
+  hd->hdr = hdr;
   hd->pool = pool;
   hd->pool_cap = pool_cap;
   hd->pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + 1024);
+  hd->blk_sums = reinterpret_cast<uint32_t *>(ctx->d_ws + o_bsum);
+  hd->blk_off = reinterpret_cast<unsigned long long *>(ctx->d_ws + o_boff);
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
   if (n) LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, 1, n, mode, (flags & FGMM_TAB_CLAMP) != 0, false, s));
@@ -1009,7 +1023,7 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   HIP_TRY(hipMemcpyAsync(used, ctx->d_ws + 1024, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipMemcpy(pool_used, used, sizeof(uint64_t), hipMemcpyHostToDevice));
-  if (used[1]) return fail(FGMM_ERR_NOMEM, "pool_cap %llu too small", (unsigned long long)pool_cap);
+  if (used[1]) return fail(FGMM_ERR_NOMEM, "pool_cap %llu bytes too small (need %llu)", (unsigned long long)pool_cap, used[0]);
   return FGMM_OK;
 }
 

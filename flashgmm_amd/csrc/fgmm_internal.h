@@ -41,22 +41,34 @@ struct DecDesc {
   int32_t n_ch;
   int32_t max_bs;
   int32_t clamp;
-  int32_t prune;                 // 1: skip the saturated tails (exact, see cdftab_kernel); 0: evaluate all of F
-  unsigned long long *hdr;       // [n_ch*hw]
-  uint16_t *pool;
-  unsigned long long pool_cap;   // entries
-  unsigned long long *pool_used; // [0] entries used, [1] overflow flag
+  int32_t prune;                 // 1: skip the saturated tails (exact, see cdftab_count_kernel); 0: evaluate all of F
+  int32_t tiles;                 // blocks per channel = ceil(hw / 256)
+  int32_t pad_;
+  uint32_t *hdr;                 // [n_ch*hw] 4-byte headers
+  uint8_t *pool;                 // rows, latent order
+  unsigned long long pool_cap;   // bytes
+  unsigned long long *pool_used; // [0] bytes used, [1] overflow flag
+  uint32_t *blk_sums;            // [n_ch*tiles] row bytes per block
+  unsigned long long *blk_off;   // [n_ch*tiles] byte offset of each block's first row
 };
 
-// edge-table header (8 bytes): int16 a | (uint16 cnt | nonmono<<15) << 16 | (uint32 off/4) << 32
-FGMM_HD static inline uint64_t hdr_pack(int32_t a, uint32_t cnt, uint32_t nonmono, uint64_t off_entries) {
-  return (uint64_t)(uint16_t)(int16_t)a | ((uint64_t)((cnt & 0x7FFFu) | (nonmono << 15)) << 16) |
-         ((off_entries >> 2) << 32);
+// ---- decode-side table format v2 (documented in include/flashgmm_amd.h) -------------------------------------
+//   hdr  (uint32): int16 a | cnt << 16 (15 bits) | nonmono << 31
+//   rows in latent order, each 8-byte aligned, no stored offset:
+//     raw (cnt < 64 or nonmono): uint16[round4(cnt)], padded with the last value
+//     EF  (cnt >= 64, monotone): uint8 lows[round8(cnt)] ; uint64 upper[U], U = ceil((cnt + 256) / 64),
+//                                bit ((E_j >> 8) + j) set for every entry j
+constexpr uint32_t kTabEfMin = 64;
+FGMM_HD static inline uint32_t tab_hdr_pack(int32_t a, uint32_t cnt, uint32_t nonmono) {
+  return (uint32_t)(uint16_t)(int16_t)a | ((cnt & 0x7FFFu) << 16) | (nonmono << 31);
 }
-FGMM_HD static inline int32_t hdr_a(uint64_t h) { return (int32_t)(int16_t)(uint16_t)(h & 0xFFFFu); }
-FGMM_HD static inline uint32_t hdr_cnt(uint64_t h) { return (uint32_t)(h >> 16) & 0x7FFFu; }
-FGMM_HD static inline uint32_t hdr_nonmono(uint64_t h) { return (uint32_t)(h >> 31) & 1u; }
-FGMM_HD static inline uint64_t hdr_off(uint64_t h) { return (h >> 32) << 2; }
+FGMM_HD static inline int32_t tab_hdr_a(uint32_t h) { return (int32_t)(int16_t)(uint16_t)(h & 0xFFFFu); }
+FGMM_HD static inline uint32_t tab_hdr_cnt(uint32_t h) { return (h >> 16) & 0x7FFFu; }
+FGMM_HD static inline uint32_t tab_hdr_nonmono(uint32_t h) { return h >> 31; }
+FGMM_HD static inline bool tab_row_is_ef(uint32_t cnt, uint32_t nonmono) { return cnt >= kTabEfMin && !nonmono; }
+FGMM_HD static inline uint32_t tab_row_bytes(uint32_t cnt, uint32_t nonmono) {
+  return tab_row_is_ef(cnt, nonmono) ? ((cnt + 7u) & ~7u) + 8u * ((cnt + 256u + 63u) >> 6) : 2u * ((cnt + 3u) & ~3u);
+}
 
 // ---- kernel launchers (fgmm_kernels.hip); stream is a hipStream_t; all return hipError_t as int ----------
 int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *stream);
@@ -74,7 +86,7 @@ int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream
 // returns 0 or an fgmm_status; *out malloc'ed
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len);
-int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint64_t *hdr, const uint16_t *pool, int64_t n,
+int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, const uint8_t *pool, int64_t n,
                        int32_t max_bs, int32_t *out);
 
 } // namespace fgmm

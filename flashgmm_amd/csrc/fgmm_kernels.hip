@@ -3,7 +3,7 @@
 //   quant_stats_kernel   y -> round(y), per-channel {min, max, any-nonzero}            (entropy_models.py:834-842)
 //   symtab_kernel        (y | symbols, sigma, mu, pi) -> packed start|range<<16         (rans_interface.cpp:487-517)
 //   cdf_pair_kernel      float CDF pair probe                                           (rans_interface.cpp:250-292)
-//   cdftab_kernel        (sigma, mu, pi, max_bs) -> trimmed per-latent edge tables      (rans_interface.cpp:826-862)
+//   cdftab_{count,scan,fill}  (sigma, mu, pi, max_bs) -> trimmed per-latent edge tables (rans_interface.cpp:826-862)
 //
 // All kernels are batched over `count` independent bitstreams (blockIdx.z = item) through a device array of
 // descriptors, because one Kodak-sized half (<= 147 456 latents) is far too small to fill 256 CUs on its own.
@@ -289,29 +289,22 @@ __global__ __launch_bounds__(kBlock) void cdf_pair_kernel(const int32_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// cdftab_kernel — decode-side edge tables.  Lane = latent.
-//   pass 1: evaluate F[v] = quant16(cdf(v - 0.5)) over the whole range the reference's bisection can probe,
-//           v in [-max_bs, max_bs+1] (W = 2*max_bs + 2 values), tracking the leading run of zeros, the trailing
-//           constant run and whether the sequence ever decreases — so the stored window is exact by
-//           construction, whatever the parameters are;
-//   alloc : wave-wide prefix sum of the (4-padded) row lengths, ONE atomicAdd per wave on the item's pool head;
-//   pass 2: re-evaluate only the window and store it (8 B per store), then the 8-byte header.
-// Transcendental-VALU bound (about 200 VALU ops per edge), not HBM bound: 48 B in per latent.
+// Decode-side edge tables (format v2, include/flashgmm_amd.h).  Lane = latent.  Three launches per group of items:
+//   cdftab_count_kernel  find, exactly, the window outside which F_i is constant (leading zeros, trailing constant
+//                        run, non-monotone flag) -> 4-byte header; row byte length -> per-block sums
+//   cdftab_scan_kernel   exclusive scan of the block sums (one block per item) -> block offsets, total bytes
+//   cdftab_fill_kernel   re-evaluate only the window and store the row at its offset: rows lie in LATENT ORDER with
+//                        no per-row offset (the host walks them sequentially), narrow / non-monotone rows as
+//                        uint16 entries, wide monotone rows Elias-Fano coded (low bytes + unary high parts)
+// F[v] = quant16(cdf(v - 0.5)) over v in [-max_bs, max_bs+1] is all the reference's bisection can probe
+// (rans_interface.cpp:826-862).  Transcendental-VALU bound (about 150 VALU ops per edge), not HBM bound.
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE, bool CLAMPED, typename PT>
-__global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restrict__ descs) {
-  const DecDesc &d = descs[blockIdx.z];
-  const int cj = blockIdx.y;
-  if (cj >= d.n_ch) return;
-  const int64_t hw = d.hw;
-  if ((int64_t)blockIdx.x * kBlock >= hw) return;
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool active = p < hw;
-  const int c = d.chan_list ? d.chan_list[cj] : cj;
-
+template <int MODE, bool CLAMPED, typename PT> struct TabLatent {
   float mu[4], sg[4], pi[4], rs[4];
-  {
-    const int64_t base = (int64_t)c * d.stride_c + (active ? p : 0) * d.stride_p;
+  int max_bs;
+
+  __device__ __forceinline__ void load(const DecDesc &d, int c, int64_t p) {
+    const int64_t base = (int64_t)c * d.stride_c + p * d.stride_p;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float s = ld1<PT>(d.scales, base + k * d.stride_k);
@@ -320,9 +313,10 @@ __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restric
       mu[k] = ld1<PT>(d.means, base + k * d.stride_k);
       pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
     }
+    max_bs = d.max_bs;
   }
-  auto edge = [&](int j) -> uint32_t { // F[v = j - max_bs]
-    const float x = (float)(j - d.max_bs) - 0.5f;
+  __device__ __forceinline__ uint32_t edge(int j) const { // F[v = j - max_bs]
+    const float x = (float)(j - max_bs) - 0.5f;
     if constexpr (CLAMPED) {
       bool ok = true;
       float c = mix4_clamped<MODE>(x, mu, sg, rs, pi, ok);
@@ -332,7 +326,48 @@ __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restric
     } else {
       return quant16(mix4<MODE>(x, mu, sg, pi));
     }
-  };
+  }
+};
+
+__device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t *s_tmp) { // kBlock threads, result in all
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t t = 0;
+#pragma unroll
+  for (int i = 0; i < kBlock / 64; ++i) t += s_tmp[i];
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s_tmp) { // exclusive prefix over the block
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_tmp[w] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int i = 0; i < w; ++i) base += s_tmp[i];
+  __syncthreads();
+  return base + incl - v;
+}
+
+template <int MODE, bool CLAMPED, typename PT>
+__global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__restrict__ descs) {
+  const DecDesc &d = descs[blockIdx.z];
+  const int cj = blockIdx.y;
+  if (cj >= d.n_ch) return;
+  const int64_t hw = d.hw;
+  if ((int64_t)blockIdx.x * kBlock >= hw) return;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = p < hw;
+  const int c = d.chan_list ? d.chan_list[cj] : cj;
+  TabLatent<MODE, CLAMPED, PT> L;
+  L.load(d, c, active ? p : 0);
   const int max_bs = d.max_bs;
   const int W = 2 * max_bs + 2;
 
@@ -350,9 +385,9 @@ __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restric
     float tl = INFINITY, tr = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      ok = ok && (sg[k] > 0.0f) && (sg[k] < INFINITY) && (fabsf(mu[k]) < INFINITY) && Sat<MODE>::weight_ok(pi[k]);
-      tl = fminf(tl, __builtin_fmaf(-Sat<MODE>::ZL, sg[k], mu[k]));
-      tr = fmaxf(tr, __builtin_fmaf(Sat<MODE>::ZR, sg[k], mu[k]));
+      ok = ok && (L.sg[k] > 0.0f) && (L.sg[k] < INFINITY) && (fabsf(L.mu[k]) < INFINITY) && Sat<MODE>::weight_ok(L.pi[k]);
+      tl = fminf(tl, __builtin_fmaf(-Sat<MODE>::ZL, L.sg[k], L.mu[k]));
+      tr = fmaxf(tr, __builtin_fmaf(Sat<MODE>::ZR, L.sg[k], L.mu[k]));
     }
     if (ok) {
       const float lim = (float)max_bs + 4.0f;
@@ -363,21 +398,20 @@ __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restric
       const float xl = (float)vL - 0.5f, xr = (float)vR - 0.5f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        okL = okL && ((xl - mu[k]) / sg[k] <= -Sat<MODE>::ZL);
-        okR = okR && ((xr - mu[k]) / sg[k] >= Sat<MODE>::ZR);
+        okL = okL && ((xl - L.mu[k]) / L.sg[k] <= -Sat<MODE>::ZL);
+        okR = okR && ((xr - L.mu[k]) / L.sg[k] >= Sat<MODE>::ZR);
       }
       if (okL) j_lo = min(max(vL + max_bs + 1, 0), W); // indices < j_lo are v <= vL: all zero
       if (okR) j_hi = min(max(vR + max_bs, j_lo), W);  // indices >= j_hi are v >= vR: all T_sat
-      T_sat = quant16((pi[0] + pi[1]) + (pi[2] + pi[3]));
+      T_sat = quant16((L.pi[0] + L.pi[1]) + (L.pi[2] + L.pi[3]));
     }
   }
 
-  // ---- pass 1 -------------------------------------------------------------------------------------
   int lead = j_lo - 1, run_start = 0;
   bool allzero = true, nonmono = false;
   uint32_t prev = 0;
   for (int j = j_lo; j < j_hi; ++j) {
-    const uint32_t E = edge(j);
+    const uint32_t E = L.edge(j);
     if (allzero) {
       if (E == 0) lead = j; else allzero = false;
     }
@@ -394,42 +428,104 @@ __global__ __launch_bounds__(kBlock) void cdftab_kernel(const DecDesc *__restric
   }
   int a_idx = lead < 0 ? 0 : lead;
   if (a_idx > run_start) a_idx = run_start;
-  const int cnt = run_start - a_idx + 1;
-  const uint32_t len4 = active ? (uint32_t)((cnt + 3) & ~3) : 0u;
+  const uint32_t cnt = (uint32_t)(run_start - a_idx + 1);
 
-  // ---- wave allocation ----------------------------------------------------------------------------
-  const int lane = threadIdx.x & 63;
-  uint32_t incl = len4;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
+  if (active) d.hdr[(int64_t)cj * hw + p] = tab_hdr_pack(a_idx - max_bs, cnt, nonmono ? 1u : 0u);
+  __shared__ uint32_t s_tmp[kBlock / 64];
+  const uint32_t total = block_reduce_add(active ? tab_row_bytes(cnt, nonmono ? 1u : 0u) : 0u, s_tmp);
+  if (threadIdx.x == 0) d.blk_sums[(int64_t)cj * d.tiles + blockIdx.x] = total;
+}
+
+// one block per item: blk_off[b] = sum of blk_sums[0..b), pool_used[0] = total bytes, [1] = overflow flag
+__global__ __launch_bounds__(kBlock) void cdftab_scan_kernel(const DecDesc *__restrict__ descs) {
+  const DecDesc &d = descs[blockIdx.x];
+  const int64_t nb = (int64_t)d.n_ch * d.tiles;
+  __shared__ uint32_t s_tmp[kBlock / 64];
+  __shared__ unsigned long long s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < nb; b0 += kBlock) {
+    const int64_t b = b0 + threadIdx.x;
+    const uint32_t v = b < nb ? d.blk_sums[b] : 0u;
+    const uint32_t ex = block_scan_excl(v, s_tmp);
+    const unsigned long long carry = s_carry;
+    if (b < nb) d.blk_off[b] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) s_carry = carry + ex + v;
+    __syncthreads();
   }
-  const uint32_t total = __shfl(incl, 63, 64);
-  unsigned long long base = 0;
-  if (lane == 63 && total) base = atomicAdd(d.pool_used, (unsigned long long)total);
-  base = __shfl(base, 63, 64);
-  if (base + total > d.pool_cap) { // wave-uniform
-    if (lane == 0) d.pool_used[1] = 1;
-    return;
+  if (threadIdx.x == 0) {
+    d.pool_used[0] = s_carry;
+    d.pool_used[1] = s_carry > d.pool_cap ? 1ull : 0ull;
   }
+}
+
+template <int MODE, bool CLAMPED, typename PT>
+__global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__restrict__ descs) {
+  const DecDesc &d = descs[blockIdx.z];
+  const int cj = blockIdx.y;
+  if (cj >= d.n_ch) return;
+  const int64_t hw = d.hw;
+  if ((int64_t)blockIdx.x * kBlock >= hw) return;
+  if (d.pool_used[1]) return; // pool too small: the host sees the flag
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = p < hw;
+  const int c = d.chan_list ? d.chan_list[cj] : cj;
+  TabLatent<MODE, CLAMPED, PT> L;
+  L.load(d, c, active ? p : 0);
+
+  const uint32_t h = active ? d.hdr[(int64_t)cj * hw + p] : 0u;
+  const int a_idx = tab_hdr_a(h) + d.max_bs;
+  const uint32_t cnt = tab_hdr_cnt(h), nonmono = tab_hdr_nonmono(h);
+  const uint32_t bytes = active ? tab_row_bytes(cnt, nonmono) : 0u;
+  __shared__ uint32_t s_tmp[kBlock / 64];
+  const uint32_t ex = block_scan_excl(bytes, s_tmp);
   if (!active) return;
-  const unsigned long long off = base + (incl - len4);
+  uint8_t *__restrict__ row = d.pool + d.blk_off[(int64_t)cj * d.tiles + blockIdx.x] + ex; // 8-byte aligned
 
-  // ---- pass 2 -------------------------------------------------------------------------------------
-  uint16_t *__restrict__ row = d.pool + off;
-  uint32_t last = 0;
-  for (uint32_t j0 = 0; j0 < len4; j0 += 4) {
-    uint32_t e[4];
+  if (!tab_row_is_ef(cnt, nonmono)) {
+    // raw: uint16 entries, padded to a multiple of 4 with the last value
+    const uint32_t len4 = (cnt + 3u) & ~3u;
+    uint32_t last = 0;
+    for (uint32_t j0 = 0; j0 < len4; j0 += 4) {
+      uint32_t e[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int j = (int)(j0 + t);
-      if (j < cnt) last = edge(a_idx + j);
-      e[t] = last; // pad with the row's last value (= the trailing constant)
+      for (int t = 0; t < 4; ++t) {
+        if (j0 + t < cnt) last = L.edge(a_idx + (int)(j0 + t));
+        e[t] = last;
+      }
+      *reinterpret_cast<uint2 *>(row + 2 * j0) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
     }
-    *reinterpret_cast<uint2 *>(row + j0) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+  } else {
+    // Elias-Fano, 8 low bits: lows[cnt] (padded to 8), then U 64-bit words with bit ((E_j >> 8) + j) set
+    const uint32_t lows_bytes = (cnt + 7u) & ~7u, U = (cnt + 256u + 63u) >> 6;
+    unsigned long long *__restrict__ up = reinterpret_cast<unsigned long long *>(row + lows_bytes);
+    unsigned long long wcur = 0;
+    uint32_t widx = 0, lowacc = 0;
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t E = L.edge(a_idx + (int)j);
+      lowacc |= (E & 0xFFu) << (8u * (j & 3u));
+      if ((j & 3u) == 3u) {
+        *reinterpret_cast<uint32_t *>(row + (j & ~3u)) = lowacc;
+        lowacc = 0;
+      }
+      const uint32_t pos = (E >> 8) + j; // strictly increasing: the row is monotone
+      const uint32_t wi = pos >> 6;
+      while (widx < wi) {
+        up[widx++] = wcur;
+        wcur = 0;
+      }
+      wcur |= 1ull << (pos & 63u);
+    }
+    for (uint32_t j = cnt & ~3u; j < lows_bytes; j += 4) { // tail of the low bytes + zero padding
+      *reinterpret_cast<uint32_t *>(row + j) = lowacc;
+      lowacc = 0;
+    }
+    while (widx < U) {
+      up[widx++] = wcur;
+      wcur = 0;
+    }
   }
-  d.hdr[(int64_t)cj * hw + p] = hdr_pack(a_idx - max_bs, (uint32_t)cnt, nonmono ? 1u : 0u, off);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -575,11 +671,16 @@ int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, c
 template <bool CLAMPED, typename PT>
 static int launch_cdftab_c(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, hipStream_t s) {
   dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)n_ch_max, (unsigned)count);
+#define FGMM_TAB_LAUNCH(M)                                                                                          \
+  hipLaunchKernelGGL((cdftab_count_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);                     \
+  hipLaunchKernelGGL(cdftab_scan_kernel, dim3((unsigned)count), dim3(kBlock), 0, s, d_descs);                       \
+  hipLaunchKernelGGL((cdftab_fill_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);
   switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((cdftab_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((cdftab_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs); break;
-  default: hipLaunchKernelGGL((cdftab_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs); break;
+  case MODE_AS: FGMM_TAB_LAUNCH(MODE_AS) break;
+  case MODE_LOGISTIC: FGMM_TAB_LAUNCH(MODE_LOGISTIC) break;
+  default: FGMM_TAB_LAUNCH(MODE_POLYA) break;
   }
+#undef FGMM_TAB_LAUNCH
   return launch_err();
 }
 

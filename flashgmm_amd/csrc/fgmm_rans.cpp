@@ -2,7 +2,8 @@
 //
 // Nothing in this file touches floating point.  It consumes
 //   * the encode-side symbol table (uint32 start | range<<16 per symbol, range == 0 = bypass escape) and
-//   * the decode-side trimmed edge tables (8-byte header + uint16 window per latent)
+//   * the decode-side trimmed edge tables (4-byte header + row per latent, rows in latent order: uint16 entries,
+//     or Elias-Fano coded when wide and monotone)
 // produced by fgmm_kernels.hip and reproduces, bit for bit, the streams / symbols of
 //   BufferedRansEncoder::flush            compressai/cpp_exts/rans/rans_interface.cpp:557-585
 //   the bypass escape                     compressai/cpp_exts/rans/rans_interface.cpp:513-552, :808-824
@@ -12,9 +13,10 @@
 // Encoder: the per-symbol 64-bit division of Rans64EncPut is replaced by a multiply with an exact
 // Alverson reciprocal from a 65 536-entry table (state-identical by construction for every state the
 // encoder can reach; the same identity ryg's Rans64EncPutSymbol relies on).
-// Decoder: rows flagged monotone are searched with one or two AVX2 compares; everything else (flagged
-// non-monotone rows, a cum_freq no interval contains) goes through a literal replay of the reference's
-// bisection over the virtual table, so the result is the reference's result in every case.
+// Decoder: monotone rows are searched with one or two AVX2 compares (uint16 rows) or a select on the unary high
+// parts (Elias-Fano rows); everything else (flagged non-monotone rows, a cum_freq no interval contains) goes
+// through a literal replay of the reference's bisection over the virtual table, so the result is the
+// reference's result in every case.
 #include <immintrin.h>
 #include <stdlib.h>
 #include <string.h>
@@ -177,7 +179,7 @@ struct Dec {
   }
 };
 
-// virtual full table F[v], v in [-max_bs, max_bs+1], rebuilt from the trimmed row
+// virtual full table F[v], v in [-max_bs, max_bs+1], rebuilt from a row held as plain uint16 entries
 struct Row {
   const uint16_t *row;
   int32_t a;
@@ -225,9 +227,51 @@ __attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *r
   return cnt;
 }
 
+// ---- Elias-Fano rows (8 low bits): lows[round8(cnt)] then U words whose bit ((E_j >> 8) + j) is set -----------
+struct EfRow {
+  const uint8_t *lows;
+  const uint64_t *up;
+  int32_t cnt;
+  int32_t U;
+};
+// position of the k-th (0-based) ZERO bit; k <= 255 always exists (U*64 - cnt >= 256 zeros)
+__attribute__((target("bmi2,popcnt"))) inline uint32_t ef_select0(const EfRow &r, uint32_t k) {
+  uint32_t base = 0;
+  for (int32_t w = 0; w < r.U; ++w, base += 64) {
+    const uint64_t z = ~r.up[w];
+    const uint32_t c = (uint32_t)__builtin_popcountll(z);
+    if (k < c) return base + (uint32_t)__builtin_ctzll(_pdep_u64(1ull << k, z));
+    k -= c;
+  }
+  return base; // unreachable for well-formed rows
+}
+// position of the k-th (0-based) ONE bit, k < cnt
+__attribute__((target("bmi2,popcnt"))) inline uint32_t ef_select1(const EfRow &r, uint32_t k) {
+  uint32_t base = 0;
+  for (int32_t w = 0; w < r.U; ++w, base += 64) {
+    const uint64_t o = r.up[w];
+    const uint32_t c = (uint32_t)__builtin_popcountll(o);
+    if (k < c) return base + (uint32_t)__builtin_ctzll(_pdep_u64(1ull << k, o));
+    k -= c;
+  }
+  return base;
+}
+inline uint32_t ef_get(const EfRow &r, int32_t j) { // E_j
+  return ((ef_select1(r, (uint32_t)j) - (uint32_t)j) << 8) | r.lows[j];
+}
+// number of entries <= cf  (= first index whose entry is > cf)
+inline int32_t ef_upper_bound(const EfRow &r, uint32_t cf) {
+  const uint32_t h = cf >> 8, l = cf & 0xFFu;
+  const int32_t lo = h ? (int32_t)(ef_select0(r, h - 1) - (h - 1)) : 0; // entries with high part < h
+  const int32_t hi = (int32_t)(ef_select0(r, h) - h);                  // entries with high part <= h
+  int32_t j = lo;
+  while (j < hi && r.lows[j] <= l) ++j;
+  return j;
+}
+
 } // namespace
 
-int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint64_t *hdr, const uint16_t *pool, int64_t n,
+int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, const uint8_t *pool, int64_t n,
                        int32_t max_bs, int32_t *out) {
   if (n < 0 || (n > 0 && (!hdr || !pool || !out)) || !enc) return FGMM_ERR_INVALID;
   if (enc_len < 8 || (enc_len & 3)) return FGMM_ERR_STREAM;
@@ -245,43 +289,72 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint64_t *hdr, 
   d.x = (uint64_t)words[0] | ((uint64_t)words[1] << 32); // Rans64DecInit
   d.ptr = words + 2;
   d.end = words + enc_len / 4;
+  uint16_t *scratch = nullptr; // an EF row expanded for the (rare) bisection replay
+  size_t scratch_cap = 0;
 
-  constexpr int64_t kAhead = 12; // rows are found through hdr only (state-independent): fetch them early
+  const uint8_t *rowp = pool; // rows lie in latent order: the offset is a running sum, never stored
   for (int64_t i = 0; i < n; ++i) {
-    {
-      const uint64_t hp = hdr[i + kAhead < n ? i + kAhead : n - 1];
-      const char *rp = reinterpret_cast<const char *>(pool + hdr_off(hp));
-      __builtin_prefetch(rp);
-      __builtin_prefetch(rp + 64);
-    }
-    const uint64_t h = hdr[i];
+    __builtin_prefetch(rowp + 512);
+    __builtin_prefetch(rowp + 576);
+    const uint32_t h = hdr[i];
+    const int32_t a = tab_hdr_a(h), cnt = (int32_t)tab_hdr_cnt(h);
+    const uint32_t nonmono = tab_hdr_nonmono(h);
+    const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono);
+    const uint8_t *row_bytes = rowp;
+    rowp += tab_row_bytes((uint32_t)cnt, nonmono);
+
     const uint32_t cf = (uint32_t)(d.x & 0xFFFFu); // Rans64DecGet
     int32_t value;
     if (__builtin_expect(cf == kMaxCdf, 0)) {
       value = d.bypass();
     } else {
-      Row r{pool + hdr_off(h), hdr_a(h), (int32_t)hdr_cnt(h)};
-      uint32_t start, freq;
+      uint32_t start = 0, freq = 0;
       bool done = false;
-      if (__builtin_expect(!hdr_nonmono(h), 1)) {
-        const int32_t j = upper_bound_u16(r.row, r.cnt, cf);
-        if (__builtin_expect(j >= 1 && j < r.cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
-          start = r.row[j - 1];
-          freq = r.row[j] - start;
-          value = r.a + j - 1;
-          done = true;
+      if (!is_ef) {
+        const uint16_t *row = reinterpret_cast<const uint16_t *>(row_bytes);
+        if (__builtin_expect(!nonmono, 1)) {
+          const int32_t j = upper_bound_u16(row, cnt, cf);
+          if (__builtin_expect(j >= 1 && j < cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
+            start = row[j - 1];
+            freq = row[j] - start;
+            value = a + j - 1;
+            done = true;
+          }
+        }
+        if (!done) value = bisect_reference(Row{row, a, cnt}, cf, max_bs, &start, &freq);
+      } else {
+        const EfRow r{row_bytes, reinterpret_cast<const uint64_t *>(row_bytes + (((uint32_t)cnt + 7u) & ~7u)), cnt,
+                      (int32_t)(((uint32_t)cnt + 256u + 63u) >> 6)};
+        const int32_t j = ef_upper_bound(r, cf);
+        if (__builtin_expect(j >= 1 && j < cnt, 1)) {
+          start = ef_get(r, j - 1);
+          freq = ef_get(r, j) - start;
+          value = a + j - 1;
+        } else { // no interval contains cf: expand the row and replay the reference's bisection
+          if ((size_t)cnt > scratch_cap) {
+            free(scratch);
+            scratch_cap = (size_t)cnt + 64;
+            scratch = (uint16_t *)malloc(scratch_cap * sizeof(uint16_t));
+            if (!scratch) {
+              free(copy);
+              return FGMM_ERR_NOMEM;
+            }
+          }
+          for (int32_t k = 0; k < cnt; ++k) scratch[k] = (uint16_t)ef_get(r, k);
+          value = bisect_reference(Row{scratch, a, cnt}, cf, max_bs, &start, &freq);
         }
       }
-      if (!done) value = bisect_reference(r, cf, max_bs, &start, &freq);
       d.advance(start, freq);
     }
     out[i] = value;
     if (__builtin_expect(d.underrun, 0)) {
       free(copy);
+      free(scratch);
       return FGMM_ERR_STREAM;
     }
   }
   free(copy);
+  free(scratch);
   return FGMM_OK;
 }
 
@@ -294,7 +367,7 @@ int fgmm_rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_nu
   return fgmm::rans_encode_symtab(packed, symbols_or_null, n, -1, out, out_len);
 }
 
-int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint64_t *hdr, const uint16_t *pool,
+int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint32_t *hdr, const uint8_t *pool,
                             int64_t n, int32_t max_bs, int32_t *out_symbols) {
   return fgmm::rans_decode_cdftab(encoded, encoded_len, hdr, pool, n, max_bs, out_symbols);
 }

@@ -171,18 +171,21 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
 
 /* GPU: decode-side edge tables.  For latent i the reference's bisection can only ever look at
  *   F_i[v] = (uint16)(cdf_i(v - 0.5) * 65535),  v in [-max_bs, max_bs + 1]      (rans_interface.cpp:826-862).
- * The kernel finds, exactly, the window outside which F_i is constant (evaluating F_i everywhere except where
- * every mixture component is provably saturated — fgmm_selftest_saturation) and stores it:
- *   hdr[i]  = { int16 a; uint16 cnt | nonmono << 15; uint32 off }   (8 bytes)
- *   pool[off .. off+cnt) = F_i[a .. a+cnt),   F_i[v < a] = 0,  F_i[v >= a+cnt] = pool[off+cnt-1]
- * rows are padded to a multiple of 4 entries with their last value.  `nonmono` is set when the stored row
- * decreases somewhere.  hdr: device uint64[n]; pool: device uint16[pool_cap]; pool_used: device uint64[1],
- * zeroed by the call.  pool_cap >= n * (2*max_bs + 5) always suffices. */
+ * The kernels find, exactly, the window outside which F_i is constant (evaluating F_i everywhere except where
+ * every mixture component is provably saturated — fgmm_selftest_saturation) and store it:
+ *   hdr[i] (uint32) = int16 a | cnt << 16 (15 bits) | nonmono << 31
+ *   row i  = F_i[a .. a+cnt);   F_i[v < a] = 0,   F_i[v >= a+cnt] = the row's last entry
+ * Rows lie in LATENT ORDER in `pool`, 8-byte aligned, with no stored offset (row i+1 starts where row i ends):
+ *   cnt < 64 or nonmono : uint16[round4(cnt)], padded with the last value              (2*round4(cnt) bytes)
+ *   cnt >= 64, monotone : Elias-Fano with 8 low bits: uint8 lows[round8(cnt)], then uint64 upper[U],
+ *                         U = ceil((cnt + 256) / 64), bit ((F >> 8) + j) set for entry j  (round8(cnt) + 8U bytes)
+ * `nonmono` is set when the row decreases somewhere.  hdr: device uint32[n]; pool: device bytes; pool_used: device
+ * uint64[1] = bytes written.  pool_cap >= n * 2 * round4(2*max_bs + 2) always suffices. */
 #define FGMM_TAB_NO_PRUNE 1 /* flags: evaluate all of F_i instead of skipping its saturated tails (A/B testing) */
 #define FGMM_TAB_CLAMP 2    /* flags: clamp sigma to [0.11, 256] first (the entropy-model path's kernel variant) */
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
                           const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode,
-                          int32_t max_bs, int flags, uint64_t *hdr, uint16_t *pool, uint64_t pool_cap,
+                          int32_t max_bs, int flags, uint32_t *hdr, uint8_t *pool, uint64_t pool_cap,
                           uint64_t *pool_used);
 
 /* GPU self-test: exhaustive scan (every binary32 beyond the thresholds) of the saturation lemmas that let the
@@ -201,7 +204,7 @@ int fgmm_rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_nu
 
 /* Host, integer only: edge tables -> symbols; the reference's bisection with every float evaluation replaced
  * by a look-up in F_i. */
-int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint64_t *hdr, const uint16_t *pool,
+int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint32_t *hdr, const uint8_t *pool,
                             int64_t n, int32_t max_bs, int32_t *out_symbols);
 
 #ifdef __cplusplus
