@@ -32,16 +32,21 @@ __all__ = ["GaussianMixtureConditional"]
 def _plane_view(t: Tensor, K: int) -> Tuple[Tensor, int, int]:
     """-> (tensor kept alive, stride_k, stride_c) for a [1, K*M, h, w] parameter tensor whose (h, w) planes are
     dense; anything else is made contiguous first.  chunk(3, 1) views of the parameter head qualify as they are."""
-    if t.dim() != 4 or t.size(0) != 1:
+    shape = t.shape
+    if len(shape) != 4 or shape[0] != 1:
         raise RuntimeError("entropy parameters must be [1, K*M, h, w] (the reference squeezes batch 1 too, entropy_models.py:841)")
-    if t.dtype not in (torch.float32, torch.float16):
+    if t.dtype not in _PARAM_DTYPES:
         raise RuntimeError(f"entropy parameters must be float32 or float16, got {t.dtype}")
-    h, w = t.size(2), t.size(3)
-    if not (t.stride(3) == 1 and t.stride(2) == w) and h * w > 1:
+    hw = shape[2] * shape[3]
+    st = t.stride()
+    if hw > 1 and not (st[3] == 1 and st[2] == shape[3]):
         t = t.contiguous()
-    sc = t.stride(1) if t.size(1) > 1 else h * w
-    M = t.size(1) // K
-    return t, M * sc, sc
+        st = t.stride()
+    sc = st[1] if shape[1] > 1 else hw
+    return t, (shape[1] // K) * sc, sc
+
+
+_PARAM_DTYPES = (torch.float32, torch.float16)
 
 
 class GaussianMixtureConditional(nn.Module):
@@ -77,12 +82,15 @@ class GaussianMixtureConditional(nn.Module):
         s, sk, sc = _plane_view(scales, self.K)
         m, mk, mc = _plane_view(means, self.K)
         w, wk, wc = _plane_view(weights, self.K)
-        if (mk, mc) != (sk, sc) or (wk, wc) != (sk, sc):
+        if (mk, mc) != (sk, sc) or (wk, wc) != (sk, sc) or m.shape != s.shape or w.shape != s.shape:
+            if m.shape != s.shape or w.shape != s.shape:
+                raise RuntimeError("scales, means and weights must have one shape")
             s, m, w = s.contiguous(), m.contiguous(), w.contiguous()
             hw_ = s.size(2) * s.size(3)
             sc, sk = hw_, (s.size(1) // self.K) * hw_
-        M = s.size(1) // self.K
-        hw = s.size(2) * s.size(3)
+        shp = s.shape
+        M = shp[1] // self.K
+        hw = shp[2] * shp[3]
         it = _lib.fgmm_item()
         if not (s.dtype == m.dtype == w.dtype):
             raise RuntimeError("scales, means and weights must share one dtype")
@@ -91,8 +99,9 @@ class GaussianMixtureConditional(nn.Module):
         it.M, it.K, it.hw = M, self.K, hw
         keep += [s, m, w]
         if y is not None:
-            if y.dim() != 4 or y.size(0) != 1 or y.size(1) != M or y.size(2) * y.size(3) != hw:
-                raise RuntimeError(f"y must be [1, {M}, h, w] matching the parameters; got {tuple(y.shape)}")
+            ys_ = y.shape
+            if len(ys_) != 4 or ys_[0] != 1 or ys_[1] != M or ys_[2] * ys_[3] != hw:
+                raise RuntimeError(f"y must be [1, {M}, h, w] matching the parameters; got {tuple(ys_)}")
             if y.dtype != torch.float32 or y.device != s.device:  # latents stay float32 (32 B/symbol with fp16 planes)
                 raise RuntimeError("y must be float32 on the parameters' device")
             yc = y.contiguous()
@@ -153,17 +162,20 @@ class GaussianMixtureConditional(nn.Module):
             dev = dev or d
             if d != dev:
                 raise RuntimeError("all items of a batch must be on one device")
-            zb = zero_bitmaps[i].to("cpu", torch.int64).contiguous()
+            zb = zero_bitmaps[i]
+            if zb.device.type != "cpu" or zb.dtype != torch.int64 or not zb.is_contiguous():
+                zb = zb.to("cpu", torch.int64).contiguous()
             if zb.numel() != M:
                 raise RuntimeError(f"zero_bitmap has {zb.numel()} entries, expected {M}")
-            data = bytes(strings[i])
-            buf = C.create_string_buffer(data, len(data))
-            y_hat = torch.empty((1, M, scales[i].size(2), scales[i].size(3)), dtype=torch.float32, device=d)
+            data = strings[i] if isinstance(strings[i], bytes) else bytes(strings[i])
+            buf = C.c_char_p(data)  # borrowed pointer into the bytes object (kept alive below), no copy
+            shp = scales[i].shape
+            y_hat = torch.empty((1, M, shp[2], shp[3]), dtype=torch.float32, device=d)
             it.yq_out, it.zero_bitmap = y_hat.data_ptr(), zb.data_ptr()
             it.abs_max = int(abs_maxes[i])
             it.bytes, it.bytes_len = C.cast(buf, C.c_void_p), len(data)
             items[i] = it
-            keep += [zb, buf]
+            keep += [zb, buf, data]
             outs.append(y_hat)
         if n_items == 0:
             return []
