@@ -474,8 +474,19 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   Trace tr("decode");
   int rc;
   if ((rc = ctx->ensure_streams())) return rc;
-  const int group_size = count >= 16 ? std::max(2, count / 8) : count;
-  const int n_groups = (count + group_size - 1) / group_size;
+  // groups of items: small first (the table copies start as early as possible), then larger
+  std::vector<int> gbeg;
+  {
+    const int steady = count >= 16 ? std::max(2, count / 8) : count;
+    int i = 0, sz = count >= 16 ? 2 : count;
+    while (i < count) {
+      gbeg.push_back(i);
+      i += sz;
+      sz = std::min(steady, sz * 2);
+    }
+    gbeg.push_back(count);
+  }
+  const int n_groups = (int)gbeg.size() - 1;
 
   Arena ar; // device workspace; the part before the counters is mirrored in h_ws and uploaded in one copy
   const size_t o_descs = ar.take(sizeof(DecDesc) * count);
@@ -541,7 +552,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   HIP_TRY(hipMemsetAsync(ctx->d_ws + o_used, 0, 16 * (size_t)count, stream));
   if ((rc = ctx->prof_begin(1, stream))) return rc;
   for (int g = 0; g < n_groups; ++g) {
-    const int i0 = g * group_size, i1 = std::min(count, i0 + group_size);
+    const int i0 = gbeg[g], i1 = gbeg[g + 1];
     int n_ch_max = 0;
     int64_t hw_max = 0;
     for (int i = i0; i < i1; ++i) {
@@ -561,7 +572,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
 
   // ---- as each group's sizes arrive, queue its table copies --------------------------------------------
   for (int g = 0; g < n_groups; ++g) {
-    const int i0 = g * group_size, i1 = std::min(count, i0 + group_size);
+    const int i0 = gbeg[g], i1 = gbeg[g + 1];
     HIP_TRY(hipEventSynchronize(ev_counters[g]));
     for (int i = i0; i < i1; ++i) {
       DecItem &it = items[i];

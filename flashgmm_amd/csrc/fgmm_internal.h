@@ -58,7 +58,10 @@ struct DecDesc {
 //     raw (cnt < 64 or nonmono): uint16[round4(cnt)], padded with the last value
 //     EF  (cnt >= 64, monotone): uint8 lows[round8(cnt)] ; uint64 upper[U], U = ceil((cnt + 256) / 64),
 //                                bit ((E_j >> 8) + j) set for every entry j
-constexpr uint32_t kTabEfMin = 64;
+#ifndef FGMM_EF_MIN
+#define FGMM_EF_MIN 64
+#endif
+constexpr uint32_t kTabEfMin = FGMM_EF_MIN; // rows with at least this many entries are Elias-Fano coded
 FGMM_HD static inline uint32_t tab_hdr_pack(int32_t a, uint32_t cnt, uint32_t nonmono) {
   return (uint32_t)(uint16_t)(int16_t)a | ((cnt & 0x7FFFu) << 16) | (nonmono << 31);
 }

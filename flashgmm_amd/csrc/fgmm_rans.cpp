@@ -228,24 +228,27 @@ __attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *r
 }
 
 // ---- Elias-Fano rows (8 low bits): lows[round8(cnt)] then U words whose bit ((E_j >> 8) + j) is set -----------
+// Bucket b (entries whose high byte is b) is a run of ones followed by one zero; zero #b sits at bit
+// b + (number of entries with high byte <= b).
 struct EfRow {
   const uint8_t *lows;
   const uint64_t *up;
   int32_t cnt;
   int32_t U;
 };
-// position of the k-th (0-based) ZERO bit; k <= 255 always exists (U*64 - cnt >= 256 zeros)
+// position of the k-th (0-based) ZERO bit, k <= 255 (always exists: U*64 - cnt >= 256).  Branch-free in the
+// search (one pass over the U words, U is 5..7 for the rows of a Kodak-sized latent).
 __attribute__((target("bmi2,popcnt"))) inline uint32_t ef_select0(const EfRow &r, uint32_t k) {
-  uint32_t base = 0;
-  for (int32_t w = 0; w < r.U; ++w, base += 64) {
-    const uint64_t z = ~r.up[w];
-    const uint32_t c = (uint32_t)__builtin_popcountll(z);
-    if (k < c) return base + (uint32_t)__builtin_ctzll(_pdep_u64(1ull << k, z));
-    k -= c;
+  uint32_t wsel = 0, zbase = 0, acc = 0;
+  for (int32_t w = 0; w < r.U; ++w) {
+    acc += (uint32_t)__builtin_popcountll(~r.up[w]);
+    const bool le = acc <= k;
+    wsel += le;
+    zbase = le ? acc : zbase;
   }
-  return base; // unreachable for well-formed rows
+  return wsel * 64u + (uint32_t)__builtin_ctzll(_pdep_u64(1ull << (k - zbase), ~r.up[wsel]));
 }
-// position of the k-th (0-based) ONE bit, k < cnt
+// position of the k-th (0-based) ONE bit, k < cnt (only used to expand a row for the bisection replay)
 __attribute__((target("bmi2,popcnt"))) inline uint32_t ef_select1(const EfRow &r, uint32_t k) {
   uint32_t base = 0;
   for (int32_t w = 0; w < r.U; ++w, base += 64) {
@@ -259,14 +262,63 @@ __attribute__((target("bmi2,popcnt"))) inline uint32_t ef_select1(const EfRow &r
 inline uint32_t ef_get(const EfRow &r, int32_t j) { // E_j
   return ((ef_select1(r, (uint32_t)j) - (uint32_t)j) << 8) | r.lows[j];
 }
-// number of entries <= cf  (= first index whose entry is > cf)
-inline int32_t ef_upper_bound(const EfRow &r, uint32_t cf) {
+// Bracket search: on success returns true with (*j, *start, *freq) such that E[j-1] = start <= cf < E[j];
+// false when no entry pair brackets cf (j would be 0 or cnt) — the caller replays the reference's bisection.
+__attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow &r, uint32_t cf, int32_t *jout,
+                                                                    uint32_t *start, uint32_t *freq) {
   const uint32_t h = cf >> 8, l = cf & 0xFFu;
-  const int32_t lo = h ? (int32_t)(ef_select0(r, h - 1) - (h - 1)) : 0; // entries with high part < h
-  const int32_t hi = (int32_t)(ef_select0(r, h) - h);                  // entries with high part <= h
-  int32_t j = lo;
-  while (j < hi && r.lows[j] <= l) ++j;
-  return j;
+  const int32_t p_prev = h ? (int32_t)ef_select0(r, h - 1) : -1; // zero that closes bucket h-1
+  const int32_t lo = p_prev + 1 - (int32_t)h;                    // entries with high byte < h
+  // length of the run of ones that starts at bit p_prev + 1  (= size of bucket h)
+  int32_t run = 0;
+  {
+    uint32_t s = (uint32_t)(p_prev + 1);
+    for (;;) {
+      const uint32_t b = s & 63u;
+      const uint64_t t = ~(r.up[s >> 6] >> b); // shifted-in zeros become ones: the run ends at the word end at the latest
+      const int32_t len = t ? (int32_t)__builtin_ctzll(t) : 64;
+      run += len;
+      if (__builtin_expect(len < (int32_t)(64u - b), 1)) break;
+      s += (uint32_t)len; // the run continues in the next word (rare)
+    }
+  }
+  // entries of bucket h whose low byte is <= l (low bytes ascend inside a bucket)
+  int32_t c;
+  if (__builtin_expect(run <= 16, 1)) {
+    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(r.lows + lo));
+    const __m128i key = _mm_set1_epi8((char)l);
+    const uint32_t le = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(v, key), v));
+    c = __builtin_popcount(le & ((1u << run) - 1u));
+  } else {
+    c = 0;
+    while (c < run && r.lows[lo + c] <= l) ++c;
+  }
+  const int32_t j = lo + c;
+  if (__builtin_expect(j < 1 || j >= r.cnt, 0)) return false;
+  uint32_t e0, e1;
+  if (c > 0) {
+    e0 = (h << 8) | r.lows[j - 1];
+  } else { // previous entry lives in an earlier bucket: the highest one below bit p_prev
+    int32_t w = p_prev >> 6;
+    uint64_t m = r.up[w] & ((1ull << (p_prev & 63)) - 1ull);
+    while (!m) m = r.up[--w];
+    const int32_t pos = w * 64 + 63 - (int32_t)__builtin_clzll(m);
+    e0 = ((uint32_t)(pos - (j - 1)) << 8) | r.lows[j - 1];
+  }
+  if (c < run) {
+    e1 = (h << 8) | r.lows[j];
+  } else { // next entry lives in a later bucket: the lowest one above the zero that closes bucket h
+    const int32_t pz = p_prev + 1 + run;
+    int32_t w = (pz + 1) >> 6;
+    uint64_t m = r.up[w] & ~((1ull << ((pz + 1) & 63)) - 1ull);
+    while (!m) m = r.up[++w];
+    const int32_t pos = w * 64 + (int32_t)__builtin_ctzll(m);
+    e1 = ((uint32_t)(pos - j) << 8) | r.lows[j];
+  }
+  *jout = j;
+  *start = e0;
+  *freq = e1 - e0;
+  return true;
 }
 
 } // namespace
@@ -325,10 +377,8 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
       } else {
         const EfRow r{row_bytes, reinterpret_cast<const uint64_t *>(row_bytes + (((uint32_t)cnt + 7u) & ~7u)), cnt,
                       (int32_t)(((uint32_t)cnt + 256u + 63u) >> 6)};
-        const int32_t j = ef_upper_bound(r, cf);
-        if (__builtin_expect(j >= 1 && j < cnt, 1)) {
-          start = ef_get(r, j - 1);
-          freq = ef_get(r, j) - start;
+        int32_t j;
+        if (__builtin_expect(ef_bracket(r, cf, &j, &start, &freq), 1)) {
           value = a + j - 1;
         } else { // no interval contains cf: expand the row and replay the reference's bisection
           if ((size_t)cnt > scratch_cap) {

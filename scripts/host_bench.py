@@ -1,0 +1,34 @@
+"""Dev aid (CPU only): ns/symbol of the host rANS encoder / decoder on one Kodak half, tables from the oracle."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from oracle import oracle as O
+from flashgmm_amd import _lib, testing as T
+import helpers
+from helpers import trim_full_table, host_decode_cdftab, host_encode_symtab
+helpers.EF_MIN = int(os.environ.get("EF_MIN", "64"))
+
+cache = f"/tmp/host_bench_tables_{helpers.EF_MIN}.npz"
+if os.path.exists(cache):
+    z = np.load(cache); hdr, pool, sym, packed, max_bs = z["hdr"], z["pool"], z["sym"], z["packed"], int(z["max_bs"])
+    enc = bytes(z["enc"])
+else:
+    y, sg, mu, pi = T.make_latent(0)
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    max_bs = abs_max + 1
+    enc = O.encode_gmm(0, sym, s, m, w)
+    packed = O.symtab(0, sym, s, m, w)
+    tab = O.cdftab(0, s, m, w, max_bs)
+    hdr, pool, used = trim_full_table(tab, max_bs)
+    np.savez(cache, hdr=hdr, pool=pool, sym=sym, packed=packed, max_bs=max_bs, enc=np.frombuffer(enc, np.uint8))
+L = _lib.lib()
+n = len(sym)
+cnt = (hdr >> 16) & 0x7FFF
+print(f"n={n} pool={len(pool)/n:.1f} B/latent  EF rows {(cnt>=64).mean():.3f}")
+for rep in range(3):
+    t0 = time.perf_counter(); rc, out = host_decode_cdftab(L, enc, hdr, pool, max_bs); t1 = time.perf_counter()
+    assert rc == 0 and np.array_equal(out, sym)
+    t2 = time.perf_counter(); b = host_encode_symtab(L, packed, None); t3 = time.perf_counter()
+    assert b == enc
+    print(f"decode {1e9*(t1-t0)/n:.1f} ns/sym   encode {1e9*(t3-t2)/n:.1f} ns/sym")
