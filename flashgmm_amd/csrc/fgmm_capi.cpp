@@ -348,10 +348,8 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     if ((rc = ctx->prof_end(2, stream))) return rc;
   }
   if ((rc = ctx->prof_begin(0, stream))) return rc;
-  // vec: 1 = scalar loads (any layout), 4 = one 4-wide load per plane per lane, 8 = the same loads, software-pipelined
-  // over consecutive tiles (default when the planes are aligned).  FGMM_VEC overrides for A/B runs.
-  static const int force_vec = getenv("FGMM_VEC") ? atoi(getenv("FGMM_VEC")) : 0;
-  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4 ? (force_vec ? force_vec : 8) : 1, items[0].clamp != 0,
+  static const int force_vec = getenv("FGMM_VEC") ? atoi(getenv("FGMM_VEC")) : 0; // dev: A/B the load width
+  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4 ? (force_vec ? force_vec : 4) : 1, items[0].clamp != 0,
                            items[0].prm.dtype == FGMM_F16, stream));
   if ((rc = ctx->prof_end(0, stream))) return rc;
   // ---- tables back to the host: small region first, then one copy + event per item ----------------

@@ -267,104 +267,6 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// symtab_pipe_kernel — the same table, software-pipelined (the variant the batched path launches when the planes
-// are aligned).  The plain kernel above lets every wave load once, wait, then compute: on a launch this short
-// (~80 us) the resident waves move through those two phases together, so HBM and the VALUs take turns instead of
-// overlapping.  Here the coded symbols of an item are one flat sequence of quads (compact channel j, 4 positions);
-// a block walks TPB consecutive 256-quad tiles and issues ALL loads of tile t+1 before it evaluates tile t, so
-// every wave always has ~14 KiB in flight while it computes.  Two register tiles (~150 VGPRs, 3 waves/SIMD).
-// ---------------------------------------------------------------------------------------------------------
-template <typename PT> struct SymTile {
-  float y4[4];      // y (or the symbol as float)
-  int vi[4];        // integer symbols (raw boundary only)
-  float S[4][4], Mu[4][4], Pi[4][4];
-  int64_t out_idx;  // index of the quad's first entry in the packed table
-  bool active;
-};
-
-template <typename PT>
-__device__ __forceinline__ void symtile_load(SymTile<PT> &t, const EncDesc &d, int64_t q, int64_t Q, int hw4) {
-  t.active = q < Q;
-  const int64_t qq = t.active ? q : 0;
-  const int j = (int)(qq / hw4);
-  const int64_t p0 = (qq - (int64_t)j * hw4) * 4;
-  const int c = d.chan_list ? d.chan_list[j] : j;
-  t.out_idx = (int64_t)j * d.hw + p0;
-  const int64_t base = (int64_t)c * d.stride_c + p0;
-  if (d.sym) {
-    const int4 v = *reinterpret_cast<const int4 *>(d.sym + (int64_t)c * d.hw + p0);
-    t.vi[0] = v.x; t.vi[1] = v.y; t.vi[2] = v.z; t.vi[3] = v.w;
-  } else {
-    const float4 v = *reinterpret_cast<const float4 *>(d.y + (int64_t)c * d.hw + p0);
-    t.y4[0] = v.x; t.y4[1] = v.y; t.y4[2] = v.z; t.y4[3] = v.w;
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    ld4<PT>(d.scales, base + k * d.stride_k, t.S[k]);
-    ld4<PT>(d.means, base + k * d.stride_k, t.Mu[k]);
-    ld4<PT>(d.weights, base + k * d.stride_k, t.Pi[k]);
-  }
-}
-
-template <int MODE, bool CLAMPED, typename PT>
-__device__ __forceinline__ int symtile_eval(const SymTile<PT> &t, const EncDesc &d) {
-  if (!t.active) return 0;
-  int nbypass = 0;
-  uint4 out;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float mu[4], sg[4], pi[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      sg[k] = t.S[k][e];
-      mu[k] = t.Mu[k][e];
-      pi[k] = t.Pi[k][e];
-    }
-    float vq;
-    int vi;
-    if (d.sym) {
-      vi = t.vi[e];
-      vq = (float)vi;
-    } else {
-      vq = __builtin_rintf(t.y4[e]);
-      vi = (int)vq;
-    }
-    int bp;
-    (&out.x)[e] = sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp);
-    nbypass += bp;
-  }
-  *reinterpret_cast<uint4 *>(d.packed + t.out_idx) = out;
-  return nbypass;
-}
-
-constexpr int kSymTilesPerBlock = 4;
-
-template <int MODE, bool CLAMPED, typename PT>
-__global__ __launch_bounds__(kBlock, 3) void symtab_pipe_kernel(const EncDesc *__restrict__ descs) {
-  const EncDesc &d = descs[blockIdx.y];
-  const int hw4 = (int)(d.hw >> 2);
-  const int n_ch = d.chan_list ? d.chan_list[d.M] : d.M;
-  const int64_t Q = (int64_t)n_ch * hw4;
-  const int64_t q0 = (int64_t)blockIdx.x * (kSymTilesPerBlock * kBlock);
-  if (q0 >= Q) return;
-  int64_t q = q0 + threadIdx.x;
-  int nbypass = 0;
-  SymTile<PT> A, B;
-  symtile_load(A, d, q, Q, hw4);
-#pragma unroll
-  for (int t = 0; t < kSymTilesPerBlock; t += 2) {
-    symtile_load(B, d, q + kBlock, Q, hw4);       // in flight while A is evaluated
-    nbypass += symtile_eval<MODE, CLAMPED, PT>(A, d);
-    if (t + 2 < kSymTilesPerBlock) symtile_load(A, d, q + 2 * kBlock, Q, hw4);
-    nbypass += symtile_eval<MODE, CLAMPED, PT>(B, d);
-    q += 2 * kBlock;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) nbypass += __shfl_xor(nbypass, o, 64);
-  if ((threadIdx.x & 63) == 0 && nbypass) atomicAdd(d.meta, (unsigned long long)nbypass);
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // cdf_pair_kernel: float probe of the mixture CDF at both edges of v (parity tests: 1e-5 bar, in fact bit-exact)
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE>
@@ -737,22 +639,8 @@ static int launch_symtab_v(const EncDesc *d, int count, int M_max, int64_t hw_ma
   }
   return launch_err();
 }
-template <bool CLAMPED, typename PT>
-static int launch_symtab_pipe(const EncDesc *d, int count, int M_max, int64_t hw_max, int mode, hipStream_t s) {
-  const int64_t quads = (int64_t)M_max * (hw_max / 4), per_block = (int64_t)kSymTilesPerBlock * kBlock;
-  dim3 grid((unsigned)((quads + per_block - 1) / per_block), (unsigned)count);
-  switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((symtab_pipe_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((symtab_pipe_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d); break;
-  default: hipLaunchKernelGGL((symtab_pipe_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d); break;
-  }
-  return launch_err();
-}
-
 template <typename PT>
 static int launch_symtab_t(const EncDesc *d, int count, int M_max, int64_t hw_max, int mode, int vec, bool clamped, hipStream_t s) {
-  if (vec == 8) return clamped ? launch_symtab_pipe<true, PT>(d, count, M_max, hw_max, mode, s)
-                               : launch_symtab_pipe<false, PT>(d, count, M_max, hw_max, mode, s);
   if (vec == 4) return clamped ? launch_symtab_v<4, true, PT>(d, count, M_max, hw_max, mode, s)
                                : launch_symtab_v<4, false, PT>(d, count, M_max, hw_max, mode, s);
   return clamped ? launch_symtab_v<1, true, PT>(d, count, M_max, hw_max, mode, s)
