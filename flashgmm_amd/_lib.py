@@ -64,6 +64,20 @@ SIGNATURES = {
     "fgmm_selftest_fastmath": (_i, [_p, _i, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "fgmm_rans_encode_symtab": (_i, [_p, _p, _i64, _pp, _psz]),
     "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, _i64, _i32, _p]),
+    # table path (z hyper-latent coder), host only
+    "fgmm_encode_with_indexes": (_i, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _pp, _psz]),
+    "fgmm_decode_with_indexes": (_i, [_p, _sz, _p, _i64, _p, _i64, _i32, _p, _p, _p]),
+    "fgmm_symbuf_create": (_i, [_pp]),
+    "fgmm_symbuf_destroy": (None, [_p]),
+    "fgmm_symbuf_size": (_i64, [_p]),
+    "fgmm_symbuf_append_table": (_i, [_p, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
+    "fgmm_symbuf_append_symtab": (_i, [_p, _p, _p, _i64]),
+    "fgmm_symbuf_flush": (_i, [_p, _pp, _psz]),
+    "fgmm_symbuf_append_gmm": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i]),
+    "fgmm_decstream_create": (_i, [_p, _sz, _pp]),
+    "fgmm_decstream_destroy": (None, [_p]),
+    "fgmm_decstream_decode": (_i, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p]),
+    "fgmm_pmf_to_quantized_cdf": (_i, [_p, _i, _i, _p]),
 }
 
 _lib = None

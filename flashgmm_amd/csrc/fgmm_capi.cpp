@@ -275,6 +275,7 @@ struct EncItem {
   int64_t hw = 0;
   int clamp = 0;
   float *yq = nullptr; // device out
+  fgmm_symbuf *symbuf = nullptr; // raw boundary, buffered form: append the symbols instead of flushing a stream
   // outputs
   int64_t *zero_bitmap = nullptr; // host [M] or null
   int32_t abs_max = 0;
@@ -421,7 +422,8 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     const uint32_t *packed = reinterpret_cast<const uint32_t *>(ctx->h_ws + it.o_packed);
     EncItem *pit = &it;
     auto job = [pit, packed, syms_for_bypass, n, n_bypass] {
-      pit->status = rans_encode_symtab(packed, syms_for_bypass, n, (int64_t)n_bypass, &pit->bytes, &pit->bytes_len);
+      if (pit->symbuf) pit->status = fgmm_symbuf_append_symtab(pit->symbuf, packed, syms_for_bypass, n);
+      else pit->status = rans_encode_symtab(packed, syms_for_bypass, n, (int64_t)n_bypass, &pit->bytes, &pit->bytes_len);
     };
     if (count == 1) job(); else ctx->pool->submit(job);
   }
@@ -886,11 +888,11 @@ struct FreeList {
 
 } // namespace
 
-int fgmm_encode_with_indexes_gmm(fgmm_ctx *ctx, const int32_t *symbols, const float *scales, const float *means,
-                                 const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int K,
-                                 int mode, int memspace, int32_t max_value, uint8_t **out, size_t *out_len) {
-  (void)max_value; // ignored by the reference too (rans_interface.cpp:462)
-  if (!ctx || !out || !out_len || n < 0 || !mode_ok(mode)) return fail(FGMM_ERR_INVALID, "bad argument");
+namespace {
+int encode_rows(fgmm_ctx *ctx, const int32_t *symbols, const float *scales, const float *means, const float *weights,
+                int64_t n, int64_t stride_n, int64_t stride_k, int K, int mode, int memspace, fgmm_symbuf *symbuf,
+                uint8_t **out, size_t *out_len) {
+  if (!ctx || n < 0 || !mode_ok(mode)) return fail(FGMM_ERR_INVALID, "bad argument");
   if (K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", K);
   if (n && (!symbols || !scales || !means || !weights)) return fail(FGMM_ERR_INVALID, "null tensor");
   std::lock_guard<std::mutex> lock(ctx->mu);
@@ -918,11 +920,30 @@ int fgmm_encode_with_indexes_gmm(fgmm_ctx *ctx, const int32_t *symbols, const fl
   e.M = 1;
   e.hw = n;
   e.clamp = 0;
+  e.symbuf = symbuf;
   rc = encode_batch(ctx, stream, v, mode);
   if (rc) return rc;
-  *out = e.bytes;
-  *out_len = e.bytes_len;
+  if (out) {
+    *out = e.bytes;
+    *out_len = e.bytes_len;
+  }
   return FGMM_OK;
+}
+} // namespace
+
+int fgmm_encode_with_indexes_gmm(fgmm_ctx *ctx, const int32_t *symbols, const float *scales, const float *means,
+                                 const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int K,
+                                 int mode, int memspace, int32_t max_value, uint8_t **out, size_t *out_len) {
+  (void)max_value; // ignored by the reference too (rans_interface.cpp:462)
+  if (!out || !out_len) return fail(FGMM_ERR_INVALID, "bad argument");
+  return encode_rows(ctx, symbols, scales, means, weights, n, stride_n, stride_k, K, mode, memspace, nullptr, out, out_len);
+}
+
+int fgmm_symbuf_append_gmm(fgmm_ctx *ctx, fgmm_symbuf *b, const int32_t *symbols, const float *scales,
+                           const float *means, const float *weights, int64_t n, int64_t stride_n, int64_t stride_k,
+                           int K, int mode, int memspace) {
+  if (!b) return fail(FGMM_ERR_INVALID, "symbuf == NULL");
+  return encode_rows(ctx, symbols, scales, means, weights, n, stride_n, stride_k, K, mode, memspace, b, nullptr, nullptr);
 }
 
 int fgmm_decode_with_indexes_gmm(fgmm_ctx *ctx, const uint8_t *encoded, size_t encoded_len, const float *scales,

@@ -21,7 +21,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
 #include <mutex>
+#include <vector>
 
 #include "../../include/flashgmm_amd.h"
 #include "fgmm_internal.h"
@@ -408,6 +410,219 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
   return FGMM_OK;
 }
 
+// ============================================================================================================
+// Table path — CompressAI's original table rANS, used for the `z` hyper-latent:
+//   BufferedRansEncoder::encode_with_indexes (lists)   rans_interface.cpp:334-399
+//   RansDecoder::decode_with_indexes / decode_stream   rans_interface.cpp:619-688, :894-956
+// plus the buffered form shared with the GMM tables (BufferedRansEncoder::_syms, rans_interface.hpp:85).
+// Integer only.  Unlike the reference (asserts compiled out) every index is validated.
+// ============================================================================================================
+struct SymBuf {
+  // one entry of the reference's _syms: start | range << 16 | bypass << 32
+  std::vector<uint64_t> e;
+  inline void push(uint32_t start, uint32_t range, bool bypass) {
+    e.push_back((uint64_t)(start & 0xFFFFu) | ((uint64_t)(range & 0xFFFFu) << 16) | ((uint64_t)bypass << 32));
+  }
+};
+
+static int table_args_ok(const int32_t *cdfs, int64_t cdf_stride, int32_t n_cdfs, const int32_t *cdfs_sizes,
+                         const int32_t *offsets) {
+  if (!cdfs || !cdfs_sizes || !offsets || n_cdfs <= 0 || cdf_stride < 2) return 0;
+  for (int32_t k = 0; k < n_cdfs; ++k)
+    if (cdfs_sizes[k] < 2 || cdfs_sizes[k] > cdf_stride) return 0;
+  return 1;
+}
+
+int symbuf_append_table(SymBuf &sb, const int32_t *symbols, const int32_t *indexes, int64_t n, const int32_t *cdfs,
+                        int64_t cdf_stride, int32_t n_cdfs, const int32_t *cdfs_sizes, const int32_t *offsets) {
+  if (n < 0 || (n > 0 && (!symbols || !indexes))) return FGMM_ERR_INVALID;
+  if (n == 0) return FGMM_OK;
+  if (!table_args_ok(cdfs, cdf_stride, n_cdfs, cdfs_sizes, offsets)) return FGMM_ERR_INVALID;
+  sb.e.reserve(sb.e.size() + (size_t)n + 16);
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t k = indexes[i];
+    if (k < 0 || k >= n_cdfs) return FGMM_ERR_INVALID;
+    const int32_t *cdf = cdfs + (int64_t)k * cdf_stride;
+    const int32_t max_value = cdfs_sizes[k] - 2; // :350
+    int64_t value = (int64_t)symbols[i] - offsets[k];
+    uint32_t raw_val = 0;
+    if (value < 0) { // :357-363 (the reference computes in int32: identical while |value| < 2^30)
+      raw_val = (uint32_t)(-2 * value - 1);
+      value = max_value;
+    } else if (value >= max_value) {
+      raw_val = (uint32_t)(2 * (value - max_value));
+      value = max_value;
+    }
+    sb.push((uint32_t)cdf[value], (uint32_t)(cdf[value + 1] - cdf[value]), false); // :368-370
+    if (value == max_value) { // bypass: nibble count in base-15 continuation, then the nibbles (:373-397)
+      int32_t n_bypass = 0;
+      while (n_bypass < 8 && (raw_val >> (n_bypass * kBypassBits)) != 0) ++n_bypass;
+      int32_t val = n_bypass;
+      while (val >= (int32_t)kMaxBypassVal) {
+        sb.push(kMaxBypassVal, kMaxBypassVal + 1, true);
+        val -= (int32_t)kMaxBypassVal;
+      }
+      sb.push((uint32_t)val, (uint32_t)val + 1, true);
+      for (int32_t j = 0; j < n_bypass; ++j) {
+        const uint32_t nib = (raw_val >> (j * kBypassBits)) & kMaxBypassVal;
+        sb.push(nib, nib + 1, true);
+      }
+    }
+  }
+  return FGMM_OK;
+}
+
+// GMM symbol table (start | range << 16, range == 0 = escape) -> _syms entries, rans_interface.cpp:509-552
+int symbuf_append_symtab(SymBuf &sb, const uint32_t *packed, const int32_t *symbols, int64_t n) {
+  if (n < 0 || (n > 0 && !packed)) return FGMM_ERR_INVALID;
+  sb.e.reserve(sb.e.size() + (size_t)n + 16);
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t ent = packed[i], freq = ent >> 16;
+    if (freq) {
+      sb.push(ent & 0xFFFFu, freq, false);
+      continue;
+    }
+    const int32_t value = symbols ? symbols[i] : (int32_t)(int16_t)(uint16_t)(ent & 0xFFFFu);
+    const uint32_t raw = (uint32_t)value;
+    int nn = 0;
+    for (uint32_t t = raw; t != 0; t >>= kBypassBits) ++nn;
+    sb.push(kMaxCdf, 1, false);
+    sb.push((uint32_t)nn, (uint32_t)nn + 1, true);
+    for (int j = 0; j < nn; ++j) {
+      const uint32_t nib = (raw >> (j * kBypassBits)) & kMaxBypassVal;
+      sb.push(nib, nib + 1, true);
+    }
+  }
+  return FGMM_OK;
+}
+
+// BufferedRansEncoder::flush, rans_interface.cpp:557-585
+int symbuf_flush(SymBuf &sb, uint8_t **out, size_t *out_len) {
+  std::call_once(g_rcp_once, init_rcp);
+  if (!out || !out_len) return FGMM_ERR_INVALID;
+  const size_t nwords = sb.e.size() + 16;
+  uint32_t *buf = (uint32_t *)malloc(nwords * sizeof(uint32_t));
+  if (!buf) return FGMM_ERR_NOMEM;
+  uint32_t *const end = buf + nwords;
+  Enc e{kRansL, end};
+  for (size_t i = sb.e.size(); i-- > 0;) {
+    const uint64_t v = sb.e[i];
+    const uint32_t start = (uint32_t)(v & 0xFFFFu), range = (uint32_t)((v >> 16) & 0xFFFFu);
+    if (v >> 32) e.put_bits(start);
+    else if (range) e.put(start, range);
+    else { // a zero-width table entry cannot be coded (the reference divides by zero): refuse
+      free(buf);
+      sb.e.clear();
+      return FGMM_ERR_INVALID;
+    }
+  }
+  sb.e.clear();
+  e.ptr -= 2;
+  e.ptr[0] = (uint32_t)(e.x >> 0);
+  e.ptr[1] = (uint32_t)(e.x >> 32);
+  const size_t nbytes = (size_t)(end - e.ptr) * sizeof(uint32_t);
+  uint8_t *o = (uint8_t *)malloc(nbytes);
+  if (!o) {
+    free(buf);
+    return FGMM_ERR_NOMEM;
+  }
+  memcpy(o, e.ptr, nbytes);
+  free(buf);
+  *out = o;
+  *out_len = nbytes;
+  return FGMM_OK;
+}
+
+struct DecStream { // RansDecoder's streaming state: _rans, _stream, _ptr (rans_interface.hpp:150-153)
+  std::vector<uint32_t> words;
+  Dec d;
+};
+
+int decstream_init(DecStream &ds, const uint8_t *enc, size_t enc_len) {
+  if (!enc || enc_len < 8 || (enc_len & 3)) return FGMM_ERR_STREAM;
+  ds.words.resize(enc_len / 4);
+  memcpy(ds.words.data(), enc, enc_len);
+  ds.d = Dec();
+  ds.d.x = (uint64_t)ds.words[0] | ((uint64_t)ds.words[1] << 32);
+  ds.d.ptr = ds.words.data() + 2;
+  ds.d.end = ds.words.data() + ds.words.size();
+  return FGMM_OK;
+}
+
+int decstream_decode(DecStream &ds, const int32_t *indexes, int64_t n, const int32_t *cdfs, int64_t cdf_stride,
+                     int32_t n_cdfs, const int32_t *cdfs_sizes, const int32_t *offsets, int32_t *out) {
+  if (n < 0 || (n > 0 && (!indexes || !out))) return FGMM_ERR_INVALID;
+  if (n == 0) return FGMM_OK;
+  if (!table_args_ok(cdfs, cdf_stride, n_cdfs, cdfs_sizes, offsets)) return FGMM_ERR_INVALID;
+  Dec &d = ds.d;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t k = indexes[i];
+    if (k < 0 || k >= n_cdfs) return FGMM_ERR_INVALID;
+    const int32_t *cdf = cdfs + (int64_t)k * cdf_stride;
+    const int32_t size = cdfs_sizes[k], max_value = size - 2;
+    const uint32_t cf = (uint32_t)(d.x & 0xFFFFu); // :648
+    // std::lower_bound(cdf, cdf + size, cf + 1) - 1: the last s with cdf[s] <= cf   (:651-653)
+    int32_t lo = 0, hi = size;
+    while (lo < hi) {
+      const int32_t mid = lo + (hi - lo) / 2;
+      if ((uint32_t)cdf[mid] < cf + 1) lo = mid + 1; else hi = mid;
+    }
+    const int32_t s = lo - 1;
+    if (s < 0 || s + 1 >= size) return FGMM_ERR_INVALID; // malformed table (cdf[0] != 0 or not reaching 2^16)
+    d.advance((uint32_t)cdf[s], (uint32_t)(cdf[s + 1] - cdf[s])); // :656
+    int32_t value = s;
+    if (value == max_value) { // :660-682
+      int32_t val = (int32_t)d.get_bits();
+      int32_t n_bypass = val;
+      while (val == (int32_t)kMaxBypassVal && !d.underrun) {
+        val = (int32_t)d.get_bits();
+        n_bypass += val;
+      }
+      int32_t raw_val = 0;
+      for (int j = 0; j < n_bypass && !d.underrun; ++j)
+        raw_val |= (int32_t)(d.get_bits() << ((j * kBypassBits) & 31));
+      value = raw_val >> 1;
+      if (raw_val & 1) value = -value - 1; else value += max_value;
+    }
+    out[i] = value + offsets[k]; // :684
+    if (d.underrun) return FGMM_ERR_STREAM;
+  }
+  return FGMM_OK;
+}
+
+// compressai._CXX.pmf_to_quantized_cdf, ops.cpp:40-109 (runs once per model; float -> integer, host)
+int pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf) {
+  if (n <= 0 || !pmf || !cdf || precision < 1 || precision > 16) return FGMM_ERR_INVALID;
+  for (int i = 0; i < n; ++i)
+    if (pmf[i] < 0 || !std::isfinite(pmf[i])) return FGMM_ERR_INVALID;
+  cdf[0] = 0;
+  for (int i = 0; i < n; ++i) cdf[i + 1] = (uint32_t)std::round(pmf[i] * (float)(1 << precision));
+  uint32_t total = 0;
+  for (int i = 0; i <= n; ++i) total += cdf[i];
+  if (total == 0) return FGMM_ERR_INVALID;
+  for (int i = 0; i <= n; ++i) cdf[i] = (uint32_t)(((uint64_t)(1 << precision) * cdf[i]) / total);
+  for (int i = 1; i <= n; ++i) cdf[i] += cdf[i - 1];
+  cdf[n] = 1u << precision;
+  for (int i = 0; i < n; ++i) {
+    if (cdf[i] != cdf[i + 1]) continue;
+    uint32_t best_freq = ~0u; // steal one count from the rarest symbol that can spare it
+    int best_steal = -1;
+    for (int j = 0; j < n; ++j) {
+      const uint32_t freq = cdf[j + 1] - cdf[j];
+      if (freq > 1 && freq < best_freq) {
+        best_freq = freq;
+        best_steal = j;
+      }
+    }
+    if (best_steal < 0) return FGMM_ERR_INVALID; // more symbols than 2^precision counts (the reference asserts)
+    if (best_steal < i)
+      for (int j = best_steal + 1; j <= i; ++j) cdf[j]--;
+    else
+      for (int j = i + 1; j <= best_steal; ++j) cdf[j]++;
+  }
+  return FGMM_OK;
+}
+
 } // namespace fgmm
 
 extern "C" {
@@ -423,5 +638,73 @@ int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const ui
 }
 
 void fgmm_free(void *p) { free(p); }
+
+struct fgmm_symbuf {
+  fgmm::SymBuf sb;
+};
+struct fgmm_decstream {
+  fgmm::DecStream ds;
+};
+
+int fgmm_symbuf_create(fgmm_symbuf **out) {
+  if (!out) return FGMM_ERR_INVALID;
+  *out = new (std::nothrow) fgmm_symbuf;
+  return *out ? FGMM_OK : FGMM_ERR_NOMEM;
+}
+void fgmm_symbuf_destroy(fgmm_symbuf *b) { delete b; }
+int64_t fgmm_symbuf_size(const fgmm_symbuf *b) { return b ? (int64_t)b->sb.e.size() : -1; }
+int fgmm_symbuf_append_table(fgmm_symbuf *b, const int32_t *symbols, const int32_t *indexes, int64_t n,
+                             const int32_t *cdfs, int64_t cdf_stride, int32_t n_cdfs, const int32_t *cdfs_sizes,
+                             const int32_t *offsets) {
+  if (!b) return FGMM_ERR_INVALID;
+  return fgmm::symbuf_append_table(b->sb, symbols, indexes, n, cdfs, cdf_stride, n_cdfs, cdfs_sizes, offsets);
+}
+int fgmm_symbuf_append_symtab(fgmm_symbuf *b, const uint32_t *packed, const int32_t *symbols_or_null, int64_t n) {
+  if (!b) return FGMM_ERR_INVALID;
+  return fgmm::symbuf_append_symtab(b->sb, packed, symbols_or_null, n);
+}
+int fgmm_symbuf_flush(fgmm_symbuf *b, uint8_t **out, size_t *out_len) {
+  if (!b) return FGMM_ERR_INVALID;
+  return fgmm::symbuf_flush(b->sb, out, out_len);
+}
+
+int fgmm_encode_with_indexes(const int32_t *symbols, const int32_t *indexes, int64_t n, const int32_t *cdfs,
+                             int64_t cdf_stride, int32_t n_cdfs, const int32_t *cdfs_sizes, const int32_t *offsets,
+                             uint8_t **out, size_t *out_len) {
+  fgmm::SymBuf sb;
+  const int rc = fgmm::symbuf_append_table(sb, symbols, indexes, n, cdfs, cdf_stride, n_cdfs, cdfs_sizes, offsets);
+  return rc ? rc : fgmm::symbuf_flush(sb, out, out_len);
+}
+
+int fgmm_decstream_create(const uint8_t *encoded, size_t encoded_len, fgmm_decstream **out) {
+  if (!out) return FGMM_ERR_INVALID;
+  fgmm_decstream *d = new (std::nothrow) fgmm_decstream;
+  if (!d) return FGMM_ERR_NOMEM;
+  const int rc = fgmm::decstream_init(d->ds, encoded, encoded_len);
+  if (rc) {
+    delete d;
+    return rc;
+  }
+  *out = d;
+  return FGMM_OK;
+}
+void fgmm_decstream_destroy(fgmm_decstream *d) { delete d; }
+int fgmm_decstream_decode(fgmm_decstream *d, const int32_t *indexes, int64_t n, const int32_t *cdfs, int64_t cdf_stride,
+                          int32_t n_cdfs, const int32_t *cdfs_sizes, const int32_t *offsets, int32_t *out_symbols) {
+  if (!d) return FGMM_ERR_INVALID;
+  return fgmm::decstream_decode(d->ds, indexes, n, cdfs, cdf_stride, n_cdfs, cdfs_sizes, offsets, out_symbols);
+}
+
+int fgmm_decode_with_indexes(const uint8_t *encoded, size_t encoded_len, const int32_t *indexes, int64_t n,
+                             const int32_t *cdfs, int64_t cdf_stride, int32_t n_cdfs, const int32_t *cdfs_sizes,
+                             const int32_t *offsets, int32_t *out_symbols) {
+  fgmm::DecStream ds;
+  const int rc = fgmm::decstream_init(ds, encoded, encoded_len);
+  return rc ? rc : fgmm::decstream_decode(ds, indexes, n, cdfs, cdf_stride, n_cdfs, cdfs_sizes, offsets, out_symbols);
+}
+
+int fgmm_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf_out) {
+  return fgmm::pmf_to_quantized_cdf(pmf, n, precision, cdf_out);
+}
 
 } // extern "C"

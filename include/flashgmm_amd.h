@@ -207,6 +207,48 @@ int fgmm_rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_nu
 int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint32_t *hdr, const uint8_t *pool,
                             int64_t n, int32_t max_bs, int32_t *out_symbols);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * 4. Table path — the `z` hyper-latent coder: CompressAI's original table rANS, the other
+ *    half of `compressai.ans`.  Host only, integer only.  `cdfs` is a row-major int32 [n_cdfs, cdf_stride] matrix
+ *    (the reference takes a list of lists, rans_interface.cpp:334-338); every index is validated here (the
+ *    reference's asserts are compiled out).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* RansEncoder.encode_with_indexes(symbols, indexes, cdfs, cdfs_sizes, offsets) -> bytes  (rans_interface.cpp:587-598) */
+int fgmm_encode_with_indexes(const int32_t *symbols, const int32_t *indexes, int64_t n, const int32_t *cdfs,
+                             int64_t cdf_stride, int32_t n_cdfs, const int32_t *cdfs_sizes, const int32_t *offsets,
+                             uint8_t **out, size_t *out_len);
+/* RansDecoder.decode_with_indexes(encoded, indexes, cdfs, cdfs_sizes, offsets) -> int32[n]  (rans_interface.cpp:619-688) */
+int fgmm_decode_with_indexes(const uint8_t *encoded, size_t encoded_len, const int32_t *indexes, int64_t n,
+                             const int32_t *cdfs, int64_t cdf_stride, int32_t n_cdfs, const int32_t *cdfs_sizes,
+                             const int32_t *offsets, int32_t *out_symbols);
+
+/* BufferedRansEncoder (rans_interface.hpp:57-86): symbols accumulate over calls — table calls and GMM symbol tables
+ * may be mixed — and ONE stream is flushed (rans_interface.cpp:557-585). */
+typedef struct fgmm_symbuf fgmm_symbuf;
+int fgmm_symbuf_create(fgmm_symbuf **out);
+void fgmm_symbuf_destroy(fgmm_symbuf *b);
+int64_t fgmm_symbuf_size(const fgmm_symbuf *b); /* entries buffered (symbols + escape nibbles) */
+int fgmm_symbuf_append_table(fgmm_symbuf *b, const int32_t *symbols, const int32_t *indexes, int64_t n,
+                             const int32_t *cdfs, int64_t cdf_stride, int32_t n_cdfs, const int32_t *cdfs_sizes,
+                             const int32_t *offsets);
+int fgmm_symbuf_append_symtab(fgmm_symbuf *b, const uint32_t *packed, const int32_t *symbols_or_null, int64_t n);
+int fgmm_symbuf_flush(fgmm_symbuf *b, uint8_t **out, size_t *out_len); /* empties the buffer */
+/* GPU-built GMM symbols appended to a buffer: BufferedRansEncoder.encode_with_indexes_gmm (rans_interface.cpp:458-554) */
+int fgmm_symbuf_append_gmm(fgmm_ctx *ctx, fgmm_symbuf *b, const int32_t *symbols, const float *scales,
+                           const float *means, const float *weights, int64_t n, int64_t stride_n, int64_t stride_k,
+                           int K, int mode, int memspace);
+
+/* RansDecoder.set_stream / decode_stream (rans_interface.cpp:886-956): a decoder that keeps its state between calls */
+typedef struct fgmm_decstream fgmm_decstream;
+int fgmm_decstream_create(const uint8_t *encoded, size_t encoded_len, fgmm_decstream **out); /* copies the stream */
+void fgmm_decstream_destroy(fgmm_decstream *d);
+int fgmm_decstream_decode(fgmm_decstream *d, const int32_t *indexes, int64_t n, const int32_t *cdfs, int64_t cdf_stride,
+                          int32_t n_cdfs, const int32_t *cdfs_sizes, const int32_t *offsets, int32_t *out_symbols);
+
+/* compressai._CXX.pmf_to_quantized_cdf (compressai/cpp_exts/ops/ops.cpp:40-109): cdf_out has n + 1 entries */
+int fgmm_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -521,3 +521,140 @@ int fgo_rans_decode_cdftab(const uint8_t *enc, size_t enc_len, int64_t n, const 
   free(words);
   return 0;
 }
+
+/* ================================================================================================
+ * Table path (the `z` hyper-latent coder) — CompressAI's original table rANS
+ *   BufferedRansEncoder::encode_with_indexes   rans_interface.cpp:334-399
+ *   RansDecoder::decode_with_indexes           rans_interface.cpp:619-688   (decode_stream :894-956 is the same loop)
+ *   pmf_to_quantized_cdf                       compressai/cpp_exts/ops/ops.cpp:40-109
+ * cdfs is a row-major [n_cdfs, cdf_stride] int32 matrix (the reference takes a list of lists).
+ * ============================================================================================== */
+
+static int fgo_push_table_symbol(fgo_symvec *sv, int32_t symbol, const int32_t *cdf, int32_t cdf_size, int32_t offset) {
+  const int32_t max_value = cdf_size - 2; /* :350 */
+  int32_t value = symbol - offset;        /* :354 */
+  uint32_t raw_val = 0;
+  if (value < 0) { /* :357-363 */
+    raw_val = (uint32_t)(-2 * value - 1);
+    value = max_value;
+  } else if (value >= max_value) {
+    raw_val = (uint32_t)(2 * (value - max_value));
+    value = max_value;
+  }
+  if (fgo_push(sv, (uint16_t)cdf[value], (uint16_t)(cdf[value + 1] - cdf[value]), 0)) return -1; /* :368-370 */
+  if (value == max_value) { /* :373-397 */
+    int32_t n_bypass = 0;
+    while ((raw_val >> (n_bypass * FGO_BYPASS_PRECISION)) != 0) ++n_bypass;
+    int32_t val = n_bypass;
+    while (val >= FGO_MAX_BYPASS_VAL) {
+      if (fgo_push(sv, FGO_MAX_BYPASS_VAL, FGO_MAX_BYPASS_VAL + 1, 1)) return -1;
+      val -= FGO_MAX_BYPASS_VAL;
+    }
+    if (fgo_push(sv, (uint32_t)val, (uint32_t)val + 1, 1)) return -1;
+    for (int32_t j = 0; j < n_bypass; ++j) {
+      const uint32_t nib = (raw_val >> (j * FGO_BYPASS_PRECISION)) & FGO_MAX_BYPASS_VAL;
+      if (fgo_push(sv, nib, nib + 1, 1)) return -1;
+    }
+  }
+  return 0;
+}
+
+int fgo_encode_table(int64_t n, const int32_t *symbols, const int32_t *indexes, const int32_t *cdfs,
+                     int64_t cdf_stride, const int32_t *cdfs_sizes, const int32_t *offsets, uint8_t **out,
+                     size_t *out_len) {
+  fgo_symvec sv = {0, 0, 0};
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t k = indexes[i];
+    if (fgo_push_table_symbol(&sv, symbols[i], cdfs + k * cdf_stride, cdfs_sizes[k], offsets[k])) {
+      free(sv.s);
+      return -1;
+    }
+  }
+  int rc = fgo_flush(&sv, out, out_len);
+  free(sv.s);
+  return rc;
+}
+
+int fgo_decode_table(const uint8_t *enc, size_t enc_len, int64_t n, const int32_t *indexes, const int32_t *cdfs,
+                     int64_t cdf_stride, const int32_t *cdfs_sizes, const int32_t *offsets, int32_t *out) {
+  if (enc_len < 8) return -2;
+  uint32_t *words = (uint32_t *)malloc(enc_len + 64);
+  if (!words) return -1;
+  memset(words, 0, enc_len + 64);
+  memcpy(words, enc, enc_len);
+  const uint32_t *ptr = words;
+  uint64_t rans = (uint64_t)ptr[0] | ((uint64_t)ptr[1] << 32);
+  ptr += 2;
+  const uint32_t *limit = words + (enc_len + 64) / 4 - 12;
+  for (int64_t i = 0; i < n; ++i) {
+    if (ptr > limit) {
+      free(words);
+      return -3;
+    }
+    const int32_t k = indexes[i];
+    const int32_t *cdf = cdfs + k * cdf_stride;
+    const int32_t max_value = cdfs_sizes[k] - 2;
+    const uint32_t cum_freq = (uint32_t)(rans & 0xFFFFu); /* :648 */
+    /* std::lower_bound(cdf, cdf + size, cum_freq + 1) - 1  == last s with cdf[s] <= cum_freq   (:651-653) */
+    int32_t lo = 0, hi = cdfs_sizes[k];
+    while (lo < hi) {
+      const int32_t mid = lo + (hi - lo) / 2;
+      if ((uint32_t)cdf[mid] < cum_freq + 1) lo = mid + 1; else hi = mid;
+    }
+    const int32_t s = lo - 1;
+    fgo_dec_advance(&rans, &ptr, (uint32_t)cdf[s], (uint32_t)(cdf[s + 1] - cdf[s])); /* :656 */
+    int32_t value = s;
+    if (value == max_value) { /* :660-682 */
+      int32_t val = (int32_t)fgo_dec_get_bits(&rans, &ptr, FGO_BYPASS_PRECISION);
+      int32_t n_bypass = val;
+      while (val == FGO_MAX_BYPASS_VAL) {
+        val = (int32_t)fgo_dec_get_bits(&rans, &ptr, FGO_BYPASS_PRECISION);
+        n_bypass += val;
+      }
+      int32_t raw_val = 0;
+      for (int j = 0; j < n_bypass; ++j) {
+        val = (int32_t)fgo_dec_get_bits(&rans, &ptr, FGO_BYPASS_PRECISION);
+        raw_val |= (int32_t)((uint32_t)val << ((j * FGO_BYPASS_PRECISION) & 31));
+      }
+      value = raw_val >> 1;
+      if (raw_val & 1) value = -value - 1; else value += max_value;
+    }
+    out[i] = value + offsets[k]; /* :684 */
+  }
+  free(words);
+  return 0;
+}
+
+/* ops.cpp:40-109.  Returns 0, or -1 for a negative / non-finite element, -2 for an all-zero pmf. */
+int fgo_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf /* n+1 */) {
+  for (int i = 0; i < n; ++i)
+    if (pmf[i] < 0 || !isfinite(pmf[i])) return -1;
+  cdf[0] = 0;
+  for (int i = 0; i < n; ++i) cdf[i + 1] = (uint32_t)roundf(pmf[i] * (float)(1 << precision)); /* std::round(float) */
+  uint32_t total = 0;
+  for (int i = 0; i <= n; ++i) total += cdf[i];
+  if (total == 0) return -2;
+  for (int i = 0; i <= n; ++i) cdf[i] = (uint32_t)(((uint64_t)(1 << precision) * cdf[i]) / total);
+  for (int i = 1; i <= n; ++i) cdf[i] += cdf[i - 1];
+  cdf[n] = 1u << precision;
+  for (int i = 0; i < n; ++i) {
+    if (cdf[i] == cdf[i + 1]) {
+      uint32_t best_freq = ~0u;
+      int best_steal = -1;
+      for (int j = 0; j < n; ++j) {
+        uint32_t freq = cdf[j + 1] - cdf[j];
+        if (freq > 1 && freq < best_freq) {
+          best_freq = freq;
+          best_steal = j;
+        }
+      }
+      if (best_steal < 0) return -3; /* the reference asserts */
+      if (best_steal < i) {
+        for (int j = best_steal + 1; j <= i; ++j) cdf[j]--;
+      } else {
+        for (int j = i + 1; j <= best_steal; ++j) cdf[j]++;
+      }
+    }
+  }
+  return 0;
+}

@@ -57,6 +57,12 @@ def lib() -> C.CDLL:
         L.fgo_rans_decode_cdftab.argtypes = [p, C.c_size_t, i64, p, i32, p]
         L.fgo_rans_decode_cdftab.restype = C.c_int
         L.fgo_free.argtypes = [p]
+        L.fgo_encode_table.argtypes = [i64, p, p, p, i64, p, p, C.POINTER(p), C.POINTER(C.c_size_t)]
+        L.fgo_encode_table.restype = C.c_int
+        L.fgo_decode_table.argtypes = [p, C.c_size_t, i64, p, p, i64, p, p, p]
+        L.fgo_decode_table.restype = C.c_int
+        L.fgo_pmf_to_quantized_cdf.argtypes = [p, C.c_int, C.c_int, p]
+        L.fgo_pmf_to_quantized_cdf.restype = C.c_int
         _lib = L
     return _lib
 
@@ -172,6 +178,51 @@ def rans_decode_cdftab(encoded: bytes, tab: np.ndarray, max_bs_value: int) -> np
     return out
 
 
+def _table_args(indexes, cdfs, cdfs_sizes, offsets):
+    idx = np.ascontiguousarray(indexes, dtype=np.int32)
+    sizes = np.ascontiguousarray(cdfs_sizes, dtype=np.int32)
+    offs = np.ascontiguousarray(offsets, dtype=np.int32)
+    width = max(len(c) for c in cdfs)
+    mat = np.zeros((len(cdfs), width), np.int32)
+    for i, c in enumerate(cdfs):
+        mat[i, : len(c)] = c
+    return idx, mat, sizes, offs
+
+
+def encode_table(symbols, indexes, cdfs, cdfs_sizes, offsets) -> bytes:
+    """RansEncoder.encode_with_indexes(symbols, indexes, cdfs, cdfs_sizes, offsets)  (rans_interface.cpp:587-598)"""
+    sym = np.ascontiguousarray(symbols, dtype=np.int32)
+    idx, mat, sizes, offs = _table_args(indexes, cdfs, cdfs_sizes, offsets)
+    out_p, out_len = C.c_void_p(), C.c_size_t()
+    rc = lib().fgo_encode_table(len(sym), _ptr(sym), _ptr(idx), _ptr(mat), mat.shape[1], _ptr(sizes), _ptr(offs),
+                                C.byref(out_p), C.byref(out_len))
+    if rc:
+        raise RuntimeError(f"fgo_encode_table rc={rc}")
+    return _take_bytes(out_p, out_len)
+
+
+def decode_table(encoded: bytes, indexes, cdfs, cdfs_sizes, offsets) -> np.ndarray:
+    """RansDecoder.decode_with_indexes(encoded, indexes, cdfs, cdfs_sizes, offsets)  (rans_interface.cpp:619-688)"""
+    idx, mat, sizes, offs = _table_args(indexes, cdfs, cdfs_sizes, offsets)
+    out = np.empty(len(idx), np.int32)
+    buf = np.frombuffer(encoded, dtype=np.uint8)
+    rc = lib().fgo_decode_table(_ptr(buf), len(encoded), len(idx), _ptr(idx), _ptr(mat), mat.shape[1], _ptr(sizes),
+                                _ptr(offs), _ptr(out))
+    if rc:
+        raise RuntimeError(f"fgo_decode_table rc={rc}")
+    return out
+
+
+def pmf_to_quantized_cdf(pmf, precision: int = 16):
+    """compressai._CXX.pmf_to_quantized_cdf  (ops.cpp:40-109)"""
+    pmf = np.ascontiguousarray(pmf, dtype=np.float32)
+    out = np.zeros(len(pmf) + 1, np.uint32)
+    rc = lib().fgo_pmf_to_quantized_cdf(_ptr(pmf), len(pmf), precision, _ptr(out))
+    if rc:
+        raise ValueError(f"fgo_pmf_to_quantized_cdf rc={rc}")
+    return out.tolist()
+
+
 # ---------------------------------------------------------------------------------------------------
 # The REAL reference (oracle/_ref): only present where `make ref` ran (this container), or where the
 # prebuilt files travelled to (the GPU box).  APPROX_MODE is latched once per process by the reference
@@ -189,6 +240,17 @@ def ref_ans(flavour: str = ""):
 
     path = os.path.join(REF_DIR, flavour, "ans" + sysconfig.get_config_var("EXT_SUFFIX"))
     spec = importlib.util.spec_from_file_location("ans", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def ref_cxx(flavour: str = ""):
+    """Import the unmodified reference extension `compressai._CXX` (pmf_to_quantized_cdf) from oracle/_ref."""
+    path = os.path.join(REF_DIR, flavour, "_CXX" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if not os.path.exists(path):  # only the x86-64-v3 flavour of this (pybind11-only, scalar) module is built
+        path = os.path.join(REF_DIR, "_CXX" + sysconfig.get_config_var("EXT_SUFFIX"))
+    spec = importlib.util.spec_from_file_location("_CXX", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod

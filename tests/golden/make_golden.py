@@ -14,6 +14,9 @@ Fixtures:
   g3_small.json     G3     encode_with_indexes_gmm bytes, verbatim hex: n in {0,1,17,1000}, forced-bypass rows
                            with positive and negative symbols, plus decoder outputs
   ka1.json          KA-1   Kodak-half [1,192,32,24] cases (seeds 1234, 0..3): len + md5 + bypass count, 3 modes
+  g5_table.json     G5/G6  table path (the z hyper-latent coder): encode_with_indexes bytes for ragged CDF rows
+                           built by the reference's pmf_to_quantized_cdf, in-range and far out-of-range symbols
+                           (bypass), buffered + streaming forms; the known answer of tests/test_ops.py:104-106
   g4_api.json       G4     Python-API level: the reference's own GaussianMixtureConditional.compress /
                            decompress imported IN PLACE from /root/reference (un-clamped sigma, >=10 % zero
                            channels): md5(bytes), len, abs_max, zero_bitmap, sha256(y_q), decompress == y_q
@@ -82,6 +85,31 @@ def g3_cases():
     return cases
 
 
+def g5_cases(pmf_to_cdf):
+    """table path: name -> (symbols, indexes, cdfs(list of lists), cdfs_sizes, offsets).  CDF rows come from
+    `pmf_to_cdf` (the reference's / the oracle's pmf_to_quantized_cdf) on seeded pmfs of different lengths, so the
+    matrix is ragged as EntropyBottleneck's is; symbols fall inside and far outside the tables (bypass)."""
+    rng = np.random.default_rng(55)
+    n_cdfs = 6
+    lengths = [5, 9, 17, 33, 3, 64]
+    cdfs, sizes, offsets = [], [], []
+    for L in lengths:
+        pmf = rng.dirichlet(np.ones(L) * 0.7).astype(np.float32)
+        pmf[rng.integers(0, L)] = 0.0  # a zero-probability symbol: exercises the frequency stealing
+        tail = np.float32(1e-4)
+        cdf = pmf_to_cdf(np.concatenate([pmf, [tail]]).tolist(), 16)  # last entry = the bypass sentinel
+        cdfs.append([int(v) for v in cdf])
+        sizes.append(len(cdf))
+        offsets.append(-(L // 2))
+    cases = {}
+    for name, n, spread in (("t0", 0, 1), ("t1", 1, 1), ("t_in", 300, 1), ("t_mixed", 2000, 4), ("t_far", 64, 4000)):
+        idx = rng.integers(0, n_cdfs, n).astype(np.int32)
+        half = np.array([lengths[k] // 2 for k in idx], np.float64)
+        sym = np.round(rng.standard_normal(n) * half * 0.6 * spread).astype(np.int32)
+        cases[name] = (sym, idx, cdfs, sizes, offsets)
+    return cases
+
+
 def ka1_case(seed):
     y, sg, mu, pi = T.make_latent(seed)
     return T.to_coder_inputs(y, sg, mu, pi)
@@ -146,6 +174,25 @@ def worker(mode: int, flavour: str):
                          "md5": hashlib.md5(b).hexdigest(), "roundtrip": bool((d == sym).all())}
     out["ka1"] = ka
 
+    cxx = O.ref_cxx(flavour)
+    g5 = {}
+    for name, (sym, idx, cdfs, sizes, offsets) in g5_cases(cxx.pmf_to_quantized_cdf).items():
+        b = ans.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdfs, sizes, offsets)
+        d = ans.RansDecoder().decode_with_indexes(b, idx.tolist(), cdfs, sizes, offsets)
+        # buffered form, two calls into one stream + streaming decoder (set_stream / decode_stream)
+        be = ans.BufferedRansEncoder()
+        h = len(sym) // 2
+        be.encode_with_indexes(sym[:h].tolist(), idx[:h].tolist(), cdfs, sizes, offsets)
+        be.encode_with_indexes(sym[h:].tolist(), idx[h:].tolist(), cdfs, sizes, offsets)
+        b2 = be.flush()
+        dec = ans.RansDecoder()
+        dec.set_stream(b2)
+        d2 = dec.decode_stream(idx[:h].tolist(), cdfs, sizes, offsets) + dec.decode_stream(idx[h:].tolist(), cdfs, sizes, offsets)
+        g5[name] = {"hex": b.hex(), "decoded": list(d), "buffered_equal": b2 == b, "stream_decoded_equal": list(d2) == list(d)}
+    out["g5"] = g5
+    out["g5_cdfs"] = [list(map(int, c)) for c in g5_cases(cxx.pmf_to_quantized_cdf)["t1"][2]]
+    out["g6"] = [int(v) for v in cxx.pmf_to_quantized_cdf([0.1, 0.2, 0, 0], 16)]  # tests/test_ops.py:104-106
+
     if flavour == "":
         GMC = import_reference_entropy_models(ans)
         g4 = {}
@@ -187,7 +234,7 @@ def main():
         r = run_worker(mode, "")
         if have_native:
             rn = run_worker(mode, "native")
-            for key in ("g1_c1_bits", "g1_c2_bits", "g3", "ka1"):
+            for key in ("g1_c1_bits", "g1_c2_bits", "g3", "ka1", "g5", "g5_cdfs", "g6"):
                 assert r[key] == rn[key], f"x86-64-v3 and native reference builds differ: {name}/{key}"
         res[name] = r
         print(f"[{name}] reference run ok" + (" (v3 == native)" if have_native else ""))
@@ -227,6 +274,19 @@ def main():
     json.dump(g3_out, open(os.path.join(HERE, "g3_small.json"), "w"), indent=1)
     json.dump({name: res[name]["ka1"] for name in MODE_NAMES}, open(os.path.join(HERE, "ka1.json"), "w"), indent=1)
     json.dump({name: res[name]["g4"] for name in MODE_NAMES}, open(os.path.join(HERE, "g4_api.json"), "w"), indent=1)
+    # table path (mode independent): the oracle must rebuild the same CDF rows and the same bytes
+    r0 = res["polya"]
+    assert r0["g6"] == [0, 21845, 65534, 65535, 65536] == O.pmf_to_quantized_cdf([0.1, 0.2, 0, 0], 16)
+    ocases = g5_cases(O.pmf_to_quantized_cdf)
+    assert [list(c) for c in ocases["t1"][2]] == r0["g5_cdfs"], "oracle pmf_to_quantized_cdf differs from the reference"
+    for name, (sym, idx, cdfs, sizes, offsets) in ocases.items():
+        assert O.encode_table(sym, idx, cdfs, sizes, offsets).hex() == r0["g5"][name]["hex"], name
+        assert O.decode_table(bytes.fromhex(r0["g5"][name]["hex"]), idx, cdfs, sizes, offsets).tolist() == r0["g5"][name]["decoded"]
+        assert r0["g5"][name]["buffered_equal"] and r0["g5"][name]["stream_decoded_equal"], name
+        assert r0["g5"][name]["decoded"] == sym.tolist(), name  # the reference round-trips, bypass included
+    json.dump({"g6_pmf_to_quantized_cdf": r0["g6"], "cdfs": r0["g5_cdfs"],
+               "cases": {k: {"hex": v["hex"], "decoded": v["decoded"]} for k, v in r0["g5"].items()}},
+              open(os.path.join(HERE, "g5_table.json"), "w"), indent=1)
     # the survey's KA-1 must be what we just reproduced
     assert res["polya"]["ka1"]["1234"]["md5"] == "e759909d27406fbc0168c33b4509772d"
     assert res["as"]["ka1"]["1234"]["md5"] == "9283e03480f545471e6245b21aa61af5"
