@@ -170,7 +170,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("FGMM_BENCH_ONE_DEVICE"):  # RCCL refuses two ranks on one GPU: rehearse with gloo
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    coll_dev = dev if (dist and dist.get_backend() == "nccl") else torch.device("cpu")
 
     from flashgmm_amd import GaussianMixtureConditional, _lib
 
@@ -196,7 +200,7 @@ def main():
             k_sym.append(_lib.kernel_ms(local_rank, 0))
             k_qs.append(_lib.kernel_ms(local_rank, 2))
         if world > 1:  # the path's one exchange: per-stream bitstream lengths, RCCL all-gather
-            P.all_gather_stream_lengths([len(r[0][0]) for r in res], len(res), device=dev)
+            P.all_gather_stream_lengths([len(r[0][0]) for r in res], len(res), device=coll_dev)
         outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
         if record:
             k_tab.append(_lib.kernel_ms(local_rank, 1))
@@ -228,7 +232,7 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
