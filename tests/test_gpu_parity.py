@@ -445,3 +445,33 @@ def test_config0_256x256_plumbing(oracle):
             assert b == oracle.encode_gmm(mode, sym, s, m, wt)
             assert np.array_equal(oracle.decode_gmm(mode, b, s, m, wt, am + 1), sym)  # the reference's own decoder agrees
             assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq)
+
+
+@pytest.mark.parametrize("quantizer", ["noise", "weighted_mean_ste"])
+def test_latent_codec_contract(oracle, quantizer):
+    """GaussianMixtureConditionalLatentCodec.compress/decompress (latent_codecs/gaussian_mixture_conditional.py:127-181):
+    chunk(3,1) + softmax over K feed the entropy model in place; the output structure is the reference's."""
+    from flashgmm_amd.latent_codecs import GaussianMixtureConditionalLatentCodec
+
+    M, h, w, K = 24, 12, 10, 4
+    rng = np.random.default_rng(61)
+    y, sg, mu, pi = T.make_latent(61, M=M, h=h, w=w, clamp=False)
+    logits = rng.standard_normal((1, K * M, h, w)).astype(np.float32)
+    ctx = dv(np.concatenate([sg, mu, logits], axis=1))  # what entropy_parameters would output: [1, 3*K*M, h, w]
+    codec = GaussianMixtureConditionalLatentCodec(K=K, quantizer=quantizer, mode="polya")
+    out = codec.compress(dv(y), ctx)
+    assert set(out) == {"strings", "shape", "y_hat"} and tuple(out["shape"]) == (h, w)
+    (b, abs_max, zb), = out["strings"]
+    # independent recomputation of what must have been coded
+    s_t, m_t, l_t = ctx.chunk(3, 1)
+    w_t = torch.softmax(l_t.reshape(1, K, M, h, w), dim=1).reshape(1, K * M, h, w)
+    y_t = dv(y)
+    if quantizer == "weighted_mean_ste":
+        ws = (m_t.view(1, K, M, h, w) * w_t.view(1, K, M, h, w)).sum(1)
+        y_t = torch.round(y_t - ws)
+        m_t = (m_t.view(1, K, M, h, w) - ws.unsqueeze(1)).reshape(1, K * M, h, w)
+    sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y_t.cpu().numpy(), s_t.cpu().numpy(), m_t.cpu().numpy(), w_t.cpu().numpy())
+    assert b == oracle.encode_gmm("polya", sym, s, m, wt) and abs_max == am
+    dec = codec.decompress(out["strings"], out["shape"], ctx)
+    want = out["y_hat"] if quantizer == "noise" else out["y_hat"] + ws
+    assert torch.equal(dec["y_hat"], want)
