@@ -1,0 +1,101 @@
+"""GPU (-m gpu): randomized shapes / modes / dtypes / layouts against the oracle, concurrency, envelope edges."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from flashgmm_amd import GaussianMixtureConditional, testing as T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MODES = ["polya", "as", "logistic"]
+
+
+def dv(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_fuzz_shapes_modes_dtypes(oracle):
+    rng = np.random.default_rng(2025)
+    for case in range(48):
+        M = int(rng.integers(1, 41))
+        h, w = int(rng.integers(1, 21)), int(rng.integers(1, 21))
+        mode = MODES[case % 3]
+        f16 = bool(case % 4 == 3)
+        clamp = bool(case % 5 != 4)
+        y, sg, mu, pi = T.make_latent(9000 + case, M=M, h=h, w=w, clamp=False, zero_frac=float(rng.choice([0, 0.2, 0.6])))
+        if case % 7 == 0:  # outliers: far symbols -> bypass escape
+            y = y.copy()
+            y.reshape(-1)[rng.integers(0, y.size, max(1, y.size // 50))] *= 40
+        if not clamp:
+            sg = np.maximum(sg, np.float32(0.02))  # raw sigma path: keep it positive (the reference divides by it)
+        if f16:
+            sg, mu, pi = T.to_float16_planes(sg, mu, pi)
+        gmc = GaussianMixtureConditional(K=4, mode=mode, clamp_scales=clamp)
+        t = [dv(y)] + [dv(a) for a in (sg, mu, pi)]
+        if case % 6 == 1:  # non-contiguous channel stride: every second channel of a twice-as-large tensor
+            t[1:] = [torch.stack([x, x.flip(1)], 2).reshape(1, 2 * x.size(1), h, w)[:, ::2] for x in t[1:]]
+        (b, abs_max, zb), yq = gmc.compress(*t)
+        sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, *(a.astype(np.float32) for a in (sg, mu, pi)), clamp=clamp)
+        tag = (case, M, h, w, mode, f16, clamp)
+        assert abs_max == am and zb.cpu().tolist() == zbm.tolist(), tag
+        assert b == oracle.encode_gmm(mode, sym, s, m, wt), tag
+        if abs_max + 1 <= 16382:
+            assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq), tag
+
+
+def test_concurrent_callers_share_one_context(oracle):
+    """four Python threads compress / decompress on one GPU at once: calls serialise on the context, results stay right"""
+    cases = []
+    for seed in range(4):
+        y, sg, mu, pi = T.make_latent(700 + seed, M=16, h=12, w=8)
+        sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi)
+        cases.append(([dv(a) for a in (y, sg, mu, pi)], oracle.encode_gmm("polya", sym, s, m, wt), am))
+    errors = []
+
+    def worker(k):
+        try:
+            gmc = GaussianMixtureConditional(K=4, mode="polya")
+            t, want, am = cases[k]
+            for _ in range(25):
+                (b, abs_max, zb), yq = gmc.compress(*t)
+                assert b == want and abs_max == am
+                assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq)
+        except Exception as e:  # pragma: no cover
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errors, errors
+
+
+def test_decoder_half_width_envelope(oracle):
+    """max_bs_value = abs_max + 1 up to FGMM_MAX_BS = 16382 works (tables prune the saturated tails); beyond is loud"""
+    M, h, w = 2, 2, 2
+    y, sg, mu, pi = T.make_latent(5, M=M, h=h, w=w)
+    y = y.copy()
+    y[0, 0, 0, 0] = 16380.6  # abs_max = 16381 -> max_bs = 16382
+    gmc = GaussianMixtureConditional(K=4, mode="as")
+    t = [dv(a) for a in (y, sg, mu, pi)]
+    (b, abs_max, zb), yq = gmc.compress(*t)
+    assert abs_max == 16381
+    sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi)
+    assert b == oracle.encode_gmm("as", sym, s, m, wt)
+    assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq)
+    y[0, 0, 0, 0] = 16381.6
+    (b, abs_max, zb), yq = gmc.compress(dv(y), *t[1:])
+    assert abs_max == 16382
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        gmc.decompress(b, abs_max, zb, *t[1:])
+
+
+def test_empty_and_degenerate_batches():
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    assert gmc.compress_batch([], [], [], []) == [] and gmc.decompress_batch([], [], [], [], [], []) == []
+    z = torch.zeros(1, 3, 2, 2, device=DEV)
+    p = torch.ones(1, 12, 2, 2, device=DEV)
+    (b, abs_max, zb), yq = gmc.compress(z, p, p * 0, p / 4)
+    assert b == bytes.fromhex("0000008000000000") and abs_max == 1 and zb.tolist() == [0, 0, 0]
+    assert torch.equal(gmc.decompress(b, abs_max, zb, p, p * 0, p / 4), z)
