@@ -403,14 +403,18 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
       it.abs_max = (int32_t)am;
       n = (int64_t)n_nz * it.hw;
       if (n_bypass && am > 32767) {
-        // a bypassed symbol may not fit the 16 bits the table carries: fetch y and rebuild the int32 symbols
-        // (integer conversion only; y is complete — the kernels that read it have finished)
-        std::vector<float> yraw((size_t)it.M * it.hw);
-        HIP_TRY(hipMemcpy(yraw.data(), it.y, sizeof(float) * yraw.size(), hipMemcpyDeviceToHost));
+        // a bypassed symbol may not fit the 16 bits the table carries: fetch the GPU-rounded latents (y_q, written
+        // by quant_stats_kernel) and convert them to the int32 symbols — an integer conversion, no arithmetic.
+        // Without a y_q buffer the raw latents are fetched and rounded to nearest-even here (rintf semantics).
+        std::vector<float> yv((size_t)it.M * it.hw);
+        HIP_TRY(hipMemcpy(yv.data(), it.yq ? it.yq : it.y, sizeof(float) * yv.size(), hipMemcpyDeviceToHost));
         wide_syms[i].reserve((size_t)n);
         for (int c = 0; c < it.M; ++c)
           if (nz[c])
-            for (int64_t p = 0; p < it.hw; ++p) wide_syms[i].push_back((int32_t)nearbyintf(yraw[(size_t)c * it.hw + p]));
+            for (int64_t p = 0; p < it.hw; ++p) {
+              const float v = yv[(size_t)c * it.hw + p];
+              wide_syms[i].push_back((int32_t)(it.yq ? v : nearbyintf(v)));
+            }
         syms_for_bypass = wide_syms[i].data();
       }
     } else if (n_bypass && !it.sym_host) {
