@@ -177,6 +177,7 @@ def main():
     coll_dev = dev if (dist and dist.get_backend() == "nccl") else torch.device("cpu")
 
     from flashgmm_amd import GaussianMixtureConditional, _lib
+    numa = P.bind_to_gpu_numa_node(local_rank)  # before the worker threads and pinned buffers exist
 
     if a.images is None:
         a.images = 24 if a.workload == "kodak24" else 1
@@ -259,7 +260,7 @@ def main():
                        "stream_shapes": sorted({tuple(y.shape) for y in ys}), "K": 4, "approx_mode": a.mode,
                        "param_dtype": "f16" if f16 else "f32",
                        "coded_symbols_per_gpu": n_coded, "bitstream_bytes_per_gpu": total_bytes,
-                       "host_threads_per_gpu": _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank)),
+                       "host_threads_per_gpu": _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank)), "numa": numa,
                        "parallelism": f"images sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "symtab_kernel (encode-side GMM-CDF)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -13,7 +13,7 @@ from typing import List, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_units", "owner_of", "all_gather_stream_lengths", "container_index"]
+__all__ = ["shard_units", "owner_of", "all_gather_stream_lengths", "container_index", "bind_to_gpu_numa_node"]
 
 
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:
@@ -53,3 +53,30 @@ def container_index(lengths: torch.Tensor, n_units: int, streams_per_unit: int) 
             out.append((u, s, off, ln))
             off += ln
     return out
+
+
+def bind_to_gpu_numa_node(device_index: int) -> str:
+    """Pin this process (and the threads / pinned buffers it creates afterwards) to the NUMA node the GPU hangs off.
+
+    The decode-side tables cross PCIe at ~57 GB/s per GPU into pinned host memory and are then read by the host
+    rANS workers; with 8 GPUs on a 2-socket host that traffic should stay on the GPU's own socket.  Best effort:
+    returns a short description, never raises."""
+    import os
+
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return f"gpu {device_index} ({bdf}): no NUMA affinity reported"
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return f"gpu {device_index} ({bdf}): node {node} has no allowed CPUs"
+        os.sched_setaffinity(0, cpus)
+        return f"gpu {device_index} ({bdf}) -> NUMA node {node}, {len(cpus)} CPUs"
+    except Exception as e:  # pragma: no cover - topology files differ between hosts
+        return f"gpu {device_index}: not bound ({e})"
