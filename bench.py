@@ -177,6 +177,8 @@ def main():
     coll_dev = dev if (dist and dist.get_backend() == "nccl") else torch.device("cpu")
 
     from flashgmm_amd import GaussianMixtureConditional, _lib
+    from flashgmm_amd import parallel as P
+
     numa = P.bind_to_gpu_numa_node(local_rank)  # before the worker threads and pinned buffers exist
 
     if a.images is None:
@@ -191,7 +193,6 @@ def main():
     ws = [t[3] for t in devt]
     gmc = GaussianMixtureConditional(K=4, mode=a.mode)
     _lib.set_profiling(local_rank, True)
-    from flashgmm_amd import parallel as P
 
     k_sym, k_tab, k_qs = [], [], []
 
