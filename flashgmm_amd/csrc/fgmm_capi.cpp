@@ -19,7 +19,6 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
-#include <memory>
 #include <mutex>
 #include <queue>
 #include <thread>
@@ -375,9 +374,6 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
 
   // ---- host side: per item side information, then one rANS job per item -----------------------------
   std::vector<std::vector<int32_t>> wide_syms(count); // only for bypass symbols beyond int16 (rare)
-  std::vector<EncJob> pending;
-  std::vector<EncItem *> pending_items;
-  const int bundle = std::min(4, std::max(1, (count + ctx->pool->size() - 1) / ctx->pool->size()));
   PoolDrain drain{ctx->pool};
   for (int i = 0; i < count; ++i) {
     EncItem &it = items[i];
@@ -428,26 +424,12 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     }
     HIP_TRY(hipEventSynchronize(ctx->events[group_of[i]]));
     const uint32_t *packed = reinterpret_cast<const uint32_t *>(ctx->h_ws + it.o_packed);
-    if (it.symbuf) { // buffered raw boundary: append, in order, on this thread
-      it.status = fgmm_symbuf_append_symtab(it.symbuf, packed, syms_for_bypass, n);
-      continue;
-    }
-    // bundle k consecutive bitstreams per job so that one pass of jobs fills the pool: a worker codes its k streams
-    // interleaved in one loop (the rANS state update is latency-, not throughput-bound)
-    pending.push_back(EncJob{packed, syms_for_bypass, n, (int64_t)n_bypass, &it.bytes, &it.bytes_len, FGMM_OK});
-    pending_items.push_back(&it);
-    const bool last_of_group = (i + 1 == count) || group_of[i + 1] != group_of[i];
-    if ((int)pending.size() == bundle || last_of_group) {
-      auto batch = std::make_shared<std::vector<EncJob>>(std::move(pending));
-      auto owners = std::make_shared<std::vector<EncItem *>>(std::move(pending_items));
-      pending.clear();
-      pending_items.clear();
-      auto job = [batch, owners] {
-        rans_encode_symtab_multi(batch->data(), (int)batch->size());
-        for (size_t s = 0; s < batch->size(); ++s) (*owners)[s]->status = (*batch)[s].status;
-      };
-      if (count == 1) job(); else ctx->pool->submit(job);
-    }
+    EncItem *pit = &it;
+    auto job = [pit, packed, syms_for_bypass, n, n_bypass] {
+      if (pit->symbuf) pit->status = fgmm_symbuf_append_symtab(pit->symbuf, packed, syms_for_bypass, n);
+      else pit->status = rans_encode_symtab(packed, syms_for_bypass, n, (int64_t)n_bypass, &pit->bytes, &pit->bytes_len);
+    };
+    if (count == 1) job(); else ctx->pool->submit(job);
   }
   tr.mark("all tables landed, jobs out");
   if (count > 1) ctx->pool->wait_all();

@@ -89,15 +89,6 @@ int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream
 // returns 0 or an fgmm_status; *out malloc'ed
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len);
-struct EncJob { // one bitstream of rans_encode_symtab_multi
-  const uint32_t *packed;
-  const int32_t *symbols; // or null
-  int64_t n, n_bypass;
-  uint8_t **out;
-  size_t *out_len;
-  int status;
-};
-int rans_encode_symtab_multi(EncJob *jobs, int k); // k <= 4 streams interleaved on the calling thread
 int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, const uint8_t *pool, int64_t n,
                        int32_t max_bs, int32_t *out);
 

@@ -92,109 +92,53 @@ struct Enc {
 
 } // namespace
 
-namespace {
-
-// one bitstream being written (BufferedRansEncoder::flush walks _syms backwards, rans_interface.cpp:569-577)
-struct EncStream {
-  const uint32_t *packed = nullptr;
-  const int32_t *symbols = nullptr;
-  int64_t i = -1; // next symbol to code (counts down)
-  uint32_t *buf = nullptr, *end = nullptr;
-  Enc e{kRansL, nullptr};
-
-  int begin(const uint32_t *p, const int32_t *s, int64_t n, int64_t n_bypass_hint) {
-    packed = p;
-    symbols = s;
-    int64_t nb = n_bypass_hint;
-    if (nb < 0) {
-      nb = 0;
-      for (int64_t k = 0; k < n; ++k) nb += (p[k] >> 16) == 0;
-    }
-    // every entry of the reference's _syms emits at most one 32-bit word; a bypassed symbol is 1 + 1 + <=8 entries
-    const size_t nwords = (size_t)n + (size_t)nb * 10 + 16;
-    buf = (uint32_t *)malloc(nwords * sizeof(uint32_t));
-    if (!buf) return FGMM_ERR_NOMEM;
-    end = buf + nwords;
-    e = Enc{kRansL, end}; // Rans64EncInit
-    i = n - 1;
-    return FGMM_OK;
-  }
-  inline void step() { // one symbol
-    const uint32_t ent = packed[i];
-    const uint32_t freq = ent >> 16;
-    if (__builtin_expect(freq != 0, 1)) {
-      e.put(ent & 0xFFFFu, freq);
-    } else {
-      // bypass escape; forward order was [sentinel {65535,1}] [count] [nibble 0 .. nibble k-1]  (:519-551)
-      const int32_t value = symbols ? symbols[i] : (int32_t)(int16_t)(uint16_t)(ent & 0xFFFFu);
-      const uint32_t raw = (uint32_t)value;
-      int nn = 0;
-      for (uint32_t t = raw; t != 0; t >>= kBypassBits) ++nn; // <= 8
-      for (int j = nn - 1; j >= 0; --j) e.put_bits((raw >> (j * kBypassBits)) & kMaxBypassVal);
-      e.put_bits((uint32_t)nn); // nn <= 8 < 15: the count is always a single nibble (:538-543)
-      e.put(kMaxCdf, 1);
-    }
-    --i;
-  }
-  int finish(uint8_t **out, size_t *out_len) { // Rans64EncFlush + copy out
-    e.ptr -= 2;
-    e.ptr[0] = (uint32_t)(e.x >> 0);
-    e.ptr[1] = (uint32_t)(e.x >> 32);
-    const size_t nbytes = (size_t)(end - e.ptr) * sizeof(uint32_t);
-    uint8_t *o = (uint8_t *)malloc(nbytes);
-    if (!o) {
-      free(buf);
-      buf = nullptr;
-      return FGMM_ERR_NOMEM;
-    }
-    memcpy(o, e.ptr, nbytes);
-    free(buf);
-    buf = nullptr;
-    *out = o;
-    *out_len = nbytes;
-    return FGMM_OK;
-  }
-};
-
-} // namespace
-
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len) {
   std::call_once(g_rcp_once, init_rcp);
   if (n < 0 || !out || !out_len || (n > 0 && !packed)) return FGMM_ERR_INVALID;
-  EncStream a;
-  int rc = a.begin(packed, symbols, n, n_bypass_hint);
-  if (rc) return rc;
-  while (a.i >= 0) a.step();
-  return a.finish(out, out_len);
-}
+  int64_t nb = n_bypass_hint;
+  if (nb < 0) {
+    nb = 0;
+    for (int64_t i = 0; i < n; ++i) nb += (packed[i] >> 16) == 0;
+  }
+  // every entry of the reference's _syms emits at most one 32-bit word; a bypassed symbol is 1 + 1 + <=8 entries
+  const size_t nwords = (size_t)n + (size_t)nb * 10 + 16;
+  uint32_t *buf = (uint32_t *)malloc(nwords * sizeof(uint32_t));
+  if (!buf) return FGMM_ERR_NOMEM;
+  uint32_t *const end = buf + nwords;
+  Enc e{kRansL, end}; // Rans64EncInit
 
-// Up to 4 independent bitstreams coded in one loop: the state update of a stream is a serial chain (renormalise ->
-// mulhi -> multiply-add, ~12 cycles); interleaving the chains lets one core retire them in about the time of one.
-int rans_encode_symtab_multi(EncJob *jobs, int k) {
-  std::call_once(g_rcp_once, init_rcp);
-  if (k < 1 || k > 4) return FGMM_ERR_INVALID;
-  EncStream st[4];
-  for (int s = 0; s < k; ++s) jobs[s].status = st[s].begin(jobs[s].packed, jobs[s].symbols, jobs[s].n, jobs[s].n_bypass);
-  bool all_ok = true;
-  for (int s = 0; s < k; ++s) all_ok = all_ok && jobs[s].status == FGMM_OK;
-  if (all_ok) {
-    if (k == 2) {
-      while (st[0].i >= 0 && st[1].i >= 0) { st[0].step(); st[1].step(); }
-    } else if (k == 3) {
-      while (st[0].i >= 0 && st[1].i >= 0 && st[2].i >= 0) { st[0].step(); st[1].step(); st[2].step(); }
-    } else if (k == 4) {
-      while (st[0].i >= 0 && st[1].i >= 0 && st[2].i >= 0 && st[3].i >= 0) { st[0].step(); st[1].step(); st[2].step(); st[3].step(); }
+  for (int64_t i = n - 1; i >= 0; --i) { // reversed _syms (rans_interface.cpp:569)
+    const uint32_t ent = packed[i];
+    const uint32_t freq = ent >> 16;
+    if (__builtin_expect(freq != 0, 1)) {
+      e.put(ent & 0xFFFFu, freq);
+      continue;
     }
+    // bypass escape; forward order was [sentinel {65535,1}] [count] [nibble 0 .. nibble k-1]  (:519-551)
+    const int32_t value = symbols ? symbols[i] : (int32_t)(int16_t)(uint16_t)(ent & 0xFFFFu);
+    const uint32_t raw = (uint32_t)value;
+    int nn = 0;
+    for (uint32_t t = raw; t != 0; t >>= kBypassBits) ++nn; // <= 8
+    for (int j = nn - 1; j >= 0; --j) e.put_bits((raw >> (j * kBypassBits)) & kMaxBypassVal);
+    e.put_bits((uint32_t)nn); // nn <= 8 < 15: the count is always a single nibble (:538-543)
+    e.put(kMaxCdf, 1);
   }
-  int rc = FGMM_OK;
-  for (int s = 0; s < k; ++s) {
-    if (jobs[s].status != FGMM_OK) { rc = jobs[s].status; continue; }
-    while (st[s].i >= 0) st[s].step(); // the remainder of the longer streams
-    jobs[s].status = st[s].finish(jobs[s].out, jobs[s].out_len);
-    if (jobs[s].status) rc = jobs[s].status;
+  // Rans64EncFlush
+  e.ptr -= 2;
+  e.ptr[0] = (uint32_t)(e.x >> 0);
+  e.ptr[1] = (uint32_t)(e.x >> 32);
+  const size_t nbytes = (size_t)(end - e.ptr) * sizeof(uint32_t);
+  uint8_t *o = (uint8_t *)malloc(nbytes);
+  if (!o) {
+    free(buf);
+    return FGMM_ERR_NOMEM;
   }
-  return rc;
+  memcpy(o, e.ptr, nbytes);
+  free(buf);
+  *out = o;
+  *out_len = nbytes;
+  return FGMM_OK;
 }
 
 namespace {
