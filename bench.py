@@ -270,6 +270,10 @@ def main():
                          "bytes_per_symbol": bytes_per_symbol},
             "kernels_ms": {"symtab": round(sym_ms, 4), "cdftab": round(float(np.mean(k_tab)), 4),
                            "quant_stats": round(float(np.mean(k_qs)), 4)},
+            # what crosses PCIe per step and rank (the decode-side tables are the longest leg of a step)
+            "pcie": {"encode_tables_bytes": _lib.ctx_stat(local_rank, 0), "decode_tables_bytes": _lib.ctx_stat(local_rank, 1),
+                     "decode_table_bytes_per_latent": round(_lib.ctx_stat(local_rank, 1) / max(1, _lib.ctx_stat(local_rank, 2)), 2),
+                     "bitstream_bytes": total_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, pix_per_image, streams_per_image)

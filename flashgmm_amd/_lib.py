@@ -51,6 +51,7 @@ SIGNATURES = {
     "fgmm_free": (None, [_p]),
     "fgmm_ctx_set_profiling": (_i, [_p, _i]),
     "fgmm_ctx_kernel_ms": (_i, [_p, _i, C.POINTER(C.c_float)]),
+    "fgmm_ctx_stat": (_i, [_p, _i, C.POINTER(C.c_uint64)]),
     "fgmm_encode_with_indexes_gmm": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _i32, _pp, _psz]),
     "fgmm_decode_with_indexes_gmm": (_i, [_p, _p, _sz, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _i32, _p]),
     "fgmm_gmc_compress": (_i, [_p, _p, _p, C.POINTER(fgmm_params), _i, _i, _i64, _i, _i, _p, C.POINTER(_i32), _p, _pp, _psz]),
@@ -162,3 +163,10 @@ def kernel_ms(device: int, which: int) -> float:
     out = C.c_float()
     check(lib().fgmm_ctx_kernel_ms(ctx(device), which, C.byref(out)), "fgmm_ctx_kernel_ms")
     return float(out.value)
+
+
+def ctx_stat(device: int, which: int) -> int:
+    """Byte / latent counts of the most recent batched call (0 encode tables D2H, 1 decode tables D2H, 2 decode latents)."""
+    out = C.c_uint64()
+    check(lib().fgmm_ctx_stat(ctx(device), which, C.byref(out)), "fgmm_ctx_stat")
+    return int(out.value)

@@ -190,6 +190,8 @@ struct fgmm_ctx {
     return FGMM_OK;
   }
   bool profiling = false;
+  unsigned long long stat[4] = {0, 0, 0, 0}; // last batched call: [0] encode table bytes D2H, [1] decode hdr+row bytes D2H,
+                                             // [2] decode latents, [3] decode rows that are Elias-Fano coded (unused: 0)
   hipEvent_t prof[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool prof_valid[3] = {false, false, false};
 
@@ -371,6 +373,8 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   tr.mark("enqueued");
   HIP_TRY(hipEventSynchronize(ctx->events[count]));
   tr.mark("kernels + meta landed");
+  ctx->stat[0] = 0;
+  for (auto &it : items) ctx->stat[0] += sizeof(uint32_t) * (unsigned long long)it.M * (unsigned long long)it.hw;
 
   // ---- host side: per item side information, then one rANS job per item -----------------------------
   std::vector<std::vector<int32_t>> wide_syms(count); // only for bypass symbols beyond int16 (rare)
@@ -598,6 +602,11 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       HIP_TRY(hipEventRecord(ev_item[i], ctx->copy_stream));
     }
   }
+  ctx->stat[1] = ctx->stat[2] = 0;
+  for (auto &it : items) {
+    ctx->stat[1] += it.pool_used + sizeof(uint32_t) * (unsigned long long)it.n;
+    ctx->stat[2] += (unsigned long long)it.n;
+  }
   tr.mark("table kernels done, copies queued");
 
   // ---- one host rANS job per item, started as its tables land ------------------------------------------
@@ -738,6 +747,13 @@ int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out) {
   DeviceGuard g(ctx->device);
   HIP_TRY(hipEventSynchronize(ctx->prof[which][1]));
   HIP_TRY(hipEventElapsedTime(ms_out, ctx->prof[which][0], ctx->prof[which][1]));
+  return FGMM_OK;
+}
+
+int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out) {
+  if (!ctx || which < 0 || which > 3 || !out) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  *out = ctx->stat[which];
   return FGMM_OK;
 }
 

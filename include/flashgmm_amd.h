@@ -75,6 +75,9 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  * LAUNCHED ON; fgmm_ctx_kernel_ms returns the duration of the most recent launch of
  * which = 0: symtab kernel (encode-side CDF), 1: cdftab kernel (decode-side tables), 2: quant_stats kernel. */
 int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable);
+/* Byte counts of the most recent batched call: which = 0 encode tables copied D2H, 1 decode headers + rows copied D2H,
+ * 2 latents those decode tables describe. */
+int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out);
 int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out);
 
 /* ------------------------------------------------------------------------------------------------------------
