@@ -478,10 +478,18 @@ struct DecItem {
 //   host workers  : item i starts when its event fires; writes y_hat (zero channels restored) into pinned memory
 // so the PCIe transfer of the tables — the longest leg — overlaps both the table kernels of later groups and
 // the host coding of earlier items.
+struct DevFreeList { // device buffers released when the call ends
+  std::vector<void *> v;
+  ~DevFreeList() {
+    for (void *p : v) (void)hipFree(p);
+  }
+};
+
 int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items, int mode) {
   const int count = (int)items.size();
   if (count == 0) return FGMM_OK;
   Trace tr("decode");
+  DevFreeList extra_pools;
   int rc;
   if ((rc = ctx->ensure_streams())) return rc;
   // groups of items: small first (the table copies start as early as possible), then larger
@@ -513,8 +521,12 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   for (int i = 0; i < count; ++i) items[i].o_used = o_used + 16 * (size_t)i;
   const size_t host_fixed = ar.off;
   for (auto &it : items) {
+    // Row pool: provisioned for an average of `per_latent` bytes per latent (measured: ~75 on the wide synthetic
+    // Kodak rows), never more than the worst case n * widest raw row.  The scan kernel knows the exact total before
+    // anything is written; an item that does not fit is re-run below with an exactly sized pool.
+    static const uint64_t per_latent = getenv("FGMM_POOL_BYTES_PER_LATENT") ? strtoull(getenv("FGMM_POOL_BYTES_PER_LATENT"), nullptr, 10) : 256;
     const uint64_t rowcap = 2 * (((uint64_t)(2 * (int64_t)it.max_bs + 2) + 3) & ~3ull); // widest row, raw form, bytes
-    it.pool_cap = (uint64_t)it.n * rowcap;
+    it.pool_cap = std::min((uint64_t)it.n * rowcap, (uint64_t)it.n * per_latent + 4096);
     it.tiles = (int32_t)((it.hw + 255) / 256);
     const size_t nblk = (size_t)it.n_ch * (size_t)it.tiles;
     it.o_hdr = ar.take(sizeof(uint32_t) * (size_t)it.n + 64);
@@ -587,7 +599,26 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     for (int i = i0; i < i1; ++i) {
       DecItem &it = items[i];
       const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
-      if (u[1]) return fail(FGMM_ERR_HIP, "edge-table pool overflow on item %d (internal sizing error)", i);
+      uint8_t *pool_dev = reinterpret_cast<uint8_t *>(ctx->d_ws + it.o_pool);
+      if (u[1]) {
+        // the rows of this item need u[0] bytes, more than provisioned: nothing was written (the fill kernel saw
+        // the flag).  Re-run the item alone with an exactly sized pool.
+        const unsigned long long need = u[0];
+        uint8_t *extra = nullptr;
+        HIP_TRY(hipMalloc((void **)&extra, need + 256));
+        extra_pools.v.push_back(extra);
+        hd[i].pool = extra;
+        hd[i].pool_cap = need;
+        HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs + sizeof(DecDesc) * (size_t)i, &hd[i], sizeof(DecDesc), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_ws + it.o_used, 0, 16, stream));
+        LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs) + i, 1, it.n_ch, it.hw, mode,
+                                 it.clamp != 0, it.prm.dtype == FGMM_F16, stream));
+        unsigned long long again[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(again, ctx->d_ws + it.o_used, 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (again[1] || again[0] != need) return fail(FGMM_ERR_HIP, "edge-table pool re-run failed on item %d", i);
+        pool_dev = extra;
+      }
       it.pool_used = u[0];
       const size_t out_bytes = it.y_hat ? sizeof(float) * (size_t)it.M * (size_t)it.hw : sizeof(int32_t) * (size_t)it.n;
       if ((rc = ctx->chunk_alloc(sizeof(uint32_t) * (size_t)it.n + 64, &it.h_hdr)) ||
@@ -597,7 +628,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       if (it.n) {
         HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, sizeof(uint32_t) * (size_t)it.n, hipMemcpyDeviceToHost, ctx->copy_stream));
         if (it.pool_used)
-          HIP_TRY(hipMemcpyAsync(it.h_pool, ctx->d_ws + it.o_pool, it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
+          HIP_TRY(hipMemcpyAsync(it.h_pool, pool_dev, it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
       }
       HIP_TRY(hipEventRecord(ev_item[i], ctx->copy_stream));
     }

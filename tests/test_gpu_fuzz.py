@@ -99,3 +99,25 @@ def test_empty_and_degenerate_batches():
     (b, abs_max, zb), yq = gmc.compress(z, p, p * 0, p / 4)
     assert b == bytes.fromhex("0000008000000000") and abs_max == 1 and zb.tolist() == [0, 0, 0]
     assert torch.equal(gmc.decompress(b, abs_max, zb, p, p * 0, p / 4), z)
+
+
+def test_row_pool_overflow_rerun():
+    """the decode row pool is provisioned for an average row; items that need more are re-run with an exact pool.
+    Forced here by provisioning 8 bytes per latent (the knob is read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, torch\n"
+        "from flashgmm_amd import GaussianMixtureConditional, testing as T\n"
+        "g = GaussianMixtureConditional(K=4, mode='logistic')\n"
+        "ts = [[torch.from_numpy(a).cuda() for a in T.make_latent(s, M=24, h=16, w=8)] for s in range(20)]\n"
+        "res = g.compress_batch(*[[t[k] for t in ts] for k in range(4)])\n"
+        "out = g.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res],\n"
+        "                         *[[t[k] for t in ts] for k in (1, 2, 3)])\n"
+        "assert all(torch.equal(o, r[1]) for o, r in zip(out, res))\n"
+        "print('rerun ok')\n")
+    env = dict(os.environ, FGMM_POOL_BYTES_PER_LATENT="8", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rerun ok" in r.stdout, r.stderr[-1500:]
