@@ -465,6 +465,7 @@ struct DecItem {
   size_t o_list = 0, o_hdr = 0, o_pool = 0, o_used = 0, o_bsum = 0, o_boff = 0;
   int32_t tiles = 0;
   char *h_hdr = nullptr, *h_pool = nullptr, *h_out = nullptr; // pinned
+  size_t hdr_bytes = 0; // header array rounded up so that the row pool behind it stays 256-B aligned
   uint64_t pool_cap = 0, pool_used = 0;
   std::atomic<int> done{0};
   DecItem() = default;
@@ -529,8 +530,10 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.pool_cap = std::min((uint64_t)it.n * rowcap, (uint64_t)it.n * per_latent + 4096);
     it.tiles = (int32_t)((it.hw + 255) / 256);
     const size_t nblk = (size_t)it.n_ch * (size_t)it.tiles;
-    it.o_hdr = ar.take(sizeof(uint32_t) * (size_t)it.n + 64);
-    it.o_pool = ar.take(it.pool_cap + 128);
+    // header array and row pool are adjacent: one D2H copy per item brings both
+    it.hdr_bytes = align_up(sizeof(uint32_t) * (size_t)it.n, 256);
+    it.o_hdr = ar.take(it.hdr_bytes + it.pool_cap + 128);
+    it.o_pool = it.o_hdr + it.hdr_bytes;
     it.o_bsum = ar.take(sizeof(uint32_t) * nblk + 64);
     it.o_boff = ar.take(sizeof(uint64_t) * nblk + 64);
   }
@@ -621,14 +624,16 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       }
       it.pool_used = u[0];
       const size_t out_bytes = it.y_hat ? sizeof(float) * (size_t)it.M * (size_t)it.hw : sizeof(int32_t) * (size_t)it.n;
-      if ((rc = ctx->chunk_alloc(sizeof(uint32_t) * (size_t)it.n + 64, &it.h_hdr)) ||
-          (rc = ctx->chunk_alloc(it.pool_used + 1024, &it.h_pool)) ||
-          (rc = ctx->chunk_alloc(out_bytes + 64, &it.h_out)))
+      if ((rc = ctx->chunk_alloc(it.hdr_bytes + it.pool_used + 1024, &it.h_hdr)) || (rc = ctx->chunk_alloc(out_bytes + 64, &it.h_out)))
         return rc;
+      it.h_pool = it.h_hdr + it.hdr_bytes;
       if (it.n) {
-        HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, sizeof(uint32_t) * (size_t)it.n, hipMemcpyDeviceToHost, ctx->copy_stream));
-        if (it.pool_used)
-          HIP_TRY(hipMemcpyAsync(it.h_pool, pool_dev, it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (pool_dev == reinterpret_cast<uint8_t *>(ctx->d_ws + it.o_pool)) { // the usual case: one copy
+          HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, it.hdr_bytes + it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
+        } else { // re-run item: its rows live in the extra pool
+          HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, sizeof(uint32_t) * (size_t)it.n, hipMemcpyDeviceToHost, ctx->copy_stream));
+          if (it.pool_used) HIP_TRY(hipMemcpyAsync(it.h_pool, pool_dev, it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
+        }
       }
       HIP_TRY(hipEventRecord(ev_item[i], ctx->copy_stream));
     }
