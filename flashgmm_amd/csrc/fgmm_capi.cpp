@@ -73,6 +73,7 @@ struct Trace {
             std::chrono::duration<double, std::milli>(now - t0).count());
     last = now;
   }
+  double ms() const { return on ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() : 0.0; }
 };
 
 // ---- host worker pool ----------------------------------------------------------------------------------
@@ -452,6 +453,7 @@ struct DecItem {
   fgmm_params prm{};
   int64_t stride_p = 1;
   int32_t M = 0;
+  static constexpr int kMaxPieces = 8;
   int64_t hw = 0;
   int clamp = 0;
   int32_t max_bs = 1;
@@ -466,6 +468,13 @@ struct DecItem {
   int32_t tiles = 0;
   char *h_hdr = nullptr, *h_pool = nullptr, *h_out = nullptr; // pinned
   size_t hdr_bytes = 0; // header array rounded up so that the row pool behind it stays 256-B aligned
+  // items of the tail window land in pieces (see decode_batch): pool bytes valid after each piece, and its event
+  int n_piece = 0;
+  uint64_t piece_end[kMaxPieces] = {};
+  hipEvent_t piece_ev[kMaxPieces] = {};
+  uint8_t *pool_dev = nullptr;
+  std::atomic<int> copy_queued{0}; // ev_item recorded in this call (events are reused: never wait on one that was not)
+  double t_start = 0, t_end = 0, t_wait = 0; // FGMM_TRACE=2: job timeline
   uint64_t pool_cap = 0, pool_used = 0;
   std::atomic<int> done{0};
   DecItem() = default;
@@ -479,6 +488,10 @@ struct DecItem {
 //   host workers  : item i starts when its event fires; writes y_hat (zero channels restored) into pinned memory
 // so the PCIe transfer of the tables — the longest leg — overlaps both the table kernels of later groups and
 // the host coding of earlier items.
+// Tail window: a bitstream decodes sequentially (~9 ns/symbol), so whatever lands last leaves one whole item of
+// host work behind it.  The last few items are therefore copied in pieces, round-robin (piece 0 of each, then
+// piece 1 of each, ...): their decoders start on piece 0 and follow the pieces as they land (rows are in latent
+// order), and what remains after the final copy is one piece of work instead of one item.
 struct DevFreeList { // device buffers released when the call ends
   std::vector<void *> v;
   ~DevFreeList() {
@@ -506,6 +519,12 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     gbeg.push_back(count);
   }
   const int n_groups = (int)gbeg.size() - 1;
+  // tail window (see above): how many trailing items land in pieces, and in how many pieces each
+  const int tail_cfg = getenv("FGMM_TAIL_ITEMS") ? atoi(getenv("FGMM_TAIL_ITEMS")) : 8;
+  const int piece_cfg = getenv("FGMM_TAIL_PIECES") ? atoi(getenv("FGMM_TAIL_PIECES")) : 4;
+  const int n_piece = std::min(std::max(piece_cfg, 1), (int)DecItem::kMaxPieces);
+  const int tail_items = (count >= 4 && n_piece > 1) ? std::min({std::max(tail_cfg, 0), count, std::max(ctx->pool->size() / 2, 1)}) : 0;
+  const int tail_begin = count - tail_items;
 
   Arena ar; // device workspace; the part before the counters is mirrored in h_ws and uploaded in one copy
   const size_t o_descs = ar.take(sizeof(DecDesc) * count);
@@ -538,11 +557,11 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.o_boff = ar.take(sizeof(uint64_t) * nblk + 64);
   }
   if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(host_fixed)) ||
-      (rc = ctx->ensure_events((size_t)count + 2 * (size_t)n_groups)))
+      (rc = ctx->ensure_events((size_t)count + 2 * (size_t)n_groups + (size_t)tail_items * DecItem::kMaxPieces)))
     return rc;
   ctx->chunks_reset();
   hipEvent_t *ev_item = ctx->events.data();
-  hipEvent_t *ev_kernel = ev_item + count, *ev_counters = ev_kernel + n_groups;
+  hipEvent_t *ev_kernel = ev_item + count, *ev_counters = ev_kernel + n_groups, *ev_piece = ev_counters + n_groups;
 
   DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_descs);
   for (int i = 0; i < count; ++i) {
@@ -595,10 +614,13 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   if ((rc = ctx->prof_end(1, stream))) return rc; // brackets all groups' launches
   tr.mark("enqueued");
 
-  // ---- as each group's sizes arrive, queue its table copies --------------------------------------------
-  for (int g = 0; g < n_groups; ++g) {
+  // ---- as each group's sizes arrive: queue its table copies, hand its items to the workers -------------------
+  std::mutex done_mu;
+  std::condition_variable done_cv;
+  const char *h_ws = ctx->h_ws;
+
+  auto queue_group_copies = [&](int g) -> int {
     const int i0 = gbeg[g], i1 = gbeg[g + 1];
-    HIP_TRY(hipEventSynchronize(ev_counters[g]));
     for (int i = i0; i < i1; ++i) {
       DecItem &it = items[i];
       const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
@@ -624,11 +646,18 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       }
       it.pool_used = u[0];
       const size_t out_bytes = it.y_hat ? sizeof(float) * (size_t)it.M * (size_t)it.hw : sizeof(int32_t) * (size_t)it.n;
-      if ((rc = ctx->chunk_alloc(it.hdr_bytes + it.pool_used + 1024, &it.h_hdr)) || (rc = ctx->chunk_alloc(out_bytes + 64, &it.h_out)))
-        return rc;
+      int rc2;
+      if ((rc2 = ctx->chunk_alloc(it.hdr_bytes + it.pool_used + 1024, &it.h_hdr)) || (rc2 = ctx->chunk_alloc(out_bytes + 64, &it.h_out)))
+        return rc2;
       it.h_pool = it.h_hdr + it.hdr_bytes;
+      it.pool_dev = pool_dev;
+      const bool in_place = pool_dev == reinterpret_cast<uint8_t *>(ctx->d_ws + it.o_pool);
+      if (i >= tail_begin && in_place && it.pool_used >= (1u << 20)) {
+        it.n_piece = n_piece; // copied by queue_tail_copies, round-robin with the other items of the tail window
+        continue;
+      }
       if (it.n) {
-        if (pool_dev == reinterpret_cast<uint8_t *>(ctx->d_ws + it.o_pool)) { // the usual case: one copy
+        if (in_place) { // the usual case: one copy
           HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, it.hdr_bytes + it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
         } else { // re-run item: its rows live in the extra pool
           HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, sizeof(uint32_t) * (size_t)it.n, hipMemcpyDeviceToHost, ctx->copy_stream));
@@ -636,33 +665,54 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         }
       }
       HIP_TRY(hipEventRecord(ev_item[i], ctx->copy_stream));
+      it.copy_queued.store(1, std::memory_order_release);
     }
-  }
-  ctx->stat[1] = ctx->stat[2] = 0;
-  for (auto &it : items) {
-    ctx->stat[1] += it.pool_used + sizeof(uint32_t) * (unsigned long long)it.n;
-    ctx->stat[2] += (unsigned long long)it.n;
-  }
-  tr.mark("table kernels done, copies queued");
+    return FGMM_OK;
+  };
 
-  // ---- one host rANS job per item, started as its tables land ------------------------------------------
-  std::mutex done_mu;
-  std::condition_variable done_cv;
-  PoolDrain drain{ctx->pool}; // declared after the objects the jobs reference: destroyed (= drained) before them
-  const char *h_ws = ctx->h_ws;
-  for (int i = 0; i < count; ++i) {
+  auto queue_tail_copies = [&]() -> int {
+    for (int k = 0; k < n_piece; ++k) {
+      for (int i = tail_begin; i < count; ++i) {
+        DecItem &it = items[i];
+        if (!it.n_piece) continue;
+        const uint64_t b0 = k ? it.piece_end[k - 1] : 0;
+        const uint64_t b1 = k + 1 == n_piece ? it.pool_used : (it.pool_used * (uint64_t)(k + 1) / (uint64_t)n_piece) & ~255ull;
+        it.piece_end[k] = b1;
+        it.piece_ev[k] = ev_piece[(size_t)(i - tail_begin) * DecItem::kMaxPieces + k];
+        if (k == 0) { // header array + first piece of the pool, which lies right behind it
+          HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, it.hdr_bytes + b1, hipMemcpyDeviceToHost, ctx->copy_stream));
+          HIP_TRY(hipEventRecord(ev_item[i], ctx->copy_stream));
+          it.copy_queued.store(1, std::memory_order_release);
+        } else {
+          if (b1 > b0) HIP_TRY(hipMemcpyAsync(it.h_pool + b0, it.pool_dev + b0, b1 - b0, hipMemcpyDeviceToHost, ctx->copy_stream));
+          HIP_TRY(hipEventRecord(it.piece_ev[k], ctx->copy_stream));
+        }
+      }
+    }
+    return FGMM_OK;
+  };
+
+  auto submit_job = [&](int i, bool here) { // here: the item's tables (or their first piece) are on the host
     DecItem *pit = &items[i];
-    HIP_TRY(hipEventSynchronize(ev_item[i]));
+    pit->t_wait = tr.ms();
     const int32_t *list = reinterpret_cast<const int32_t *>(h_ws + pit->o_list);
-    auto job = [pit, list, &done_mu, &done_cv] {
+    auto job = [pit, list, here, &done_mu, &done_cv, &tr] {
+      pit->t_start = tr.ms();
       memset(pit->h_pool + pit->pool_used, 0, 64); // defined bytes for the SIMD over-read
       int32_t *sym = pit->y_hat ? (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(pit->n, 1))
                                 : reinterpret_cast<int32_t *>(pit->h_out);
-      if (!sym) {
+      if (!here) { // the copy failed
+        pit->status = FGMM_ERR_HIP;
+        if (pit->y_hat) free(sym);
+      } else if (!sym) {
         pit->status = FGMM_ERR_NOMEM;
       } else {
+        Landing land{pit->n_piece, pit->piece_end, pit, [](void *arg, int k) -> int {
+                       return hipEventSynchronize(static_cast<DecItem *>(arg)->piece_ev[k]) == hipSuccess ? (int)FGMM_OK : (int)FGMM_ERR_HIP;
+                     }};
         pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, reinterpret_cast<const uint32_t *>(pit->h_hdr),
-                                         reinterpret_cast<const uint8_t *>(pit->h_pool), pit->n, pit->max_bs, sym);
+                                         reinterpret_cast<const uint8_t *>(pit->h_pool), pit->n, pit->max_bs, sym,
+                                         pit->n_piece ? &land : nullptr);
         if (pit->status == FGMM_OK && pit->y_hat) {
           // y_hat[:, nonzero] = symbols.float(), zeros elsewhere   (entropy_models.py:903-908)
           float *yh = reinterpret_cast<float *>(pit->h_out);
@@ -677,6 +727,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         }
         if (pit->y_hat) free(sym);
       }
+      pit->t_end = tr.ms();
       {
         std::lock_guard<std::mutex> l(done_mu);
         pit->done.store(1);
@@ -684,8 +735,39 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       done_cv.notify_all();
     };
     if (count == 1) job(); else ctx->pool->submit(job);
+  };
+
+  // One dispatcher (itself a pool job) waits for the items' copies in order and hands each item to the workers as
+  // it lands, while this thread keeps feeding the copy stream group by group.
+  std::atomic<int> abandon{0};
+  auto dispatcher = [&, ev_item] {
+    for (int i = 0; i < count; ++i) {
+      while (!items[i].copy_queued.load(std::memory_order_acquire)) {
+        if (abandon.load()) return;
+        __builtin_ia32_pause();
+      }
+      submit_job(i, hipEventSynchronize(ev_item[i]) == hipSuccess);
+    }
+  };
+  // Order of destruction on any return: release the dispatcher, wait for every job, then the objects they use.
+  PoolDrain drain{ctx->pool};
+  struct Abandon {
+    std::atomic<int> &f;
+    ~Abandon() { f.store(1); }
+  } abandon_on_exit{abandon};
+  if (count > 1) ctx->pool->submit(dispatcher);
+  for (int g = 0; g < n_groups; ++g) {
+    HIP_TRY(hipEventSynchronize(ev_counters[g]));
+    if ((rc = queue_group_copies(g))) return rc;
+    if (g + 1 == n_groups && (rc = queue_tail_copies())) return rc;
   }
-  tr.mark("all tables landed, jobs out");
+  if (count == 1) dispatcher();
+  ctx->stat[1] = ctx->stat[2] = 0;
+  for (auto &it : items) {
+    ctx->stat[1] += it.pool_used + sizeof(uint32_t) * (unsigned long long)it.n;
+    ctx->stat[2] += (unsigned long long)it.n;
+  }
+  tr.mark("table kernels done, copies queued");
 
   // ---- y_hat back to the GPU item by item, on the caller's stream ----------------------------------------
   int first_err = FGMM_OK;
@@ -702,6 +784,10 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   tr.mark("host rANS done");
   HIP_TRY(hipStreamSynchronize(stream));
   tr.mark("y_hat uploaded");
+  if (tr.on && getenv("FGMM_TRACE") && atoi(getenv("FGMM_TRACE")) > 1)
+    for (int i = 0; i < count; ++i)
+      fprintf(stderr, "[fgmm decode]   item %2d  pieces %d  taken %7.3f  job %7.3f .. %7.3f  (%.3f ms)\n", i, items[i].n_piece,
+              items[i].t_wait, items[i].t_start, items[i].t_end, items[i].t_end - items[i].t_start);
   if (first_err)
     return fail(first_err, "host rANS decode failed (%d)%s", first_err, first_err == FGMM_ERR_STREAM ? ": bitstream too short" : "");
   return FGMM_OK;

@@ -89,7 +89,17 @@ int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream
 // returns 0 or an fgmm_status; *out malloc'ed
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len);
+// Rows that reach the host in pieces: after piece k has landed, the first end[k] bytes of the pool are valid
+// (end[nseg-1] = all of it).  Piece 0 (which also carries the header array) has landed before the decoder is
+// called; wait(arg, k) blocks until piece k (k >= 1) has.  The decoder walks rows in order, so it only ever waits
+// for the next piece.
+struct Landing {
+  int nseg;
+  const uint64_t *end;
+  void *arg;
+  int (*wait)(void *arg, int k); // FGMM_OK or an error status
+};
 int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, const uint8_t *pool, int64_t n,
-                       int32_t max_bs, int32_t *out);
+                       int32_t max_bs, int32_t *out, const Landing *land = nullptr);
 
 } // namespace fgmm

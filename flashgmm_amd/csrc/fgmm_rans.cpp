@@ -326,7 +326,7 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow
 } // namespace
 
 int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, const uint8_t *pool, int64_t n,
-                       int32_t max_bs, int32_t *out) {
+                       int32_t max_bs, int32_t *out, const Landing *land) {
   if (n < 0 || (n > 0 && (!hdr || !pool || !out)) || !enc) return FGMM_ERR_INVALID;
   if (enc_len < 8 || (enc_len & 3)) return FGMM_ERR_STREAM;
   const uint32_t *words;
@@ -347,6 +347,8 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
   size_t scratch_cap = 0;
 
   const uint8_t *rowp = pool; // rows lie in latent order: the offset is a running sum, never stored
+  const uint8_t *landed = land ? pool + land->end[0] : reinterpret_cast<const uint8_t *>(UINTPTR_MAX);
+  int piece = 1;
   for (int64_t i = 0; i < n; ++i) {
     __builtin_prefetch(rowp + 512);
     __builtin_prefetch(rowp + 576);
@@ -356,6 +358,17 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
     const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono);
     const uint8_t *row_bytes = rowp;
     rowp += tab_row_bytes((uint32_t)cnt, nonmono);
+    if (__builtin_expect(rowp > landed, 0)) { // this row is not on the host yet: wait for the piece(s) it lies in
+      while (rowp > landed) {
+        int st = FGMM_ERR_INVALID; // a row past the last piece: header and pieces disagree
+        if (piece >= land->nseg || (st = land->wait(land->arg, piece)) != FGMM_OK) {
+          free(copy);
+          free(scratch);
+          return st;
+        }
+        landed = pool + land->end[piece++];
+      }
+    }
 
     const uint32_t cf = (uint32_t)(d.x & 0xFFFFu); // Rans64DecGet
     int32_t value;

@@ -390,6 +390,29 @@ def test_batch_of_kodak_halves_full_size(mode):
         assert torch.equal(res[seed][1], torch.round(ys[seed]))
 
 
+@pytest.mark.parametrize("tail,pieces", [(0, 4), (8, 1), (3, 2), (6, 3), (8, 8), (5, 50)])
+def test_decode_tail_window_settings(monkeypatch, tail, pieces):
+    """The last items of a decode batch land on the host in pieces and their decoders follow the pieces
+    (fgmm_capi.cpp, decode_batch): every setting of the window must give the same symbols."""
+    monkeypatch.setenv("FGMM_TAIL_ITEMS", str(tail))
+    monkeypatch.setenv("FGMM_TAIL_PIECES", str(pieces))
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    ys, ss, ms, ws = [], [], [], []
+    for seed in range(9):
+        # a mix of sizes: full Kodak halves (pool >> 1 MiB, land in pieces) and small items (land whole)
+        y, sg, mu, pi = T.make_latent(seed) if seed % 3 else T.make_latent(seed, M=24, h=8, w=6)
+        ys.append(dv(y)); ss.append(dv(sg)); ms.append(dv(mu)); ws.append(dv(pi))
+    res = gmc.compress_batch(ys, ss, ms, ws)
+    outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+    for i in range(9):
+        assert torch.equal(outs[i], torch.round(ys[i])), i
+    # a truncated stream in the window still fails loudly (the decoder must not wait for pieces forever)
+    bad = [r[0][0] for r in res]
+    bad[8] = bad[8][:64]
+    with pytest.raises(RuntimeError):
+        gmc.decompress_batch(bad, [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_fp16_parameter_planes(oracle, mode):
     """BASELINE configs[4]: fp16 (mu, sigma, pi), fp32 CDF.  Result == the reference path fed the widened values."""
