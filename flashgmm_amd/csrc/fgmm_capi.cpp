@@ -158,6 +158,7 @@ struct fgmm_ctx {
   char *h_ws = nullptr; // pinned
   size_t h_cap = 0;
   std::vector<hipEvent_t> events;
+  hipStream_t fill_stream = nullptr; // decode: fill passes (the count passes of later groups run beside them)
   hipStream_t copy_stream = nullptr; // bulk D2H of the decode tables (overlaps the table kernels of later groups)
   hipStream_t aux_stream = nullptr;  // the few bytes of per-group pool counters
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while
@@ -167,8 +168,26 @@ struct fgmm_ctx {
     size_t cap, used;
   };
   std::vector<Chunk> chunks;
+  // device staging area of the decode rows (same scheme): the fill pass writes there, one copy per group fetches it
+  std::vector<Chunk> dchunks;
   void chunks_reset() {
     for (auto &c : chunks) c.used = 0;
+    for (auto &c : dchunks) c.used = 0;
+  }
+  int dchunk_alloc(size_t bytes, char **out) {
+    bytes = align_up(bytes, 256);
+    for (auto &c : dchunks)
+      if (c.cap - c.used >= bytes) {
+        *out = c.p + c.used;
+        c.used += bytes;
+        return FGMM_OK;
+      }
+    Chunk c{nullptr, std::max(bytes, (size_t)256 << 20), 0};
+    HIP_TRY(hipMalloc((void **)&c.p, c.cap));
+    c.used = bytes;
+    dchunks.push_back(c);
+    *out = c.p;
+    return FGMM_OK;
   }
   int chunk_alloc(size_t bytes, char **out) {
     bytes = align_up(bytes, 256);
@@ -186,6 +205,7 @@ struct fgmm_ctx {
     return FGMM_OK;
   }
   int ensure_streams() {
+    if (!fill_stream) HIP_TRY(hipStreamCreateWithFlags(&fill_stream, hipStreamNonBlocking));
     if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     if (!aux_stream) HIP_TRY(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
     return FGMM_OK;
@@ -193,8 +213,8 @@ struct fgmm_ctx {
   bool profiling = false;
   unsigned long long stat[4] = {0, 0, 0, 0}; // last batched call: [0] encode table bytes D2H, [1] decode hdr+row bytes D2H,
                                              // [2] decode latents, [3] decode rows that are Elias-Fano coded (unused: 0)
-  hipEvent_t prof[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  bool prof_valid[3] = {false, false, false};
+  hipEvent_t prof[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  bool prof_valid[4] = {false, false, false, false};
 
   int prof_begin(int which, hipStream_t s) {
     if (!profiling) return FGMM_OK;
@@ -453,7 +473,6 @@ struct DecItem {
   fgmm_params prm{};
   int64_t stride_p = 1;
   int32_t M = 0;
-  static constexpr int kMaxPieces = 8;
   int64_t hw = 0;
   int clamp = 0;
   int32_t max_bs = 1;
@@ -464,70 +483,77 @@ struct DecItem {
   // derived
   int32_t n_ch = 0;
   int64_t n = 0;
-  size_t o_list = 0, o_hdr = 0, o_pool = 0, o_used = 0, o_bsum = 0, o_boff = 0;
+  size_t o_list = 0, o_rank = 0, o_hdr = 0, o_used = 0, o_bsum = 0, o_boff = 0;
   int32_t tiles = 0;
-  char *h_hdr = nullptr, *h_pool = nullptr, *h_out = nullptr; // pinned
-  size_t hdr_bytes = 0; // header array rounded up so that the row pool behind it stays 256-B aligned
-  // items of the tail window land in pieces (see decode_batch): pool bytes valid after each piece, and its event
-  int n_piece = 0;
-  uint64_t piece_end[kMaxPieces] = {};
-  hipEvent_t piece_ev[kMaxPieces] = {};
-  uint8_t *pool_dev = nullptr;
-  std::atomic<int> copy_queued{0}; // ev_item recorded in this call (events are reused: never wait on one that was not)
-  double t_start = 0, t_end = 0, t_wait = 0; // FGMM_TRACE=2: job timeline
-  uint64_t pool_cap = 0, pool_used = 0;
+  size_t hdr_bytes = 0;                   // header array, rounded up to 256 B
+  const uint32_t *h_hdr = nullptr;        // pinned: headers
+  char *h_out = nullptr;                  // pinned: decoded symbols (host-written, read by the scatter kernel)
+  uint64_t pool_used = 0;
+  int wide = 0; // h_out holds int32 symbols (some symbol outside int16), else int16
+  // how the rows reach the host (see decode_batch): whole, or in n_piece pieces for the items of the tail window
+  int n_piece = 1;
+  uint64_t piece_end[kMaxPieces] = {};       // latents on the host once piece k has landed
+  const uint8_t *piece_base[kMaxPieces] = {}; // pinned: rows of piece k
+  hipEvent_t piece_ev[kMaxPieces] = {};      // [0] is the event the dispatcher waits for
+  std::atomic<int> copy_queued{0};           // piece_ev[0] recorded in this call (events are reused: never wait on a stale one)
   std::atomic<int> done{0};
+  double t_taken = 0, t_start = 0, t_end = 0; // FGMM_TRACE=2: job timeline
   DecItem() = default;
   DecItem(const DecItem &) = delete;
 };
 
-// Decode, batched and pipelined.  Items are cut into groups; per group one cdftab launch on the caller's stream.
-//   caller stream : [H2D descs][memset counters][cdftab g0][cdftab g1] ... later [H2D y_hat item by item]
-//   aux stream    : after cdftab g -> D2H of group g's pool counters (sizes of the variable-length tables)
-//   copy stream   : per item of a group whose counters have landed: D2H hdr, D2H pool, event
-//   host workers  : item i starts when its event fires; writes y_hat (zero channels restored) into pinned memory
-// so the PCIe transfer of the tables — the longest leg — overlaps both the table kernels of later groups and
-// the host coding of earlier items.
-// Tail window: a bitstream decodes sequentially (~9 ns/symbol), so whatever lands last leaves one whole item of
-// host work behind it.  The last few items are therefore copied in pieces, round-robin (piece 0 of each, then
-// piece 1 of each, ...): their decoders start on piece 0 and follow the pieces as they land (rows are in latent
-// order), and what remains after the final copy is one piece of work instead of one item.
-struct DevFreeList { // device buffers released when the call ends
-  std::vector<void *> v;
-  ~DevFreeList() {
-    for (void *p : v) (void)hipFree(p);
-  }
-};
+constexpr size_t kCounterBytes = sizeof(unsigned long long) * (2 + kMaxPieces); // per item, see DecDesc::pool_used
 
+// Decode, batched and pipelined.  Items are cut into groups; the sizes of the variable-length tables are only known
+// on the device, so every group takes one host round trip between its two passes:
+//   caller's stream : [H2D descs][count+scan g0][count+scan g1] ...              ... [y_hat scatter, item by item]
+//   aux stream      : after count+scan g -> D2H of group g's row-pool sizes
+//   this thread     : sizes of group g known -> pack the group's rows into one staging range (device) and one
+//                     pinned range (host) of exactly that size, patch the descriptors
+//   fill stream     : [H2D descs g][fill g]            (runs beside the count passes of later groups)
+//   copy stream     : after fill g -> ONE copy for the group's header arrays, ONE for its rows (few large copies:
+//                     measured 55.7 GB/s, against 51 GB/s for a copy per item)
+//   dispatcher job  : waits for the groups' copies in order and hands each item to the workers as it lands
+//   host workers    : one bitstream each; symbols go to pinned memory as int16 (int32 if one does not fit)
+//   caller's stream : yhat_scatter_kernel reads them from there and writes the full float latent, zero channels too
+// so the PCIe transfer of the tables, the longest leg, overlaps the table kernels of later groups and the host
+// coding of earlier items.
+// Tail window: a bitstream decodes sequentially (~9 ns/symbol), so whatever lands last leaves one whole item of
+// host work behind it.  The last few items are therefore transferred in pieces (channel ranges), piece k of all of
+// them in one copy: their decoders start on piece 0 and follow the pieces as they land (rows are in latent order),
+// and what remains after the final copy is one piece of work instead of one item.
 int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items, int mode) {
   const int count = (int)items.size();
   if (count == 0) return FGMM_OK;
   Trace tr("decode");
-  DevFreeList extra_pools;
   int rc;
   if ((rc = ctx->ensure_streams())) return rc;
-  // groups of items: small first (the table copies start as early as possible), then larger
+  // tail window: how many trailing items land in pieces, and in how many pieces each
+  const int tail_cfg = getenv("FGMM_TAIL_ITEMS") ? atoi(getenv("FGMM_TAIL_ITEMS")) : 8;
+  const int piece_cfg = getenv("FGMM_TAIL_PIECES") ? atoi(getenv("FGMM_TAIL_PIECES")) : 4;
+  const int n_piece = std::min(std::max(piece_cfg, 1), (int)kMaxPieces);
+  const int tail_items = (count >= 4 && n_piece > 1) ? std::min({std::max(tail_cfg, 0), count, std::max(ctx->pool->size() / 2, 1)}) : 0;
+  const int tail_begin = count - tail_items;
+  // groups of items: small first (the first tables land as early as possible), then larger; the tail window is
+  // one group of its own
   std::vector<int> gbeg;
   {
-    const int steady = count >= 16 ? std::max(2, count / 8) : count;
-    int i = 0, sz = count >= 16 ? 2 : count;
-    while (i < count) {
+    const int steady_cfg = getenv("FGMM_DEC_GROUP") ? atoi(getenv("FGMM_DEC_GROUP")) : 0;
+    const int steady = steady_cfg > 0 ? steady_cfg : (count >= 16 ? std::max(2, count / 8) : count);
+    int i = 0, sz = count >= 16 ? std::min(2, steady) : count;
+    while (i < tail_begin) {
       gbeg.push_back(i);
-      i += sz;
+      i = std::min(i + sz, tail_begin);
       sz = std::min(steady, sz * 2);
     }
+    if (tail_items) gbeg.push_back(tail_begin);
     gbeg.push_back(count);
   }
   const int n_groups = (int)gbeg.size() - 1;
-  // tail window (see above): how many trailing items land in pieces, and in how many pieces each
-  const int tail_cfg = getenv("FGMM_TAIL_ITEMS") ? atoi(getenv("FGMM_TAIL_ITEMS")) : 8;
-  const int piece_cfg = getenv("FGMM_TAIL_PIECES") ? atoi(getenv("FGMM_TAIL_PIECES")) : 4;
-  const int n_piece = std::min(std::max(piece_cfg, 1), (int)DecItem::kMaxPieces);
-  const int tail_items = (count >= 4 && n_piece > 1) ? std::min({std::max(tail_cfg, 0), count, std::max(ctx->pool->size() / 2, 1)}) : 0;
-  const int tail_begin = count - tail_items;
 
-  Arena ar; // device workspace; the part before the counters is mirrored in h_ws and uploaded in one copy
-  const size_t o_descs = ar.take(sizeof(DecDesc) * count);
+  Arena ar; // device workspace; the part before the counters is mirrored in h_ws
+  const size_t o_descs = ar.take(sizeof(DecDesc) * (size_t)count);
+  const size_t o_pdescs = ar.take(sizeof(DecDesc) * (size_t)std::max(tail_items * n_piece, 1)); // piece k of tail item t: [k * tail_items + t]
   for (auto &it : items) {
     if (it.max_bs < 0 || it.max_bs > FGMM_MAX_BS)
       return fail(FGMM_ERR_UNSUPPORTED, "max_bs_value %d outside [0, %d]", it.max_bs, FGMM_MAX_BS);
@@ -535,41 +561,45 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     for (int c = 0; c < it.M; ++c) it.n_ch += it.zero_bitmap ? (it.zero_bitmap[c] != 0) : 1;
     it.n = (int64_t)it.n_ch * it.hw;
     it.o_list = ar.take(sizeof(int32_t) * std::max(it.n_ch, 1), 16);
+    it.o_rank = ar.take(sizeof(int32_t) * std::max(it.M, 1), 16);
   }
-  const size_t o_used = ar.take(16 * (size_t)count, 256);
+  const size_t o_used = ar.take(kCounterBytes * (size_t)count, 256);
   const size_t upload_bytes = o_used;
-  for (int i = 0; i < count; ++i) items[i].o_used = o_used + 16 * (size_t)i;
+  for (int i = 0; i < count; ++i) items[i].o_used = o_used + kCounterBytes * (size_t)i;
   const size_t host_fixed = ar.off;
+  for (auto &it : items) { // the header arrays of consecutive items are adjacent: one copy per group fetches them
+    it.hdr_bytes = align_up(sizeof(uint32_t) * (size_t)it.n, 256);
+    it.o_hdr = ar.take(it.hdr_bytes);
+  }
   for (auto &it : items) {
-    // Row pool: provisioned for an average of `per_latent` bytes per latent (measured: ~75 on the wide synthetic
-    // Kodak rows), never more than the worst case n * widest raw row.  The scan kernel knows the exact total before
-    // anything is written; an item that does not fit is re-run below with an exactly sized pool.
-    static const uint64_t per_latent = getenv("FGMM_POOL_BYTES_PER_LATENT") ? strtoull(getenv("FGMM_POOL_BYTES_PER_LATENT"), nullptr, 10) : 256;
-    const uint64_t rowcap = 2 * (((uint64_t)(2 * (int64_t)it.max_bs + 2) + 3) & ~3ull); // widest row, raw form, bytes
-    it.pool_cap = std::min((uint64_t)it.n * rowcap, (uint64_t)it.n * per_latent + 4096);
     it.tiles = (int32_t)((it.hw + 255) / 256);
     const size_t nblk = (size_t)it.n_ch * (size_t)it.tiles;
-    // header array and row pool are adjacent: one D2H copy per item brings both
-    it.hdr_bytes = align_up(sizeof(uint32_t) * (size_t)it.n, 256);
-    it.o_hdr = ar.take(it.hdr_bytes + it.pool_cap + 128);
-    it.o_pool = it.o_hdr + it.hdr_bytes;
     it.o_bsum = ar.take(sizeof(uint32_t) * nblk + 64);
     it.o_boff = ar.take(sizeof(uint64_t) * nblk + 64);
   }
+  // events: per group [scan done][counters landed][fill done][tables landed], plus per piece of the tail window
+  // [fill done][landed]
   if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(host_fixed)) ||
-      (rc = ctx->ensure_events((size_t)count + 2 * (size_t)n_groups + (size_t)tail_items * DecItem::kMaxPieces)))
+      (rc = ctx->ensure_events(4 * (size_t)n_groups + 2 * (size_t)n_piece)))
     return rc;
   ctx->chunks_reset();
-  hipEvent_t *ev_item = ctx->events.data();
-  hipEvent_t *ev_kernel = ev_item + count, *ev_counters = ev_kernel + n_groups, *ev_piece = ev_counters + n_groups;
+  hipEvent_t *ev_scan = ctx->events.data(), *ev_counters = ev_scan + n_groups, *ev_fill = ev_counters + n_groups,
+             *ev_landed = ev_fill + n_groups, *ev_pfill = ev_landed + n_groups, *ev_pland = ev_pfill + n_piece;
 
   DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_descs);
+  DecDesc *hpd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_pdescs);
+  const DecDesc *dd = reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs);
+  const DecDesc *dpd = reinterpret_cast<const DecDesc *>(ctx->d_ws + o_pdescs);
   for (int i = 0; i < count; ++i) {
     DecItem &it = items[i];
     int32_t *list = reinterpret_cast<int32_t *>(ctx->h_ws + it.o_list);
+    int32_t *rank = reinterpret_cast<int32_t *>(ctx->h_ws + it.o_rank);
     int r = 0;
-    for (int c = 0; c < it.M; ++c)
-      if (!it.zero_bitmap || it.zero_bitmap[c] != 0) list[r++] = c;
+    for (int c = 0; c < it.M; ++c) {
+      const bool coded = !it.zero_bitmap || it.zero_bitmap[c] != 0;
+      rank[c] = coded ? r : -1;
+      if (coded) list[r++] = c;
+    }
     DecDesc &d = hd[i];
     memset(&d, 0, sizeof d);
     d.scales = it.prm.scales;
@@ -581,152 +611,81 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.hw = it.hw;
     d.chan_list = reinterpret_cast<const int32_t *>(ctx->d_ws + it.o_list);
     d.n_ch = it.n_ch;
+    d.ch_begin = 0;
+    d.ch_end = it.n_ch;
     d.max_bs = it.max_bs;
     d.clamp = it.clamp;
     d.prune = 1;
     d.tiles = it.tiles;
     d.hdr = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_hdr);
-    d.pool = reinterpret_cast<uint8_t *>(ctx->d_ws + it.o_pool);
-    d.pool_cap = it.pool_cap;
+    d.pool = nullptr;   // set once the size is known
+    d.pool_cap = ~0ull; // the pool is carved to the exact size: the overflow flag of the scan pass stays clear
     d.pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_used);
+    d.n_piece = i >= tail_begin ? n_piece : 1;
     d.blk_sums = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_bsum);
     d.blk_off = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_boff);
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(ctx->d_ws + o_used, 0, 16 * (size_t)count, stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + o_used, 0, kCounterBytes * (size_t)count, stream));
+  const bool clamped = items[0].clamp != 0, f16 = items[0].prm.dtype == FGMM_F16;
+  auto extent = [&](int i0, int i1, int *n_ch_max, int64_t *hw_max) {
+    *n_ch_max = 0;
+    *hw_max = 0;
+    for (int i = i0; i < i1; ++i) {
+      *n_ch_max = std::max(*n_ch_max, items[i].n_ch);
+      *hw_max = std::max(*hw_max, items[i].hw);
+    }
+  };
   if ((rc = ctx->prof_begin(1, stream))) return rc;
   for (int g = 0; g < n_groups; ++g) {
     const int i0 = gbeg[g], i1 = gbeg[g + 1];
-    int n_ch_max = 0;
-    int64_t hw_max = 0;
-    for (int i = i0; i < i1; ++i) {
-      n_ch_max = std::max(n_ch_max, items[i].n_ch);
-      hw_max = std::max(hw_max, items[i].hw);
-    }
-    LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs) + i0, i1 - i0, n_ch_max, hw_max, mode,
-                             items[0].clamp != 0, items[0].prm.dtype == FGMM_F16, stream));
-    HIP_TRY(hipEventRecord(ev_kernel[g], stream));
-    HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_kernel[g], 0));
-    HIP_TRY(hipMemcpyAsync(ctx->h_ws + items[i0].o_used, ctx->d_ws + items[i0].o_used, 16 * (size_t)(i1 - i0),
+    int n_ch_max;
+    int64_t hw_max;
+    extent(i0, i1, &n_ch_max, &hw_max);
+    LAUNCH_TRY(launch_cdftab_count(dd + i0, i1 - i0, n_ch_max, hw_max, mode, clamped, f16, stream));
+    HIP_TRY(hipEventRecord(ev_scan[g], stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_scan[g], 0));
+    HIP_TRY(hipMemcpyAsync(ctx->h_ws + items[i0].o_used, ctx->d_ws + items[i0].o_used, kCounterBytes * (size_t)(i1 - i0),
                            hipMemcpyDeviceToHost, ctx->aux_stream));
     HIP_TRY(hipEventRecord(ev_counters[g], ctx->aux_stream));
   }
-  if ((rc = ctx->prof_end(1, stream))) return rc; // brackets all groups' launches
+  if ((rc = ctx->prof_end(1, stream))) return rc; // brackets the count + scan passes of all groups
   tr.mark("enqueued");
 
-  // ---- as each group's sizes arrive: queue its table copies, hand its items to the workers -------------------
   std::mutex done_mu;
   std::condition_variable done_cv;
-  const char *h_ws = ctx->h_ws;
-
-  auto queue_group_copies = [&](int g) -> int {
-    const int i0 = gbeg[g], i1 = gbeg[g + 1];
-    for (int i = i0; i < i1; ++i) {
-      DecItem &it = items[i];
-      const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
-      uint8_t *pool_dev = reinterpret_cast<uint8_t *>(ctx->d_ws + it.o_pool);
-      if (u[1]) {
-        // the rows of this item need u[0] bytes, more than provisioned: nothing was written (the fill kernel saw
-        // the flag).  Re-run the item alone with an exactly sized pool.
-        const unsigned long long need = u[0];
-        uint8_t *extra = nullptr;
-        HIP_TRY(hipMalloc((void **)&extra, need + 256));
-        extra_pools.v.push_back(extra);
-        hd[i].pool = extra;
-        hd[i].pool_cap = need;
-        HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs + sizeof(DecDesc) * (size_t)i, &hd[i], sizeof(DecDesc), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemsetAsync(ctx->d_ws + it.o_used, 0, 16, stream));
-        LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs) + i, 1, it.n_ch, it.hw, mode,
-                                 it.clamp != 0, it.prm.dtype == FGMM_F16, stream));
-        unsigned long long again[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(again, ctx->d_ws + it.o_used, 16, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (again[1] || again[0] != need) return fail(FGMM_ERR_HIP, "edge-table pool re-run failed on item %d", i);
-        pool_dev = extra;
-      }
-      it.pool_used = u[0];
-      const size_t out_bytes = it.y_hat ? sizeof(float) * (size_t)it.M * (size_t)it.hw : sizeof(int32_t) * (size_t)it.n;
-      int rc2;
-      if ((rc2 = ctx->chunk_alloc(it.hdr_bytes + it.pool_used + 1024, &it.h_hdr)) || (rc2 = ctx->chunk_alloc(out_bytes + 64, &it.h_out)))
-        return rc2;
-      it.h_pool = it.h_hdr + it.hdr_bytes;
-      it.pool_dev = pool_dev;
-      const bool in_place = pool_dev == reinterpret_cast<uint8_t *>(ctx->d_ws + it.o_pool);
-      if (i >= tail_begin && in_place && it.pool_used >= (1u << 20)) {
-        it.n_piece = n_piece; // copied by queue_tail_copies, round-robin with the other items of the tail window
-        continue;
-      }
-      if (it.n) {
-        if (in_place) { // the usual case: one copy
-          HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, it.hdr_bytes + it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
-        } else { // re-run item: its rows live in the extra pool
-          HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, sizeof(uint32_t) * (size_t)it.n, hipMemcpyDeviceToHost, ctx->copy_stream));
-          if (it.pool_used) HIP_TRY(hipMemcpyAsync(it.h_pool, pool_dev, it.pool_used, hipMemcpyDeviceToHost, ctx->copy_stream));
-        }
-      }
-      HIP_TRY(hipEventRecord(ev_item[i], ctx->copy_stream));
-      it.copy_queued.store(1, std::memory_order_release);
-    }
-    return FGMM_OK;
-  };
-
-  auto queue_tail_copies = [&]() -> int {
-    for (int k = 0; k < n_piece; ++k) {
-      for (int i = tail_begin; i < count; ++i) {
-        DecItem &it = items[i];
-        if (!it.n_piece) continue;
-        const uint64_t b0 = k ? it.piece_end[k - 1] : 0;
-        const uint64_t b1 = k + 1 == n_piece ? it.pool_used : (it.pool_used * (uint64_t)(k + 1) / (uint64_t)n_piece) & ~255ull;
-        it.piece_end[k] = b1;
-        it.piece_ev[k] = ev_piece[(size_t)(i - tail_begin) * DecItem::kMaxPieces + k];
-        if (k == 0) { // header array + first piece of the pool, which lies right behind it
-          HIP_TRY(hipMemcpyAsync(it.h_hdr, ctx->d_ws + it.o_hdr, it.hdr_bytes + b1, hipMemcpyDeviceToHost, ctx->copy_stream));
-          HIP_TRY(hipEventRecord(ev_item[i], ctx->copy_stream));
-          it.copy_queued.store(1, std::memory_order_release);
-        } else {
-          if (b1 > b0) HIP_TRY(hipMemcpyAsync(it.h_pool + b0, it.pool_dev + b0, b1 - b0, hipMemcpyDeviceToHost, ctx->copy_stream));
-          HIP_TRY(hipEventRecord(it.piece_ev[k], ctx->copy_stream));
-        }
-      }
-    }
-    return FGMM_OK;
-  };
 
   auto submit_job = [&](int i, bool here) { // here: the item's tables (or their first piece) are on the host
     DecItem *pit = &items[i];
-    pit->t_wait = tr.ms();
-    const int32_t *list = reinterpret_cast<const int32_t *>(h_ws + pit->o_list);
-    auto job = [pit, list, here, &done_mu, &done_cv, &tr] {
+    pit->t_taken = tr.ms();
+    auto job = [pit, here, &done_mu, &done_cv, &tr] {
       pit->t_start = tr.ms();
-      memset(pit->h_pool + pit->pool_used, 0, 64); // defined bytes for the SIMD over-read
-      int32_t *sym = pit->y_hat ? (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(pit->n, 1))
-                                : reinterpret_cast<int32_t *>(pit->h_out);
-      if (!here) { // the copy failed
+      int32_t *sym = pit->sym_host_out ? pit->sym_host_out
+                                       : (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(pit->n, 1));
+      if (!here) { // a kernel or copy of the item's group failed
         pit->status = FGMM_ERR_HIP;
-        if (pit->y_hat) free(sym);
       } else if (!sym) {
         pit->status = FGMM_ERR_NOMEM;
       } else {
-        Landing land{pit->n_piece, pit->piece_end, pit, [](void *arg, int k) -> int {
+        Landing land{pit->n_piece, pit->piece_end, pit->piece_base, pit, [](void *arg, int k) -> int {
                        return hipEventSynchronize(static_cast<DecItem *>(arg)->piece_ev[k]) == hipSuccess ? (int)FGMM_OK : (int)FGMM_ERR_HIP;
                      }};
-        pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, reinterpret_cast<const uint32_t *>(pit->h_hdr),
-                                         reinterpret_cast<const uint8_t *>(pit->h_pool), pit->n, pit->max_bs, sym,
-                                         pit->n_piece ? &land : nullptr);
+        pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, pit->h_hdr, pit->piece_base[0], pit->n, pit->max_bs, sym,
+                                         pit->n_piece > 1 ? &land : nullptr);
         if (pit->status == FGMM_OK && pit->y_hat) {
-          // y_hat[:, nonzero] = symbols.float(), zeros elsewhere   (entropy_models.py:903-908)
-          float *yh = reinterpret_cast<float *>(pit->h_out);
-          memset(yh, 0, sizeof(float) * (size_t)pit->M * (size_t)pit->hw);
-          for (int r = 0; r < pit->n_ch; ++r) {
-            float *dst = yh + (size_t)list[r] * pit->hw;
-            const int32_t *src = sym + (size_t)r * pit->hw;
-            for (int64_t p = 0; p < pit->hw; ++p) dst[p] = (float)src[p];
+          // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
+          int16_t *s16 = reinterpret_cast<int16_t *>(pit->h_out);
+          int32_t acc = 0;
+          for (int64_t k = 0; k < pit->n; ++k) {
+            const int32_t v = sym[k];
+            s16[k] = (int16_t)v;
+            acc |= v ^ (int32_t)(int16_t)v;
           }
-        } else if (pit->status == FGMM_OK && pit->sym_host_out) {
-          memcpy(pit->sym_host_out, sym, sizeof(int32_t) * (size_t)pit->n);
+          pit->wide = acc != 0;
+          if (pit->wide) memcpy(pit->h_out, sym, sizeof(int32_t) * (size_t)pit->n);
         }
-        if (pit->y_hat) free(sym);
       }
+      if (sym != pit->sym_host_out) free(sym);
       pit->t_end = tr.ms();
       {
         std::lock_guard<std::mutex> l(done_mu);
@@ -737,16 +696,16 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     if (count == 1) job(); else ctx->pool->submit(job);
   };
 
-  // One dispatcher (itself a pool job) waits for the items' copies in order and hands each item to the workers as
-  // it lands, while this thread keeps feeding the copy stream group by group.
+  // One dispatcher (itself a pool job) waits for the copies in order and hands each item to the workers as it
+  // lands, while this thread keeps feeding the fill and copy streams group by group.
   std::atomic<int> abandon{0};
-  auto dispatcher = [&, ev_item] {
+  auto dispatcher = [&] {
     for (int i = 0; i < count; ++i) {
       while (!items[i].copy_queued.load(std::memory_order_acquire)) {
         if (abandon.load()) return;
         __builtin_ia32_pause();
       }
-      submit_job(i, hipEventSynchronize(ev_item[i]) == hipSuccess);
+      submit_job(i, hipEventSynchronize(items[i].piece_ev[0]) == hipSuccess);
     }
   };
   // Order of destruction on any return: release the dispatcher, wait for every job, then the objects they use.
@@ -756,20 +715,100 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     ~Abandon() { f.store(1); }
   } abandon_on_exit{abandon};
   if (count > 1) ctx->pool->submit(dispatcher);
+
+  if ((rc = ctx->prof_begin(3, ctx->fill_stream))) return rc;
   for (int g = 0; g < n_groups; ++g) {
+    const int i0 = gbeg[g], i1 = gbeg[g + 1];
+    const bool tail = tail_items && i0 == tail_begin;
+    const int np = tail ? n_piece : 1;
     HIP_TRY(hipEventSynchronize(ev_counters[g]));
-    if ((rc = queue_group_copies(g))) return rc;
-    if (g + 1 == n_groups && (rc = queue_tail_copies())) return rc;
+    // ---- layout of the group's rows: piece-major (piece k of every item, then piece k+1 ...), each range 256-B
+    // aligned; the same offsets in the device staging range and in the pinned range
+    size_t piece_off[kMaxPieces + 1] = {0}; // byte range of piece k within the group's rows
+    std::vector<size_t> at((size_t)(i1 - i0) * (size_t)np); // [k * (i1-i0) + t]: where piece k of item t starts
+    size_t off = 0, out_total = 0;
+    for (int k = 0; k < np; ++k) {
+      piece_off[k] = off;
+      for (int i = i0; i < i1; ++i) {
+        DecItem &it = items[i];
+        const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
+        it.pool_used = u[0];
+        const uint64_t b0 = k ? u[2 + k - 1] : 0, b1 = k + 1 < np ? u[2 + k] : u[0];
+        if (b1 < b0 || b1 > u[0]) return fail(FGMM_ERR_HIP, "inconsistent piece offsets for item %d", i);
+        at[(size_t)k * (size_t)(i1 - i0) + (size_t)(i - i0)] = off;
+        off = align_up(off + (size_t)(b1 - b0), 256);
+      }
+    }
+    piece_off[np] = off;
+    const size_t rows_bytes = off + 256; // + slack: the host's SIMD search reads a little past a row
+    const size_t hdr_total = items[i1 - 1].o_hdr + items[i1 - 1].hdr_bytes - items[i0].o_hdr;
+    for (int i = i0; i < i1; ++i) out_total += align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(items[i].n, 1), 256);
+    char *d_rows = nullptr, *h_rows = nullptr, *h_hdrs = nullptr, *h_outs = nullptr;
+    if ((rc = ctx->dchunk_alloc(rows_bytes, &d_rows)) || (rc = ctx->chunk_alloc(rows_bytes, &h_rows)) ||
+        (rc = ctx->chunk_alloc(hdr_total + 256, &h_hdrs)) || (rc = ctx->chunk_alloc(out_total + 256, &h_outs)))
+      return rc;
+    memset(h_rows + off, 0, 256);
+    size_t out_off = 0;
+    for (int i = i0; i < i1; ++i) {
+      DecItem &it = items[i];
+      const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
+      it.h_hdr = reinterpret_cast<const uint32_t *>(h_hdrs + (it.o_hdr - items[i0].o_hdr));
+      it.h_out = h_outs + out_off;
+      out_off += align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(it.n, 1), 256);
+      it.n_piece = np;
+      for (int k = 0; k < np; ++k) {
+        const size_t a = at[(size_t)k * (size_t)(i1 - i0) + (size_t)(i - i0)];
+        const uint64_t b0 = k ? u[2 + k - 1] : 0;
+        it.piece_base[k] = reinterpret_cast<const uint8_t *>(h_rows + a);
+        it.piece_end[k] = (uint64_t)((int64_t)it.n_ch * (k + 1) / np) * (uint64_t)it.hw;
+        it.piece_ev[k] = tail ? ev_pland[k] : ev_landed[g];
+        // the fill pass addresses rows as pool + (offset within the item): bias the base by the piece's start
+        DecDesc &d = tail ? hpd[k * tail_items + (i - i0)] : hd[i];
+        if (tail) d = hd[i];
+        d.pool = reinterpret_cast<uint8_t *>(d_rows + a) - b0;
+        d.ch_begin = (int32_t)((int64_t)it.n_ch * k / np);
+        d.ch_end = (int32_t)((int64_t)it.n_ch * (k + 1) / np);
+      }
+    }
+    int n_ch_max;
+    int64_t hw_max;
+    extent(i0, i1, &n_ch_max, &hw_max);
+    // ---- fill, then fetch: headers of the whole group in one copy, rows in one copy per piece
+    if (!tail) {
+      HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs + sizeof(DecDesc) * (size_t)i0, &hd[i0], sizeof(DecDesc) * (size_t)(i1 - i0),
+                             hipMemcpyHostToDevice, ctx->fill_stream));
+      LAUNCH_TRY(launch_cdftab_fill(dd + i0, i1 - i0, n_ch_max, hw_max, mode, clamped, f16, ctx->fill_stream));
+      HIP_TRY(hipEventRecord(ev_fill[g], ctx->fill_stream));
+      HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_fill[g], 0));
+      HIP_TRY(hipMemcpyAsync(h_hdrs, ctx->d_ws + items[i0].o_hdr, hdr_total, hipMemcpyDeviceToHost, ctx->copy_stream));
+      if (off) HIP_TRY(hipMemcpyAsync(h_rows, d_rows, off, hipMemcpyDeviceToHost, ctx->copy_stream));
+      HIP_TRY(hipEventRecord(ev_landed[g], ctx->copy_stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_pdescs, hpd, sizeof(DecDesc) * (size_t)(tail_items * n_piece), hipMemcpyHostToDevice,
+                             ctx->fill_stream));
+      for (int k = 0; k < np; ++k) {
+        LAUNCH_TRY(launch_cdftab_fill(dpd + k * tail_items, tail_items, n_ch_max, hw_max, mode, clamped, f16, ctx->fill_stream));
+        HIP_TRY(hipEventRecord(ev_pfill[k], ctx->fill_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_pfill[k], 0));
+        if (k == 0) HIP_TRY(hipMemcpyAsync(h_hdrs, ctx->d_ws + items[i0].o_hdr, hdr_total, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (piece_off[k + 1] > piece_off[k])
+          HIP_TRY(hipMemcpyAsync(h_rows + piece_off[k], d_rows + piece_off[k], piece_off[k + 1] - piece_off[k], hipMemcpyDeviceToHost,
+                                 ctx->copy_stream));
+        HIP_TRY(hipEventRecord(ev_pland[k], ctx->copy_stream));
+      }
+    }
+    for (int i = i0; i < i1; ++i) items[i].copy_queued.store(1, std::memory_order_release);
   }
+  if ((rc = ctx->prof_end(3, ctx->fill_stream))) return rc;
   if (count == 1) dispatcher();
   ctx->stat[1] = ctx->stat[2] = 0;
   for (auto &it : items) {
     ctx->stat[1] += it.pool_used + sizeof(uint32_t) * (unsigned long long)it.n;
     ctx->stat[2] += (unsigned long long)it.n;
   }
-  tr.mark("table kernels done, copies queued");
+  tr.mark("sizes known, fill + copies queued");
 
-  // ---- y_hat back to the GPU item by item, on the caller's stream ----------------------------------------
+  // ---- symbols back to the GPU item by item: scatter kernel on the caller's stream ---------------------------
   int first_err = FGMM_OK;
   for (int i = 0; i < count; ++i) {
     DecItem &it = items[i];
@@ -779,15 +818,16 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
     if (it.status && !first_err) first_err = it.status;
     if (it.status == FGMM_OK && it.y_hat && it.M * it.hw)
-      HIP_TRY(hipMemcpyAsync(it.y_hat, it.h_out, sizeof(float) * (size_t)it.M * (size_t)it.hw, hipMemcpyHostToDevice, stream));
+      LAUNCH_TRY(launch_yhat_scatter(it.h_out, it.wide, reinterpret_cast<const int32_t *>(ctx->d_ws + it.o_rank), it.y_hat, it.M,
+                                     it.hw, stream));
   }
   tr.mark("host rANS done");
   HIP_TRY(hipStreamSynchronize(stream));
-  tr.mark("y_hat uploaded");
+  tr.mark("y_hat written");
   if (tr.on && getenv("FGMM_TRACE") && atoi(getenv("FGMM_TRACE")) > 1)
     for (int i = 0; i < count; ++i)
       fprintf(stderr, "[fgmm decode]   item %2d  pieces %d  taken %7.3f  job %7.3f .. %7.3f  (%.3f ms)\n", i, items[i].n_piece,
-              items[i].t_wait, items[i].t_start, items[i].t_end, items[i].t_end - items[i].t_start);
+              items[i].t_taken, items[i].t_start, items[i].t_end, items[i].t_end - items[i].t_start);
   if (first_err)
     return fail(first_err, "host rANS decode failed (%d)%s", first_err, first_err == FGMM_ERR_STREAM ? ": bitstream too short" : "");
   return FGMM_OK;
@@ -844,7 +884,9 @@ void fgmm_ctx_destroy(fgmm_ctx *ctx) {
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_ws) (void)hipHostFree(ctx->h_ws);
     for (auto &c : ctx->chunks) (void)hipHostFree(c.p);
+    for (auto &c : ctx->dchunks) (void)hipFree(c.p);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->fill_stream) (void)hipStreamDestroy(ctx->fill_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   }
   delete ctx;
@@ -863,7 +905,7 @@ int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable) {
 }
 
 int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out) {
-  if (!ctx || which < 0 || which > 2 || !ms_out) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (!ctx || which < 0 || which > 3 || !ms_out) return fail(FGMM_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lock(ctx->mu);
   if (!ctx->profiling || !ctx->prof_valid[which]) return fail(FGMM_ERR_INVALID, "no profiled launch of kernel %d yet", which);
   DeviceGuard g(ctx->device);
@@ -1180,6 +1222,8 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   hd->stride_p = stride_n;
   hd->hw = n;
   hd->n_ch = 1;
+  hd->ch_begin = 0;
+  hd->ch_end = 1;
   hd->max_bs = max_bs;
   hd->prune = (flags & FGMM_TAB_NO_PRUNE) ? 0 : 1;
   hd->clamp = (flags & FGMM_TAB_CLAMP) ? 1 : 0;

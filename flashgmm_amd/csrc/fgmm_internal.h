@@ -44,10 +44,15 @@ struct DecDesc {
   int32_t prune;                 // 1: skip the saturated tails (exact, see cdftab_count_kernel); 0: evaluate all of F
   int32_t tiles;                 // blocks per channel = ceil(hw / 256)
   int32_t pad_;
-  uint32_t *hdr;                 // [n_ch*hw] 4-byte headers
-  uint8_t *pool;                 // rows, latent order
+  uint32_t *hdr;                 // [n_ch*hw] 4-byte headers (device: written by the count pass, read by the fill pass)
+  uint32_t *hdr_out;             // null, or where the fill pass also stores the headers (pinned host memory)
+  int32_t ch_begin, ch_end;      // compact channels the fill pass covers (a launch may fill an item piece by piece)
+  uint8_t *pool;                 // rows, latent order (device memory, or pinned host memory written over PCIe)
   unsigned long long pool_cap;   // bytes
-  unsigned long long *pool_used; // [0] bytes used, [1] overflow flag
+  unsigned long long *pool_used; // [0] bytes used, [1] overflow flag, [2 + k] byte offset of the first row of piece
+                                 // k + 1 (k < n_piece - 1), piece k = compact channels [n_ch*k/n_piece, n_ch*(k+1)/n_piece)
+  int32_t n_piece;               // 0 or 1: no piece offsets wanted (at most FGMM_MAX_PIECES)
+  int32_t pad2_;
   uint32_t *blk_sums;            // [n_ch*tiles] row bytes per block
   unsigned long long *blk_off;   // [n_ch*tiles] byte offset of each block's first row
 };
@@ -58,6 +63,7 @@ struct DecDesc {
 //     raw (cnt < 64 or nonmono): uint16[round4(cnt)], padded with the last value
 //     EF  (cnt >= 64, monotone): uint8 lows[round8(cnt)] ; uint64 upper[U], U = ceil((cnt + 256) / 64),
 //                                bit ((E_j >> 8) + j) set for every entry j
+constexpr int kMaxPieces = 8; // FGMM_MAX_PIECES
 #ifndef FGMM_EF_MIN
 #define FGMM_EF_MIN 64
 #endif
@@ -79,8 +85,16 @@ int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, 
                   bool f16, void *stream);
 int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
                     int64_t stride_n, int64_t stride_k, int mode, float *c1, float *c2, void *stream);
+// count + scan (sizes and offsets), then fill (rows); launch_cdftab = both, back to back on one stream
+int launch_cdftab_count(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                        void *stream);
+int launch_cdftab_fill(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                       void *stream);
 int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
                   void *stream);
+// y_hat[c, p] = rank[c] < 0 ? 0 : (float)sym[rank[c] * hw + p]; sym is int16 (wide = 0) or int32 and may live in pinned
+// host memory (read over PCIe)   (entropy_models.py:903-908)
+int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y_hat, int M, int64_t hw, void *stream);
 int launch_fastmath_selftest(int which, unsigned long long n, unsigned long long seed, unsigned long long *n_bad, void *stream);
 // exhaustive check of the saturation lemmas behind the pruning; *n_bad (device) receives the number of violations
 int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream);
@@ -89,13 +103,13 @@ int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream
 // returns 0 or an fgmm_status; *out malloc'ed
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len);
-// Rows that reach the host in pieces: after piece k has landed, the first end[k] bytes of the pool are valid
-// (end[nseg-1] = all of it).  Piece 0 (which also carries the header array) has landed before the decoder is
-// called; wait(arg, k) blocks until piece k (k >= 1) has.  The decoder walks rows in order, so it only ever waits
-// for the next piece.
+// Tables that reach the host in pieces: after piece k has landed, the headers and rows of the first end[k] latents
+// are valid (end[nseg-1] = n), the rows of piece k starting at base[k].  Piece 0 has landed before the decoder is called; wait(arg, k) blocks until piece k
+// (k >= 1) has.  The decoder walks the latents in order, so it only ever waits for the next piece.
 struct Landing {
   int nseg;
   const uint64_t *end;
+  const uint8_t *const *base; // rows of piece k start at base[k] (the pieces need not be adjacent in memory)
   void *arg;
   int (*wait)(void *arg, int k); // FGMM_OK or an error status
 };

@@ -458,13 +458,17 @@ __global__ __launch_bounds__(kBlock) void cdftab_scan_kernel(const DecDesc *__re
     d.pool_used[0] = s_carry;
     d.pool_used[1] = s_carry > d.pool_cap ? 1ull : 0ull;
   }
+  if (d.n_piece > 1 && (int)threadIdx.x < d.n_piece - 1) { // where the pieces of the item begin (blk_off is this block's own)
+    const int64_t ch = (int64_t)d.n_ch * ((int)threadIdx.x + 1) / d.n_piece;
+    d.pool_used[2 + threadIdx.x] = ch * d.tiles < nb ? d.blk_off[ch * d.tiles] : s_carry;
+  }
 }
 
 template <int MODE, bool CLAMPED, typename PT>
 __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__restrict__ descs) {
   const DecDesc &d = descs[blockIdx.z];
-  const int cj = blockIdx.y;
-  if (cj >= d.n_ch) return;
+  const int cj = (int)blockIdx.y + d.ch_begin;
+  if (cj >= d.ch_end) return;
   const int64_t hw = d.hw;
   if ((int64_t)blockIdx.x * kBlock >= hw) return;
   if (d.pool_used[1]) return; // pool too small: the host sees the flag
@@ -475,6 +479,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
   L.load(d, c, active ? p : 0);
 
   const uint32_t h = active ? d.hdr[(int64_t)cj * hw + p] : 0u;
+  if (d.hdr_out && active) d.hdr_out[(int64_t)cj * hw + p] = h;
   const int a_idx = tab_hdr_a(h) + d.max_bs;
   const uint32_t cnt = tab_hdr_cnt(h), nonmono = tab_hdr_nonmono(h);
   const uint32_t bytes = active ? tab_row_bytes(cnt, nonmono) : 0u;
@@ -526,6 +531,20 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
       wcur = 0;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// yhat_scatter_kernel: the decoded symbols of the coded channels back into the full [M, hw] latent, as floats, zero
+// channels restored (entropy_models.py:903-908).  `sym` is read where the host decoder left it (pinned host memory).
+// ---------------------------------------------------------------------------------------------------------
+template <typename ST>
+__global__ __launch_bounds__(kBlock) void yhat_scatter_kernel(const ST *__restrict__ sym, const int32_t *__restrict__ rank,
+                                                             float *__restrict__ y_hat, int64_t hw) {
+  const int c = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= hw) return;
+  const int r = rank[c];
+  y_hat[(int64_t)c * hw + p] = r < 0 ? 0.0f : (float)sym[(int64_t)r * hw + p];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -669,12 +688,14 @@ int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, c
 }
 
 template <bool CLAMPED, typename PT>
-static int launch_cdftab_c(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, hipStream_t s) {
+static int launch_cdftab_c(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, int pass, hipStream_t s) {
   dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)n_ch_max, (unsigned)count);
 #define FGMM_TAB_LAUNCH(M)                                                                                          \
-  hipLaunchKernelGGL((cdftab_count_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);                     \
-  hipLaunchKernelGGL(cdftab_scan_kernel, dim3((unsigned)count), dim3(kBlock), 0, s, d_descs);                       \
-  hipLaunchKernelGGL((cdftab_fill_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);
+  if (pass & 1) {                                                                                                   \
+    hipLaunchKernelGGL((cdftab_count_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);                   \
+    hipLaunchKernelGGL(cdftab_scan_kernel, dim3((unsigned)count), dim3(kBlock), 0, s, d_descs);                     \
+  }                                                                                                                 \
+  if (pass & 2) hipLaunchKernelGGL((cdftab_fill_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);
   switch (mode) {
   case MODE_AS: FGMM_TAB_LAUNCH(MODE_AS) break;
   case MODE_LOGISTIC: FGMM_TAB_LAUNCH(MODE_LOGISTIC) break;
@@ -684,14 +705,34 @@ static int launch_cdftab_c(const DecDesc *d_descs, int count, int n_ch_max, int6
   return launch_err();
 }
 
-int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
-                  void *stream) {
+static int launch_cdftab_pass(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                              int pass, void *stream) {
   if (count <= 0 || n_ch_max <= 0 || hw_max <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (f16) return clamped ? launch_cdftab_c<true, _Float16>(d_descs, count, n_ch_max, hw_max, mode, s)
-                          : launch_cdftab_c<false, _Float16>(d_descs, count, n_ch_max, hw_max, mode, s);
-  return clamped ? launch_cdftab_c<true, float>(d_descs, count, n_ch_max, hw_max, mode, s)
-                 : launch_cdftab_c<false, float>(d_descs, count, n_ch_max, hw_max, mode, s);
+  if (f16) return clamped ? launch_cdftab_c<true, _Float16>(d_descs, count, n_ch_max, hw_max, mode, pass, s)
+                          : launch_cdftab_c<false, _Float16>(d_descs, count, n_ch_max, hw_max, mode, pass, s);
+  return clamped ? launch_cdftab_c<true, float>(d_descs, count, n_ch_max, hw_max, mode, pass, s)
+                 : launch_cdftab_c<false, float>(d_descs, count, n_ch_max, hw_max, mode, pass, s);
+}
+int launch_cdftab_count(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                        void *stream) {
+  return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 1, stream);
+}
+int launch_cdftab_fill(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                       void *stream) {
+  return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 2, stream);
+}
+int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                  void *stream) {
+  return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 3, stream);
+}
+
+int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y_hat, int M, int64_t hw, void *stream) {
+  if (M <= 0 || hw <= 0) return 0;
+  dim3 grid((unsigned)((hw + kBlock - 1) / kBlock), (unsigned)M);
+  if (wide) hipLaunchKernelGGL(yhat_scatter_kernel<int32_t>, grid, dim3(kBlock), 0, (hipStream_t)stream, (const int32_t *)sym, rank, y_hat, hw);
+  else hipLaunchKernelGGL(yhat_scatter_kernel<int16_t>, grid, dim3(kBlock), 0, (hipStream_t)stream, (const int16_t *)sym, rank, y_hat, hw);
+  return launch_err();
 }
 
 int launch_fastmath_selftest(int which, unsigned long long n, unsigned long long seed, unsigned long long *n_bad, void *stream) {

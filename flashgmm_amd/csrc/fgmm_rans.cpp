@@ -347,9 +347,21 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
   size_t scratch_cap = 0;
 
   const uint8_t *rowp = pool; // rows lie in latent order: the offset is a running sum, never stored
-  const uint8_t *landed = land ? pool + land->end[0] : reinterpret_cast<const uint8_t *>(UINTPTR_MAX);
+  int64_t landed = land ? (int64_t)land->end[0] : n; // latents whose header and row are on the host
   int piece = 1;
   for (int64_t i = 0; i < n; ++i) {
+    if (__builtin_expect(i >= landed, 0)) { // this latent is not on the host yet: wait for the piece(s) it lies in
+      while (i >= landed) {
+        int st = FGMM_ERR_INVALID; // a latent past the last piece
+        if (piece >= land->nseg || (st = land->wait(land->arg, piece)) != FGMM_OK) {
+          free(copy);
+          free(scratch);
+          return st;
+        }
+        landed = (int64_t)land->end[piece];
+        rowp = land->base[piece++];
+      }
+    }
     __builtin_prefetch(rowp + 512);
     __builtin_prefetch(rowp + 576);
     const uint32_t h = hdr[i];
@@ -358,17 +370,6 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
     const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono);
     const uint8_t *row_bytes = rowp;
     rowp += tab_row_bytes((uint32_t)cnt, nonmono);
-    if (__builtin_expect(rowp > landed, 0)) { // this row is not on the host yet: wait for the piece(s) it lies in
-      while (rowp > landed) {
-        int st = FGMM_ERR_INVALID; // a row past the last piece: header and pieces disagree
-        if (piece >= land->nseg || (st = land->wait(land->arg, piece)) != FGMM_OK) {
-          free(copy);
-          free(scratch);
-          return st;
-        }
-        landed = pool + land->end[piece++];
-      }
-    }
 
     const uint32_t cf = (uint32_t)(d.x & 0xFFFFu); // Rans64DecGet
     int32_t value;

@@ -73,10 +73,11 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
 
 /* Measurement aid (bench.py): when enabled, timing HIP events bracket each table kernel ON THE STREAM IT IS
  * LAUNCHED ON; fgmm_ctx_kernel_ms returns the duration of the most recent launch of
- * which = 0: symtab kernel (encode-side CDF), 1: cdftab kernel (decode-side tables), 2: quant_stats kernel. */
+ * which = 0: symtab kernel (encode-side CDF), 1: cdftab count + scan passes (decode-side table sizes), 2: quant_stats
+ * kernel, 3: cdftab fill passes (decode-side rows, stored over PCIe into pinned host memory: PCIe-bound by design). */
 int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable);
-/* Byte counts of the most recent batched call: which = 0 encode tables copied D2H, 1 decode headers + rows copied D2H,
- * 2 latents those decode tables describe. */
+/* Byte counts of the most recent batched call: which = 0 encode tables copied D2H, 1 decode headers + rows stored
+ * into host memory by the fill pass, 2 latents those decode tables describe. */
 int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out);
 int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out);
 

@@ -17,4 +17,4 @@ for it in range(6):
     t1 = time.perf_counter()
     outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(f"iter {it}: encode {1e3*(t1-t0):.2f} ms  decode {1e3*(t2-t1):.2f} ms   kernels: symtab {_lib.kernel_ms(0,0):.3f} cdftab {_lib.kernel_ms(0,1):.3f} qs {_lib.kernel_ms(0,2):.3f}  threads {_lib.lib().fgmm_ctx_threads(_lib.ctx(0))}")
+    print(f"iter {it}: encode {1e3*(t1-t0):.2f} ms  decode {1e3*(t2-t1):.2f} ms   kernels: symtab {_lib.kernel_ms(0,0):.3f} cdftab count {_lib.kernel_ms(0,1):.3f} fill {_lib.kernel_ms(0,3):.3f} qs {_lib.kernel_ms(0,2):.3f}  threads {_lib.lib().fgmm_ctx_threads(_lib.ctx(0))}")
