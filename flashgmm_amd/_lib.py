@@ -38,6 +38,24 @@ class fgmm_item(C.Structure):
                 ("bytes", C.c_void_p), ("bytes_len", C.c_size_t), ("status", C.c_int32)]
 
 
+def _item_dtype():
+    """numpy view of ``fgmm_item[]`` (offsets taken from the ctypes declaration): lets a batch be filled column by
+    column instead of field by field."""
+    import numpy as np
+    names, formats, offsets = [], [], []
+    kinds = {C.c_void_p: "<u8", C.c_int64: "<i8", C.c_int32: "<i4", C.c_size_t: "<u8"}
+    for name, typ in fgmm_item._fields_:
+        base = getattr(fgmm_item, name).offset
+        if typ is fgmm_params:
+            for pn, pt in fgmm_params._fields_:
+                names.append(pn); formats.append(kinds[pt]); offsets.append(base + getattr(fgmm_params, pn).offset)
+        else:
+            names.append(name); formats.append(kinds[typ]); offsets.append(base)
+    return np.dtype({"names": names, "formats": formats, "offsets": offsets, "itemsize": C.sizeof(fgmm_item)})
+
+
+ITEM_DTYPE = _item_dtype()
+
 # every symbol include/flashgmm_amd.h declares: (restype, argtypes)
 _p, _i, _i32, _i64, _sz = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_size_t
 _pp, _psz = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)

@@ -540,7 +540,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   {
     const int steady_cfg = getenv("FGMM_DEC_GROUP") ? atoi(getenv("FGMM_DEC_GROUP")) : 0;
     const int steady = steady_cfg > 0 ? steady_cfg : (count >= 16 ? std::max(2, count / 8) : count);
-    int i = 0, sz = count >= 16 ? std::min(2, steady) : count;
+    const int first_cfg = getenv("FGMM_DEC_FIRST") ? atoi(getenv("FGMM_DEC_FIRST")) : 2;
+    int i = 0, sz = count >= 16 ? std::min(std::max(first_cfg, 1), steady) : count;
     while (i < tail_begin) {
       gbeg.push_back(i);
       i = std::min(i + sz, tail_begin);

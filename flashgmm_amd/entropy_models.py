@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -109,12 +110,109 @@ class GaussianMixtureConditional(nn.Module):
             keep.append(yc)
         return it, M, hw, s.device
 
-    def compress_batch(self, ys: Sequence[Tensor], scales: Sequence[Tensor], means: Sequence[Tensor],
-                       weights: Sequence[Tensor]):
+    def _stacked_items(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor):
+        """``fgmm_item[N]`` (as a numpy record array) for N items given as ONE tensor each: y ``[N, M, h, w]``,
+        parameters ``[N, K*M, h, w]``.  One validation and one set of strides for the whole batch; the item
+        pointers are the batch-dimension offsets."""
+        if not scales.is_cuda:
+            raise RuntimeError(
+                "flashgmm_amd runs the GMM entropy-coding path on the GPU only: tensors must be on a HIP device "
+                "(there is deliberately no CPU fallback)")
+        if scales.dim() != 4 or means.shape != scales.shape or weights.shape != scales.shape:
+            raise RuntimeError("stacked entropy parameters must be three [N, K*M, h, w] tensors of one shape")
+        if not (scales.dtype == means.dtype == weights.dtype) or scales.dtype not in _PARAM_DTYPES:
+            raise RuntimeError("scales, means and weights must share one dtype, float32 or float16")
+        N, KM, h, w = scales.shape
+        hw = h * w
+        st = scales.stride()
+        if (hw > 1 and not (st[3] == 1 and st[2] == w)) or means.stride() != st or weights.stride() != st:
+            scales, means, weights = scales.contiguous(), means.contiguous(), weights.contiguous()
+            st = scales.stride()
+        M = KM // self.K
+        sc = st[1] if KM > 1 else hw
+        esz = scales.element_size()
+        items = np.zeros(N, _lib.ITEM_DTYPE)
+        step = np.arange(N, dtype=np.uint64) * np.uint64(st[0] * esz)
+        items["scales"] = np.uint64(scales.data_ptr()) + step
+        items["means"] = np.uint64(means.data_ptr()) + step
+        items["weights"] = np.uint64(weights.data_ptr()) + step
+        items["stride_k"], items["stride_c"] = M * sc, sc
+        items["dtype"] = _lib.FGMM_F16 if scales.dtype == torch.float16 else _lib.FGMM_F32
+        items["M"], items["K"], items["hw"] = M, self.K, hw
+        keep = [scales, means, weights]
+        if y is not None:
+            if y.dim() != 4 or tuple(y.shape) != (N, M, h, w):
+                raise RuntimeError(f"y must be [{N}, {M}, {h}, {w}] matching the parameters; got {tuple(y.shape)}")
+            if y.dtype != torch.float32 or y.device != scales.device:
+                raise RuntimeError("y must be float32 on the parameters' device")
+            y = y.contiguous()
+            items["y"] = np.uint64(y.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * hw * 4)
+            keep.append(y)
+        return items, keep, N, M, h, w, scales.device
+
+    def _compress_stacked(self, y: Tensor, scales: Tensor, means: Tensor, weights: Tensor):
+        items, keep, N, M, h, w, dev = self._stacked_items(y, scales, means, weights)
+        if N == 0:
+            return []
+        yq = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
+        zb = torch.empty((N, M), dtype=torch.int64)
+        items["yq_out"] = np.uint64(yq.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * h * w * 4)
+        items["zero_bitmap"] = np.uint64(zb.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * 8)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = _lib.lib().fgmm_gmc_compress_batch(_lib.ctx(dev.index if dev.index is not None else -1), stream,
+                                                C.cast(items.ctypes.data, C.POINTER(_lib.fgmm_item)), N, self._mode(),
+            int(self.clamp_scales))
+        _lib.check(rc, "GaussianMixtureConditional.compress")
+        ptrs, lens, amax = items["bytes"].tolist(), items["bytes_len"].tolist(), items["abs_max"].tolist()
+        string_at, free = C.string_at, _lib.lib().fgmm_free
+        out = []
+        for i, (q, b) in enumerate(zip(yq.unbind(0), zb.unbind(0))):
+            data = string_at(ptrs[i], lens[i])
+            free(ptrs[i])
+            out.append(((data, amax[i], b), q))
+        return out
+
+    def _decompress_stacked(self, strings: Sequence[bytes], abs_maxes: Sequence[int], zero_bitmaps, scales: Tensor,
+                            means: Tensor, weights: Tensor) -> List[Tensor]:
+        items, keep, N, M, h, w, dev = self._stacked_items(None, scales, means, weights)
+        if len(strings) != N or len(abs_maxes) != N or len(zero_bitmaps) != N:
+            raise RuntimeError(f"{N} items in the parameter tensors, {len(strings)} bitstreams")
+        if N == 0:
+            return []
+        if isinstance(zero_bitmaps, Tensor):
+            zb = zero_bitmaps
+        else:
+            zb = torch.stack([z.to("cpu", torch.int64) for z in zero_bitmaps])
+        if zb.device.type != "cpu" or zb.dtype != torch.int64 or not zb.is_contiguous():
+            zb = zb.to("cpu", torch.int64).contiguous()
+        if tuple(zb.shape) != (N, M):
+            raise RuntimeError(f"zero bitmaps have shape {tuple(zb.shape)}, expected ({N}, {M})")
+        data = [s_ if isinstance(s_, bytes) else bytes(s_) for s_ in strings]
+        bufs = (C.c_char_p * N)(*data)  # borrowed pointers into the bytes objects (kept alive by `data`)
+        y_hat = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
+        items["bytes"] = np.frombuffer(bufs, dtype=np.uint64)
+        items["bytes_len"] = [len(d) for d in data]
+        items["abs_max"] = np.asarray(abs_maxes, dtype=np.int64)
+        items["yq_out"] = np.uint64(y_hat.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * h * w * 4)
+        items["zero_bitmap"] = np.uint64(zb.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * 8)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = _lib.lib().fgmm_gmc_decompress_batch(_lib.ctx(dev.index if dev.index is not None else -1), stream,
+                                                  C.cast(items.ctypes.data, C.POINTER(_lib.fgmm_item)), N, self._mode(),
+            int(self.clamp_scales))
+        _lib.check(rc, "GaussianMixtureConditional.decompress")
+        return list(y_hat.unbind(0))
+
+    def compress_batch(self, ys, scales, means, weights):
         """N independent ``compress`` calls in one native call (kernels batched over items, one host rANS worker
-        per bitstream).  Returns a list of ``((bytes, abs_max, zero_bitmap_cpu), y_q)``."""
+        per bitstream).  Returns a list of ``((bytes, abs_max, zero_bitmap_cpu), y_q)``.
+
+        The items are given either as sequences of ``[1, M, h, w]`` / ``[1, K*M, h, w]`` tensors (any mix of shapes)
+        or, for items of one shape, stacked: ``y [N, M, h, w]``, parameters ``[N, K*M, h, w]`` — what a network
+        evaluated on a batch of images produces, and the cheaper form (one check, one allocation per output)."""
         if self.K != _lib.FGMM_K:
             raise RuntimeError(f"K = {self.K}: the coder is bound for K = 4 only (as the reference's)")
+        if isinstance(ys, Tensor):
+            return self._compress_stacked(ys, scales, means, weights)
         n_items = len(ys)
         items = (_lib.fgmm_item * n_items)()
         keep: list = []
@@ -148,10 +246,14 @@ class GaussianMixtureConditional(nn.Module):
         ((data, abs_max, zb), yq), = self.compress_batch([y], [scales], [means], [weights])
         return (data, abs_max, zb.to(y.device)), yq
 
-    def decompress_batch(self, strings: Sequence[bytes], abs_maxes: Sequence[int], zero_bitmaps: Sequence[Tensor],
-                         scales: Sequence[Tensor], means: Sequence[Tensor], weights: Sequence[Tensor]) -> List[Tensor]:
+    def decompress_batch(self, strings: Sequence[bytes], abs_maxes: Sequence[int], zero_bitmaps, scales, means,
+                         weights) -> List[Tensor]:
+        """N independent ``decompress`` calls in one native call; parameters as sequences of ``[1, K*M, h, w]``
+        tensors or stacked ``[N, K*M, h, w]`` (see ``compress_batch``).  Returns N ``[1, M, h, w]`` tensors."""
         if self.K != _lib.FGMM_K:
             raise RuntimeError(f"K = {self.K}: the coder is bound for K = 4 only (as the reference's)")
+        if isinstance(scales, Tensor):
+            return self._decompress_stacked(strings, abs_maxes, zero_bitmaps, scales, means, weights)
         n_items = len(strings)
         items = (_lib.fgmm_item * n_items)()
         keep: list = []

@@ -390,6 +390,35 @@ def test_batch_of_kodak_halves_full_size(mode):
         assert torch.equal(res[seed][1], torch.round(ys[seed]))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_stacked_batch_equals_item_lists(dtype):
+    """Items of one shape given as ONE tensor each ([N, M, h, w] / [N, K*M, h, w], batch-strided views included)
+    must give exactly what the list form gives: same bytes, side information and tensors."""
+    gmc = GaussianMixtureConditional(K=4, mode="as")
+    N = 7
+    lat = [T.make_latent(100 + i, M=24, h=8, w=12, zero_frac=0.2) for i in range(N)]
+    if dtype == "f16":
+        lat = [(y,) + tuple(T.to_float16_planes(sg, mu, pi)) for y, sg, mu, pi in lat]
+    y, sg, mu, pi = (torch.cat([dv(l[k]) for l in lat]) for k in range(4))
+    # parameters as chunk(3, 1) views of one [N, 3*K*M, h, w] head output: batch stride != K*M*h*w
+    head = torch.cat([sg, mu, pi], dim=1)
+    sg_v, mu_v, pi_v = head.chunk(3, 1)
+    a = gmc.compress_batch(y, sg_v, mu_v, pi_v)
+    b = gmc.compress_batch([y[i:i + 1] for i in range(N)], [sg[i:i + 1] for i in range(N)], [mu[i:i + 1] for i in range(N)],
+                           [pi[i:i + 1] for i in range(N)])
+    for (sa, qa), (sb, qb) in zip(a, b):
+        assert sa[0] == sb[0] and sa[1] == sb[1] and torch.equal(sa[2], sb[2]) and torch.equal(qa, qb)
+    outs = gmc.decompress_batch([r[0][0] for r in a], [r[0][1] for r in a], [r[0][2] for r in a], sg_v, mu_v, pi_v)
+    outs2 = gmc.decompress_batch([r[0][0] for r in a], [r[0][1] for r in a], torch.stack([r[0][2] for r in a]), sg, mu, pi)
+    for i in range(N):
+        assert outs[i].shape == (1, 24, 8, 12) and torch.equal(outs[i], a[i][1]) and torch.equal(outs2[i], a[i][1])
+        assert torch.equal(a[i][1], torch.round(y[i:i + 1]))
+    with pytest.raises(RuntimeError):
+        gmc.compress_batch(y, sg, mu[:-1], pi)
+    with pytest.raises(RuntimeError):
+        gmc.decompress_batch([r[0][0] for r in a][:-1], [r[0][1] for r in a], [r[0][2] for r in a], sg, mu, pi)
+
+
 @pytest.mark.parametrize("tail,pieces", [(0, 4), (8, 1), (3, 2), (6, 3), (8, 8), (5, 50)])
 def test_decode_tail_window_settings(monkeypatch, tail, pieces):
     """The last items of a decode batch land on the host in pieces and their decoders follow the pieces
