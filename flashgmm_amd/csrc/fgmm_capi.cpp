@@ -306,7 +306,8 @@ struct EncItem {
   size_t bytes_len = 0;
   int status = FGMM_OK;
   // workspace offsets
-  size_t o_min = 0, o_max = 0, o_nz = 0, o_list = 0, o_meta = 0, o_packed = 0;
+  size_t o_min = 0, o_max = 0, o_nz = 0, o_list = 0, o_meta = 0, o_packed = 0, meta_count = 0;
+  double t_sub = 0, t_start = 0, t_end = 0; // FGMM_TRACE=2: job timeline
 };
 
 int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items, int mode) {
@@ -324,7 +325,8 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     it.o_max = ar.take(sizeof(float) * it.M, 16);
     it.o_nz = ar.take(sizeof(int32_t) * it.M, 16);
     it.o_list = ar.take(sizeof(int32_t) * ((size_t)it.M + 1), 16);
-    it.o_meta = ar.take(16, 16);
+    it.meta_count = (size_t)it.M * (size_t)((it.hw + 255) / 256) * 4; // one slot per wave, sized for the 1-symbol-per-lane form
+    it.o_meta = ar.take(sizeof(uint32_t) * it.meta_count, 16);
     M_max = std::max(M_max, it.M);
     hw_max = std::max(hw_max, it.hw);
   }
@@ -358,7 +360,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     d.chan_nz = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_nz) : nullptr;
     d.chan_list = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_list) : nullptr;
     d.packed = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_packed);
-    d.meta = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_meta);
+    d.meta = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_meta);
     vec4 = vec4 && enc_vec4_ok(d, it.prm.dtype == FGMM_F16);
     any_y = any_y || it.y;
   }
@@ -373,7 +375,15 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   }
   if ((rc = ctx->prof_begin(0, stream))) return rc;
   static const int force_vec = getenv("FGMM_VEC") ? atoi(getenv("FGMM_VEC")) : 0; // dev: A/B the load width
-  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, mode, vec4 ? (force_vec ? force_vec : 4) : 1, items[0].clamp != 0,
+  const int vec = vec4 ? (force_vec ? force_vec : 4) : 1;
+  static const int no_linear = getenv("FGMM_NO_LINEAR") ? atoi(getenv("FGMM_NO_LINEAR")) : 0; // dev: A/B the two grid forms
+  int64_t n_max = 0;
+  bool linear = !no_linear;
+  for (auto &it : items) {
+    n_max = std::max(n_max, (int64_t)it.M * it.hw);
+    linear = linear && it.hw % (64 * vec) == 0;
+  }
+  LAUNCH_TRY(launch_symtab(dd, count, M_max, hw_max, n_max, linear, mode, vec, items[0].clamp != 0,
                            items[0].prm.dtype == FGMM_F16, stream));
   if ((rc = ctx->prof_end(0, stream))) return rc;
   // ---- tables back to the host: small region first, then one copy + event per item ----------------
@@ -403,7 +413,8 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   for (int i = 0; i < count; ++i) {
     EncItem &it = items[i];
     int64_t n = (int64_t)it.M * it.hw;
-    const unsigned long long n_bypass = *reinterpret_cast<unsigned long long *>(ctx->h_ws + it.o_meta);
+    unsigned long long n_bypass = 0;
+    for (size_t k = 0; k < it.meta_count; ++k) n_bypass += reinterpret_cast<const uint32_t *>(ctx->h_ws + it.o_meta)[k];
     const int32_t *syms_for_bypass = it.sym_host;
     if (it.y) {
       const float *mn = reinterpret_cast<const float *>(ctx->h_ws + it.o_min);
@@ -450,15 +461,22 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     HIP_TRY(hipEventSynchronize(ctx->events[group_of[i]]));
     const uint32_t *packed = reinterpret_cast<const uint32_t *>(ctx->h_ws + it.o_packed);
     EncItem *pit = &it;
-    auto job = [pit, packed, syms_for_bypass, n, n_bypass] {
+    pit->t_sub = tr.ms();
+    auto job = [pit, packed, syms_for_bypass, n, n_bypass, &tr] {
+      pit->t_start = tr.ms();
       if (pit->symbuf) pit->status = fgmm_symbuf_append_symtab(pit->symbuf, packed, syms_for_bypass, n);
       else pit->status = rans_encode_symtab(packed, syms_for_bypass, n, (int64_t)n_bypass, &pit->bytes, &pit->bytes_len);
+      pit->t_end = tr.ms();
     };
     if (count == 1) job(); else ctx->pool->submit(job);
   }
   tr.mark("all tables landed, jobs out");
   if (count > 1) ctx->pool->wait_all();
   tr.mark("host rANS done");
+  if (tr.on && getenv("FGMM_TRACE") && atoi(getenv("FGMM_TRACE")) > 1)
+    for (int i = 0; i < count; ++i)
+      fprintf(stderr, "[fgmm encode]   item %2d  submitted %7.3f  job %7.3f .. %7.3f  (%.3f ms)\n", i, items[i].t_sub,
+              items[i].t_start, items[i].t_end, items[i].t_end - items[i].t_start);
   for (auto &it : items)
     if (it.status) return fail(it.status, "host rANS encode failed (%d)", it.status);
   return FGMM_OK;
@@ -1180,7 +1198,8 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   int rc;
-  if ((rc = ctx->ensure_device(4096)) || (rc = ctx->ensure_host(4096))) return rc;
+  const size_t meta_bytes = sizeof(uint32_t) * (size_t)((n + 255) / 256) * 4; // per-wave bypass counts (unused here)
+  if ((rc = ctx->ensure_device(1024 + meta_bytes + 256)) || (rc = ctx->ensure_host(4096))) return rc;
   EncDesc *hd = reinterpret_cast<EncDesc *>(ctx->h_ws);
   memset(hd, 0, sizeof *hd);
   hd->sym = symbols;
@@ -1192,11 +1211,11 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
   hd->hw = n;
   hd->M = 1;
   hd->packed = packed;
-  hd->meta = reinterpret_cast<unsigned long long *>(ctx->d_ws + 1024);
+  hd->meta = reinterpret_cast<uint32_t *>(ctx->d_ws + 1024);
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
-  LAUNCH_TRY(launch_symtab(reinterpret_cast<const EncDesc *>(ctx->d_ws), 1, 1, n, mode, enc_vec4_ok(*hd, false) ? 4 : 1, false, false, s));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, meta_bytes, s));
+  LAUNCH_TRY(launch_symtab(reinterpret_cast<const EncDesc *>(ctx->d_ws), 1, 1, n, n, false, mode, enc_vec4_ok(*hd, false) ? 4 : 1, false, false, s));
   HIP_TRY(hipStreamSynchronize(s));
   return FGMM_OK;
 }

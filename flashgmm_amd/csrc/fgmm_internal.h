@@ -30,7 +30,8 @@ struct EncDesc {
   int32_t *chan_nz;      // [M]  any round(y) != 0
   int32_t *chan_list;    // [M+1] compact index -> channel; [M] = number of non-zero channels (null: identity)
   uint32_t *packed;      // [n_nz*hw] start | range<<16, channels compacted
-  unsigned long long *meta; // [0] = number of bypass symbols
+  uint32_t *meta;        // [4 * blocks] bypass symbols seen by each wave (zeroed by the host, summed by the host:
+                         // device-scope atomics on one counter serialise across the 8 XCDs, ~0.1 ms for a 6 M-symbol item)
 };
 
 struct DecDesc {
@@ -81,8 +82,10 @@ FGMM_HD static inline uint32_t tab_row_bytes(uint32_t cnt, uint32_t nonmono) {
 
 // ---- kernel launchers (fgmm_kernels.hip); stream is a hipStream_t; all return hipError_t as int ----------
 int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *stream);
-int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, int vec, bool clamped,
-                  bool f16, void *stream);
+// M_max, hw_max, n_max: the largest M, hw and M * hw of the batch.  linear: every hw is a multiple of 64 * vec, waves
+// take consecutive coded symbols across channels (all waves full); else one block per (tile, channel).
+int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int64_t n_max, bool linear, int mode, int vec,
+                  bool clamped, bool f16, void *stream);
 int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
                     int64_t stride_n, int64_t stride_k, int mode, float *c1, float *c2, void *stream);
 // count + scan (sizes and offsets), then fill (rows); launch_cdftab = both, back to back on one stream

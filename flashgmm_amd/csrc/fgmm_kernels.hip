@@ -179,21 +179,37 @@ __device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu
 #ifndef FGMM_SYMTAB_WAVES
 #define FGMM_SYMTAB_WAVES 5 // min waves per SIMD the register allocator must leave room for (<= 96 VGPRs)
 #endif
-template <int MODE, int VEC, bool CLAMPED, typename PT>
+template <int MODE, int VEC, bool CLAMPED, typename PT, bool LINEAR>
 __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const EncDesc *__restrict__ descs) {
   const EncDesc &d = descs[blockIdx.z];
-  const int rank = blockIdx.y;
-  if (rank >= d.M) return;
   const int64_t hw = d.hw;
-  const int64_t p0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
-  if ((int64_t)blockIdx.x * kBlock * VEC >= hw) return;
-  int c = rank;
-  if (d.chan_list) { // wave-uniform scalar loads
-    if (rank >= d.chan_list[d.M]) return;
-    c = d.chan_list[rank];
+  const int n_nz = d.chan_list ? d.chan_list[d.M] : d.M; // wave-uniform scalar load
+  int rank;     // compact (coded) channel of this wave: wave-uniform in both forms, so all addressing stays scalar
+  int64_t p0;   // position of the lane's first symbol within the channel
+  int64_t slot; // where this wave leaves its bypass count
+  bool active;  // lanes past the end stay for the wave reduction below
+  if constexpr (LINEAR) {
+    // Every hw of the batch is a multiple of 64 * VEC (checked by the host): the coded symbols of an item are one
+    // linear range [0, n_nz * hw) and each WAVE takes 64 * VEC consecutive ones, never straddling a channel.  All
+    // waves are full whatever hw is (a 768-symbol Kodak plane fills only 3 of the 4 waves of a per-channel block).
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t w0 = ((int64_t)blockIdx.x * kBlock + wave * 64) * VEC;
+    if (w0 >= (int64_t)n_nz * hw) return;
+    rank = __builtin_amdgcn_readfirstlane((int)(w0 / hw));
+    p0 = (w0 - (int64_t)rank * hw) + (int64_t)(threadIdx.x & 63) * VEC;
+    slot = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    active = true;
+  } else {
+    // one block per (tile of kBlock * VEC positions, compact channel)
+    rank = blockIdx.y;
+    if (rank >= n_nz) return;
+    if ((int64_t)blockIdx.x * kBlock * VEC >= hw) return;
+    p0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+    const int64_t tiles = (hw + (int64_t)kBlock * VEC - 1) / ((int64_t)kBlock * VEC);
+    slot = ((int64_t)rank * tiles + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    active = p0 < hw;
   }
-  const bool active = p0 < hw; // lanes past the end stay for the wave reduction below
-
+  const int c = d.chan_list ? d.chan_list[rank] : rank;
   int nbypass = 0;
   if (!active) {
   } else if constexpr (VEC == 4) {
@@ -260,10 +276,11 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
     d.packed[(int64_t)rank * hw + p0] = sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp);
     nbypass = bp;
   }
-  // bypass census: one atomic per wave that saw any (the host sizes its output buffer from it)
+  // bypass census (the host sizes its output buffer from it): one plain store per wave that saw any, no atomics
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nbypass += __shfl_xor(nbypass, o, 64);
-  if ((threadIdx.x & 63) == 0 && nbypass) atomicAdd(d.meta, (unsigned long long)nbypass);
+  if ((threadIdx.x & 63) == 0 && nbypass)
+    d.meta[slot] = (uint32_t)nbypass;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -647,31 +664,37 @@ int launch_quant_stats(const EncDesc *d_descs, int count, int M_max, void *strea
   return launch_err();
 }
 
-template <int VEC, bool CLAMPED, typename PT>
-static int launch_symtab_v(const EncDesc *d, int count, int M_max, int64_t hw_max, int mode, hipStream_t s) {
+template <int VEC, bool CLAMPED, typename PT, bool LINEAR>
+static int launch_symtab_v(const EncDesc *d, int count, int M_max, int64_t hw_max, int64_t n_max, int mode, hipStream_t s) {
   const int64_t per_block = (int64_t)kBlock * VEC;
-  dim3 grid((unsigned)((hw_max + per_block - 1) / per_block), (unsigned)M_max, (unsigned)count);
+  const dim3 grid = LINEAR ? dim3((unsigned)((n_max + per_block - 1) / per_block), 1u, (unsigned)count)
+                           : dim3((unsigned)((hw_max + per_block - 1) / per_block), (unsigned)M_max, (unsigned)count);
   switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((symtab_kernel<MODE_AS, VEC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((symtab_kernel<MODE_LOGISTIC, VEC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d); break;
-  default: hipLaunchKernelGGL((symtab_kernel<MODE_POLYA, VEC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d); break;
+  case MODE_AS: hipLaunchKernelGGL((symtab_kernel<MODE_AS, VEC, CLAMPED, PT, LINEAR>), grid, dim3(kBlock), 0, s, d); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((symtab_kernel<MODE_LOGISTIC, VEC, CLAMPED, PT, LINEAR>), grid, dim3(kBlock), 0, s, d); break;
+  default: hipLaunchKernelGGL((symtab_kernel<MODE_POLYA, VEC, CLAMPED, PT, LINEAR>), grid, dim3(kBlock), 0, s, d); break;
   }
   return launch_err();
 }
-template <typename PT>
-static int launch_symtab_t(const EncDesc *d, int count, int M_max, int64_t hw_max, int mode, int vec, bool clamped, hipStream_t s) {
-  if (vec == 4) return clamped ? launch_symtab_v<4, true, PT>(d, count, M_max, hw_max, mode, s)
-                               : launch_symtab_v<4, false, PT>(d, count, M_max, hw_max, mode, s);
-  return clamped ? launch_symtab_v<1, true, PT>(d, count, M_max, hw_max, mode, s)
-                 : launch_symtab_v<1, false, PT>(d, count, M_max, hw_max, mode, s);
+template <typename PT, bool LINEAR>
+static int launch_symtab_t(const EncDesc *d, int count, int M_max, int64_t hw_max, int64_t n_max, int mode, int vec, bool clamped,
+                           hipStream_t s) {
+  if (vec == 4) return clamped ? launch_symtab_v<4, true, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s)
+                               : launch_symtab_v<4, false, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s);
+  return clamped ? launch_symtab_v<1, true, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s)
+                 : launch_symtab_v<1, false, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s);
 }
 
-int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int mode, int vec, bool clamped,
-                  bool f16, void *stream) {
+int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, int64_t n_max, bool linear, int mode, int vec,
+                  bool clamped, bool f16, void *stream) {
   if (count <= 0 || M_max <= 0 || hw_max <= 0) return 0;
+  if (linear && (n_max + kBlock - 1) / kBlock > 0x7FFFFFFFll) linear = false; // grid.x
   hipStream_t s = (hipStream_t)stream;
-  return f16 ? launch_symtab_t<_Float16>(d_descs, count, M_max, hw_max, mode, vec, clamped, s)
-             : launch_symtab_t<float>(d_descs, count, M_max, hw_max, mode, vec, clamped, s);
+  if (linear)
+    return f16 ? launch_symtab_t<_Float16, true>(d_descs, count, M_max, hw_max, n_max, mode, vec, clamped, s)
+               : launch_symtab_t<float, true>(d_descs, count, M_max, hw_max, n_max, mode, vec, clamped, s);
+  return f16 ? launch_symtab_t<_Float16, false>(d_descs, count, M_max, hw_max, n_max, mode, vec, clamped, s)
+             : launch_symtab_t<float, false>(d_descs, count, M_max, hw_max, n_max, mode, vec, clamped, s);
 }
 
 int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
