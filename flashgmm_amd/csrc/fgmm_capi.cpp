@@ -1266,7 +1266,7 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
 }
 
 int fgmm_selftest_fastmath(fgmm_ctx *ctx, int which, uint64_t n, uint64_t seed, uint64_t *n_bad_out) {
-  if (!ctx || which < 0 || which > 2 || !n_bad_out) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (!ctx || which < 0 || which > 5 || !n_bad_out) return fail(FGMM_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   int rc;

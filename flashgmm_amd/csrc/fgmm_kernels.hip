@@ -598,12 +598,24 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void saturation_selftes
 //              would return +0 where IEEE returns -0), s over [0.11, 256]
 //              with the end points, powers of two and all-ones mantissas over-represented
 //   which = 2: rcp_ge1(d) == 1 / d for EVERY binary32 d in [1, +inf] and NaN                   (exhaustive)
+//   which = 3, 4, 5: Phi<MODE, true>(z) == Phi<MODE, false>(z) (MODE = which - 3) for EVERY binary32 z with
+//              |z| < 2^48, both signs, zeros and denormals included — the domain the kernels' guard admits (exhaustive)
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t hash32(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
   return (uint32_t)x;
 }
 __device__ __forceinline__ bool same_f32(float a, float b) { return f2bits(a) == f2bits(b) || (a != a && b != b); }
+template <int MODE> __device__ __forceinline__ unsigned long long phi_fast_vs_plain(uint64_t t0, uint64_t stride) {
+  const uint32_t top = f2bits(0x1p48f); // magnitudes [0, 2^48)
+  unsigned long long bad = 0;
+  for (uint64_t i = t0; i < 2ull * top; i += stride) {
+    const float z = bits2f(i < top ? (uint32_t)i : (0x80000000u | (uint32_t)(i - top)));
+    bad += !same_f32(Phi<MODE, true>::eval(z), Phi<MODE, false>::eval(z));
+  }
+  return bad;
+}
+
 
 __global__ __launch_bounds__(kBlock) void fastmath_selftest_kernel(int which, unsigned long long n, unsigned long long seed,
                                                                    unsigned long long *n_bad) {
@@ -617,6 +629,12 @@ __global__ __launch_bounds__(kBlock) void fastmath_selftest_kernel(int which, un
       const float x = k <= top ? bits2f((uint32_t)k) : (k == (uint64_t)top + 1 ? -1.0f : (k == (uint64_t)top + 2 ? 0.0f : bits2f(0x7FC00000u)));
       bad += !same_f32(sqrt_core(x), __builtin_sqrtf(x));
     }
+  } else if (which == 3) {
+    bad = phi_fast_vs_plain<MODE_POLYA>(t0, stride);
+  } else if (which == 4) {
+    bad = phi_fast_vs_plain<MODE_AS>(t0, stride);
+  } else if (which == 5) {
+    bad = phi_fast_vs_plain<MODE_LOGISTIC>(t0, stride);
   } else if (which == 2) {
     const uint32_t lo = f2bits(1.0f), hi = 0x7F800000u;
     for (uint64_t i = t0; i <= (uint64_t)(hi - lo) + 1; i += stride) {

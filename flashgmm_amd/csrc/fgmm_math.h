@@ -42,6 +42,29 @@ __device__ __forceinline__ float exp_ref(float x) {
   return y * bits2f((uint32_t)(n + 127) << 23);
 }
 
+// exp_ref for an argument known to be <= 0 (or -0) and not NaN — what Polya's and A&S's exp always get when z is
+// finite.  Same value with two operations fewer: the upper clamp cannot act, and y * 2^n (n in [-127, 0]) is
+// v_ldexp_f32 except at n = -127, where the reference's bit pattern is +0 and ldexp gives a denormal < 2^-126:
+// both callers only use e in 1 - e resp. fma(-c*e, poly, 1) with |c*poly| < 1, which is 1.0f either way.
+// Phi<MODE, true> == Phi<MODE, false> is checked for EVERY binary32 |z| < 2^48 by fgmm_selftest_fastmath(3..5).
+__device__ __forceinline__ float exp_nonpos(float x) {
+  x = (x > -88.3762626647949f) ? x : -88.3762626647949f;
+  float fx = __builtin_fmaf(x, 1.44269504088896341f, 0.5f);
+  fx = __builtin_floorf(fx);
+  x = __builtin_fmaf(-fx, 0.693359375f, x);
+  x = __builtin_fmaf(-fx, -2.12194440e-4f, x);
+  const float z = x * x;
+  float y = 1.9875691500E-4f;
+  y = __builtin_fmaf(y, x, 1.3981999507E-3f);
+  y = __builtin_fmaf(y, x, 8.3334519073E-3f);
+  y = __builtin_fmaf(y, x, 4.1665795894E-2f);
+  y = __builtin_fmaf(y, x, 1.6666665459E-1f);
+  y = __builtin_fmaf(y, x, 5.0000001201E-1f);
+  y = __builtin_fmaf(y, z, x);
+  y = y + 1.0f;
+  return __builtin_ldexpf(y, (int)fx);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Correctly-rounded division and square root, hand-expanded.
 //
@@ -94,18 +117,20 @@ __device__ __forceinline__ float sqrt_core(float x) {
   return s;
 }
 
-// FAST = false: plain IEEE '/' and sqrtf, any input.  FAST = true: the cores above (identical results).
+// FAST = false: plain IEEE '/' and sqrtf, any input.  FAST = true: the cores above, for finite |z| < 2^48 (the
+// callers' guard): identical results, checked exhaustively over that domain (fgmm_selftest_fastmath 3..5).
 template <int MODE, bool FAST> struct Phi;
 
 // Polya/Watterson, rans_interface.cpp:135-146
 template <bool FAST> struct Phi<MODE_POLYA, FAST> {
   static __device__ __forceinline__ float eval(float z) {
     const float c = -2.0f / 3.14159265358979323846f; // folded in binary32, as the reference's constant is
-    const float e = exp_ref(c * (z * z));
+    const float e = FAST ? exp_nonpos(c * (z * z)) : exp_ref(c * (z * z));
     // 1 - e is +0, >= 2^-24, or (NaN path: e = exp(+88.4)) hugely negative -> NaN: always in sqrt_core's domain
     float s = FAST ? sqrt_core(1.0f - e) : __builtin_sqrtf(1.0f - e);
     s = bits2f((f2bits(z) & 0x80000000u) | (f2bits(s) & 0x7fffffffu)); // copysign_ps(z, s)
-    return 0.5f * (1.0f + s);
+    // 0.5 * (1 + s): the product is an exact scaling (1 + s is 0 or >= 2^-24), so one fma rounds the same way
+    return FAST ? __builtin_fmaf(0.5f, s, 0.5f) : 0.5f * (1.0f + s);
   }
 };
 
@@ -113,7 +138,7 @@ template <bool FAST> struct Phi<MODE_POLYA, FAST> {
 template <bool FAST> struct Phi<MODE_AS, FAST> {
   static __device__ __forceinline__ float eval(float z) {
     const float az = bits2f(f2bits(z) & 0x7fffffffu);
-    const float zx = 0.3989422804014327f * exp_ref((z * z) * -0.5f);
+    const float zx = 0.3989422804014327f * (FAST ? exp_nonpos((z * z) * -0.5f) : exp_ref((z * z) * -0.5f));
     const float d = __builtin_fmaf(0.2316419f, az, 1.0f);
     // FAST callers guarantee |z| < 2^48 (|x - mu| < 2^40, sigma >= 0.11), hence d < 2^60
     const float t = FAST ? rcp_ge1_tame(d) : 1.0f / d;
@@ -149,17 +174,18 @@ __device__ __forceinline__ float mix4(float x, const float (&mu)[4], const float
 }
 
 // Same value, for CLAMPED sigma (entropy-model path), with the refined reciprocals rs[k] = rcp_refined(sg[k])
-// computed once per latent and reused for every abscissa.  Branch-free: `ok` comes back false when some
-// |x - mu_k| is not < 2^40 (huge / inf / NaN mean) — the caller then discards the value and takes mix4_slow.
+// computed once per latent and reused for every abscissa.  Branch-free: `ok` comes back false when some z_k is
+// not finite with |z_k| < 2^48 (huge / inf / NaN mean, NaN sigma: then |x - mu_k| < 2^56 is not established and
+// the cores' domains do not hold) — the caller then discards the value and takes mix4_slow.
 template <int MODE>
 __device__ __forceinline__ float mix4_clamped(float x, const float (&mu)[4], const float (&sg)[4], const float (&rs)[4],
                                               const float (&pi)[4], bool &ok) {
   float p[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float a = x - mu[k];
-    ok = ok && (__builtin_fabsf(a) < 0x1p40f);
-    p[k] = pi[k] * Phi<MODE, true>::eval(div_core(a, sg[k], rs[k]));
+    const float z = div_core(x - mu[k], sg[k], rs[k]); // exact when |x - mu| < 2^60; else huge, inf or NaN
+    ok = ok && (__builtin_fabsf(z) < 0x1p48f);
+    p[k] = pi[k] * Phi<MODE, true>::eval(z);
   }
   return (p[0] + p[1]) + (p[2] + p[3]);
 }
