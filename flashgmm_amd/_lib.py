@@ -97,6 +97,8 @@ SIGNATURES = {
     "fgmm_decstream_destroy": (None, [_p]),
     "fgmm_decstream_decode": (_i, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p]),
     "fgmm_pmf_to_quantized_cdf": (_i, [_p, _i, _i, _p]),
+    "fgmm_ckbd_unembed": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i]),
+    "fgmm_ckbd_embed": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i]),
 }
 
 _lib = None

@@ -1265,6 +1265,30 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   return FGMM_OK;
 }
 
+static int ckbd(fgmm_ctx *ctx, void *stream, const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes,
+                int anchor_odd, bool embed) {
+  if (!ctx || planes < 0 || h < 0 || w < 0 || (w & 1) || (elem_bytes != 2 && elem_bytes != 4) || (anchor_odd & ~1))
+    return fail(FGMM_ERR_INVALID, "checkerboard split/merge: bad argument (w must be even, elem_bytes 2 or 4)");
+  if (planes == 0 || h == 0 || w == 0) return FGMM_OK;
+  if (!src || !dst) return fail(FGMM_ERR_INVALID, "checkerboard split/merge: null tensor");
+  // the full tensor is accessed pair-wise (2 * elem_bytes), the halves element-wise
+  const void *full = embed ? dst : src, *halves = embed ? src : dst;
+  if (reinterpret_cast<uintptr_t>(full) % (2 * (size_t)elem_bytes) || reinterpret_cast<uintptr_t>(halves) % (size_t)elem_bytes)
+    return fail(FGMM_ERR_INVALID, "checkerboard split/merge: misaligned tensor");
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "cannot select HIP device %d", ctx->device);
+  LAUNCH_TRY(launch_ckbd(src, dst, planes, h, w, elem_bytes, anchor_odd, embed, stream));
+  return FGMM_OK;
+}
+int fgmm_ckbd_unembed(fgmm_ctx *ctx, void *stream, const void *src, void *dst, int64_t planes, int64_t h, int64_t w,
+                      int elem_bytes, int anchor_odd) {
+  return ckbd(ctx, stream, src, dst, planes, h, w, elem_bytes, anchor_odd, false);
+}
+int fgmm_ckbd_embed(fgmm_ctx *ctx, void *stream, const void *src, void *dst, int64_t planes, int64_t h, int64_t w,
+                    int elem_bytes, int anchor_odd) {
+  return ckbd(ctx, stream, src, dst, planes, h, w, elem_bytes, anchor_odd, true);
+}
+
 int fgmm_selftest_fastmath(fgmm_ctx *ctx, int which, uint64_t n, uint64_t seed, uint64_t *n_bad_out) {
   if (!ctx || which < 0 || which > 5 || !n_bad_out) return fail(FGMM_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lock(ctx->mu);

@@ -98,6 +98,9 @@ int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_ma
 // y_hat[c, p] = rank[c] < 0 ? 0 : (float)sym[rank[c] * hw + p]; sym is int16 (wide = 0) or int32 and may live in pinned
 // host memory (read over PCIe)   (entropy_models.py:903-908)
 int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y_hat, int M, int64_t hw, void *stream);
+// checkerboard split (embed = false: [planes,h,w] -> [2,planes,h,w/2]) / merge (embed = true); w even, elem_bytes 2 or 4
+int launch_ckbd(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes, int anchor_odd, bool embed,
+                void *stream);
 int launch_fastmath_selftest(int which, unsigned long long n, unsigned long long seed, unsigned long long *n_bad, void *stream);
 // exhaustive check of the saturation lemmas behind the pruning; *n_bad (device) receives the number of violations
 int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fgmm_internal.h"
+#include <algorithm>
 #include "fgmm_math.h"
 
 namespace fgmm {
@@ -565,6 +566,37 @@ __global__ __launch_bounds__(kBlock) void yhat_scatter_kernel(const ST *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Checkerboard split / merge (latent_codecs/checkerboard.py:333-377), pure data movement, HBM bound:
+//   unembed: full [planes, h, w] -> halves [2, planes, h, w/2]   (half 0 = anchors, half 1 = non-anchors)
+//   embed  : the inverse
+// Lane = one horizontal pair (columns 2j, 2j+1): the pair is one 2*sizeof(T) access of the full tensor, its two
+// elements one coalesced access each of the two halves.  In row i the anchor is column 2j + ((i & 1) ^ anchor_odd).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool EMBED>
+__global__ __launch_bounds__(kBlock) void ckbd_kernel(const T *__restrict__ src, T *__restrict__ dst, int64_t rows, int64_t h,
+                                                     int64_t w2, int anchor_odd) {
+  struct alignas(2 * sizeof(T)) Pair { T a, b; };
+  const int64_t half = rows * w2; // elements of one half
+  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+    const int b = (int)((row % h) & 1) ^ anchor_odd;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < w2; j += (int64_t)gridDim.x * kBlock) {
+      const int64_t e = row * w2 + j;
+      if constexpr (EMBED) {
+        const T anchor = src[e], other = src[half + e];
+        Pair p;
+        p.a = b ? other : anchor;
+        p.b = b ? anchor : other;
+        reinterpret_cast<Pair *>(dst)[e] = p;
+      } else {
+        const Pair p = reinterpret_cast<const Pair *>(src)[e];
+        dst[e] = b ? p.b : p.a;
+        dst[half + e] = b ? p.a : p.b;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // saturation_selftest_kernel: exhaustive proof-by-enumeration of the lemmas in fgmm_math.h (Sat<MODE>):
 // every binary32 z >= ZR (up to and including +inf) must give phi(z) == 1, every z <= -ZL must give
 // 0 <= phi(z) <= LEFT_MAX.  ~2.1e9 evaluations per mode; a few milliseconds.
@@ -773,6 +805,22 @@ int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y
   dim3 grid((unsigned)((hw + kBlock - 1) / kBlock), (unsigned)M);
   if (wide) hipLaunchKernelGGL(yhat_scatter_kernel<int32_t>, grid, dim3(kBlock), 0, (hipStream_t)stream, (const int32_t *)sym, rank, y_hat, hw);
   else hipLaunchKernelGGL(yhat_scatter_kernel<int16_t>, grid, dim3(kBlock), 0, (hipStream_t)stream, (const int16_t *)sym, rank, y_hat, hw);
+  return launch_err();
+}
+
+int launch_ckbd(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes, int anchor_odd, bool embed,
+                void *stream) {
+  const int64_t rows = planes * h, w2 = w / 2;
+  if (rows <= 0 || w2 <= 0) return 0;
+  dim3 grid((unsigned)std::min<int64_t>((w2 + kBlock - 1) / kBlock, 64), (unsigned)std::min<int64_t>(rows, 65535));
+  hipStream_t s = (hipStream_t)stream;
+  if (elem_bytes == 4) {
+    if (embed) hipLaunchKernelGGL((ckbd_kernel<uint32_t, true>), grid, dim3(kBlock), 0, s, (const uint32_t *)src, (uint32_t *)dst, rows, h, w2, anchor_odd);
+    else hipLaunchKernelGGL((ckbd_kernel<uint32_t, false>), grid, dim3(kBlock), 0, s, (const uint32_t *)src, (uint32_t *)dst, rows, h, w2, anchor_odd);
+  } else {
+    if (embed) hipLaunchKernelGGL((ckbd_kernel<uint16_t, true>), grid, dim3(kBlock), 0, s, (const uint16_t *)src, (uint16_t *)dst, rows, h, w2, anchor_odd);
+    else hipLaunchKernelGGL((ckbd_kernel<uint16_t, false>), grid, dim3(kBlock), 0, s, (const uint16_t *)src, (uint16_t *)dst, rows, h, w2, anchor_odd);
+  }
   return launch_err();
 }
 

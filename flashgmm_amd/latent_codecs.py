@@ -10,6 +10,15 @@ mixture logits, the logits are soft-maxed over K on the ``[1, K, M, h, w]`` view
 on the GPU — and handed to the entropy model in place.  Both quantizers of the reference are kept ("noise": code round(y);
 "weighted_mean_ste": code round(y - sum_k pi_k mu_k) against re-centred means, :135-145, :167-179).
 ``forward`` (training-time likelihoods, :99-125) is outside the entropy-coding path and not provided.
+
+``CheckerboardLatentCodec`` and ``ChannelGroupsLatentCodec`` mirror the two codecs that drive the path in the
+reference's GMM models (compressai/latent_codecs/checkerboard.py:275-330, channel_groups.py:111-158;
+models/ckbd_gmm.py:111, models/elic_gmm.py:198-219): same constructor arguments, same ``compress / decompress``
+contract and nested ``{"strings": [...], "shape": ...}`` result, the networks (``context_prediction``,
+``entropy_parameters``, ``channel_context``) supplied by the caller as torch modules.  What changes is the schedule:
+the checkerboard split / merge is one HIP kernel each, and on encode both halves are coded in ONE batched call —
+the anchors' reconstruction that the non-anchor parameters depend on is ``round(.)`` of data the encoder already
+holds (checkerboard.py:282-288), so nothing has to wait for the anchors' bitstream.
 """
 from __future__ import annotations
 
@@ -19,9 +28,12 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from .entropy_models import GaussianMixtureConditional
+from itertools import accumulate
 
-__all__ = ["GaussianMixtureConditionalLatentCodec"]
+from .entropy_models import GaussianMixtureConditional
+from .ops import ckbd_embed, ckbd_unembed
+
+__all__ = ["GaussianMixtureConditionalLatentCodec", "CheckerboardLatentCodec", "ChannelGroupsLatentCodec"]
 
 
 class GaussianMixtureConditionalLatentCodec(nn.Module):
@@ -63,15 +75,29 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
         weighted_sum = torch.sum(me * we, dim=1)
         return weighted_sum, (me - weighted_sum.unsqueeze(1)).reshape(B, KM, H, W)
 
-    def compress(self, y: Tensor, ctx_params: Tensor) -> Dict[str, Any]:
+    def coder_inputs(self, y: Tensor, ctx_params: Tensor):
+        """What ``compress`` hands the entropy model: ``(y_to_code, scales, means, weights)``.  ``round(y_to_code)`` is
+        the ``y_hat`` that ``compress`` returns (:127-149) — known before any coding happens."""
         scales_hat, means_hat, weights = self._params(ctx_params)
         if self.quantizer == "noise":
-            y_strings, y_hat = self.gaussian_mixture_conditional.compress(y, scales_hat, means_hat, weights)
-        else:
-            weighted_sum, means_rel = self._recentre(means_hat, weights)
-            y_strings, y_hat = self.gaussian_mixture_conditional.compress(torch.round(y - weighted_sum), scales_hat,
-                                                                          means_rel, weights)
+            return y, scales_hat, means_hat, weights
+        weighted_sum, means_rel = self._recentre(means_hat, weights)
+        d = y - weighted_sum
+        # quantize_ste (compressai/ops/ops.py:66-80) is (round(d) - d) + d: the value of round(d), but +0.0 where
+        # round(d) is -0.0 — kept, so that the returned y_hat has the reference's bits
+        return (torch.round(d) - d) + d, scales_hat, means_rel, weights
+
+    def compress(self, y: Tensor, ctx_params: Tensor) -> Dict[str, Any]:
+        y_code, scales_hat, means_hat, weights = self.coder_inputs(y, ctx_params)
+        y_strings, y_hat = self.gaussian_mixture_conditional.compress(y_code, scales_hat, means_hat, weights)
         return {"strings": [y_strings], "shape": y.shape[2:4], "y_hat": y_hat}
+
+    def compress_many(self, prepared: List[Tuple[Tensor, Tensor, Tensor, Tensor]]) -> List[Dict[str, Any]]:
+        """``compress`` of several ``coder_inputs`` results in one batched native call."""
+        ys, ss, ms, ws = zip(*prepared)
+        res = self.gaussian_mixture_conditional.compress_batch(list(ys), list(ss), list(ms), list(ws))
+        return [{"strings": [(b, a, zb.to(y.device))], "shape": y.shape[2:4], "y_hat": yq}
+                for ((b, a, zb), yq), y in zip(res, ys)]
 
     def decompress(self, strings: List[Any], shape: Tuple[int, int], ctx_params: Tensor, **kwargs: Any) -> Dict[str, Any]:
         (y_strings,) = strings
@@ -87,3 +113,134 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
     def forward(self, y: Tensor, ctx_params: Tensor):
         raise NotImplementedError("training-time likelihoods are outside the entropy-coding path; use the reference's "
                                   "GaussianMixtureConditionalLatentCodec.forward (pure torch)")
+
+
+class CheckerboardLatentCodec(nn.Module):
+    """Two-pass checkerboard context model, ``compress`` / ``decompress`` only (checkerboard.py:275-330).
+
+    ``latent_codec["y"]`` is a ``GaussianMixtureConditionalLatentCodec`` (its own ``entropy_parameters`` is the
+    identity: the parameter network sits here, as in the reference's models); ``entropy_parameters`` must be
+    pointwise (the reference's warning, checkerboard.py:80-82); batch size 1 (checkerboard.py:307)."""
+
+    def __init__(self, latent_codec: Optional[Dict[str, nn.Module]] = None, entropy_parameters: Optional[nn.Module] = None,
+                 context_prediction: Optional[nn.Module] = None, anchor_parity: str = "even", forward_method: str = "twopass",
+                 **kwargs: Any):
+        super().__init__()
+        if anchor_parity not in ("even", "odd"):
+            raise ValueError(f"anchor_parity {anchor_parity!r}")
+        self.anchor_parity = anchor_parity
+        self.non_anchor_parity = {"odd": "even", "even": "odd"}[anchor_parity]
+        self.forward_method = forward_method
+        self.entropy_parameters = entropy_parameters or nn.Identity()
+        self.context_prediction = context_prediction or nn.Identity()
+        self.latent_codec = nn.ModuleDict(latent_codec if latent_codec is not None
+                                          else {"y": GaussianMixtureConditionalLatentCodec()})
+
+    def __getitem__(self, key: str) -> nn.Module:
+        return self.latent_codec[key]
+
+    # checkerboard.py:333-377, one kernel each
+    def unembed(self, y: Tensor) -> Tensor:
+        return ckbd_unembed(y, self.anchor_parity)
+
+    def embed(self, y_: Tensor) -> Tensor:
+        return ckbd_embed(y_, self.anchor_parity)
+
+    def merge(self, *args: Tensor) -> Tensor:
+        return torch.cat(args, dim=1)
+
+    def _ctx(self, y_hat_: Tensor, i: int) -> Tensor:
+        """context of half i from the halves reconstructed so far (:281-284, :310-313)"""
+        y_ctx_i = self.unembed(self.context_prediction(self.embed(y_hat_)))[i]
+        return torch.zeros_like(y_ctx_i) if i == 0 else y_ctx_i  # _mask(., "all") for the anchors
+
+    def compress(self, y: Tensor, side_params: Tensor) -> Dict[str, Any]:
+        n, c, h, w = y.shape
+        if n != 1:
+            raise RuntimeError("batch size 1 (as the reference's coder path, checkerboard.py:307)")
+        codec = self.latent_codec["y"]
+        y_hat_ = side_params.new_zeros((2, n, c, h, w // 2))
+        side_params_ = self.unembed(side_params)
+        y_ = self.unembed(y)
+        prepared = []
+        for i in range(2):
+            params_i = self.entropy_parameters(self.merge(self._ctx(y_hat_, i), side_params_[i]))
+            prepared.append(codec.coder_inputs(y_[i], params_i))
+            if i == 0:  # what compress() of the anchors will return as y_hat: no need to wait for their bitstream
+                y_hat_[0] = torch.round(prepared[0][0])
+        outs = codec.compress_many(prepared)
+        y_hat_[1] = outs[1]["y_hat"]
+        y_strings_ = [o["strings"][0] for o in outs]
+        y_hat = self.embed(y_hat_)
+        return {"strings": y_strings_, "shape": y_hat.shape[1:], "y_hat": y_hat}
+
+    def decompress(self, strings: List[Any], shape: Tuple[int, ...], side_params: Tensor, **kwargs: Any) -> Dict[str, Any]:
+        n = 1
+        c, h, w = shape
+        codec = self.latent_codec["y"]
+        y_hat_ = side_params.new_zeros((2, n, c, h, w // 2))
+        side_params_ = self.unembed(side_params)
+        for i in range(2):  # sequential by construction: the non-anchor parameters need the decoded anchors
+            params_i = self.entropy_parameters(self.merge(self._ctx(y_hat_, i), side_params_[i]))
+            y_hat_[i] = codec.decompress([strings[i]], (h, w // 2), params_i)["y_hat"]
+        return {"y_hat": self.embed(y_hat_)}
+
+    def forward(self, y: Tensor, side_params: Tensor):
+        raise NotImplementedError("training-time likelihoods are outside the entropy-coding path")
+
+
+class ChannelGroupsLatentCodec(nn.Module):
+    """Channel groups coded one after the other, each conditioned on the previous ones (channel_groups.py:111-158);
+    ``latent_codec[f"y{k}"]`` is typically a ``CheckerboardLatentCodec`` (models/elic_gmm.py:198-219)."""
+
+    def __init__(self, latent_codec: Optional[Dict[str, nn.Module]] = None,
+                 channel_context: Optional[Dict[str, nn.Module]] = None, *, groups: List[int], **kwargs: Any):
+        super().__init__()
+        self.groups = list(groups)
+        self.groups_acc = list(accumulate(self.groups, initial=0))
+        self.channel_context = nn.ModuleDict(channel_context)
+        self.latent_codec = nn.ModuleDict(latent_codec)
+
+    def __getitem__(self, key: str) -> nn.Module:
+        return self.latent_codec[key]
+
+    def merge_y(self, *args: Tensor) -> Tensor:
+        return torch.cat(args, dim=1)
+
+    def merge_params(self, *args: Tensor) -> Tensor:
+        return torch.cat(args, dim=1)
+
+    def _get_ctx_params(self, k: int, side_params: Tensor, y_hat_: Tuple[Tensor, ...]) -> Tensor:
+        if k == 0:
+            return side_params
+        ch_ctx_params = self.channel_context[f"y{k}"](self.merge_y(*y_hat_[:k]))
+        return self.merge_params(ch_ctx_params, side_params)
+
+    def compress(self, y: Tensor, side_params: Tensor) -> Dict[str, Any]:
+        y_ = torch.split(y, self.groups, dim=1)
+        y_hat = torch.zeros_like(y)
+        y_hat_ = y_hat.split(self.groups, dim=1)
+        y_out_ = []
+        for k in range(len(self.groups)):
+            params = self._get_ctx_params(k, side_params, y_hat_)
+            y_out_.append(self.latent_codec[f"y{k}"].compress(y_[k], params))
+            y_hat_[k][:] = y_out_[k]["y_hat"]
+        y_strings_groups = [y_out["strings"] for y_out in y_out_]
+        assert all(len(y_strings_groups[0]) == len(ss) for ss in y_strings_groups)
+        return {"strings": [s for ss in y_strings_groups for s in ss], "shape": [y_out["shape"] for y_out in y_out_],
+                "y_hat": y_hat}
+
+    def decompress(self, strings: List[Any], shape: List[Tuple[int, ...]], side_params: Tensor, **kwargs: Any) -> Dict[str, Any]:
+        n = 1
+        strings_per_group = len(strings) // len(self.groups)
+        y_shape = (sum(s[0] for s in shape), *shape[0][1:])
+        y_hat = torch.zeros((n, *y_shape), device=side_params.device)
+        y_hat_ = y_hat.split(self.groups, dim=1)
+        for k in range(len(self.groups)):
+            params = self._get_ctx_params(k, side_params, y_hat_)
+            out = self.latent_codec[f"y{k}"].decompress(strings[strings_per_group * k: strings_per_group * (k + 1)], shape[k], params)
+            y_hat_[k][:] = out["y_hat"]
+        return {"y_hat": y_hat}
+
+    def forward(self, y: Tensor, side_params: Tensor):
+        raise NotImplementedError("training-time likelihoods are outside the entropy-coding path")

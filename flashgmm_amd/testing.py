@@ -77,3 +77,74 @@ def to_float16_planes(scales, means, weights):
     over = w16.astype(np.float32) > weights
     w16[over] = np.nextafter(w16[over], np.float16(0))
     return scales.astype(np.float16), means.astype(np.float16), w16
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Networks whose outputs are the same bits on every device, for parity tests of the codecs that sit ABOVE the
+# entropy model (CheckerboardLatentCodec, ChannelGroupsLatentCodec): a real convolution or softmax differs in the
+# last bits between a CPU and a GPU, and the bitstream depends on every bit of (sigma, mu, pi).  Everything below is
+# exact arithmetic: dyadic constants, shifts, sums of a few exactly representable terms, and mixture logits in
+# {0, -inf} with 1, 2 or 4 active components (softmax = 1, 1/2, 1/4 exactly).  The reference's own codec classes
+# run with these modules on the CPU when the golden vectors are made (tests/golden/make_golden.py), ours on the GPU.
+# ---------------------------------------------------------------------------------------------------------------
+def exact_modules():
+    """-> (ExactContext, ExactParams) classes (torch imported lazily: this module stays numpy-only otherwise)."""
+    import torch
+    import torch.nn as nn
+
+    class ExactContext(nn.Module):
+        """[n, c_in, h, w] -> [n, c_out, h, w]: out[o] = x[o % c_in] shifted down / 2 + x[(o+1) % c_in] shifted right / 4
+        - x[(3o+2) % c_in] shifted left / 4 (zero fill).  Exact for integer-valued x."""
+
+        def __init__(self, c_in: int, c_out: int):
+            super().__init__()
+            self.c_in, self.c_out = c_in, c_out
+
+        def forward(self, x):
+            n, c, h, w = x.shape
+            down = torch.zeros_like(x); down[:, :, 1:, :] = x[:, :, :-1, :]
+            right = torch.zeros_like(x); right[:, :, :, 1:] = x[:, :, :, :-1]
+            left = torch.zeros_like(x); left[:, :, :, :-1] = x[:, :, :, 1:]
+            o = torch.arange(self.c_out, device=x.device)
+            return 0.5 * down[:, o % c] + 0.25 * right[:, (o + 1) % c] - 0.25 * left[:, (3 * o + 2) % c]
+
+    class ExactParams(nn.Module):
+        """pointwise [n, c_in, h, w] -> [n, 3*K*M, h, w] = [scales | means | logits], channel k*M + c each."""
+
+        def __init__(self, c_in: int, M: int, K: int = 4):
+            super().__init__()
+            self.c_in, self.M, self.K = c_in, M, K
+
+        def forward(self, x):
+            n, c_in, h, w = x.shape
+            M, K = self.M, self.K
+            c = torch.arange(M, device=x.device)
+            scales, means, logits = [], [], []
+            a = x[:, (5 * c + 1) % c_in]  # decides how many components are active
+            b = x[:, (7 * c + 3) % c_in]
+            ninf = torch.full_like(a, float("-inf"))
+            zero = torch.zeros_like(a)
+            for k in range(K):
+                xin = x[:, (c + k) % c_in]
+                scales.append(0.0625 + 0.25 * xin.abs() + 0.125 * k)  # some below the 0.11 clamp
+                means.append(0.5 * x[:, (c + 2 * k) % c_in] + (k - 1.5))
+                if k == 0:
+                    logits.append(zero)
+                elif k == 1:
+                    logits.append(torch.where(a > 0, zero, ninf))
+                else:
+                    logits.append(torch.where((a > 0) & (b > 0), zero, ninf))
+            return torch.cat(scales + means + logits, dim=1)
+
+    return ExactContext, ExactParams
+
+
+def exact_codec_inputs(seed: int, c: int, c_side: int, h: int, w: int, dead: int = 0):
+    """y float32 [1, c, h, w] (arbitrary floats; `dead` leading channels within +-0.4 so that they quantise to all-zero),
+    side_params float32 [1, c_side, h, w] (multiples of 1/4, so that everything derived from them stays exact)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    y = (rng.standard_normal((1, c, h, w)) * rng.uniform(0.5, 6.0, (1, c, 1, 1))).astype(np.float32)
+    if dead:
+        y[:, :dead] = rng.uniform(-0.4, 0.4, (1, dead, h, w)).astype(np.float32)
+    side = (rng.integers(-12, 13, (1, c_side, h, w)) / 4.0).astype(np.float32)
+    return y, side

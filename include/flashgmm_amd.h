@@ -251,6 +251,16 @@ void fgmm_decstream_destroy(fgmm_decstream *d);
 int fgmm_decstream_decode(fgmm_decstream *d, const int32_t *indexes, int64_t n, const int32_t *cdfs, int64_t cdf_stride,
                           int32_t n_cdfs, const int32_t *cdfs_sizes, const int32_t *offsets, int32_t *out_symbols);
 
+/* ---- section 5: the callers either side of the path ---------------------------------
+ * CheckerboardLatentCodec.unembed / embed (compressai/latent_codecs/checkerboard.py:333-377): split a [planes, h, w]
+ * device tensor into its two checkerboard halves [2, planes, h, w/2] (half 0 = anchors) and back.  planes = n * c;
+ * w must be even; elem_bytes 4 (float32 / int32) or 2 (float16); anchor_odd = 0 for anchor_parity "even" (anchors at
+ * (even row, even column) and (odd row, odd column)), 1 for "odd".  Pure data movement: any bit pattern is preserved. */
+int fgmm_ckbd_unembed(fgmm_ctx *ctx, void *stream, const void *src, void *dst, int64_t planes, int64_t h, int64_t w,
+                      int elem_bytes, int anchor_odd);
+int fgmm_ckbd_embed(fgmm_ctx *ctx, void *stream, const void *src, void *dst, int64_t planes, int64_t h, int64_t w,
+                    int elem_bytes, int anchor_odd);
+
 /* compressai._CXX.pmf_to_quantized_cdf (compressai/cpp_exts/ops/ops.cpp:40-109): cdf_out has n + 1 entries */
 int fgmm_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf_out);
 

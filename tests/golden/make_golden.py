@@ -141,6 +141,59 @@ def import_reference_entropy_models(ans_mod):
     return GaussianMixtureConditional
 
 
+def import_reference_latent_codecs():
+    """The reference's own CheckerboardLatentCodec / ChannelGroupsLatentCodec / GaussianMixtureConditionalLatentCodec,
+    imported IN PLACE (after import_reference_entropy_models).  compressai.registry pulls in torch_geometric,
+    torchvision and pytorch_msssim, which are not installed: inert stand-ins for those three THIRD-PARTY packages
+    (none of their code is on the path) let the import proceed."""
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            m = _Any(self.__name__ + "." + name)
+            sys.modules[m.__name__] = m
+            return m
+
+        def __call__(self, *a, **k):
+            return None
+
+    for name in ("torch_geometric", "torch_geometric.transforms", "torchvision", "torchvision.transforms", "pytorch_msssim"):
+        sys.modules.setdefault(name, _Any(name))
+    from compressai.latent_codecs.channel_groups import ChannelGroupsLatentCodec
+    from compressai.latent_codecs.checkerboard import CheckerboardLatentCodec
+    from compressai.latent_codecs.gaussian_mixture_conditional import GaussianMixtureConditionalLatentCodec
+
+    return CheckerboardLatentCodec, ChannelGroupsLatentCodec, GaussianMixtureConditionalLatentCodec
+
+
+G7_CKBD = [  # CheckerboardLatentCodec cases: (name, seed, c, c_side, h, w, dead channels, quantizer, anchor_parity)
+    ("ckbd_noise_even", 11, 6, 8, 8, 12, 0, "noise", "even"),
+    ("ckbd_ste_odd", 12, 5, 6, 6, 10, 1, "weighted_mean_ste", "odd"),
+]
+G7_GROUPS = [  # ChannelGroupsLatentCodec of checkerboard codecs: (name, seed, groups, c_side, h, w, quantizer)
+    ("groups_224", 21, [2, 2, 4], 8, 8, 12, "noise"),
+]
+
+
+def build_codecs(Ckbd, Groups, Gmm, Ctx, Par, kind, cfg):
+    """the same wiring for the reference's classes and for flashgmm_amd's (models/ckbd_gmm.py:111, elic_gmm.py:198-219)"""
+    if kind == "ckbd":
+        name, seed, c, c_side, h, w, dead, quantizer, parity = cfg
+        return Ckbd(latent_codec={"y": Gmm(K=4, quantizer=quantizer)}, context_prediction=Ctx(c, 2 * c),
+                    entropy_parameters=Par(2 * c + c_side, c), anchor_parity=parity)
+    name, seed, groups, c_side, h, w, quantizer = cfg
+    latent = {f"y{k}": Ckbd(latent_codec={"y": Gmm(K=4, quantizer=quantizer)}, context_prediction=Ctx(g, 2 * g),
+                            entropy_parameters=Par(2 * g + (k > 0) * 2 * g + c_side, g))
+              for k, g in enumerate(groups)}
+    chctx = {f"y{k}": Ctx(sum(groups[:k]), 2 * groups[k]) for k in range(1, len(groups))}
+    return Groups(groups=groups, channel_context=chctx, latent_codec=latent)
+
+
+def strings_to_json(strings):
+    return [{"hex": b.hex(), "abs_max": int(a), "zero_bitmap": [int(v) for v in zb.tolist()]} for (b, a, zb) in strings]
+
+
 def worker(mode: int, flavour: str):
     import torch
 
@@ -209,6 +262,31 @@ def worker(mode: int, flavour: str):
                 "y_hat_dtype": str(y_hat.dtype), "y_hat_shape": list(y_hat.shape),
             }
         out["g4"] = g4
+
+        # G7: the codecs above the entropy model, run with the reference's own classes on exact networks
+        import contextlib
+
+        Ckbd, Groups, Gmm = import_reference_latent_codecs()
+        Ctx, Par = T.exact_modules()
+        g7 = {}
+        with contextlib.redirect_stdout(sys.stderr):  # the reference's codecs print timings
+            for kind, cfgs in (("ckbd", G7_CKBD), ("groups", G7_GROUPS)):
+                for cfg in cfgs:
+                    name, seed = cfg[0], cfg[1]
+                    if kind == "ckbd":
+                        y, side = T.exact_codec_inputs(seed, cfg[2], cfg[3], cfg[4], cfg[5], dead=cfg[6])
+                    else:
+                        y, side = T.exact_codec_inputs(seed, sum(cfg[2]), cfg[3], cfg[4], cfg[5])
+                    codec = build_codecs(Ckbd, Groups, Gmm, Ctx, Par, kind, cfg)
+                    enc = codec.compress(ts(y), ts(side))
+                    dec = codec.decompress(enc["strings"], enc["shape"], ts(side))
+                    g7[name] = {
+                        "strings": strings_to_json(enc["strings"]),
+                        "shape": [list(s_) for s_ in enc["shape"]] if kind == "groups" else list(enc["shape"]),
+                        "y_hat_sha256": hashlib.sha256(enc["y_hat"].contiguous().numpy().tobytes()).hexdigest(),
+                        "decompress_y_hat_sha256": hashlib.sha256(dec["y_hat"].contiguous().numpy().tobytes()).hexdigest(),
+                    }
+        out["g7"] = g7
     json.dump(out, sys.stdout)
 
 
@@ -274,6 +352,7 @@ def main():
     json.dump(g3_out, open(os.path.join(HERE, "g3_small.json"), "w"), indent=1)
     json.dump({name: res[name]["ka1"] for name in MODE_NAMES}, open(os.path.join(HERE, "ka1.json"), "w"), indent=1)
     json.dump({name: res[name]["g4"] for name in MODE_NAMES}, open(os.path.join(HERE, "g4_api.json"), "w"), indent=1)
+    json.dump({name: res[name]["g7"] for name in MODE_NAMES}, open(os.path.join(HERE, "g7_codecs.json"), "w"), indent=1)
     # table path (mode independent): the oracle must rebuild the same CDF rows and the same bytes
     r0 = res["polya"]
     assert r0["g6"] == [0, 21845, 65534, 65535, 65536] == O.pmf_to_quantized_cdf([0.1, 0.2, 0, 0], 16)

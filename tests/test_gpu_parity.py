@@ -528,3 +528,80 @@ def test_latent_codec_contract(oracle, quantizer):
     dec = codec.decompress(out["strings"], out["shape"], ctx)
     want = out["y_hat"] if quantizer == "noise" else out["y_hat"] + ws
     assert torch.equal(dec["y_hat"], want)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the codecs above the entropy model
+# ---------------------------------------------------------------------------------------------------------------
+def _ref_unembed(y, parity):  # restatement of checkerboard.py:333-354 with torch slicing
+    n, c, h, w = y.shape
+    y_ = y.new_zeros((2, n, c, h, w // 2))
+    a, b = (0, 1) if parity == "even" else (1, 0)
+    y_[0, ..., 0::2, :] = y[..., 0::2, a::2]
+    y_[0, ..., 1::2, :] = y[..., 1::2, b::2]
+    y_[1, ..., 0::2, :] = y[..., 0::2, b::2]
+    y_[1, ..., 1::2, :] = y[..., 1::2, a::2]
+    return y_
+
+
+@pytest.mark.parametrize("parity", ["even", "odd"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.int32])
+def test_checkerboard_split_merge_equals_reference_slicing(parity, dtype):
+    from flashgmm_amd.ops import ckbd_embed, ckbd_unembed
+
+    g = torch.Generator().manual_seed(5)
+    for shape in [(1, 6, 8, 12), (1, 3, 7, 10), (2, 5, 1, 2), (1, 192, 32, 48), (1, 1, 33, 258), (1, 4, 0, 6)]:
+        y = (torch.randn(shape, generator=g) * 50).to(dtype).to("cuda")
+        want = _ref_unembed(y, parity)
+        got = ckbd_unembed(y, parity)
+        assert got.shape == want.shape and torch.equal(got, want), (shape, "unembed")
+        back = ckbd_embed(got, parity)
+        assert back.shape == y.shape and torch.equal(back, y), (shape, "embed")
+    # -0.0, NaN payloads and infinities are data, not numbers, to a copy kernel
+    bits = torch.tensor([0x80000000, 0x7FC12345, 0x7F800000, 0xFF800001], dtype=torch.int64).to(torch.int32)
+    y = bits.view(torch.float32).reshape(1, 1, 2, 2).cuda()
+    assert torch.equal(ckbd_embed(ckbd_unembed(y, parity), parity).view(torch.int32), y.view(torch.int32))
+    with pytest.raises(RuntimeError):
+        ckbd_unembed(torch.zeros(1, 2, 4, 5, device="cuda"), parity)  # odd width
+    with pytest.raises(RuntimeError):
+        ckbd_unembed(torch.zeros(1, 2, 4, 6), parity)  # not on the GPU: no CPU fallback
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_g7_codecs_equal_the_reference_classes(mode):
+    """CheckerboardLatentCodec / ChannelGroupsLatentCodec (checkerboard.py:275-330, channel_groups.py:111-158): the
+    reference's own classes were run on device-independent networks (flashgmm_amd.testing.exact_modules) when
+    tests/golden/g7_codecs.json was made; the mirrors must give the same strings, side information and tensors —
+    including the reference's -0.0 in y_hat and its encoder/decoder mismatch for quantizer="weighted_mean_ste"
+    (compress() feeds the un-recentred residual to the non-anchor context, decompress() the re-centred value)."""
+    import importlib.util
+
+    from flashgmm_amd.latent_codecs import (ChannelGroupsLatentCodec, CheckerboardLatentCodec,
+                                            GaussianMixtureConditionalLatentCodec)
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)  # the case tables and the wiring helper only: nothing of the reference is touched
+    gold = json.load(open(os.path.join(GOLD, "g7_codecs.json")))[mode]
+    Ctx, Par = T.exact_modules()
+    Gmm = lambda K, quantizer: GaussianMixtureConditionalLatentCodec(K=K, quantizer=quantizer, mode=mode)  # noqa: E731
+    sha = lambda t: hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest()  # noqa: E731
+    for kind, cfgs in (("ckbd", mg.G7_CKBD), ("groups", mg.G7_GROUPS)):
+        for cfg in cfgs:
+            name, seed = cfg[0], cfg[1]
+            if kind == "ckbd":
+                y, side = T.exact_codec_inputs(seed, cfg[2], cfg[3], cfg[4], cfg[5], dead=cfg[6])
+            else:
+                y, side = T.exact_codec_inputs(seed, sum(cfg[2]), cfg[3], cfg[4], cfg[5])
+            codec = mg.build_codecs(CheckerboardLatentCodec, ChannelGroupsLatentCodec, Gmm, Ctx, Par, kind, cfg).cuda()
+            enc = codec.compress(dv(y), dv(side))
+            want = gold[name]
+            got = [{"hex": b.hex(), "abs_max": int(a), "zero_bitmap": [int(v) for v in zb.tolist()]} for (b, a, zb) in enc["strings"]]
+            assert got == want["strings"], (name, "strings")
+            shape = [list(s_) for s_ in enc["shape"]] if kind == "groups" else list(enc["shape"])
+            assert shape == want["shape"], name
+            assert sha(enc["y_hat"]) == want["y_hat_sha256"], (name, "compress y_hat")
+            dec = codec.decompress(enc["strings"], enc["shape"], dv(side))
+            assert sha(dec["y_hat"]) == want["decompress_y_hat_sha256"], (name, "decompress y_hat")
+            if cfg[-1] == "noise" or cfg[-2] == "noise":
+                assert torch.equal(dec["y_hat"], enc["y_hat"]), name  # (-0.0 == 0.0)
