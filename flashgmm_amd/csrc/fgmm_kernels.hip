@@ -572,26 +572,42 @@ __global__ __launch_bounds__(kBlock) void yhat_scatter_kernel(const ST *__restri
 // Lane = one horizontal pair (columns 2j, 2j+1): the pair is one 2*sizeof(T) access of the full tensor, its two
 // elements one coalesced access each of the two halves.  In row i the anchor is column 2j + ((i & 1) ^ anchor_odd).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, bool EMBED>
+template <typename T, bool EMBED, int V>
 __global__ __launch_bounds__(kBlock) void ckbd_kernel(const T *__restrict__ src, T *__restrict__ dst, int64_t rows, int64_t h,
                                                      int64_t w2, int anchor_odd) {
-  struct alignas(2 * sizeof(T)) Pair { T a, b; };
-  const int64_t half = rows * w2; // elements of one half
-  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
-    const int b = (int)((row % h) & 1) ^ anchor_odd;
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < w2; j += (int64_t)gridDim.x * kBlock) {
-      const int64_t e = row * w2 + j;
-      if constexpr (EMBED) {
-        const T anchor = src[e], other = src[half + e];
-        Pair p;
-        p.a = b ? other : anchor;
-        p.b = b ? anchor : other;
-        reinterpret_cast<Pair *>(dst)[e] = p;
-      } else {
-        const Pair p = reinterpret_cast<const Pair *>(src)[e];
-        dst[e] = b ? p.b : p.a;
-        dst[half + e] = b ? p.a : p.b;
+  // V consecutive pairs per lane (w2 % V == 0, checked by the launcher: they share a row): 16-byte accesses of the
+  // full tensor for V = 2 (4-byte elements) / V = 4 (2-byte elements)
+  struct alignas(2 * sizeof(T) * V) Pairs { T v[2 * V]; };
+  struct alignas(sizeof(T) * V) Halves { T v[V]; };
+  const int64_t half = rows * w2; // pairs in all = elements of one half
+  const int64_t groups = half / V;
+  const bool h_even = (h & 1) == 0, small = half <= 0xFFFFFFFFll;
+  // pairs are taken in linear order, whatever the row length (a Kodak half-row is 24 pairs: one row per block would
+  // leave 9 lanes in 10 idle)
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
+    const int64_t e = g * V;
+    const int64_t row = small ? (int64_t)((uint32_t)e / (uint32_t)w2) : e / w2;
+    const int i_par = h_even ? (int)(row & 1) : (int)((small ? (int64_t)((uint32_t)row % (uint32_t)h) : row % h) & 1);
+    const int b = i_par ^ anchor_odd;
+    if constexpr (EMBED) {
+      const Halves anchor = reinterpret_cast<const Halves *>(src)[g], other = reinterpret_cast<const Halves *>(src + half)[g];
+      Pairs p;
+#pragma unroll
+      for (int t = 0; t < V; ++t) {
+        p.v[2 * t] = b ? other.v[t] : anchor.v[t];
+        p.v[2 * t + 1] = b ? anchor.v[t] : other.v[t];
       }
+      reinterpret_cast<Pairs *>(dst)[g] = p;
+    } else {
+      const Pairs p = reinterpret_cast<const Pairs *>(src)[g];
+      Halves anchor, other;
+#pragma unroll
+      for (int t = 0; t < V; ++t) {
+        anchor.v[t] = b ? p.v[2 * t + 1] : p.v[2 * t];
+        other.v[t] = b ? p.v[2 * t] : p.v[2 * t + 1];
+      }
+      reinterpret_cast<Halves *>(dst)[g] = anchor;
+      reinterpret_cast<Halves *>(dst + half)[g] = other;
     }
   }
 }
@@ -808,18 +824,28 @@ int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y
   return launch_err();
 }
 
+template <typename T, int V>
+static void launch_ckbd_t(const void *src, void *dst, int64_t rows, int64_t h, int64_t w2, int anchor_odd, bool embed, hipStream_t s) {
+  dim3 grid((unsigned)std::min<int64_t>((rows * w2 / V + kBlock - 1) / kBlock, 1 << 20));
+  if (embed) hipLaunchKernelGGL((ckbd_kernel<T, true, V>), grid, dim3(kBlock), 0, s, (const T *)src, (T *)dst, rows, h, w2, anchor_odd);
+  else hipLaunchKernelGGL((ckbd_kernel<T, false, V>), grid, dim3(kBlock), 0, s, (const T *)src, (T *)dst, rows, h, w2, anchor_odd);
+}
 int launch_ckbd(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes, int anchor_odd, bool embed,
                 void *stream) {
   const int64_t rows = planes * h, w2 = w / 2;
   if (rows <= 0 || w2 <= 0) return 0;
-  dim3 grid((unsigned)std::min<int64_t>((w2 + kBlock - 1) / kBlock, 64), (unsigned)std::min<int64_t>(rows, 65535));
   hipStream_t s = (hipStream_t)stream;
+  // wide form: V pairs per lane, when rows hold a multiple of V pairs and both tensors are 16-byte aligned (the second
+  // half starts rows * w2 elements into the halves tensor)
+  const int V = elem_bytes == 4 ? 2 : 4;
+  const bool wide = w2 % V == 0 && (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) % 16 == 0 &&
+                    (rows * w2 * elem_bytes) % 16 == 0;
   if (elem_bytes == 4) {
-    if (embed) hipLaunchKernelGGL((ckbd_kernel<uint32_t, true>), grid, dim3(kBlock), 0, s, (const uint32_t *)src, (uint32_t *)dst, rows, h, w2, anchor_odd);
-    else hipLaunchKernelGGL((ckbd_kernel<uint32_t, false>), grid, dim3(kBlock), 0, s, (const uint32_t *)src, (uint32_t *)dst, rows, h, w2, anchor_odd);
+    if (wide) launch_ckbd_t<uint32_t, 2>(src, dst, rows, h, w2, anchor_odd, embed, s);
+    else launch_ckbd_t<uint32_t, 1>(src, dst, rows, h, w2, anchor_odd, embed, s);
   } else {
-    if (embed) hipLaunchKernelGGL((ckbd_kernel<uint16_t, true>), grid, dim3(kBlock), 0, s, (const uint16_t *)src, (uint16_t *)dst, rows, h, w2, anchor_odd);
-    else hipLaunchKernelGGL((ckbd_kernel<uint16_t, false>), grid, dim3(kBlock), 0, s, (const uint16_t *)src, (uint16_t *)dst, rows, h, w2, anchor_odd);
+    if (wide) launch_ckbd_t<uint16_t, 4>(src, dst, rows, h, w2, anchor_odd, embed, s);
+    else launch_ckbd_t<uint16_t, 1>(src, dst, rows, h, w2, anchor_odd, embed, s);
   }
   return launch_err();
 }

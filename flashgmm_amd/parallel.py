@@ -13,7 +13,8 @@ from typing import List, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_units", "owner_of", "all_gather_stream_lengths", "container_index", "bind_to_gpu_numa_node"]
+__all__ = ["shard_units", "owner_of", "all_gather_stream_lengths", "container_index", "gather_containers",
+           "bind_to_gpu_numa_node"]
 
 
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:
@@ -52,6 +53,44 @@ def container_index(lengths: torch.Tensor, n_units: int, streams_per_unit: int) 
             assert ln >= 0, f"unit {u} stream {s}: length missing"
             out.append((u, s, off, ln))
             off += ln
+    return out
+
+
+def gather_containers(local: Sequence[bytes], n_units: int, device=None, group=None) -> List[bytes]:
+    """Every rank contributes the packed containers (``flashgmm_amd.container.pack``) of ITS units, in its local unit
+    order; every rank gets all ``n_units`` containers back in unit order (unit i lives on rank i mod world).
+
+    Two collectives: the lengths (``all_gather_stream_lengths``), then one all-gather of the payloads padded to the
+    longest rank — a Kodak image is ~100 KB, so this too is latency-bound.  ``device``: where the collective buffers
+    live ("nccl"/RCCL needs the rank's GPU, gloo the CPU)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = shard_units(n_units, rank, world)
+    if len(local) != len(mine):
+        raise ValueError(f"rank {rank} owns {len(mine)} units, got {len(local)} containers")
+    per_rank = (n_units + world - 1) // world
+    lengths = all_gather_stream_lengths([len(b) for b in local], per_rank, device=device, group=group).cpu()
+    totals = lengths.clamp(min=0).sum(1)
+    pad = int(totals.max())
+    buf = torch.zeros(max(pad, 1), dtype=torch.uint8)
+    blob = b"".join(local)
+    if blob:
+        buf[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+    if device is not None:
+        buf = buf.to(device)
+    if world == 1:
+        gathered = [buf]
+    else:
+        gathered = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(gathered, buf, group=group)
+    out: List[bytes] = []
+    L = lengths.tolist()
+    offs = [0] * world
+    for u in range(n_units):
+        r, j = u % world, u // world
+        ln = L[r][j]
+        out.append(gathered[r][offs[r]: offs[r] + ln].cpu().numpy().tobytes())
+        offs[r] += ln
     return out
 
 

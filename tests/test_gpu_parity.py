@@ -605,3 +605,10 @@ def test_g7_codecs_equal_the_reference_classes(mode):
             assert sha(dec["y_hat"]) == want["decompress_y_hat_sha256"], (name, "decompress y_hat")
             if cfg[-1] == "noise" or cfg[-2] == "noise":
                 assert torch.equal(dec["y_hat"], enc["y_hat"]), name  # (-0.0 == 0.0)
+            # through the byte container (flashgmm_amd/container.py) and back: same reconstruction
+            from flashgmm_amd import container as Cn
+
+            blob = Cn.pack(enc["strings"], enc["shape"])
+            s2, shape2 = Cn.unpack(blob, device="cuda")
+            assert torch.equal(codec.decompress(s2, shape2, dv(side))["y_hat"], dec["y_hat"]), (name, "container")
+            assert len(blob) - sum(len(t[0]) for t in enc["strings"]) == Cn.side_info_bytes(enc["strings"], enc["shape"])

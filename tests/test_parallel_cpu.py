@@ -58,3 +58,70 @@ def test_single_process_degenerates():
     assert g.tolist() == [[5, 6, 7, 8]]
     assert P.container_index(g, 2, 2) == [(0, 0, 0, 5), (0, 1, 5, 6), (1, 0, 11, 7), (1, 1, 18, 8)]
     assert P.owner_of(9, 8) == 1
+
+
+# ---- container byte layout (flashgmm_amd/container.py) and its gather across ranks -------------------------------
+def _fake_strings(unit: int):
+    """what net.compress()["strings"] looks like for a checkerboard GMM model: two GMM streams + the hyper-latent's"""
+    rng = torch.Generator().manual_seed(unit)
+    def stream(k):
+        n = 50 + 13 * unit + k
+        data = bytes(torch.randint(0, 256, (n,), generator=rng, dtype=torch.uint8).tolist())
+        zb = (torch.rand(19 + unit, generator=rng) > 0.3).to(torch.int64)
+        return (data, 7 + unit + k, zb)
+    return [stream(0), stream(1), [b"z" * (unit % 3), b""]], {"y": [(4, 8, 12), [2, 3]], "hyper": (2, 3), "none": None}
+
+
+def test_container_round_trip_and_accounting():
+    from flashgmm_amd import container as Cn
+
+    strings, shape = _fake_strings(3)
+    blob = Cn.pack(strings, shape)
+    s2, shape2 = Cn.unpack(blob)
+    assert shape2 == shape and len(s2) == len(strings)
+    for a, b in zip(strings, s2):
+        if isinstance(a, tuple):
+            assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2]) and b[2].dtype == torch.int64
+        else:
+            assert list(a) == list(b)
+    payload = sum(len(s[0]) for s in strings[:2]) + sum(len(b) for b in strings[2])
+    assert Cn.num_bytes(strings, shape) == len(blob) and Cn.side_info_bytes(strings, shape) == len(blob) - payload > 0
+    assert Cn.unpack(Cn.pack([], None)) == ([], None)
+    assert Cn.unpack(Cn.pack([], torch.Size([3, 4])))[1] == (3, 4)
+    for bad in (blob[:-1], blob + b"\0", b"XXXX" + blob[4:], blob[:20]):
+        with pytest.raises(ValueError):
+            Cn.unpack(bad)
+    with pytest.raises(TypeError):
+        Cn.pack([("not bytes", 1, torch.zeros(2))])
+
+
+def _gather_worker(rank, world, port, n_units, q):
+    from flashgmm_amd import container as Cn
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = [Cn.pack(*_fake_strings(u)) for u in P.shard_units(n_units, rank, world)]
+    allc = P.gather_containers(local, n_units)
+    q.put((rank, [bytes(b) for b in allc]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_units", [6, 5, 1])
+def test_gather_containers_world2(n_units):
+    from flashgmm_amd import container as Cn
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, n_units, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [Cn.pack(*_fake_strings(u)) for u in range(n_units)]
+    assert got[0] == want and got[1] == want  # every rank holds every unit's container, in unit order
+    assert P.gather_containers(want[:1], 1) == want[:1]  # world size 1 degenerates to the identity
