@@ -679,8 +679,17 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     pit->t_taken = tr.ms();
     auto job = [pit, here, &done_mu, &done_cv, &tr] {
       pit->t_start = tr.ms();
-      int32_t *sym = pit->sym_host_out ? pit->sym_host_out
-                                       : (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(pit->n, 1));
+      // decoded symbols: the caller's buffer, or a per-thread scratch (a fresh 600 KB malloc per stream is an mmap)
+      static thread_local std::vector<int32_t> scratch;
+      int32_t *sym = pit->sym_host_out;
+      if (!sym) {
+        try {
+          if (scratch.size() < (size_t)std::max<int64_t>(pit->n, 1)) scratch.resize((size_t)std::max<int64_t>(pit->n, 1));
+          sym = scratch.data();
+        } catch (const std::bad_alloc &) {
+          sym = nullptr;
+        }
+      }
       if (!here) { // a kernel or copy of the item's group failed
         pit->status = FGMM_ERR_HIP;
       } else if (!sym) {
@@ -704,7 +713,6 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
           if (pit->wide) memcpy(pit->h_out, sym, sizeof(int32_t) * (size_t)pit->n);
         }
       }
-      if (sym != pit->sym_host_out) free(sym);
       pit->t_end = tr.ms();
       {
         std::lock_guard<std::mutex> l(done_mu);

@@ -103,12 +103,19 @@ int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n
   }
   // every entry of the reference's _syms emits at most one 32-bit word; a bypassed symbol is 1 + 1 + <=8 entries
   const size_t nwords = (size_t)n + (size_t)nb * 10 + 16;
-  uint32_t *buf = (uint32_t *)malloc(nwords * sizeof(uint32_t));
-  if (!buf) return FGMM_ERR_NOMEM;
+  // worst-case sized scratch, kept per thread: a fresh 600 KB malloc per stream is an mmap + page faults + munmap
+  static thread_local std::vector<uint32_t> scratch;
+  try {
+    if (scratch.size() < nwords) scratch.resize(nwords);
+  } catch (const std::bad_alloc &) {
+    return FGMM_ERR_NOMEM;
+  }
+  uint32_t *const buf = scratch.data();
   uint32_t *const end = buf + nwords;
   Enc e{kRansL, end}; // Rans64EncInit
 
   for (int64_t i = n - 1; i >= 0; --i) { // reversed _syms (rans_interface.cpp:569)
+    if ((i & 15) == 15) __builtin_prefetch(packed + i - 512); // the table was just DMA-written: not in any cache
     const uint32_t ent = packed[i];
     const uint32_t freq = ent >> 16;
     if (__builtin_expect(freq != 0, 1)) {
@@ -131,11 +138,9 @@ int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n
   const size_t nbytes = (size_t)(end - e.ptr) * sizeof(uint32_t);
   uint8_t *o = (uint8_t *)malloc(nbytes);
   if (!o) {
-    free(buf);
     return FGMM_ERR_NOMEM;
   }
   memcpy(o, e.ptr, nbytes);
-  free(buf);
   *out = o;
   *out_len = nbytes;
   return FGMM_OK;
