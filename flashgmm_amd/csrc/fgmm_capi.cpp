@@ -174,6 +174,17 @@ struct fgmm_ctx {
     for (auto &c : chunks) c.used = 0;
     for (auto &c : dchunks) c.used = 0;
   }
+  char *d_tmp = nullptr; // decode: the edges the count passes evaluated, read back by the fill passes
+  size_t d_tmp_cap = 0;
+  int ensure_tmp(size_t bytes) {
+    if (bytes <= d_tmp_cap) return FGMM_OK;
+    if (d_tmp) HIP_TRY(hipFree(d_tmp));
+    d_tmp = nullptr;
+    d_tmp_cap = 0;
+    HIP_TRY(hipMalloc((void **)&d_tmp, bytes));
+    d_tmp_cap = bytes;
+    return FGMM_OK;
+  }
   int dchunk_alloc(size_t bytes, char **out) {
     bytes = align_up(bytes, 256);
     for (auto &c : dchunks)
@@ -596,6 +607,21 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.o_bsum = ar.take(sizeof(uint32_t) * nblk + 64);
     it.o_boff = ar.take(sizeof(uint64_t) * nblk + 64);
   }
+  // temp buffer of evaluated edges, [block][W][256] uint16 per item: 300 B/latent at max_bs = 74 (1.9 GB for the Kodak
+  // batch, of 288 GB); batches that would need more than FGMM_TMP_MAX_MB (default 16 GiB) evaluate the rows twice instead
+  std::vector<size_t> tmp_off((size_t)count, 0);
+  size_t tmp_total = 0;
+  {
+    const size_t cap = (getenv("FGMM_TMP_MAX_MB") ? strtoull(getenv("FGMM_TMP_MAX_MB"), nullptr, 10) : 16384ull) << 20;
+    for (int i = 0; i < count; ++i) {
+      const DecItem &it = items[i];
+      tmp_off[(size_t)i] = tmp_total;
+      tmp_total += sizeof(uint16_t) * (size_t)it.n_ch * (size_t)it.tiles * 256 * (size_t)(2 * (int64_t)it.max_bs + 2);
+      tmp_total = align_up(tmp_total, 256);
+    }
+    if (tmp_total > cap) tmp_total = 0;
+  }
+  if (tmp_total && (rc = ctx->ensure_tmp(tmp_total))) return rc;
   // events: per group [scan done][counters landed][fill done][tables landed], plus per piece of the tail window
   // [fill done][landed]
   if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(host_fixed)) ||
@@ -641,6 +667,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.pool_cap = ~0ull; // the pool is carved to the exact size: the overflow flag of the scan pass stays clear
     d.pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_used);
     d.n_piece = i >= tail_begin ? n_piece : 1;
+    d.tmp = tmp_total ? reinterpret_cast<uint16_t *>(ctx->d_tmp + tmp_off[(size_t)i]) : nullptr;
     d.blk_sums = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_bsum);
     d.blk_off = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_boff);
   }
@@ -912,6 +939,7 @@ void fgmm_ctx_destroy(fgmm_ctx *ctx) {
     if (ctx->h_ws) (void)hipHostFree(ctx->h_ws);
     for (auto &c : ctx->chunks) (void)hipHostFree(c.p);
     for (auto &c : ctx->dchunks) (void)hipFree(c.p);
+    if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->fill_stream) (void)hipStreamDestroy(ctx->fill_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);

@@ -374,31 +374,20 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s_tmp)
   return base + incl - v;
 }
 
+// ---- evaluation window: skip the part of [-max_bs, max_bs+1] where every component is saturated -------------
+// Saturation lemmas (fgmm_math.h Sat<MODE>, proved by exhaustive scan: fgmm_selftest_saturation):
+//   all z_k <= -ZL  =>  F[v] == 0          all z_k >= +ZR  =>  F[v] == quant16((pi0+pi1)+(pi2+pi3))
+// z_k(v) = ((float)v - 0.5f - mu_k) / sg_k is non-decreasing in v for finite mu and 0 < sg < inf (every IEEE
+// operation is monotone), so it is enough to VERIFY the condition, with the kernel's own arithmetic, at one v:
+// it then holds for every v beyond it.  Any latent whose parameters fall outside the lemmas' domain is
+// evaluated over the full range instead.  Indices < j_lo are all zero, indices >= j_hi are all T_sat.
 template <int MODE, bool CLAMPED, typename PT>
-__global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__restrict__ descs) {
-  const DecDesc &d = descs[blockIdx.z];
-  const int cj = blockIdx.y;
-  if (cj >= d.n_ch) return;
-  const int64_t hw = d.hw;
-  if ((int64_t)blockIdx.x * kBlock >= hw) return;
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool active = p < hw;
-  const int c = d.chan_list ? d.chan_list[cj] : cj;
-  TabLatent<MODE, CLAMPED, PT> L;
-  L.load(d, c, active ? p : 0);
-  const int max_bs = d.max_bs;
-  const int W = 2 * max_bs + 2;
-
-  // ---- evaluation window: skip the part of [-max_bs, max_bs+1] where every component is saturated ---------
-  // Saturation lemmas (fgmm_math.h Sat<MODE>, proved by exhaustive scan: fgmm_selftest_saturation):
-  //   all z_k <= -ZL  =>  F[v] == 0          all z_k >= +ZR  =>  F[v] == quant16((pi0+pi1)+(pi2+pi3))
-  // z_k(v) = ((float)v - 0.5f - mu_k) / sg_k is non-decreasing in v for finite mu and 0 < sg < inf (every IEEE
-  // operation is monotone), so it is enough to VERIFY the condition, with the kernel's own arithmetic, at one v:
-  // it then holds for every v beyond it.  Any latent whose parameters fall outside the lemmas' domain is
-  // evaluated over the full range instead.
-  int j_lo = 0, j_hi = W;
-  uint32_t T_sat = 0;
-  if (d.prune) {
+__device__ __forceinline__ void tab_window(const TabLatent<MODE, CLAMPED, PT> &L, int prune, int max_bs, int W, int &j_lo, int &j_hi,
+                                           uint32_t &T_sat) {
+  j_lo = 0;
+  j_hi = W;
+  T_sat = 0;
+  if (prune) {
     bool ok = true;
     float tl = INFINITY, tr = -INFINITY;
 #pragma unroll
@@ -424,12 +413,34 @@ __global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__r
       T_sat = quant16((L.pi[0] + L.pi[1]) + (L.pi[2] + L.pi[3]));
     }
   }
+}
+
+template <int MODE, bool CLAMPED, typename PT>
+__global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__restrict__ descs) {
+  const DecDesc &d = descs[blockIdx.z];
+  const int cj = blockIdx.y;
+  if (cj >= d.n_ch) return;
+  const int64_t hw = d.hw;
+  if ((int64_t)blockIdx.x * kBlock >= hw) return;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = p < hw;
+  const int c = d.chan_list ? d.chan_list[cj] : cj;
+  TabLatent<MODE, CLAMPED, PT> L;
+  L.load(d, c, active ? p : 0);
+  const int max_bs = d.max_bs;
+  const int W = 2 * max_bs + 2;
+
+  int j_lo, j_hi;
+  uint32_t T_sat;
+  tab_window(L, d.prune, max_bs, W, j_lo, j_hi, T_sat);
+  uint16_t *__restrict__ tmp = d.tmp ? d.tmp + ((int64_t)cj * d.tiles + blockIdx.x) * ((int64_t)W * kBlock) + threadIdx.x : nullptr;
 
   int lead = j_lo - 1, run_start = 0;
   bool allzero = true, nonmono = false;
   uint32_t prev = 0;
   for (int j = j_lo; j < j_hi; ++j) {
     const uint32_t E = L.edge(j);
+    if (tmp) tmp[(int64_t)(j - j_lo) * kBlock] = (uint16_t)E; // lanes of a block side by side: coalesced
     if (allzero) {
       if (E == 0) lead = j; else allzero = false;
     }
@@ -505,6 +516,22 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
   const uint32_t ex = block_scan_excl(bytes, s_tmp);
   if (!active) return;
   uint8_t *__restrict__ row = d.pool + d.blk_off[(int64_t)cj * d.tiles + blockIdx.x] + ex; // 8-byte aligned
+  // the row's entries: what the count pass left in the temp buffer (outside its evaluation window the entries are
+  // the saturated constants), or a second evaluation when there is no temp buffer
+  const int W = 2 * d.max_bs + 2;
+  int j_lo = 0, j_hi = W;
+  uint32_t T_sat = 0;
+  const uint16_t *__restrict__ tmp = nullptr;
+  if (d.tmp) {
+    tab_window(L, d.prune, d.max_bs, W, j_lo, j_hi, T_sat);
+    tmp = d.tmp + ((int64_t)cj * d.tiles + blockIdx.x) * ((int64_t)W * kBlock) + threadIdx.x;
+  }
+  auto edge_at = [&](int idx) -> uint32_t {
+    if (!tmp) return L.edge(idx);
+    if (idx < j_lo) return 0u;
+    if (idx >= j_hi) return T_sat;
+    return tmp[(int64_t)(idx - j_lo) * kBlock];
+  };
 
   if (!tab_row_is_ef(cnt, nonmono)) {
     // raw: uint16 entries, padded to a multiple of 4 with the last value
@@ -514,7 +541,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
       uint32_t e[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        if (j0 + t < cnt) last = L.edge(a_idx + (int)(j0 + t));
+        if (j0 + t < cnt) last = edge_at(a_idx + (int)(j0 + t));
         e[t] = last;
       }
       *reinterpret_cast<uint2 *>(row + 2 * j0) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
@@ -526,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
     unsigned long long wcur = 0;
     uint32_t widx = 0, lowacc = 0;
     for (uint32_t j = 0; j < cnt; ++j) {
-      const uint32_t E = L.edge(a_idx + (int)j);
+      const uint32_t E = edge_at(a_idx + (int)j);
       lowacc |= (E & 0xFFu) << (8u * (j & 3u));
       if ((j & 3u) == 3u) {
         *reinterpret_cast<uint32_t *>(row + (j & ~3u)) = lowacc;

@@ -6,6 +6,8 @@ from flashgmm_amd import GaussianMixtureConditional, testing as T
 dev = torch.device("cuda:0")
 devt = [[torch.from_numpy(a).to(dev) for a in T.make_latent(i)] for i in range(48)]
 ys, ss, ms, ws = ([t[k] for t in devt] for k in range(4))
+if len(sys.argv) > 1 and sys.argv[1] == "stacked":
+    ys, ss, ms, ws = (torch.cat(t) for t in (ys, ss, ms, ws))
 gmc = GaussianMixtureConditional(K=4, mode="polya")
 def step():
     res = gmc.compress_batch(ys, ss, ms, ws)
@@ -14,4 +16,4 @@ for _ in range(3): step()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10): step()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
