@@ -45,8 +45,7 @@ struct DecDesc {
   int32_t prune;                 // 1: skip the saturated tails (exact, see cdftab_count_kernel); 0: evaluate all of F
   int32_t tiles;                 // blocks per channel = ceil(hw / 256)
   int32_t pad_;
-  uint32_t *hdr;                 // [n_ch*hw] 4-byte headers (device: written by the count pass, read by the fill pass)
-  uint32_t *hdr_out;             // null, or where the fill pass also stores the headers (pinned host memory)
+  uint32_t *hdr;                 // [n_ch*hw] 4-byte headers (written by the count pass, read by the fill pass and the host)
   int32_t ch_begin, ch_end;      // compact channels the fill pass covers (a launch may fill an item piece by piece)
   uint8_t *pool;                 // rows, latent order (device memory, or pinned host memory written over PCIe)
   unsigned long long pool_cap;   // bytes

@@ -508,7 +508,6 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
   L.load(d, c, active ? p : 0);
 
   const uint32_t h = active ? d.hdr[(int64_t)cj * hw + p] : 0u;
-  if (d.hdr_out && active) d.hdr_out[(int64_t)cj * hw + p] = h;
   const int a_idx = tab_hdr_a(h) + d.max_bs;
   const uint32_t cnt = tab_hdr_cnt(h), nonmono = tab_hdr_nonmono(h);
   const uint32_t bytes = active ? tab_row_bytes(cnt, nonmono) : 0u;
