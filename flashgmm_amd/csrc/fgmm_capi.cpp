@@ -616,7 +616,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     for (int i = 0; i < count; ++i) {
       const DecItem &it = items[i];
       tmp_off[(size_t)i] = tmp_total;
-      tmp_total += sizeof(uint16_t) * (size_t)it.n_ch * (size_t)it.tiles * 256 * (size_t)(2 * (int64_t)it.max_bs + 2);
+      tmp_total += sizeof(uint16_t) * (size_t)it.n_ch * (size_t)it.tiles * 256 * (size_t)(2 * (int64_t)it.max_bs + 2 + kTmpHdrRows);
       tmp_total = align_up(tmp_total, 256);
     }
     if (tmp_total > cap) tmp_total = 0;

@@ -53,9 +53,9 @@ struct DecDesc {
                                  // k + 1 (k < n_piece - 1), piece k = compact channels [n_ch*k/n_piece, n_ch*(k+1)/n_piece)
   int32_t n_piece;               // 0 or 1: no piece offsets wanted (at most FGMM_MAX_PIECES)
   int32_t pad2_;
-  uint16_t *tmp;                 // null, or [n_ch*tiles][W][256] the edges the count pass evaluated (slot t of a lane = its
-                                 // t-th evaluated edge, W = 2*max_bs+2): the fill pass then formats rows from them
-                                 // instead of evaluating every edge a second time
+  uint16_t *tmp;                 // null, or [n_ch*tiles][kTmpHdrRows + W][256]: per lane its evaluation window (j_lo, j_hi,
+                                 // T_sat) and the edges the count pass evaluated (row t = each lane's t-th edge,
+                                 // W = 2*max_bs+2): the fill pass formats rows from them, no second evaluation
   uint32_t *blk_sums;            // [n_ch*tiles] row bytes per block
   unsigned long long *blk_off;   // [n_ch*tiles] byte offset of each block's first row
 };
@@ -67,6 +67,7 @@ struct DecDesc {
 //     EF  (cnt >= 64, monotone): uint8 lows[round8(cnt)] ; uint64 upper[U], U = ceil((cnt + 256) / 64),
 //                                bit ((E_j >> 8) + j) set for every entry j
 constexpr int kMaxPieces = 8; // FGMM_MAX_PIECES
+constexpr int kTmpHdrRows = 4; // see DecDesc::tmp
 #ifndef FGMM_EF_MIN
 #define FGMM_EF_MIN 64
 #endif

@@ -433,7 +433,14 @@ __global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__r
   int j_lo, j_hi;
   uint32_t T_sat;
   tab_window(L, d.prune, max_bs, W, j_lo, j_hi, T_sat);
-  uint16_t *__restrict__ tmp = d.tmp ? d.tmp + ((int64_t)cj * d.tiles + blockIdx.x) * ((int64_t)W * kBlock) + threadIdx.x : nullptr;
+  // temp buffer of this block: 4 header rows (j_lo, j_hi, T_sat of each lane, one spare), then W rows of edges
+  uint16_t *__restrict__ tmp = d.tmp ? d.tmp + ((int64_t)cj * d.tiles + blockIdx.x) * ((int64_t)(W + kTmpHdrRows) * kBlock) + threadIdx.x : nullptr;
+  if (tmp) {
+    tmp[0] = (uint16_t)j_lo; // W <= 2 * FGMM_MAX_BS + 2 < 65536
+    tmp[kBlock] = (uint16_t)j_hi;
+    tmp[2 * kBlock] = (uint16_t)T_sat;
+    tmp += kTmpHdrRows * kBlock;
+  }
 
   int lead = j_lo - 1, run_start = 0;
   bool allzero = true, nonmono = false;
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
   const bool active = p < hw;
   const int c = d.chan_list ? d.chan_list[cj] : cj;
   TabLatent<MODE, CLAMPED, PT> L;
-  L.load(d, c, active ? p : 0);
+  if (!d.tmp) L.load(d, c, active ? p : 0); // with a temp buffer the fill pass never looks at the parameters
 
   const uint32_t h = active ? d.hdr[(int64_t)cj * hw + p] : 0u;
   const int a_idx = tab_hdr_a(h) + d.max_bs;
@@ -522,8 +529,11 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
   uint32_t T_sat = 0;
   const uint16_t *__restrict__ tmp = nullptr;
   if (d.tmp) {
-    tab_window(L, d.prune, d.max_bs, W, j_lo, j_hi, T_sat);
-    tmp = d.tmp + ((int64_t)cj * d.tiles + blockIdx.x) * ((int64_t)W * kBlock) + threadIdx.x;
+    tmp = d.tmp + ((int64_t)cj * d.tiles + blockIdx.x) * ((int64_t)(W + kTmpHdrRows) * kBlock) + threadIdx.x;
+    j_lo = tmp[0];
+    j_hi = tmp[kBlock];
+    T_sat = tmp[2 * kBlock];
+    tmp += kTmpHdrRows * kBlock;
   }
   auto edge_at = [&](int idx) -> uint32_t {
     if (!tmp) return L.edge(idx);
@@ -532,43 +542,54 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
     return tmp[(int64_t)(idx - j_lo) * kBlock];
   };
 
+  // Entries are fetched 8 at a time before any is used: a lane's loop is a chain of dependent steps, and with one
+  // temp-buffer load per step the kernel would be bound by memory latency times the longest row of the wave.
+  constexpr int CH = 8;
   if (!tab_row_is_ef(cnt, nonmono)) {
     // raw: uint16 entries, padded to a multiple of 4 with the last value
     const uint32_t len4 = (cnt + 3u) & ~3u;
     uint32_t last = 0;
-    for (uint32_t j0 = 0; j0 < len4; j0 += 4) {
-      uint32_t e[4];
+    for (uint32_t j0 = 0; j0 < len4; j0 += CH) {
+      uint32_t e[CH];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (j0 + t < cnt) last = edge_at(a_idx + (int)(j0 + t));
+      for (int t = 0; t < CH; ++t) e[t] = (j0 + t < cnt) ? edge_at(a_idx + (int)(j0 + t)) : 0u;
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        if (j0 + t < cnt) last = e[t];
         e[t] = last;
       }
       *reinterpret_cast<uint2 *>(row + 2 * j0) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+      if (j0 + 4 < len4) *reinterpret_cast<uint2 *>(row + 2 * j0 + 8) = make_uint2(e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
   } else {
     // Elias-Fano, 8 low bits: lows[cnt] (padded to 8), then U 64-bit words with bit ((E_j >> 8) + j) set
     const uint32_t lows_bytes = (cnt + 7u) & ~7u, U = (cnt + 256u + 63u) >> 6;
     unsigned long long *__restrict__ up = reinterpret_cast<unsigned long long *>(row + lows_bytes);
     unsigned long long wcur = 0;
-    uint32_t widx = 0, lowacc = 0;
-    for (uint32_t j = 0; j < cnt; ++j) {
-      const uint32_t E = edge_at(a_idx + (int)j);
-      lowacc |= (E & 0xFFu) << (8u * (j & 3u));
-      if ((j & 3u) == 3u) {
-        *reinterpret_cast<uint32_t *>(row + (j & ~3u)) = lowacc;
-        lowacc = 0;
+    uint32_t widx = 0;
+    for (uint32_t j0 = 0; j0 < lows_bytes; j0 += CH) { // lows_bytes is a multiple of 8 = CH
+      uint32_t e[CH];
+#pragma unroll
+      for (int t = 0; t < CH; ++t) e[t] = (j0 + t < cnt) ? edge_at(a_idx + (int)(j0 + t)) : 0u;
+      uint32_t lo0 = 0, lo1 = 0; // the low bytes of the 8 entries (zero padding past the row)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        lo0 |= (e[t] & 0xFFu) << (8 * t);
+        lo1 |= (e[t + 4] & 0xFFu) << (8 * t);
       }
-      const uint32_t pos = (E >> 8) + j; // strictly increasing: the row is monotone
-      const uint32_t wi = pos >> 6;
-      while (widx < wi) {
-        up[widx++] = wcur;
-        wcur = 0;
+      *reinterpret_cast<uint2 *>(row + j0) = make_uint2(lo0, lo1);
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        if (j0 + t < cnt) {
+          const uint32_t pos = (e[t] >> 8) + j0 + t; // strictly increasing: the row is monotone
+          const uint32_t wi = pos >> 6;
+          while (widx < wi) {
+            up[widx++] = wcur;
+            wcur = 0;
+          }
+          wcur |= 1ull << (pos & 63u);
+        }
       }
-      wcur |= 1ull << (pos & 63u);
-    }
-    for (uint32_t j = cnt & ~3u; j < lows_bytes; j += 4) { // tail of the low bytes + zero padding
-      *reinterpret_cast<uint32_t *>(row + j) = lowacc;
-      lowacc = 0;
     }
     while (widx < U) {
       up[widx++] = wcur;
