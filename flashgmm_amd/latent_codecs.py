@@ -211,35 +211,38 @@ class ChannelGroupsLatentCodec(nn.Module):
         return torch.cat(args, dim=1)
 
     def _get_ctx_params(self, k: int, side_params: Tensor, y_hat_: Tuple[Tensor, ...]) -> Tensor:
+        """parameters group k is coded under: the side parameters, preceded (k > 0) by the channel context computed
+        from the reconstructions of groups 0..k-1 (channel_groups.py:166-173)"""
         if k == 0:
             return side_params
-        ch_ctx_params = self.channel_context[f"y{k}"](self.merge_y(*y_hat_[:k]))
-        return self.merge_params(ch_ctx_params, side_params)
+        return self.merge_params(self.channel_context[f"y{k}"](self.merge_y(*y_hat_[:k])), side_params)
+
+    def _run(self, y_hat: Tensor, side_params: Tensor, code_group):
+        """Groups in order; ``code_group(k, params) -> result dict`` codes one group and its ``"y_hat"`` becomes visible
+        to the later groups through views of the one full-size ``y_hat`` tensor."""
+        views = y_hat.split(self.groups, dim=1)
+        results = []
+        for k in range(len(self.groups)):
+            res = code_group(k, self._get_ctx_params(k, side_params, views))
+            views[k].copy_(res["y_hat"])
+            results.append(res)
+        return results
 
     def compress(self, y: Tensor, side_params: Tensor) -> Dict[str, Any]:
-        y_ = torch.split(y, self.groups, dim=1)
+        parts = torch.split(y, self.groups, dim=1)
         y_hat = torch.zeros_like(y)
-        y_hat_ = y_hat.split(self.groups, dim=1)
-        y_out_ = []
-        for k in range(len(self.groups)):
-            params = self._get_ctx_params(k, side_params, y_hat_)
-            y_out_.append(self.latent_codec[f"y{k}"].compress(y_[k], params))
-            y_hat_[k][:] = y_out_[k]["y_hat"]
-        y_strings_groups = [y_out["strings"] for y_out in y_out_]
-        assert all(len(y_strings_groups[0]) == len(ss) for ss in y_strings_groups)
-        return {"strings": [s for ss in y_strings_groups for s in ss], "shape": [y_out["shape"] for y_out in y_out_],
-                "y_hat": y_hat}
+        results = self._run(y_hat, side_params, lambda k, params: self.latent_codec[f"y{k}"].compress(parts[k], params))
+        per_group = {len(r["strings"]) for r in results}
+        if len(per_group) != 1:
+            raise RuntimeError("every group codec must emit the same number of strings (channel_groups.py:124)")
+        return {"strings": [s for r in results for s in r["strings"]], "shape": [r["shape"] for r in results], "y_hat": y_hat}
 
     def decompress(self, strings: List[Any], shape: List[Tuple[int, ...]], side_params: Tensor, **kwargs: Any) -> Dict[str, Any]:
-        n = 1
-        strings_per_group = len(strings) // len(self.groups)
-        y_shape = (sum(s[0] for s in shape), *shape[0][1:])
-        y_hat = torch.zeros((n, *y_shape), device=side_params.device)
-        y_hat_ = y_hat.split(self.groups, dim=1)
-        for k in range(len(self.groups)):
-            params = self._get_ctx_params(k, side_params, y_hat_)
-            out = self.latent_codec[f"y{k}"].decompress(strings[strings_per_group * k: strings_per_group * (k + 1)], shape[k], params)
-            y_hat_[k][:] = out["y_hat"]
+        per_group = len(strings) // len(self.groups)
+        channels = sum(s[0] for s in shape)
+        y_hat = torch.zeros((1, channels, *shape[0][1:]), device=side_params.device)  # batch 1, as the reference (:139)
+        self._run(y_hat, side_params, lambda k, params: self.latent_codec[f"y{k}"].decompress(
+            strings[per_group * k: per_group * (k + 1)], shape[k], params))
         return {"y_hat": y_hat}
 
     def forward(self, y: Tensor, side_params: Tensor):

@@ -612,3 +612,16 @@ def test_g7_codecs_equal_the_reference_classes(mode):
             s2, shape2 = Cn.unpack(blob, device="cuda")
             assert torch.equal(codec.decompress(s2, shape2, dv(side))["y_hat"], dec["y_hat"]), (name, "container")
             assert len(blob) - sum(len(t[0]) for t in enc["strings"]) == Cn.side_info_bytes(enc["strings"], enc["shape"])
+
+
+def test_rccl_collectives_single_rank():
+    """the collectives of flashgmm_amd.parallel through RCCL with GPU buffers (their multi-rank logic: test_parallel_cpu.py)"""
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "nccl_worker.py"), str(port)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
