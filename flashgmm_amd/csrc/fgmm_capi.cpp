@@ -834,7 +834,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       LAUNCH_TRY(launch_cdftab_fill(dd + i0, i1 - i0, n_ch_max, hw_max, mode, clamped, f16, ctx->fill_stream));
       HIP_TRY(hipEventRecord(ev_fill[g], ctx->fill_stream));
       HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_fill[g], 0));
-      HIP_TRY(hipMemcpyAsync(h_hdrs, ctx->d_ws + items[i0].o_hdr, hdr_total, hipMemcpyDeviceToHost, ctx->copy_stream));
+      if (hdr_total) HIP_TRY(hipMemcpyAsync(h_hdrs, ctx->d_ws + items[i0].o_hdr, hdr_total, hipMemcpyDeviceToHost, ctx->copy_stream));
       if (off) HIP_TRY(hipMemcpyAsync(h_rows, d_rows, off, hipMemcpyDeviceToHost, ctx->copy_stream));
       HIP_TRY(hipEventRecord(ev_landed[g], ctx->copy_stream));
     } else {
@@ -844,7 +844,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         LAUNCH_TRY(launch_cdftab_fill(dpd + k * tail_items, tail_items, n_ch_max, hw_max, mode, clamped, f16, ctx->fill_stream));
         HIP_TRY(hipEventRecord(ev_pfill[k], ctx->fill_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_pfill[k], 0));
-        if (k == 0) HIP_TRY(hipMemcpyAsync(h_hdrs, ctx->d_ws + items[i0].o_hdr, hdr_total, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (k == 0 && hdr_total) HIP_TRY(hipMemcpyAsync(h_hdrs, ctx->d_ws + items[i0].o_hdr, hdr_total, hipMemcpyDeviceToHost, ctx->copy_stream));
         if (piece_off[k + 1] > piece_off[k])
           HIP_TRY(hipMemcpyAsync(h_rows + piece_off[k], d_rows + piece_off[k], piece_off[k + 1] - piece_off[k], hipMemcpyDeviceToHost,
                                  ctx->copy_stream));

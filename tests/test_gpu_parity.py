@@ -391,6 +391,29 @@ def test_batch_of_kodak_halves_full_size(mode):
         assert torch.equal(res[seed][1], torch.round(ys[seed]))
 
 
+@pytest.mark.parametrize("tail", [None, "3", "0"])
+def test_batch_of_ragged_empty_and_tiny_items(oracle, monkeypatch, tail):
+    """one batch mixing full-size items with all-zero ones (empty streams), single-channel / single-position ones and
+    odd sizes: every item must equal its own single-item result and the oracle, whatever part of the decode pipeline
+    (ordinary group, tail-window pieces with fewer channels than pieces) it falls into"""
+    if tail is not None:
+        monkeypatch.setenv("FGMM_TAIL_ITEMS", tail)
+    gmc = GaussianMixtureConditional(K=4, mode="logistic")
+    specs = [(1, (192, 32, 24), 0.1), (2, (5, 3, 3), 1.0), (3, (1, 1, 2), 0.0), (4, (3, 5, 7), 0.0), (5, (17, 1, 1), 0.3),
+             (6, (192, 32, 24), 0.0), (7, (6, 4, 4), 1.0), (8, (2, 2, 2), 0.0), (9, (2, 64, 66), 0.0)]
+    lat = [T.make_latent(seed, M=M, h=h, w=w, clamp=False, zero_frac=zf) for seed, (M, h, w), zf in specs]
+    ys, ss, ms, ws = ([dv(l[k]) for l in lat] for k in range(4))
+    res = gmc.compress_batch(ys, ss, ms, ws)
+    for i, l in enumerate(lat):
+        sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(*l)
+        (b, abs_max, zb), yq = res[i]
+        assert b == oracle.encode_gmm("logistic", sym, s, m, wt) and abs_max == am and zb.tolist() == zbm.tolist(), specs[i]
+        assert np.array_equal(yq.cpu().numpy(), yqn)
+    outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+    for i in range(len(lat)):
+        assert outs[i].shape == ys[i].shape and torch.equal(outs[i], res[i][1]), specs[i]
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_stacked_batch_equals_item_lists(dtype):
     """Items of one shape given as ONE tensor each ([N, M, h, w] / [N, K*M, h, w], batch-strided views included)
