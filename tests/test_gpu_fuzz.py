@@ -45,6 +45,33 @@ def test_fuzz_shapes_modes_dtypes(oracle):
             assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq), tag
 
 
+def test_fuzz_symtab_grid_forms(oracle):
+    """the three launch forms of the encode kernel — linear waves (every hw a multiple of 256), per-channel blocks with
+    16-byte loads (hw % 4 == 0), one symbol per lane (odd hw) — on batches, both parameter dtypes, all modes"""
+    rng = np.random.default_rng(77)
+    case = 0
+    for (h, w) in [(16, 16), (16, 32), (32, 24), (32, 32), (40, 32), (13, 20), (2, 257), (64, 64), (1, 256), (9, 7)]:
+        for f16 in (False, True):
+            mode = MODES[case % 3]
+            case += 1
+            Ms = [int(rng.integers(1, 25)) for _ in range(3)]
+            lat = [T.make_latent(4000 + 10 * case + i, M=M, h=h, w=w, clamp=False, zero_frac=float(rng.choice([0, 0.3])))
+                   for i, M in enumerate(Ms)]
+            if f16:
+                lat = [(y,) + tuple(T.to_float16_planes(sg, mu, pi)) for y, sg, mu, pi in lat]
+            gmc = GaussianMixtureConditional(K=4, mode=mode)
+            ys, ss, ms, ws = ([dv(l[k]) for l in lat] for k in range(4))
+            res = gmc.compress_batch(ys, ss, ms, ws)
+            for i, l in enumerate(lat):
+                sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(l[0], *(a.astype(np.float32) for a in l[1:]))
+                (b, abs_max, zb), yq = res[i]
+                tag = (h, w, Ms[i], mode, f16)
+                assert b == oracle.encode_gmm(mode, sym, s, m, wt) and abs_max == am and zb.tolist() == zbm.tolist(), tag
+            outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+            for i in range(3):
+                assert torch.equal(outs[i], res[i][1]), (h, w, Ms[i], mode, f16)
+
+
 def test_concurrent_callers_share_one_context(oracle):
     """four Python threads compress / decompress on one GPU at once: calls serialise on the context, results stay right"""
     cases = []
