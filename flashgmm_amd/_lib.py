@@ -82,6 +82,7 @@ SIGNATURES = {
     "fgmm_selftest_saturation": (_i, [_p, _i, C.POINTER(C.c_uint64)]),
     "fgmm_selftest_fastmath": (_i, [_p, _i, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "fgmm_rans_encode_symtab": (_i, [_p, _p, _i64, _pp, _psz]),
+    "fgmm_rans_encode_symtab2": (_i, [_p, _p, _i64, _p, _p, _i64, _pp, _psz, _pp, _psz]),
     "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, _i64, _i32, _p]),
     # table path (z hyper-latent coder), host only
     "fgmm_encode_with_indexes": (_i, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _pp, _psz]),

@@ -112,6 +112,9 @@ int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream
 // returns 0 or an fgmm_status; *out malloc'ed
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len);
+// two streams by one thread, interleaved (each output identical to rans_encode_symtab's)
+int rans_encode_symtab2(const uint32_t *const packed[2], const int32_t *const symbols[2], const int64_t n[2],
+                        const int64_t n_bypass_hint[2], uint8_t **out[2], size_t *out_len[2]);
 // Tables that reach the host in pieces: after piece k has landed, the headers and rows of the first end[k] latents
 // are valid (end[nseg-1] = n), the rows of piece k starting at base[k].  Piece 0 has landed before the decoder is called; wait(arg, k) blocks until piece k
 // (k >= 1) has.  The decoder walks the latents in order, so it only ever waits for the next piece.

@@ -71,10 +71,13 @@ struct Enc {
   inline void put(uint32_t start, uint32_t freq) { // Rans64EncPut(start, freq, 16)
     const uint64_t x_max = (uint64_t)freq << 47;   // ((RANS64_L >> 16) << 32) * freq
     uint64_t xx = x;
-    if (xx >= x_max) {
-      *--ptr = (uint32_t)xx;
-      xx >>= 32;
-    }
+    // renormalisation without a branch (it is taken for ~1 symbol in 10, unpredictably): the word is always stored
+    // below the write pointer — there is always room, the buffers are sized for one word per entry — and the pointer
+    // moves only if it was due.  2.8 -> 2.4 ns/symbol on Zen 5, and what lets two streams share a core (below).
+    const bool renorm = xx >= x_max;
+    ptr[-1] = (uint32_t)xx;
+    ptr -= renorm;
+    xx = renorm ? (xx >> 32) : xx;
     const Rcp &r = g_rcp[freq];
     const uint64_t q = mulhi(xx, r.rcp) >> r.shift;
     x = xx + start + r.bias_add + q * (65536u - freq); // == ((xx / freq) << 16) + xx % freq + start
@@ -92,17 +95,48 @@ struct Enc {
 
 } // namespace
 
+// one symbol of the reversed walk over a GPU-built table (rans_interface.cpp:569-583)
+static inline void encode_entry(Enc &e, uint32_t ent, const int32_t *symbols, int64_t i) {
+  const uint32_t freq = ent >> 16;
+  if (__builtin_expect(freq != 0, 1)) {
+    e.put(ent & 0xFFFFu, freq);
+    return;
+  }
+  // bypass escape; forward order was [sentinel {65535,1}] [count] [nibble 0 .. nibble k-1]  (:519-551)
+  const int32_t value = symbols ? symbols[i] : (int32_t)(int16_t)(uint16_t)(ent & 0xFFFFu);
+  const uint32_t raw = (uint32_t)value;
+  int nn = 0;
+  for (uint32_t t = raw; t != 0; t >>= kBypassBits) ++nn; // <= 8
+  for (int j = nn - 1; j >= 0; --j) e.put_bits((raw >> (j * kBypassBits)) & kMaxBypassVal);
+  e.put_bits((uint32_t)nn); // nn <= 8 < 15: the count is always a single nibble (:538-543)
+  e.put(kMaxCdf, 1);
+}
+static int64_t count_bypass(const uint32_t *packed, int64_t n) {
+  int64_t nb = 0;
+  for (int64_t i = 0; i < n; ++i) nb += (packed[i] >> 16) == 0;
+  return nb;
+}
+// every entry of the reference's _syms emits at most one 32-bit word; a bypassed symbol is 1 + 1 + <=8 entries;
+// +16: the flush words and the word the branch-free renormalisation always stores below the pointer
+static inline size_t encode_words(int64_t n, int64_t nb) { return (size_t)n + (size_t)nb * 10 + 16; }
+static int finish_stream(Enc &e, uint32_t *end, uint8_t **out, size_t *out_len) { // Rans64EncFlush + copy out
+  e.ptr -= 2;
+  e.ptr[0] = (uint32_t)(e.x >> 0);
+  e.ptr[1] = (uint32_t)(e.x >> 32);
+  const size_t nbytes = (size_t)(end - e.ptr) * sizeof(uint32_t);
+  uint8_t *o = (uint8_t *)malloc(nbytes);
+  if (!o) return FGMM_ERR_NOMEM;
+  memcpy(o, e.ptr, nbytes);
+  *out = o;
+  *out_len = nbytes;
+  return FGMM_OK;
+}
+
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len) {
   std::call_once(g_rcp_once, init_rcp);
   if (n < 0 || !out || !out_len || (n > 0 && !packed)) return FGMM_ERR_INVALID;
-  int64_t nb = n_bypass_hint;
-  if (nb < 0) {
-    nb = 0;
-    for (int64_t i = 0; i < n; ++i) nb += (packed[i] >> 16) == 0;
-  }
-  // every entry of the reference's _syms emits at most one 32-bit word; a bypassed symbol is 1 + 1 + <=8 entries
-  const size_t nwords = (size_t)n + (size_t)nb * 10 + 16;
+  const size_t nwords = encode_words(n, n_bypass_hint < 0 ? count_bypass(packed, n) : n_bypass_hint);
   // worst-case sized scratch, kept per thread: a fresh 600 KB malloc per stream is an mmap + page faults + munmap
   static thread_local std::vector<uint32_t> scratch;
   try {
@@ -110,40 +144,51 @@ int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n
   } catch (const std::bad_alloc &) {
     return FGMM_ERR_NOMEM;
   }
-  uint32_t *const buf = scratch.data();
-  uint32_t *const end = buf + nwords;
+  uint32_t *const end = scratch.data() + nwords;
   Enc e{kRansL, end}; // Rans64EncInit
-
   for (int64_t i = n - 1; i >= 0; --i) { // reversed _syms (rans_interface.cpp:569)
     if ((i & 15) == 15) __builtin_prefetch(packed + i - 512); // the table was just DMA-written: not in any cache
-    const uint32_t ent = packed[i];
-    const uint32_t freq = ent >> 16;
-    if (__builtin_expect(freq != 0, 1)) {
-      e.put(ent & 0xFFFFu, freq);
-      continue;
-    }
-    // bypass escape; forward order was [sentinel {65535,1}] [count] [nibble 0 .. nibble k-1]  (:519-551)
-    const int32_t value = symbols ? symbols[i] : (int32_t)(int16_t)(uint16_t)(ent & 0xFFFFu);
-    const uint32_t raw = (uint32_t)value;
-    int nn = 0;
-    for (uint32_t t = raw; t != 0; t >>= kBypassBits) ++nn; // <= 8
-    for (int j = nn - 1; j >= 0; --j) e.put_bits((raw >> (j * kBypassBits)) & kMaxBypassVal);
-    e.put_bits((uint32_t)nn); // nn <= 8 < 15: the count is always a single nibble (:538-543)
-    e.put(kMaxCdf, 1);
+    encode_entry(e, packed[i], symbols, i);
   }
-  // Rans64EncFlush
-  e.ptr -= 2;
-  e.ptr[0] = (uint32_t)(e.x >> 0);
-  e.ptr[1] = (uint32_t)(e.x >> 32);
-  const size_t nbytes = (size_t)(end - e.ptr) * sizeof(uint32_t);
-  uint8_t *o = (uint8_t *)malloc(nbytes);
-  if (!o) {
+  return finish_stream(e, end, out, out_len);
+}
+
+// Two independent bitstreams coded by one thread, symbol by symbol in turn.  A stream's state update is a chain of
+// ~11 dependent cycles per symbol; two chains fill the core's issue slots: 1.47 ns/symbol against 2.4 for one stream
+// alone (Zen 5, scripts/enc_ilp.cpp).  Each stream's output is exactly what rans_encode_symtab gives.
+int rans_encode_symtab2(const uint32_t *const packed[2], const int32_t *const symbols[2], const int64_t n[2],
+                        const int64_t n_bypass_hint[2], uint8_t **out[2], size_t *out_len[2]) {
+  std::call_once(g_rcp_once, init_rcp);
+  size_t nwords[2];
+  for (int k = 0; k < 2; ++k) {
+    if (n[k] < 0 || !out[k] || !out_len[k] || (n[k] > 0 && !packed[k])) return FGMM_ERR_INVALID;
+    nwords[k] = encode_words(n[k], n_bypass_hint[k] < 0 ? count_bypass(packed[k], n[k]) : n_bypass_hint[k]);
+  }
+  static thread_local std::vector<uint32_t> scratch;
+  try {
+    if (scratch.size() < nwords[0] + nwords[1]) scratch.resize(nwords[0] + nwords[1]);
+  } catch (const std::bad_alloc &) {
     return FGMM_ERR_NOMEM;
   }
-  memcpy(o, e.ptr, nbytes);
-  *out = o;
-  *out_len = nbytes;
-  return FGMM_OK;
+  uint32_t *const end0 = scratch.data() + nwords[0], *const end1 = end0 + nwords[1];
+  Enc e0{kRansL, end0}, e1{kRansL, end1};
+  int64_t i0 = n[0] - 1, i1 = n[1] - 1;
+  for (; i0 >= 0 && i1 >= 0; --i0, --i1) {
+    if ((i0 & 15) == 15) {
+      __builtin_prefetch(packed[0] + i0 - 512);
+      __builtin_prefetch(packed[1] + i1 - 512);
+    }
+    encode_entry(e0, packed[0][i0], symbols[0], i0);
+    encode_entry(e1, packed[1][i1], symbols[1], i1);
+  }
+  for (; i0 >= 0; --i0) encode_entry(e0, packed[0][i0], symbols[0], i0); // the longer stream's remainder
+  for (; i1 >= 0; --i1) encode_entry(e1, packed[1][i1], symbols[1], i1);
+  int rc = finish_stream(e0, end0, out[0], out_len[0]);
+  if (rc == FGMM_OK && (rc = finish_stream(e1, end1, out[1], out_len[1])) != FGMM_OK) {
+    free(*out[0]);
+    *out[0] = nullptr;
+  }
+  return rc;
 }
 
 namespace {
@@ -649,6 +694,17 @@ extern "C" {
 int fgmm_rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, uint8_t **out,
                             size_t *out_len) {
   return fgmm::rans_encode_symtab(packed, symbols_or_null, n, -1, out, out_len);
+}
+
+int fgmm_rans_encode_symtab2(const uint32_t *packed0, const int32_t *symbols0_or_null, int64_t n0, const uint32_t *packed1,
+                             const int32_t *symbols1_or_null, int64_t n1, uint8_t **out0, size_t *out0_len, uint8_t **out1,
+                             size_t *out1_len) {
+  const uint32_t *const packed[2] = {packed0, packed1};
+  const int32_t *const syms[2] = {symbols0_or_null, symbols1_or_null};
+  const int64_t n[2] = {n0, n1}, nb[2] = {-1, -1};
+  uint8_t **out[2] = {out0, out1};
+  size_t *len[2] = {out0_len, out1_len};
+  return fgmm::rans_encode_symtab2(packed, syms, n, nb, out, len);
 }
 
 int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint32_t *hdr, const uint8_t *pool,

@@ -206,6 +206,12 @@ int fgmm_selftest_fastmath(fgmm_ctx *ctx, int which, uint64_t n, uint64_t seed, 
  * -> bitstream.  BufferedRansEncoder::flush semantics (rans_interface.cpp:557-585). */
 int fgmm_rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, uint8_t **out,
                             size_t *out_len);
+/* Two independent tables -> two bitstreams, coded by the calling thread in turn symbol by symbol (the batched paths use
+ * this when there are more bitstreams than workers: two dependency chains share a core).  out[k] is byte for byte what
+ * fgmm_rans_encode_symtab returns for table k. */
+int fgmm_rans_encode_symtab2(const uint32_t *packed0, const int32_t *symbols0_or_null, int64_t n0, const uint32_t *packed1,
+                             const int32_t *symbols1_or_null, int64_t n1, uint8_t **out0, size_t *out0_len, uint8_t **out1,
+                             size_t *out1_len);
 
 /* Host, integer only: edge tables -> symbols; the reference's bisection with every float evaluation replaced
  * by a look-up in F_i. */

@@ -88,6 +88,50 @@ def test_host_encoder_small_and_wide_bypass(oracle, mode):
         assert host_encode_symtab(L, packed, sym).hex() == gold[name][mode]["hex"], name  # incl. 2^30, -2^31 bypass
 
 
+def test_host_pair_encoder_equals_single(oracle):
+    """fgmm_rans_encode_symtab2 (two streams coded in turn by one thread): each output == the single-stream coder's,
+    for equal and unequal lengths, empty tables, dense bypass entries and wide (raw-symbol) bypass values"""
+    import ctypes as C
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    L = _lib.lib()
+    tabs = []
+    for seed, (M, h, w) in ((1234, (192, 32, 24)), (3, (40, 9, 7)), (4, (7, 5, 3))):
+        y, sg, mu, pi = T.make_latent(seed, M=M, h=h, w=w)
+        sym, s, m, wt, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+        tabs.append((oracle.symtab("as", sym, s, m, wt), None))
+    for name, (sym, s, m, wt) in mg.g3_cases().items():  # n = 0, 1, 17, 1000; forced bypass incl. 2^30 and -2^31
+        tabs.append((oracle.symtab("polya", sym, s, m, wt), sym))
+    rng = np.random.default_rng(5)
+    dense = rng.integers(0, 1 << 32, 5000, dtype=np.uint64).astype(np.uint32)
+    dense[rng.random(5000) < 0.3] &= 0xFFFF  # 30 % bypass entries (range == 0)
+    dense[(dense >> 16) != 0] = (dense[(dense >> 16) != 0] & 0xFFFF0FFF)  # keep start + range <= 65535 plausible
+    ok = ((dense & 0xFFFF).astype(np.int64) + (dense >> 16).astype(np.int64)) <= 65535
+    dense[~ok] = 0x00010000
+    tabs.append((dense, None))
+    single = [host_encode_symtab(L, p, sy) for p, sy in tabs]
+
+    def ptr(a):
+        return None if a is None else np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+
+    for i in range(len(tabs)):
+        for j in range(len(tabs)):
+            (p0, s0), (p1, s1) = tabs[i], tabs[j]
+            p0, p1 = np.ascontiguousarray(p0, np.uint32), np.ascontiguousarray(p1, np.uint32)
+            s0 = None if s0 is None else np.ascontiguousarray(s0, np.int32)
+            s1 = None if s1 is None else np.ascontiguousarray(s1, np.int32)
+            o0, o1, l0, l1 = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+            rc = L.fgmm_rans_encode_symtab2(ptr(p0), ptr(s0), len(p0), ptr(p1), ptr(s1), len(p1), C.byref(o0), C.byref(l0),
+                                            C.byref(o1), C.byref(l1))
+            assert rc == 0
+            b0, b1 = C.string_at(o0, l0.value), C.string_at(o1, l1.value)
+            L.fgmm_free(o0); L.fgmm_free(o1)
+            assert b0 == single[i] and b1 == single[j], (i, j)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_host_decoder_from_oracle_tables(oracle, mode):
     L = _lib.lib()
