@@ -1352,7 +1352,7 @@ int fgmm_ckbd_embed(fgmm_ctx *ctx, void *stream, const void *src, void *dst, int
 }
 
 int fgmm_selftest_fastmath(fgmm_ctx *ctx, int which, uint64_t n, uint64_t seed, uint64_t *n_bad_out) {
-  if (!ctx || which < 0 || which > 5 || !n_bad_out) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (!ctx || which < 0 || which > 6 || !n_bad_out) return fail(FGMM_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   int rc;

@@ -724,6 +724,12 @@ __global__ __launch_bounds__(kBlock) void fastmath_selftest_kernel(int which, un
       const float x = k <= top ? bits2f((uint32_t)k) : (k == (uint64_t)top + 1 ? -1.0f : (k == (uint64_t)top + 2 ? 0.0f : bits2f(0x7FC00000u)));
       bad += !same_f32(sqrt_core(x), __builtin_sqrtf(x));
     }
+  } else if (which == 6) { // sqrt_unit over {0} U [2^-24, 1]
+    const uint32_t bot = f2bits(0x1p-24f), top = f2bits(1.0f);
+    for (uint64_t i = t0; i <= (uint64_t)(top - bot) + 1; i += stride) {
+      const float x = i <= (uint64_t)(top - bot) ? bits2f(bot + (uint32_t)i) : 0.0f;
+      bad += !same_f32(sqrt_unit(x), __builtin_sqrtf(x));
+    }
   } else if (which == 3) {
     bad = phi_fast_vs_plain<MODE_POLYA>(t0, stride);
   } else if (which == 4) {

@@ -117,6 +117,17 @@ __device__ __forceinline__ float sqrt_core(float x) {
   return s;
 }
 
+// sqrt for x in {+0} U [2^-24, 1] (all Polya's 1 - e can be on the guarded path): Markstein's final step — from
+// y ~ 1/sqrt(x) (v_rsq_f32), s0 = x*y and h = y/2, one fused correction s0 + (x - s0^2) * h.  Two instructions fewer
+// than the probe form; equality with sqrtf over the whole domain is checked by fgmm_selftest_fastmath(6).
+__device__ __forceinline__ float sqrt_unit(float x) {
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s0 = x * y, h = 0.5f * y;
+  const float r = __builtin_fmaf(-s0, s0, x);
+  const float s = __builtin_fmaf(r, h, s0);
+  return (x == 0.0f) ? 0.0f : s;
+}
+
 // FAST = false: plain IEEE '/' and sqrtf, any input.  FAST = true: the cores above, for finite |z| < 2^48 (the
 // callers' guard): identical results, checked exhaustively over that domain (fgmm_selftest_fastmath 3..5).
 template <int MODE, bool FAST> struct Phi;
@@ -127,7 +138,7 @@ template <bool FAST> struct Phi<MODE_POLYA, FAST> {
     const float c = -2.0f / 3.14159265358979323846f; // folded in binary32, as the reference's constant is
     const float e = FAST ? exp_nonpos(c * (z * z)) : exp_ref(c * (z * z));
     // 1 - e is +0, >= 2^-24, or (NaN path: e = exp(+88.4)) hugely negative -> NaN: always in sqrt_core's domain
-    float s = FAST ? sqrt_core(1.0f - e) : __builtin_sqrtf(1.0f - e);
+    float s = FAST ? sqrt_unit(1.0f - e) : __builtin_sqrtf(1.0f - e); // FAST: e in [0, 1], so 1 - e in {0} U [2^-24, 1]
     s = bits2f((f2bits(z) & 0x80000000u) | (f2bits(s) & 0x7fffffffu)); // copysign_ps(z, s)
     // 0.5 * (1 + s): the product is an exact scaling (1 + s is 0 or >= 2^-24), so one fma rounds the same way
     return FAST ? __builtin_fmaf(0.5f, s, 0.5f) : 0.5f * (1.0f + s);

@@ -199,7 +199,8 @@ int fgmm_selftest_saturation(fgmm_ctx *ctx, int mode, uint64_t *n_bad_out);
 /* GPU self-test of the hand-expanded correctly-rounded cores (fgmm_math.h) against the compiler's IEEE '/' and
  * sqrtf: which = 0 sqrt (every binary32 in [0,2]), 1 division by a clamped sigma (n hashed pairs from `seed`),
  * 2 reciprocal of d >= 1 (every binary32 in [1,+inf]); which = 3, 4, 5: the kernels' slimmed Phi evaluation against
- * the literal one (mode which - 3) for every binary32 |z| < 2^48.  *n_bad_out must come back 0. */
+ * the literal one (mode which - 3) for every binary32 |z| < 2^48; which = 6: the Markstein-step sqrt of the Polya
+ * path for every binary32 in {0} U [2^-24, 1].  *n_bad_out must come back 0. */
 int fgmm_selftest_fastmath(fgmm_ctx *ctx, int which, uint64_t n, uint64_t seed, uint64_t *n_bad_out);
 
 /* Host, integer only: symbol table (+ raw symbols, needed only where range == 0 and abs(symbol) >= 32768)

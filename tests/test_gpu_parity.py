@@ -262,7 +262,7 @@ def test_fastmath_cores_equal_ieee():
     sqrt and reciprocal exhaustively over their domains, division on 4e9 hashed pairs; the kernels' slimmed Phi
     (no upper exp clamp, ldexp, fused 0.5*(1+s)) equals the literal one for every binary32 |z| < 2^48, all modes"""
     L, ctx = _lib.lib(), _lib.ctx(0)
-    for which, n in ((0, 0), (2, 0), (1, 1 << 32), (3, 0), (4, 0), (5, 0)):
+    for which, n in ((0, 0), (2, 0), (1, 1 << 32), (3, 0), (4, 0), (5, 0), (6, 0)):
         for seed in ((1, 2) if which == 1 else (0,)):
             bad = C.c_uint64(99)
             _lib.check(L.fgmm_selftest_fastmath(ctx, which, n, seed, C.byref(bad)))
