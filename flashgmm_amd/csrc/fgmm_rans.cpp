@@ -396,6 +396,7 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
   uint16_t *scratch = nullptr; // an EF row expanded for the (rare) bisection replay
   size_t scratch_cap = 0;
 
+  static const int kPf = getenv("FGMM_DEC_PREFETCH") ? atoi(getenv("FGMM_DEC_PREFETCH")) : 1024; // bytes ahead (dev: A/B)
   const uint8_t *rowp = pool; // rows lie in latent order: the offset is a running sum, never stored
   int64_t landed = land ? (int64_t)land->end[0] : n; // latents whose header and row are on the host
   int piece = 1;
@@ -412,8 +413,8 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
         rowp = land->base[piece++];
       }
     }
-    __builtin_prefetch(rowp + 512);
-    __builtin_prefetch(rowp + 576);
+    __builtin_prefetch(rowp + kPf);
+    __builtin_prefetch(rowp + kPf + 64);
     const uint32_t h = hdr[i];
     const int32_t a = tab_hdr_a(h), cnt = (int32_t)tab_hdr_cnt(h);
     const uint32_t nonmono = tab_hdr_nonmono(h);
