@@ -60,10 +60,10 @@ struct DecDesc {
   unsigned long long *blk_off;   // [n_ch*tiles] byte offset of each block's first row
 };
 
-// ---- decode-side table format v2 (documented in include/flashgmm_amd.h) -------------------------------------
+// ---- decode-side table format v3 (documented in include/flashgmm_amd.h) -------------------------------------
 //   hdr  (uint32): int16 a | cnt << 16 (15 bits) | nonmono << 31
-//   rows in latent order, each 8-byte aligned, no stored offset:
-//     raw (cnt < 64 or nonmono): uint16[round4(cnt)], padded with the last value
+//   rows in latent order, each 4-byte aligned, no stored offset:
+//     raw (cnt < 64 or nonmono): uint16[round2(cnt)], padded with the last value
 //     EF  (cnt >= 64, monotone): uint8 lows[round8(cnt)] ; uint64 upper[U], U = ceil((cnt + 256) / 64),
 //                                bit ((E_j >> 8) + j) set for every entry j
 constexpr int kMaxPieces = 8; // FGMM_MAX_PIECES
@@ -80,7 +80,7 @@ FGMM_HD static inline uint32_t tab_hdr_cnt(uint32_t h) { return (h >> 16) & 0x7F
 FGMM_HD static inline uint32_t tab_hdr_nonmono(uint32_t h) { return h >> 31; }
 FGMM_HD static inline bool tab_row_is_ef(uint32_t cnt, uint32_t nonmono) { return cnt >= kTabEfMin && !nonmono; }
 FGMM_HD static inline uint32_t tab_row_bytes(uint32_t cnt, uint32_t nonmono) {
-  return tab_row_is_ef(cnt, nonmono) ? ((cnt + 7u) & ~7u) + 8u * ((cnt + 256u + 63u) >> 6) : 2u * ((cnt + 3u) & ~3u);
+  return tab_row_is_ef(cnt, nonmono) ? ((cnt + 7u) & ~7u) + 8u * ((cnt + 256u + 63u) >> 6) : 2u * ((cnt + 1u) & ~1u);
 }
 
 // ---- kernel launchers (fgmm_kernels.hip); stream is a hipStream_t; all return hipError_t as int ----------

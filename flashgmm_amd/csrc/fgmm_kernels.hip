@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void cdf_pair_kernel(const int32_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Decode-side edge tables (format v2, include/flashgmm_amd.h).  Lane = latent.  Three launches per group of items:
+// Decode-side edge tables (format v3, include/flashgmm_amd.h).  Lane = latent.  Three launches per group of items:
 //   cdftab_count_kernel  find, exactly, the window outside which F_i is constant (leading zeros, trailing constant
 //                        run, non-monotone flag) -> 4-byte header; row byte length -> per-block sums
 //   cdftab_scan_kernel   exclusive scan of the block sums (one block per item) -> block offsets, total bytes
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
   __shared__ uint32_t s_tmp[kBlock / 64];
   const uint32_t ex = block_scan_excl(bytes, s_tmp);
   if (!active) return;
-  uint8_t *__restrict__ row = d.pool + d.blk_off[(int64_t)cj * d.tiles + blockIdx.x] + ex; // 8-byte aligned
+  uint8_t *__restrict__ row = d.pool + d.blk_off[(int64_t)cj * d.tiles + blockIdx.x] + ex; // 4-byte aligned
   // the row's entries: what the count pass left in the temp buffer (outside its evaluation window the entries are
   // the saturated constants), or a second evaluation when there is no temp buffer
   const int W = 2 * d.max_bs + 2;
@@ -546,10 +546,10 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
   // temp-buffer load per step the kernel would be bound by memory latency times the longest row of the wave.
   constexpr int CH = 8;
   if (!tab_row_is_ef(cnt, nonmono)) {
-    // raw: uint16 entries, padded to a multiple of 4 with the last value
-    const uint32_t len4 = (cnt + 3u) & ~3u;
+    // raw: uint16 entries, padded to an even count with the last value (rows are 4-byte aligned)
+    const uint32_t len2 = (cnt + 1u) & ~1u;
     uint32_t last = 0;
-    for (uint32_t j0 = 0; j0 < len4; j0 += CH) {
+    for (uint32_t j0 = 0; j0 < len2; j0 += CH) {
       uint32_t e[CH];
 #pragma unroll
       for (int t = 0; t < CH; ++t) e[t] = (j0 + t < cnt) ? edge_at(a_idx + (int)(j0 + t)) : 0u;
@@ -558,13 +558,18 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
         if (j0 + t < cnt) last = e[t];
         e[t] = last;
       }
-      *reinterpret_cast<uint2 *>(row + 2 * j0) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
-      if (j0 + 4 < len4) *reinterpret_cast<uint2 *>(row + 2 * j0 + 8) = make_uint2(e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+#pragma unroll
+      for (int t = 0; t < CH; t += 2)
+        if (j0 + t < len2) *reinterpret_cast<uint32_t *>(row + 2 * (j0 + t)) = e[t] | (e[t + 1] << 16);
     }
   } else {
     // Elias-Fano, 8 low bits: lows[cnt] (padded to 8), then U 64-bit words with bit ((E_j >> 8) + j) set
     const uint32_t lows_bytes = (cnt + 7u) & ~7u, U = (cnt + 256u + 63u) >> 6;
-    unsigned long long *__restrict__ up = reinterpret_cast<unsigned long long *>(row + lows_bytes);
+    uint32_t *__restrict__ up32 = reinterpret_cast<uint32_t *>(row + lows_bytes); // the 64-bit words, as two halves each
+    auto put_word = [&](uint32_t wi, unsigned long long w) {
+      up32[2 * wi] = (uint32_t)w;
+      up32[2 * wi + 1] = (uint32_t)(w >> 32);
+    };
     unsigned long long wcur = 0;
     uint32_t widx = 0;
     for (uint32_t j0 = 0; j0 < lows_bytes; j0 += CH) { // lows_bytes is a multiple of 8 = CH
@@ -577,14 +582,15 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
         lo0 |= (e[t] & 0xFFu) << (8 * t);
         lo1 |= (e[t + 4] & 0xFFu) << (8 * t);
       }
-      *reinterpret_cast<uint2 *>(row + j0) = make_uint2(lo0, lo1);
+      reinterpret_cast<uint32_t *>(row + j0)[0] = lo0; // rows are only 4-byte aligned
+      reinterpret_cast<uint32_t *>(row + j0)[1] = lo1;
 #pragma unroll
       for (int t = 0; t < CH; ++t) {
         if (j0 + t < cnt) {
           const uint32_t pos = (e[t] >> 8) + j0 + t; // strictly increasing: the row is monotone
           const uint32_t wi = pos >> 6;
           while (widx < wi) {
-            up[widx++] = wcur;
+            put_word(widx++, wcur);
             wcur = 0;
           }
           wcur |= 1ull << (pos & 63u);
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
       }
     }
     while (widx < U) {
-      up[widx++] = wcur;
+      put_word(widx++, wcur);
       wcur = 0;
     }
   }

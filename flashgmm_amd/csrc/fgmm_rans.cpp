@@ -282,9 +282,17 @@ __attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *r
 // ---- Elias-Fano rows (8 low bits): lows[round8(cnt)] then U words whose bit ((E_j >> 8) + j) is set -----------
 // Bucket b (entries whose high byte is b) is a run of ones followed by one zero; zero #b sits at bit
 // b + (number of entries with high byte <= b).
+struct Up64 { // the unary high parts: 64-bit words that are only 4-byte aligned in the pool
+  const uint8_t *p;
+  inline uint64_t operator[](int64_t w) const {
+    uint64_t v;
+    memcpy(&v, p + 8 * w, 8);
+    return v;
+  }
+};
 struct EfRow {
   const uint8_t *lows;
-  const uint64_t *up;
+  Up64 up;
   int32_t cnt;
   int32_t U;
 };
@@ -442,7 +450,7 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
         }
         if (!done) value = bisect_reference(Row{row, a, cnt}, cf, max_bs, &start, &freq);
       } else {
-        const EfRow r{row_bytes, reinterpret_cast<const uint64_t *>(row_bytes + (((uint32_t)cnt + 7u) & ~7u)), cnt,
+        const EfRow r{row_bytes, Up64{row_bytes + (((uint32_t)cnt + 7u) & ~7u)}, cnt,
                       (int32_t)(((uint32_t)cnt + 256u + 63u) >> 6)};
         int32_t j;
         if (__builtin_expect(ef_bracket(r, cf, &j, &start, &freq), 1)) {

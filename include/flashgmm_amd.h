@@ -179,12 +179,12 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
  * every mixture component is provably saturated — fgmm_selftest_saturation) and store it:
  *   hdr[i] (uint32) = int16 a | cnt << 16 (15 bits) | nonmono << 31
  *   row i  = F_i[a .. a+cnt);   F_i[v < a] = 0,   F_i[v >= a+cnt] = the row's last entry
- * Rows lie in LATENT ORDER in `pool`, 8-byte aligned, with no stored offset (row i+1 starts where row i ends):
- *   cnt < 64 or nonmono : uint16[round4(cnt)], padded with the last value              (2*round4(cnt) bytes)
+ * Rows lie in LATENT ORDER in `pool`, 4-byte aligned, with no stored offset (row i+1 starts where row i ends):
+ *   cnt < 64 or nonmono : uint16[round2(cnt)], padded with the last value              (2*round2(cnt) bytes)
  *   cnt >= 64, monotone : Elias-Fano with 8 low bits: uint8 lows[round8(cnt)], then uint64 upper[U],
  *                         U = ceil((cnt + 256) / 64), bit ((F >> 8) + j) set for entry j  (round8(cnt) + 8U bytes)
  * `nonmono` is set when the row decreases somewhere.  hdr: device uint32[n]; pool: device bytes; pool_used: device
- * uint64[1] = bytes written.  pool_cap >= n * 2 * round4(2*max_bs + 2) always suffices. */
+ * uint64[1] = bytes written.  pool_cap >= n * 2 * round2(2*max_bs + 2) always suffices. */
 #define FGMM_TAB_NO_PRUNE 1 /* flags: evaluate all of F_i instead of skipping its saturated tails (A/B testing) */
 #define FGMM_TAB_CLAMP 2    /* flags: clamp sigma to [0.11, 256] first (the entropy-model path's kernel variant) */
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,

@@ -18,12 +18,12 @@ def row_is_ef(cnt: int, nonmono: int) -> bool:
 def row_bytes(cnt: int, nonmono: int) -> int:
     if row_is_ef(cnt, nonmono):
         return ((cnt + 7) & ~7) + 8 * ((cnt + 256 + 63) >> 6)
-    return 2 * ((cnt + 3) & ~3)
+    return 2 * ((cnt + 1) & ~1)
 
 
 def trim_full_table(tab: np.ndarray, max_bs: int):
     """full table [n, W=2*max_bs+2] (F_i[v], v=-max_bs..max_bs+1) -> (hdr uint32[n], pool uint8[...], used bytes),
-    format v2 of include/flashgmm_amd.h exactly as the cdftab kernels lay it out."""
+    format v3 of include/flashgmm_amd.h exactly as the cdftab kernels lay it out."""
     n, W = tab.shape
     assert W == 2 * max_bs + 2
     hdr = np.zeros(n, np.uint32)
@@ -49,7 +49,7 @@ def trim_full_table(tab: np.ndarray, max_bs: int):
             up = np.packbits(bits.reshape(U, 64)[:, ::-1], axis=1).view(">u8").astype("<u8").reshape(-1)
             chunks += [lows, up.view(np.uint8)]
         else:
-            pad = (-cnt) % 4
+            pad = (-cnt) % 2
             chunks.append(np.concatenate([row, np.full(pad, row[-1])]).astype("<u2").view(np.uint8))
     used = sum(len(c) for c in chunks)
     pool = np.concatenate(chunks + [np.zeros(128, np.uint8)]) if chunks else np.zeros(128, np.uint8)
