@@ -541,7 +541,8 @@ struct DecItem {
   size_t o_list = 0, o_rank = 0, o_hdr = 0, o_used = 0, o_bsum = 0, o_boff = 0;
   int32_t tiles = 0;
   size_t hdr_bytes = 0;                   // header array, rounded up to 256 B
-  const uint32_t *h_hdr = nullptr;        // pinned: headers
+  const char *h_hdr = nullptr;            // pinned: headers (uint32, or uint16 when hdr16)
+  bool hdr16 = false;                     // the item's headers travel in the 2-byte form
   char *h_out = nullptr;                  // pinned: decoded symbols (host-written, read by the scatter kernel)
   uint64_t pool_used = 0;
   int wide = 0; // h_out holds int32 symbols (some symbol outside int16), else int16
@@ -557,7 +558,7 @@ struct DecItem {
   DecItem(const DecItem &) = delete;
 };
 
-constexpr size_t kCounterBytes = sizeof(unsigned long long) * (2 + kMaxPieces); // per item, see DecDesc::pool_used
+constexpr size_t kCounterBytes = sizeof(unsigned long long) * (3 + kMaxPieces); // per item, see DecDesc::pool_used
 
 // Decode, batched and pipelined.  Items are cut into groups; the sizes of the variable-length tables are only known
 // on the device, so every group takes one host round trip between its two passes:
@@ -566,8 +567,10 @@ constexpr size_t kCounterBytes = sizeof(unsigned long long) * (2 + kMaxPieces); 
 //   this thread     : sizes of group g known -> pack the group's rows into one staging range (device) and one
 //                     pinned range (host) of exactly that size, patch the descriptors
 //   fill stream     : [H2D descs g][fill g]            (runs beside the count passes of later groups)
-//   copy stream     : after fill g -> ONE copy for the group's header arrays, ONE for its rows (few large copies:
-//                     measured 55.7 GB/s, against 51 GB/s for a copy per item)
+//   fill stream     : ... the headers go into the same range (hdr_pack_kernel: 2 bytes per latent where the item's
+//                     half-width fits and no row is non-monotone, else 4)
+//   copy stream     : after fill g -> ONE copy for the group's range, headers + rows (few large copies: measured
+//                     55.7 GB/s, against 51 GB/s for a copy per item)
 //   dispatcher job  : waits for the groups' copies in order and hands each item to the workers as it lands
 //   host workers    : one bitstream each; symbols go to pinned memory as int16 (int32 if one does not fit)
 //   caller's stream : yhat_scatter_kernel reads them from there and writes the full float latent, zero channels too
@@ -751,8 +754,9 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         Landing land{pit->n_piece, pit->piece_end, pit->piece_base, pit, [](void *arg, int k) -> int {
                        return hipEventSynchronize(static_cast<DecItem *>(arg)->piece_ev[k]) == hipSuccess ? (int)FGMM_OK : (int)FGMM_ERR_HIP;
                      }};
-        pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, pit->h_hdr, pit->piece_base[0], pit->n, pit->max_bs, sym,
-                                         pit->n_piece > 1 ? &land : nullptr);
+        pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, reinterpret_cast<const uint32_t *>(pit->h_hdr), pit->piece_base[0],
+                                         pit->n, pit->max_bs, sym, pit->n_piece > 1 ? &land : nullptr,
+                                         pit->hdr16 ? reinterpret_cast<const uint16_t *>(pit->h_hdr) : nullptr);
         if (pit->status == FGMM_OK && pit->y_hat) {
           // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
           int16_t *s16 = reinterpret_cast<int16_t *>(pit->h_out);
@@ -802,8 +806,19 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     const bool tail = tail_items && i0 == tail_begin;
     const int np = tail ? n_piece : 1;
     HIP_TRY(hipEventSynchronize(ev_counters[g]));
-    // ---- layout of the group's rows: piece-major (piece k of every item, then piece k+1 ...), each range 256-B
-    // aligned; the same offsets in the device staging range and in the pinned range
+    // ---- layout of the group's range, the same in the device staging area and in pinned memory:
+    //   [headers of every item: 2 bytes per latent where the item allows it, else 4][rows, piece-major: piece k of
+    //   every item, then piece k+1 ...], every part 256-byte aligned
+    size_t hdr_total = 0, n_lat_max = 0;
+    std::vector<size_t> hdr_at((size_t)(i1 - i0));
+    for (int i = i0; i < i1; ++i) {
+      DecItem &it = items[i];
+      const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
+      it.hdr16 = tab_hdr_fits16(it.max_bs) && u[2 + kMaxPieces] == 0;
+      hdr_at[(size_t)(i - i0)] = hdr_total;
+      hdr_total += align_up((it.hdr16 ? sizeof(uint16_t) : sizeof(uint32_t)) * (size_t)it.n, 256);
+      n_lat_max = std::max(n_lat_max, (size_t)it.n);
+    }
     size_t piece_off[kMaxPieces + 1] = {0}; // byte range of piece k within the group's rows
     std::vector<size_t> at((size_t)(i1 - i0) * (size_t)np); // [k * (i1-i0) + t]: where piece k of item t starts
     size_t off = 0, out_total = 0;
@@ -820,19 +835,21 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       }
     }
     piece_off[np] = off;
-    const size_t rows_bytes = off + 256; // + slack: the host's SIMD search reads a little past a row
-    const size_t hdr_total = items[i1 - 1].o_hdr + items[i1 - 1].hdr_bytes - items[i0].o_hdr;
+    const size_t range_bytes = hdr_total + off + 256; // + slack: the host's SIMD search reads a little past a row
     for (int i = i0; i < i1; ++i) out_total += align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(items[i].n, 1), 256);
-    char *d_rows = nullptr, *h_rows = nullptr, *h_hdrs = nullptr, *h_outs = nullptr;
-    if ((rc = ctx->dchunk_alloc(rows_bytes, &d_rows)) || (rc = ctx->chunk_alloc(rows_bytes, &h_rows)) ||
-        (rc = ctx->chunk_alloc(hdr_total + 256, &h_hdrs)) || (rc = ctx->chunk_alloc(out_total + 256, &h_outs)))
+    char *d_range = nullptr, *h_range = nullptr, *h_outs = nullptr;
+    if ((rc = ctx->dchunk_alloc(range_bytes, &d_range)) || (rc = ctx->chunk_alloc(range_bytes, &h_range)) ||
+        (rc = ctx->chunk_alloc(out_total + 256, &h_outs)))
       return rc;
+    char *const d_rows = d_range + hdr_total, *const h_rows = h_range + hdr_total;
     memset(h_rows + off, 0, 256);
     size_t out_off = 0;
     for (int i = i0; i < i1; ++i) {
       DecItem &it = items[i];
       const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
-      it.h_hdr = reinterpret_cast<const uint32_t *>(h_hdrs + (it.o_hdr - items[i0].o_hdr));
+      it.h_hdr = h_range + hdr_at[(size_t)(i - i0)];
+      hd[i].hdr_out = d_range + hdr_at[(size_t)(i - i0)];
+      hd[i].hdr_compact = it.hdr16 ? 1 : 0;
       it.h_out = h_outs + out_off;
       out_off += align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(it.n, 1), 256);
       it.n_piece = np;
@@ -853,15 +870,16 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     int n_ch_max;
     int64_t hw_max;
     extent(i0, i1, &n_ch_max, &hw_max);
-    // ---- fill, then fetch: headers of the whole group in one copy, rows in one copy per piece
+    // ---- headers into the range, fill, then fetch: ONE copy for an ordinary group (headers + rows), one per piece
+    // for the tail window (the first carries the headers)
+    HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs + sizeof(DecDesc) * (size_t)i0, &hd[i0], sizeof(DecDesc) * (size_t)(i1 - i0),
+                           hipMemcpyHostToDevice, ctx->fill_stream));
+    LAUNCH_TRY(launch_hdr_pack(dd + i0, i1 - i0, (int64_t)n_lat_max, ctx->fill_stream));
     if (!tail) {
-      HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs + sizeof(DecDesc) * (size_t)i0, &hd[i0], sizeof(DecDesc) * (size_t)(i1 - i0),
-                             hipMemcpyHostToDevice, ctx->fill_stream));
       LAUNCH_TRY(launch_cdftab_fill(dd + i0, i1 - i0, n_ch_max, hw_max, mode, clamped, f16, ctx->fill_stream));
       HIP_TRY(hipEventRecord(ev_fill[g], ctx->fill_stream));
       HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_fill[g], 0));
-      if (hdr_total) HIP_TRY(hipMemcpyAsync(h_hdrs, ctx->d_ws + items[i0].o_hdr, hdr_total, hipMemcpyDeviceToHost, ctx->copy_stream));
-      if (off) HIP_TRY(hipMemcpyAsync(h_rows, d_rows, off, hipMemcpyDeviceToHost, ctx->copy_stream));
+      if (hdr_total + off) HIP_TRY(hipMemcpyAsync(h_range, d_range, hdr_total + off, hipMemcpyDeviceToHost, ctx->copy_stream));
       HIP_TRY(hipEventRecord(ev_landed[g], ctx->copy_stream));
     } else {
       HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_pdescs, hpd, sizeof(DecDesc) * (size_t)(tail_items * n_piece), hipMemcpyHostToDevice,
@@ -870,10 +888,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         LAUNCH_TRY(launch_cdftab_fill(dpd + k * tail_items, tail_items, n_ch_max, hw_max, mode, clamped, f16, ctx->fill_stream));
         HIP_TRY(hipEventRecord(ev_pfill[k], ctx->fill_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_pfill[k], 0));
-        if (k == 0 && hdr_total) HIP_TRY(hipMemcpyAsync(h_hdrs, ctx->d_ws + items[i0].o_hdr, hdr_total, hipMemcpyDeviceToHost, ctx->copy_stream));
-        if (piece_off[k + 1] > piece_off[k])
-          HIP_TRY(hipMemcpyAsync(h_rows + piece_off[k], d_rows + piece_off[k], piece_off[k + 1] - piece_off[k], hipMemcpyDeviceToHost,
-                                 ctx->copy_stream));
+        const size_t c0 = k ? hdr_total + piece_off[k] : 0, c1 = hdr_total + piece_off[k + 1];
+        if (c1 > c0) HIP_TRY(hipMemcpyAsync(h_range + c0, d_range + c0, c1 - c0, hipMemcpyDeviceToHost, ctx->copy_stream));
         HIP_TRY(hipEventRecord(ev_pland[k], ctx->copy_stream));
       }
     }
@@ -883,7 +899,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   if (count == 1) dispatcher();
   ctx->stat[1] = ctx->stat[2] = 0;
   for (auto &it : items) {
-    ctx->stat[1] += it.pool_used + sizeof(uint32_t) * (unsigned long long)it.n;
+    ctx->stat[1] += it.pool_used + (it.hdr16 ? sizeof(uint16_t) : sizeof(uint32_t)) * (unsigned long long)it.n;
     ctx->stat[2] += (unsigned long long)it.n;
   }
   tr.mark("sizes known, fill + copies queued");

@@ -46,11 +46,14 @@ struct DecDesc {
   int32_t tiles;                 // blocks per channel = ceil(hw / 256)
   int32_t pad_;
   uint32_t *hdr;                 // [n_ch*hw] 4-byte headers (written by the count pass, read by the fill pass and the host)
+  void *hdr_out;                 // hdr_pack_kernel: the headers as the host gets them (uint32, or uint16 if hdr_compact)
+  int32_t hdr_compact, pad3_;
   int32_t ch_begin, ch_end;      // compact channels the fill pass covers (a launch may fill an item piece by piece)
   uint8_t *pool;                 // rows, latent order (device memory, or pinned host memory written over PCIe)
   unsigned long long pool_cap;   // bytes
   unsigned long long *pool_used; // [0] bytes used, [1] overflow flag, [2 + k] byte offset of the first row of piece
-                                 // k + 1 (k < n_piece - 1), piece k = compact channels [n_ch*k/n_piece, n_ch*(k+1)/n_piece)
+                                 // k + 1 (k < n_piece - 1), piece k = compact channels [n_ch*k/n_piece, n_ch*(k+1)/n_piece),
+                                 // [2 + kMaxPieces] some row is non-monotone (written when n_piece >= 1)
   int32_t n_piece;               // 0 or 1: no piece offsets wanted (at most FGMM_MAX_PIECES)
   int32_t pad2_;
   uint16_t *tmp;                 // null, or [n_ch*tiles][kTmpHdrRows + W][256]: per lane its evaluation window (j_lo, j_hi,
@@ -62,6 +65,7 @@ struct DecDesc {
 
 // ---- decode-side table format v3 (documented in include/flashgmm_amd.h) -------------------------------------
 //   hdr  (uint32): int16 a | cnt << 16 (15 bits) | nonmono << 31
+//   hdr  (uint16, batched decode only, items with 2*max_bs+2 <= 254 and no non-monotone row): (a + max_bs) | cnt << 8
 //   rows in latent order, each 4-byte aligned, no stored offset:
 //     raw (cnt < 64 or nonmono): uint16[round2(cnt)], padded with the last value
 //     EF  (cnt >= 64, monotone): uint8 lows[round8(cnt)] ; uint64 upper[U], U = ceil((cnt + 256) / 64),
@@ -100,6 +104,8 @@ int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_ma
                   void *stream);
 // y_hat[c, p] = rank[c] < 0 ? 0 : (float)sym[rank[c] * hw + p]; sym is int16 (wide = 0) or int32 and may live in pinned
 // host memory (read over PCIe)   (entropy_models.py:903-908)
+// headers into the staging range (DecDesc::hdr_out), 2-byte form where DecDesc::hdr_compact; n_max = largest n_ch*hw
+int launch_hdr_pack(const DecDesc *d_descs, int count, int64_t n_max, void *stream);
 int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y_hat, int M, int64_t hw, void *stream);
 // checkerboard split (embed = false: [planes,h,w] -> [2,planes,h,w/2]) / merge (embed = true); w even, elem_bytes 2 or 4
 int launch_ckbd(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes, int anchor_odd, bool embed,
@@ -125,7 +131,9 @@ struct Landing {
   void *arg;
   int (*wait)(void *arg, int k); // FGMM_OK or an error status
 };
+// hdr16: null, or the headers in their 2-byte form (then `hdr` is ignored)
 int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, const uint8_t *pool, int64_t n,
-                       int32_t max_bs, int32_t *out, const Landing *land = nullptr);
+                       int32_t max_bs, int32_t *out, const Landing *land = nullptr, const uint16_t *hdr16 = nullptr);
+FGMM_HD static inline bool tab_hdr_fits16(int32_t max_bs) { return 2 * max_bs + 2 <= 254; }
 
 } // namespace fgmm

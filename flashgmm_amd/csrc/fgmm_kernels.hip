@@ -469,10 +469,13 @@ __global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__r
   if (active) d.hdr[(int64_t)cj * hw + p] = tab_hdr_pack(a_idx - max_bs, cnt, nonmono ? 1u : 0u);
   __shared__ uint32_t s_tmp[kBlock / 64];
   const uint32_t total = block_reduce_add(active ? tab_row_bytes(cnt, nonmono ? 1u : 0u) : 0u, s_tmp);
-  if (threadIdx.x == 0) d.blk_sums[(int64_t)cj * d.tiles + blockIdx.x] = total;
+  const int any_nonmono = __syncthreads_or(active && nonmono);
+  // bit 31: some row of the block is non-monotone (a block holds < 2^31 bytes of rows: 256 rows of < 64 KiB)
+  if (threadIdx.x == 0) d.blk_sums[(int64_t)cj * d.tiles + blockIdx.x] = total | (any_nonmono ? 0x80000000u : 0u);
 }
 
-// one block per item: blk_off[b] = sum of blk_sums[0..b), pool_used[0] = total bytes, [1] = overflow flag
+// one block per item: blk_off[b] = sum of blk_sums[0..b), pool_used[0] = total bytes, [1] = overflow flag,
+// [2 .. 2+n_piece-1) piece offsets, [2 + kMaxPieces] = some row of the item is non-monotone
 __global__ __launch_bounds__(kBlock) void cdftab_scan_kernel(const DecDesc *__restrict__ descs) {
   const DecDesc &d = descs[blockIdx.x];
   const int64_t nb = (int64_t)d.n_ch * d.tiles;
@@ -480,9 +483,12 @@ __global__ __launch_bounds__(kBlock) void cdftab_scan_kernel(const DecDesc *__re
   __shared__ unsigned long long s_carry;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
+  uint32_t flagged = 0;
   for (int64_t b0 = 0; b0 < nb; b0 += kBlock) {
     const int64_t b = b0 + threadIdx.x;
-    const uint32_t v = b < nb ? d.blk_sums[b] : 0u;
+    const uint32_t raw = b < nb ? d.blk_sums[b] : 0u;
+    flagged |= raw >> 31;
+    const uint32_t v = raw & 0x7FFFFFFFu;
     const uint32_t ex = block_scan_excl(v, s_tmp);
     const unsigned long long carry = s_carry;
     if (b < nb) d.blk_off[b] = carry + ex;
@@ -494,9 +500,23 @@ __global__ __launch_bounds__(kBlock) void cdftab_scan_kernel(const DecDesc *__re
     d.pool_used[0] = s_carry;
     d.pool_used[1] = s_carry > d.pool_cap ? 1ull : 0ull;
   }
+  const int any_nonmono = __syncthreads_or((int)flagged);
+  if (d.n_piece >= 1 && threadIdx.x == 0) d.pool_used[2 + kMaxPieces] = (unsigned long long)(any_nonmono != 0);
   if (d.n_piece > 1 && (int)threadIdx.x < d.n_piece - 1) { // where the pieces of the item begin (blk_off is this block's own)
     const int64_t ch = (int64_t)d.n_ch * ((int)threadIdx.x + 1) / d.n_piece;
     d.pool_used[2 + threadIdx.x] = ch * d.tiles < nb ? d.blk_off[ch * d.tiles] : s_carry;
+  }
+}
+
+// Headers for the host, next to the rows in the staging range: the 4-byte form, or — for items whose half-width fits
+// (2*max_bs+2 <= 254) and that have no non-monotone row — 2 bytes: (a + max_bs) | cnt << 8.
+__global__ __launch_bounds__(kBlock) void hdr_pack_kernel(const DecDesc *__restrict__ descs) {
+  const DecDesc &d = descs[blockIdx.y];
+  const int64_t n = (int64_t)d.n_ch * d.hw;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const uint32_t h = d.hdr[i];
+    if (d.hdr_compact) reinterpret_cast<uint16_t *>(d.hdr_out)[i] = (uint16_t)(((uint32_t)(tab_hdr_a(h) + d.max_bs) & 0xFFu) | (tab_hdr_cnt(h) << 8));
+    else reinterpret_cast<uint32_t *>(d.hdr_out)[i] = h;
   }
 }
 
@@ -873,6 +893,13 @@ int launch_cdftab_fill(const DecDesc *d_descs, int count, int n_ch_max, int64_t 
 int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
                   void *stream) {
   return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 3, stream);
+}
+
+int launch_hdr_pack(const DecDesc *d_descs, int count, int64_t n_max, void *stream) {
+  if (count <= 0 || n_max <= 0) return 0;
+  dim3 grid((unsigned)std::min<int64_t>((n_max + kBlock - 1) / kBlock, 1024), (unsigned)count);
+  hipLaunchKernelGGL(hdr_pack_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, d_descs);
+  return launch_err();
 }
 
 int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y_hat, int M, int64_t hw, void *stream) {

@@ -384,8 +384,8 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow
 } // namespace
 
 int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, const uint8_t *pool, int64_t n,
-                       int32_t max_bs, int32_t *out, const Landing *land) {
-  if (n < 0 || (n > 0 && (!hdr || !pool || !out)) || !enc) return FGMM_ERR_INVALID;
+                       int32_t max_bs, int32_t *out, const Landing *land, const uint16_t *hdr16) {
+  if (n < 0 || (n > 0 && ((!hdr && !hdr16) || !pool || !out)) || !enc) return FGMM_ERR_INVALID;
   if (enc_len < 8 || (enc_len & 3)) return FGMM_ERR_STREAM;
   const uint32_t *words;
   uint32_t *copy = nullptr;
@@ -423,9 +423,19 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
     }
     __builtin_prefetch(rowp + kPf);
     __builtin_prefetch(rowp + kPf + 64);
-    const uint32_t h = hdr[i];
-    const int32_t a = tab_hdr_a(h), cnt = (int32_t)tab_hdr_cnt(h);
-    const uint32_t nonmono = tab_hdr_nonmono(h);
+    int32_t a, cnt;
+    uint32_t nonmono;
+    if (hdr16) { // 2-byte form: (a + max_bs) | cnt << 8, never a non-monotone row
+      const uint32_t c = hdr16[i];
+      a = (int32_t)(c & 0xFFu) - max_bs;
+      cnt = (int32_t)(c >> 8);
+      nonmono = 0;
+    } else {
+      const uint32_t h = hdr[i];
+      a = tab_hdr_a(h);
+      cnt = (int32_t)tab_hdr_cnt(h);
+      nonmono = tab_hdr_nonmono(h);
+    }
     const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono);
     const uint8_t *row_bytes = rowp;
     rowp += tab_row_bytes((uint32_t)cnt, nonmono);

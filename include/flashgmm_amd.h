@@ -184,7 +184,9 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
  *   cnt >= 64, monotone : Elias-Fano with 8 low bits: uint8 lows[round8(cnt)], then uint64 upper[U],
  *                         U = ceil((cnt + 256) / 64), bit ((F >> 8) + j) set for entry j  (round8(cnt) + 8U bytes)
  * `nonmono` is set when the row decreases somewhere.  hdr: device uint32[n]; pool: device bytes; pool_used: device
- * uint64[1] = bytes written.  pool_cap >= n * 2 * round2(2*max_bs + 2) always suffices. */
+ * uint64[1] = bytes written.  pool_cap >= n * 2 * round2(2*max_bs + 2) always suffices.  (Table format v3.  Inside
+ * the batched decode calls the headers of an item with 2*max_bs + 2 <= 254 and no non-monotone row cross PCIe as
+ * uint16 (a + max_bs) | cnt << 8; this entry point and fgmm_rans_decode_cdftab always use the 4-byte form.) */
 #define FGMM_TAB_NO_PRUNE 1 /* flags: evaluate all of F_i instead of skipping its saturated tails (A/B testing) */
 #define FGMM_TAB_CLAMP 2    /* flags: clamp sigma to [0.11, 256] first (the entropy-model path's kernel variant) */
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,

@@ -338,6 +338,26 @@ def test_decoder_equals_reference_on_garbage_streams(oracle, mode):
         ans.RansDecoder().decode_with_indexes_gmm(enc[:64], dv(sg), dv(mu), dv(pi), max_bs, mode=mode)
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_header_forms_of_the_batched_decoder(oracle, mode):
+    """the batched decoder ships 2-byte headers for an item whose half-width fits and that has no non-monotone row, the
+    4-byte form otherwise: a small-width item, the same with negative sigmas (decreasing CDFs: non-monotone rows, the
+    raw coder boundary does not clamp) and a wide one, all on a garbage stream, must equal the reference's decoder"""
+    rng = np.random.default_rng(23)
+    n = 3000
+    e = np.exp(rng.uniform(-2, 1.0, n)).astype(np.float32)
+    mu = (rng.standard_normal((n, 4)) * e[:, None]).astype(np.float32)
+    sg = ((rng.uniform(0, 2, (n, 4)) + 0.11) * e[:, None]).astype(np.float32)
+    pi = rng.dirichlet(np.ones(4), n).astype(np.float32)
+    sg_neg = sg.copy()
+    sg_neg[rng.random(n) < 0.2, 1] *= -1.0
+    enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+    for sgx, max_bs in ((sg, 20), (sg_neg, 20), (sg, 126), (sg, 127), (sg_neg, 400)):
+        want = oracle.decode_gmm(mode, enc, sgx, mu, pi, max_bs)
+        got = ans.RansDecoder().decode_with_indexes_gmm(enc, dv(sgx), dv(mu), dv(pi), max_bs, mode=mode)
+        assert np.array_equal(got.numpy(), want), (max_bs, bool((sgx < 0).any()))
+
+
 def test_input_validation_is_loud():
     s = torch.rand(8, 4, device=DEV) + 0.2
     v = torch.zeros(8, dtype=torch.int32, device=DEV)
