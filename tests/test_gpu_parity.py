@@ -487,6 +487,22 @@ def test_decode_tail_window_settings(monkeypatch, tail, pieces):
 
 
 @pytest.mark.parametrize("mode", MODES)
+def test_fill_pass_with_and_without_the_temp_buffer(monkeypatch, mode):
+    """the fill pass formats rows from the edges the count pass kept (default) or, when the temp buffer would exceed
+    FGMM_TMP_MAX_MB, evaluates them a second time: both must decode a batch to the same symbols"""
+    gmc = GaussianMixtureConditional(K=4, mode=mode)
+    lat = [T.make_latent(300 + i, M=48, h=16, w=16, clamp=False, zero_frac=0.1) for i in range(6)]
+    ys, ss, ms, ws = ([dv(l[k]) for l in lat] for k in range(4))
+    res = gmc.compress_batch(ys, ss, ms, ws)
+    args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+    a = gmc.decompress_batch(*args)
+    monkeypatch.setenv("FGMM_TMP_MAX_MB", "0")
+    b = gmc.decompress_batch(*args)
+    for i in range(6):
+        assert torch.equal(a[i], res[i][1]) and torch.equal(b[i], res[i][1]), i
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_fp16_parameter_planes(oracle, mode):
     """BASELINE configs[4]: fp16 (mu, sigma, pi), fp32 CDF.  Result == the reference path fed the widened values."""
     for seed, (M, h, w) in ((41, (32, 16, 12)), (42, (7, 5, 3))):  # 8-B vector loads, and the scalar kernel
