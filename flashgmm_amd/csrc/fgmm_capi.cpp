@@ -590,7 +590,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   const int tail_cfg = getenv("FGMM_TAIL_ITEMS") ? atoi(getenv("FGMM_TAIL_ITEMS")) : 8;
   const int piece_cfg = getenv("FGMM_TAIL_PIECES") ? atoi(getenv("FGMM_TAIL_PIECES")) : 4;
   const int n_piece = std::min(std::max(piece_cfg, 1), (int)kMaxPieces);
-  const int tail_items = (count >= 4 && n_piece > 1) ? std::min({std::max(tail_cfg, 0), count, std::max(ctx->pool->size() / 2, 1)}) : 0;
+  const int tail_items = (n_piece > 1) ? std::min({std::max(tail_cfg, 0), count, std::max(ctx->pool->size() / 2, 1)}) : 0;
   const int tail_begin = count - tail_items;
   // groups of items: small first (the first tables land as early as possible), then larger; the tail window is
   // one group of its own
@@ -803,7 +803,12 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   if ((rc = ctx->prof_begin(3, ctx->fill_stream))) return rc;
   for (int g = 0; g < n_groups; ++g) {
     const int i0 = gbeg[g], i1 = gbeg[g + 1];
-    const bool tail = tail_items && i0 == tail_begin;
+    bool tail = tail_items && i0 == tail_begin;
+    if (tail) { // pieces only pay for rows that take a while to cross: small tail groups travel whole
+      int64_t lat = 0;
+      for (int i = i0; i < i1; ++i) lat += items[i].n;
+      tail = lat >= 65536;
+    }
     const int np = tail ? n_piece : 1;
     HIP_TRY(hipEventSynchronize(ev_counters[g]));
     // ---- layout of the group's range, the same in the device staging area and in pinned memory:
