@@ -252,7 +252,8 @@ def main():
         sym_ms = float(np.mean(k_sym))
         achieved = n_coded * bytes_per_symbol / (sym_ms * 1e-3) / 1e9
         out = {
-            "metric": "encode+decode Mpixels/s (Kodak, K=4 N=192)" if a.workload == "kodak24"
+            # BASELINE.json's metric, verbatim: `value` is its Mpixels/s half, the `roofline` object its GMM-CDF HBM half
+            "metric": "encode+decode Mpixels/s (Kodak, K=4 N=192) + GMM-CDF HBM GB/s vs roofline" if a.workload == "kodak24"
             else "encode+decode Mpixels/s (ELIC 4K, K=4, fp16 params)",
             "value": round(value, 2),
             "unit": "Mpixels/s",
