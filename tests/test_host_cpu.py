@@ -33,6 +33,46 @@ def test_library_exports_every_declared_symbol():
     assert L.fgmm_abi_version() == 1
 
 
+def test_header_is_plain_c_and_links():
+    """include/flashgmm_amd.h is the drop-in boundary: it must compile as C99 (no torch / C++ types in the signatures) and
+    a C program calling it must link against the library and run (no GPU needed for the host-only entry points)"""
+    import shutil
+    import subprocess
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "flashgmm_amd.h")
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    src = r"""
+#include "flashgmm_amd.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+  /* an empty symbol table flushes the initial rANS state: 00 00 00 80 00 00 00 00 (rans_interface.cpp:557-585) */
+  uint8_t *out = NULL; size_t len = 0; uint32_t none = 0;
+  if (fgmm_rans_encode_symtab(&none, NULL, 0, &out, &len) != FGMM_OK || len != 8) return 1;
+  static const unsigned char want[8] = {0, 0, 0, 0x80, 0, 0, 0, 0};
+  if (memcmp(out, want, 8)) return 2;
+  fgmm_free(out);
+  float pmf[4] = {0.1f, 0.2f, 0.f, 0.f}; uint32_t cdf[5];
+  if (fgmm_pmf_to_quantized_cdf(pmf, 4, 16, cdf) != FGMM_OK || cdf[1] != 21845 || cdf[4] != 65536) return 3;
+  printf("abi %d ok\n", fgmm_abi_version());
+  return 0;
+}
+"""
+    lib_dir = os.path.join(root, "flashgmm_amd")
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), c, "-o", exe, "-L", lib_dir,
+                        "-lflashgmm_amd", "-Wl,-rpath," + lib_dir], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def test_no_gpu_fails_loudly():
     import torch
 
