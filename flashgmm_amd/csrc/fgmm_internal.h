@@ -66,6 +66,7 @@ struct DecDesc {
 // ---- decode-side table format v3 (documented in include/flashgmm_amd.h) -------------------------------------
 //   hdr  (uint32): int16 a | cnt << 16 (15 bits) | nonmono << 31
 //   hdr  (uint16, batched decode only, items with 2*max_bs+2 <= 254 and no non-monotone row): (a + max_bs) | cnt << 8
+//   row i = F_i[a .. a+cnt), starting at the first non-zero edge (F_i[v < a] = 0, F_i[v >= a+cnt] = last entry);
 //   rows in latent order, each 4-byte aligned, no stored offset:
 //     raw (cnt < 64 or nonmono): uint16[round2(cnt)], padded with the last value
 //     EF  (cnt >= 64, monotone): uint8 lows[round8(cnt)] ; uint64 upper[U], U = ceil((cnt + 256) / 64),

@@ -462,7 +462,9 @@ __global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__r
     if (j_hi == 0 || T_sat != prev) run_start = j_hi;
     nonmono |= (j_hi > 0) && (T_sat < prev);
   }
-  int a_idx = lead < 0 ? 0 : lead;
+  // the row starts at the first non-zero edge: F[v < a] = 0 is implied by the format, and the host takes "cf below the
+  // first entry" as the interval [0, first entry) of the symbol before it (2 bytes less per row than storing that zero)
+  int a_idx = lead + 1;
   if (a_idx > run_start) a_idx = run_start;
   const uint32_t cnt = (uint32_t)(run_start - a_idx + 1);
 

@@ -324,7 +324,8 @@ inline uint32_t ef_get(const EfRow &r, int32_t j) { // E_j
 }
 // Bracket search: on success returns true with (*j, *start, *freq) such that E[j-1] = start <= cf < E[j];
 // false when no entry pair brackets cf (j would be 0 or cnt) — the caller replays the reference's bisection.
-__attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow &r, uint32_t cf, int32_t *jout,
+// zero_before: an (unstored) zero edge precedes the row, so cf below the first entry is the interval [0, E_0): j = 0.
+__attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
                                                                     uint32_t *start, uint32_t *freq) {
   const uint32_t h = cf >> 8, l = cf & 0xFFu;
   const int32_t p_prev = h ? (int32_t)ef_select0(r, h - 1) : -1; // zero that closes bucket h-1
@@ -354,9 +355,11 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow
     while (c < run && r.lows[lo + c] <= l) ++c;
   }
   const int32_t j = lo + c;
-  if (__builtin_expect(j < 1 || j >= r.cnt, 0)) return false;
+  if (__builtin_expect((j < 1 && !zero_before) || j >= r.cnt, 0)) return false;
   uint32_t e0, e1;
-  if (c > 0) {
+  if (j < 1) {
+    e0 = 0; // the implied zero edge
+  } else if (c > 0) {
     e0 = (h << 8) | r.lows[j - 1];
   } else { // previous entry lives in an earlier bucket: the highest one below bit p_prev
     int32_t w = p_prev >> 6;
@@ -437,6 +440,7 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
       nonmono = tab_hdr_nonmono(h);
     }
     const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono);
+    const bool zero_before = a > -max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
     const uint8_t *row_bytes = rowp;
     rowp += tab_row_bytes((uint32_t)cnt, nonmono);
 
@@ -456,6 +460,11 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
             freq = row[j] - start;
             value = a + j - 1;
             done = true;
+          } else if (j == 0 && zero_before) { // 0 <= cf < row[0]: the symbol whose lower edge is the implied zero
+            start = 0;
+            freq = row[0];
+            value = a - 1;
+            done = true;
           }
         }
         if (!done) value = bisect_reference(Row{row, a, cnt}, cf, max_bs, &start, &freq);
@@ -463,7 +472,7 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
         const EfRow r{row_bytes, Up64{row_bytes + (((uint32_t)cnt + 7u) & ~7u)}, cnt,
                       (int32_t)(((uint32_t)cnt + 256u + 63u) >> 6)};
         int32_t j;
-        if (__builtin_expect(ef_bracket(r, cf, &j, &start, &freq), 1)) {
+        if (__builtin_expect(ef_bracket(r, cf, zero_before, &j, &start, &freq), 1)) {
           value = a + j - 1;
         } else { // no interval contains cf: expand the row and replay the reference's bisection
           if ((size_t)cnt > scratch_cap) {

@@ -178,7 +178,8 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
  * The kernels find, exactly, the window outside which F_i is constant (evaluating F_i everywhere except where
  * every mixture component is provably saturated — fgmm_selftest_saturation) and store it:
  *   hdr[i] (uint32) = int16 a | cnt << 16 (15 bits) | nonmono << 31
- *   row i  = F_i[a .. a+cnt);   F_i[v < a] = 0,   F_i[v >= a+cnt] = the row's last entry
+ *   row i  = F_i[a .. a+cnt), from the first non-zero edge to the start of the trailing constant run;
+ *            F_i[v < a] = 0,   F_i[v >= a+cnt] = the row's last entry
  * Rows lie in LATENT ORDER in `pool`, 4-byte aligned, with no stored offset (row i+1 starts where row i ends):
  *   cnt < 64 or nonmono : uint16[round2(cnt)], padded with the last value              (2*round2(cnt) bytes)
  *   cnt >= 64, monotone : Elias-Fano with 8 low bits: uint8 lows[round8(cnt)], then uint64 upper[U],

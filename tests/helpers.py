@@ -34,7 +34,7 @@ def trim_full_table(tab: np.ndarray, max_bs: int):
         lead = (nzpos[0] - 1) if len(nzpos) else W - 1  # index of the last leading zero (-1: none)
         diff = np.nonzero(F != F[-1])[0]
         run_start = (diff[-1] + 1) if len(diff) else 0  # start of the trailing constant run
-        a_idx = min(max(lead, 0), run_start)
+        a_idx = min(lead + 1, run_start)  # first non-zero edge (the zero before it is implied: F[v < a] = 0)
         cnt = run_start - a_idx + 1
         row = F[a_idx:a_idx + cnt]
         nonmono = int((np.diff(row) < 0).any())
