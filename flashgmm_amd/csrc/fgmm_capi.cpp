@@ -566,9 +566,9 @@ constexpr size_t kCounterBytes = sizeof(unsigned long long) * (3 + kMaxPieces); 
 //   aux stream      : after count+scan g -> D2H of group g's row-pool sizes
 //   this thread     : sizes of group g known -> pack the group's rows into one staging range (device) and one
 //                     pinned range (host) of exactly that size, patch the descriptors
-//   fill stream     : [H2D descs g][fill g]            (runs beside the count passes of later groups)
-//   fill stream     : ... the headers go into the same range (hdr_pack_kernel: 2 bytes per latent where the item's
-//                     half-width fits and no row is non-monotone, else 4)
+//   fill stream     : [H2D descs g][hdr_pack g][fill g]   (beside the count passes of later groups; the headers go
+//                     into the same range: 2 bytes per latent where the item's half-width fits and no row is
+//                     non-monotone, else 4; the fill pass formats rows from the edges the count pass kept)
 //   copy stream     : after fill g -> ONE copy for the group's range, headers + rows (few large copies: measured
 //                     55.7 GB/s, against 51 GB/s for a copy per item)
 //   dispatcher job  : waits for the groups' copies in order and hands each item to the workers as it lands
