@@ -144,7 +144,91 @@ def pmc_traffic(workload: str, mode: str, f16: bool):
     return best
 
 
-def main():
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run around it: start N fresh child processes, one
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), BEFORE anything in this process touches the
+    GPU; forward rank 0's JSON line; exit non-zero if any rank fails.  Children are started as children (never exec'ed
+    over this process)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FGMM_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+
+
+_REAL_STDOUT = None
+
+
+def emit(line: dict) -> None:
+    out = _REAL_STDOUT or sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
+def dryrun(a, world, rank):
+    """FGMM_BENCH_DRYRUN=1 (tests/test_bench_launcher_cpu.py): everything of an N-rank run EXCEPT the GPU work — process
+    group (gloo), the per-step all-gather of stream lengths, barriers, max-over-ranks timing, rank 0's one JSON line.
+    The line says so ("data": "dryrun-no-gpu", value 0): it is never a measurement."""
+    import torch.distributed as dist
+    from flashgmm_amd import parallel as P
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_streams = 2 * (a.images or 24)
+    t_gather = []
+
+    def step():
+        lens = [1000 + 7 * rank + i for i in range(n_streams)]  # stand-in for the coder's output lengths
+        t0 = time.perf_counter()
+        g = P.all_gather_stream_lengths(lens, n_streams) if world > 1 else None
+        t_gather.append(time.perf_counter() - t0)
+        return g
+
+    for _ in range(max(a.warmup, 1)):
+        g = step()
+    if world > 1:
+        assert g.shape == (world, n_streams) and g[rank].tolist() == [1000 + 7 * rank + i for i in range(n_streams)]
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = [dt]
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        gathered = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        per_rank = [float(t) for t in gathered]
+        dt = max(per_rank)
+    if rank == 0:
+        emit(({"metric": "dryrun", "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dryrun-no-gpu",
+                          "config": {"workload": a.workload, "streams_per_gpu": n_streams},
+                          "ranks": {"backend": "gloo" if world > 1 else None, "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
+                                    "allgather_ms": round(float(np.mean(t_gather[-a.steps:])) * 1e3, 4)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -154,13 +238,22 @@ def main():
     ap.add_argument("--param-dtype", default=None, choices=["f32", "f16"], help="default f32 (kodak24) / f16 (elic4k)")
     ap.add_argument("--mode", default="polya", choices=["polya", "as", "logistic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a, argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}, or without a launcher")
+    # stdout carries exactly ONE line (rank 0's JSON): whatever libraries print there (gloo / RCCL banners) goes to stderr
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    if os.environ.get("FGMM_BENCH_DRYRUN"):  # no GPU: the launcher, the collective and the JSON contract only (CPU test)
+        return dryrun(a, world, rank)
     if os.environ.get("FGMM_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 code path on a 1-GPU box (dev aid)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -286,7 +379,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, pix_per_image, streams_per_image)
-        print(json.dumps(out))
+        emit(out)
     if dist:
         dist.destroy_process_group()
 

@@ -1,0 +1,58 @@
+"""CPU: `python bench.py --gpus N` launches its own ranks (no torch.distributed.run around it) and prints ONE well-formed
+JSON line from rank 0.  FGMM_BENCH_DRYRUN=1 replaces the GPU work of a step by a stand-in; the launcher, the process
+group (gloo), the per-step all-gather, the barriers and the max-over-ranks timing are the real ones."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None):
+    env = dict(os.environ, FGMM_BENCH_DRYRUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_self_launch_prints_one_line(n):
+    r = _run(["--gpus", str(n), "--steps", "4", "--warmup", "1", "--images", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 4 and d["warmup"] == 1 and d["data"] == "dryrun-no-gpu"
+    assert len(d["ranks"]["ms_per_step"]) == n and d["ms_per_step"] == max(d["ranks"]["ms_per_step"])
+    for key in ("metric", "value", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "config"):
+        assert key in d
+
+
+def test_under_an_external_launcher_nothing_is_spawned():
+    """With WORLD_SIZE set (torch.distributed.run, the driver's form) a rank runs as itself."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = {"WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FGMM_BENCH_DRYRUN": "1"}
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), **base)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                                       "--warmup", "1", "--images", "2"], env=env, stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert json.loads(outs[0].strip())["n_gpus"] == 2 and outs[1].strip() == ""
+
+
+def test_a_failing_rank_fails_the_launch():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1"], {"WORLD_SIZE_MISMATCH": "1", "FGMM_BENCH_DRYRUN": "",
+                                                                  "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    # without the dry-run switch the children need a GPU; here there is none, so they fail and so must the launcher
+    assert r.returncode != 0
