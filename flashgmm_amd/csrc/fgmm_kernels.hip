@@ -36,17 +36,33 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // parameter planes are float32, or float16 converted on load (BASELINE configs[4]: "fp16 (mu,sigma,pi) with fp32 CDF
 // accumulate"): every value is widened exactly, then the fp32 path runs unchanged
+// Descriptor pointers are generic (they come out of a struct in memory): cast to the global address space so that the
+// accesses are global_load / global_store (a flat_load also takes a slot of the LDS queue and is waited for out of order).
+#define FGMM_GLOBAL __attribute__((address_space(1)))
+#ifndef FGMM_NT_LOADS
+#define FGMM_NT_LOADS 1 // stream the inputs with the non-temporal hint (measured +3-4 % on the symtab kernel; 0: A/B)
+#endif
+template <typename T> __device__ __forceinline__ T ldg(const void *p) {
+  const FGMM_GLOBAL T *g = (const FGMM_GLOBAL T *)p;
+#if FGMM_NT_LOADS
+  return __builtin_nontemporal_load(g);
+#else
+  return *g;
+#endif
+}
+template <typename T> __device__ __forceinline__ void stg(void *p, T v) { *(FGMM_GLOBAL T *)p = v; }
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
 template <typename PT> __device__ __forceinline__ float ld1(const void *base, int64_t idx) {
-  return (float)static_cast<const PT *>(base)[idx];
+  return (float)ldg<PT>(static_cast<const PT *>(base) + idx);
 }
 template <typename PT> __device__ __forceinline__ void ld4(const void *base, int64_t idx, float (&out)[4]);
 template <> __device__ __forceinline__ void ld4<float>(const void *base, int64_t idx, float (&out)[4]) {
-  const float4 v = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + idx); // 16 B / lane
-  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  const float4_t v = ldg<float4_t>(static_cast<const float *>(base) + idx); // 16 B / lane
+  out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
 }
 template <> __device__ __forceinline__ void ld4<_Float16>(const void *base, int64_t idx, float (&out)[4]) {
-  const half4_t v = *reinterpret_cast<const half4_t *>(static_cast<const _Float16 *>(base) + idx); // 8 B / lane
+  const half4_t v = ldg<half4_t>(static_cast<const _Float16 *>(base) + idx); // 8 B / lane
   out[0] = (float)v[0]; out[1] = (float)v[1]; out[2] = (float)v[2]; out[3] = (float)v[3];
 }
 
@@ -147,24 +163,21 @@ __global__ __launch_bounds__(kBlock) void chan_compact_kernel(const EncDesc *__r
 // VEC = 4: each lane owns 4 consecutive positions, every plane read is one 16-B load (1 KiB per wave-instr).
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE, bool CLAMPED>
-__device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu)[4], float (&sg)[4], const float (&pi)[4],
+__device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu)[4], const float (&sg)[4], const float (&pi)[4],
                                               int &bypass) {
   const float x1 = vq - 0.5f;          // static_cast<float>(value) - offset             (:499)
   const float x2 = vq - 0.5f + 1.0f;   // static_cast<float>(value) - offset + 1.0f
   uint32_t lo, hi;
   if constexpr (CLAMPED) {
-    float rs[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      sg[k] = clamp_scale(sg[k]);
-      rs[k] = rcp_refined(sg[k]); // shared by both edges
-    }
-    bool ok = true;
-    float c1 = mix4_clamped<MODE>(x1, mu, sg, rs, pi, ok);
-    float c2 = mix4_clamped<MODE>(x2, mu, sg, rs, pi, ok);
-    if (__builtin_expect(!ok, 0)) { // huge / non-finite mean: one rare out-of-line IEEE evaluation
-      c1 = mix4_slow<MODE>(x1, mu[0], mu[1], mu[2], mu[3], sg[0], sg[1], sg[2], sg[3], pi[0], pi[1], pi[2], pi[3]);
-      c2 = mix4_slow<MODE>(x2, mu[0], mu[1], mu[2], mu[3], sg[0], sg[1], sg[2], sg[3], pi[0], pi[1], pi[2], pi[3]);
+    Sigma4 S;
+    S.set(sg[0], sg[1], sg[2], sg[3]); // clamp + refined reciprocals, shared by both edges
+    bool ok = S.tame;
+    const f2 cc = mix4_clamped2<MODE>((f2){x1, x2}, mu, S, pi, ok); // both edges share every parameter: packed fp32
+    float c1 = cc.x, c2 = cc.y;
+    if (__builtin_expect(!ok, 0)) { // far-off / non-finite mean, NaN sigma: one rare out-of-line IEEE evaluation
+      const float s0 = clamp_scale(sg[0]), s1 = clamp_scale(sg[1]), s2 = clamp_scale(sg[2]), s3 = clamp_scale(sg[3]);
+      c1 = mix4_slow<MODE>(x1, mu[0], mu[1], mu[2], mu[3], s0, s1, s2, s3, pi[0], pi[1], pi[2], pi[3]);
+      c2 = mix4_slow<MODE>(x2, mu[0], mu[1], mu[2], mu[3], s0, s1, s2, s3, pi[0], pi[1], pi[2], pi[3]);
     }
     lo = quant16(c1);
     hi = quant16(c2);
@@ -219,17 +232,18 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
     float vq[4];
     int vi[4];
     if (d.sym) {
-      const int4 t = *reinterpret_cast<const int4 *>(d.sym + (int64_t)c * hw + p0);
+      typedef int int4_t __attribute__((ext_vector_type(4)));
+      const int4_t t = ldg<int4_t>(d.sym + (int64_t)c * hw + p0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        vi[e] = (&t.x)[e];
+        vi[e] = t[e];
         vq[e] = (float)vi[e];
       }
     } else {
-      const float4 t = *reinterpret_cast<const float4 *>(d.y + (int64_t)c * hw + p0);
+      const float4_t t = ldg<float4_t>(d.y + (int64_t)c * hw + p0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        vq[e] = __builtin_rintf((&t.x)[e]);
+        vq[e] = __builtin_rintf(t[e]);
         vi[e] = (int)vq[e];
       }
     }
@@ -240,7 +254,8 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
       ld4<PT>(d.means, base + k * d.stride_k, Mu[k]);
       ld4<PT>(d.weights, base + k * d.stride_k, Pi[k]);
     }
-    uint4 out;
+    typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
+    uint4_t out;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float mu[4], sg[4], pi[4];
@@ -251,19 +266,19 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
         pi[k] = Pi[k][e];
       }
       int bp;
-      (&out.x)[e] = sym_entry<MODE, CLAMPED>(vq[e], vi[e], mu, sg, pi, bp);
+      out[e] = sym_entry<MODE, CLAMPED>(vq[e], vi[e], mu, sg, pi, bp);
       nbypass += bp;
     }
-    *reinterpret_cast<uint4 *>(d.packed + (int64_t)rank * hw + p0) = out;
+    stg<uint4_t>(d.packed + (int64_t)rank * hw + p0, out);
   } else {
     const int64_t base = (int64_t)c * d.stride_c + p0 * d.stride_p;
     float vq;
     int vi;
     if (d.sym) {
-      vi = d.sym[(int64_t)c * hw + p0];
+      vi = ldg<int32_t>(d.sym + (int64_t)c * hw + p0);
       vq = (float)vi;
     } else {
-      vq = __builtin_rintf(d.y[(int64_t)c * hw + p0]);
+      vq = __builtin_rintf(ldg<float>(d.y + (int64_t)c * hw + p0));
       vi = (int)vq;
     }
     float mu[4], sg[4], pi[4];
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
       pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
     }
     int bp;
-    d.packed[(int64_t)rank * hw + p0] = sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp);
+    stg<uint32_t>(d.packed + (int64_t)rank * hw + p0, sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp));
     nbypass = bp;
   }
   // bypass census (the host sizes its output buffer from it): one plain store per wave that saw any, no atomics
@@ -730,11 +745,18 @@ __device__ __forceinline__ uint32_t hash32(uint64_t x) {
 }
 __device__ __forceinline__ bool same_f32(float a, float b) { return f2bits(a) == f2bits(b) || (a != a && b != b); }
 template <int MODE> __device__ __forceinline__ unsigned long long phi_fast_vs_plain(uint64_t t0, uint64_t stride) {
-  const uint32_t top = f2bits(0x1p48f); // magnitudes [0, 2^48)
+  const uint32_t top = f2bits(0x1p48f), top15 = f2bits(0x1p15f); // magnitudes [0, 2^48)
   unsigned long long bad = 0;
   for (uint64_t i = t0; i < 2ull * top; i += stride) {
     const float z = bits2f(i < top ? (uint32_t)i : (0x80000000u | (uint32_t)(i - top)));
-    bad += !same_f32(Phi<MODE, true>::eval(z), Phi<MODE, false>::eval(z));
+    const float want = Phi<MODE, false>::eval(z);
+    bad += !same_f32(Phi<MODE, true>::eval(z), want);
+    // the packed form (domain |z| < 2^15), z in either half beside an unrelated value in the other (hashed)
+    if (__builtin_fabsf(z) < 0x1p15f) {
+      const float other = bits2f((hash32(i) % top15) | (hash32(i + 1) & 0x80000000u));
+      const f2 a = Phi2<MODE>::eval((f2){z, other}), b = Phi2<MODE>::eval((f2){other, z});
+      bad += !same_f32(a.x, want) + !same_f32(b.y, want);
+    }
   }
   return bad;
 }
@@ -757,6 +779,10 @@ __global__ __launch_bounds__(kBlock) void fastmath_selftest_kernel(int which, un
     for (uint64_t i = t0; i <= (uint64_t)(top - bot) + 1; i += stride) {
       const float x = i <= (uint64_t)(top - bot) ? bits2f(bot + (uint32_t)i) : 0.0f;
       bad += !same_f32(sqrt_unit(x), __builtin_sqrtf(x));
+      const f2 sq = sqrt_unit2((f2){x, bits2f(bot + (hash32(i) % (top - bot + 1)))});
+      bad += !same_f32(sq.x, __builtin_sqrtf(x));
+      const f2 sq2 = sqrt_unit2((f2){0.0f, x});
+      bad += !same_f32(sq2.y, __builtin_sqrtf(x)) + !same_f32(sq2.x, 0.0f);
     }
   } else if (which == 3) {
     bad = phi_fast_vs_plain<MODE_POLYA>(t0, stride);

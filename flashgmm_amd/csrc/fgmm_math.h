@@ -208,6 +208,170 @@ __device__ __noinline__ float mix4_slow(float x, float m0, float m1, float m2, f
   return mix4<MODE>(x, mu, sg, pi);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two abscissae at once: packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).
+//
+// Measured on MI355X (scripts/valu_peak.hip, profiles/r02_valu_peak.txt): a wave64 v_fma_f32 issues once per ~4.5
+// cycles per SIMD at any occupancy (36 T lane-op/s chip-wide), a v_pk_fma_f32 once per ~5.2 — two results for little
+// more than the price of one.  Both CDF kernels have a natural pair that shares all twelve parameters: the two edges
+// v - 0.5, v + 0.5 of a symbol (encode side) and two consecutive edges of a latent's row (decode side).  Each half of
+// a packed operation is the same single IEEE-754 binary32 operation as its scalar form, so every function below is
+// the scalar sequence above, lane for lane: the non-arithmetic steps (floor, int conversion, ldexp, rsq / rcp seeds,
+// compares, sign transfer) stay scalar per half.  Equality with Phi<MODE, false> is checked for EVERY binary32
+// |z| < 2^48 in both halves by fgmm_selftest_fastmath(3..5).
+// (The compiler's own SLP pairing of unrelated scalars stays off, build.sh: it pays for its pairs with moves.)
+// ---------------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat(float s) { return (f2){s, s}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// exp_nonpos on both halves WITHOUT its lower clamp, for arguments in [-2^30, 0]: below -88.38 the clamped form returns
+// less than 2^-126, and so does this one — n = floor(x * log2e + 0.5) <= -127 fits an int, the reduced argument and the
+// polynomial stay finite (|x_red| grows with the rounding of x * log2e: <= ~16 at 2^28), and v_ldexp_f32 of a finite y by
+// n <= -127 is +-0 or a denormal.  Polya and A&S only use e in 1 - e resp. fma(-c*e, poly, 1) with finite poly: 1.0f for
+// every |e| < 2^-25 of either sign.  The callers' guard (|x - mu| < 2^11, sigma >= 0.11: |z| < 2^15) keeps the argument
+// above -2^30; Phi2 == Phi<MODE, false> is checked for EVERY binary32 |z| < 2^15 (fgmm_selftest_fastmath 3, 4).
+__device__ __forceinline__ f2 exp_nonpos2(f2 x) {
+  f2 fx = fma2(x, splat(1.44269504088896341f), splat(0.5f));
+  fx.x = __builtin_floorf(fx.x);
+  fx.y = __builtin_floorf(fx.y);
+  x = fma2(-fx, splat(0.693359375f), x);
+  x = fma2(-fx, splat(-2.12194440e-4f), x);
+  const f2 z = x * x;
+  f2 y = splat(1.9875691500E-4f);
+  y = fma2(y, x, splat(1.3981999507E-3f));
+  y = fma2(y, x, splat(8.3334519073E-3f));
+  y = fma2(y, x, splat(4.1665795894E-2f));
+  y = fma2(y, x, splat(1.6666665459E-1f));
+  y = fma2(y, x, splat(5.0000001201E-1f));
+  y = fma2(y, z, x);
+  y = y + splat(1.0f);
+  return (f2){__builtin_ldexpf(y.x, (int)fx.x), __builtin_ldexpf(y.y, (int)fx.y)};
+}
+__device__ __forceinline__ f2 exp_ref2(f2 x) { // exp_ref, both halves (any argument)
+  x.x = (x.x < 88.3762626647949f) ? x.x : 88.3762626647949f;
+  x.y = (x.y < 88.3762626647949f) ? x.y : 88.3762626647949f;
+  x.x = (x.x > -88.3762626647949f) ? x.x : -88.3762626647949f;
+  x.y = (x.y > -88.3762626647949f) ? x.y : -88.3762626647949f;
+  f2 fx = fma2(x, splat(1.44269504088896341f), splat(0.5f));
+  fx.x = __builtin_floorf(fx.x);
+  fx.y = __builtin_floorf(fx.y);
+  x = fma2(-fx, splat(0.693359375f), x);
+  x = fma2(-fx, splat(-2.12194440e-4f), x);
+  const f2 z = x * x;
+  f2 y = splat(1.9875691500E-4f);
+  y = fma2(y, x, splat(1.3981999507E-3f));
+  y = fma2(y, x, splat(8.3334519073E-3f));
+  y = fma2(y, x, splat(4.1665795894E-2f));
+  y = fma2(y, x, splat(1.6666665459E-1f));
+  y = fma2(y, x, splat(5.0000001201E-1f));
+  y = fma2(y, z, x);
+  y = y + splat(1.0f);
+  const f2 p2 = {bits2f((uint32_t)((int)fx.x + 127) << 23), bits2f((uint32_t)((int)fx.y + 127) << 23)};
+  return y * p2;
+}
+// a / d for both halves of a, one denominator d with r = rcp_refined(d) (domain as div_core)
+__device__ __forceinline__ f2 div_core2(f2 a, float d, float r) {
+  const f2 nd = splat(-d), rr = splat(r);
+  const f2 q0 = a * rr;
+  const f2 e2 = fma2(nd, q0, a);
+  const f2 q1 = fma2(e2, rr, q0);
+  const f2 e3 = fma2(nd, q1, a);
+  return fma2(e3, rr, q1);
+}
+// 1 / d per half, 1 <= d < 2^60 (rcp_ge1_tame): q0 = 1 * r is r itself
+__device__ __forceinline__ f2 rcp_ge1_tame2(f2 d) {
+  const f2 r0 = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f2 e = fma2(-d, r0, splat(1.0f));
+  const f2 r = fma2(e, r0, r0);
+  const f2 e2 = fma2(-d, r, splat(1.0f));
+  const f2 q1 = fma2(e2, r, r);
+  const f2 e3 = fma2(-d, q1, splat(1.0f));
+  return fma2(e3, r, q1);
+}
+// sqrt_unit per half: x in {+0} U [2^-24, 1]
+__device__ __forceinline__ f2 sqrt_unit2(f2 x) {
+  // x == 0: rsq gives +inf and 0 * inf would be NaN; with the seed capped (any x >= 2^-24 has rsq <= 2^12) every step
+  // below yields +0, which is sqrt(0)
+  const f2 y = {__builtin_fminf(__builtin_amdgcn_rsqf(x.x), 0x1p100f), __builtin_fminf(__builtin_amdgcn_rsqf(x.y), 0x1p100f)};
+  const f2 s0 = x * y, h = splat(0.5f) * y;
+  const f2 r = fma2(-s0, s0, x);
+  return fma2(r, h, s0);
+}
+
+// Phi<MODE, true> on both halves; same domain (finite |z| < 2^48 in each half)
+template <int MODE> struct Phi2;
+template <> struct Phi2<MODE_POLYA> {
+  static __device__ __forceinline__ f2 eval(f2 z) {
+    const float c = -2.0f / 3.14159265358979323846f;
+    const f2 e = exp_nonpos2(splat(c) * (z * z));
+    f2 s = sqrt_unit2(splat(1.0f) - e);
+    s.x = bits2f((f2bits(z.x) & 0x80000000u) | (f2bits(s.x) & 0x7fffffffu));
+    s.y = bits2f((f2bits(z.y) & 0x80000000u) | (f2bits(s.y) & 0x7fffffffu));
+    return fma2(splat(0.5f), s, splat(0.5f));
+  }
+};
+template <> struct Phi2<MODE_AS> {
+  static __device__ __forceinline__ f2 eval(f2 z) {
+    const f2 az = {bits2f(f2bits(z.x) & 0x7fffffffu), bits2f(f2bits(z.y) & 0x7fffffffu)};
+    const f2 zx = splat(0.3989422804014327f) * exp_nonpos2((z * z) * splat(-0.5f));
+    const f2 d = fma2(splat(0.2316419f), az, splat(1.0f));
+    const f2 t = rcp_ge1_tame2(d);
+    f2 poly = fma2(splat(1.330274429f), t, splat(-1.821255978f));
+    poly = fma2(poly, t, splat(1.781477937f));
+    poly = fma2(poly, t, splat(-0.356563782f));
+    poly = fma2(poly, t, splat(0.319381530f));
+    poly = poly * t;
+    const f2 res_pos = fma2(-zx, poly, splat(1.0f));
+    const f2 res_neg = splat(1.0f) - res_pos;
+    return (f2){(f2bits(z.x) & 0x80000000u) ? res_neg.x : res_pos.x, (f2bits(z.y) & 0x80000000u) ? res_neg.y : res_pos.y};
+  }
+};
+template <> struct Phi2<MODE_LOGISTIC> {
+  static __device__ __forceinline__ f2 eval(f2 z) {
+    const f2 e = exp_ref2(splat(-1.0f) * (splat(1.702f) * z));
+    const f2 d = splat(1.0f) + e;
+    // d = 1 + e >= 1; e can be huge (+inf at z << 0): the guarded reciprocal, per half
+    f2 q = rcp_ge1_tame2(d);
+    if (__builtin_expect(!(tame(d.x) && tame(d.y)), 0)) q = (f2){1.0f / d.x, 1.0f / d.y};
+    return q;
+  }
+};
+
+// Parameters of one latent prepared for mix4_clamped2: sigma clamped to [0.11, 256] (entropy_models.py:817) and its
+// refined reciprocal, components paired so that the two Newton fmas are packed.  `tame` is false when some sigma is
+// NaN (torch.clamp keeps NaN; v_med3_f32 does not): the caller then takes the IEEE path with clamp_scale().
+struct Sigma4 {
+  float sg[4], rs[4];
+  bool tame;
+  __device__ __forceinline__ void set(float s0, float s1, float s2, float s3) {
+    tame = (s0 == s0) && (s1 == s1) && (s2 == s2) && (s3 == s3);
+    const f2 a = {__builtin_amdgcn_fmed3f(s0, 0.11f, 256.0f), __builtin_amdgcn_fmed3f(s1, 0.11f, 256.0f)};
+    const f2 b = {__builtin_amdgcn_fmed3f(s2, 0.11f, 256.0f), __builtin_amdgcn_fmed3f(s3, 0.11f, 256.0f)};
+    const f2 ra = {__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}, rb = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    const f2 ea = fma2(-a, ra, splat(1.0f)), eb = fma2(-b, rb, splat(1.0f));
+    const f2 qa = fma2(ea, ra, ra), qb = fma2(eb, rb, rb); // rcp_refined, two at a time
+    sg[0] = a.x; sg[1] = a.y; sg[2] = b.x; sg[3] = b.y;
+    rs[0] = qa.x; rs[1] = qa.y; rs[2] = qb.x; rs[3] = qb.y;
+  }
+};
+
+// mix4_clamped at two abscissae of one latent that lie one apart (x.y == x.x + 1.0f: the two edges of a symbol, two
+// consecutive edges of a row).  Guard: `ok` comes back false unless every numerator x.x - mu_k is finite and below
+// 2^11 in magnitude — then both halves have |x - mu_k| <= 2^11 + 1 and, sigma being in [0.11, 256], |z| < 2^15: inside
+// the domain of div_core2 and of Phi2.  One compare per component; NaN sigmas are Sigma4::tame's to catch.
+template <int MODE>
+__device__ __forceinline__ f2 mix4_clamped2(f2 x, const float (&mu)[4], const Sigma4 &S, const float (&pi)[4], bool &ok) {
+  f2 p[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f2 a = x - splat(mu[k]);
+    ok = ok && (__builtin_fabsf(a.x) < 0x1p11f); // false for inf / NaN too
+    p[k] = splat(pi[k]) * Phi2<MODE>::eval(div_core2(a, S.sg[k], S.rs[k]));
+  }
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
 // static_cast<uint16_t>(float) as x86-64 GCC emits it (cvttss2si r32 ; movzwl), rans_interface.cpp:509-510.
 // cvttss2si yields 0x80000000 for NaN / out-of-range, v_cvt_i32_f32 saturates: make the x86 answer explicit.
 __device__ __forceinline__ uint32_t quant16(float cdf) {
