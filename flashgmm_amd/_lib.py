@@ -83,7 +83,12 @@ SIGNATURES = {
     "fgmm_selftest_fastmath": (_i, [_p, _i, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "fgmm_rans_encode_symtab": (_i, [_p, _p, _i64, _pp, _psz]),
     "fgmm_rans_encode_symtab2": (_i, [_p, _p, _i64, _p, _p, _i64, _pp, _psz, _pp, _psz]),
-    "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, _i64, _i32, _p]),
+    "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, C.c_uint64, _i64, _i32, _p]),
+    "fgmm_rans_decode_tab": (_i, [_p, _sz, _p, _i, _p, _i32, _p, C.c_uint64, _i64, _i32, _p]),
+    "fgmm_build_tab_hip": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i32, _i, _p, _p, _p, C.c_uint64, _p, C.POINTER(_i32)]),
+    "fgmm_ctx_set_option": (_i, [_p, C.c_char_p, _i64]),
+    "fgmm_ctx_get_option": (_i, [_p, C.c_char_p, C.POINTER(_i64)]),
+    "fgmm_ctx_trim": (_i, [_p]),
     # table path (z hyper-latent coder), host only
     "fgmm_encode_with_indexes": (_i, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _pp, _psz]),
     "fgmm_decode_with_indexes": (_i, [_p, _sz, _p, _i64, _p, _i64, _i32, _p, _p, _p]),
@@ -174,20 +179,46 @@ def default_mode() -> int:
     return m if 0 <= m <= 2 else 0
 
 
+def set_option(device: int, name: str, value: int) -> None:
+    """a tuning knob of the device's context (include/flashgmm_amd.h: fgmm_ctx_set_option)"""
+    check(lib().fgmm_ctx_set_option(ctx(device), name.encode(), int(value)), f"fgmm_ctx_set_option({name})")
+
+
+def get_option(device: int, name: str) -> int:
+    out = C.c_int64()
+    check(lib().fgmm_ctx_get_option(ctx(device), name.encode(), C.byref(out)), f"fgmm_ctx_get_option({name})")
+    return int(out.value)
+
+
+def trim(device: int) -> None:
+    check(lib().fgmm_ctx_trim(ctx(device)), "fgmm_ctx_trim")
+
+
+def set_threads(device: int, n_threads: int) -> None:
+    """Re-create the device's context with `n_threads` host rANS workers (0: default).  Measurement aid."""
+    L = lib()
+    with _lock:
+        h = _ctxs.pop(int(device), None)
+    if h is not None:
+        L.fgmm_ctx_destroy(h)
+    ctx(device, n_threads)
+
+
 def set_profiling(device: int, enable: bool) -> None:
     check(lib().fgmm_ctx_set_profiling(ctx(device), int(enable)), "fgmm_ctx_set_profiling")
 
 
 def kernel_ms(device: int, which: int) -> float:
-    """Duration (ms) of the most recent launch of kernel `which` (0 symtab, 1 cdftab, 2 quant_stats), from HIP
-    events recorded on the stream the kernel ran on."""
+    """Duration (ms) of the most recent launch of kernel `which` (0 symtab, 1 decode-side table kernels of the last call,
+    first to last, 2 quant_stats), from HIP events recorded on the stream the kernel ran on."""
     out = C.c_float()
     check(lib().fgmm_ctx_kernel_ms(ctx(device), which, C.byref(out)), "fgmm_ctx_kernel_ms")
     return float(out.value)
 
 
 def ctx_stat(device: int, which: int) -> int:
-    """Byte / latent counts of the most recent batched call (0 encode tables D2H, 1 decode tables D2H, 2 decode latents)."""
+    """Counters of the most recent batched call (0 encode tables D2H bytes, 1 decode tables D2H bytes, 2 decode latents,
+    3 edges the decode-side kernels evaluated)."""
     out = C.c_uint64()
     check(lib().fgmm_ctx_stat(ctx(device), which, C.byref(out)), "fgmm_ctx_stat")
     return int(out.value)

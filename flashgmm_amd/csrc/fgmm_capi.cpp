@@ -55,14 +55,13 @@ int fail(int code, const char *fmt, ...) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// FGMM_TRACE=1: phase timestamps of every batched call on stderr (development aid)
+// ctx option "trace" >= 1: phase timestamps of every batched call on stderr (development aid)
 struct Trace {
   bool on;
+  int level;
   std::chrono::steady_clock::time_point t0, last;
   const char *what;
-  explicit Trace(const char *w) : what(w) {
-    static const bool enabled = getenv("FGMM_TRACE") && atoi(getenv("FGMM_TRACE")) > 0;
-    on = enabled;
+  Trace(const char *w, int lvl) : on(lvl > 0), level(lvl), what(w) {
     if (on) t0 = last = std::chrono::steady_clock::now();
   }
   void mark(const char *phase) {
@@ -158,47 +157,21 @@ struct fgmm_ctx {
   char *h_ws = nullptr; // pinned
   size_t h_cap = 0;
   std::vector<hipEvent_t> events;
-  hipStream_t fill_stream = nullptr; // decode: fill passes (the count passes of later groups run beside them)
-  hipStream_t copy_stream = nullptr; // bulk D2H of the decode tables (overlaps the table kernels of later groups)
-  hipStream_t aux_stream = nullptr;  // the few bytes of per-group pool counters
-  // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while
-  // copies are in flight (sizes are only known group by group)
+  hipStream_t copy_stream = nullptr; // bulk D2H of the decode tables (overlaps the table kernels of later launches)
+  hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
+  // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
+  struct Opts {
+    int64_t tail_items = 8, tail_pieces = 4, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1;
+  } opt;
+  // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
+  // are in flight (sizes are only known launch by launch)
   struct Chunk {
     char *p;
     size_t cap, used;
   };
   std::vector<Chunk> chunks;
-  // device staging area of the decode rows (same scheme): the fill pass writes there, one copy per group fetches it
-  std::vector<Chunk> dchunks;
   void chunks_reset() {
     for (auto &c : chunks) c.used = 0;
-    for (auto &c : dchunks) c.used = 0;
-  }
-  char *d_tmp = nullptr; // decode: the edges the count passes evaluated, read back by the fill passes
-  size_t d_tmp_cap = 0;
-  int ensure_tmp(size_t bytes) {
-    if (bytes <= d_tmp_cap) return FGMM_OK;
-    if (d_tmp) HIP_TRY(hipFree(d_tmp));
-    d_tmp = nullptr;
-    d_tmp_cap = 0;
-    HIP_TRY(hipMalloc((void **)&d_tmp, bytes));
-    d_tmp_cap = bytes;
-    return FGMM_OK;
-  }
-  int dchunk_alloc(size_t bytes, char **out) {
-    bytes = align_up(bytes, 256);
-    for (auto &c : dchunks)
-      if (c.cap - c.used >= bytes) {
-        *out = c.p + c.used;
-        c.used += bytes;
-        return FGMM_OK;
-      }
-    Chunk c{nullptr, std::max(bytes, (size_t)256 << 20), 0};
-    HIP_TRY(hipMalloc((void **)&c.p, c.cap));
-    c.used = bytes;
-    dchunks.push_back(c);
-    *out = c.p;
-    return FGMM_OK;
   }
   int chunk_alloc(size_t bytes, char **out) {
     bytes = align_up(bytes, 256);
@@ -215,15 +188,43 @@ struct fgmm_ctx {
     *out = c.p;
     return FGMM_OK;
   }
+  // device staging area of the decode tables (headers, block offsets, rows): the table kernels write there, one copy
+  // per launch fetches what was used.  Provisioned for the worst case of a call where memory allows (rows are placed by a
+  // cursor, nothing is touched beyond it), else capped: a launch that overflows is re-run with the exact size.
+  char *d_stage = nullptr;
+  size_t d_stage_cap = 0;
+  int ensure_stage(size_t bytes) {
+    if (bytes <= d_stage_cap) return FGMM_OK;
+    if (d_stage) HIP_TRY(hipFree(d_stage));
+    d_stage = nullptr;
+    d_stage_cap = 0;
+    HIP_TRY(hipMalloc((void **)&d_stage, bytes));
+    d_stage_cap = bytes;
+    return FGMM_OK;
+  }
+  size_t stage_budget() const { // bytes the staging area may take
+    if (opt.stage_max_mb > 0) return (size_t)opt.stage_max_mb << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)4 << 30;
+    return std::max((free_b + d_stage_cap) / 4, (size_t)64 << 20);
+  }
   int ensure_streams() {
-    if (!fill_stream) HIP_TRY(hipStreamCreateWithFlags(&fill_stream, hipStreamNonBlocking));
     if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     if (!aux_stream) HIP_TRY(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
     return FGMM_OK;
   }
+  void trim() {
+    if (d_ws) (void)hipFree(d_ws);
+    if (h_ws) (void)hipHostFree(h_ws);
+    if (d_stage) (void)hipFree(d_stage);
+    for (auto &c : chunks) (void)hipHostFree(c.p);
+    chunks.clear();
+    d_ws = h_ws = d_stage = nullptr;
+    d_cap = h_cap = d_stage_cap = 0;
+  }
   bool profiling = false;
-  unsigned long long stat[4] = {0, 0, 0, 0}; // last batched call: [0] encode table bytes D2H, [1] decode hdr+row bytes D2H,
-                                             // [2] decode latents, [3] decode rows that are Elias-Fano coded (unused: 0)
+  unsigned long long stat[4] = {0, 0, 0, 0}; // last batched call: [0] encode table bytes D2H, [1] decode table bytes D2H,
+                                             // [2] decode latents, [3] edges the decode-side kernels evaluated
   hipEvent_t prof[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool prof_valid[4] = {false, false, false, false};
 
@@ -327,7 +328,7 @@ struct EncItem {
 int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items, int mode) {
   const int count = (int)items.size();
   if (count == 0) return FGMM_OK;
-  Trace tr("encode");
+  Trace tr("encode", (int)ctx->opt.trace);
   // ---- plan the workspace: [descs][small: per item min|max|nz|meta][tables: per item packed] -------
   Arena ar;
   const size_t o_descs = ar.take(sizeof(EncDesc) * count);
@@ -388,11 +389,9 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     if ((rc = ctx->prof_end(2, stream))) return rc;
   }
   if ((rc = ctx->prof_begin(0, stream))) return rc;
-  static const int force_vec = getenv("FGMM_VEC") ? atoi(getenv("FGMM_VEC")) : 0; // dev: A/B the load width
-  const int vec = vec4 ? (force_vec ? force_vec : 4) : 1;
-  static const int no_linear = getenv("FGMM_NO_LINEAR") ? atoi(getenv("FGMM_NO_LINEAR")) : 0; // dev: A/B the two grid forms
+  const int vec = vec4 ? (ctx->opt.enc_vec == 1 ? 1 : 4) : 1; // option "enc_vec" = 1: A/B the narrow loads
   int64_t n_max = 0;
-  bool linear = !no_linear;
+  bool linear = ctx->opt.enc_linear != 0; // option "enc_linear" = 0: A/B the per-channel grid
   for (auto &it : items) {
     n_max = std::max(n_max, (int64_t)it.M * it.hw);
     linear = linear && it.hw % (64 * vec) == 0;
@@ -510,7 +509,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   tr.mark("all tables landed, jobs out");
   if (count > 1) ctx->pool->wait_all();
   tr.mark("host rANS done");
-  if (tr.on && getenv("FGMM_TRACE") && atoi(getenv("FGMM_TRACE")) > 1)
+  if (tr.level > 1)
     for (int i = 0; i < count; ++i)
       fprintf(stderr, "[fgmm encode]   item %2d  submitted %7.3f  job %7.3f .. %7.3f  (%.3f ms)\n", i, items[i].t_sub,
               items[i].t_start, items[i].t_end, items[i].t_end - items[i].t_start);
@@ -538,82 +537,72 @@ struct DecItem {
   // derived
   int32_t n_ch = 0;
   int64_t n = 0;
-  size_t o_list = 0, o_rank = 0, o_hdr = 0, o_used = 0, o_bsum = 0, o_boff = 0;
-  int32_t tiles = 0;
-  size_t hdr_bytes = 0;                   // header array, rounded up to 256 B
-  const char *h_hdr = nullptr;            // pinned: headers (uint32, or uint16 when hdr16)
-  bool hdr16 = false;                     // the item's headers travel in the 2-byte form
-  char *h_out = nullptr;                  // pinned: decoded symbols (host-written, read by the scatter kernel)
-  uint64_t pool_used = 0;
-  int wide = 0; // h_out holds int32 symbols (some symbol outside int16), else int16
-  // how the rows reach the host (see decode_batch): whole, or in n_piece pieces for the items of the tail window
+  size_t o_list = 0, o_rank = 0;
+  int hdr_form = 4;
+  int32_t tl = 0;     // latents per block of the single-pass kernel; 0: generic two-pass path
+  int64_t nblk = 0;   // blocks of tl latents
+  uint64_t table_bytes = 0; // headers + block offsets + rows that crossed PCIe
+  // how the tables reach the host (see decode_batch): whole, or in n_piece pieces for the items of the tail window
   int n_piece = 1;
-  uint64_t piece_end[kMaxPieces] = {};       // latents on the host once piece k has landed
-  const uint8_t *piece_base[kMaxPieces] = {}; // pinned: rows of piece k
-  hipEvent_t piece_ev[kMaxPieces] = {};      // [0] is the event the dispatcher waits for
-  std::atomic<int> copy_queued{0};           // piece_ev[0] recorded in this call (events are reused: never wait on a stale one)
+  TabPiece piece[kMaxPieces] = {};
+  hipEvent_t piece_ev[kMaxPieces] = {}; // recorded (this call) before the item's job is submitted
+  char *h_out = nullptr;                // pinned: decoded symbols (host-written, read by the scatter kernel)
+  int wide = 0; // h_out holds int32 symbols (some symbol outside int16), else int16
   std::atomic<int> done{0};
-  double t_taken = 0, t_start = 0, t_end = 0; // FGMM_TRACE=2: job timeline
+  double t_taken = 0, t_start = 0, t_end = 0; // trace level 2: job timeline
   DecItem() = default;
   DecItem(const DecItem &) = delete;
 };
 
-constexpr size_t kCounterBytes = sizeof(unsigned long long) * (3 + kMaxPieces); // per item, see DecDesc::pool_used
+constexpr size_t kCounterBytes = 4 * sizeof(unsigned long long); // per launch unit, see DecDesc::counters
 
-// Decode, batched and pipelined.  Items are cut into groups; the sizes of the variable-length tables are only known
-// on the device, so every group takes one host round trip between its two passes:
-//   caller's stream : [H2D descs][count+scan g0][count+scan g1] ...              ... [y_hat scatter, item by item]
-//   aux stream      : after count+scan g -> D2H of group g's row-pool sizes
-//   this thread     : sizes of group g known -> pack the group's rows into one staging range (device) and one
-//                     pinned range (host) of exactly that size, patch the descriptors
-//   fill stream     : [H2D descs g][hdr_pack g][fill g]   (beside the count passes of later groups; the headers go
-//                     into the same range: 2 bytes per latent where the item's half-width fits and no row is
-//                     non-monotone, else 4; the fill pass formats rows from the edges the count pass kept)
-//   copy stream     : after fill g -> ONE copy for the group's range, headers + rows (few large copies: measured
-//                     55.7 GB/s, against 51 GB/s for a copy per item)
-//   dispatcher job  : waits for the groups' copies in order and hands each item to the workers as it lands
+// frees what a call allocated outside the context's reusable buffers (rare paths: overflow re-runs, generic items)
+struct TempDevice {
+  std::vector<void *> v;
+  ~TempDevice() {
+    for (void *p : v) (void)hipFree(p);
+  }
+  int alloc(size_t bytes, char **out) {
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+    v.push_back(p);
+    *out = static_cast<char *>(p);
+    return FGMM_OK;
+  }
+};
+
+// Decode, batched and pipelined.
+//   caller's stream : [H2D descriptors][tab_kernel unit 0][tab_kernel unit 1] ...          [y_hat scatter, item by item]
+//   aux stream      : after unit u's kernel -> D2H of its four counters (cursor = bytes of rows placed)
+//   this thread     : unit u's size known -> a pinned range of exactly that size; copy stream: ONE copy per unit
+//                     (headers + block offsets + rows; few large copies reach 55.7 GB/s, a copy per item 51);
+//                     the unit's decode jobs go to the workers, each begins by waiting for its own copy
 //   host workers    : one bitstream each; symbols go to pinned memory as int16 (int32 if one does not fit)
 //   caller's stream : yhat_scatter_kernel reads them from there and writes the full float latent, zero channels too
-// so the PCIe transfer of the tables, the longest leg, overlaps the table kernels of later groups and the host
-// coding of earlier items.
+// A launch unit is a group of items (small groups first: the first tables reach the host as early as possible) or, for
+// the tail window, one piece (block range) of each of the last few items.  The single-pass kernel needs no host
+// decision before its rows exist — they go to a provisioned staging area, placed by a cursor — so every kernel of the
+// call is enqueued up front and the PCIe transfer, the longest leg, starts as soon as the first small unit is done.
 // Tail window: a bitstream decodes sequentially (~9 ns/symbol), so whatever lands last leaves one whole item of
-// host work behind it.  The last few items are therefore transferred in pieces (channel ranges), piece k of all of
-// them in one copy: their decoders start on piece 0 and follow the pieces as they land (rows are in latent order),
-// and what remains after the final copy is one piece of work instead of one item.
+// host work behind it.  The last few items therefore cross in pieces, piece k of all of them in one copy: their
+// decoders start on piece 0 and follow the pieces as they land, and what remains after the final copy is one piece of
+// work instead of one item.
+// Items whose half-width does not fit the single-pass kernel (tab_tl() == 0) take the generic two-pass kernels, one
+// item at a time, synchronously (8-byte headers past max_bs 16382).
 int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items, int mode) {
   const int count = (int)items.size();
   if (count == 0) return FGMM_OK;
-  Trace tr("decode");
+  Trace tr("decode", (int)ctx->opt.trace);
   int rc;
   if ((rc = ctx->ensure_streams())) return rc;
-  // tail window: how many trailing items land in pieces, and in how many pieces each
-  const int tail_cfg = getenv("FGMM_TAIL_ITEMS") ? atoi(getenv("FGMM_TAIL_ITEMS")) : 8;
-  const int piece_cfg = getenv("FGMM_TAIL_PIECES") ? atoi(getenv("FGMM_TAIL_PIECES")) : 4;
-  const int n_piece = std::min(std::max(piece_cfg, 1), (int)kMaxPieces);
-  const int tail_items = (n_piece > 1) ? std::min({std::max(tail_cfg, 0), count, std::max(ctx->pool->size() / 2, 1)}) : 0;
-  const int tail_begin = count - tail_items;
-  // groups of items: small first (the first tables land as early as possible), then larger; the tail window is
-  // one group of its own
-  std::vector<int> gbeg;
-  {
-    const int steady_cfg = getenv("FGMM_DEC_GROUP") ? atoi(getenv("FGMM_DEC_GROUP")) : 0;
-    const int steady = steady_cfg > 0 ? steady_cfg : (count >= 16 ? std::max(2, count / 8) : count);
-    const int first_cfg = getenv("FGMM_DEC_FIRST") ? atoi(getenv("FGMM_DEC_FIRST")) : 2;
-    int i = 0, sz = count >= 16 ? std::min(std::max(first_cfg, 1), steady) : count;
-    while (i < tail_begin) {
-      gbeg.push_back(i);
-      i = std::min(i + sz, tail_begin);
-      sz = std::min(steady, sz * 2);
-    }
-    if (tail_items) gbeg.push_back(tail_begin);
-    gbeg.push_back(count);
-  }
-  const int n_groups = (int)gbeg.size() - 1;
+  const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 65536) & ~1;
+  const bool clamped = items[0].clamp != 0, f16 = items[0].prm.dtype == FGMM_F16;
 
-  Arena ar; // device workspace; the part before the counters is mirrored in h_ws
-  const size_t o_descs = ar.take(sizeof(DecDesc) * (size_t)count);
-  const size_t o_pdescs = ar.take(sizeof(DecDesc) * (size_t)std::max(tail_items * n_piece, 1)); // piece k of tail item t: [k * tail_items + t]
-  for (auto &it : items) {
+  // ---- items: coded channels, header form, path --------------------------------------------------------------------
+  Arena ar; // device workspace, mirrored in h_ws up to the counters
+  std::vector<int> fast, generic;
+  for (int i = 0; i < count; ++i) {
+    DecItem &it = items[i];
     if (it.max_bs < 0 || it.max_bs > FGMM_MAX_BS)
       return fail(FGMM_ERR_UNSUPPORTED, "max_bs_value %d outside [0, %d]", it.max_bs, FGMM_MAX_BS);
     it.n_ch = 0;
@@ -621,49 +610,106 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.n = (int64_t)it.n_ch * it.hw;
     it.o_list = ar.take(sizeof(int32_t) * std::max(it.n_ch, 1), 16);
     it.o_rank = ar.take(sizeof(int32_t) * std::max(it.M, 1), 16);
+    it.hdr_form = tab_hdr_form(it.max_bs);
+    it.tl = tab_tl(it.max_bs, cap_e);
+    it.nblk = it.tl ? (it.n + it.tl - 1) / it.tl : 0;
+    if (it.nblk > 0x7FFFFFFFll) it.tl = 0, it.nblk = 0;
+    (it.tl ? fast : generic).push_back(i);
   }
-  const size_t o_used = ar.take(kCounterBytes * (size_t)count, 256);
-  const size_t upload_bytes = o_used;
-  for (int i = 0; i < count; ++i) items[i].o_used = o_used + kCounterBytes * (size_t)i;
-  const size_t host_fixed = ar.off;
-  for (auto &it : items) { // the header arrays of consecutive items are adjacent: one copy per group fetches them
-    it.hdr_bytes = align_up(sizeof(uint32_t) * (size_t)it.n, 256);
-    it.o_hdr = ar.take(it.hdr_bytes);
-  }
-  for (auto &it : items) {
-    it.tiles = (int32_t)((it.hw + 255) / 256);
-    const size_t nblk = (size_t)it.n_ch * (size_t)it.tiles;
-    it.o_bsum = ar.take(sizeof(uint32_t) * nblk + 64);
-    it.o_boff = ar.take(sizeof(uint64_t) * nblk + 64);
-  }
-  // temp buffer of evaluated edges, [block][W][256] uint16 per item: 300 B/latent at max_bs = 74 (1.9 GB for the Kodak
-  // batch, of 288 GB); batches that would need more than FGMM_TMP_MAX_MB (default 16 GiB) evaluate the rows twice instead
-  std::vector<size_t> tmp_off((size_t)count, 0);
-  size_t tmp_total = 0;
+  const int n_fast = (int)fast.size();
+
+  // ---- launch units over the fast items (in item order) -----------------------------------------------------------
+  struct Part { // one item's share of a unit
+    int item;
+    int64_t blk_begin, blk_end;
+    size_t o_hdr, o_blkoff; // within the unit's range
+    int piece;              // which piece of the item this is
+  };
+  struct Unit {
+    std::vector<Part> parts;
+    size_t fixed = 0, rows_cap = 0; // bytes: headers + block offsets | provisioned rows
+    size_t o_stage = 0;             // where the unit's range starts in the staging area
+    char *d_range = nullptr;        // device: [fixed | rows]
+    bool tail = false;
+  };
+  std::vector<Unit> units;
   {
-    const size_t cap = (getenv("FGMM_TMP_MAX_MB") ? strtoull(getenv("FGMM_TMP_MAX_MB"), nullptr, 10) : 16384ull) << 20;
-    for (int i = 0; i < count; ++i) {
-      const DecItem &it = items[i];
-      tmp_off[(size_t)i] = tmp_total;
-      tmp_total += sizeof(uint16_t) * (size_t)it.n_ch * (size_t)it.tiles * 256 * (size_t)(2 * (int64_t)it.max_bs + 2 + kTmpHdrRows);
-      tmp_total = align_up(tmp_total, 256);
+    const int n_piece = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tail_pieces, 1), kMaxPieces);
+    int tail_items = n_piece > 1 ? (int)std::min<int64_t>({std::max<int64_t>(ctx->opt.tail_items, 0), (int64_t)n_fast,
+                                                            (int64_t)std::max(ctx->pool->size() / 2, 1)}) : 0;
+    if (tail_items) { // pieces only pay for rows that take a while to cross: a small tail travels whole
+      int64_t lat = 0;
+      for (int k = n_fast - tail_items; k < n_fast; ++k) lat += items[fast[k]].n;
+      if (lat < 65536) tail_items = 0;
     }
-    if (tmp_total > cap) tmp_total = 0;
+    const int tail_begin = n_fast - tail_items;
+    const int steady = ctx->opt.dec_group > 0 ? (int)ctx->opt.dec_group : (n_fast >= 16 ? std::max(2, n_fast / 8) : std::max(n_fast, 1));
+    int k = 0, sz = n_fast >= 16 ? (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.dec_first, 1), steady) : std::max(n_fast, 1);
+    while (k < tail_begin) {
+      Unit u;
+      const int k1 = std::min(k + sz, tail_begin);
+      for (; k < k1; ++k) u.parts.push_back(Part{fast[k], 0, items[fast[k]].nblk, 0, 0, 0});
+      units.push_back(std::move(u));
+      sz = std::min(steady, sz * 2);
+    }
+    for (int p = 0; p < n_piece && tail_items; ++p) {
+      Unit u;
+      u.tail = true;
+      for (int t = tail_begin; t < n_fast; ++t) {
+        const DecItem &it = items[fast[t]];
+        const int64_t b0 = it.nblk * p / n_piece, b1 = it.nblk * (p + 1) / n_piece;
+        u.parts.push_back(Part{fast[t], b0, b1, 0, 0, p});
+      }
+      units.push_back(std::move(u));
+    }
+    for (int t = 0; t < n_fast; ++t) items[fast[t]].n_piece = (t >= tail_begin && tail_items) ? n_piece : 1;
   }
-  if (tmp_total && (rc = ctx->ensure_tmp(tmp_total))) return rc;
-  // events: per group [scan done][counters landed][fill done][tables landed], plus per piece of the tail window
-  // [fill done][landed]
-  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(host_fixed)) ||
-      (rc = ctx->ensure_events(4 * (size_t)n_groups + 2 * (size_t)n_piece)))
+  const int n_units = (int)units.size();
+  size_t n_parts = 0, stage_total = 0, rows_worst_total = 0;
+  for (auto &u : units) {
+    size_t off = 0;
+    for (auto &p : u.parts) {
+      const DecItem &it = items[p.item];
+      const int64_t lat = std::min<int64_t>(p.blk_end * it.tl, it.n) - std::min<int64_t>(p.blk_begin * it.tl, it.n);
+      p.o_hdr = off;
+      off += align_up((size_t)it.hdr_form * (size_t)lat, 256);
+      p.o_blkoff = off;
+      off += align_up(sizeof(uint32_t) * (size_t)(p.blk_end - p.blk_begin), 256);
+      // worst case of a row: every edge of the window kept as a uint16, plus the 2-byte form's escape header
+      u.rows_cap += (size_t)lat * (2 * (size_t)(2 * (int64_t)it.max_bs + 2) + 4);
+    }
+    u.fixed = off;
+    u.rows_cap = align_up(u.rows_cap, 256);
+    rows_worst_total += u.rows_cap;
+    n_parts += u.parts.size();
+  }
+  // staging: the worst case when it fits the budget, else every unit's row area shrinks by the same factor (a unit
+  // that then overflows is re-run with the exact size its cursor reports)
+  {
+    size_t fixed_total = 0;
+    for (auto &u : units) fixed_total += u.fixed + 512;
+    const size_t budget = fixed_total + rows_worst_total + 256 * (size_t)n_units <= ctx->d_stage_cap && ctx->opt.stage_max_mb <= 0
+                              ? ctx->d_stage_cap : ctx->stage_budget(); // the device is asked only when the area has to grow
+    if (fixed_total + rows_worst_total + 256 * (size_t)n_units > budget && rows_worst_total) {
+      const double f = budget > fixed_total ? (double)(budget - fixed_total) / (double)rows_worst_total : 0.0;
+      for (auto &u : units) u.rows_cap = align_up(std::max<size_t>((size_t)((double)u.rows_cap * f), 4096), 256);
+    }
+    for (auto &u : units) {
+      u.o_stage = stage_total;
+      stage_total += align_up(u.fixed + u.rows_cap + 256, 256);
+    }
+  }
+  const size_t o_descs = ar.take(sizeof(DecDesc) * std::max<size_t>(n_parts, 1));
+  const size_t o_counters = ar.take(kCounterBytes * (size_t)std::max(n_units, 1), 256);
+  const size_t upload_bytes = o_counters;
+  // events: per unit [kernel done][counters landed][tables landed]
+  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off)) || (rc = ctx->ensure_events(3 * (size_t)std::max(n_units, 1) + 2)) ||
+      (rc = ctx->ensure_stage(stage_total)))
     return rc;
   ctx->chunks_reset();
-  hipEvent_t *ev_scan = ctx->events.data(), *ev_counters = ev_scan + n_groups, *ev_fill = ev_counters + n_groups,
-             *ev_landed = ev_fill + n_groups, *ev_pfill = ev_landed + n_groups, *ev_pland = ev_pfill + n_piece;
+  hipEvent_t *ev_kernel = ctx->events.data(), *ev_counters = ev_kernel + n_units, *ev_landed = ev_counters + n_units;
 
-  DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_descs);
-  DecDesc *hpd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_pdescs);
-  const DecDesc *dd = reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs);
-  const DecDesc *dpd = reinterpret_cast<const DecDesc *>(ctx->d_ws + o_pdescs);
+  // ---- channel lists, descriptors ------------------------------------------------------------------------------------
   for (int i = 0; i < count; ++i) {
     DecItem &it = items[i];
     int32_t *list = reinterpret_cast<int32_t *>(ctx->h_ws + it.o_list);
@@ -674,7 +720,9 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       rank[c] = coded ? r : -1;
       if (coded) list[r++] = c;
     }
-    DecDesc &d = hd[i];
+  }
+  auto base_desc = [&](const DecItem &it) {
+    DecDesc d;
     memset(&d, 0, sizeof d);
     d.scales = it.prm.scales;
     d.means = it.prm.means;
@@ -683,58 +731,71 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.stride_c = it.prm.stride_c;
     d.stride_p = it.stride_p;
     d.hw = it.hw;
+    d.n = it.n;
     d.chan_list = reinterpret_cast<const int32_t *>(ctx->d_ws + it.o_list);
     d.n_ch = it.n_ch;
-    d.ch_begin = 0;
-    d.ch_end = it.n_ch;
     d.max_bs = it.max_bs;
     d.clamp = it.clamp;
     d.prune = 1;
-    d.tiles = it.tiles;
-    d.hdr = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_hdr);
-    d.pool = nullptr;   // set once the size is known
-    d.pool_cap = ~0ull; // the pool is carved to the exact size: the overflow flag of the scan pass stays clear
-    d.pool_used = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_used);
-    d.n_piece = i >= tail_begin ? n_piece : 1;
-    d.tmp = tmp_total ? reinterpret_cast<uint16_t *>(ctx->d_tmp + tmp_off[(size_t)i]) : nullptr;
-    d.blk_sums = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_bsum);
-    d.blk_off = reinterpret_cast<unsigned long long *>(ctx->d_ws + it.o_boff);
-  }
-  HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(ctx->d_ws + o_used, 0, kCounterBytes * (size_t)count, stream));
-  const bool clamped = items[0].clamp != 0, f16 = items[0].prm.dtype == FGMM_F16;
-  auto extent = [&](int i0, int i1, int *n_ch_max, int64_t *hw_max) {
-    *n_ch_max = 0;
-    *hw_max = 0;
-    for (int i = i0; i < i1; ++i) {
-      *n_ch_max = std::max(*n_ch_max, items[i].n_ch);
-      *hw_max = std::max(*hw_max, items[i].hw);
+    d.hdr_form = it.hdr_form;
+    d.tl = it.tl;
+    return d;
+  };
+  DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_descs);
+  const DecDesc *dd = reinterpret_cast<const DecDesc *>(ctx->d_ws + o_descs);
+  std::vector<size_t> unit_desc0((size_t)n_units + 1, 0);
+  auto fill_unit_descs = [&](int u) {
+    Unit &un = units[(size_t)u];
+    for (size_t k = 0; k < un.parts.size(); ++k) {
+      const Part &p = un.parts[k];
+      DecDesc &d = hd[unit_desc0[(size_t)u] + k];
+      d = base_desc(items[p.item]);
+      d.blk_begin = (int32_t)p.blk_begin;
+      d.blk_end = (int32_t)p.blk_end;
+      d.hdr_out = un.d_range + p.o_hdr;
+      d.blkoff_out = reinterpret_cast<uint32_t *>(un.d_range + p.o_blkoff);
+      d.rows = reinterpret_cast<uint8_t *>(un.d_range + un.fixed);
+      d.rows_cap = un.rows_cap;
+      d.counters = reinterpret_cast<unsigned long long *>(ctx->d_ws + o_counters + kCounterBytes * (size_t)u);
     }
   };
-  if ((rc = ctx->prof_begin(1, stream))) return rc;
-  for (int g = 0; g < n_groups; ++g) {
-    const int i0 = gbeg[g], i1 = gbeg[g + 1];
-    int n_ch_max;
-    int64_t hw_max;
-    extent(i0, i1, &n_ch_max, &hw_max);
-    LAUNCH_TRY(launch_cdftab_count(dd + i0, i1 - i0, n_ch_max, hw_max, mode, clamped, f16, stream));
-    HIP_TRY(hipEventRecord(ev_scan[g], stream));
-    HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_scan[g], 0));
-    HIP_TRY(hipMemcpyAsync(ctx->h_ws + items[i0].o_used, ctx->d_ws + items[i0].o_used, kCounterBytes * (size_t)(i1 - i0),
-                           hipMemcpyDeviceToHost, ctx->aux_stream));
-    HIP_TRY(hipEventRecord(ev_counters[g], ctx->aux_stream));
+  for (int u = 0; u < n_units; ++u) {
+    unit_desc0[(size_t)u + 1] = unit_desc0[(size_t)u] + units[(size_t)u].parts.size();
+    units[(size_t)u].d_range = ctx->d_stage + units[(size_t)u].o_stage;
+    fill_unit_descs(u);
   }
-  if ((rc = ctx->prof_end(1, stream))) return rc; // brackets the count + scan passes of all groups
+  HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + o_counters, 0, kCounterBytes * (size_t)std::max(n_units, 1), stream));
+  auto launch_unit = [&](int u) -> int {
+    const Unit &un = units[(size_t)u];
+    int64_t blocks_max = 0;
+    int tl_max = 16;
+    for (auto &p : un.parts) {
+      blocks_max = std::max(blocks_max, p.blk_end - p.blk_begin);
+      tl_max = std::max(tl_max, (int)items[p.item].tl);
+    }
+    LAUNCH_TRY(launch_tab(dd + unit_desc0[(size_t)u], (int)un.parts.size(), (int)blocks_max, tl_max, cap_e, mode, clamped, f16, stream));
+    return FGMM_OK;
+  };
+  unsigned long long *h_counters = reinterpret_cast<unsigned long long *>(ctx->h_ws + o_counters);
+  if ((rc = ctx->prof_begin(1, stream))) return rc;
+  for (int u = 0; u < n_units; ++u) {
+    if ((rc = launch_unit(u))) return rc;
+    HIP_TRY(hipEventRecord(ev_kernel[u], stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_kernel[u], 0));
+    HIP_TRY(hipMemcpyAsync(h_counters + 4 * (size_t)u, ctx->d_ws + o_counters + kCounterBytes * (size_t)u, kCounterBytes, hipMemcpyDeviceToHost,
+                           ctx->aux_stream));
+    HIP_TRY(hipEventRecord(ev_counters[u], ctx->aux_stream));
+  }
+  if ((rc = ctx->prof_end(1, stream))) return rc; // brackets every table kernel of the call
   tr.mark("enqueued");
 
   std::mutex done_mu;
   std::condition_variable done_cv;
-
-  auto submit_job = [&](int i, bool here) { // here: the item's tables (or their first piece) are on the host
+  auto submit_job = [&](int i) { // the item's piece events have been recorded
     DecItem *pit = &items[i];
     pit->t_taken = tr.ms();
-    auto job = [pit, here, &done_mu, &done_cv, &tr] {
-      pit->t_start = tr.ms();
+    auto job = [pit, &done_mu, &done_cv, &tr] {
       // decoded symbols: the caller's buffer, or a per-thread scratch (a fresh 600 KB malloc per stream is an mmap)
       static thread_local std::vector<int32_t> scratch;
       int32_t *sym = pit->sym_host_out;
@@ -746,17 +807,17 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
           sym = nullptr;
         }
       }
-      if (!here) { // a kernel or copy of the item's group failed
-        pit->status = FGMM_ERR_HIP;
+      if (pit->status != FGMM_OK) { // failed before its tables were built
       } else if (!sym) {
         pit->status = FGMM_ERR_NOMEM;
+      } else if (hipEventSynchronize(pit->piece_ev[0]) != hipSuccess) { // the item's (first) copy
+        pit->status = FGMM_ERR_HIP;
       } else {
-        Landing land{pit->n_piece, pit->piece_end, pit->piece_base, pit, [](void *arg, int k) -> int {
-                       return hipEventSynchronize(static_cast<DecItem *>(arg)->piece_ev[k]) == hipSuccess ? (int)FGMM_OK : (int)FGMM_ERR_HIP;
-                     }};
-        pit->status = rans_decode_cdftab(pit->enc, pit->enc_len, reinterpret_cast<const uint32_t *>(pit->h_hdr), pit->piece_base[0],
-                                         pit->n, pit->max_bs, sym, pit->n_piece > 1 ? &land : nullptr,
-                                         pit->hdr16 ? reinterpret_cast<const uint16_t *>(pit->h_hdr) : nullptr);
+        pit->t_start = tr.ms();
+        const TabView tv{pit->hdr_form, pit->tl, pit->n_piece, pit->piece, pit, [](void *arg, int k) -> int {
+                           return hipEventSynchronize(static_cast<DecItem *>(arg)->piece_ev[k]) == hipSuccess ? (int)FGMM_OK : (int)FGMM_ERR_HIP;
+                         }};
+        pit->status = rans_decode_tab(pit->enc, pit->enc_len, tv, pit->n, pit->max_bs, sym);
         if (pit->status == FGMM_OK && pit->y_hat) {
           // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
           int16_t *s16 = reinterpret_cast<int16_t *>(pit->h_out);
@@ -779,135 +840,138 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     };
     if (count == 1) job(); else ctx->pool->submit(job);
   };
+  PoolDrain drain{ctx->pool}; // on any return: wait for every job before the objects they use go away
+  TempDevice temp;
 
-  // One dispatcher (itself a pool job) waits for the copies in order and hands each item to the workers as it
-  // lands, while this thread keeps feeding the fill and copy streams group by group.
-  std::atomic<int> abandon{0};
-  auto dispatcher = [&] {
-    for (int i = 0; i < count; ++i) {
-      while (!items[i].copy_queued.load(std::memory_order_acquire)) {
-        if (abandon.load()) return;
-        __builtin_ia32_pause();
-      }
-      submit_job(i, hipEventSynchronize(items[i].piece_ev[0]) == hipSuccess);
+  // pinned output areas (decoded symbols) of all items
+  {
+    size_t out_total = 256;
+    for (auto &it : items) out_total += align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(it.n, 1), 256);
+    char *h_outs = nullptr;
+    if ((rc = ctx->chunk_alloc(out_total, &h_outs))) return rc;
+    size_t o = 0;
+    for (auto &it : items) {
+      it.h_out = h_outs + o;
+      o += align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(it.n, 1), 256);
     }
-  };
-  // Order of destruction on any return: release the dispatcher, wait for every job, then the objects they use.
-  PoolDrain drain{ctx->pool};
-  struct Abandon {
-    std::atomic<int> &f;
-    ~Abandon() { f.store(1); }
-  } abandon_on_exit{abandon};
-  if (count > 1) ctx->pool->submit(dispatcher);
-
-  if ((rc = ctx->prof_begin(3, ctx->fill_stream))) return rc;
-  for (int g = 0; g < n_groups; ++g) {
-    const int i0 = gbeg[g], i1 = gbeg[g + 1];
-    bool tail = tail_items && i0 == tail_begin;
-    if (tail) { // pieces only pay for rows that take a while to cross: small tail groups travel whole
-      int64_t lat = 0;
-      for (int i = i0; i < i1; ++i) lat += items[i].n;
-      tail = lat >= 65536;
-    }
-    const int np = tail ? n_piece : 1;
-    HIP_TRY(hipEventSynchronize(ev_counters[g]));
-    // ---- layout of the group's range, the same in the device staging area and in pinned memory:
-    //   [headers of every item: 2 bytes per latent where the item allows it, else 4][rows, piece-major: piece k of
-    //   every item, then piece k+1 ...], every part 256-byte aligned
-    size_t hdr_total = 0, n_lat_max = 0;
-    std::vector<size_t> hdr_at((size_t)(i1 - i0));
-    for (int i = i0; i < i1; ++i) {
-      DecItem &it = items[i];
-      const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
-      it.hdr16 = tab_hdr_fits16(it.max_bs) && u[2 + kMaxPieces] == 0;
-      hdr_at[(size_t)(i - i0)] = hdr_total;
-      hdr_total += align_up((it.hdr16 ? sizeof(uint16_t) : sizeof(uint32_t)) * (size_t)it.n, 256);
-      n_lat_max = std::max(n_lat_max, (size_t)it.n);
-    }
-    size_t piece_off[kMaxPieces + 1] = {0}; // byte range of piece k within the group's rows
-    std::vector<size_t> at((size_t)(i1 - i0) * (size_t)np); // [k * (i1-i0) + t]: where piece k of item t starts
-    size_t off = 0, out_total = 0;
-    for (int k = 0; k < np; ++k) {
-      piece_off[k] = off;
-      for (int i = i0; i < i1; ++i) {
-        DecItem &it = items[i];
-        const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
-        it.pool_used = u[0];
-        const uint64_t b0 = k ? u[2 + k - 1] : 0, b1 = k + 1 < np ? u[2 + k] : u[0];
-        if (b1 < b0 || b1 > u[0]) return fail(FGMM_ERR_HIP, "inconsistent piece offsets for item %d", i);
-        at[(size_t)k * (size_t)(i1 - i0) + (size_t)(i - i0)] = off;
-        off = align_up(off + (size_t)(b1 - b0), 256);
-      }
-    }
-    piece_off[np] = off;
-    const size_t range_bytes = hdr_total + off + 256; // + slack: the host's SIMD search reads a little past a row
-    for (int i = i0; i < i1; ++i) out_total += align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(items[i].n, 1), 256);
-    char *d_range = nullptr, *h_range = nullptr, *h_outs = nullptr;
-    if ((rc = ctx->dchunk_alloc(range_bytes, &d_range)) || (rc = ctx->chunk_alloc(range_bytes, &h_range)) ||
-        (rc = ctx->chunk_alloc(out_total + 256, &h_outs)))
-      return rc;
-    char *const d_rows = d_range + hdr_total, *const h_rows = h_range + hdr_total;
-    memset(h_rows + off, 0, 256);
-    size_t out_off = 0;
-    for (int i = i0; i < i1; ++i) {
-      DecItem &it = items[i];
-      const unsigned long long *u = reinterpret_cast<const unsigned long long *>(ctx->h_ws + it.o_used);
-      it.h_hdr = h_range + hdr_at[(size_t)(i - i0)];
-      hd[i].hdr_out = d_range + hdr_at[(size_t)(i - i0)];
-      hd[i].hdr_compact = it.hdr16 ? 1 : 0;
-      it.h_out = h_outs + out_off;
-      out_off += align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(it.n, 1), 256);
-      it.n_piece = np;
-      for (int k = 0; k < np; ++k) {
-        const size_t a = at[(size_t)k * (size_t)(i1 - i0) + (size_t)(i - i0)];
-        const uint64_t b0 = k ? u[2 + k - 1] : 0;
-        it.piece_base[k] = reinterpret_cast<const uint8_t *>(h_rows + a);
-        it.piece_end[k] = (uint64_t)((int64_t)it.n_ch * (k + 1) / np) * (uint64_t)it.hw;
-        it.piece_ev[k] = tail ? ev_pland[k] : ev_landed[g];
-        // the fill pass addresses rows as pool + (offset within the item): bias the base by the piece's start
-        DecDesc &d = tail ? hpd[k * tail_items + (i - i0)] : hd[i];
-        if (tail) d = hd[i];
-        d.pool = reinterpret_cast<uint8_t *>(d_rows + a) - b0;
-        d.ch_begin = (int32_t)((int64_t)it.n_ch * k / np);
-        d.ch_end = (int32_t)((int64_t)it.n_ch * (k + 1) / np);
-      }
-    }
-    int n_ch_max;
-    int64_t hw_max;
-    extent(i0, i1, &n_ch_max, &hw_max);
-    // ---- headers into the range, fill, then fetch: ONE copy for an ordinary group (headers + rows), one per piece
-    // for the tail window (the first carries the headers)
-    HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs + sizeof(DecDesc) * (size_t)i0, &hd[i0], sizeof(DecDesc) * (size_t)(i1 - i0),
-                           hipMemcpyHostToDevice, ctx->fill_stream));
-    LAUNCH_TRY(launch_hdr_pack(dd + i0, i1 - i0, (int64_t)n_lat_max, ctx->fill_stream));
-    if (!tail) {
-      LAUNCH_TRY(launch_cdftab_fill(dd + i0, i1 - i0, n_ch_max, hw_max, mode, clamped, f16, ctx->fill_stream));
-      HIP_TRY(hipEventRecord(ev_fill[g], ctx->fill_stream));
-      HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_fill[g], 0));
-      if (hdr_total + off) HIP_TRY(hipMemcpyAsync(h_range, d_range, hdr_total + off, hipMemcpyDeviceToHost, ctx->copy_stream));
-      HIP_TRY(hipEventRecord(ev_landed[g], ctx->copy_stream));
-    } else {
-      HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_pdescs, hpd, sizeof(DecDesc) * (size_t)(tail_items * n_piece), hipMemcpyHostToDevice,
-                             ctx->fill_stream));
-      for (int k = 0; k < np; ++k) {
-        LAUNCH_TRY(launch_cdftab_fill(dpd + k * tail_items, tail_items, n_ch_max, hw_max, mode, clamped, f16, ctx->fill_stream));
-        HIP_TRY(hipEventRecord(ev_pfill[k], ctx->fill_stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_pfill[k], 0));
-        const size_t c0 = k ? hdr_total + piece_off[k] : 0, c1 = hdr_total + piece_off[k + 1];
-        if (c1 > c0) HIP_TRY(hipMemcpyAsync(h_range + c0, d_range + c0, c1 - c0, hipMemcpyDeviceToHost, ctx->copy_stream));
-        HIP_TRY(hipEventRecord(ev_pland[k], ctx->copy_stream));
-      }
-    }
-    for (int i = i0; i < i1; ++i) items[i].copy_queued.store(1, std::memory_order_release);
   }
-  if ((rc = ctx->prof_end(3, ctx->fill_stream))) return rc;
-  if (count == 1) dispatcher();
+
+  // ---- unit by unit: size known -> pinned range, ONE copy, jobs -------------------------------------------------------
+  unsigned long long edges = 0;
+  std::vector<int> tail_jobs;
+  for (int u = 0; u < n_units; ++u) {
+    Unit &un = units[(size_t)u];
+    HIP_TRY(hipEventSynchronize(ev_counters[u]));
+    unsigned long long *cn = h_counters + 4 * (size_t)u;
+    if (cn[1]) { // the provisioned row area was too small: once more, into an area of exactly the size the cursor asks for
+      const size_t need = align_up((size_t)cn[0], 256);
+      char *d_new = nullptr;
+      if ((rc = temp.alloc(un.fixed + need + 256, &d_new))) return rc;
+      un.d_range = d_new;
+      un.rows_cap = need;
+      fill_unit_descs(u);
+      HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs + sizeof(DecDesc) * unit_desc0[(size_t)u], hd + unit_desc0[(size_t)u],
+                             sizeof(DecDesc) * un.parts.size(), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemsetAsync(ctx->d_ws + o_counters + kCounterBytes * (size_t)u, 0, kCounterBytes, stream));
+      if ((rc = launch_unit(u))) return rc;
+      HIP_TRY(hipEventRecord(ev_kernel[u], stream));
+      HIP_TRY(hipMemcpyAsync(cn, ctx->d_ws + o_counters + kCounterBytes * (size_t)u, kCounterBytes, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (cn[1]) return fail(FGMM_ERR_HIP, "decode tables overflow their exactly sized area (unit %d: %llu of %zu bytes)", u, cn[0], need);
+    }
+    const size_t used = (size_t)cn[0];
+    edges += cn[2];
+    char *h_range = nullptr;
+    if ((rc = ctx->chunk_alloc(un.fixed + used + 256, &h_range))) return rc;
+    memset(h_range + un.fixed + used, 0, 256); // slack: the host's SIMD search reads a little past a row
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_kernel[u], 0));
+    if (un.fixed + used) HIP_TRY(hipMemcpyAsync(h_range, un.d_range, un.fixed + used, hipMemcpyDeviceToHost, ctx->copy_stream));
+    HIP_TRY(hipEventRecord(ev_landed[u], ctx->copy_stream));
+    for (auto &p : un.parts) {
+      DecItem &it = items[p.item];
+      TabPiece &pc = it.piece[p.piece];
+      pc.hdr = h_range + p.o_hdr;
+      pc.blk_off = reinterpret_cast<const uint32_t *>(h_range + p.o_blkoff);
+      pc.rows = reinterpret_cast<const uint8_t *>(h_range + un.fixed);
+      pc.rows_len = used + 256;
+      pc.end = std::min<int64_t>(p.blk_end * it.tl, it.n);
+      it.piece_ev[p.piece] = ev_landed[u];
+      const int64_t lat = pc.end - std::min<int64_t>(p.blk_begin * it.tl, it.n);
+      it.table_bytes += (uint64_t)it.hdr_form * (uint64_t)lat + sizeof(uint32_t) * (uint64_t)(p.blk_end - p.blk_begin);
+      if (!un.tail) submit_job(p.item); // its one copy is queued
+      else if (p.piece == 0) tail_jobs.push_back(p.item);
+    }
+    // rows are shared by the unit's items: account them once
+    if (!un.parts.empty()) items[un.parts[0].item].table_bytes += used;
+  }
+  for (int i : tail_jobs) submit_job(i); // every piece's copy is queued: the events the decoders wait on are this call's
+  tr.mark("sizes known, copies queued");
+
+  // ---- generic path: items too wide for the single-pass kernel, one at a time ------------------------------------------
+  for (int i : generic) {
+    DecItem &it = items[i];
+    it.n_piece = 1;
+    if (it.n == 0) {
+      it.piece[0] = TabPiece{ctx->h_ws, nullptr, reinterpret_cast<const uint8_t *>(ctx->h_ws), 0, 0};
+      it.piece_ev[0] = ev_landed[n_units];
+      HIP_TRY(hipEventRecord(ev_landed[n_units], stream));
+      submit_job(i);
+      continue;
+    }
+    const int32_t tiles = (int32_t)((it.hw + 255) / 256);
+    const size_t nblk = (size_t)it.n_ch * (size_t)tiles;
+    const size_t hdr_bytes = align_up((size_t)(it.hdr_form == 8 ? 8 : 4) * (size_t)it.n, 256);
+    Arena ga;
+    const size_t g_desc = ga.take(sizeof(DecDesc)), g_used = ga.take(64), g_hdr = ga.take(hdr_bytes), g_bsum = ga.take(4 * nblk + 64),
+                 g_boff = ga.take(8 * nblk + 64);
+    char *d_g = nullptr;
+    if ((rc = temp.alloc(ga.off, &d_g))) return rc;
+    DecDesc d = base_desc(it);
+    d.hdr_form = it.hdr_form == 8 ? 8 : 4; // the generic kernels write 4- or 8-byte headers
+    it.hdr_form = d.hdr_form;
+    d.hdr = d_g + g_hdr;
+    d.tiles = tiles;
+    d.pool = nullptr;
+    d.pool_cap = ~0ull;
+    d.pool_used = reinterpret_cast<unsigned long long *>(d_g + g_used);
+    d.blk_sums = reinterpret_cast<uint32_t *>(d_g + g_bsum);
+    d.blk_off = reinterpret_cast<unsigned long long *>(d_g + g_boff);
+    HIP_TRY(hipMemsetAsync(d_g + g_used, 0, 64, stream));
+    HIP_TRY(hipMemcpyAsync(d_g + g_desc, &d, sizeof d, hipMemcpyHostToDevice, stream));
+    LAUNCH_TRY(launch_cdftab_count(reinterpret_cast<const DecDesc *>(d_g + g_desc), 1, it.n_ch, it.hw, mode, clamped, f16, stream));
+    unsigned long long used4[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(used4, d_g + g_used, sizeof used4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (used4[3]) {
+      it.status = FGMM_ERR_UNSUPPORTED;
+      it.piece_ev[0] = ev_landed[n_units];
+      HIP_TRY(hipEventRecord(ev_landed[n_units], stream));
+      submit_job(i);
+      continue;
+    }
+    const size_t pool_bytes = (size_t)used4[0];
+    char *d_pool = nullptr, *h_range = nullptr;
+    if ((rc = temp.alloc(pool_bytes + 256, &d_pool)) || (rc = ctx->chunk_alloc(hdr_bytes + pool_bytes + 256, &h_range))) return rc;
+    d.pool = reinterpret_cast<uint8_t *>(d_pool);
+    HIP_TRY(hipMemcpyAsync(d_g + g_desc, &d, sizeof d, hipMemcpyHostToDevice, stream));
+    LAUNCH_TRY(launch_cdftab_fill(reinterpret_cast<const DecDesc *>(d_g + g_desc), 1, it.n_ch, it.hw, mode, clamped, f16, stream));
+    HIP_TRY(hipMemcpyAsync(h_range, d_g + g_hdr, hdr_bytes, hipMemcpyDeviceToHost, stream));
+    if (pool_bytes) HIP_TRY(hipMemcpyAsync(h_range + hdr_bytes, d_pool, pool_bytes, hipMemcpyDeviceToHost, stream));
+    memset(h_range + hdr_bytes + pool_bytes, 0, 256);
+    HIP_TRY(hipStreamSynchronize(stream));
+    it.piece[0] = TabPiece{h_range, nullptr, reinterpret_cast<const uint8_t *>(h_range + hdr_bytes), pool_bytes + 256, it.n};
+    it.piece_ev[0] = ev_landed[n_units]; // nothing left to wait for: the stream has just been synchronised
+    HIP_TRY(hipEventRecord(ev_landed[n_units], stream));
+    it.table_bytes = hdr_bytes + pool_bytes;
+    submit_job(i);
+  }
+
   ctx->stat[1] = ctx->stat[2] = 0;
+  ctx->stat[3] = edges;
   for (auto &it : items) {
-    ctx->stat[1] += it.pool_used + (it.hdr16 ? sizeof(uint16_t) : sizeof(uint32_t)) * (unsigned long long)it.n;
+    ctx->stat[1] += it.table_bytes;
     ctx->stat[2] += (unsigned long long)it.n;
   }
-  tr.mark("sizes known, fill + copies queued");
 
   // ---- symbols back to the GPU item by item: scatter kernel on the caller's stream ---------------------------
   int first_err = FGMM_OK;
@@ -925,12 +989,14 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   tr.mark("host rANS done");
   HIP_TRY(hipStreamSynchronize(stream));
   tr.mark("y_hat written");
-  if (tr.on && getenv("FGMM_TRACE") && atoi(getenv("FGMM_TRACE")) > 1)
+  if (tr.level > 1)
     for (int i = 0; i < count; ++i)
       fprintf(stderr, "[fgmm decode]   item %2d  pieces %d  taken %7.3f  job %7.3f .. %7.3f  (%.3f ms)\n", i, items[i].n_piece,
               items[i].t_taken, items[i].t_start, items[i].t_end, items[i].t_end - items[i].t_start);
   if (first_err)
-    return fail(first_err, "host rANS decode failed (%d)%s", first_err, first_err == FGMM_ERR_STREAM ? ": bitstream too short" : "");
+    return fail(first_err, "host rANS decode failed (%d)%s", first_err,
+                first_err == FGMM_ERR_STREAM ? ": bitstream too short"
+                : first_err == FGMM_ERR_UNSUPPORTED ? ": an evaluation window beyond 2^20 edges (see FGMM_MAX_BS)" : "");
   return FGMM_OK;
 }
 
@@ -949,6 +1015,26 @@ extern "C" {
 
 int fgmm_abi_version(void) { return FGMM_ABI_VERSION; }
 const char *fgmm_last_error(void) { return t_err; }
+
+namespace {
+struct OptName {
+  const char *name;
+  int64_t fgmm_ctx::Opts::*field;
+  int64_t lo, hi;
+  const char *env; // read once at context creation (compatibility with round-1 scripts)
+};
+const OptName kOpts[] = {
+    {"tail_items", &fgmm_ctx::Opts::tail_items, 0, 1 << 20, "FGMM_TAIL_ITEMS"},
+    {"tail_pieces", &fgmm_ctx::Opts::tail_pieces, 1, kMaxPieces, "FGMM_TAIL_PIECES"},
+    {"dec_group", &fgmm_ctx::Opts::dec_group, 0, 1 << 20, "FGMM_DEC_GROUP"},
+    {"dec_first", &fgmm_ctx::Opts::dec_first, 1, 1 << 20, "FGMM_DEC_FIRST"},
+    {"tab_cap_e", &fgmm_ctx::Opts::tab_cap_e, 256, 65536, "FGMM_TAB_CAP_E"},
+    {"stage_max_mb", &fgmm_ctx::Opts::stage_max_mb, 0, 1 << 30, "FGMM_STAGE_MAX_MB"},
+    {"trace", &fgmm_ctx::Opts::trace, 0, 2, "FGMM_TRACE"},
+    {"enc_vec", &fgmm_ctx::Opts::enc_vec, 0, 4, "FGMM_VEC"},
+    {"enc_linear", &fgmm_ctx::Opts::enc_linear, 0, 1, nullptr},
+};
+} // namespace
 
 int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {
   if (!out) return fail(FGMM_ERR_INVALID, "out == NULL");
@@ -969,6 +1055,8 @@ int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {
   if (!c) return fail(FGMM_ERR_NOMEM, "ctx");
   c->device = device;
   c->pool = new Pool(n_threads);
+  for (const OptName &o : kOpts)
+    if (o.env && getenv(o.env)) c->opt.*(o.field) = std::min(std::max<int64_t>(atoll(getenv(o.env)), o.lo), o.hi);
   *out = c;
   return FGMM_OK;
 }
@@ -982,16 +1070,43 @@ void fgmm_ctx_destroy(fgmm_ctx *ctx) {
     for (auto &pr : ctx->prof)
       for (auto e : pr)
         if (e) (void)hipEventDestroy(e);
-    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
-    if (ctx->h_ws) (void)hipHostFree(ctx->h_ws);
-    for (auto &c : ctx->chunks) (void)hipHostFree(c.p);
-    for (auto &c : ctx->dchunks) (void)hipFree(c.p);
-    if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
+    ctx->trim();
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-    if (ctx->fill_stream) (void)hipStreamDestroy(ctx->fill_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   }
   delete ctx;
+}
+
+int fgmm_ctx_set_option(fgmm_ctx *ctx, const char *name, int64_t value) {
+  if (!ctx || !name) return fail(FGMM_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  for (const OptName &o : kOpts)
+    if (!strcmp(o.name, name)) {
+      if (value < o.lo || value > o.hi) return fail(FGMM_ERR_INVALID, "option %s: %lld outside [%lld, %lld]", name, (long long)value, (long long)o.lo, (long long)o.hi);
+      ctx->opt.*(o.field) = value;
+      return FGMM_OK;
+    }
+  return fail(FGMM_ERR_INVALID, "unknown option '%s'", name);
+}
+
+int fgmm_ctx_get_option(fgmm_ctx *ctx, const char *name, int64_t *value_out) {
+  if (!ctx || !name || !value_out) return fail(FGMM_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  for (const OptName &o : kOpts)
+    if (!strcmp(o.name, name)) {
+      *value_out = ctx->opt.*(o.field);
+      return FGMM_OK;
+    }
+  return fail(FGMM_ERR_INVALID, "unknown option '%s'", name);
+}
+
+int fgmm_ctx_trim(fgmm_ctx *ctx) {
+  if (!ctx) return fail(FGMM_ERR_INVALID, "ctx == NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+  ctx->trim();
+  return FGMM_OK;
 }
 
 int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable) {
@@ -1308,7 +1423,7 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
                           int32_t max_bs, int flags, uint32_t *hdr, uint8_t *pool, uint64_t pool_cap,
                           uint64_t *pool_used) {
   if (!ctx || n < 0 || !mode_ok(mode) || !pool_used) return fail(FGMM_ERR_INVALID, "bad argument");
-  if (max_bs < 0 || max_bs > FGMM_MAX_BS) return fail(FGMM_ERR_UNSUPPORTED, "max_bs %d outside [0, %d]", max_bs, FGMM_MAX_BS);
+  if (max_bs < 0 || max_bs > FGMM_MAX_BS_H4) return fail(FGMM_ERR_UNSUPPORTED, "max_bs %d outside [0, %d] (4-byte headers)", max_bs, FGMM_MAX_BS_H4);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   const int32_t tiles = (int32_t)((n + 255) / 256);
@@ -1324,12 +1439,12 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   hd->stride_k = stride_k;
   hd->stride_p = stride_n;
   hd->hw = n;
+  hd->n = n;
   hd->n_ch = 1;
-  hd->ch_begin = 0;
-  hd->ch_end = 1;
   hd->max_bs = max_bs;
   hd->prune = (flags & FGMM_TAB_NO_PRUNE) ? 0 : 1;
   hd->clamp = (flags & FGMM_TAB_CLAMP) ? 1 : 0;
+  hd->hdr_form = 4;
   hd->tiles = tiles;
   hd->hdr = hdr;
   hd->pool = pool;
@@ -1338,13 +1453,64 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   hd->blk_sums = reinterpret_cast<uint32_t *>(ctx->d_ws + o_bsum);
   hd->blk_off = reinterpret_cast<unsigned long long *>(ctx->d_ws + o_boff);
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 16, s));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 32, s));
   if (n) LAUNCH_TRY(launch_cdftab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, 1, n, mode, (flags & FGMM_TAB_CLAMP) != 0, false, s));
-  unsigned long long used[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(used, ctx->d_ws + 1024, 16, hipMemcpyDeviceToHost, s));
+  unsigned long long used[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(used, ctx->d_ws + 1024, 32, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipMemcpy(pool_used, used, sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (used[3]) return fail(FGMM_ERR_UNSUPPORTED, "an evaluation window beyond 2^20 edges");
   if (used[1]) return fail(FGMM_ERR_NOMEM, "pool_cap %llu bytes too small (need %llu)", (unsigned long long)pool_cap, used[0]);
+  return FGMM_OK;
+}
+
+int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means, const float *weights,
+                       int64_t n, int64_t stride_n, int64_t stride_k, int mode, int32_t max_bs, int flags, void *hdr,
+                       uint32_t *blk_off, uint8_t *rows, uint64_t rows_cap, uint64_t *rows_used, int32_t *tl_out) {
+  if (!ctx || n < 0 || !mode_ok(mode) || !rows_used || !tl_out) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (max_bs < 0 || max_bs > FGMM_MAX_BS) return fail(FGMM_ERR_UNSUPPORTED, "max_bs %d outside [0, %d]", max_bs, FGMM_MAX_BS);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 65536) & ~1;
+  const int tl = tab_tl(max_bs, cap_e);
+  *tl_out = tl;
+  if (!tl) return fail(FGMM_ERR_UNSUPPORTED, "2*max_bs+2 = %lld edges per latent do not fit the single-pass kernel (tab_cap_e = %d)", 2ll * max_bs + 2, cap_e);
+  const int64_t nblk = (n + tl - 1) / tl;
+  if (nblk > 0x7FFFFFFFll) return fail(FGMM_ERR_UNSUPPORTED, "too many blocks");
+  int rc;
+  if ((rc = ctx->ensure_device(4096)) || (rc = ctx->ensure_host(4096))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws);
+  memset(hd, 0, sizeof *hd);
+  hd->scales = scales;
+  hd->means = means;
+  hd->weights = weights;
+  hd->stride_k = stride_k;
+  hd->stride_p = stride_n;
+  hd->hw = n;
+  hd->n = n;
+  hd->n_ch = 1;
+  hd->max_bs = max_bs;
+  hd->prune = (flags & FGMM_TAB_NO_PRUNE) ? 0 : 1;
+  hd->clamp = (flags & FGMM_TAB_CLAMP) ? 1 : 0;
+  hd->hdr_form = tab_hdr_form(max_bs);
+  hd->tl = tl;
+  hd->blk_begin = 0;
+  hd->blk_end = (int32_t)nblk;
+  hd->hdr_out = hdr;
+  hd->blkoff_out = blk_off;
+  hd->rows = rows;
+  hd->rows_cap = rows_cap;
+  hd->counters = reinterpret_cast<unsigned long long *>(ctx->d_ws + 1024);
+  HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 32, s));
+  if (n) LAUNCH_TRY(launch_tab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, (int)nblk, tl, cap_e, mode, (flags & FGMM_TAB_CLAMP) != 0, false, s));
+  unsigned long long cn[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(cn, ctx->d_ws + 1024, 32, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMemcpy(rows_used, cn, sizeof(uint64_t), hipMemcpyHostToDevice));
+  ctx->stat[3] = cn[2];
+  if (cn[1]) return fail(FGMM_ERR_NOMEM, "rows_cap %llu bytes too small (need %llu)", (unsigned long long)rows_cap, cn[0]);
   return FGMM_OK;
 }
 

@@ -38,54 +38,77 @@ struct DecDesc {
   const void *scales, *means, *weights; // float32 or float16 planes
   int64_t stride_k, stride_c, stride_p;
   int64_t hw;
-  const int32_t *chan_list; // device [n_ch] source channel of compact channel j; null: identity
+  int64_t n;                     // latents = n_ch * hw
+  const int32_t *chan_list;      // device [n_ch] source channel of compact channel j; null: identity
   int32_t n_ch;
   int32_t max_bs;
   int32_t clamp;
-  int32_t prune;                 // 1: skip the saturated tails (exact, see cdftab_count_kernel); 0: evaluate all of F
+  int32_t prune;                 // 1: skip the saturated tails (exact, see tab_window); 0: evaluate all of F
+  int32_t hdr_form;              // bytes per header as the host gets them: 2, 4 or 8 (format v4 below)
+  int32_t tl;                    // tab_kernel: latents per block (rows of a block are contiguous, blocks are placed by a cursor)
+  // ---- tab_kernel (single pass): the blocks [blk_begin, blk_end) of this item, into one launch's range
+  int32_t blk_begin, blk_end;
+  void *hdr_out;                 // headers of latent blk_begin * tl onward
+  uint32_t *blkoff_out;          // [blk_end - blk_begin] byte offset / 4 of each block's first row, from `rows`
+  uint8_t *rows;                 // the launch's row area (device staging)
+  unsigned long long rows_cap;   // bytes
+  unsigned long long *counters;  // shared by the launch: [0] cursor = bytes of rows placed, [1] overflow (a block did not fit),
+                                 // [2] edges evaluated, [3] non-monotone rows
+  // ---- generic two-pass path (cdftab_count / scan / fill): any half-width, rows sequential in latent order
+  void *hdr;                     // [n] headers, 4-byte form (8-byte form when hdr_form == 8)
   int32_t tiles;                 // blocks per channel = ceil(hw / 256)
   int32_t pad_;
-  uint32_t *hdr;                 // [n_ch*hw] 4-byte headers (written by the count pass, read by the fill pass and the host)
-  void *hdr_out;                 // hdr_pack_kernel: the headers as the host gets them (uint32, or uint16 if hdr_compact)
-  int32_t hdr_compact, pad3_;
-  int32_t ch_begin, ch_end;      // compact channels the fill pass covers (a launch may fill an item piece by piece)
-  uint8_t *pool;                 // rows, latent order (device memory, or pinned host memory written over PCIe)
+  uint8_t *pool;                 // rows, latent order
   unsigned long long pool_cap;   // bytes
-  unsigned long long *pool_used; // [0] bytes used, [1] overflow flag, [2 + k] byte offset of the first row of piece
-                                 // k + 1 (k < n_piece - 1), piece k = compact channels [n_ch*k/n_piece, n_ch*(k+1)/n_piece),
-                                 // [2 + kMaxPieces] some row is non-monotone (written when n_piece >= 1)
-  int32_t n_piece;               // 0 or 1: no piece offsets wanted (at most FGMM_MAX_PIECES)
-  int32_t pad2_;
-  uint16_t *tmp;                 // null, or [n_ch*tiles][kTmpHdrRows + W][256]: per lane its evaluation window (j_lo, j_hi,
-                                 // T_sat) and the edges the count pass evaluated (row t = each lane's t-th edge,
-                                 // W = 2*max_bs+2): the fill pass formats rows from them, no second evaluation
+  unsigned long long *pool_used; // [0] bytes used, [1] overflow flag, [2] some row is non-monotone
   uint32_t *blk_sums;            // [n_ch*tiles] row bytes per block
   unsigned long long *blk_off;   // [n_ch*tiles] byte offset of each block's first row
 };
 
-// ---- decode-side table format v3 (documented in include/flashgmm_amd.h) -------------------------------------
-//   hdr  (uint32): int16 a | cnt << 16 (15 bits) | nonmono << 31
-//   hdr  (uint16, batched decode only, items with 2*max_bs+2 <= 254 and no non-monotone row): (a + max_bs) | cnt << 8
+// ---- decode-side table format v4 (documented in include/flashgmm_amd.h) -------------------------------------
+//   header of latent i, one of three forms (per item):
+//     2 bytes: (a + max_bs) | cnt << 8, cnt in [1, 254]                    items with 2*max_bs + 2 <= 254
+//              cnt field 255 = escape: the row starts with a 4-byte header of the next form (non-monotone rows)
+//     4 bytes: int16 a | cnt << 16 (15 bits) | nonmono << 31                 items with max_bs <= 16382
+//     8 bytes: int32 a ; cnt (31 bits) | nonmono << 31                       any half-width
 //   row i = F_i[a .. a+cnt), starting at the first non-zero edge (F_i[v < a] = 0, F_i[v >= a+cnt] = last entry);
-//   rows in latent order, each 4-byte aligned, no stored offset:
-//     raw (cnt < 64 or nonmono): uint16[round2(cnt)], padded with the last value
-//     EF  (cnt >= 64, monotone): uint8 lows[round8(cnt)] ; uint64 upper[U], U = ceil((cnt + 256) / 64),
-//                                bit ((E_j >> 8) + j) set for every entry j
+//   rows 4-byte aligned:
+//     raw (cnt < kTabEfMin or nonmono): uint16[round2(cnt)], padded with the last value
+//     EF  (cnt >= kTabEfMin, monotone): uint8 lows[round4(cnt)] ; uint32 upper[U], U = ceil((cnt + 256) / 32),
+//                                       bit ((E_j >> 8) + j) set for every entry j
+//   placement: sequential in latent order (generic path, the building-block API), or per block of `tl` latents at
+//   rows + 4 * blk_off[block] (tab_kernel: blocks are placed by an atomic cursor, in no particular order)
 constexpr int kMaxPieces = 8; // FGMM_MAX_PIECES
-constexpr int kTmpHdrRows = 4; // see DecDesc::tmp
 #ifndef FGMM_EF_MIN
-#define FGMM_EF_MIN 64
+#define FGMM_EF_MIN 48
 #endif
 constexpr uint32_t kTabEfMin = FGMM_EF_MIN; // rows with at least this many entries are Elias-Fano coded
+constexpr uint32_t kHdr2Escape = 255;
 FGMM_HD static inline uint32_t tab_hdr_pack(int32_t a, uint32_t cnt, uint32_t nonmono) {
   return (uint32_t)(uint16_t)(int16_t)a | ((cnt & 0x7FFFu) << 16) | (nonmono << 31);
 }
 FGMM_HD static inline int32_t tab_hdr_a(uint32_t h) { return (int32_t)(int16_t)(uint16_t)(h & 0xFFFFu); }
 FGMM_HD static inline uint32_t tab_hdr_cnt(uint32_t h) { return (h >> 16) & 0x7FFFu; }
 FGMM_HD static inline uint32_t tab_hdr_nonmono(uint32_t h) { return h >> 31; }
+FGMM_HD static inline unsigned long long tab_hdr8_pack(int32_t a, uint32_t cnt, uint32_t nonmono) {
+  return (unsigned long long)(uint32_t)a | ((unsigned long long)((cnt & 0x7FFFFFFFu) | (nonmono << 31)) << 32);
+}
 FGMM_HD static inline bool tab_row_is_ef(uint32_t cnt, uint32_t nonmono) { return cnt >= kTabEfMin && !nonmono; }
-FGMM_HD static inline uint32_t tab_row_bytes(uint32_t cnt, uint32_t nonmono) {
-  return tab_row_is_ef(cnt, nonmono) ? ((cnt + 7u) & ~7u) + 8u * ((cnt + 256u + 63u) >> 6) : 2u * ((cnt + 1u) & ~1u);
+FGMM_HD static inline uint32_t tab_ef_lows_bytes(uint32_t cnt) { return (cnt + 3u) & ~3u; }
+FGMM_HD static inline uint32_t tab_ef_words(uint32_t cnt) { return (cnt + 256u + 31u) >> 5; }
+FGMM_HD static inline unsigned long long tab_row_bytes(uint32_t cnt, uint32_t nonmono) {
+  return tab_row_is_ef(cnt, nonmono) ? (unsigned long long)tab_ef_lows_bytes(cnt) + 4ull * tab_ef_words(cnt)
+                                     : 2ull * (((unsigned long long)cnt + 1u) & ~1ull);
+}
+FGMM_HD static inline bool tab_hdr_fits16(int32_t max_bs) { return 2 * (int64_t)max_bs + 2 <= 254; }
+FGMM_HD static inline int tab_hdr_form(int32_t max_bs) { return tab_hdr_fits16(max_bs) ? 2 : (max_bs <= 16382 ? 4 : 8); }
+// tab_kernel: entries of evaluated edges one block may keep in LDS, and the latents per block that guarantees it
+constexpr int kTabCapE = 16384;
+constexpr int kTabMaxTl = 256;
+FGMM_HD static inline int tab_tl(int32_t max_bs, int cap_e) { // 0: the item does not fit the single-pass kernel
+  const int64_t W = 2 * (int64_t)max_bs + 2;
+  const int64_t t = (cap_e / W) & ~15ll;
+  return t >= 16 ? (int)(t > kTabMaxTl ? kTabMaxTl : t) : 0;
 }
 
 // ---- kernel launchers (fgmm_kernels.hip); stream is a hipStream_t; all return hipError_t as int ----------
@@ -96,17 +119,19 @@ int launch_symtab(const EncDesc *d_descs, int count, int M_max, int64_t hw_max, 
                   bool clamped, bool f16, void *stream);
 int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, const float *weights, int64_t n,
                     int64_t stride_n, int64_t stride_k, int mode, float *c1, float *c2, void *stream);
-// count + scan (sizes and offsets), then fill (rows); launch_cdftab = both, back to back on one stream
+// generic path: count + scan (sizes and offsets), then fill (rows); launch_cdftab = both, back to back on one stream
 int launch_cdftab_count(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
                         void *stream);
 int launch_cdftab_fill(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
                        void *stream);
 int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
                   void *stream);
+// single pass: window, evaluation (flattened over pairs of edges, parameters staged in LDS), trimming, rows.
+// blocks_max = largest blk_end - blk_begin of the launch; tl_max = largest tl; cap_e as passed to tab_tl().
+int launch_tab(const DecDesc *d_descs, int count, int blocks_max, int tl_max, int cap_e, int mode, bool clamped, bool f16,
+               void *stream);
 // y_hat[c, p] = rank[c] < 0 ? 0 : (float)sym[rank[c] * hw + p]; sym is int16 (wide = 0) or int32 and may live in pinned
 // host memory (read over PCIe)   (entropy_models.py:903-908)
-// headers into the staging range (DecDesc::hdr_out), 2-byte form where DecDesc::hdr_compact; n_max = largest n_ch*hw
-int launch_hdr_pack(const DecDesc *d_descs, int count, int64_t n_max, void *stream);
 int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y_hat, int M, int64_t hw, void *stream);
 // checkerboard split (embed = false: [planes,h,w] -> [2,planes,h,w/2]) / merge (embed = true); w even, elem_bytes 2 or 4
 int launch_ckbd(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes, int anchor_odd, bool embed,
@@ -122,19 +147,25 @@ int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, i
 // two streams by one thread, interleaved (each output identical to rans_encode_symtab's)
 int rans_encode_symtab2(const uint32_t *const packed[2], const int32_t *const symbols[2], const int64_t n[2],
                         const int64_t n_bypass_hint[2], uint8_t **out[2], size_t *out_len[2]);
-// Tables that reach the host in pieces: after piece k has landed, the headers and rows of the first end[k] latents
-// are valid (end[nseg-1] = n), the rows of piece k starting at base[k].  Piece 0 has landed before the decoder is called; wait(arg, k) blocks until piece k
-// (k >= 1) has.  The decoder walks the latents in order, so it only ever waits for the next piece.
-struct Landing {
-  int nseg;
-  const uint64_t *end;
-  const uint8_t *const *base; // rows of piece k start at base[k] (the pieces need not be adjacent in memory)
-  void *arg;
-  int (*wait)(void *arg, int k); // FGMM_OK or an error status
+// Decode-side tables as the host decoder sees them: `npiece` pieces in latent order; piece k holds the latents
+// [k ? piece[k-1].end : 0, piece[k].end) and begins on a block boundary (a multiple of tl latents).  Piece 0 has landed
+// before the decoder is called; wait(arg, k) blocks until piece k (k >= 1) has.  The decoder walks the latents in
+// order, so it only ever waits for the next piece.
+struct TabPiece {
+  const void *hdr;         // headers of the piece's latents (hdr_form bytes each)
+  const uint32_t *blk_off; // per block of tl latents: offset / 4 of its first row from `rows`; null: rows are sequential
+  const uint8_t *rows;
+  size_t rows_len;         // bytes of the row area that may be read (rows lie inside; checked before every access)
+  int64_t end;             // one past the piece's last latent
 };
-// hdr16: null, or the headers in their 2-byte form (then `hdr` is ignored)
-int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, const uint8_t *pool, int64_t n,
-                       int32_t max_bs, int32_t *out, const Landing *land = nullptr, const uint16_t *hdr16 = nullptr);
-FGMM_HD static inline bool tab_hdr_fits16(int32_t max_bs) { return 2 * max_bs + 2 <= 254; }
+struct TabView {
+  int hdr_form; // 2, 4, 8
+  int tl;       // latents per block (blk_off granularity); ignored when blk_off is null
+  int npiece;
+  const TabPiece *piece;
+  void *arg;
+  int (*wait)(void *arg, int k); // FGMM_OK or an error status; null when npiece == 1
+};
+int rans_decode_tab(const uint8_t *enc, size_t enc_len, const TabView &tv, int64_t n, int32_t max_bs, int32_t *out);
 
 } // namespace fgmm

@@ -12,59 +12,11 @@
 // (k, c, p) layout.  Wave = 64 lanes throughout.
 #include <hip/hip_runtime.h>
 
-#include "fgmm_internal.h"
 #include <algorithm>
-#include "fgmm_math.h"
+
+#include "fgmm_dev.h"
 
 namespace fgmm {
-
-constexpr int kBlock = 256;
-
-// ---------------------------------------------------------------------------------------------------------
-// wave / block helpers (wave64)
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-// parameter planes are float32, or float16 converted on load (BASELINE configs[4]: "fp16 (mu,sigma,pi) with fp32 CDF
-// accumulate"): every value is widened exactly, then the fp32 path runs unchanged
-// Descriptor pointers are generic (they come out of a struct in memory): cast to the global address space so that the
-// accesses are global_load / global_store (a flat_load also takes a slot of the LDS queue and is waited for out of order).
-#define FGMM_GLOBAL __attribute__((address_space(1)))
-#ifndef FGMM_NT_LOADS
-#define FGMM_NT_LOADS 1 // stream the inputs with the non-temporal hint (measured +3-4 % on the symtab kernel; 0: A/B)
-#endif
-template <typename T> __device__ __forceinline__ T ldg(const void *p) {
-  const FGMM_GLOBAL T *g = (const FGMM_GLOBAL T *)p;
-#if FGMM_NT_LOADS
-  return __builtin_nontemporal_load(g);
-#else
-  return *g;
-#endif
-}
-template <typename T> __device__ __forceinline__ void stg(void *p, T v) { *(FGMM_GLOBAL T *)p = v; }
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-typedef float float4_t __attribute__((ext_vector_type(4)));
-template <typename PT> __device__ __forceinline__ float ld1(const void *base, int64_t idx) {
-  return (float)ldg<PT>(static_cast<const PT *>(base) + idx);
-}
-template <typename PT> __device__ __forceinline__ void ld4(const void *base, int64_t idx, float (&out)[4]);
-template <> __device__ __forceinline__ void ld4<float>(const void *base, int64_t idx, float (&out)[4]) {
-  const float4_t v = ldg<float4_t>(static_cast<const float *>(base) + idx); // 16 B / lane
-  out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
-}
-template <> __device__ __forceinline__ void ld4<_Float16>(const void *base, int64_t idx, float (&out)[4]) {
-  const half4_t v = ldg<half4_t>(static_cast<const _Float16 *>(base) + idx); // 8 B / lane
-  out[0] = (float)v[0]; out[1] = (float)v[1]; out[2] = (float)v[2]; out[3] = (float)v[3];
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // quant_stats_kernel: one block per (channel, item).  8 B/latent of traffic (4 in, 4 out).
@@ -322,326 +274,6 @@ __global__ __launch_bounds__(kBlock) void cdf_pair_kernel(const int32_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Decode-side edge tables (format v3, include/flashgmm_amd.h).  Lane = latent.  Three launches per group of items:
-//   cdftab_count_kernel  find, exactly, the window outside which F_i is constant (leading zeros, trailing constant
-//                        run, non-monotone flag) -> 4-byte header; row byte length -> per-block sums
-//   cdftab_scan_kernel   exclusive scan of the block sums (one block per item) -> block offsets, total bytes
-//   cdftab_fill_kernel   re-evaluate only the window and store the row at its offset: rows lie in LATENT ORDER with
-//                        no per-row offset (the host walks them sequentially), narrow / non-monotone rows as
-//                        uint16 entries, wide monotone rows Elias-Fano coded (low bytes + unary high parts)
-// F[v] = quant16(cdf(v - 0.5)) over v in [-max_bs, max_bs+1] is all the reference's bisection can probe
-// (rans_interface.cpp:826-862).  Transcendental-VALU bound (about 150 VALU ops per edge), not HBM bound.
-// ---------------------------------------------------------------------------------------------------------
-template <int MODE, bool CLAMPED, typename PT> struct TabLatent {
-  float mu[4], sg[4], pi[4], rs[4];
-  int max_bs;
-
-  __device__ __forceinline__ void load(const DecDesc &d, int c, int64_t p) {
-    const int64_t base = (int64_t)c * d.stride_c + p * d.stride_p;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float s = ld1<PT>(d.scales, base + k * d.stride_k);
-      sg[k] = CLAMPED ? clamp_scale(s) : s;
-      rs[k] = CLAMPED ? rcp_refined(sg[k]) : 0.0f; // one refined reciprocal per component for the whole row
-      mu[k] = ld1<PT>(d.means, base + k * d.stride_k);
-      pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
-    }
-    max_bs = d.max_bs;
-  }
-  __device__ __forceinline__ uint32_t edge(int j) const { // F[v = j - max_bs]
-    const float x = (float)(j - max_bs) - 0.5f;
-    if constexpr (CLAMPED) {
-      bool ok = true;
-      float c = mix4_clamped<MODE>(x, mu, sg, rs, pi, ok);
-      if (__builtin_expect(!ok, 0))
-        c = mix4_slow<MODE>(x, mu[0], mu[1], mu[2], mu[3], sg[0], sg[1], sg[2], sg[3], pi[0], pi[1], pi[2], pi[3]);
-      return quant16(c);
-    } else {
-      return quant16(mix4<MODE>(x, mu, sg, pi));
-    }
-  }
-};
-
-__device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t *s_tmp) { // kBlock threads, result in all
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
-  __syncthreads();
-  uint32_t t = 0;
-#pragma unroll
-  for (int i = 0; i < kBlock / 64; ++i) t += s_tmp[i];
-  __syncthreads();
-  return t;
-}
-__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s_tmp) { // exclusive prefix over the block
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) s_tmp[w] = incl;
-  __syncthreads();
-  uint32_t base = 0;
-  for (int i = 0; i < w; ++i) base += s_tmp[i];
-  __syncthreads();
-  return base + incl - v;
-}
-
-// ---- evaluation window: skip the part of [-max_bs, max_bs+1] where every component is saturated -------------
-// Saturation lemmas (fgmm_math.h Sat<MODE>, proved by exhaustive scan: fgmm_selftest_saturation):
-//   all z_k <= -ZL  =>  F[v] == 0          all z_k >= +ZR  =>  F[v] == quant16((pi0+pi1)+(pi2+pi3))
-// z_k(v) = ((float)v - 0.5f - mu_k) / sg_k is non-decreasing in v for finite mu and 0 < sg < inf (every IEEE
-// operation is monotone), so it is enough to VERIFY the condition, with the kernel's own arithmetic, at one v:
-// it then holds for every v beyond it.  Any latent whose parameters fall outside the lemmas' domain is
-// evaluated over the full range instead.  Indices < j_lo are all zero, indices >= j_hi are all T_sat.
-template <int MODE, bool CLAMPED, typename PT>
-__device__ __forceinline__ void tab_window(const TabLatent<MODE, CLAMPED, PT> &L, int prune, int max_bs, int W, int &j_lo, int &j_hi,
-                                           uint32_t &T_sat) {
-  j_lo = 0;
-  j_hi = W;
-  T_sat = 0;
-  if (prune) {
-    bool ok = true;
-    float tl = INFINITY, tr = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      ok = ok && (L.sg[k] > 0.0f) && (L.sg[k] < INFINITY) && (fabsf(L.mu[k]) < INFINITY) && Sat<MODE>::weight_ok(L.pi[k]);
-      tl = fminf(tl, __builtin_fmaf(-Sat<MODE>::ZL, L.sg[k], L.mu[k]));
-      tr = fmaxf(tr, __builtin_fmaf(Sat<MODE>::ZR, L.sg[k], L.mu[k]));
-    }
-    if (ok) {
-      const float lim = (float)max_bs + 4.0f;
-      // left: largest candidate v with v - 0.5 <= tl, minus one for the rounding of tl itself
-      int vL = (int)fminf(fmaxf(floorf(tl + 0.5f) - 1.0f, -lim), lim);
-      int vR = (int)fminf(fmaxf(ceilf(tr + 0.5f) + 1.0f, -lim), lim);
-      bool okL = true, okR = true;
-      const float xl = (float)vL - 0.5f, xr = (float)vR - 0.5f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        okL = okL && ((xl - L.mu[k]) / L.sg[k] <= -Sat<MODE>::ZL);
-        okR = okR && ((xr - L.mu[k]) / L.sg[k] >= Sat<MODE>::ZR);
-      }
-      if (okL) j_lo = min(max(vL + max_bs + 1, 0), W); // indices < j_lo are v <= vL: all zero
-      if (okR) j_hi = min(max(vR + max_bs, j_lo), W);  // indices >= j_hi are v >= vR: all T_sat
-      T_sat = quant16((L.pi[0] + L.pi[1]) + (L.pi[2] + L.pi[3]));
-    }
-  }
-}
-
-template <int MODE, bool CLAMPED, typename PT>
-__global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__restrict__ descs) {
-  const DecDesc &d = descs[blockIdx.z];
-  const int cj = blockIdx.y;
-  if (cj >= d.n_ch) return;
-  const int64_t hw = d.hw;
-  if ((int64_t)blockIdx.x * kBlock >= hw) return;
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool active = p < hw;
-  const int c = d.chan_list ? d.chan_list[cj] : cj;
-  TabLatent<MODE, CLAMPED, PT> L;
-  L.load(d, c, active ? p : 0);
-  const int max_bs = d.max_bs;
-  const int W = 2 * max_bs + 2;
-
-  int j_lo, j_hi;
-  uint32_t T_sat;
-  tab_window(L, d.prune, max_bs, W, j_lo, j_hi, T_sat);
-  // temp buffer of this block: 4 header rows (j_lo, j_hi, T_sat of each lane, one spare), then W rows of edges
-  uint16_t *__restrict__ tmp = d.tmp ? d.tmp + ((int64_t)cj * d.tiles + blockIdx.x) * ((int64_t)(W + kTmpHdrRows) * kBlock) + threadIdx.x : nullptr;
-  if (tmp) {
-    tmp[0] = (uint16_t)j_lo; // W <= 2 * FGMM_MAX_BS + 2 < 65536
-    tmp[kBlock] = (uint16_t)j_hi;
-    tmp[2 * kBlock] = (uint16_t)T_sat;
-    tmp += kTmpHdrRows * kBlock;
-  }
-
-  int lead = j_lo - 1, run_start = 0;
-  bool allzero = true, nonmono = false;
-  uint32_t prev = 0;
-  for (int j = j_lo; j < j_hi; ++j) {
-    const uint32_t E = L.edge(j);
-    if (tmp) tmp[(int64_t)(j - j_lo) * kBlock] = (uint16_t)E; // lanes of a block side by side: coalesced
-    if (allzero) {
-      if (E == 0) lead = j; else allzero = false;
-    }
-    if (j == 0 || E != prev) run_start = j;
-    nonmono |= (j > 0) && (E < prev);
-    prev = E;
-  }
-  if (j_hi < W) { // the saturated right part, one virtual step: F[j_hi .. W-1] == T_sat
-    if (allzero) {
-      if (T_sat == 0) lead = W - 1; else allzero = false;
-    }
-    if (j_hi == 0 || T_sat != prev) run_start = j_hi;
-    nonmono |= (j_hi > 0) && (T_sat < prev);
-  }
-  // the row starts at the first non-zero edge: F[v < a] = 0 is implied by the format, and the host takes "cf below the
-  // first entry" as the interval [0, first entry) of the symbol before it (2 bytes less per row than storing that zero)
-  int a_idx = lead + 1;
-  if (a_idx > run_start) a_idx = run_start;
-  const uint32_t cnt = (uint32_t)(run_start - a_idx + 1);
-
-  if (active) d.hdr[(int64_t)cj * hw + p] = tab_hdr_pack(a_idx - max_bs, cnt, nonmono ? 1u : 0u);
-  __shared__ uint32_t s_tmp[kBlock / 64];
-  const uint32_t total = block_reduce_add(active ? tab_row_bytes(cnt, nonmono ? 1u : 0u) : 0u, s_tmp);
-  const int any_nonmono = __syncthreads_or(active && nonmono);
-  // bit 31: some row of the block is non-monotone (a block holds < 2^31 bytes of rows: 256 rows of < 64 KiB)
-  if (threadIdx.x == 0) d.blk_sums[(int64_t)cj * d.tiles + blockIdx.x] = total | (any_nonmono ? 0x80000000u : 0u);
-}
-
-// one block per item: blk_off[b] = sum of blk_sums[0..b), pool_used[0] = total bytes, [1] = overflow flag,
-// [2 .. 2+n_piece-1) piece offsets, [2 + kMaxPieces] = some row of the item is non-monotone
-__global__ __launch_bounds__(kBlock) void cdftab_scan_kernel(const DecDesc *__restrict__ descs) {
-  const DecDesc &d = descs[blockIdx.x];
-  const int64_t nb = (int64_t)d.n_ch * d.tiles;
-  __shared__ uint32_t s_tmp[kBlock / 64];
-  __shared__ unsigned long long s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  uint32_t flagged = 0;
-  for (int64_t b0 = 0; b0 < nb; b0 += kBlock) {
-    const int64_t b = b0 + threadIdx.x;
-    const uint32_t raw = b < nb ? d.blk_sums[b] : 0u;
-    flagged |= raw >> 31;
-    const uint32_t v = raw & 0x7FFFFFFFu;
-    const uint32_t ex = block_scan_excl(v, s_tmp);
-    const unsigned long long carry = s_carry;
-    if (b < nb) d.blk_off[b] = carry + ex;
-    __syncthreads();
-    if (threadIdx.x == kBlock - 1) s_carry = carry + ex + v;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    d.pool_used[0] = s_carry;
-    d.pool_used[1] = s_carry > d.pool_cap ? 1ull : 0ull;
-  }
-  const int any_nonmono = __syncthreads_or((int)flagged);
-  if (d.n_piece >= 1 && threadIdx.x == 0) d.pool_used[2 + kMaxPieces] = (unsigned long long)(any_nonmono != 0);
-  if (d.n_piece > 1 && (int)threadIdx.x < d.n_piece - 1) { // where the pieces of the item begin (blk_off is this block's own)
-    const int64_t ch = (int64_t)d.n_ch * ((int)threadIdx.x + 1) / d.n_piece;
-    d.pool_used[2 + threadIdx.x] = ch * d.tiles < nb ? d.blk_off[ch * d.tiles] : s_carry;
-  }
-}
-
-// Headers for the host, next to the rows in the staging range: the 4-byte form, or — for items whose half-width fits
-// (2*max_bs+2 <= 254) and that have no non-monotone row — 2 bytes: (a + max_bs) | cnt << 8.
-__global__ __launch_bounds__(kBlock) void hdr_pack_kernel(const DecDesc *__restrict__ descs) {
-  const DecDesc &d = descs[blockIdx.y];
-  const int64_t n = (int64_t)d.n_ch * d.hw;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const uint32_t h = d.hdr[i];
-    if (d.hdr_compact) reinterpret_cast<uint16_t *>(d.hdr_out)[i] = (uint16_t)(((uint32_t)(tab_hdr_a(h) + d.max_bs) & 0xFFu) | (tab_hdr_cnt(h) << 8));
-    else reinterpret_cast<uint32_t *>(d.hdr_out)[i] = h;
-  }
-}
-
-template <int MODE, bool CLAMPED, typename PT>
-__global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__restrict__ descs) {
-  const DecDesc &d = descs[blockIdx.z];
-  const int cj = (int)blockIdx.y + d.ch_begin;
-  if (cj >= d.ch_end) return;
-  const int64_t hw = d.hw;
-  if ((int64_t)blockIdx.x * kBlock >= hw) return;
-  if (d.pool_used[1]) return; // pool too small: the host sees the flag
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool active = p < hw;
-  const int c = d.chan_list ? d.chan_list[cj] : cj;
-  TabLatent<MODE, CLAMPED, PT> L;
-  if (!d.tmp) L.load(d, c, active ? p : 0); // with a temp buffer the fill pass never looks at the parameters
-
-  const uint32_t h = active ? d.hdr[(int64_t)cj * hw + p] : 0u;
-  const int a_idx = tab_hdr_a(h) + d.max_bs;
-  const uint32_t cnt = tab_hdr_cnt(h), nonmono = tab_hdr_nonmono(h);
-  const uint32_t bytes = active ? tab_row_bytes(cnt, nonmono) : 0u;
-  __shared__ uint32_t s_tmp[kBlock / 64];
-  const uint32_t ex = block_scan_excl(bytes, s_tmp);
-  if (!active) return;
-  uint8_t *__restrict__ row = d.pool + d.blk_off[(int64_t)cj * d.tiles + blockIdx.x] + ex; // 4-byte aligned
-  // the row's entries: what the count pass left in the temp buffer (outside its evaluation window the entries are
-  // the saturated constants), or a second evaluation when there is no temp buffer
-  const int W = 2 * d.max_bs + 2;
-  int j_lo = 0, j_hi = W;
-  uint32_t T_sat = 0;
-  const uint16_t *__restrict__ tmp = nullptr;
-  if (d.tmp) {
-    tmp = d.tmp + ((int64_t)cj * d.tiles + blockIdx.x) * ((int64_t)(W + kTmpHdrRows) * kBlock) + threadIdx.x;
-    j_lo = tmp[0];
-    j_hi = tmp[kBlock];
-    T_sat = tmp[2 * kBlock];
-    tmp += kTmpHdrRows * kBlock;
-  }
-  auto edge_at = [&](int idx) -> uint32_t {
-    if (!tmp) return L.edge(idx);
-    if (idx < j_lo) return 0u;
-    if (idx >= j_hi) return T_sat;
-    return tmp[(int64_t)(idx - j_lo) * kBlock];
-  };
-
-  // Entries are fetched 8 at a time before any is used: a lane's loop is a chain of dependent steps, and with one
-  // temp-buffer load per step the kernel would be bound by memory latency times the longest row of the wave.
-  constexpr int CH = 8;
-  if (!tab_row_is_ef(cnt, nonmono)) {
-    // raw: uint16 entries, padded to an even count with the last value (rows are 4-byte aligned)
-    const uint32_t len2 = (cnt + 1u) & ~1u;
-    uint32_t last = 0;
-    for (uint32_t j0 = 0; j0 < len2; j0 += CH) {
-      uint32_t e[CH];
-#pragma unroll
-      for (int t = 0; t < CH; ++t) e[t] = (j0 + t < cnt) ? edge_at(a_idx + (int)(j0 + t)) : 0u;
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        if (j0 + t < cnt) last = e[t];
-        e[t] = last;
-      }
-#pragma unroll
-      for (int t = 0; t < CH; t += 2)
-        if (j0 + t < len2) *reinterpret_cast<uint32_t *>(row + 2 * (j0 + t)) = e[t] | (e[t + 1] << 16);
-    }
-  } else {
-    // Elias-Fano, 8 low bits: lows[cnt] (padded to 8), then U 64-bit words with bit ((E_j >> 8) + j) set
-    const uint32_t lows_bytes = (cnt + 7u) & ~7u, U = (cnt + 256u + 63u) >> 6;
-    uint32_t *__restrict__ up32 = reinterpret_cast<uint32_t *>(row + lows_bytes); // the 64-bit words, as two halves each
-    auto put_word = [&](uint32_t wi, unsigned long long w) {
-      up32[2 * wi] = (uint32_t)w;
-      up32[2 * wi + 1] = (uint32_t)(w >> 32);
-    };
-    unsigned long long wcur = 0;
-    uint32_t widx = 0;
-    for (uint32_t j0 = 0; j0 < lows_bytes; j0 += CH) { // lows_bytes is a multiple of 8 = CH
-      uint32_t e[CH];
-#pragma unroll
-      for (int t = 0; t < CH; ++t) e[t] = (j0 + t < cnt) ? edge_at(a_idx + (int)(j0 + t)) : 0u;
-      uint32_t lo0 = 0, lo1 = 0; // the low bytes of the 8 entries (zero padding past the row)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        lo0 |= (e[t] & 0xFFu) << (8 * t);
-        lo1 |= (e[t + 4] & 0xFFu) << (8 * t);
-      }
-      reinterpret_cast<uint32_t *>(row + j0)[0] = lo0; // rows are only 4-byte aligned
-      reinterpret_cast<uint32_t *>(row + j0)[1] = lo1;
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        if (j0 + t < cnt) {
-          const uint32_t pos = (e[t] >> 8) + j0 + t; // strictly increasing: the row is monotone
-          const uint32_t wi = pos >> 6;
-          while (widx < wi) {
-            put_word(widx++, wcur);
-            wcur = 0;
-          }
-          wcur |= 1ull << (pos & 63u);
-        }
-      }
-    }
-    while (widx < U) {
-      put_word(widx++, wcur);
-      wcur = 0;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // yhat_scatter_kernel: the decoded symbols of the coded channels back into the full [M, hw] latent, as floats, zero
 // channels restored (entropy_models.py:903-908).  `sym` is read where the host decoder left it (pinned host memory).
 // ---------------------------------------------------------------------------------------------------------
@@ -880,53 +512,6 @@ int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, c
   case MODE_LOGISTIC: hipLaunchKernelGGL((cdf_pair_kernel<MODE_LOGISTIC>), grid, dim3(kBlock), 0, s, v, scales, means, weights, n, stride_n, stride_k, c1, c2); break;
   default: hipLaunchKernelGGL((cdf_pair_kernel<MODE_POLYA>), grid, dim3(kBlock), 0, s, v, scales, means, weights, n, stride_n, stride_k, c1, c2); break;
   }
-  return launch_err();
-}
-
-template <bool CLAMPED, typename PT>
-static int launch_cdftab_c(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, int pass, hipStream_t s) {
-  dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)n_ch_max, (unsigned)count);
-#define FGMM_TAB_LAUNCH(M)                                                                                          \
-  if (pass & 1) {                                                                                                   \
-    hipLaunchKernelGGL((cdftab_count_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);                   \
-    hipLaunchKernelGGL(cdftab_scan_kernel, dim3((unsigned)count), dim3(kBlock), 0, s, d_descs);                     \
-  }                                                                                                                 \
-  if (pass & 2) hipLaunchKernelGGL((cdftab_fill_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);
-  switch (mode) {
-  case MODE_AS: FGMM_TAB_LAUNCH(MODE_AS) break;
-  case MODE_LOGISTIC: FGMM_TAB_LAUNCH(MODE_LOGISTIC) break;
-  default: FGMM_TAB_LAUNCH(MODE_POLYA) break;
-  }
-#undef FGMM_TAB_LAUNCH
-  return launch_err();
-}
-
-static int launch_cdftab_pass(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
-                              int pass, void *stream) {
-  if (count <= 0 || n_ch_max <= 0 || hw_max <= 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  if (f16) return clamped ? launch_cdftab_c<true, _Float16>(d_descs, count, n_ch_max, hw_max, mode, pass, s)
-                          : launch_cdftab_c<false, _Float16>(d_descs, count, n_ch_max, hw_max, mode, pass, s);
-  return clamped ? launch_cdftab_c<true, float>(d_descs, count, n_ch_max, hw_max, mode, pass, s)
-                 : launch_cdftab_c<false, float>(d_descs, count, n_ch_max, hw_max, mode, pass, s);
-}
-int launch_cdftab_count(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
-                        void *stream) {
-  return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 1, stream);
-}
-int launch_cdftab_fill(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
-                       void *stream) {
-  return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 2, stream);
-}
-int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
-                  void *stream) {
-  return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 3, stream);
-}
-
-int launch_hdr_pack(const DecDesc *d_descs, int count, int64_t n_max, void *stream) {
-  if (count <= 0 || n_max <= 0) return 0;
-  dim3 grid((unsigned)std::min<int64_t>((n_max + kBlock - 1) / kBlock, 1024), (unsigned)count);
-  hipLaunchKernelGGL(hdr_pack_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, d_descs);
   return launch_err();
 }
 

@@ -279,14 +279,18 @@ __attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *r
   return cnt;
 }
 
-// ---- Elias-Fano rows (8 low bits): lows[round8(cnt)] then U words whose bit ((E_j >> 8) + j) is set -----------
+// ---- Elias-Fano rows (8 low bits): lows[round4(cnt)] then U 32-bit words whose bit ((E_j >> 8) + j) is set ----
 // Bucket b (entries whose high byte is b) is a run of ones followed by one zero; zero #b sits at bit
-// b + (number of entries with high byte <= b).
-struct Up64 { // the unary high parts: 64-bit words that are only 4-byte aligned in the pool
+// b + (number of entries with high byte <= b).  The words are read 64 bits at a time (they are only 4-byte aligned in
+// the pool); when U is odd the upper half of the last read lies past the row: it is forced to ones ("no zero there").
+struct Up64 {
   const uint8_t *p;
+  int32_t U32; // valid 32-bit words
+  inline int32_t words() const { return (U32 + 1) >> 1; }
   inline uint64_t operator[](int64_t w) const {
     uint64_t v;
     memcpy(&v, p + 8 * w, 8);
+    if (__builtin_expect(2 * w + 1 >= U32, 0)) v |= 0xFFFFFFFF00000000ull;
     return v;
   }
 };
@@ -294,47 +298,53 @@ struct EfRow {
   const uint8_t *lows;
   Up64 up;
   int32_t cnt;
-  int32_t U;
 };
-// position of the k-th (0-based) ZERO bit, k <= 255 (always exists: U*64 - cnt >= 256).  Branch-free in the
-// search (one pass over the U words, U is 5..7 for the rows of a Kodak-sized latent).
-__attribute__((target("bmi2,popcnt"))) inline uint32_t ef_select0(const EfRow &r, uint32_t k) {
+// position of the k-th (0-based) ZERO bit, k <= 255 (always exists in a well-formed row: 32 U - cnt >= 256); -1 if not
+__attribute__((target("bmi2,popcnt"))) inline int32_t ef_select0(const EfRow &r, uint32_t k) {
   uint32_t wsel = 0, zbase = 0, acc = 0;
-  for (int32_t w = 0; w < r.U; ++w) {
+  const int32_t U = r.up.words();
+  for (int32_t w = 0; w < U; ++w) {
     acc += (uint32_t)__builtin_popcountll(~r.up[w]);
     const bool le = acc <= k;
     wsel += le;
     zbase = le ? acc : zbase;
   }
-  return wsel * 64u + (uint32_t)__builtin_ctzll(_pdep_u64(1ull << (k - zbase), ~r.up[wsel]));
+  if (__builtin_expect((int32_t)wsel >= U, 0)) return -1; // malformed row
+  return (int32_t)(wsel * 64u + (uint32_t)__builtin_ctzll(_pdep_u64(1ull << (k - zbase), ~r.up[wsel])));
 }
-// position of the k-th (0-based) ONE bit, k < cnt (only used to expand a row for the bisection replay)
-__attribute__((target("bmi2,popcnt"))) inline uint32_t ef_select1(const EfRow &r, uint32_t k) {
-  uint32_t base = 0;
-  for (int32_t w = 0; w < r.U; ++w, base += 64) {
-    const uint64_t o = r.up[w];
+// position of the k-th (0-based) ONE bit, k < cnt (only used to expand a row for the bisection replay); -1 if not found
+__attribute__((target("bmi2,popcnt"))) inline int32_t ef_select1(const EfRow &r, uint32_t k) {
+  int32_t base = 0;
+  const int32_t U = r.up.words();
+  for (int32_t w = 0; w < U; ++w, base += 64) {
+    uint64_t o = r.up[w];
+    if (2 * w + 1 >= r.up.U32) o &= 0xFFFFFFFFull; // the forced ones are not entries
     const uint32_t c = (uint32_t)__builtin_popcountll(o);
-    if (k < c) return base + (uint32_t)__builtin_ctzll(_pdep_u64(1ull << k, o));
+    if (k < c) return base + (int32_t)__builtin_ctzll(_pdep_u64(1ull << k, o));
     k -= c;
   }
-  return base;
+  return -1;
 }
-inline uint32_t ef_get(const EfRow &r, int32_t j) { // E_j
-  return ((ef_select1(r, (uint32_t)j) - (uint32_t)j) << 8) | r.lows[j];
-}
-// Bracket search: on success returns true with (*j, *start, *freq) such that E[j-1] = start <= cf < E[j];
-// false when no entry pair brackets cf (j would be 0 or cnt) — the caller replays the reference's bisection.
+// Bracket search: 1 with (*j, *start, *freq) such that E[j-1] = start <= cf < E[j]; 0 when no entry pair brackets cf
+// (j would be 0 or cnt) — the caller replays the reference's bisection; -1 for a malformed row (hostile table).
 // zero_before: an (unstored) zero edge precedes the row, so cf below the first entry is the interval [0, E_0): j = 0.
-__attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
-                                                                    uint32_t *start, uint32_t *freq) {
+__attribute__((target("bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
+                                                                   uint32_t *start, uint32_t *freq) {
   const uint32_t h = cf >> 8, l = cf & 0xFFu;
-  const int32_t p_prev = h ? (int32_t)ef_select0(r, h - 1) : -1; // zero that closes bucket h-1
-  const int32_t lo = p_prev + 1 - (int32_t)h;                    // entries with high byte < h
+  const int32_t nbits = r.up.U32 * 32;
+  int32_t p_prev = -1; // zero that closes bucket h-1
+  if (h) {
+    p_prev = ef_select0(r, h - 1);
+    if (__builtin_expect(p_prev < 0, 0)) return -1;
+  }
+  const int32_t lo = p_prev + 1 - (int32_t)h; // entries with high byte < h
+  if (__builtin_expect(lo < 0 || lo > r.cnt, 0)) return -1;
   // length of the run of ones that starts at bit p_prev + 1  (= size of bucket h)
   int32_t run = 0;
   {
     uint32_t s = (uint32_t)(p_prev + 1);
     for (;;) {
+      if (__builtin_expect((int32_t)s >= nbits, 0)) return -1; // no closing zero: malformed
       const uint32_t b = s & 63u;
       const uint64_t t = ~(r.up[s >> 6] >> b); // shifted-in zeros become ones: the run ends at the word end at the latest
       const int32_t len = t ? (int32_t)__builtin_ctzll(t) : 64;
@@ -343,6 +353,7 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow
       s += (uint32_t)len; // the run continues in the next word (rare)
     }
   }
+  if (__builtin_expect(lo + run > r.cnt, 0)) return -1;
   // entries of bucket h whose low byte is <= l (low bytes ascend inside a bucket)
   int32_t c;
   if (__builtin_expect(run <= 16, 1)) {
@@ -355,7 +366,7 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow
     while (c < run && r.lows[lo + c] <= l) ++c;
   }
   const int32_t j = lo + c;
-  if (__builtin_expect((j < 1 && !zero_before) || j >= r.cnt, 0)) return false;
+  if (__builtin_expect((j < 1 && !zero_before) || j >= r.cnt, 0)) return 0;
   uint32_t e0, e1;
   if (j < 1) {
     e0 = 0; // the implied zero edge
@@ -364,7 +375,10 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow
   } else { // previous entry lives in an earlier bucket: the highest one below bit p_prev
     int32_t w = p_prev >> 6;
     uint64_t m = r.up[w] & ((1ull << (p_prev & 63)) - 1ull);
-    while (!m) m = r.up[--w];
+    while (!m) {
+      if (__builtin_expect(--w < 0, 0)) return -1;
+      m = r.up[w];
+    }
     const int32_t pos = w * 64 + 63 - (int32_t)__builtin_clzll(m);
     e0 = ((uint32_t)(pos - (j - 1)) << 8) | r.lows[j - 1];
   }
@@ -373,22 +387,29 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline bool ef_bracket(const EfRow
   } else { // next entry lives in a later bucket: the lowest one above the zero that closes bucket h
     const int32_t pz = p_prev + 1 + run;
     int32_t w = (pz + 1) >> 6;
+    if (__builtin_expect(w >= r.up.words(), 0)) return -1;
     uint64_t m = r.up[w] & ~((1ull << ((pz + 1) & 63)) - 1ull);
-    while (!m) m = r.up[++w];
+    while (!m) {
+      if (__builtin_expect(++w >= r.up.words(), 0)) return -1;
+      m = r.up[w];
+    }
     const int32_t pos = w * 64 + (int32_t)__builtin_ctzll(m);
     e1 = ((uint32_t)(pos - j) << 8) | r.lows[j];
   }
   *jout = j;
   *start = e0;
-  *freq = e1 - e0;
-  return true;
+  *freq = (e1 - e0) & 0xFFFFu;
+  return 1;
 }
 
 } // namespace
 
-int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, const uint8_t *pool, int64_t n,
-                       int32_t max_bs, int32_t *out, const Landing *land, const uint16_t *hdr16) {
-  if (n < 0 || (n > 0 && ((!hdr && !hdr16) || !pool || !out)) || !enc) return FGMM_ERR_INVALID;
+// The decoder proper: walks the latents in order; per latent the header gives (a, cnt, nonmono), the row follows in
+// the pool.  Every row extent is checked against the piece's row area before it is touched (a table is trusted to be
+// well-formed only as far as memory safety does not depend on it).
+int rans_decode_tab(const uint8_t *enc, size_t enc_len, const TabView &tv, int64_t n, int32_t max_bs, int32_t *out) {
+  if (n < 0 || !enc || (n > 0 && (!out || !tv.piece || tv.npiece < 1))) return FGMM_ERR_INVALID;
+  if (tv.hdr_form != 2 && tv.hdr_form != 4 && tv.hdr_form != 8) return FGMM_ERR_INVALID;
   if (enc_len < 8 || (enc_len & 3)) return FGMM_ERR_STREAM;
   const uint32_t *words;
   uint32_t *copy = nullptr;
@@ -406,100 +427,125 @@ int rans_decode_cdftab(const uint8_t *enc, size_t enc_len, const uint32_t *hdr, 
   d.end = words + enc_len / 4;
   uint16_t *scratch = nullptr; // an EF row expanded for the (rare) bisection replay
   size_t scratch_cap = 0;
+  int rc = FGMM_OK;
+  const int64_t W = 2 * (int64_t)max_bs + 2;
 
-  static const int kPf = getenv("FGMM_DEC_PREFETCH") ? atoi(getenv("FGMM_DEC_PREFETCH")) : 1024; // bytes ahead (dev: A/B)
-  const uint8_t *rowp = pool; // rows lie in latent order: the offset is a running sum, never stored
-  int64_t landed = land ? (int64_t)land->end[0] : n; // latents whose header and row are on the host
-  int piece = 1;
-  for (int64_t i = 0; i < n; ++i) {
-    if (__builtin_expect(i >= landed, 0)) { // this latent is not on the host yet: wait for the piece(s) it lies in
-      while (i >= landed) {
-        int st = FGMM_ERR_INVALID; // a latent past the last piece
-        if (piece >= land->nseg || (st = land->wait(land->arg, piece)) != FGMM_OK) {
-          free(copy);
-          free(scratch);
-          return st;
-        }
-        landed = (int64_t)land->end[piece];
-        rowp = land->base[piece++];
+  int64_t i = 0;
+  for (int k = 0; k < tv.npiece && i < n && rc == FGMM_OK; ++k) {
+    if (k > 0 && tv.wait && (rc = tv.wait(tv.arg, k)) != FGMM_OK) break;
+    const TabPiece &pc = tv.piece[k];
+    const int64_t i_beg = i, i_end = pc.end < n ? pc.end : n;
+    const uint8_t *const rows_end = pc.rows + pc.rows_len;
+    const uint8_t *rowp = pc.rows; // sequential placement: a running sum, never stored
+    const int64_t tl = pc.blk_off ? (tv.tl > 0 ? tv.tl : 1) : (i_end - i_beg > 0 ? i_end - i_beg : 1);
+    for (int64_t blk = 0; i < i_end; ++blk) {
+      if (pc.blk_off) {
+        rowp = pc.rows + 4 * (size_t)pc.blk_off[blk];
+        if (__builtin_expect(rowp > rows_end, 0)) { rc = FGMM_ERR_INVALID; break; }
       }
-    }
-    __builtin_prefetch(rowp + kPf);
-    __builtin_prefetch(rowp + kPf + 64);
-    int32_t a, cnt;
-    uint32_t nonmono;
-    if (hdr16) { // 2-byte form: (a + max_bs) | cnt << 8, never a non-monotone row
-      const uint32_t c = hdr16[i];
-      a = (int32_t)(c & 0xFFu) - max_bs;
-      cnt = (int32_t)(c >> 8);
-      nonmono = 0;
-    } else {
-      const uint32_t h = hdr[i];
-      a = tab_hdr_a(h);
-      cnt = (int32_t)tab_hdr_cnt(h);
-      nonmono = tab_hdr_nonmono(h);
-    }
-    const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono);
-    const bool zero_before = a > -max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
-    const uint8_t *row_bytes = rowp;
-    rowp += tab_row_bytes((uint32_t)cnt, nonmono);
-
-    const uint32_t cf = (uint32_t)(d.x & 0xFFFFu); // Rans64DecGet
-    int32_t value;
-    if (__builtin_expect(cf == kMaxCdf, 0)) {
-      value = d.bypass();
-    } else {
-      uint32_t start = 0, freq = 0;
-      bool done = false;
-      if (!is_ef) {
-        const uint16_t *row = reinterpret_cast<const uint16_t *>(row_bytes);
-        if (__builtin_expect(!nonmono, 1)) {
-          const int32_t j = upper_bound_u16(row, cnt, cf);
-          if (__builtin_expect(j >= 1 && j < cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
-            start = row[j - 1];
-            freq = row[j] - start;
-            value = a + j - 1;
-            done = true;
-          } else if (j == 0 && zero_before) { // 0 <= cf < row[0]: the symbol whose lower edge is the implied zero
-            start = 0;
-            freq = row[0];
-            value = a - 1;
-            done = true;
+      const int64_t b_end = i + tl < i_end ? i + tl : i_end;
+      for (; i < b_end; ++i) {
+        __builtin_prefetch(rowp + 1024);
+        __builtin_prefetch(rowp + 1024 + 64);
+        int64_t a;
+        int64_t cnt;
+        uint32_t nonmono;
+        const int64_t li = i - i_beg;
+        if (tv.hdr_form == 2) { // (a + max_bs) | cnt << 8; cnt 255: the row carries a 4-byte header
+          const uint32_t c = static_cast<const uint16_t *>(pc.hdr)[li];
+          a = (int64_t)(c & 0xFFu) - max_bs;
+          cnt = c >> 8;
+          nonmono = 0;
+          if (__builtin_expect(cnt == kHdr2Escape, 0)) {
+            if (rows_end - rowp < 4) { rc = FGMM_ERR_INVALID; break; }
+            uint32_t h;
+            memcpy(&h, rowp, 4);
+            rowp += 4;
+            a = tab_hdr_a(h);
+            cnt = tab_hdr_cnt(h);
+            nonmono = tab_hdr_nonmono(h);
           }
+        } else if (tv.hdr_form == 4) {
+          const uint32_t h = static_cast<const uint32_t *>(pc.hdr)[li];
+          a = tab_hdr_a(h);
+          cnt = tab_hdr_cnt(h);
+          nonmono = tab_hdr_nonmono(h);
+        } else {
+          const uint64_t h = static_cast<const uint64_t *>(pc.hdr)[li];
+          a = (int32_t)(uint32_t)h;
+          cnt = (int64_t)((h >> 32) & 0x7FFFFFFFu);
+          nonmono = (uint32_t)(h >> 63);
         }
-        if (!done) value = bisect_reference(Row{row, a, cnt}, cf, max_bs, &start, &freq);
-      } else {
-        const EfRow r{row_bytes, Up64{row_bytes + (((uint32_t)cnt + 7u) & ~7u)}, cnt,
-                      (int32_t)(((uint32_t)cnt + 256u + 63u) >> 6)};
-        int32_t j;
-        if (__builtin_expect(ef_bracket(r, cf, zero_before, &j, &start, &freq), 1)) {
-          value = a + j - 1;
-        } else { // no interval contains cf: expand the row and replay the reference's bisection
-          if ((size_t)cnt > scratch_cap) {
-            free(scratch);
-            scratch_cap = (size_t)cnt + 64;
-            scratch = (uint16_t *)malloc(scratch_cap * sizeof(uint16_t));
-            if (!scratch) {
-              free(copy);
-              return FGMM_ERR_NOMEM;
+        // a row covers indices [a + max_bs, a + max_bs + cnt) of the W-entry virtual table
+        if (__builtin_expect(cnt < 1 || a < -(int64_t)max_bs || a + max_bs + cnt > W, 0)) { rc = FGMM_ERR_INVALID; break; }
+        const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono);
+        const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono);
+        if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; break; }
+        const bool zero_before = a > -(int64_t)max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
+        const uint8_t *row_bytes = rowp;
+        rowp += rbytes;
+
+        const uint32_t cf = (uint32_t)(d.x & 0xFFFFu); // Rans64DecGet
+        int32_t value;
+        if (__builtin_expect(cf == kMaxCdf, 0)) {
+          value = d.bypass();
+        } else {
+          uint32_t start = 0, freq = 0;
+          bool done = false;
+          if (!is_ef) {
+            const uint16_t *row = reinterpret_cast<const uint16_t *>(row_bytes);
+            if (__builtin_expect(!nonmono, 1)) {
+              const int32_t j = upper_bound_u16(row, (int32_t)cnt, cf);
+              if (__builtin_expect(j >= 1 && j < cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
+                start = row[j - 1];
+                freq = (uint32_t)(row[j] - start) & 0xFFFFu;
+                value = (int32_t)(a + j - 1);
+                done = true;
+              } else if (j == 0 && zero_before) { // 0 <= cf < row[0]: the symbol whose lower edge is the implied zero
+                start = 0;
+                freq = row[0];
+                value = (int32_t)(a - 1);
+                done = true;
+              }
+            }
+            if (!done) value = bisect_reference(Row{row, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
+          } else {
+            const EfRow r{row_bytes, Up64{row_bytes + tab_ef_lows_bytes((uint32_t)cnt), (int32_t)tab_ef_words((uint32_t)cnt)}, (int32_t)cnt};
+            int32_t j;
+            const int br = ef_bracket(r, cf, zero_before, &j, &start, &freq);
+            if (__builtin_expect(br > 0, 1)) {
+              value = (int32_t)(a + j - 1);
+            } else if (br < 0) {
+              rc = FGMM_ERR_INVALID;
+              break;
+            } else { // no interval contains cf: expand the row and replay the reference's bisection
+              if ((size_t)cnt > scratch_cap) {
+                free(scratch);
+                scratch_cap = (size_t)cnt + 64;
+                scratch = (uint16_t *)malloc(scratch_cap * sizeof(uint16_t));
+                if (!scratch) { rc = FGMM_ERR_NOMEM; break; }
+              }
+              for (int32_t q = 0; q < cnt && rc == FGMM_OK; ++q) {
+                const int32_t pos = ef_select1(r, (uint32_t)q);
+                if (pos < q) rc = FGMM_ERR_INVALID; else scratch[q] = (uint16_t)((((uint32_t)(pos - q)) << 8) | r.lows[q]);
+              }
+              if (rc != FGMM_OK) break;
+              value = bisect_reference(Row{scratch, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
             }
           }
-          for (int32_t k = 0; k < cnt; ++k) scratch[k] = (uint16_t)ef_get(r, k);
-          value = bisect_reference(Row{scratch, a, cnt}, cf, max_bs, &start, &freq);
+          if (__builtin_expect(freq == 0, 0)) { rc = FGMM_ERR_INVALID; break; } // cannot come out of a well-formed row
+          d.advance(start, freq);
         }
+        out[i] = value;
+        if (__builtin_expect(d.underrun, 0)) { rc = FGMM_ERR_STREAM; break; }
       }
-      d.advance(start, freq);
-    }
-    out[i] = value;
-    if (__builtin_expect(d.underrun, 0)) {
-      free(copy);
-      free(scratch);
-      return FGMM_ERR_STREAM;
+      if (rc != FGMM_OK) break;
     }
   }
+  if (rc == FGMM_OK && i < n) rc = FGMM_ERR_INVALID; // the pieces do not cover the latents
   free(copy);
   free(scratch);
-  return FGMM_OK;
+  return rc;
 }
 
 // ============================================================================================================
@@ -736,8 +782,23 @@ int fgmm_rans_encode_symtab2(const uint32_t *packed0, const int32_t *symbols0_or
 }
 
 int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint32_t *hdr, const uint8_t *pool,
-                            int64_t n, int32_t max_bs, int32_t *out_symbols) {
-  return fgmm::rans_decode_cdftab(encoded, encoded_len, hdr, pool, n, max_bs, out_symbols);
+                            uint64_t pool_len, int64_t n, int32_t max_bs, int32_t *out_symbols) {
+  if (n > 0 && (!hdr || !pool)) return FGMM_ERR_INVALID;
+  if (max_bs < 0 || max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_UNSUPPORTED; // this entry point takes 4-byte headers
+  const fgmm::TabPiece pc{hdr, nullptr, pool, (size_t)pool_len, n};
+  const fgmm::TabView tv{4, 0, 1, &pc, nullptr, nullptr};
+  return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
+}
+
+int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void *hdr, int hdr_form, const uint32_t *blk_off,
+                         int32_t tl, const uint8_t *rows, uint64_t rows_len, int64_t n, int32_t max_bs, int32_t *out_symbols) {
+  if (n > 0 && (!hdr || !rows)) return FGMM_ERR_INVALID;
+  if (max_bs < 0 || max_bs > FGMM_MAX_BS || (blk_off && tl < 1)) return FGMM_ERR_INVALID;
+  if (hdr_form == 2 && !fgmm::tab_hdr_fits16(max_bs)) return FGMM_ERR_INVALID;
+  if (hdr_form == 4 && max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_INVALID;
+  const fgmm::TabPiece pc{hdr, blk_off, rows, (size_t)rows_len, n};
+  const fgmm::TabView tv{hdr_form, tl, 1, &pc, nullptr, nullptr};
+  return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
 }
 
 void fgmm_free(void *p) { free(p); }

@@ -1,0 +1,667 @@
+// fgmm_tab.hip — decode-side edge tables on CDNA4 / gfx950 (MI355X): what the reference's per-symbol float bisection
+// (RansDecoder::decode_with_indexes_gmm, compressai/cpp_exts/rans/rans_interface.cpp:826-862) can ever look at,
+//     F_i[v] = (uint16)(cdf_i(v - 0.5) * 65535),   v in [-max_bs, max_bs + 1],
+// evaluated once on the GPU, trimmed losslessly to the window outside which it is constant, and laid out for the host
+// rANS decoder (format v4: fgmm_internal.h, include/flashgmm_amd.h).
+//
+//   tab_kernel            single pass, the production path (items whose half-width fits: tab_tl() > 0).
+//                         Block = `tl` consecutive latents:
+//                           0  lane = latent: twelve parameters -> LDS (64 B per latent, sigma clamped, refined reciprocal),
+//                              the evaluation window [j_lo, j_hi) between the provably saturated tails
+//                           1  block scan of the window lengths (in PAIRS of edges)
+//                           2  FLATTENED over (latent, pair of consecutive edges): every lane of every wave evaluates two
+//                              edges per step whatever the window lengths of its neighbours are (lane = latent left a
+//                              third of the lanes idle), parameters from LDS — each is reused by every edge of its latent,
+//                              ~51 times — both edges in packed fp32 (they share all twelve); edges -> LDS as uint16
+//                           3  lane = latent: first non-zero edge, start of the trailing constant run, monotonicity ->
+//                              header (2 / 4 / 8 bytes, straight into the host's layout) and row size
+//                           4  block scan of the row sizes; ONE atomic add on the launch's cursor places the block's rows
+//                           5  FLATTENED over the 4-byte words of the block's rows: formatted from LDS (uint16 rows, or
+//                              Elias-Fano: low bytes + unary high parts), coalesced stores
+//                         No temporary buffer in HBM, no second evaluation, no host round trip before the rows exist.
+//   cdftab_count/scan/fill  generic two-pass path, lane = latent, any half-width (8-byte headers past 16382), rows
+//                         sequential in latent order: the building-block API and items too wide for the LDS kernel.
+// Both produce the same virtual table; tests compare them with each other and with the oracle.
+#include <algorithm>
+
+#include "fgmm_dev.h"
+
+namespace fgmm {
+
+// ---------------------------------------------------------------------------------------------------------
+// one latent's parameters in registers (generic path; phase 0 of tab_kernel)
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, bool CLAMPED, typename PT> struct TabLatent {
+  float mu[4], sg[4], pi[4], rs[4];
+  int max_bs;
+
+  __device__ __forceinline__ void load(const DecDesc &d, int c, int64_t p) {
+    const int64_t base = (int64_t)c * d.stride_c + p * d.stride_p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float s = ld1<PT>(d.scales, base + k * d.stride_k);
+      sg[k] = CLAMPED ? clamp_scale(s) : s;
+      rs[k] = CLAMPED ? rcp_refined(sg[k]) : 0.0f; // one refined reciprocal per component for the whole row
+      mu[k] = ld1<PT>(d.means, base + k * d.stride_k);
+      pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
+    }
+    max_bs = d.max_bs;
+  }
+  __device__ __forceinline__ uint32_t edge(int j) const { // F[v = j - max_bs]
+    const float x = (float)(j - max_bs) - 0.5f;
+    if constexpr (CLAMPED) {
+      bool ok = true;
+      float c = mix4_clamped<MODE>(x, mu, sg, rs, pi, ok);
+      if (__builtin_expect(!ok, 0))
+        c = mix4_slow<MODE>(x, mu[0], mu[1], mu[2], mu[3], sg[0], sg[1], sg[2], sg[3], pi[0], pi[1], pi[2], pi[3]);
+      return quant16(c);
+    } else {
+      return quant16(mix4<MODE>(x, mu, sg, pi));
+    }
+  }
+};
+
+// ---- evaluation window: skip the part of [-max_bs, max_bs+1] where every component is saturated -------------
+// Saturation lemmas (fgmm_math.h Sat<MODE>, proved by exhaustive scan: fgmm_selftest_saturation):
+//   all z_k <= -ZL  =>  F[v] == 0          all z_k >= +ZR  =>  F[v] == quant16((pi0+pi1)+(pi2+pi3))
+// z_k(v) = ((float)v - 0.5f - mu_k) / sg_k is non-decreasing in v for finite mu and 0 < sg < inf (every IEEE
+// operation is monotone), so it is enough to VERIFY the condition, with the kernel's own arithmetic, at one v:
+// it then holds for every v beyond it.  Any latent whose parameters fall outside the lemmas' domain is
+// evaluated over the full range instead.  Indices < j_lo are all zero, indices >= j_hi are all T_sat.
+template <int MODE>
+__device__ __forceinline__ void tab_window(const float (&mu)[4], const float (&sg)[4], const float (&pi)[4], int prune, int max_bs, int W,
+                                           int &j_lo, int &j_hi, uint32_t &T_sat) {
+  j_lo = 0;
+  j_hi = W;
+  T_sat = 0;
+  if (prune) {
+    bool ok = true;
+    float tl = INFINITY, tr = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ok = ok && (sg[k] > 0.0f) && (sg[k] < INFINITY) && (fabsf(mu[k]) < INFINITY) && Sat<MODE>::weight_ok(pi[k]);
+      tl = fminf(tl, __builtin_fmaf(-Sat<MODE>::ZL, sg[k], mu[k]));
+      tr = fmaxf(tr, __builtin_fmaf(Sat<MODE>::ZR, sg[k], mu[k]));
+    }
+    if (ok) {
+      const float lim = (float)max_bs + 4.0f;
+      // left: largest candidate v with v - 0.5 <= tl, minus one for the rounding of tl itself
+      const int vL = (int)fminf(fmaxf(floorf(tl + 0.5f) - 1.0f, -lim), lim);
+      const int vR = (int)fminf(fmaxf(ceilf(tr + 0.5f) + 1.0f, -lim), lim);
+      bool okL = true, okR = true;
+      const float xl = (float)vL - 0.5f, xr = (float)vR - 0.5f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        okL = okL && ((xl - mu[k]) / sg[k] <= -Sat<MODE>::ZL);
+        okR = okR && ((xr - mu[k]) / sg[k] >= Sat<MODE>::ZR);
+      }
+      const int64_t lo = (int64_t)vL + max_bs + 1, hi = (int64_t)vR + max_bs;
+      if (okL) j_lo = (int)std::min<int64_t>(std::max<int64_t>(lo, 0), W); // indices < j_lo are v <= vL: all zero
+      if (okR) j_hi = (int)std::min<int64_t>(std::max<int64_t>(hi, j_lo), W); // indices >= j_hi are v >= vR: all T_sat
+      T_sat = quant16((pi[0] + pi[1]) + (pi[2] + pi[3]));
+    }
+  }
+}
+
+// trimming state of one row, fed edge by edge in index order (both paths run exactly this)
+struct TrimState {
+  int lead, run_start;
+  bool allzero, nonmono;
+  uint32_t prev;
+  __device__ __forceinline__ void init(int j_lo) {
+    lead = j_lo - 1;
+    run_start = 0;
+    allzero = true;
+    nonmono = false;
+    prev = 0;
+  }
+  __device__ __forceinline__ void step(int j, uint32_t E) {
+    if (allzero) {
+      if (E == 0) lead = j; else allzero = false;
+    }
+    if (j == 0 || E != prev) run_start = j;
+    nonmono |= (j > 0) && (E < prev);
+    prev = E;
+  }
+  // after the evaluated window: the saturated right part as one virtual step (F[j_hi .. W-1] == T_sat)
+  __device__ __forceinline__ void finish(int j_hi, int W, uint32_t T_sat, int &a_idx, uint32_t &cnt) {
+    if (j_hi < W) {
+      if (allzero) {
+        if (T_sat == 0) lead = W - 1; else allzero = false;
+      }
+      if (j_hi == 0 || T_sat != prev) run_start = j_hi;
+      nonmono |= (j_hi > 0) && (T_sat < prev);
+    }
+    // the row starts at the first non-zero edge: F[v < a] = 0 is implied by the format, and the host takes "cf below the
+    // first entry" as the interval [0, first entry) of the symbol before it
+    a_idx = lead + 1;
+    if (a_idx > run_start) a_idx = run_start;
+    cnt = (uint32_t)(run_start - a_idx + 1);
+  }
+};
+
+constexpr int kGenericMaxWindow = 1 << 20; // generic path: longest evaluation window of one latent (a lane walks it alone)
+
+// ---------------------------------------------------------------------------------------------------------
+// generic path, pass 1: window, every edge once -> header, row size -> block sums
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, bool CLAMPED, typename PT>
+__global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__restrict__ descs) {
+  const DecDesc &d = descs[blockIdx.z];
+  const int cj = blockIdx.y;
+  if (cj >= d.n_ch) return;
+  const int64_t hw = d.hw;
+  if ((int64_t)blockIdx.x * kBlock >= hw) return;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = p < hw;
+  const int c = d.chan_list ? d.chan_list[cj] : cj;
+  TabLatent<MODE, CLAMPED, PT> L;
+  L.load(d, c, active ? p : 0);
+  const int max_bs = d.max_bs;
+  const int W = 2 * max_bs + 2;
+
+  int j_lo, j_hi;
+  uint32_t T_sat;
+  tab_window<MODE>(L.mu, L.sg, L.pi, d.prune, max_bs, W, j_lo, j_hi, T_sat);
+  bool too_long = false;
+  if (j_hi - j_lo > kGenericMaxWindow) { // refused (the host sees the flag): do not walk it
+    too_long = active;
+    j_hi = j_lo;
+  }
+  TrimState ts;
+  ts.init(j_lo);
+  for (int j = j_lo; j < j_hi; ++j) ts.step(j, L.edge(j));
+  int a_idx;
+  uint32_t cnt;
+  ts.finish(j_hi, W, T_sat, a_idx, cnt);
+  const uint32_t nm = ts.nonmono ? 1u : 0u;
+  if (active) {
+    const int64_t i = (int64_t)cj * hw + p;
+    if (d.hdr_form == 8) static_cast<unsigned long long *>(d.hdr)[i] = tab_hdr8_pack(a_idx - max_bs, cnt, nm);
+    else static_cast<uint32_t *>(d.hdr)[i] = tab_hdr_pack(a_idx - max_bs, cnt, nm);
+  }
+  __shared__ uint32_t s_tmp[kBlock / 64];
+  // a block holds < 2^31 bytes of rows: 256 rows of at most 2 * (2^20 + 2) bytes
+  const uint32_t total = block_reduce_add(active ? (uint32_t)tab_row_bytes(cnt, nm) : 0u, s_tmp);
+  const int any_nonmono = __syncthreads_or(active && ts.nonmono);
+  const int any_long = __syncthreads_or(too_long);
+  if (threadIdx.x == 0) {
+    d.blk_sums[(int64_t)cj * d.tiles + blockIdx.x] = total | (any_nonmono ? 0x80000000u : 0u);
+    if (any_long) d.pool_used[3] = 1ull;
+  }
+}
+
+// one block per item: blk_off[b] = sum of blk_sums[0..b), pool_used[0] = total bytes, [1] = overflow flag,
+// [2] = some row of the item is non-monotone  ([3] = some window was refused, set by the count pass)
+__global__ __launch_bounds__(kBlock) void cdftab_scan_kernel(const DecDesc *__restrict__ descs) {
+  const DecDesc &d = descs[blockIdx.x];
+  const int64_t nb = (int64_t)d.n_ch * d.tiles;
+  __shared__ uint32_t s_tmp[kBlock / 64];
+  __shared__ unsigned long long s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  uint32_t flagged = 0;
+  for (int64_t b0 = 0; b0 < nb; b0 += kBlock) {
+    const int64_t b = b0 + threadIdx.x;
+    const uint32_t raw = b < nb ? d.blk_sums[b] : 0u;
+    flagged |= raw >> 31;
+    const uint32_t v = raw & 0x7FFFFFFFu;
+    const uint32_t ex = block_scan_excl(v, s_tmp);
+    const unsigned long long carry = s_carry;
+    if (b < nb) d.blk_off[b] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) s_carry = carry + ex + v;
+    __syncthreads();
+  }
+  const int any_nonmono = __syncthreads_or((int)flagged);
+  if (threadIdx.x == 0) {
+    d.pool_used[0] = s_carry;
+    d.pool_used[1] = s_carry > d.pool_cap ? 1ull : 0ull;
+    d.pool_used[2] = (unsigned long long)(any_nonmono != 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// generic path, pass 2: re-evaluate the trimmed window and store the row at its offset (latent order)
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, bool CLAMPED, typename PT>
+__global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__restrict__ descs) {
+  const DecDesc &d = descs[blockIdx.z];
+  const int cj = (int)blockIdx.y;
+  if (cj >= d.n_ch) return;
+  const int64_t hw = d.hw;
+  if ((int64_t)blockIdx.x * kBlock >= hw) return;
+  if (d.pool_used[1] || d.pool_used[3]) return; // pool too small / a window refused: the host sees the flags
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = p < hw;
+  const int c = d.chan_list ? d.chan_list[cj] : cj;
+  TabLatent<MODE, CLAMPED, PT> L;
+  L.load(d, c, active ? p : 0);
+
+  int a_idx = 0;
+  uint32_t cnt = 0, nonmono = 0;
+  if (active) {
+    const int64_t i = (int64_t)cj * hw + p;
+    if (d.hdr_form == 8) {
+      const unsigned long long h = static_cast<const unsigned long long *>(d.hdr)[i];
+      a_idx = (int)((int64_t)(int32_t)(uint32_t)h + d.max_bs);
+      cnt = (uint32_t)(h >> 32) & 0x7FFFFFFFu;
+      nonmono = (uint32_t)(h >> 63);
+    } else {
+      const uint32_t h = static_cast<const uint32_t *>(d.hdr)[i];
+      a_idx = tab_hdr_a(h) + d.max_bs;
+      cnt = tab_hdr_cnt(h);
+      nonmono = tab_hdr_nonmono(h);
+    }
+  }
+  const uint32_t bytes = active ? (uint32_t)tab_row_bytes(cnt, nonmono) : 0u;
+  __shared__ uint32_t s_tmp[kBlock / 64];
+  const uint32_t ex = block_scan_excl(bytes, s_tmp);
+  if (!active) return;
+  uint8_t *__restrict__ row = d.pool + d.blk_off[(int64_t)cj * d.tiles + blockIdx.x] + ex; // 4-byte aligned
+
+  if (!tab_row_is_ef(cnt, nonmono)) {
+    // raw: uint16 entries, padded to an even count with the last value
+    const uint32_t len2 = (cnt + 1u) & ~1u;
+    for (uint32_t j0 = 0; j0 < len2; j0 += 2) {
+      const uint32_t e0 = L.edge(a_idx + (int)j0);
+      const uint32_t e1 = (j0 + 1 < cnt) ? L.edge(a_idx + (int)j0 + 1) : e0;
+      *reinterpret_cast<uint32_t *>(row + 2 * j0) = e0 | (e1 << 16);
+    }
+  } else {
+    // Elias-Fano, 8 low bits: lows[cnt] (padded to 4), then U 32-bit words with bit ((E_j >> 8) + j) set
+    const uint32_t lows_bytes = tab_ef_lows_bytes(cnt), U = tab_ef_words(cnt);
+    uint32_t *__restrict__ up = reinterpret_cast<uint32_t *>(row + lows_bytes);
+    uint32_t wcur = 0, widx = 0;
+    for (uint32_t j0 = 0; j0 < lows_bytes; j0 += 4) {
+      uint32_t lo = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (j0 + t < cnt) {
+          const uint32_t e = L.edge(a_idx + (int)(j0 + t));
+          lo |= (e & 0xFFu) << (8 * t);
+          const uint32_t pos = (e >> 8) + j0 + t; // strictly increasing: the row is monotone
+          const uint32_t wi = pos >> 5;
+          while (widx < wi) {
+            up[widx++] = wcur;
+            wcur = 0;
+          }
+          wcur |= 1u << (pos & 31u);
+        }
+      }
+      *reinterpret_cast<uint32_t *>(row + j0) = lo;
+    }
+    while (widx < U) {
+      up[widx++] = wcur;
+      wcur = 0;
+    }
+  }
+}
+
+// =========================================================================================================
+// tab_kernel — the single-pass path
+// =========================================================================================================
+// largest l in [0, n) with pref[l] <= t   (pref non-decreasing, pref[0] <= t < pref[n])
+__device__ __forceinline__ int find_owner(const uint32_t *pref, int n, uint32_t t) {
+  int lo = 0, hi = n; // pref[lo] <= t < pref[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pref[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+struct TabSmem { // carve-up of the dynamic LDS of one block (every offset a multiple of 16)
+  float4_t *P;       // [tl][4]: mu, sigma (clamped), pi, refined 1/sigma
+  uint32_t *offP;    // [tl + 1] pairs of edges before latent l
+  uint32_t *win;     // [tl] j_lo | (j_hi - j_lo) << 16
+  uint32_t *meta;    // [tl] a_idx | cnt << 16   (tab_tl: W <= cap_e <= 32768, so both fit)
+  uint32_t *rowoff;  // [tl + 1] byte offset of row l within the block's rows
+  uint16_t *tsat;    // [tl]
+  uint8_t *flags;    // [tl] bit 0: parameters tame (fast evaluation allowed), bit 1: row non-monotone
+  uint32_t *scratch; // [16]
+  uint32_t *E32;     // [cap_e / 2] evaluated edges, two uint16 per word: entry k of latent l is uint16 2 * offP[l] + k
+  __device__ __forceinline__ TabSmem(unsigned char *base, int tl, int cap_e) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+      unsigned char *p = base + o;
+      o += (bytes + 15) & ~(size_t)15;
+      return p;
+    };
+    P = reinterpret_cast<float4_t *>(take(sizeof(float4_t) * 4 * (size_t)tl));
+    offP = reinterpret_cast<uint32_t *>(take(4 * ((size_t)tl + 1)));
+    win = reinterpret_cast<uint32_t *>(take(4 * (size_t)tl));
+    meta = reinterpret_cast<uint32_t *>(take(4 * (size_t)tl));
+    rowoff = reinterpret_cast<uint32_t *>(take(4 * ((size_t)tl + 1)));
+    tsat = reinterpret_cast<uint16_t *>(take(2 * (size_t)tl));
+    flags = reinterpret_cast<uint8_t *>(take((size_t)tl));
+    scratch = reinterpret_cast<uint32_t *>(take(64));
+    E32 = reinterpret_cast<uint32_t *>(take(2 * (size_t)cap_e));
+  }
+};
+static size_t tab_smem_bytes(int tl, int cap_e) {
+  auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  return r(64 * (size_t)tl) + r(4 * ((size_t)tl + 1)) * 2 + r(4 * (size_t)tl) * 2 + r(2 * (size_t)tl) + r((size_t)tl) + 64 + r(2 * (size_t)cap_e);
+}
+
+// block-wide exclusive scan for up to kBlock values held by the first threads (others pass 0); total in *total
+__device__ __forceinline__ uint32_t tab_scan(uint32_t v, uint32_t *scratch, uint32_t *total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) scratch[w] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kBlock / 64; ++i) {
+    const uint32_t s = scratch[i];
+    base += (i < w) ? s : 0u;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+#ifndef FGMM_TAB_WAVES
+#define FGMM_TAB_WAVES 4
+#endif
+template <int MODE, bool CLAMPED, typename PT>
+__global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDesc *__restrict__ descs, int tl_max, int cap_e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const DecDesc &d = descs[blockIdx.y];
+  const int b = d.blk_begin + (int)blockIdx.x;
+  if (b >= d.blk_end) return;
+  const int tl = d.tl;
+  const int64_t i0 = (int64_t)b * tl;
+  const int nl = (int)std::min<int64_t>(tl, d.n - i0); // latents of this block (>= 1)
+  TabSmem S(smem_raw, tl_max, cap_e);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int max_bs = d.max_bs;
+  const int W = 2 * max_bs + 2;
+
+  // ---- phase 0: parameters -> LDS, evaluation window ------------------------------------------------------------
+  uint32_t pairs = 0;
+  if (tid < nl) {
+    const int64_t i = i0 + tid;
+    const int64_t cj = i / d.hw, p = i - cj * d.hw;
+    const int c = d.chan_list ? d.chan_list[cj] : (int)cj;
+    const int64_t base = (int64_t)c * d.stride_c + p * d.stride_p;
+    float mu[4], sg[4], pi[4], rs[4];
+    bool tame = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sg[k] = ld1<PT>(d.scales, base + k * d.stride_k);
+      mu[k] = ld1<PT>(d.means, base + k * d.stride_k);
+      pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
+    }
+    if constexpr (CLAMPED) {
+      Sigma4 S4;
+      S4.set(sg[0], sg[1], sg[2], sg[3]);
+      tame = S4.tame;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sg[k] = tame ? S4.sg[k] : clamp_scale(sg[k]); // a NaN sigma stays NaN (the IEEE path is taken for this latent)
+        rs[k] = S4.rs[k];
+      }
+    } else {
+      tame = false; // un-clamped sigma: IEEE division, scalar evaluation
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rs[k] = 0.0f;
+    }
+    int j_lo, j_hi;
+    uint32_t T_sat;
+    tab_window<MODE>(mu, sg, pi, d.prune, max_bs, W, j_lo, j_hi, T_sat);
+    S.P[4 * tid + 0] = (float4_t){mu[0], mu[1], mu[2], mu[3]};
+    S.P[4 * tid + 1] = (float4_t){sg[0], sg[1], sg[2], sg[3]};
+    S.P[4 * tid + 2] = (float4_t){pi[0], pi[1], pi[2], pi[3]};
+    S.P[4 * tid + 3] = (float4_t){rs[0], rs[1], rs[2], rs[3]};
+    S.win[tid] = (uint32_t)j_lo | ((uint32_t)(j_hi - j_lo) << 16);
+    S.tsat[tid] = (uint16_t)T_sat;
+    S.flags[tid] = tame ? 1 : 0;
+    pairs = (uint32_t)(j_hi - j_lo + 1) >> 1;
+  }
+  // ---- phase 1: pairs before each latent -------------------------------------------------------------------------
+  uint32_t NP;
+  const uint32_t exP = tab_scan(pairs, S.scratch, &NP);
+  if (tid < nl) S.offP[tid] = exP;
+  if (tid == 0) S.offP[nl] = NP;
+  __syncthreads();
+
+  // ---- phase 2: flattened evaluation, two consecutive edges per lane and step ------------------------------------
+  {
+    // each wave takes a contiguous quarter of the pairs (in steps of 64), so that from one step to the next a lane
+    // moves on by 64 pairs: two or three latents further, found by walking the prefix array forward
+    const uint32_t Q = (((NP + 3) >> 2) + 63u) & ~63u;
+    const uint32_t t_end = std::min(NP, (uint32_t)(wave + 1) * Q);
+    uint32_t t = (uint32_t)wave * Q + (uint32_t)lane;
+    int l = 0;
+    uint32_t l_beg = 0, l_end = 0;
+    if (t < t_end) {
+      l = find_owner(S.offP, nl, t);
+      l_beg = S.offP[l];
+      l_end = S.offP[l + 1];
+    }
+    for (; t < t_end; t += 64) {
+      while (t >= l_end) { // next latent with a non-empty window
+        ++l;
+        l_beg = l_end;
+        l_end = S.offP[l + 1];
+      }
+      const float4_t m4 = S.P[4 * l + 0], s4 = S.P[4 * l + 1], p4 = S.P[4 * l + 2], r4 = S.P[4 * l + 3];
+      const float mu[4] = {m4[0], m4[1], m4[2], m4[3]}, pi[4] = {p4[0], p4[1], p4[2], p4[3]};
+      const int j = (int)(S.win[l] & 0xFFFFu) + 2 * (int)(t - l_beg);
+      const float x0 = (float)(j - max_bs) - 0.5f, x1 = (float)(j + 1 - max_bs) - 0.5f;
+      float c0 = 0.0f, c1 = 0.0f;
+      bool fast = false;
+      if constexpr (CLAMPED) {
+        Sigma4 S4;
+        S4.tame = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          S4.sg[k] = s4[k];
+          S4.rs[k] = r4[k];
+        }
+        bool ok = (S.flags[l] & 1) != 0;
+        const f2 cc = mix4_clamped2<MODE>((f2){x0, x1}, mu, S4, pi, ok);
+        c0 = cc.x;
+        c1 = cc.y;
+        fast = ok;
+      }
+      if (__builtin_expect(!fast, 0)) { // un-clamped sigma, NaN sigma, far-off or non-finite mean: IEEE evaluation
+        c0 = mix4_slow<MODE>(x0, mu[0], mu[1], mu[2], mu[3], s4[0], s4[1], s4[2], s4[3], pi[0], pi[1], pi[2], pi[3]);
+        c1 = mix4_slow<MODE>(x1, mu[0], mu[1], mu[2], mu[3], s4[0], s4[1], s4[2], s4[3], pi[0], pi[1], pi[2], pi[3]);
+      }
+      S.E32[t] = quant16(c0) | (quant16(c1) << 16);
+    }
+  }
+  __syncthreads();
+  const uint16_t *E16 = reinterpret_cast<const uint16_t *>(S.E32);
+
+  // ---- phase 3: trim every row, header, row size ------------------------------------------------------------------
+  uint32_t bytes = 0;
+  if (tid < nl) {
+    const uint32_t w = S.win[tid];
+    const int j_lo = (int)(w & 0xFFFFu), len = (int)(w >> 16), j_hi = j_lo + len;
+    const uint16_t *e = E16 + 2 * (size_t)S.offP[tid];
+    TrimState ts;
+    ts.init(j_lo);
+    for (int k = 0; k < len; ++k) ts.step(j_lo + k, e[k]);
+    int a_idx;
+    uint32_t cnt;
+    ts.finish(j_hi, W, S.tsat[tid], a_idx, cnt);
+    const uint32_t nm = ts.nonmono ? 1u : 0u;
+    S.meta[tid] = (uint32_t)a_idx | (cnt << 16);
+    if (nm) S.flags[tid] |= 2;
+    bytes = (uint32_t)tab_row_bytes(cnt, nm);
+    const int64_t li = (int64_t)(b - d.blk_begin) * tl + tid; // latent index within this launch's header array
+    if (d.hdr_form == 2) {
+      const uint32_t c8 = nm ? kHdr2Escape : cnt; // W <= 254 here, so cnt <= 254
+      static_cast<uint16_t *>(d.hdr_out)[li] = (uint16_t)((uint32_t)a_idx | (c8 << 8));
+      if (nm) bytes += 4; // the escaped row carries its own 4-byte header
+    } else if (d.hdr_form == 4) {
+      static_cast<uint32_t *>(d.hdr_out)[li] = tab_hdr_pack(a_idx - max_bs, cnt, nm);
+    } else {
+      static_cast<unsigned long long *>(d.hdr_out)[li] = tab_hdr8_pack(a_idx - max_bs, cnt, nm);
+    }
+  }
+  // ---- phase 4: place the block's rows -----------------------------------------------------------------------------
+  uint32_t B;
+  const uint32_t exB = tab_scan(bytes, S.scratch, &B);
+  if (tid < nl) S.rowoff[tid] = exB;
+  if (tid == 0) {
+    S.rowoff[nl] = B;
+    const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)B);
+    const bool fits = base + B <= d.rows_cap;
+    if (!fits) atomicMax(&d.counters[1], 1ull);
+    atomicAdd(&d.counters[2], 2ull * NP);
+    d.blkoff_out[b - d.blk_begin] = (uint32_t)(base >> 2);
+    S.scratch[8] = (uint32_t)base;
+    S.scratch[9] = (uint32_t)(base >> 32);
+    S.scratch[10] = fits ? 1u : 0u;
+  }
+  {
+    const int any_nm = __syncthreads_or(tid < nl && (S.flags[tid] & 2)); // also publishes rowoff / scratch
+    if (tid == 0 && any_nm) atomicAdd(&d.counters[3], 1ull);
+  }
+  if (!S.scratch[10]) return; // the launch's row area is too small: the host re-runs it with what the cursor asks for
+  uint8_t *__restrict__ out = d.rows + (((unsigned long long)S.scratch[9] << 32) | S.scratch[8]);
+
+  // ---- phase 5: flattened over the 4-byte words of the block's rows ------------------------------------------------
+  {
+    const uint32_t NW = B >> 2;
+    const uint32_t Q = (((NW + 3) >> 2) + 63u) & ~63u;
+    const uint32_t q_end = std::min(NW, (uint32_t)(wave + 1) * Q);
+    uint32_t q = (uint32_t)wave * Q + (uint32_t)lane;
+    int l = 0;
+    uint32_t r_beg = 0, r_end = 0;
+    if (q < q_end) {
+      l = find_owner(S.rowoff, nl, 4 * q);
+      r_beg = S.rowoff[l];
+      r_end = S.rowoff[l + 1];
+    }
+    for (; q < q_end; q += 64) {
+      while (4 * q >= r_end) {
+        ++l;
+        r_beg = r_end;
+        r_end = S.rowoff[l + 1];
+      }
+      const uint32_t w = S.win[l], mt = S.meta[l];
+      const int j_lo = (int)(w & 0xFFFFu), j_hi = j_lo + (int)(w >> 16);
+      const int a_idx = (int)(mt & 0xFFFFu);
+      const uint32_t cnt = mt >> 16, nm = (S.flags[l] >> 1) & 1u, T_sat = S.tsat[l];
+      const uint16_t *e = E16 + 2 * (size_t)S.offP[l];
+      auto ent = [&](uint32_t k) -> uint32_t { // entry k of the row: F[a_idx + k]
+        const int idx = a_idx + (int)k;
+        return idx < j_lo ? 0u : (idx >= j_hi ? T_sat : (uint32_t)e[idx - j_lo]);
+      };
+      uint32_t word = (4 * q - r_beg) >> 2; // word of the row
+      uint32_t val;
+      const bool escaped = d.hdr_form == 2 && nm;
+      if (escaped && word == 0) {
+        val = tab_hdr_pack(a_idx - max_bs, cnt, 1u);
+      } else if (!tab_row_is_ef(cnt, nm)) {
+        if (escaped) --word;
+        const uint32_t k0 = 2 * word, e0 = ent(k0);
+        val = e0 | ((k0 + 1 < cnt ? ent(k0 + 1) : e0) << 16);
+      } else {
+        const uint32_t LW = tab_ef_lows_bytes(cnt) >> 2;
+        if (word < LW) {
+          val = 0;
+#pragma unroll
+          for (uint32_t t = 0; t < 4; ++t)
+            if (4 * word + t < cnt) val |= (ent(4 * word + t) & 0xFFu) << (8 * t);
+        } else {
+          // upper word h: the entries with (E_j >> 8) + j in [32 h, 32 h + 32); (E_j >> 8) + j is strictly increasing
+          // and lies in [j, j + 255], so the first of them is found by bisection over [32 h - 255, 32 h]
+          const uint32_t h = word - LW, p0 = 32 * h;
+          uint32_t lo = p0 > 255 ? p0 - 255 : 0, hi = std::min(cnt, p0); // answer in [lo, hi]: first j with pos_j >= p0
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((ent(mid) >> 8) + mid < p0) lo = mid + 1; else hi = mid;
+          }
+          val = 0;
+          for (uint32_t j = lo; j < cnt; ++j) {
+            const uint32_t pos = (ent(j) >> 8) + j;
+            if (pos >= p0 + 32) break;
+            val |= 1u << (pos - p0);
+          }
+        }
+      }
+      stg<uint32_t>(out + 4 * (size_t)q, val);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+static inline int launch_err() { return (int)hipGetLastError(); }
+
+template <bool CLAMPED, typename PT>
+static int launch_cdftab_c(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, int pass, hipStream_t s) {
+  dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)n_ch_max, (unsigned)count);
+#define FGMM_TAB_LAUNCH(M)                                                                                          \
+  if (pass & 1) {                                                                                                   \
+    hipLaunchKernelGGL((cdftab_count_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);                   \
+    hipLaunchKernelGGL(cdftab_scan_kernel, dim3((unsigned)count), dim3(kBlock), 0, s, d_descs);                     \
+  }                                                                                                                 \
+  if (pass & 2) hipLaunchKernelGGL((cdftab_fill_kernel<M, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d_descs);
+  switch (mode) {
+  case MODE_AS: FGMM_TAB_LAUNCH(MODE_AS) break;
+  case MODE_LOGISTIC: FGMM_TAB_LAUNCH(MODE_LOGISTIC) break;
+  default: FGMM_TAB_LAUNCH(MODE_POLYA) break;
+  }
+#undef FGMM_TAB_LAUNCH
+  return launch_err();
+}
+
+static int launch_cdftab_pass(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                              int pass, void *stream) {
+  if (count <= 0 || n_ch_max <= 0 || hw_max <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (f16) return clamped ? launch_cdftab_c<true, _Float16>(d_descs, count, n_ch_max, hw_max, mode, pass, s)
+                          : launch_cdftab_c<false, _Float16>(d_descs, count, n_ch_max, hw_max, mode, pass, s);
+  return clamped ? launch_cdftab_c<true, float>(d_descs, count, n_ch_max, hw_max, mode, pass, s)
+                 : launch_cdftab_c<false, float>(d_descs, count, n_ch_max, hw_max, mode, pass, s);
+}
+int launch_cdftab_count(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                        void *stream) {
+  return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 1, stream);
+}
+int launch_cdftab_fill(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                       void *stream) {
+  return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 2, stream);
+}
+int launch_cdftab(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, bool clamped, bool f16,
+                  void *stream) {
+  return launch_cdftab_pass(d_descs, count, n_ch_max, hw_max, mode, clamped, f16, 3, stream);
+}
+
+template <bool CLAMPED, typename PT>
+static int launch_tab_c(const DecDesc *d, int count, int blocks_max, int tl_max, int cap_e, int mode, hipStream_t s) {
+  const dim3 grid((unsigned)blocks_max, (unsigned)count);
+  const size_t lds = tab_smem_bytes(tl_max, cap_e);
+  switch (mode) {
+  case MODE_AS: hipLaunchKernelGGL((tab_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(kBlock), lds, s, d, tl_max, cap_e); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((tab_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(kBlock), lds, s, d, tl_max, cap_e); break;
+  default: hipLaunchKernelGGL((tab_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(kBlock), lds, s, d, tl_max, cap_e); break;
+  }
+  return launch_err();
+}
+int launch_tab(const DecDesc *d_descs, int count, int blocks_max, int tl_max, int cap_e, int mode, bool clamped, bool f16,
+               void *stream) {
+  if (count <= 0 || blocks_max <= 0) return 0;
+  if (tl_max < 1 || tl_max > kTabMaxTl || cap_e < 2 || cap_e > 65536 || tab_smem_bytes(tl_max, cap_e) > 160 * 1024) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  if (f16) return clamped ? launch_tab_c<true, _Float16>(d_descs, count, blocks_max, tl_max, cap_e, mode, s)
+                          : launch_tab_c<false, _Float16>(d_descs, count, blocks_max, tl_max, cap_e, mode, s);
+  return clamped ? launch_tab_c<true, float>(d_descs, count, blocks_max, tl_max, cap_e, mode, s)
+                 : launch_tab_c<false, float>(d_descs, count, blocks_max, tl_max, cap_e, mode, s);
+}
+
+} // namespace fgmm

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FGMM_ABI_VERSION 1
+#define FGMM_ABI_VERSION 2
 
 typedef enum {
   FGMM_OK = 0,
@@ -56,7 +56,11 @@ typedef enum { FGMM_MODE_POLYA = 0, FGMM_MODE_AS = 1, FGMM_MODE_LOGISTIC = 2 } f
 typedef enum { FGMM_HOST = 0, FGMM_DEVICE = 1 } fgmm_memspace;
 
 #define FGMM_K 4              /* the reference binds K = 4 only (rans_interface.cpp:60,982,1003,1033) */
-#define FGMM_MAX_BS 16382     /* largest decoder half-width (abs_max + 1) the edge-table header can carry */
+#define FGMM_MAX_BS 1073741822 /* largest decoder half-width (abs_max + 1): 2^30 - 2, so that 2*max_bs + 2 fits an int32.
+                                 Beyond 16382 headers are 8 bytes and rows are built by the generic two-pass kernels,
+                                 which refuse (FGMM_ERR_UNSUPPORTED) a latent whose evaluation window — what is left of
+                                 [-max_bs, max_bs+1] between the provably saturated tails — exceeds 2^20 edges */
+#define FGMM_MAX_BS_H4 16382  /* largest half-width the 4-byte header form can carry */
 
 typedef struct fgmm_ctx fgmm_ctx; /* one per process per GPU: streams, pinned staging, workspaces, host threads */
 
@@ -71,13 +75,28 @@ int fgmm_ctx_threads(const fgmm_ctx *ctx);
 
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
 
-/* Measurement aid (bench.py): when enabled, timing HIP events bracket each table kernel ON THE STREAM IT IS
- * LAUNCHED ON; fgmm_ctx_kernel_ms returns the duration of the most recent launch of
- * which = 0: symtab kernel (encode-side CDF), 1: cdftab count + scan passes (decode-side table sizes), 2: quant_stats
- * kernel, 3: cdftab fill passes (decode-side rows, stored over PCIe into pinned host memory: PCIe-bound by design). */
+/* Tuning knobs of a context (defaults in brackets).  Unknown names return FGMM_ERR_INVALID.
+ *   "tail_items"  [8]   decode: how many trailing bitstreams of a call land in pieces (a bitstream decodes sequentially:
+ *                       whatever lands last leaves one item of host work behind it)
+ *   "tail_pieces" [4]   ... and in how many pieces each (1: whole), at most 8
+ *   "dec_group"   [0]   decode: bitstreams per launch / copy (0: automatic)
+ *   "dec_first"   [2]   decode: size of the first group (the first tables reach the host as early as possible)
+ *   "tab_cap_e"   [8192] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2))
+ *   "stage_max_mb" [0]  decode: cap of the device staging area for rows in MiB (0: a quarter of the free device memory).
+ *                       A launch whose rows do not fit is re-run with the exact size its cursor reports.
+ *   "trace"       [0]   1: phase timestamps of every batched call on stderr, 2: + per-bitstream job timeline */
+int fgmm_ctx_set_option(fgmm_ctx *ctx, const char *name, int64_t value);
+int fgmm_ctx_get_option(fgmm_ctx *ctx, const char *name, int64_t *value_out);
+/* Releases the context's grown buffers (device workspace and staging, pinned host ranges); they grow again on demand. */
+int fgmm_ctx_trim(fgmm_ctx *ctx);
+
+/* Measurement aid (bench.py): when enabled, timing HIP events bracket the table kernels ON THE STREAM THEY ARE
+ * LAUNCHED ON; fgmm_ctx_kernel_ms returns the duration of the most recent launch(es) of
+ * which = 0: symtab kernel (encode-side CDF), 1: decode-side table kernels of the last call (all launches, first to
+ * last), 2: quant_stats kernel, 3: unused (0). */
 int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable);
-/* Byte counts of the most recent batched call: which = 0 encode tables copied D2H, 1 decode headers + rows stored
- * into host memory by the fill pass, 2 latents those decode tables describe. */
+/* Counters of the most recent batched call: which = 0 encode tables copied D2H (bytes), 1 decode headers + block offsets
+ * + rows copied D2H (bytes), 2 latents those decode tables describe, 3 edges the decode-side kernels evaluated. */
 int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out);
 int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out);
 
@@ -173,27 +192,41 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
                           const float *means, const float *weights, int64_t n, int64_t stride_n, int64_t stride_k,
                           int mode, uint32_t *packed);
 
-/* GPU: decode-side edge tables.  For latent i the reference's bisection can only ever look at
+/* GPU: decode-side edge tables (format v4).  For latent i the reference's bisection can only ever look at
  *   F_i[v] = (uint16)(cdf_i(v - 0.5) * 65535),  v in [-max_bs, max_bs + 1]      (rans_interface.cpp:826-862).
  * The kernels find, exactly, the window outside which F_i is constant (evaluating F_i everywhere except where
  * every mixture component is provably saturated — fgmm_selftest_saturation) and store it:
- *   hdr[i] (uint32) = int16 a | cnt << 16 (15 bits) | nonmono << 31
+ *   header of latent i, one of three forms (chosen per table from max_bs: FGMM_HDR_FORM(max_bs)):
+ *     2 bytes  (a + max_bs) | cnt << 8, cnt in [1, 254]            when 2*max_bs + 2 <= 254
+ *              cnt field 255: the row begins with a 4-byte header of the next form (non-monotone rows)
+ *     4 bytes  int16 a | cnt << 16 (15 bits) | nonmono << 31        when max_bs <= FGMM_MAX_BS_H4
+ *     8 bytes  int32 a ; cnt (31 bits) | nonmono << 31              any max_bs <= FGMM_MAX_BS
  *   row i  = F_i[a .. a+cnt), from the first non-zero edge to the start of the trailing constant run;
- *            F_i[v < a] = 0,   F_i[v >= a+cnt] = the row's last entry
- * Rows lie in LATENT ORDER in `pool`, 4-byte aligned, with no stored offset (row i+1 starts where row i ends):
- *   cnt < 64 or nonmono : uint16[round2(cnt)], padded with the last value              (2*round2(cnt) bytes)
- *   cnt >= 64, monotone : Elias-Fano with 8 low bits: uint8 lows[round8(cnt)], then uint64 upper[U],
- *                         U = ceil((cnt + 256) / 64), bit ((F >> 8) + j) set for entry j  (round8(cnt) + 8U bytes)
- * `nonmono` is set when the row decreases somewhere.  hdr: device uint32[n]; pool: device bytes; pool_used: device
- * uint64[1] = bytes written.  pool_cap >= n * 2 * round2(2*max_bs + 2) always suffices.  (Table format v3.  Inside
- * the batched decode calls the headers of an item with 2*max_bs + 2 <= 254 and no non-monotone row cross PCIe as
- * uint16 (a + max_bs) | cnt << 8; this entry point and fgmm_rans_decode_cdftab always use the 4-byte form.) */
+ *            F_i[v < a] = 0,   F_i[v >= a+cnt] = the row's last entry;  rows are 4-byte aligned:
+ *     cnt < 48 or nonmono : uint16[round2(cnt)], padded with the last value              (2*round2(cnt) bytes)
+ *     cnt >= 48, monotone : Elias-Fano with 8 low bits: uint8 lows[round4(cnt)], then uint32 upper[U],
+ *                           U = ceil((cnt + 256) / 32), bit ((F >> 8) + j) set for entry j  (round4(cnt) + 4U bytes)
+ *   `nonmono` is set when the row decreases somewhere.
+ * fgmm_build_cdftab_hip (generic two-pass kernels, lane = latent, any max_bs <= FGMM_MAX_BS_H4 here): 4-byte headers, rows
+ *   in LATENT ORDER with no stored offset (row i+1 starts where row i ends).  hdr: device uint32[n]; pool: device bytes;
+ *   pool_used: device uint64[1] = bytes written.  pool_cap >= n * 2 * round2(2*max_bs + 2) always suffices; a smaller
+ *   pool yields FGMM_ERR_NOMEM with *pool_used = the bytes needed.
+ * fgmm_build_tab_hip (the single-pass kernel of the batched decode path: parameters staged in LDS, evaluation flattened
+ *   over pairs of edges in packed fp32): headers in the form FGMM_HDR_FORM(max_bs) (device, n * form bytes); rows of each
+ *   block of *tl_out consecutive latents are contiguous and start at rows + 4 * blk_off[block]  (blocks are placed by an
+ *   atomic cursor: any order); blk_off: device uint32[ceil(n / tl)], provide ceil(n / 16) entries; rows_used: device
+ *   uint64[1].  FGMM_ERR_UNSUPPORTED when 2*max_bs + 2 does not fit the kernel's LDS budget (use the generic kernels),
+ *   FGMM_ERR_NOMEM (with *rows_used = the bytes needed) when rows_cap is too small. */
 #define FGMM_TAB_NO_PRUNE 1 /* flags: evaluate all of F_i instead of skipping its saturated tails (A/B testing) */
 #define FGMM_TAB_CLAMP 2    /* flags: clamp sigma to [0.11, 256] first (the entropy-model path's kernel variant) */
+#define FGMM_HDR_FORM(max_bs) ((2 * (int64_t)(max_bs) + 2 <= 254) ? 2 : ((max_bs) <= FGMM_MAX_BS_H4 ? 4 : 8))
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
                           const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode,
                           int32_t max_bs, int flags, uint32_t *hdr, uint8_t *pool, uint64_t pool_cap,
                           uint64_t *pool_used);
+int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means, const float *weights,
+                       int64_t n, int64_t stride_n, int64_t stride_k, int mode, int32_t max_bs, int flags, void *hdr,
+                       uint32_t *blk_off, uint8_t *rows, uint64_t rows_cap, uint64_t *rows_used, int32_t *tl_out);
 
 /* GPU self-test: exhaustive scan (every binary32 beyond the thresholds) of the saturation lemmas that let the
  * table kernel skip the tails of F_i.  *n_bad_out = number of violating inputs (must be 0). */
@@ -217,10 +250,16 @@ int fgmm_rans_encode_symtab2(const uint32_t *packed0, const int32_t *symbols0_or
                              const int32_t *symbols1_or_null, int64_t n1, uint8_t **out0, size_t *out0_len, uint8_t **out1,
                              size_t *out1_len);
 
-/* Host, integer only: edge tables -> symbols; the reference's bisection with every float evaluation replaced
- * by a look-up in F_i. */
+/* Host, integer only: edge tables (4-byte headers, rows sequential in latent order, as fgmm_build_cdftab_hip lays them
+ * out) -> symbols; the reference's bisection with every float evaluation replaced by a look-up in F_i.  pool_len bounds
+ * every row access: a malformed table (cnt = 0, a row past the pool, an inconsistent Elias-Fano row) yields
+ * FGMM_ERR_INVALID, never an out-of-bounds read; up to 32 bytes past a row may be read, so keep 32 bytes of slack
+ * after the last row inside pool_len. */
 int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint32_t *hdr, const uint8_t *pool,
-                            int64_t n, int32_t max_bs, int32_t *out_symbols);
+                            uint64_t pool_len, int64_t n, int32_t max_bs, int32_t *out_symbols);
+/* The same for any header form and block-placed rows (fgmm_build_tab_hip); blk_off may be NULL (sequential rows). */
+int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void *hdr, int hdr_form, const uint32_t *blk_off,
+                         int32_t tl, const uint8_t *rows, uint64_t rows_len, int64_t n, int32_t max_bs, int32_t *out_symbols);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 4. Table path — the `z` hyper-latent coder: CompressAI's original table rANS, the other

@@ -8,7 +8,12 @@ import ctypes as C
 import numpy as np
 
 
-EF_MIN = 64
+EF_MIN = 48
+MAX_BS_H4 = 16382
+
+
+def hdr_form(max_bs: int) -> int:
+    return 2 if 2 * max_bs + 2 <= 254 else (4 if max_bs <= MAX_BS_H4 else 8)
 
 
 def row_is_ef(cnt: int, nonmono: int) -> bool:
@@ -17,64 +22,121 @@ def row_is_ef(cnt: int, nonmono: int) -> bool:
 
 def row_bytes(cnt: int, nonmono: int) -> int:
     if row_is_ef(cnt, nonmono):
-        return ((cnt + 7) & ~7) + 8 * ((cnt + 256 + 63) >> 6)
+        return ((cnt + 3) & ~3) + 4 * ((cnt + 256 + 31) >> 5)
     return 2 * ((cnt + 1) & ~1)
 
 
-def trim_full_table(tab: np.ndarray, max_bs: int):
-    """full table [n, W=2*max_bs+2] (F_i[v], v=-max_bs..max_bs+1) -> (hdr uint32[n], pool uint8[...], used bytes),
-    format v3 of include/flashgmm_amd.h exactly as the cdftab kernels lay it out."""
+def _trim_row(F: np.ndarray):
+    """full row F[0..W) -> (a_idx, cnt, nonmono): first non-zero edge .. start of the trailing constant run"""
+    W = len(F)
+    nzpos = np.nonzero(F)[0]
+    lead = (nzpos[0] - 1) if len(nzpos) else W - 1  # index of the last leading zero (-1: none)
+    diff = np.nonzero(F != F[-1])[0]
+    run_start = (diff[-1] + 1) if len(diff) else 0  # start of the trailing constant run
+    a_idx = min(lead + 1, run_start)  # first non-zero edge (the zero before it is implied: F[v < a] = 0)
+    cnt = run_start - a_idx + 1
+    nonmono = int((np.diff(F[a_idx:a_idx + cnt]) < 0).any())
+    return int(a_idx), int(cnt), nonmono
+
+
+def _row_payload(row: np.ndarray, nonmono: int):
+    cnt = len(row)
+    if row_is_ef(cnt, nonmono):
+        lows = np.zeros((cnt + 3) & ~3, np.uint8)
+        lows[:cnt] = row & 0xFF
+        U = (cnt + 256 + 31) >> 5
+        bits = np.zeros(U * 32, np.uint8)
+        bits[(row >> 8) + np.arange(cnt)] = 1
+        up = np.packbits(bits.reshape(U, 32)[:, ::-1], axis=1).view(">u4").astype("<u4").reshape(-1)
+        return [lows, up.view(np.uint8)]
+    pad = (-cnt) % 2
+    return [np.concatenate([row, np.full(pad, row[-1])]).astype("<u2").view(np.uint8)]
+
+
+def _pack_hdr4(a: int, cnt: int, nonmono: int) -> int:
+    return (a & 0xFFFF) | (cnt << 16) | (nonmono << 31)
+
+
+def trim_full_table(tab: np.ndarray, max_bs: int, form: int = 4, tl: int = 0, shuffle_seed=None):
+    """full table [n, W=2*max_bs+2] (F_i[v], v=-max_bs..max_bs+1) -> (hdr, pool uint8[...], used bytes) in format v4 of
+    include/flashgmm_amd.h: `form`-byte headers; rows sequential in latent order (tl = 0) or, with tl > 0, per block of tl
+    latents at 4 * blk_off[block] — then (hdr, blk_off, pool, used) is returned, the blocks placed in a shuffled order
+    when shuffle_seed is given (the single-pass kernel places them in no particular order)."""
     n, W = tab.shape
     assert W == 2 * max_bs + 2
-    hdr = np.zeros(n, np.uint32)
-    chunks = []
+    dt = {2: np.uint16, 4: np.uint32, 8: np.uint64}[form]
+    hdr = np.zeros(n, dt)
+    rows = []
     for i in range(n):
         F = tab[i].astype(np.int64)
-        nzpos = np.nonzero(F)[0]
-        lead = (nzpos[0] - 1) if len(nzpos) else W - 1  # index of the last leading zero (-1: none)
-        diff = np.nonzero(F != F[-1])[0]
-        run_start = (diff[-1] + 1) if len(diff) else 0  # start of the trailing constant run
-        a_idx = min(lead + 1, run_start)  # first non-zero edge (the zero before it is implied: F[v < a] = 0)
-        cnt = run_start - a_idx + 1
+        a_idx, cnt, nonmono = _trim_row(F)
         row = F[a_idx:a_idx + cnt]
-        nonmono = int((np.diff(row) < 0).any())
         a = a_idx - max_bs
-        hdr[i] = (a & 0xFFFF) | (cnt << 16) | (nonmono << 31)
-        if row_is_ef(cnt, nonmono):
-            lows = np.zeros((cnt + 7) & ~7, np.uint8)
-            lows[:cnt] = row & 0xFF
-            U = (cnt + 256 + 63) >> 6
-            bits = np.zeros(U * 64, np.uint8)
-            bits[(row >> 8) + np.arange(cnt)] = 1
-            up = np.packbits(bits.reshape(U, 64)[:, ::-1], axis=1).view(">u8").astype("<u8").reshape(-1)
-            chunks += [lows, up.view(np.uint8)]
+        chunks = _row_payload(row, nonmono)
+        if form == 2:
+            assert W <= 254
+            hdr[i] = a_idx | ((255 if nonmono else cnt) << 8)
+            if nonmono:
+                chunks = [np.array([_pack_hdr4(a, cnt, 1)], "<u4").view(np.uint8)] + chunks
+        elif form == 4:
+            hdr[i] = _pack_hdr4(a, cnt, nonmono)
         else:
-            pad = (-cnt) % 2
-            chunks.append(np.concatenate([row, np.full(pad, row[-1])]).astype("<u2").view(np.uint8))
-    used = sum(len(c) for c in chunks)
-    pool = np.concatenate(chunks + [np.zeros(128, np.uint8)]) if chunks else np.zeros(128, np.uint8)
-    return hdr, pool, used
+            hdr[i] = (a & 0xFFFFFFFF) | ((cnt | (nonmono << 31)) << 32)
+        rows.append(np.concatenate(chunks))
+    if not tl:
+        used = sum(len(c) for c in rows)
+        pool = np.concatenate(rows + [np.zeros(128, np.uint8)]) if rows else np.zeros(128, np.uint8)
+        return hdr, pool, used
+    nblk = (n + tl - 1) // tl
+    order = np.arange(nblk)
+    if shuffle_seed is not None:
+        np.random.default_rng(shuffle_seed).shuffle(order)
+    blk_off = np.zeros(nblk, np.uint32)
+    parts, off = [], 0
+    for b in order:
+        blk_off[b] = off // 4
+        for r in rows[b * tl:(b + 1) * tl]:
+            parts.append(r)
+            off += len(r)
+    pool = np.concatenate(parts + [np.zeros(128, np.uint8)]) if parts else np.zeros(128, np.uint8)
+    return hdr, blk_off, pool, off
 
 
-def expand_trimmed(hdr: np.ndarray, pool: np.ndarray, max_bs: int) -> np.ndarray:
-    """(hdr, pool) -> full table [n, 2*max_bs+2] (the virtual F of the header comment)."""
+def expand_trimmed(hdr: np.ndarray, pool: np.ndarray, max_bs: int, blk_off=None, tl: int = 0) -> np.ndarray:
+    """(hdr, pool[, blk_off, tl]) -> full table [n, 2*max_bs+2] (the virtual F of the header comment); the header form is
+    taken from hdr.dtype."""
     n = len(hdr)
     W = 2 * max_bs + 2
+    form = hdr.dtype.itemsize
     out = np.zeros((n, W), np.uint16)
     pool = np.asarray(pool).view(np.uint8)
     off = 0
     for i in range(n):
+        if blk_off is not None and i % tl == 0:
+            off = 4 * int(blk_off[i // tl])
         h = int(hdr[i])
-        a = h & 0xFFFF
-        a = a - 65536 if a >= 32768 else a
-        cnt = (h >> 16) & 0x7FFF
-        nonmono = h >> 31
+        if form == 2:
+            a, cnt, nonmono = (h & 0xFF) - max_bs, h >> 8, 0
+            if cnt == 255:
+                h4 = int(pool[off:off + 4].view("<u4")[0])
+                off += 4
+                a = h4 & 0xFFFF
+                a = a - 65536 if a >= 32768 else a
+                cnt, nonmono = (h4 >> 16) & 0x7FFF, h4 >> 31
+        elif form == 4:
+            a = h & 0xFFFF
+            a = a - 65536 if a >= 32768 else a
+            cnt, nonmono = (h >> 16) & 0x7FFF, h >> 31
+        else:
+            a = h & 0xFFFFFFFF
+            a = a - (1 << 32) if a >= (1 << 31) else a
+            cnt, nonmono = (h >> 32) & 0x7FFFFFFF, h >> 63
         if row_is_ef(cnt, nonmono):
-            lb = (cnt + 7) & ~7
-            U = (cnt + 256 + 63) >> 6
+            lb = (cnt + 3) & ~3
+            U = (cnt + 256 + 31) >> 5
             lows = pool[off:off + cnt].astype(np.int64)
-            up = pool[off + lb:off + lb + 8 * U].view("<u8")
-            bits = np.unpackbits(up.astype(">u8").view(np.uint8).reshape(U, 8), axis=1)[:, ::-1].reshape(-1)
+            up = pool[off + lb:off + lb + 4 * U].view("<u4")
+            bits = np.unpackbits(up.astype(">u4").view(np.uint8).reshape(U, 4), axis=1)[:, ::-1].reshape(-1)
             pos = np.nonzero(bits)[0]
             assert len(pos) == cnt, (i, len(pos), cnt)
             row = ((pos - np.arange(cnt)) << 8) | lows
@@ -101,10 +163,26 @@ def host_encode_symtab(lib, packed: np.ndarray, symbols) -> bytes:
     return data
 
 
-def host_decode_cdftab(lib, enc: bytes, hdr: np.ndarray, pool: np.ndarray, max_bs: int):
+def host_decode_cdftab(lib, enc: bytes, hdr: np.ndarray, pool: np.ndarray, max_bs: int, pool_len=None):
+    """the public 4-byte-header / sequential-rows entry point"""
     hdr = np.ascontiguousarray(hdr, np.uint32)
     pool = np.ascontiguousarray(np.asarray(pool).view(np.uint8))
     out = np.empty(len(hdr), np.int32)
     rc = lib.fgmm_rans_decode_cdftab(enc, len(enc), hdr.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p),
-                                     len(hdr), max_bs, out.ctypes.data_as(C.c_void_p))
+                                     len(pool) if pool_len is None else pool_len, len(hdr), max_bs, out.ctypes.data_as(C.c_void_p))
+    return rc, out
+
+
+def host_decode_tab(lib, enc: bytes, hdr: np.ndarray, pool: np.ndarray, max_bs: int, blk_off=None, tl: int = 0, pool_len=None):
+    """any header form (taken from hdr.dtype), rows sequential or block-placed"""
+    hdr = np.ascontiguousarray(hdr)
+    pool = np.ascontiguousarray(np.asarray(pool).view(np.uint8))
+    out = np.empty(len(hdr), np.int32)
+    bo = None
+    if blk_off is not None:
+        blk_off = np.ascontiguousarray(blk_off, np.uint32)
+        bo = blk_off.ctypes.data_as(C.c_void_p)
+    rc = lib.fgmm_rans_decode_tab(enc, len(enc), hdr.ctypes.data_as(C.c_void_p), hdr.dtype.itemsize, bo, tl,
+                                  pool.ctypes.data_as(C.c_void_p), len(pool) if pool_len is None else pool_len, len(hdr), max_bs,
+                                  out.ctypes.data_as(C.c_void_p))
     return rc, out

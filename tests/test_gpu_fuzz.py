@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from flashgmm_amd import GaussianMixtureConditional, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -99,21 +99,30 @@ def test_concurrent_callers_share_one_context(oracle):
 
 
 def test_decoder_half_width_envelope(oracle):
-    """max_bs_value = abs_max + 1 up to FGMM_MAX_BS = 16382 works (tables prune the saturated tails); beyond is loud"""
+    """max_bs_value = abs_max + 1: 2-byte headers up to 126, 4-byte up to 16382, 8-byte beyond (the reference bisects any
+    half-width, rans_interface.cpp:826-854); only a latent whose evaluation window exceeds 2^20 edges is refused, loudly"""
     M, h, w = 2, 2, 2
     y, sg, mu, pi = T.make_latent(5, M=M, h=h, w=w)
-    y = y.copy()
-    y[0, 0, 0, 0] = 16380.6  # abs_max = 16381 -> max_bs = 16382
     gmc = GaussianMixtureConditional(K=4, mode="as")
-    t = [dv(a) for a in (y, sg, mu, pi)]
+    for peak in (125.6, 126.6, 254.4, 255.6, 16380.6, 16381.6, 1.0e6, -3.0e8, 1073741000.0):
+        y = y.copy()
+        y[0, 0, 0, 0] = peak
+        t = [dv(a) for a in (y, sg, mu, pi)]
+        (b, abs_max, zb), yq = gmc.compress(*t)
+        sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi)
+        assert abs_max == am == int(abs(np.float32(peak))) + 1
+        assert b == oracle.encode_gmm("as", sym, s, m, wt)
+        assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq), peak
+    # a component 3e6 away from the others: the window between the saturated tails is ~3e6 edges long -> refused
+    mu2 = mu.copy()
+    mu2[0, 0, 0, 0] = 3.0e6
+    y[0, 0, 0, 0] = 4.0e6
+    t = [dv(a) for a in (y, sg, mu2, pi)]
     (b, abs_max, zb), yq = gmc.compress(*t)
-    assert abs_max == 16381
-    sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi)
-    assert b == oracle.encode_gmm("as", sym, s, m, wt)
-    assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq)
-    y[0, 0, 0, 0] = 16381.6
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        gmc.decompress(b, abs_max, zb, *t[1:])
+    y[0, 0, 0, 0] = 2.0e9  # abs_max beyond FGMM_MAX_BS
     (b, abs_max, zb), yq = gmc.compress(dv(y), *t[1:])
-    assert abs_max == 16382
     with pytest.raises(RuntimeError, match="UNSUPPORTED"):
         gmc.decompress(b, abs_max, zb, *t[1:])
 
@@ -128,23 +137,19 @@ def test_empty_and_degenerate_batches():
     assert torch.equal(gmc.decompress(b, abs_max, zb, p, p * 0, p / 4), z)
 
 
-def test_row_pool_overflow_rerun():
-    """the decode row pool is provisioned for an average row; items that need more are re-run with an exact pool.
-    Forced here by provisioning 8 bytes per latent (the knob is read once per process, hence the subprocess)."""
-    import os
-    import subprocess
-    import sys
-
-    code = (
-        "import numpy as np, torch\n"
-        "from flashgmm_amd import GaussianMixtureConditional, testing as T\n"
-        "g = GaussianMixtureConditional(K=4, mode='logistic')\n"
-        "ts = [[torch.from_numpy(a).cuda() for a in T.make_latent(s, M=24, h=16, w=8)] for s in range(20)]\n"
-        "res = g.compress_batch(*[[t[k] for t in ts] for k in range(4)])\n"
-        "out = g.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res],\n"
-        "                         *[[t[k] for t in ts] for k in (1, 2, 3)])\n"
-        "assert all(torch.equal(o, r[1]) for o, r in zip(out, res))\n"
-        "print('rerun ok')\n")
-    env = dict(os.environ, FGMM_POOL_BYTES_PER_LATENT="8", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "rerun ok" in r.stdout, r.stderr[-1500:]
+def test_staging_overflow_rerun_in_a_batch(oracle):
+    """the decode staging area capped at 1 MiB for a batch that needs ~6: every launch unit overflows its share and is
+    re-run with the exact size its cursor reports (fgmm_capi.cpp, decode_batch); symbols as without the cap"""
+    g = GaussianMixtureConditional(K=4, mode="logistic")
+    ts = [[dv(a) for a in T.make_latent(s, M=24, h=16, w=8)] for s in range(20)]
+    res = g.compress_batch(*[[t[k] for t in ts] for k in range(4)])
+    args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], *[[t[k] for t in ts] for k in (1, 2, 3)])
+    saved = _lib.get_option(0, "stage_max_mb")
+    try:
+        _lib.trim(0)
+        _lib.set_option(0, "stage_max_mb", 1)
+        out = g.decompress_batch(*args)
+    finally:
+        _lib.set_option(0, "stage_max_mb", saved)
+        _lib.trim(0)
+    assert all(torch.equal(o, r[1]) for o, r in zip(out, res))

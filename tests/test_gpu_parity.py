@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from flashgmm_amd import GaussianMixtureConditional, _lib, ans, testing as T
-from helpers import expand_trimmed
+from helpers import expand_trimmed, hdr_form
 
 pytestmark = pytest.mark.gpu
 
@@ -58,11 +58,12 @@ def gpu_symtab(mode, v, s, m, w):
     return out.cpu().numpy().view(np.uint32)
 
 
-def gpu_cdftab(mode, s, m, w, max_bs, flags=0):
+def gpu_cdftab(mode, s, m, w, max_bs, flags=0, cap=None):
+    """generic two-pass kernels: 4-byte headers, rows sequential -> (hdr, pool, used)"""
     L, ctx = _lib.lib(), _lib.ctx(0)
     s, m, w = dv(s), dv(m), dv(w)
     n = s.size(0)
-    cap = n * 2 * (2 * max_bs + 6)  # bytes
+    cap = n * 2 * (2 * max_bs + 6) if cap is None else cap  # bytes
     hdr = torch.zeros(n, dtype=torch.int32, device=DEV)
     pool = torch.zeros(cap + 128, dtype=torch.uint8, device=DEV)
     used = torch.zeros(2, dtype=torch.int64, device=DEV)
@@ -71,6 +72,41 @@ def gpu_cdftab(mode, s, m, w, max_bs, flags=0):
                                        _lib.mode_id(mode), max_bs, flags, hdr.data_ptr(), pool.data_ptr(), cap,
                                        used.data_ptr()))
     return hdr.cpu().numpy().view(np.uint32), pool.cpu().numpy(), int(used[0].item())
+
+
+def gpu_tab(mode, s, m, w, max_bs, flags=0, cap=None):
+    """the single-pass kernel of the batched decode path: headers in the form of max_bs, rows placed block by block
+    -> (hdr, blk_off, rows, used, tl)"""
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    s, m, w = dv(s), dv(m), dv(w)
+    n = s.size(0)
+    form = hdr_form(max_bs)
+    cap = n * (2 * (2 * max_bs + 2) + 4) if cap is None else cap
+    hdr = torch.zeros(max(n, 1) * form, dtype=torch.uint8, device=DEV)
+    blk_off = torch.zeros(n // 16 + 2, dtype=torch.int32, device=DEV)
+    rows = torch.zeros(cap + 128, dtype=torch.uint8, device=DEV)
+    used = torch.zeros(2, dtype=torch.int64, device=DEV)
+    tl = C.c_int32(0)
+    torch.cuda.synchronize()
+    _lib.check(L.fgmm_build_tab_hip(ctx, None, s.data_ptr(), m.data_ptr(), w.data_ptr(), n, s.stride(0), s.stride(1),
+                                    _lib.mode_id(mode), max_bs, flags, hdr.data_ptr(), blk_off.data_ptr(), rows.data_ptr(), cap,
+                                    used.data_ptr(), C.byref(tl)))
+    dt = {2: np.uint16, 4: np.uint32, 8: np.uint64}[form]
+    nblk = (n + tl.value - 1) // tl.value
+    return (hdr.cpu().numpy()[: n * form].view(dt), blk_off.cpu().numpy().view(np.uint32)[:nblk], rows.cpu().numpy(),
+            int(used[0].item()), tl.value)
+
+
+def gpu_full_table(kernel, mode, s, m, w, max_bs, flags=0):
+    """-> (the virtual full table [n, 2*max_bs+2] a kernel's output stands for, bytes of rows)"""
+    if kernel == "generic":
+        h, p_, u = gpu_cdftab(mode, s, m, w, max_bs, flags)
+        return expand_trimmed(h, p_, max_bs), u
+    h, bo, rows, u, tl = gpu_tab(mode, s, m, w, max_bs, flags)
+    return expand_trimmed(h, rows, max_bs, bo, tl), u
+
+
+KERNELS = ["generic", "tab"]
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -226,18 +262,21 @@ def test_wide_bypass_symbols(oracle):
     sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi)
     assert abs_max == am == 123457
     assert b == oracle.encode_gmm("polya", sym, s, m, wt)
-    with pytest.raises(RuntimeError, match="UNSUPPORTED"):  # decoder half-width beyond the built envelope: loud
-        gmc.decompress(b, abs_max, zb, *t[1:])
+    # decoder half-width 123458: 8-byte headers, generic kernels; the result is the reference's
+    assert np.array_equal(oracle.decode_gmm("polya", b, s, m, wt, abs_max + 1), sym)
+    y_hat = gmc.decompress(b, abs_max, zb, *t[1:])
+    assert torch.equal(y_hat, yq) and np.array_equal(y_hat.cpu().numpy(), yqn)
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("mode", MODES)
-def test_cdftab_equals_oracle_full_table(oracle, mode):
+def test_cdftab_equals_oracle_full_table(oracle, mode, kernel):
     y, sg, mu, pi = T.make_latent(31, M=24, h=16, w=8)
     sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
     max_bs = abs_max + 1
-    hdr, pool, used = gpu_cdftab(mode, s, m, w, max_bs)
     full = oracle.cdftab(mode, s, m, w, max_bs)
-    assert np.array_equal(expand_trimmed(hdr, pool, max_bs), full)
+    got, used = gpu_full_table(kernel, mode, s, m, w, max_bs)
+    assert np.array_equal(got, full)
     assert used < 0.6 * 2 * full.size  # trimmed for real (bytes)
     # un-normalised / wild parameters: still exact (the window is found by evaluation, not by assumption)
     rng = np.random.default_rng(3)
@@ -245,8 +284,50 @@ def test_cdftab_equals_oracle_full_table(oracle, mode):
     sgw = np.exp(rng.uniform(-6, 6, (n, 4))).astype(np.float32)
     muw = (rng.standard_normal((n, 4)) * 20).astype(np.float32)
     piw = rng.uniform(0, 0.6, (n, 4)).astype(np.float32)
-    hdr, pool, used = gpu_cdftab(mode, sgw, muw, piw, 37)
-    assert np.array_equal(expand_trimmed(hdr, pool, 37), oracle.cdftab(mode, sgw, muw, piw, 37))
+    for max_bs in (37, 200):  # 2-byte and 4-byte headers
+        got, _ = gpu_full_table(kernel, mode, sgw, muw, piw, max_bs)
+        assert np.array_equal(got, oracle.cdftab(mode, sgw, muw, piw, max_bs)), max_bs
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_single_pass_kernel_sizes_and_edge_cases(oracle, mode):
+    """ragged block counts (n not a multiple of the block), a single latent, every block size the LDS budget gives,
+    non-monotone rows through the 2-byte header's escape; the two kernels agree byte for byte on what they write"""
+    rng = np.random.default_rng(41)
+    for n, max_bs in ((1, 5), (15, 5), (17, 60), (1000, 126), (257, 127), (300, 255), (4097, 20), (0, 9)):
+        sg = np.exp(rng.uniform(-3, 3, (n, 4))).astype(np.float32)
+        mu = (rng.standard_normal((n, 4)) * np.exp(rng.uniform(-2, 4, (n, 1)))).astype(np.float32)
+        pi = rng.dirichlet(np.ones(4), n).astype(np.float32)
+        pi[::5] = rng.uniform(-0.4, 1.2, (len(pi[::5]), 4)).astype(np.float32)  # negative weights: non-monotone rows
+        want = oracle.cdftab(mode, sg, mu, pi, max_bs)
+        for flags in (0, 2):
+            sgc = np.clip(sg, np.float32(0.11), np.float32(256)) if flags & 2 else sg
+            want = oracle.cdftab(mode, sgc, mu, pi, max_bs)
+            h, bo, rows, used, tl = gpu_tab(mode, sg, mu, pi, max_bs, flags)
+            assert np.array_equal(expand_trimmed(h, rows, max_bs, bo, tl), want), (n, max_bs, flags)
+            hg, pg, ug = gpu_cdftab(mode, sg, mu, pi, max_bs, flags)
+            assert used - ug == 4 * int(((h >> 8) == 255).sum() if h.dtype == np.uint16 else 0), (n, max_bs, flags)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):  # 2*max_bs+2 beyond the kernel's LDS budget: the generic path's
+        gpu_tab(mode, sg[:1], mu[:1], pi[:1], 5000)
+
+
+def test_row_area_overflow_is_reported_with_the_size_needed(oracle):
+    """both building blocks: a row area that is too small -> FGMM_ERR_NOMEM, *used = the bytes needed, and a second call
+    with exactly that size succeeds (the batched decoder does the same with its staging area)"""
+    y, sg, mu, pi = T.make_latent(33, M=8, h=16, w=8)
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    max_bs = abs_max + 1
+    want = oracle.cdftab("polya", s, m, w, max_bs)
+    h, p_, need = gpu_cdftab("polya", s, m, w, max_bs)
+    with pytest.raises(RuntimeError, match=f"NOMEM.*need {need}"):
+        gpu_cdftab("polya", s, m, w, max_bs, cap=need - 4)
+    h, p_, u = gpu_cdftab("polya", s, m, w, max_bs, cap=need)
+    assert u == need and np.array_equal(expand_trimmed(h, p_, max_bs), want)
+    h, bo, rows, need_t, tl = gpu_tab("polya", s, m, w, max_bs)
+    with pytest.raises(RuntimeError, match=f"NOMEM.*need {need_t}"):
+        gpu_tab("polya", s, m, w, max_bs, cap=need_t - 4)
+    h, bo, rows, u, tl = gpu_tab("polya", s, m, w, max_bs, cap=need_t)
+    assert u == need_t and np.array_equal(expand_trimmed(h, rows, max_bs, bo, tl), want)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -269,8 +350,9 @@ def test_fastmath_cores_equal_ieee():
             assert bad.value == 0, (which, seed, bad.value)
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("mode", MODES)
-def test_cdftab_clamped_variant(oracle, mode):
+def test_cdftab_clamped_variant(oracle, mode, kernel):
     """the entropy-model kernel variant (sigma clamp + shared refined reciprocals) == oracle on clamped sigma,
     including NaN / inf / huge means and sigma far outside the clamp"""
     rng = np.random.default_rng(123)
@@ -291,12 +373,13 @@ def test_cdftab_clamped_variant(oracle, mode):
     for max_bs in (3, 60):
         want = oracle.cdftab(mode, sgc, mu, pi, max_bs)
         for flags in (2, 3):
-            h, p_, u = gpu_cdftab(mode, sg, mu, pi, max_bs, flags=flags)
-            assert np.array_equal(expand_trimmed(h, p_, max_bs), want), (max_bs, flags)
+            got, _ = gpu_full_table(kernel, mode, sg, mu, pi, max_bs, flags=flags)
+            assert np.array_equal(got, want), (max_bs, flags)
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("mode", MODES)
-def test_cdftab_pruned_equals_unpruned(oracle, mode):
+def test_cdftab_pruned_equals_unpruned(oracle, mode, kernel):
     """wide half-widths, tiny and huge sigma, far-off means, weights outside [0,1], NaN/inf/zero sigma: the pruned
     kernel must reproduce the full evaluation exactly (and both the oracle where the oracle is affordable)."""
     rng = np.random.default_rng(77)
@@ -311,12 +394,14 @@ def test_cdftab_pruned_equals_unpruned(oracle, mode):
     sg[8::101, 3] = -1.0
     mu[9::101, 0] = np.inf
     pi[10::101, 2] = np.nan
-    for max_bs in (0, 1, 40, 700):
-        h0, p0, u0 = gpu_cdftab(mode, sg, mu, pi, max_bs, flags=1)
-        h1, p1, u1 = gpu_cdftab(mode, sg, mu, pi, max_bs, flags=0)
-        f0, f1 = expand_trimmed(h0, p0, max_bs), expand_trimmed(h1, p1, max_bs)
-        assert np.array_equal(f0, f1), max_bs
-        assert np.array_equal(h0, h1) and u0 == u1 and np.array_equal(p0[:u0], p1[:u1])
+    for max_bs in (0, 1, 40, 200) if kernel == "tab" else (0, 1, 40, 700):
+        f0, u0 = gpu_full_table(kernel, mode, sg, mu, pi, max_bs, flags=1)
+        f1, u1 = gpu_full_table(kernel, mode, sg, mu, pi, max_bs, flags=0)
+        assert np.array_equal(f0, f1) and u0 == u1, max_bs
+        if kernel == "generic":  # sequential rows: the two runs are the same bytes
+            h0, p0, _ = gpu_cdftab(mode, sg, mu, pi, max_bs, flags=1)
+            h1, p1, _ = gpu_cdftab(mode, sg, mu, pi, max_bs, flags=0)
+            assert np.array_equal(h0, h1) and np.array_equal(p0[:u0], p1[:u1])
         if max_bs <= 40:
             assert np.array_equal(f1, oracle.cdftab(mode, sg, mu, pi, max_bs)), max_bs
 
@@ -411,13 +496,28 @@ def test_batch_of_kodak_halves_full_size(mode):
         assert torch.equal(res[seed][1], torch.round(ys[seed]))
 
 
-@pytest.mark.parametrize("tail", [None, "3", "0"])
-def test_batch_of_ragged_empty_and_tiny_items(oracle, monkeypatch, tail):
+@pytest.fixture
+def ctx_options():
+    """set options of the process-wide context for one test and restore them afterwards"""
+    saved = {}
+
+    def set_(**kw):
+        for k, v in kw.items():
+            saved.setdefault(k, _lib.get_option(0, k))
+            _lib.set_option(0, k, v)
+
+    yield set_
+    for k, v in saved.items():
+        _lib.set_option(0, k, v)
+
+
+@pytest.mark.parametrize("tail", [None, 3, 0])
+def test_batch_of_ragged_empty_and_tiny_items(oracle, ctx_options, tail):
     """one batch mixing full-size items with all-zero ones (empty streams), single-channel / single-position ones and
     odd sizes: every item must equal its own single-item result and the oracle, whatever part of the decode pipeline
     (ordinary group, tail-window pieces with fewer channels than pieces) it falls into"""
     if tail is not None:
-        monkeypatch.setenv("FGMM_TAIL_ITEMS", tail)
+        ctx_options(tail_items=tail)
     gmc = GaussianMixtureConditional(K=4, mode="logistic")
     specs = [(1, (192, 32, 24), 0.1), (2, (5, 3, 3), 1.0), (3, (1, 1, 2), 0.0), (4, (3, 5, 7), 0.0), (5, (17, 1, 1), 0.3),
              (6, (192, 32, 24), 0.0), (7, (6, 4, 4), 1.0), (8, (2, 2, 2), 0.0), (9, (2, 64, 66), 0.0)]
@@ -463,12 +563,11 @@ def test_stacked_batch_equals_item_lists(dtype):
         gmc.decompress_batch([r[0][0] for r in a][:-1], [r[0][1] for r in a], [r[0][2] for r in a], sg, mu, pi)
 
 
-@pytest.mark.parametrize("tail,pieces", [(0, 4), (8, 1), (3, 2), (6, 3), (8, 8), (5, 50)])
-def test_decode_tail_window_settings(monkeypatch, tail, pieces):
+@pytest.mark.parametrize("tail,pieces", [(0, 4), (8, 1), (3, 2), (6, 3), (8, 8), (5, 7)])
+def test_decode_tail_window_settings(ctx_options, tail, pieces):
     """The last items of a decode batch land on the host in pieces and their decoders follow the pieces
     (fgmm_capi.cpp, decode_batch): every setting of the window must give the same symbols."""
-    monkeypatch.setenv("FGMM_TAIL_ITEMS", str(tail))
-    monkeypatch.setenv("FGMM_TAIL_PIECES", str(pieces))
+    ctx_options(tail_items=tail, tail_pieces=pieces)
     gmc = GaussianMixtureConditional(K=4, mode="polya")
     ys, ss, ms, ws = [], [], [], []
     for seed in range(9):
@@ -487,19 +586,38 @@ def test_decode_tail_window_settings(monkeypatch, tail, pieces):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_fill_pass_with_and_without_the_temp_buffer(monkeypatch, mode):
-    """the fill pass formats rows from the edges the count pass kept (default) or, when the temp buffer would exceed
-    FGMM_TMP_MAX_MB, evaluates them a second time: both must decode a batch to the same symbols"""
+def test_decode_paths_agree(ctx_options, mode):
+    """one batch decoded (a) by the single-pass kernel into a staging area provisioned for the worst case, (b) into one
+    that is far too small, so that every launch overflows and is re-run with the size its cursor reports, (c) with tiny
+    and (d) with the largest blocks the kernel takes, (e) by the generic two-pass kernels (the LDS budget set so low
+    that no item fits): the same symbols every time.  Then the context gives its buffers back and works again."""
     gmc = GaussianMixtureConditional(K=4, mode=mode)
     lat = [T.make_latent(300 + i, M=48, h=16, w=16, clamp=False, zero_frac=0.1) for i in range(6)]
     ys, ss, ms, ws = ([dv(l[k]) for l in lat] for k in range(4))
     res = gmc.compress_batch(ys, ss, ms, ws)
     args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
-    a = gmc.decompress_batch(*args)
-    monkeypatch.setenv("FGMM_TMP_MAX_MB", "0")
-    b = gmc.decompress_batch(*args)
-    for i in range(6):
-        assert torch.equal(a[i], res[i][1]) and torch.equal(b[i], res[i][1]), i
+    want = [r[1] for r in res]
+
+    def check(tag):
+        out = gmc.decompress_batch(*args)
+        for i in range(6):
+            assert torch.equal(out[i], want[i]), (tag, i)
+        return _lib.ctx_stat(0, 1)
+
+    bytes_a = check("worst case")
+    ctx_options(stage_max_mb=1)
+    _lib.trim(0)
+    assert check("overflow, re-run") == bytes_a
+    ctx_options(stage_max_mb=0, tab_cap_e=65536)
+    _lib.trim(0)
+    check("largest blocks")
+    ctx_options(tab_cap_e=16 * (2 * max(r[0][1] + 1 for r in res) + 2))
+    check("16-latent blocks")
+    ctx_options(tab_cap_e=256)
+    assert _lib.ctx_stat(0, 3) > 0
+    check("generic kernels")
+    assert _lib.ctx_stat(0, 3) == 0  # the generic path does not count its edges: proof that it ran
+    _lib.trim(0)
 
 
 @pytest.mark.parametrize("mode", MODES)

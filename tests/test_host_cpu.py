@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from flashgmm_amd import _lib, testing as T
-from helpers import expand_trimmed, host_decode_cdftab, host_encode_symtab, trim_full_table
+from helpers import expand_trimmed, host_decode_cdftab, host_decode_tab, host_encode_symtab, trim_full_table
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.fgmm_abi_version() == 1
+    assert L.fgmm_abi_version() == 2
 
 
 def test_header_is_plain_c_and_links():
@@ -226,12 +226,82 @@ def test_host_decoder_elias_fano_rows(oracle):
     tab[4::11, 1:] = 65535                  # everything in the last bucket
     hdr, pool, used = trim_full_table(tab, max_bs)
     cnt = (hdr >> 16) & 0x7FFF
-    assert (cnt >= 64).mean() > 0.9 and not (hdr >> 31).any()
+    assert (cnt >= 48).mean() > 0.9 and not (hdr >> 31).any()
     assert np.array_equal(expand_trimmed(hdr, pool, max_bs), tab)
     enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
     want = oracle.rans_decode_cdftab(enc, tab, max_bs)
     rc, out = host_decode_cdftab(L, enc, hdr, pool, max_bs)
     assert rc == 0 and np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("max_bs,tl", [(9, 16), (9, 48), (99, 32), (200, 32), (70000, 16)])
+def test_host_decoder_header_forms_and_block_placement(oracle, max_bs, tl):
+    """format v4: 2-byte headers (with the escape for non-monotone rows), 4- and 8-byte headers, rows placed block by
+    block in a shuffled order behind blk_off — the decoder must give what the sequential 4-byte form gives, which is what
+    the reference's bisection gives (garbage stream: every fallback is exercised)."""
+    L = _lib.lib()
+    rng = np.random.default_rng(max_bs + tl)
+    n = 1500
+    W = 2 * max_bs + 2
+    if max_bs > 1000:  # a huge half-width: rows live in a small window of it
+        tab = np.zeros((n, W), np.uint16)
+        for i in range(n):
+            c = int(rng.integers(0, W - 80))
+            k = int(rng.integers(1, 70))
+            tab[i, c:c + k] = np.sort(rng.integers(1, 65536, k))
+            tab[i, c + k:] = tab[i, c + k - 1]
+    else:
+        tab = np.sort(rng.integers(0, 65536, (n, W)), axis=1).astype(np.uint16)
+        tab[::3, : W // 5] = 0
+        tab[1::3, -W // 4:] = tab[1::3, -W // 4 - 1: -W // 4]
+        for i in range(0, n, 9):  # non-monotone rows (escape in the 2-byte form)
+            j = rng.integers(1, W - 1)
+            tab[i, j], tab[i, j - 1] = tab[i, j - 1], tab[i, j]
+    enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+    want = oracle.rans_decode_cdftab(enc, tab, max_bs)
+    from helpers import hdr_form
+    form = hdr_form(max_bs)
+    assert form == {9: 2, 99: 2, 200: 4, 70000: 8}[max_bs]
+    hdr, blk_off, pool, used = trim_full_table(tab, max_bs, form=form, tl=tl, shuffle_seed=3)
+    assert hdr.dtype.itemsize == form
+    if max_bs < 1000:
+        assert np.array_equal(expand_trimmed(hdr, pool, max_bs, blk_off, tl), tab)
+    rc, out = host_decode_tab(L, enc, hdr, pool, max_bs, blk_off, tl)
+    assert rc == 0 and np.array_equal(out, want)
+    hdr_s, pool_s, _ = trim_full_table(tab, max_bs, form=form)  # the same form, rows sequential
+    rc, out = host_decode_tab(L, enc, hdr_s, pool_s, max_bs)
+    assert rc == 0 and np.array_equal(out, want)
+
+
+def test_host_decoder_rejects_malformed_tables(oracle):
+    """memory safety does not depend on the table being well-formed (include/flashgmm_amd.h): cnt = 0, a window outside the
+    half-width, rows past the pool, inconsistent Elias-Fano rows -> FGMM_ERR_INVALID (1), never a wild read"""
+    L = _lib.lib()
+    rng = np.random.default_rng(2)
+    n, max_bs = 64, 99
+    tab = np.sort(rng.integers(0, 65536, (n, 2 * max_bs + 2)), axis=1).astype(np.uint16)
+    hdr, pool, used = trim_full_table(tab, max_bs)
+    enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+    assert host_decode_cdftab(L, enc, hdr, pool, max_bs)[0] == 0
+    bad = hdr.copy(); bad[5] &= 0x8000FFFF  # cnt = 0
+    assert host_decode_cdftab(L, enc, bad, pool, max_bs)[0] == 1
+    bad = hdr.copy(); bad[7] = (bad[7] & 0xFFFF0000) | ((-max_bs - 3) & 0xFFFF)  # a below -max_bs
+    assert host_decode_cdftab(L, enc, bad, pool, max_bs)[0] == 1
+    bad = hdr.copy(); bad[9] = (bad[9] & 0x8000FFFF) | (0x7FFF << 16)  # cnt far beyond the table
+    assert host_decode_cdftab(L, enc, bad, pool, max_bs)[0] == 1
+    assert host_decode_cdftab(L, enc, hdr, pool, max_bs, pool_len=used // 2)[0] == 1  # rows past the declared pool
+    # Elias-Fano rows whose unary part is all ones / all zeros (no closing zero, no entries)
+    for fill in (0xFF, 0x00):
+        p2 = pool.copy()
+        off = 0
+        for i in range(n):
+            cnt = (int(hdr[i]) >> 16) & 0x7FFF
+            lb, U = (cnt + 3) & ~3, (cnt + 256 + 31) >> 5
+            if i % 2 == 0:
+                p2[off + lb: off + lb + 4 * U] = fill
+            off += lb + 4 * U
+        rc, _ = host_decode_cdftab(L, enc, hdr, p2, max_bs)
+        assert rc in (0, 1)  # no crash; whatever is decodable decodes, the rest is refused
 
 
 def test_host_decoder_short_stream_is_an_error(oracle):
