@@ -595,7 +595,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   Trace tr("decode", (int)ctx->opt.trace);
   int rc;
   if ((rc = ctx->ensure_streams())) return rc;
-  const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 65536) & ~1;
+  const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 32768) & ~31;
   const bool clamped = items[0].clamp != 0, f16 = items[0].prm.dtype == FGMM_F16;
 
   // ---- items: coded channels, header form, path --------------------------------------------------------------------
@@ -636,7 +636,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   {
     const int n_piece = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tail_pieces, 1), kMaxPieces);
     int tail_items = n_piece > 1 ? (int)std::min<int64_t>({std::max<int64_t>(ctx->opt.tail_items, 0), (int64_t)n_fast,
-                                                            (int64_t)std::max(ctx->pool->size() / 2, 1)}) : 0;
+                                                            (int64_t)std::max(ctx->pool->size(), 1)}) : 0;
     if (tail_items) { // pieces only pay for rows that take a while to cross: a small tail travels whole
       int64_t lat = 0;
       for (int k = n_fast - tail_items; k < n_fast; ++k) lat += items[fast[k]].n;
@@ -739,6 +739,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.prune = 1;
     d.hdr_form = it.hdr_form;
     d.tl = it.tl;
+    d.count_edges = ctx->profiling ? 1 : 0; // measurement aid only (bench.py's roofline_decode)
     return d;
   };
   DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_descs);
@@ -1028,7 +1029,7 @@ const OptName kOpts[] = {
     {"tail_pieces", &fgmm_ctx::Opts::tail_pieces, 1, kMaxPieces, "FGMM_TAIL_PIECES"},
     {"dec_group", &fgmm_ctx::Opts::dec_group, 0, 1 << 20, "FGMM_DEC_GROUP"},
     {"dec_first", &fgmm_ctx::Opts::dec_first, 1, 1 << 20, "FGMM_DEC_FIRST"},
-    {"tab_cap_e", &fgmm_ctx::Opts::tab_cap_e, 256, 65536, "FGMM_TAB_CAP_E"},
+    {"tab_cap_e", &fgmm_ctx::Opts::tab_cap_e, 256, 32768, "FGMM_TAB_CAP_E"},
     {"stage_max_mb", &fgmm_ctx::Opts::stage_max_mb, 0, 1 << 30, "FGMM_STAGE_MAX_MB"},
     {"trace", &fgmm_ctx::Opts::trace, 0, 2, "FGMM_TRACE"},
     {"enc_vec", &fgmm_ctx::Opts::enc_vec, 0, 4, "FGMM_VEC"},
@@ -1471,7 +1472,7 @@ int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const f
   if (max_bs < 0 || max_bs > FGMM_MAX_BS) return fail(FGMM_ERR_UNSUPPORTED, "max_bs %d outside [0, %d]", max_bs, FGMM_MAX_BS);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
-  const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 65536) & ~1;
+  const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 32768) & ~31;
   const int tl = tab_tl(max_bs, cap_e);
   *tl_out = tl;
   if (!tl) return fail(FGMM_ERR_UNSUPPORTED, "2*max_bs+2 = %lld edges per latent do not fit the single-pass kernel (tab_cap_e = %d)", 2ll * max_bs + 2, cap_e);
@@ -1502,6 +1503,7 @@ int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const f
   hd->rows = rows;
   hd->rows_cap = rows_cap;
   hd->counters = reinterpret_cast<unsigned long long *>(ctx->d_ws + 1024);
+  hd->count_edges = 1;
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 32, s));
   if (n) LAUNCH_TRY(launch_tab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, (int)nblk, tl, cap_e, mode, (flags & FGMM_TAB_CLAMP) != 0, false, s));

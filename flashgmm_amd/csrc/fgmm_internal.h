@@ -53,7 +53,9 @@ struct DecDesc {
   uint8_t *rows;                 // the launch's row area (device staging)
   unsigned long long rows_cap;   // bytes
   unsigned long long *counters;  // shared by the launch: [0] cursor = bytes of rows placed, [1] overflow (a block did not fit),
-                                 // [2] edges evaluated, [3] non-monotone rows
+                                 // [2] edges evaluated (only when count_edges: one more same-address atomic per block),
+                                 // [3] blocks with a non-monotone row
+  int32_t count_edges, pad2_;
   // ---- generic two-pass path (cdftab_count / scan / fill): any half-width, rows sequential in latent order
   void *hdr;                     // [n] headers, 4-byte form (8-byte form when hdr_form == 8)
   int32_t tiles;                 // blocks per channel = ceil(hw / 256)
@@ -103,7 +105,7 @@ FGMM_HD static inline unsigned long long tab_row_bytes(uint32_t cnt, uint32_t no
 FGMM_HD static inline bool tab_hdr_fits16(int32_t max_bs) { return 2 * (int64_t)max_bs + 2 <= 254; }
 FGMM_HD static inline int tab_hdr_form(int32_t max_bs) { return tab_hdr_fits16(max_bs) ? 2 : (max_bs <= 16382 ? 4 : 8); }
 // tab_kernel: entries of evaluated edges one block may keep in LDS, and the latents per block that guarantees it
-constexpr int kTabCapE = 16384;
+constexpr int kTabCapE = 16384; // default of the "tab_cap_e" option (upper limit 32768: 16-bit prefix sums in the kernel)
 constexpr int kTabMaxTl = 256;
 FGMM_HD static inline int tab_tl(int32_t max_bs, int cap_e) { // 0: the item does not fit the single-pass kernel
   const int64_t W = 2 * (int64_t)max_bs + 2;

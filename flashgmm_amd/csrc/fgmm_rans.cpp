@@ -439,11 +439,18 @@ int rans_decode_tab(const uint8_t *enc, size_t enc_len, const TabView &tv, int64
     const uint8_t *rowp = pc.rows; // sequential placement: a running sum, never stored
     const int64_t tl = pc.blk_off ? (tv.tl > 0 ? tv.tl : 1) : (i_end - i_beg > 0 ? i_end - i_beg : 1);
     for (int64_t blk = 0; i < i_end; ++blk) {
+      const int64_t b_end = i + tl < i_end ? i + tl : i_end;
       if (pc.blk_off) {
         rowp = pc.rows + 4 * (size_t)pc.blk_off[blk];
         if (__builtin_expect(rowp > rows_end, 0)) { rc = FGMM_ERR_INVALID; break; }
+        // blocks lie in no particular order: the running prefetch below (1 KiB ahead of the row being searched) runs off
+        // the end of this block into someone else's rows, so the head of the NEXT block is fetched here, a block ahead
+        if (b_end < i_end) {
+          const uint8_t *nx = pc.rows + 4 * (size_t)pc.blk_off[blk + 1];
+          if (nx + 1024 <= rows_end)
+            for (int q = 0; q < 1024; q += 64) __builtin_prefetch(nx + q);
+        }
       }
-      const int64_t b_end = i + tl < i_end ? i + tl : i_end;
       for (; i < b_end; ++i) {
         __builtin_prefetch(rowp + 1024);
         __builtin_prefetch(rowp + 1024 + 64);

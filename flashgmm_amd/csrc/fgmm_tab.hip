@@ -116,10 +116,9 @@ struct TrimState {
     prev = 0;
   }
   __device__ __forceinline__ void step(int j, uint32_t E) {
-    if (allzero) {
-      if (E == 0) lead = j; else allzero = false;
-    }
-    if (j == 0 || E != prev) run_start = j;
+    lead = (allzero && E == 0) ? j : lead; // index of the last leading zero
+    allzero = allzero && E == 0;
+    run_start = (j == 0 || E != prev) ? j : run_start;
     nonmono |= (j > 0) && (E < prev);
     prev = E;
   }
@@ -320,6 +319,8 @@ struct TabSmem { // carve-up of the dynamic LDS of one block (every offset a mul
   uint16_t *tsat;    // [tl]
   uint8_t *flags;    // [tl] bit 0: parameters tame (fast evaluation allowed), bit 1: row non-monotone
   uint32_t *scratch; // [16]
+  uint32_t *efoff;   // [tl + 1] Elias-Fano rows before latent l: entries (low 16 bits) | upper words (high 16 bits)
+  uint32_t *bitmap;  // [cap_e / 32 + 9 * tl] the unary high parts of the block's Elias-Fano rows
   uint32_t *E32;     // [cap_e / 2] evaluated edges, two uint16 per word: entry k of latent l is uint16 2 * offP[l] + k
   __device__ __forceinline__ TabSmem(unsigned char *base, int tl, int cap_e) {
     size_t o = 0;
@@ -336,12 +337,15 @@ struct TabSmem { // carve-up of the dynamic LDS of one block (every offset a mul
     tsat = reinterpret_cast<uint16_t *>(take(2 * (size_t)tl));
     flags = reinterpret_cast<uint8_t *>(take((size_t)tl));
     scratch = reinterpret_cast<uint32_t *>(take(64));
+    efoff = reinterpret_cast<uint32_t *>(take(4 * ((size_t)tl + 1)));
+    bitmap = reinterpret_cast<uint32_t *>(take(4 * ((size_t)cap_e / 32 + 9 * (size_t)tl)));
     E32 = reinterpret_cast<uint32_t *>(take(2 * (size_t)cap_e));
   }
 };
 static size_t tab_smem_bytes(int tl, int cap_e) {
   auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  return r(64 * (size_t)tl) + r(4 * ((size_t)tl + 1)) * 2 + r(4 * (size_t)tl) * 2 + r(2 * (size_t)tl) + r((size_t)tl) + 64 + r(2 * (size_t)cap_e);
+  return r(64 * (size_t)tl) + r(4 * ((size_t)tl + 1)) * 3 + r(4 * (size_t)tl) * 2 + r(2 * (size_t)tl) + r((size_t)tl) + 64 +
+         r(4 * ((size_t)cap_e / 32 + 9 * (size_t)tl)) + r(2 * (size_t)cap_e);
 }
 
 // block-wide exclusive scan for up to kBlock values held by the first threads (others pass 0); total in *total
@@ -369,6 +373,9 @@ __device__ __forceinline__ uint32_t tab_scan(uint32_t v, uint32_t *scratch, uint
 
 #ifndef FGMM_TAB_WAVES
 #define FGMM_TAB_WAVES 4
+#endif
+#ifndef FGMM_TAB_EXPERIMENT
+#define FGMM_TAB_EXPERIMENT 0 // timing experiments only: 1 = no cursor atomic (rows at block-indexed worst-case slots), 2 = also no edge counter
 #endif
 template <int MODE, bool CLAMPED, typename PT>
 __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDesc *__restrict__ descs, int tl_max, int cap_e) {
@@ -446,6 +453,9 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       l_beg = S.offP[l];
       l_end = S.offP[l + 1];
     }
+#if FGMM_TAB_EXPERIMENT == 3
+    for (; t < t_end; t += 64) S.E32[t] = t;
+#endif
     for (; t < t_end; t += 64) {
       while (t >= l_end) { // next latent with a non-empty window
         ++l;
@@ -484,13 +494,32 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
 
   // ---- phase 3: trim every row, header, row size ------------------------------------------------------------------
   uint32_t bytes = 0;
+#if FGMM_TAB_EXPERIMENT == 4
+  if (tid < nl) { S.meta[tid] = 1u << 16; bytes = 4; }
+  if (false) {
+#else
   if (tid < nl) {
+#endif
     const uint32_t w = S.win[tid];
     const int j_lo = (int)(w & 0xFFFFu), len = (int)(w >> 16), j_hi = j_lo + len;
     const uint16_t *e = E16 + 2 * (size_t)S.offP[tid];
     TrimState ts;
     ts.init(j_lo);
-    for (int k = 0; k < len; ++k) ts.step(j_lo + k, e[k]);
+    // entries two at a time (one 32-bit LDS read), eight reads in flight: the loop is bound by LDS latency otherwise
+    const uint32_t *e32 = S.E32 + S.offP[tid];
+    int k = 0;
+#pragma unroll 1
+    for (; k + 16 <= len; k += 16) {
+      uint32_t v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = e32[(k >> 1) + q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        ts.step(j_lo + k + 2 * q, v[q] & 0xFFFFu);
+        ts.step(j_lo + k + 2 * q + 1, v[q] >> 16);
+      }
+    }
+    for (; k < len; ++k) ts.step(j_lo + k, e[k]);
     int a_idx;
     uint32_t cnt;
     ts.finish(j_hi, W, S.tsat[tid], a_idx, cnt);
@@ -509,29 +538,105 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       static_cast<unsigned long long *>(d.hdr_out)[li] = tab_hdr8_pack(a_idx - max_bs, cnt, nm);
     }
   }
-  // ---- phase 4: place the block's rows -----------------------------------------------------------------------------
-  uint32_t B;
+  // ---- phase 4: place the block's rows; Elias-Fano rows: entries and upper words before each ------------------------
+  uint32_t B, EFT;
   const uint32_t exB = tab_scan(bytes, S.scratch, &B);
-  if (tid < nl) S.rowoff[tid] = exB;
+  uint32_t ef_pack = 0;
+  if (tid < nl) {
+    const uint32_t cnt = S.meta[tid] >> 16, nm = (S.flags[tid] >> 1) & 1u;
+    if (tab_row_is_ef(cnt, nm)) ef_pack = cnt | (tab_ef_words(cnt) << 16); // both sums stay below 2^16 (cap_e <= 32768)
+  }
+  const uint32_t exEF = tab_scan(ef_pack, S.scratch, &EFT);
+  if (tid < nl) {
+    S.rowoff[tid] = exB;
+    S.efoff[tid] = exEF;
+  }
   if (tid == 0) {
     S.rowoff[nl] = B;
+    S.efoff[nl] = EFT;
+#if FGMM_TAB_EXPERIMENT >= 1
+    const unsigned long long base = (unsigned long long)(b - d.blk_begin) * tl * (2ull * W + 4);
+    if (b == d.blk_end - 1) d.counters[0] = base + B;
+#else
     const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)B);
+#endif
     const bool fits = base + B <= d.rows_cap;
     if (!fits) atomicMax(&d.counters[1], 1ull);
-    atomicAdd(&d.counters[2], 2ull * NP);
+#if FGMM_TAB_EXPERIMENT < 2
+    if (d.count_edges) atomicAdd(&d.counters[2], 2ull * NP);
+#endif
     d.blkoff_out[b - d.blk_begin] = (uint32_t)(base >> 2);
     S.scratch[8] = (uint32_t)base;
     S.scratch[9] = (uint32_t)(base >> 32);
     S.scratch[10] = fits ? 1u : 0u;
   }
+  for (uint32_t q = tid; q < (EFT >> 16); q += kBlock) S.bitmap[q] = 0;
   {
-    const int any_nm = __syncthreads_or(tid < nl && (S.flags[tid] & 2)); // also publishes rowoff / scratch
+    const int any_nm = __syncthreads_or(tid < nl && (S.flags[tid] & 2)); // also publishes rowoff / efoff / scratch / bitmap
     if (tid == 0 && any_nm) atomicAdd(&d.counters[3], 1ull);
   }
   if (!S.scratch[10]) return; // the launch's row area is too small: the host re-runs it with what the cursor asks for
   uint8_t *__restrict__ out = d.rows + (((unsigned long long)S.scratch[9] << 32) | S.scratch[8]);
 
-  // ---- phase 5: flattened over the 4-byte words of the block's rows ------------------------------------------------
+  // what a lane keeps of the row it is working on (reloaded from LDS only when it moves on to another latent)
+  struct RowRef {
+    const uint16_t *e; // first evaluated edge of the latent
+    int j_lo, j_hi, a_idx;
+    uint32_t cnt, nm, T_sat, aux; // aux: first entry / first upper word of the row among the block's Elias-Fano rows
+    __device__ __forceinline__ void load(const TabSmem &S, const uint16_t *E16, int l) {
+      const uint32_t w = S.win[l], mt = S.meta[l];
+      j_lo = (int)(w & 0xFFFFu);
+      j_hi = j_lo + (int)(w >> 16);
+      a_idx = (int)(mt & 0xFFFFu);
+      cnt = mt >> 16;
+      nm = (S.flags[l] >> 1) & 1u;
+      T_sat = S.tsat[l];
+      e = E16 + 2 * (size_t)S.offP[l] - j_lo; // e[idx] for j_lo <= idx < j_hi
+      aux = S.efoff[l];
+    }
+    // entry k of the row: F[a_idx + k] — an evaluated edge, or one of the two constants outside the evaluation window
+    __device__ __forceinline__ uint32_t entry(uint32_t k) const {
+      const int idx = a_idx + (int)k;
+      return idx < j_lo ? 0u : (idx >= j_hi ? T_sat : (uint32_t)e[idx]);
+    }
+  };
+
+  // ---- phase 5a: unary high parts of the Elias-Fano rows, FLATTENED over their entries: bit ((E_j >> 8) + j) ---------
+  {
+    const uint32_t NE = EFT & 0xFFFFu;
+    const uint32_t Q = (((NE + 3) >> 2) + 63u) & ~63u;
+    const uint32_t t_end = std::min(NE, (uint32_t)(wave + 1) * Q);
+    uint32_t t = (uint32_t)wave * Q + (uint32_t)lane;
+    int l = 0;
+    uint32_t l_beg = 0, l_end = 0;
+    RowRef R;
+    if (t < t_end) { // largest l with entries-before(l) <= t
+      int lo = 0, hi = nl;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((S.efoff[mid] & 0xFFFFu) <= t) lo = mid; else hi = mid;
+      }
+      l = lo;
+      R.load(S, E16, l);
+      l_beg = R.aux & 0xFFFFu;
+      l_end = S.efoff[l + 1] & 0xFFFFu;
+    }
+    for (; t < t_end; t += 64) {
+      if (t >= l_end) {
+        do {
+          ++l;
+          l_beg = l_end;
+          l_end = S.efoff[l + 1] & 0xFFFFu;
+        } while (t >= l_end);
+        R.load(S, E16, l);
+      }
+      const uint32_t k = t - l_beg, pos = (R.entry(k) >> 8) + k;
+      atomicOr(&S.bitmap[(R.aux >> 16) + (pos >> 5)], 1u << (pos & 31u));
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 5b: FLATTENED over the 4-byte words of the block's rows, coalesced stores --------------------------------
   {
     const uint32_t NW = B >> 2;
     const uint32_t Q = (((NW + 3) >> 2) + 63u) & ~63u;
@@ -539,57 +644,40 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     uint32_t q = (uint32_t)wave * Q + (uint32_t)lane;
     int l = 0;
     uint32_t r_beg = 0, r_end = 0;
+    RowRef R;
     if (q < q_end) {
       l = find_owner(S.rowoff, nl, 4 * q);
       r_beg = S.rowoff[l];
       r_end = S.rowoff[l + 1];
+      R.load(S, E16, l);
     }
     for (; q < q_end; q += 64) {
-      while (4 * q >= r_end) {
-        ++l;
-        r_beg = r_end;
-        r_end = S.rowoff[l + 1];
+      if (4 * q >= r_end) {
+        do {
+          ++l;
+          r_beg = r_end;
+          r_end = S.rowoff[l + 1];
+        } while (4 * q >= r_end);
+        R.load(S, E16, l);
       }
-      const uint32_t w = S.win[l], mt = S.meta[l];
-      const int j_lo = (int)(w & 0xFFFFu), j_hi = j_lo + (int)(w >> 16);
-      const int a_idx = (int)(mt & 0xFFFFu);
-      const uint32_t cnt = mt >> 16, nm = (S.flags[l] >> 1) & 1u, T_sat = S.tsat[l];
-      const uint16_t *e = E16 + 2 * (size_t)S.offP[l];
-      auto ent = [&](uint32_t k) -> uint32_t { // entry k of the row: F[a_idx + k]
-        const int idx = a_idx + (int)k;
-        return idx < j_lo ? 0u : (idx >= j_hi ? T_sat : (uint32_t)e[idx - j_lo]);
-      };
       uint32_t word = (4 * q - r_beg) >> 2; // word of the row
       uint32_t val;
-      const bool escaped = d.hdr_form == 2 && nm;
+      const bool escaped = d.hdr_form == 2 && R.nm;
       if (escaped && word == 0) {
-        val = tab_hdr_pack(a_idx - max_bs, cnt, 1u);
-      } else if (!tab_row_is_ef(cnt, nm)) {
+        val = tab_hdr_pack(R.a_idx - max_bs, R.cnt, 1u);
+      } else if (!tab_row_is_ef(R.cnt, R.nm)) {
         if (escaped) --word;
-        const uint32_t k0 = 2 * word, e0 = ent(k0);
-        val = e0 | ((k0 + 1 < cnt ? ent(k0 + 1) : e0) << 16);
+        const uint32_t k0 = 2 * word, e0 = R.entry(k0);
+        val = e0 | ((k0 + 1 < R.cnt ? R.entry(k0 + 1) : e0) << 16);
       } else {
-        const uint32_t LW = tab_ef_lows_bytes(cnt) >> 2;
+        const uint32_t LW = tab_ef_lows_bytes(R.cnt) >> 2;
         if (word < LW) {
           val = 0;
 #pragma unroll
           for (uint32_t t = 0; t < 4; ++t)
-            if (4 * word + t < cnt) val |= (ent(4 * word + t) & 0xFFu) << (8 * t);
+            if (4 * word + t < R.cnt) val |= (R.entry(4 * word + t) & 0xFFu) << (8 * t);
         } else {
-          // upper word h: the entries with (E_j >> 8) + j in [32 h, 32 h + 32); (E_j >> 8) + j is strictly increasing
-          // and lies in [j, j + 255], so the first of them is found by bisection over [32 h - 255, 32 h]
-          const uint32_t h = word - LW, p0 = 32 * h;
-          uint32_t lo = p0 > 255 ? p0 - 255 : 0, hi = std::min(cnt, p0); // answer in [lo, hi]: first j with pos_j >= p0
-          while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((ent(mid) >> 8) + mid < p0) lo = mid + 1; else hi = mid;
-          }
-          val = 0;
-          for (uint32_t j = lo; j < cnt; ++j) {
-            const uint32_t pos = (ent(j) >> 8) + j;
-            if (pos >= p0 + 32) break;
-            val |= 1u << (pos - p0);
-          }
+          val = S.bitmap[(R.aux >> 16) + (word - LW)];
         }
       }
       stg<uint32_t>(out + 4 * (size_t)q, val);
@@ -656,7 +744,7 @@ static int launch_tab_c(const DecDesc *d, int count, int blocks_max, int tl_max,
 int launch_tab(const DecDesc *d_descs, int count, int blocks_max, int tl_max, int cap_e, int mode, bool clamped, bool f16,
                void *stream) {
   if (count <= 0 || blocks_max <= 0) return 0;
-  if (tl_max < 1 || tl_max > kTabMaxTl || cap_e < 2 || cap_e > 65536 || tab_smem_bytes(tl_max, cap_e) > 160 * 1024) return (int)hipErrorInvalidValue;
+  if (tl_max < 1 || tl_max > kTabMaxTl || cap_e < 32 || cap_e > 32768 || (cap_e & 31) || tab_smem_bytes(tl_max, cap_e) > 160 * 1024) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   if (f16) return clamped ? launch_tab_c<true, _Float16>(d_descs, count, blocks_max, tl_max, cap_e, mode, s)
                           : launch_tab_c<false, _Float16>(d_descs, count, blocks_max, tl_max, cap_e, mode, s);
