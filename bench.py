@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — the path's headline metric on MI355X (BASELINE.json: encode+decode Mpixels/s, Kodak, K=4 N=192).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process starts the N ranks itself)
 
 Workload (config.workload = "kodak24"): BASELINE.json configs[1] — 24 Kodak-sized images (768x512 ->
 y [1,192,32,48] -> two checkerboard halves [1,192,32,24] each), mixture parameters [1,768,32,24] x3 per half,
 synthetic and seeded (no Kodak files / checkpoint exist offline), resident in HBM before the
-timed region.  One STEP = one pass of the hot path over that batch:
-    GaussianMixtureConditional.compress  on all 48 halves   (quant_stats + symtab kernels, D2H tables, host rANS)
-    GaussianMixtureConditional.decompress on all 48 halves  (cdftab kernel, D2H tables, host rANS, H2D + scatter)
-value = pixels of all images of all ranks / wall time (Mpixels/s).  N > 1: one process per GPU, each rank codes its
-own 24 images (weak scaling); the only exchange is one RCCL all-gather of the per-stream byte lengths per step.
+timed region.  One STEP = one pass of the hot path over that batch, scheduled AS THE CODEC CAN schedule it:
+    encode  GaussianMixtureConditional.compress of all 48 halves in ONE native call — the encoder holds round(y) of the
+            anchors, which is all the non-anchor parameters depend on (checkerboard.py:282-288)
+    decode  GaussianMixtureConditional.decompress in TWO calls, the 24 anchor halves, then the 24 non-anchor halves: the
+            non-anchor parameters need the decoded anchors (checkerboard.py:316-324)
+(--workload elic4k: 5 channel groups x 2 halves; encode one call — every group's context is round(.) of data the
+encoder holds — decode ten sequential calls, channel_groups.py:147-154.)  The all-at-once schedule of round 1 (every
+stream of the batch in one decode call) is timed beside it and reported as `upper_bound`.
+value = pixels of all images of all ranks / wall time (Mpixels/s).  N > 1: one process per GPU, each rank codes its own
+24 images (weak scaling); the only exchange is one RCCL all-gather of the per-stream byte lengths per step.
 
 One JSON line is printed by rank 0; besides the driver's contract it carries
-  roofline      the symtab (encode-side GMM-CDF) kernel: algorithmic bytes (56 B/coded symbol) over
-                its launch duration measured here with HIP events on the stream it runs on, against 8 TB/s HBM
-  cpu_baseline  the REAL reference extension (oracle/_ref, built from /root/reference in the build container;
-                kind "reference"), or this repo's C restatement (kind "port"), timed on one host core of this box
-                on the same 24 images
+  roofline         the symtab (encode-side GMM-CDF) kernel: algorithmic bytes (56 B/coded symbol) over its
+                   launch duration measured here with HIP events on the stream it runs on, against 8 TB/s HBM
+  roofline_decode  the decode-side table kernel against both of its rooflines (VALU issue, HBM), edges per latent
+  cpu_baseline     the REAL reference extension (oracle/_ref, built from /root/reference in the build container; kind
+                   "reference"), or this repo's C restatement (kind "port"), timed on this box's host cores on the same
+                   images: one core (`value`), and every core this process may use, one stream per process (`all_cores`)
+  latency_ms       one image (two bitstreams), encode + decode, as the codec schedules it and all at once
+  upper_bound      the step with every stream in one decode call
+  ranks            per-rank step times and the all-gather's share (N > 1)
 """
 from __future__ import annotations
 
@@ -34,10 +43,25 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# algorithmic bytes per coded symbol of the symtab kernel: 4 (y) + 3*4*{4|2} (sigma, mu, pi) in + 4 out
-
+# VALU issue peak of the chip as scripts/valu_peak.hip measures it (profiles/r02_valu_peak.txt): a wave64 fp32 instruction
+# issues once per 4 cycles per SIMD: 256 CUs x 4 SIMDs x 64 lanes / 4 cycles x 2.4 GHz
+VALU_PEAK_LANE_SLOTS = 256 * 4 * 64 / 4 * 2.4e9
+# issue slots of the table kernel's evaluation loop per edge (ISA of tab_kernel<mode, clamped, f32>, the loop body of
+# phase 2 handles one PAIR of edges: plain VALU instructions count 1, packed ones 1.16, rsq / rcp 2)
+TAB_SLOTS_PER_EDGE = {"polya": (134 + 107 * 1.16 + 4) / 2, "as": (150 + 140 * 1.16 + 4) / 2, "logistic": (230 + 110 * 1.16 + 4) / 2}
 
 ELIC_GROUPS = (16, 16, 32, 64, 192)  # elic_gmm.py:92-96
+
+
+def workload_shapes(workload: str):
+    """-> (stream shapes of one image in coding order, pixels per image)"""
+    if workload == "kodak24":
+        return [(192, 32, 24)] * 2, 768 * 512
+    return [(g, 136, 120) for g in ELIC_GROUPS for _ in range(2)], 3840 * 2160
+
+
+def stream_seed(rank: int, image: int, stream: int, streams_per_image: int) -> int:
+    return 1000 * rank + image * streams_per_image + stream
 
 
 def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: bool = False):
@@ -47,15 +71,10 @@ def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: b
     from flashgmm_amd import testing as T
 
     host, devt = [], []
-    if workload == "kodak24":
-        shapes = [(192, 32, 24)] * 2
-        pix = 768 * 512
-    else:
-        shapes = [(g, 136, 120) for g in ELIC_GROUPS for _ in range(2)]
-        pix = 3840 * 2160
+    shapes, pix = workload_shapes(workload)
     for i in range(images):
         for j, (M, h, w) in enumerate(shapes):
-            y, sg, mu, pi = T.make_latent(1000 * rank + i * len(shapes) + j, M=M, h=h, w=w)  # sigma pre-clamped as KA-1
+            y, sg, mu, pi = T.make_latent(stream_seed(rank, i, j, len(shapes)), M=M, h=h, w=w)  # sigma pre-clamped as KA-1
             if f16:
                 sg, mu, pi = T.to_float16_planes(sg, mu, pi)
             host.append((y, sg, mu, pi))
@@ -63,85 +82,130 @@ def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: b
     return host, devt, pix
 
 
-def cpu_baseline(host, pix_per_image: int, streams_per_image: int, budget_s: float = 12.0):
-    """Time the reference's own coder on ONE core of this box on the same images (bounded sample)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's own coder (or the C restatement) on host cores of this box — test infrastructure, used
+# here only as the reported baseline
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_coder():
+    """-> (kind, prepare(host stream) -> state, code(state) -> (decoded symbols, expected symbols))"""
     from flashgmm_amd import testing as T
     from oracle import oracle as O
 
-    prepared = []
-    for y, sg, mu, pi in host:
-        sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, *(a.astype(np.float32) for a in (sg, mu, pi)))
-        prepared.append((sym, s, m, w, abs_max))
     kind = "port"
-    enc = dec = None
+    ans = None
     if O.ref_available():
         try:
             os.environ.pop("APPROX_MODE", None)
             ans = O.ref_ans()
             kind = "reference"
-            # the reference is handed (n,4) views with strides (1,n) (entropy_models.py:810-828)
-            tens = [(torch.from_numpy(sym), *(torch.from_numpy(np.ascontiguousarray(a.T)).T for a in (s, m, w)), am)
-                    for sym, s, m, w, am in prepared]
-
-            def enc(i):
-                sym, s, m, w, am = tens[i]
-                return ans.RansEncoder().encode_with_indexes_gmm(sym, s, m, w, am + 1)
-
-            def dec(i, b):
-                sym, s, m, w, am = tens[i]
-                return ans.RansDecoder().decode_with_indexes_gmm(b, s, m, w, am + 1).numpy()
         except Exception as e:  # pragma: no cover - e.g. ISA mismatch on an unexpected host
             print(f"[bench] reference extension unusable here ({e}); falling back to the C restatement", file=sys.stderr)
-            kind = "port"
-    if kind == "port":
-        def enc(i):
-            sym, s, m, w, am = prepared[i]
-            return O.encode_gmm(0, sym, s, m, w)
 
-        def dec(i, b):
-            sym, s, m, w, am = prepared[i]
-            return O.decode_gmm(0, b, s, m, w, am + 1)
+    def prepare(stream):
+        y, sg, mu, pi = stream
+        sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, *(a.astype(np.float32) for a in (sg, mu, pi)))
+        if kind == "reference":  # the reference is handed (n,4) views with strides (1,n) (entropy_models.py:810-828)
+            return (torch.from_numpy(sym), *(torch.from_numpy(np.ascontiguousarray(a.T)).T for a in (s, m, w)), abs_max, sym)
+        return (sym, s, m, w, abs_max, sym)
 
+    def code(st):
+        sym, s, m, w, am, want = st
+        if kind == "reference":
+            b = ans.RansEncoder().encode_with_indexes_gmm(sym, s, m, w, am + 1)
+            return ans.RansDecoder().decode_with_indexes_gmm(b, s, m, w, am + 1).numpy(), want
+        b = O.encode_gmm(0, sym, s, m, w)
+        return O.decode_gmm(0, b, s, m, w, am + 1), want
+
+    return kind, prepare, code
+
+
+def _all_cores_worker(args):
+    """one process of the all-cores baseline: its share of the streams, regenerated from their seeds; passes until the
+    budget is spent -> (streams coded, wall clock start, wall clock end)"""
+    seeds, shapes, f16, budget_s = args
+    from flashgmm_amd import testing as T
+
+    torch.set_num_threads(1)
+    kind, prepare, code = _cpu_coder()
+    states = []
+    for seed, (M, h, w) in zip(seeds, shapes):
+        y, sg, mu, pi = T.make_latent(seed, M=M, h=h, w=w)
+        if f16:
+            sg, mu, pi = T.to_float16_planes(sg, mu, pi)
+        states.append(prepare((y, sg, mu, pi)))
+    code(states[0])  # warm-up
+    done = 0
+    t0 = time.time()
+    while done == 0 or time.time() - t0 < budget_s:
+        for st in states:
+            code(st)
+            done += 1
+    return done, t0, time.time()
+
+
+def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank: int, f16: bool, budget_s: float = 10.0):
+    """Time the reference's own coder on this box: ONE core on the same images (bounded sample), then every core this
+    process may use, one stream at a time per process (the reference is single-threaded and holds the GIL)."""
+    kind, prepare, code = _cpu_coder()
+    prepared = [prepare(s) for s in host]
     torch.set_num_threads(1)
     best = None
     passes = 0
     t_start = time.perf_counter()
     while passes < 5 and (passes < 1 or time.perf_counter() - t_start < budget_s):
         t0 = time.perf_counter()
-        for i in range(len(prepared)):
-            b = enc(i)
-            d = dec(i, b)
+        for st in prepared:
+            got, want = code(st)
         dt = time.perf_counter() - t0
-        assert np.array_equal(d, prepared[-1][0])
+        assert np.array_equal(got, want)
         best = dt if best is None else min(best, dt)
         passes += 1
     n_img = len(prepared) // streams_per_image
-    n_sym = sum(len(p[0]) for p in prepared)
-    return {
+    n_sym = sum(len(p[-1]) for p in prepared)
+    out = {
         "value": round(n_img * pix_per_image / best / 1e6, 3),
         "unit": "Mpixels/s",
         "cores": 1,
         "kind": kind,
         "sample": f"{n_img} image(s) x {streams_per_image} streams ({n_sym} symbols), encode+decode, best of {passes} passes, "
                   f"{best * 1e3:.0f} ms/pass = {best / n_sym * 1e9:.0f} ns/symbol",
+        "ms_per_image": round(best / n_img * 1e3, 2),
     }
+    # all cores: processes, not threads; each regenerates its share of the streams from their seeds
+    try:
+        import multiprocessing as mp
+
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16, len(host)))
+        n_streams = len(host)
+        seeds = [stream_seed(rank, k // streams_per_image, k % streams_per_image, streams_per_image) for k in range(n_streams)]
+        shp = [shapes[k % streams_per_image] for k in range(n_streams)]
+        jobs = [(seeds[c::cores], shp[c::cores], f16, 6.0) for c in range(cores)]
+        with mp.get_context("spawn").Pool(cores) as pool:
+            res = pool.map(_all_cores_worker, jobs)
+        streams_done = sum(r[0] for r in res)
+        wall = max(r[2] for r in res) - min(r[1] for r in res)
+        out["all_cores"] = {"value": round(streams_done / streams_per_image * pix_per_image / wall / 1e6, 2), "unit": "Mpixels/s",
+                            "cores": cores, "sample": f"{cores} processes, one stream at a time each, {streams_done} streams in {wall:.1f} s"}
+    except Exception as e:  # pragma: no cover
+        out["all_cores"] = {"value": None, "error": str(e)[:200]}
+    return out
 
 
 def pmc_traffic(workload: str, mode: str, f16: bool):
     """roofline.traffic: HBM bytes per symtab launch from rocprofv3 PMC passes (scripts/collect_pmc.sh, committed under
     profiles/), gfx950-corrected as MI355X_MICROARCH.md prescribes.  PMC collection needs the profiler, so bench.py
-    reports the committed measurement of this same workload, or null when there is none."""
+    reports the committed measurement of this same workload (with the file it came from), or null when there is none."""
     if workload != "kodak24" or f16:
-        return None
-    best = None
+        return None, None
+    best = src = None
     for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_symtab.json"))):
         try:
             d = json.load(open(f))
             if d.get("workload") == workload and d.get("mode") == mode:
-                best = d["symtab"]["hbm_bytes_corrected"]
+                best, src = d["symtab"]["hbm_bytes_corrected"], os.path.relpath(f, ROOT)
         except Exception:
             pass
-    return best
+    return best, src
 
 
 def launch_ranks(a, argv):
@@ -217,12 +281,12 @@ def dryrun(a, world, rank):
         per_rank = [float(t) for t in gathered]
         dt = max(per_rank)
     if rank == 0:
-        emit(({"metric": "dryrun", "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
-                          "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dryrun-no-gpu",
-                          "config": {"workload": a.workload, "streams_per_gpu": n_streams},
-                          "ranks": {"backend": "gloo" if world > 1 else None, "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
-                                    "allgather_ms": round(float(np.mean(t_gather[-a.steps:])) * 1e3, 4)}}))
+        emit({"metric": "dryrun", "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
+              "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dryrun-no-gpu",
+              "config": {"workload": a.workload, "streams_per_gpu": n_streams},
+              "ranks": {"backend": "gloo" if world > 1 else None, "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
+                        "allgather_ms": round(float(np.mean(t_gather[-a.steps:])) * 1e3, 4)}})
     if world > 1:
         dist.destroy_process_group()
 
@@ -237,7 +301,10 @@ def main(argv=None):
     ap.add_argument("--images", type=int, default=None, help="images per GPU (default 24 for kodak24, 1 for elic4k)")
     ap.add_argument("--param-dtype", default=None, choices=["f32", "f16"], help="default f32 (kodak24) / f16 (elic4k)")
     ap.add_argument("--mode", default="polya", choices=["polya", "as", "logistic"])
+    ap.add_argument("--schedule", default="codec", choices=["codec", "all-at-once"],
+                    help="codec (default): decode stage by stage as the codec's dependencies demand; all-at-once: round 1's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip upper_bound / latency / per-thread legs (profiling runs)")
     a = ap.parse_args(argv)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -259,6 +326,7 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
 
@@ -267,7 +335,8 @@ def main(argv=None):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    coll_dev = dev if (dist and dist.get_backend() == "nccl") else torch.device("cpu")
+        backend = dist.get_backend()
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from flashgmm_amd import GaussianMixtureConditional, _lib
     from flashgmm_amd import parallel as P
@@ -277,44 +346,85 @@ def main(argv=None):
     if a.images is None:
         a.images = 24 if a.workload == "kodak24" else 1
     f16 = (a.param_dtype or ("f32" if a.workload == "kodak24" else "f16")) == "f16"
+    shapes1, _ = workload_shapes(a.workload)
     host, devt, pix_per_image = make_workload(rank, a.images, dev, a.workload, f16)
-    streams_per_image = len(devt) // a.images
+    spi = len(shapes1)  # streams per image = stages of the codec's decode schedule
     bytes_per_symbol = 32 if f16 else 56
-    ys = [t[0] for t in devt]
-    ss = [t[1] for t in devt]
-    ms = [t[2] for t in devt]
-    ws = [t[3] for t in devt]
-    shapes = sorted({tuple(y.shape) for y in ys})
-    n_streams = len(ys)
-    hw_of = [y.shape[2] * y.shape[3] for y in ys]
+    n_streams = len(devt)
+    hw_of = [t[0].shape[2] * t[0].shape[3] for t in devt]
+    shapes = sorted({tuple(t[0].shape) for t in devt})
     stacked = len(shapes) == 1
-    if stacked:  # items of one shape go in as ONE tensor each, [N, ., h, w]: what a network run on a batch produces
-        ys, ss, ms, ws = (torch.cat(t) for t in (ys, ss, ms, ws))
     gmc = GaussianMixtureConditional(K=4, mode=a.mode)
     _lib.set_profiling(local_rank, True)
 
-    k_sym, k_tab, k_fill, k_qs = [], [], [], []
+    # streams in coding order: image-major, stage-minor.  Stage s of the decode schedule = stream s of every image.
+    if stacked:  # items of one shape go in as ONE tensor each, [N, ., h, w]: what a network run on a batch produces
+        ys, ss, ms, ws = (torch.cat([t[k] for t in devt]) for k in range(4))
+    else:
+        ys, ss, ms, ws = ([t[k] for t in devt] for k in range(4))
+    stage_params = [(ss[s::spi], ms[s::spi], ws[s::spi]) for s in range(spi)]  # strided batch views / sub-lists
+    stage_idx = [list(range(s, n_streams, spi)) for s in range(spi)]
 
-    def step(record=False):
+    k_sym, k_tab, k_qs, t_gather, edges, tab_bytes = [], [], [], [], [], []
+
+    def decode_codec(res, record=False):
+        """stage by stage; every image's stream of a stage in one call"""
+        outs = [None] * n_streams
+        tk = eg = tb = 0.0
+        for s in range(spi):
+            idx = stage_idx[s]
+            sp, mp_, wp = stage_params[s]
+            o = gmc.decompress_batch([res[i][0][0] for i in idx], [res[i][0][1] for i in idx], [res[i][0][2] for i in idx], sp, mp_, wp)
+            for i, t in zip(idx, o):
+                outs[i] = t
+            if record:
+                tk += _lib.kernel_ms(local_rank, 1)
+                eg += _lib.ctx_stat(local_rank, 3)
+                tb += _lib.ctx_stat(local_rank, 1)
+        if record:
+            k_tab.append(tk), edges.append(eg), tab_bytes.append(tb)
+        return outs
+
+    def decode_all(res, record=False):
+        outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+        if record:
+            k_tab.append(_lib.kernel_ms(local_rank, 1)), edges.append(_lib.ctx_stat(local_rank, 3)), tab_bytes.append(_lib.ctx_stat(local_rank, 1))
+        return outs
+
+    def step(schedule, record=False):
         res = gmc.compress_batch(ys, ss, ms, ws)
         if record:
             k_sym.append(_lib.kernel_ms(local_rank, 0))
             k_qs.append(_lib.kernel_ms(local_rank, 2))
         if world > 1:  # the path's one exchange: per-stream bitstream lengths (SURVEY.md §8e), RCCL all-gather
+            t0 = time.perf_counter()
             P.all_gather_stream_lengths([len(r[0][0]) for r in res], len(res), device=coll_dev)
-        outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
-        if record:
-            k_tab.append(_lib.kernel_ms(local_rank, 1))
+            if record:
+                t_gather.append(time.perf_counter() - t0)
+        outs = decode_codec(res, record) if schedule == "codec" else decode_all(res, record)
         return res, outs
 
+    def timed(schedule, steps, record):
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(schedule, record=record)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        return time.perf_counter() - t0
+
     for _ in range(max(a.warmup, 1)):
-        res, outs = step()
+        res, outs = step(a.schedule)
     # correctness of what is being timed: decode(encode(y)) == round(y) for every stream of this rank
     for i in range(n_streams):
         y_i = ys[i:i + 1] if stacked else ys[i]
         assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(y_i)), f"stream {i} mismatch"
     n_coded = sum(int(r[0][2].sum()) * hw for r, hw in zip(res, hw_of))
     total_bytes = sum(len(r[0][0]) for r in res)
+    enc_table_bytes = _lib.ctx_stat(local_rank, 0)
 
     # a generational GC pass of the interpreter (tens of ms with torch loaded) is not part of the path
     import gc
@@ -322,27 +432,74 @@ def main(argv=None):
     gc.collect()
     gc.freeze()
     gc.disable()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(record=True)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(a.schedule, a.steps, record=True)
     gc.enable()
+    per_rank = [dt]
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        gathered = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        per_rank = [float(t.item()) for t in gathered]
+        dt = max(per_rank)
+
+    extras = {}
+    if not a.no_extras:
+        other = "all-at-once" if a.schedule == "codec" else "codec"
+        n_ub = max(3, min(a.steps, 10))
+        step(other)
+        gc.disable()
+        dt_o = timed(other, n_ub, record=False)
+        gc.enable()
+        if dist:
+            tt = torch.tensor([dt_o], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_o = float(tt.item())
+        extras["upper_bound" if other == "all-at-once" else "as_codec"] = {
+            "schedule": other, "value": round(world * a.images * pix_per_image * n_ub / dt_o / 1e6, 2), "unit": "Mpixels/s",
+            "ms_per_step": round(dt_o / n_ub * 1e3, 3), "steps": n_ub}
+        if rank == 0 and world == 1:
+            # latency of ONE image (its spi streams): encode in one call, decode stage by stage / in one call
+            def one_image(codec: bool):
+                y1 = ys[:spi]
+                p1 = [t[:spi] for t in (ss, ms, ws)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = gmc.compress_batch(y1, *p1)
+                if codec:
+                    for s in range(spi):
+                        gmc.decompress_batch([r[s][0][0]], [r[s][0][1]], [r[s][0][2]], *[t[s:s + 1] for t in p1])
+                else:
+                    gmc.decompress_batch([x[0][0] for x in r], [x[0][1] for x in r], [x[0][2] for x in r], *p1)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) * 1e3
+
+            reps = 30 if a.workload == "kodak24" else 3
+            for codec in (True, False):
+                one_image(codec)
+            extras["latency_ms"] = {"images": 1, "streams": spi,
+                                    "as_codec": round(float(np.median([one_image(True) for _ in range(reps)])), 3),
+                                    "all_at_once": round(float(np.median([one_image(False) for _ in range(reps)])), 3)}
+            # one host thread instead of the pool: what the GPU path is worth per host core
+            threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
+            _lib.set_threads(local_rank, 1)
+            step(a.schedule)
+            n1 = 3
+            gc.disable()
+            dt1 = timed(a.schedule, n1, record=False)
+            gc.enable()
+            extras["one_host_thread"] = {"value": round(a.images * pix_per_image * n1 / dt1 / 1e6, 2), "unit": "Mpixels/s",
+                                         "ms_per_step": round(dt1 / n1 * 1e3, 2), "host_threads": 1}
+            _lib.set_threads(local_rank, threads)
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * a.images * pix_per_image * a.steps / dt / 1e6
         sym_ms = float(np.mean(k_sym))
         achieved = n_coded * bytes_per_symbol / (sym_ms * 1e-3) / 1e9
+        tab_ms, n_edges, tbytes = float(np.mean(k_tab)), float(np.mean(edges)), float(np.mean(tab_bytes))
+        traffic, traffic_src = pmc_traffic(a.workload, a.mode, f16)
+        tab_alg_bytes = n_coded * (12 * (2 if f16 else 4)) + tbytes  # parameters in, headers + block offsets + rows out
+        slots = n_edges * TAB_SLOTS_PER_EDGE[a.mode]
         out = {
             # BASELINE.json's metric, verbatim: `value` is its Mpixels/s half, the `roofline` object its GMM-CDF HBM half
             "metric": "encode+decode Mpixels/s (Kodak, K=4 N=192) + GMM-CDF HBM GB/s vs roofline" if a.workload == "kodak24"
@@ -358,25 +515,49 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": "f32",  # the CDF arithmetic; parameter planes: config.param_dtype
             "data": "synthetic",
-            "config": {"workload": a.workload, "images_per_gpu": a.images, "streams_per_gpu": n_streams,
-                       "stream_shapes": shapes, "stacked_input": stacked, "K": 4, "approx_mode": a.mode,
+            "config": {"workload": a.workload, "schedule": a.schedule,
+                       "decode_calls_per_step": spi if a.schedule == "codec" else 1, "images_per_gpu": a.images,
+                       "streams_per_gpu": n_streams, "stream_shapes": shapes, "stacked_input": stacked, "K": 4, "approx_mode": a.mode,
                        "param_dtype": "f16" if f16 else "f32",
                        "coded_symbols_per_gpu": n_coded, "bitstream_bytes_per_gpu": total_bytes,
                        "host_threads_per_gpu": _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank)), "numa": numa,
                        "parallelism": f"images sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "symtab_kernel (encode-side GMM-CDF)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a.workload, a.mode, f16),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": round(sym_ms, 4), "bytes_per_launch": n_coded * bytes_per_symbol,
                          "bytes_per_symbol": bytes_per_symbol},
-            "kernels_ms": {"symtab": round(sym_ms, 4), "tab_kernels_all_launches": round(float(np.mean(k_tab)), 4), "quant_stats": round(float(np.mean(k_qs)), 4)},
+            # the decode-side table kernel against BOTH of its rooflines: VALU issue and HBM
+            "roofline_decode": {"kernel": "tab_kernel (decode-side edge tables, all launches of a step)", "bound": "valu",
+                                "ms_per_step": round(tab_ms, 4), "edges_evaluated": int(n_edges),
+                                "mean_edges_per_latent": round(n_edges / max(n_coded, 1), 2),
+                                "issue_slots_per_edge": round(TAB_SLOTS_PER_EDGE[a.mode], 1),
+                                "valu_achieved_Tslots": round(slots / (tab_ms * 1e-3) / 1e12, 2),
+                                "valu_peak_Tslots": round(VALU_PEAK_LANE_SLOTS / 1e12, 1),
+                                "valu_frac": round(slots / (tab_ms * 1e-3) / VALU_PEAK_LANE_SLOTS, 4),
+                                "hbm_bytes_algorithmic": int(tab_alg_bytes),
+                                "hbm_achieved": round(tab_alg_bytes / (tab_ms * 1e-3) / 1e9, 1),
+                                "hbm_frac": round(tab_alg_bytes / (tab_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "in situ: the launches share the GPU with the blit kernels of the table copies"},
+            "kernels_ms": {"symtab": round(sym_ms, 4), "tab_kernels_all_launches": round(tab_ms, 4),
+                           "quant_stats": round(float(np.mean(k_qs)), 4)},
             # what crosses PCIe per step and rank (the decode-side tables are the longest leg of a step)
-            "pcie": {"encode_tables_bytes": _lib.ctx_stat(local_rank, 0), "decode_tables_bytes": _lib.ctx_stat(local_rank, 1),
-                     "decode_table_bytes_per_latent": round(_lib.ctx_stat(local_rank, 1) / max(1, _lib.ctx_stat(local_rank, 2)), 2),
-                     "bitstream_bytes": total_bytes},
+            "pcie": {"encode_tables_bytes": enc_table_bytes, "decode_tables_bytes": int(tbytes),
+                     "decode_table_bytes_per_latent": round(tbytes / max(1, n_coded), 2), "bitstream_bytes": total_bytes},
+            "ranks": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+                      "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
+                      "allgather_ms": round(float(np.mean(t_gather)) * 1e3, 4) if t_gather else None},
         }
+        out.update(extras)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host, pix_per_image, streams_per_image)
+            cb = cpu_baseline(host, shapes1, pix_per_image, spi, rank, f16)
+            if "one_host_thread" in extras and cb.get("value"):
+                cb["per_thread_speedup"] = round(extras["one_host_thread"]["value"] / cb["value"], 1)
+            if cb.get("all_cores", {}).get("value"):
+                cb["speedup_vs_all_cores"] = round(value / cb["all_cores"]["value"], 1)
+            if "latency_ms" in out:
+                out["latency_ms"]["reference_cpu"] = cb["ms_per_image"]
+            out["cpu_baseline"] = cb
         emit(out)
     if dist:
         dist.destroy_process_group()

@@ -83,8 +83,8 @@ SIGNATURES = {
     "fgmm_selftest_fastmath": (_i, [_p, _i, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "fgmm_rans_encode_symtab": (_i, [_p, _p, _i64, _pp, _psz]),
     "fgmm_rans_encode_symtab2": (_i, [_p, _p, _i64, _p, _p, _i64, _pp, _psz, _pp, _psz]),
-    "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, C.c_uint64, _i64, _i32, _p]),
-    "fgmm_rans_decode_tab": (_i, [_p, _sz, _p, _i, _p, _i32, _p, C.c_uint64, _i64, _i32, _p]),
+    "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, C.c_uint64, _i64, _i32, _i, _p]),
+    "fgmm_rans_decode_tab": (_i, [_p, _sz, _p, _i, _p, _i32, _p, C.c_uint64, _i64, _i32, _i, _p]),
     "fgmm_build_tab_hip": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i32, _i, _p, _p, _p, C.c_uint64, _p, C.POINTER(_i32)]),
     "fgmm_ctx_set_option": (_i, [_p, C.c_char_p, _i64]),
     "fgmm_ctx_get_option": (_i, [_p, C.c_char_p, C.POINTER(_i64)]),

@@ -161,7 +161,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t tail_items = 8, tail_pieces = 4, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1;
+    int64_t tail_items = 8, tail_pieces = 4, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -539,6 +539,7 @@ struct DecItem {
   int64_t n = 0;
   size_t o_list = 0, o_rank = 0;
   int hdr_form = 4;
+  uint32_t ef_min = kTabEfMin;
   int32_t tl = 0;     // latents per block of the single-pass kernel; 0: generic two-pass path
   int64_t nblk = 0;   // blocks of tl latents
   uint64_t table_bytes = 0; // headers + block offsets + rows that crossed PCIe
@@ -597,6 +598,9 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   if ((rc = ctx->ensure_streams())) return rc;
   const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 32768) & ~31;
   const bool clamped = items[0].clamp != 0, f16 = items[0].prm.dtype == FGMM_F16;
+  // Elias-Fano rows are 30 % smaller than uint16 rows and 35 % slower to search: they pay when PCIe is the bottleneck of
+  // the call (at least as many bitstreams as host workers), not when it is bound by its few sequential decoders
+  const uint32_t ef_min = ctx->opt.ef_rows == 1 || (ctx->opt.ef_rows == 0 && count >= ctx->pool->size()) ? kTabEfMin : kTabNoEf;
 
   // ---- items: coded channels, header form, path --------------------------------------------------------------------
   Arena ar; // device workspace, mirrored in h_ws up to the counters
@@ -611,6 +615,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.o_list = ar.take(sizeof(int32_t) * std::max(it.n_ch, 1), 16);
     it.o_rank = ar.take(sizeof(int32_t) * std::max(it.M, 1), 16);
     it.hdr_form = tab_hdr_form(it.max_bs);
+    it.ef_min = ef_min;
     it.tl = tab_tl(it.max_bs, cap_e);
     it.nblk = it.tl ? (it.n + it.tl - 1) / it.tl : 0;
     if (it.nblk > 0x7FFFFFFFll) it.tl = 0, it.nblk = 0;
@@ -738,6 +743,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.clamp = it.clamp;
     d.prune = 1;
     d.hdr_form = it.hdr_form;
+    d.ef_min = ef_min;
     d.tl = it.tl;
     d.count_edges = ctx->profiling ? 1 : 0; // measurement aid only (bench.py's roofline_decode)
     return d;
@@ -815,7 +821,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         pit->status = FGMM_ERR_HIP;
       } else {
         pit->t_start = tr.ms();
-        const TabView tv{pit->hdr_form, pit->tl, pit->n_piece, pit->piece, pit, [](void *arg, int k) -> int {
+        const TabView tv{pit->ef_min, pit->hdr_form, pit->tl, pit->n_piece, pit->piece, pit, [](void *arg, int k) -> int {
                            return hipEventSynchronize(static_cast<DecItem *>(arg)->piece_ev[k]) == hipSuccess ? (int)FGMM_OK : (int)FGMM_ERR_HIP;
                          }};
         pit->status = rans_decode_tab(pit->enc, pit->enc_len, tv, pit->n, pit->max_bs, sym);
@@ -1034,6 +1040,7 @@ const OptName kOpts[] = {
     {"trace", &fgmm_ctx::Opts::trace, 0, 2, "FGMM_TRACE"},
     {"enc_vec", &fgmm_ctx::Opts::enc_vec, 0, 4, "FGMM_VEC"},
     {"enc_linear", &fgmm_ctx::Opts::enc_linear, 0, 1, nullptr},
+    {"ef_rows", &fgmm_ctx::Opts::ef_rows, 0, 2, "FGMM_EF_ROWS"},
 };
 } // namespace
 
@@ -1446,6 +1453,7 @@ int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, cons
   hd->prune = (flags & FGMM_TAB_NO_PRUNE) ? 0 : 1;
   hd->clamp = (flags & FGMM_TAB_CLAMP) ? 1 : 0;
   hd->hdr_form = 4;
+  hd->ef_min = (flags & FGMM_TAB_RAW_ROWS) ? kTabNoEf : kTabEfMin;
   hd->tiles = tiles;
   hd->hdr = hdr;
   hd->pool = pool;
@@ -1495,6 +1503,7 @@ int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const f
   hd->prune = (flags & FGMM_TAB_NO_PRUNE) ? 0 : 1;
   hd->clamp = (flags & FGMM_TAB_CLAMP) ? 1 : 0;
   hd->hdr_form = tab_hdr_form(max_bs);
+  hd->ef_min = (flags & FGMM_TAB_RAW_ROWS) ? kTabNoEf : kTabEfMin;
   hd->tl = tl;
   hd->blk_begin = 0;
   hd->blk_end = (int32_t)nblk;

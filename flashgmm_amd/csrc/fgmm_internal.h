@@ -45,6 +45,8 @@ struct DecDesc {
   int32_t clamp;
   int32_t prune;                 // 1: skip the saturated tails (exact, see tab_window); 0: evaluate all of F
   int32_t hdr_form;              // bytes per header as the host gets them: 2, 4 or 8 (format v4 below)
+  uint32_t ef_min;               // rows with at least this many entries are Elias-Fano coded (kTabEfMin / kTabNoEf)
+  int32_t pad0_;
   int32_t tl;                    // tab_kernel: latents per block (rows of a block are contiguous, blocks are placed by a cursor)
   // ---- tab_kernel (single pass): the blocks [blk_begin, blk_end) of this item, into one launch's range
   int32_t blk_begin, blk_end;
@@ -95,11 +97,14 @@ FGMM_HD static inline uint32_t tab_hdr_nonmono(uint32_t h) { return h >> 31; }
 FGMM_HD static inline unsigned long long tab_hdr8_pack(int32_t a, uint32_t cnt, uint32_t nonmono) {
   return (unsigned long long)(uint32_t)a | ((unsigned long long)((cnt & 0x7FFFFFFFu) | (nonmono << 31)) << 32);
 }
-FGMM_HD static inline bool tab_row_is_ef(uint32_t cnt, uint32_t nonmono) { return cnt >= kTabEfMin && !nonmono; }
+// ef_min: rows with at least this many entries are Elias-Fano coded; kTabEfMin when PCIe is the bottleneck, kTabNoEf (no
+// such row) when a call is bound by its host decoders: a uint16 row is searched faster, an Elias-Fano row is smaller
+constexpr uint32_t kTabNoEf = 0x7FFFFFFFu;
+FGMM_HD static inline bool tab_row_is_ef(uint32_t cnt, uint32_t nonmono, uint32_t ef_min) { return cnt >= ef_min && !nonmono; }
 FGMM_HD static inline uint32_t tab_ef_lows_bytes(uint32_t cnt) { return (cnt + 3u) & ~3u; }
 FGMM_HD static inline uint32_t tab_ef_words(uint32_t cnt) { return (cnt + 256u + 31u) >> 5; }
-FGMM_HD static inline unsigned long long tab_row_bytes(uint32_t cnt, uint32_t nonmono) {
-  return tab_row_is_ef(cnt, nonmono) ? (unsigned long long)tab_ef_lows_bytes(cnt) + 4ull * tab_ef_words(cnt)
+FGMM_HD static inline unsigned long long tab_row_bytes(uint32_t cnt, uint32_t nonmono, uint32_t ef_min) {
+  return tab_row_is_ef(cnt, nonmono, ef_min) ? (unsigned long long)tab_ef_lows_bytes(cnt) + 4ull * tab_ef_words(cnt)
                                      : 2ull * (((unsigned long long)cnt + 1u) & ~1ull);
 }
 FGMM_HD static inline bool tab_hdr_fits16(int32_t max_bs) { return 2 * (int64_t)max_bs + 2 <= 254; }
@@ -161,6 +166,7 @@ struct TabPiece {
   int64_t end;             // one past the piece's last latent
 };
 struct TabView {
+  uint32_t ef_min; // as the kernels were told (DecDesc::ef_min)
   int hdr_form; // 2, 4, 8
   int tl;       // latents per block (blk_off granularity); ignored when blk_off is null
   int npiece;

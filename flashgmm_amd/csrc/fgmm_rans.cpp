@@ -264,7 +264,9 @@ inline int32_t bisect_reference(const Row &r, uint32_t cum_freq, int32_t max_bs,
   return mid;
 }
 
-// first index j in [0, cnt) with row[j] > cf, or cnt; row is non-decreasing; reads up to 30 bytes past the row
+// first index j in [0, cnt) with row[j] > cf, or cnt; row is non-decreasing; reads up to 30 bytes past the row.
+// One vector at a time with an early exit: measured faster than four vectors at a time without a data-dependent branch
+// (the compares of the vectors are independent and run ahead anyway; rounds 1 and 2, scripts/host_bench.py).
 __attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *row, int32_t cnt, uint32_t cf) {
   const __m256i bias = _mm256_set1_epi16((short)0x8000);
   const __m256i key = _mm256_set1_epi16((short)(cf ^ 0x8000u));
@@ -485,8 +487,8 @@ int rans_decode_tab(const uint8_t *enc, size_t enc_len, const TabView &tv, int64
         }
         // a row covers indices [a + max_bs, a + max_bs + cnt) of the W-entry virtual table
         if (__builtin_expect(cnt < 1 || a < -(int64_t)max_bs || a + max_bs + cnt > W, 0)) { rc = FGMM_ERR_INVALID; break; }
-        const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono);
-        const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono);
+        const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono, tv.ef_min);
+        const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, tv.ef_min);
         if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; break; }
         const bool zero_before = a > -(int64_t)max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
         const uint8_t *row_bytes = rowp;
@@ -789,22 +791,23 @@ int fgmm_rans_encode_symtab2(const uint32_t *packed0, const int32_t *symbols0_or
 }
 
 int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const uint32_t *hdr, const uint8_t *pool,
-                            uint64_t pool_len, int64_t n, int32_t max_bs, int32_t *out_symbols) {
+                            uint64_t pool_len, int64_t n, int32_t max_bs, int flags, int32_t *out_symbols) {
   if (n > 0 && (!hdr || !pool)) return FGMM_ERR_INVALID;
   if (max_bs < 0 || max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_UNSUPPORTED; // this entry point takes 4-byte headers
   const fgmm::TabPiece pc{hdr, nullptr, pool, (size_t)pool_len, n};
-  const fgmm::TabView tv{4, 0, 1, &pc, nullptr, nullptr};
+  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, 4, 0, 1, &pc, nullptr, nullptr};
   return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
 }
 
 int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void *hdr, int hdr_form, const uint32_t *blk_off,
-                         int32_t tl, const uint8_t *rows, uint64_t rows_len, int64_t n, int32_t max_bs, int32_t *out_symbols) {
+                         int32_t tl, const uint8_t *rows, uint64_t rows_len, int64_t n, int32_t max_bs, int flags,
+                         int32_t *out_symbols) {
   if (n > 0 && (!hdr || !rows)) return FGMM_ERR_INVALID;
   if (max_bs < 0 || max_bs > FGMM_MAX_BS || (blk_off && tl < 1)) return FGMM_ERR_INVALID;
   if (hdr_form == 2 && !fgmm::tab_hdr_fits16(max_bs)) return FGMM_ERR_INVALID;
   if (hdr_form == 4 && max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_INVALID;
   const fgmm::TabPiece pc{hdr, blk_off, rows, (size_t)rows_len, n};
-  const fgmm::TabView tv{hdr_form, tl, 1, &pc, nullptr, nullptr};
+  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, hdr_form, tl, 1, &pc, nullptr, nullptr};
   return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
 }
 

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__r
   }
   __shared__ uint32_t s_tmp[kBlock / 64];
   // a block holds < 2^31 bytes of rows: 256 rows of at most 2 * (2^20 + 2) bytes
-  const uint32_t total = block_reduce_add(active ? (uint32_t)tab_row_bytes(cnt, nm) : 0u, s_tmp);
+  const uint32_t total = block_reduce_add(active ? (uint32_t)tab_row_bytes(cnt, nm, d.ef_min) : 0u, s_tmp);
   const int any_nonmono = __syncthreads_or(active && ts.nonmono);
   const int any_long = __syncthreads_or(too_long);
   if (threadIdx.x == 0) {
@@ -253,13 +253,13 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
       nonmono = tab_hdr_nonmono(h);
     }
   }
-  const uint32_t bytes = active ? (uint32_t)tab_row_bytes(cnt, nonmono) : 0u;
+  const uint32_t bytes = active ? (uint32_t)tab_row_bytes(cnt, nonmono, d.ef_min) : 0u;
   __shared__ uint32_t s_tmp[kBlock / 64];
   const uint32_t ex = block_scan_excl(bytes, s_tmp);
   if (!active) return;
   uint8_t *__restrict__ row = d.pool + d.blk_off[(int64_t)cj * d.tiles + blockIdx.x] + ex; // 4-byte aligned
 
-  if (!tab_row_is_ef(cnt, nonmono)) {
+  if (!tab_row_is_ef(cnt, nonmono, d.ef_min)) {
     // raw: uint16 entries, padded to an even count with the last value
     const uint32_t len2 = (cnt + 1u) & ~1u;
     for (uint32_t j0 = 0; j0 < len2; j0 += 2) {
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     const uint32_t nm = ts.nonmono ? 1u : 0u;
     S.meta[tid] = (uint32_t)a_idx | (cnt << 16);
     if (nm) S.flags[tid] |= 2;
-    bytes = (uint32_t)tab_row_bytes(cnt, nm);
+    bytes = (uint32_t)tab_row_bytes(cnt, nm, d.ef_min);
     const int64_t li = (int64_t)(b - d.blk_begin) * tl + tid; // latent index within this launch's header array
     if (d.hdr_form == 2) {
       const uint32_t c8 = nm ? kHdr2Escape : cnt; // W <= 254 here, so cnt <= 254
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   uint32_t ef_pack = 0;
   if (tid < nl) {
     const uint32_t cnt = S.meta[tid] >> 16, nm = (S.flags[tid] >> 1) & 1u;
-    if (tab_row_is_ef(cnt, nm)) ef_pack = cnt | (tab_ef_words(cnt) << 16); // both sums stay below 2^16 (cap_e <= 32768)
+    if (tab_row_is_ef(cnt, nm, d.ef_min)) ef_pack = cnt | (tab_ef_words(cnt) << 16); // both sums stay below 2^16 (cap_e <= 32768)
   }
   const uint32_t exEF = tab_scan(ef_pack, S.scratch, &EFT);
   if (tid < nl) {
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       const bool escaped = d.hdr_form == 2 && R.nm;
       if (escaped && word == 0) {
         val = tab_hdr_pack(R.a_idx - max_bs, R.cnt, 1u);
-      } else if (!tab_row_is_ef(R.cnt, R.nm)) {
+      } else if (!tab_row_is_ef(R.cnt, R.nm, d.ef_min)) {
         if (escaped) --word;
         const uint32_t k0 = 2 * word, e0 = R.entry(k0);
         val = e0 | ((k0 + 1 < R.cnt ? R.entry(k0 + 1) : e0) << 16);

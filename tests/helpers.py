@@ -163,13 +163,17 @@ def host_encode_symtab(lib, packed: np.ndarray, symbols) -> bytes:
     return data
 
 
+def _flags():
+    return 4 if EF_MIN > 65536 else 0  # FGMM_TAB_RAW_ROWS when the tables were built without Elias-Fano rows
+
+
 def host_decode_cdftab(lib, enc: bytes, hdr: np.ndarray, pool: np.ndarray, max_bs: int, pool_len=None):
     """the public 4-byte-header / sequential-rows entry point"""
     hdr = np.ascontiguousarray(hdr, np.uint32)
     pool = np.ascontiguousarray(np.asarray(pool).view(np.uint8))
     out = np.empty(len(hdr), np.int32)
     rc = lib.fgmm_rans_decode_cdftab(enc, len(enc), hdr.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p),
-                                     len(pool) if pool_len is None else pool_len, len(hdr), max_bs, out.ctypes.data_as(C.c_void_p))
+                                     len(pool) if pool_len is None else pool_len, len(hdr), max_bs, _flags(), out.ctypes.data_as(C.c_void_p))
     return rc, out
 
 
@@ -184,5 +188,5 @@ def host_decode_tab(lib, enc: bytes, hdr: np.ndarray, pool: np.ndarray, max_bs: 
         bo = blk_off.ctypes.data_as(C.c_void_p)
     rc = lib.fgmm_rans_decode_tab(enc, len(enc), hdr.ctypes.data_as(C.c_void_p), hdr.dtype.itemsize, bo, tl,
                                   pool.ctypes.data_as(C.c_void_p), len(pool) if pool_len is None else pool_len, len(hdr), max_bs,
-                                  out.ctypes.data_as(C.c_void_p))
+                                  _flags(), out.ctypes.data_as(C.c_void_p))
     return rc, out

@@ -305,6 +305,16 @@ def test_single_pass_kernel_sizes_and_edge_cases(oracle, mode):
             want = oracle.cdftab(mode, sgc, mu, pi, max_bs)
             h, bo, rows, used, tl = gpu_tab(mode, sg, mu, pi, max_bs, flags)
             assert np.array_equal(expand_trimmed(h, rows, max_bs, bo, tl), want), (n, max_bs, flags)
+            import helpers
+            saved = helpers.EF_MIN
+            try:  # FGMM_TAB_RAW_ROWS: every row as uint16 entries
+                helpers.EF_MIN = 1 << 30
+                hr, bor, rr, ur, tlr = gpu_tab(mode, sg, mu, pi, max_bs, flags | 4)
+                assert np.array_equal(expand_trimmed(hr, rr, max_bs, bor, tlr), want) and ur >= used
+                hq, pq, uq = gpu_cdftab(mode, sg, mu, pi, max_bs, flags | 4)
+                assert np.array_equal(expand_trimmed(hq, pq, max_bs), want)
+            finally:
+                helpers.EF_MIN = saved
             hg, pg, ug = gpu_cdftab(mode, sg, mu, pi, max_bs, flags)
             assert used - ug == 4 * int(((h >> 8) == 255).sum() if h.dtype == np.uint16 else 0), (n, max_bs, flags)
     with pytest.raises(RuntimeError, match="UNSUPPORTED"):  # 2*max_bs+2 beyond the kernel's LDS budget: the generic path's
@@ -605,6 +615,7 @@ def test_decode_paths_agree(ctx_options, mode):
         return _lib.ctx_stat(0, 1)
 
     _lib.set_profiling(0, True)  # the kernels count the edges they evaluate only for a profiling caller
+    ctx_options(ef_rows=1)
     bytes_a = check("worst case")
     ctx_options(stage_max_mb=1)
     _lib.trim(0)
@@ -614,7 +625,11 @@ def test_decode_paths_agree(ctx_options, mode):
     check("largest blocks")
     ctx_options(tab_cap_e=16 * (2 * max(r[0][1] + 1 for r in res) + 2))
     check("16-latent blocks")
-    ctx_options(tab_cap_e=256)
+    ctx_options(ef_rows=1)
+    bytes_ef = check("Elias-Fano rows")
+    ctx_options(ef_rows=2)
+    assert check("uint16 rows only") > 1.15 * bytes_ef
+    ctx_options(ef_rows=0, tab_cap_e=256)
     assert _lib.ctx_stat(0, 3) > 0
     check("generic kernels")
     assert _lib.ctx_stat(0, 3) == 0  # the generic path does not count its edges: proof that it ran

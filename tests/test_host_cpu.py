@@ -273,6 +273,27 @@ def test_host_decoder_header_forms_and_block_placement(oracle, max_bs, tl):
     assert rc == 0 and np.array_equal(out, want)
 
 
+def test_host_decoder_raw_rows_only(oracle, monkeypatch):
+    """FGMM_TAB_RAW_ROWS: tables without Elias-Fano rows (what a host-bound call ships) decode to the same symbols"""
+    import helpers
+
+    L = _lib.lib()
+    rng = np.random.default_rng(12)
+    n, max_bs = 2000, 99
+    tab = np.sort(rng.integers(0, 65536, (n, 2 * max_bs + 2)), axis=1).astype(np.uint16)
+    enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+    want = oracle.rans_decode_cdftab(enc, tab, max_bs)
+    hdr_e, bo_e, pool_e, used_e = trim_full_table(tab, max_bs, form=2, tl=48, shuffle_seed=5)
+    monkeypatch.setattr(helpers, "EF_MIN", 1 << 30)
+    hdr_r, bo_r, pool_r, used_r = trim_full_table(tab, max_bs, form=2, tl=48, shuffle_seed=5)
+    assert used_r > 1.2 * used_e and np.array_equal(expand_trimmed(hdr_r, pool_r, max_bs, bo_r, 48), tab)
+    rc, out = host_decode_tab(L, enc, hdr_r, pool_r, max_bs, bo_r, 48)
+    assert rc == 0 and np.array_equal(out, want)
+    hdr4, pool4, _ = trim_full_table(tab, max_bs)
+    rc, out = host_decode_cdftab(L, enc, hdr4, pool4, max_bs)
+    assert rc == 0 and np.array_equal(out, want)
+
+
 def test_host_decoder_rejects_malformed_tables(oracle):
     """memory safety does not depend on the table being well-formed (include/flashgmm_amd.h): cnt = 0, a window outside the
     half-width, rows past the pool, inconsistent Elias-Fano rows -> FGMM_ERR_INVALID (1), never a wild read"""
