@@ -27,7 +27,7 @@ from torch import Tensor
 
 from . import _lib
 
-__all__ = ["GaussianMixtureConditional"]
+__all__ = ["GaussianMixtureConditional", "EntropyBottleneckCoder"]
 
 
 def _plane_view(t: Tensor, K: int) -> Tuple[Tensor, int, int]:
@@ -291,3 +291,77 @@ class GaussianMixtureConditional(nn.Module):
                    weights: Tensor) -> Tensor:
         """-> y_hat [1, M, h, w] float32     (entropy_models.py:872-910)"""
         return self.decompress_batch([strings], [abs_max], [zero_bitmap], [scales], [means], [weights])[0]
+
+
+class EntropyBottleneckCoder(nn.Module):
+    """The coding half of the reference's ``EntropyBottleneck`` (compressai/entropy_models/entropy_models.py:605-618 over
+    ``EntropyModel.compress / decompress``, :237-327) for the `z` hyper-latent, given the tables its ``update()`` built:
+
+        coder = EntropyBottleneckCoder.from_entropy_bottleneck(eb)      # any object with the reference's buffers
+        strings = coder.compress(z)                                     # list of bytes, one per batch element
+        z_hat = coder.decompress(strings, z.shape[-2:])                 # [N, C, h, w] on the tables' device
+
+    Same bytes as the reference for the same tables and the same ``z`` (golden G5 / G8); what differs is the plumbing:
+    the reference turns the symbol tensor, the index tensor AND the whole CDF matrix into Python lists on every call
+    (:257-266); here the tables are converted once, the symbols cross as one int32 copy, and the indexes (channel of
+    every element, ``_build_indexes`` :555-566) are built once per shape.  Integer work on the host, as the reference's;
+    the learned density model behind the tables (``_likelihood``, ``update()``) stays the caller's (stock CompressAI)."""
+
+    def __init__(self, quantized_cdf: Tensor, cdf_length: Tensor, offset: Tensor, medians: Tensor):
+        super().__init__()
+        from .ans import _Tables
+
+        if quantized_cdf.dim() != 2 or cdf_length.dim() != 1 or offset.dim() != 1:
+            raise ValueError("expected _quantized_cdf [C, L], _cdf_length [C], _offset [C] (run update() first)")
+        self.channels = int(quantized_cdf.size(0))
+        if cdf_length.numel() != self.channels or offset.numel() != self.channels or medians.numel() != self.channels:
+            raise ValueError("tables and medians must describe the same number of channels")
+        self._tables = _Tables(quantized_cdf.detach().cpu().numpy(), cdf_length.detach().cpu().numpy(), offset.detach().cpu().numpy())
+        self.register_buffer("medians", medians.detach().reshape(-1).to(torch.float32).clone())
+        self._index_cache = {}
+
+    @classmethod
+    def from_entropy_bottleneck(cls, eb) -> "EntropyBottleneckCoder":
+        """``eb``: the reference's (or stock CompressAI's) ``EntropyBottleneck`` after ``update()``"""
+        return cls(eb._quantized_cdf, eb._cdf_length, eb._offset, eb.quantiles[:, 0, 1])
+
+    def _indexes(self, spatial: int) -> np.ndarray:
+        idx = self._index_cache.get(spatial)
+        if idx is None:
+            idx = np.repeat(np.arange(self.channels, dtype=np.int32), spatial)
+            self._index_cache[spatial] = idx
+        return idx
+
+    def compress(self, x: Tensor) -> List[bytes]:
+        if x.dim() < 2 or x.size(1) != self.channels:
+            raise ValueError(f"expected [N, {self.channels}, ...], got {tuple(x.shape)}")
+        med = self.medians.to(x.device).reshape(1, -1, *([1] * (x.dim() - 2)))
+        # quantize(inputs, "symbols", means): round(x - means).int()  (:158-176) — on the tensor's device, ONE copy out
+        sym = torch.round(x - med).to(torch.int32).reshape(x.size(0), -1).cpu().numpy()
+        idx = self._indexes(sym.shape[1] // self.channels)
+        L = _lib.lib()
+        out = []
+        for i in range(sym.shape[0]):
+            row = np.ascontiguousarray(sym[i])
+            o, n = C.c_void_p(), C.c_size_t()
+            _lib.check(L.fgmm_encode_with_indexes(row.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), row.size,
+                                                  *self._tables.args(), C.byref(o), C.byref(n)), "EntropyBottleneck.compress")
+            out.append(_lib.take_bytes(o, n.value))
+        return out
+
+    def decompress(self, strings: Sequence[bytes], size) -> Tensor:
+        if not isinstance(strings, (tuple, list)):
+            raise ValueError("Invalid `strings` parameter type.")
+        size = tuple(int(v) for v in size)
+        spatial = int(np.prod(size)) if size else 1
+        idx = self._indexes(spatial)
+        L = _lib.lib()
+        sym = np.empty((len(strings), idx.size), np.int32)
+        for i, sdata in enumerate(strings):
+            sdata = bytes(sdata)
+            _lib.check(L.fgmm_decode_with_indexes(sdata, len(sdata), idx.ctypes.data_as(C.c_void_p), idx.size, *self._tables.args(),
+                                                  sym[i].ctypes.data_as(C.c_void_p)), "EntropyBottleneck.decompress")
+        dev = self.medians.device
+        med = self.medians.reshape(1, -1, *([1] * len(size)))
+        # dequantize(outputs, means): outputs.type_as(means) + means  (:197-204)
+        return torch.from_numpy(sym).to(dev).reshape(len(strings), self.channels, *size).to(torch.float32) + med

@@ -33,14 +33,19 @@ from itertools import accumulate
 from .entropy_models import GaussianMixtureConditional
 from .ops import ckbd_embed, ckbd_unembed
 
-__all__ = ["GaussianMixtureConditionalLatentCodec", "CheckerboardLatentCodec", "ChannelGroupsLatentCodec"]
+__all__ = ["GaussianMixtureConditionalLatentCodec", "CheckerboardLatentCodec", "ChannelGroupsLatentCodec", "HyperLatentCodec",
+           "HyperpriorLatentCodec"]
 
 
 class GaussianMixtureConditionalLatentCodec(nn.Module):
     def __init__(self, K: int = 4, gaussian_mixture_conditional: Optional[GaussianMixtureConditional] = None,
                  entropy_parameters: Optional[nn.Module] = None, quantizer: str = "noise",
-                 chunks: Tuple[str, ...] = ("scales", "means", "weights"), mode=None, **kwargs: Any):
+                 chunks: Tuple[str, ...] = ("scales", "means", "weights"), mode=None, param_dtype: torch.dtype = torch.float32,
+                 **kwargs: Any):
         super().__init__()
+        if param_dtype not in (torch.float32, torch.float16):
+            raise ValueError("param_dtype must be torch.float32 or torch.float16")
+        self.param_dtype = param_dtype  # float16: BASELINE configs[4], "fp16 (mu, sigma, pi) with fp32 CDF accumulate"
         if quantizer not in ("noise", "weighted_mean_ste"):
             raise ValueError(f"quantizer {quantizer} not supported")
         if tuple(chunks) != ("scales", "means", "weights"):
@@ -67,6 +72,16 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
         scales_hat, means_hat, weights = self._chunk(self.entropy_parameters(ctx_params))
         return scales_hat, means_hat, self._reshape_gmm_weight(weights)
 
+    def _planes(self, scales: Tensor, means: Tensor, weights: Tensor):
+        """the planes as the entropy model gets them: float32 as they are, or float16 copies — weights rounded TOWARD ZERO,
+        because the algorithm needs sum_k pi_k <= 1 after widening (flashgmm_amd.testing.to_float16_planes)"""
+        if self.param_dtype == torch.float32:
+            return scales, means, weights
+        w16 = weights.to(torch.float16)
+        over = w16.to(torch.float32) > weights
+        w16 = torch.where(over, torch.nextafter(w16, torch.zeros_like(w16)), w16)
+        return scales.to(torch.float16), means.to(torch.float16), w16
+
     def _recentre(self, means_hat: Tensor, weights: Tensor):
         """weighted_mean_ste: sum_k pi_k mu_k and the means relative to it (:139-144)"""
         B, KM, H, W = means_hat.shape
@@ -80,12 +95,12 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
         the ``y_hat`` that ``compress`` returns (:127-149) — known before any coding happens."""
         scales_hat, means_hat, weights = self._params(ctx_params)
         if self.quantizer == "noise":
-            return y, scales_hat, means_hat, weights
+            return (y, *self._planes(scales_hat, means_hat, weights))
         weighted_sum, means_rel = self._recentre(means_hat, weights)
         d = y - weighted_sum
         # quantize_ste (compressai/ops/ops.py:66-80) is (round(d) - d) + d: the value of round(d), but +0.0 where
         # round(d) is -0.0 — kept, so that the returned y_hat has the reference's bits
-        return (torch.round(d) - d) + d, scales_hat, means_rel, weights
+        return ((torch.round(d) - d) + d, *self._planes(scales_hat, means_rel, weights))
 
     def compress(self, y: Tensor, ctx_params: Tensor) -> Dict[str, Any]:
         y_code, scales_hat, means_hat, weights = self.coder_inputs(y, ctx_params)
@@ -103,10 +118,10 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
         (y_strings,) = strings
         scales_hat, means_hat, weights = self._params(ctx_params)
         if self.quantizer == "noise":
-            y_hat = self.gaussian_mixture_conditional.decompress(*y_strings, scales_hat, means_hat, weights)
+            y_hat = self.gaussian_mixture_conditional.decompress(*y_strings, *self._planes(scales_hat, means_hat, weights))
         else:
             weighted_sum, means_rel = self._recentre(means_hat, weights)
-            y_hat = self.gaussian_mixture_conditional.decompress(*y_strings, scales_hat, means_rel, weights) + weighted_sum
+            y_hat = self.gaussian_mixture_conditional.decompress(*y_strings, *self._planes(scales_hat, means_rel, weights)) + weighted_sum
         assert tuple(y_hat.shape[2:4]) == tuple(shape)
         return {"y_hat": y_hat}
 
@@ -154,7 +169,10 @@ class CheckerboardLatentCodec(nn.Module):
         y_ctx_i = self.unembed(self.context_prediction(self.embed(y_hat_)))[i]
         return torch.zeros_like(y_ctx_i) if i == 0 else y_ctx_i  # _mask(., "all") for the anchors
 
-    def compress(self, y: Tensor, side_params: Tensor) -> Dict[str, Any]:
+    def prepare(self, y: Tensor, side_params: Tensor):
+        """Everything of ``compress`` that is not coding: -> (coder inputs of the two halves, y_hat).  The reconstruction
+        a half's parameters depend on is ``round(.)`` of data the encoder holds (checkerboard.py:282-288), so the coder
+        inputs of BOTH halves — and ``y_hat`` — exist before a single symbol is coded."""
         n, c, h, w = y.shape
         if n != 1:
             raise RuntimeError("batch size 1 (as the reference's coder path, checkerboard.py:307)")
@@ -166,13 +184,16 @@ class CheckerboardLatentCodec(nn.Module):
         for i in range(2):
             params_i = self.entropy_parameters(self.merge(self._ctx(y_hat_, i), side_params_[i]))
             prepared.append(codec.coder_inputs(y_[i], params_i))
-            if i == 0:  # what compress() of the anchors will return as y_hat: no need to wait for their bitstream
-                y_hat_[0] = torch.round(prepared[0][0])
-        outs = codec.compress_many(prepared)
-        y_hat_[1] = outs[1]["y_hat"]
-        y_strings_ = [o["strings"][0] for o in outs]
-        y_hat = self.embed(y_hat_)
-        return {"strings": y_strings_, "shape": y_hat.shape[1:], "y_hat": y_hat}
+            y_hat_[i] = torch.round(prepared[i][0])  # what compress() of this half returns as y_hat
+        return prepared, self.embed(y_hat_)
+
+    def finish(self, outs: List[Dict[str, Any]], y_hat: Tensor) -> Dict[str, Any]:
+        """the two halves' coding results (``codec.compress_many``) -> the codec's result"""
+        return {"strings": [o["strings"][0] for o in outs], "shape": y_hat.shape[1:], "y_hat": y_hat}
+
+    def compress(self, y: Tensor, side_params: Tensor) -> Dict[str, Any]:
+        prepared, y_hat = self.prepare(y, side_params)
+        return self.finish(self.latent_codec["y"].compress_many(prepared), y_hat)
 
     def decompress(self, strings: List[Any], shape: Tuple[int, ...], side_params: Tensor, **kwargs: Any) -> Dict[str, Any]:
         n = 1
@@ -228,10 +249,39 @@ class ChannelGroupsLatentCodec(nn.Module):
             results.append(res)
         return results
 
+    @staticmethod
+    def _one_call(codecs) -> bool:
+        """can all groups be coded in one batched call?  (group codecs that can prepare, one Phi approximation, one clamp
+        setting and one parameter dtype: what a batch of the entropy model must share)"""
+        try:
+            keys = {(c.latent_codec["y"].gaussian_mixture_conditional._mode(), c.latent_codec["y"].gaussian_mixture_conditional.clamp_scales,
+                     c.latent_codec["y"].param_dtype) for c in codecs if hasattr(c, "prepare") and hasattr(c, "finish")}
+        except (AttributeError, KeyError, TypeError):
+            return False
+        return len(keys) == 1 and all(hasattr(c, "prepare") for c in codecs)
+
     def compress(self, y: Tensor, side_params: Tensor) -> Dict[str, Any]:
         parts = torch.split(y, self.groups, dim=1)
         y_hat = torch.zeros_like(y)
-        results = self._run(y_hat, side_params, lambda k, params: self.latent_codec[f"y{k}"].compress(parts[k], params))
+        codecs = [self.latent_codec[f"y{k}"] for k in range(len(self.groups))]
+        if self._one_call(codecs):
+            # Every group's context is round(.) of data the encoder holds (channel_groups.py:117-120 hands over y_hat of
+            # the groups before; on the encoder that is known without coding them), so the groups are PREPARED in order
+            # and all their bitstreams are coded in ONE batched native call: ten host coders side by side, not ten calls.
+            views = y_hat.split(self.groups, dim=1)
+            prepared, hats = [], []
+            for k, c in enumerate(codecs):
+                pk, hk = c.prepare(parts[k], self._get_ctx_params(k, side_params, views))
+                views[k].copy_(hk)
+                prepared.append(pk)
+                hats.append(hk)
+            outs = codecs[0].latent_codec["y"].compress_many([p for pk in prepared for p in pk])
+            results, at = [], 0
+            for c, pk, hk in zip(codecs, prepared, hats):
+                results.append(c.finish(outs[at:at + len(pk)], hk))
+                at += len(pk)
+        else:
+            results = self._run(y_hat, side_params, lambda k, params: self.latent_codec[f"y{k}"].compress(parts[k], params))
         per_group = {len(r["strings"]) for r in results}
         if len(per_group) != 1:
             raise RuntimeError("every group codec must emit the same number of strings (channel_groups.py:124)")
@@ -246,4 +296,67 @@ class ChannelGroupsLatentCodec(nn.Module):
         return {"y_hat": y_hat}
 
     def forward(self, y: Tensor, side_params: Tensor):
+        raise NotImplementedError("training-time likelihoods are outside the entropy-coding path")
+
+
+class HyperLatentCodec(nn.Module):
+    """Hyper branch (compressai/latent_codecs/hyper.py:48-108): ``z = h_a(y)`` is table-coded, ``params = h_s(z_hat)``.
+    ``entropy_bottleneck`` is anything with the reference's ``compress(z) -> [bytes]`` / ``decompress(strings, size)``
+    contract: ``flashgmm_amd.EntropyBottleneckCoder`` (built from the tables of a trained ``EntropyBottleneck``), or the
+    reference's own class."""
+
+    def __init__(self, entropy_bottleneck=None, h_a: Optional[nn.Module] = None, h_s: Optional[nn.Module] = None,
+                 quantizer: str = "noise", **kwargs: Any):
+        super().__init__()
+        assert entropy_bottleneck is not None
+        self.entropy_bottleneck = entropy_bottleneck
+        self.h_a = h_a or nn.Identity()
+        self.h_s = h_s or nn.Identity()
+        self.quantizer = quantizer
+
+    def compress(self, y: Tensor) -> Dict[str, Any]:  # hyper.py:94-100
+        z = self.h_a(y)
+        shape = z.size()[-2:]
+        z_strings = self.entropy_bottleneck.compress(z)
+        z_hat = self.entropy_bottleneck.decompress(z_strings, shape)
+        return {"strings": [z_strings], "shape": shape, "params": self.h_s(z_hat)}
+
+    def decompress(self, strings: List[List[bytes]], shape: Tuple[int, int], **kwargs: Any) -> Dict[str, Any]:  # hyper.py:102-108
+        (z_strings,) = strings
+        z_hat = self.entropy_bottleneck.decompress(z_strings, shape)
+        return {"params": self.h_s(z_hat)}
+
+    def forward(self, y: Tensor):
+        raise NotImplementedError("training-time likelihoods are outside the entropy-coding path")
+
+
+class HyperpriorLatentCodec(nn.Module):
+    """``latent_codec = {"y": ..., "hyper": HyperLatentCodec}`` (compressai/latent_codecs/hyperprior.py:46-139): the complete
+    nested result of the GMM models, ``{"strings": [*y_strings, z_strings], "shape": {"y": ..., "hyper": ...}, "y_hat"}``
+    (models/ckbd_gmm.py:109-123: ``y`` is a ``CheckerboardLatentCodec``; models/elic_gmm.py:197-227: a
+    ``ChannelGroupsLatentCodec``)."""
+
+    def __init__(self, latent_codec: Optional[Dict[str, nn.Module]] = None, **kwargs: Any):
+        super().__init__()
+        if latent_codec is None or "y" not in latent_codec or "hyper" not in latent_codec:
+            raise ValueError('latent_codec must hold the "y" and the "hyper" codec')
+        self.latent_codec = nn.ModuleDict(latent_codec)
+
+    def __getitem__(self, key: str) -> nn.Module:
+        return self.latent_codec[key]
+
+    def compress(self, y: Tensor) -> Dict[str, Any]:  # hyperprior.py:120-128
+        hyper_out = self.latent_codec["hyper"].compress(y)
+        y_out = self.latent_codec["y"].compress(y, hyper_out["params"])
+        [z_strings] = hyper_out["strings"]
+        return {"strings": [*y_out["strings"], z_strings], "shape": {"y": y_out["shape"], "hyper": hyper_out["shape"]},
+                "y_hat": y_out["y_hat"]}
+
+    def decompress(self, strings: List[Any], shape: Dict[str, Any], **kwargs: Any) -> Dict[str, Any]:  # hyperprior.py:130-139
+        *y_strings_, z_strings = strings
+        hyper_out = self.latent_codec["hyper"].decompress([z_strings], shape["hyper"])
+        y_out = self.latent_codec["y"].decompress(y_strings_, shape["y"], hyper_out["params"])
+        return {"y_hat": y_out["y_hat"]}
+
+    def forward(self, y: Tensor):
         raise NotImplementedError("training-time likelihoods are outside the entropy-coding path")

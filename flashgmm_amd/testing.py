@@ -139,6 +139,37 @@ def exact_modules():
     return ExactContext, ExactParams
 
 
+def exact_hyper_modules():
+    """-> (ExactHa, ExactHs): the hyper branch's transforms as exact arithmetic (see exact_modules).
+    ExactHa  y [n, c, h, w] -> z [n, cz, h/2, w/2]: z[o] = round(2 * (y[o % c] + y[(o+1) % c]) sub-sampled by 2) / 2 + (o % 3 - 1) / 2
+             — multiples of 1/2 whatever y is, some beyond the bottleneck's tables (bypass-coded) (round() of an IEEE sum: the same bits on every device)
+    ExactHs  z_hat [n, cz, h/2, w/2] -> side [n, c_side, h, w]: nearest-neighbour x2 of 0.5 * z_hat[o % cz] + 0.25 * (o % 5 - 2)"""
+    import torch
+    import torch.nn as nn
+
+    class ExactHa(nn.Module):
+        def __init__(self, c: int, cz: int):
+            super().__init__()
+            self.c, self.cz = c, cz
+
+        def forward(self, y):
+            o = torch.arange(self.cz, device=y.device)
+            t = (y[:, o % self.c] + y[:, (o + 1) % self.c])[:, :, ::2, ::2]
+            return torch.round(2.0 * t) / 2.0 + ((o % 3).to(y.dtype) - 1.0).view(1, -1, 1, 1) / 2.0
+
+    class ExactHs(nn.Module):
+        def __init__(self, cz: int, c_side: int):
+            super().__init__()
+            self.cz, self.c_side = cz, c_side
+
+        def forward(self, z):
+            o = torch.arange(self.c_side, device=z.device)
+            t = 0.5 * z[:, o % self.cz] + 0.25 * ((o % 5).to(z.dtype) - 2.0).view(1, -1, 1, 1)
+            return t.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+    return ExactHa, ExactHs
+
+
 def exact_codec_inputs(seed: int, c: int, c_side: int, h: int, w: int, dead: int = 0):
     """y float32 [1, c, h, w] (arbitrary floats; `dead` leading channels within +-0.4 so that they quantise to all-zero),
     side_params float32 [1, c_side, h, w] (multiples of 1/4, so that everything derived from them stays exact)."""

@@ -167,6 +167,34 @@ def import_reference_latent_codecs():
     return CheckerboardLatentCodec, ChannelGroupsLatentCodec, GaussianMixtureConditionalLatentCodec
 
 
+def import_reference_hyper_codecs():
+    """The reference's own HyperpriorLatentCodec / HyperLatentCodec / EntropyBottleneck, in place (after the two imports above)."""
+    from compressai.entropy_models.entropy_models import EntropyBottleneck
+    from compressai.latent_codecs.hyper import HyperLatentCodec
+    from compressai.latent_codecs.hyperprior import HyperpriorLatentCodec
+
+    return HyperpriorLatentCodec, HyperLatentCodec, EntropyBottleneck
+
+
+# G8: the complete nested result of a hyperprior model around the GMM path (models/ckbd_gmm.py:109-123):
+# (name, seed, c, cz, c_side, h, w, quantizer)
+G8_HYPER = [("hyperprior_ckbd", 31, 6, 4, 8, 8, 12, "noise")]
+
+
+def build_entropy_bottleneck(EB, cz: int):
+    """the reference's EntropyBottleneck with its random initial density model (seeded) and dyadic, channel-dependent
+    medians, tables built by its own update()"""
+    import torch
+
+    torch.manual_seed(5)
+    eb = EB(cz)
+    med = (torch.arange(cz, dtype=torch.float32) % 5 - 2.0) / 4.0  # -0.5 .. 0.5 in steps of 1/4
+    q = eb.quantiles.data
+    q[:, 0, 0], q[:, 0, 1], q[:, 0, 2] = med - 7.0, med, med + 9.0  # asymmetric supports: offsets differ from -lengths/2
+    eb.update(force=True)
+    return eb
+
+
 G7_CKBD = [  # CheckerboardLatentCodec cases: (name, seed, c, c_side, h, w, dead channels, quantizer, anchor_parity)
     ("ckbd_noise_even", 11, 6, 8, 8, 12, 0, "noise", "even"),
     ("ckbd_ste_odd", 12, 5, 6, 6, 10, 1, "weighted_mean_ste", "odd"),
@@ -287,6 +315,35 @@ def worker(mode: int, flavour: str):
                         "decompress_y_hat_sha256": hashlib.sha256(dec["y_hat"].contiguous().numpy().tobytes()).hexdigest(),
                     }
         out["g7"] = g7
+
+        # G8: HyperpriorLatentCodec{y: CheckerboardLatentCodec(GMM), hyper: HyperLatentCodec(EntropyBottleneck)} — the
+        # reference's own classes end to end; the EntropyBottleneck's tables (float work of its update() on this CPU) are
+        # part of the fixture, so that the mirror codes against the same integers
+        Hyperprior, Hyper, EB = import_reference_hyper_codecs()
+        Ha, Hs = T.exact_hyper_modules()
+        g8 = {}
+        with contextlib.redirect_stdout(sys.stderr):
+            for name, seed, c, cz, c_side, h, w_, quantizer in G8_HYPER:
+                y, _ = T.exact_codec_inputs(seed, c, c_side, h, w_)
+                eb = build_entropy_bottleneck(EB, cz)
+                ycodec = build_codecs(Ckbd, Groups, Gmm, Ctx, Par, "ckbd", (name, seed, c, c_side, h, w_, 0, quantizer, "even"))
+                codec = Hyperprior(latent_codec={"y": ycodec, "hyper": Hyper(entropy_bottleneck=eb, h_a=Ha(c, cz), h_s=Hs(cz, c_side))})
+                enc = codec.compress(ts(y))
+                dec = codec.decompress(enc["strings"], enc["shape"])
+                *ys_, zs_ = enc["strings"]
+                z = Ha(c, cz)(ts(y))
+                g8[name] = {
+                    "tables": {"quantized_cdf": eb._quantized_cdf.tolist(), "cdf_length": eb._cdf_length.tolist(),
+                               "offset": eb._offset.tolist(), "medians_bits": eb.quantiles[:, 0, 1].detach().numpy().view(np.uint32).tolist()},
+                    "y_strings": strings_to_json(ys_), "z_strings": [b.hex() for b in zs_],
+                    "shape": {"y": list(enc["shape"]["y"]), "hyper": list(enc["shape"]["hyper"])},
+                    "z_sha256": hashlib.sha256(z.contiguous().numpy().tobytes()).hexdigest(),
+                    "z_bypass_symbols": int(sum(int(((zs < o) | (zs >= o + ln - 2)).sum()) for zs, o, ln in zip(
+                        (z - eb.quantiles[:, 0, 1].detach().view(1, -1, 1, 1)).round()[0], eb._offset.tolist(), eb._cdf_length.tolist()))),
+                    "y_hat_sha256": hashlib.sha256(enc["y_hat"].contiguous().numpy().tobytes()).hexdigest(),
+                    "decompress_y_hat_sha256": hashlib.sha256(dec["y_hat"].contiguous().numpy().tobytes()).hexdigest(),
+                }
+        out["g8"] = g8
     json.dump(out, sys.stdout)
 
 
@@ -353,6 +410,10 @@ def main():
     json.dump({name: res[name]["ka1"] for name in MODE_NAMES}, open(os.path.join(HERE, "ka1.json"), "w"), indent=1)
     json.dump({name: res[name]["g4"] for name in MODE_NAMES}, open(os.path.join(HERE, "g4_api.json"), "w"), indent=1)
     json.dump({name: res[name]["g7"] for name in MODE_NAMES}, open(os.path.join(HERE, "g7_codecs.json"), "w"), indent=1)
+    for name in MODE_NAMES[1:]:  # the z stream and its tables do not depend on the Phi approximation
+        for k, v in res[name]["g8"].items():
+            assert v["tables"] == res["polya"]["g8"][k]["tables"] and v["z_strings"] == res["polya"]["g8"][k]["z_strings"]
+    json.dump({name: res[name]["g8"] for name in MODE_NAMES}, open(os.path.join(HERE, "g8_hyperprior.json"), "w"), indent=1)
     # table path (mode independent): the oracle must rebuild the same CDF rows and the same bytes
     r0 = res["polya"]
     assert r0["g6"] == [0, 21845, 65534, 65535, 65536] == O.pmf_to_quantized_cdf([0.1, 0.2, 0, 0], 16)

@@ -680,6 +680,52 @@ def test_elic_channel_group_shapes(oracle):
         assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(ys[i]))
 
 
+def test_config4_elic_4k_fp16_through_the_group_codec(oracle):
+    """BASELINE configs[4] as stated: ELIC on a 4K image — y [1, 320, 136, 240], channel groups 16/16/32/64/192, each a
+    checkerboard codec over the GMM entropy model (models/elic_gmm.py:198-219) — with fp16 (mu, sigma, pi) planes and fp32
+    CDF arithmetic, all five groups in their sequential flow through ChannelGroupsLatentCodec on exact networks.  Checked:
+    the ten bitstreams of the three small groups byte for byte against the oracle on the (widened) parameters each half was
+    coded with; every group through decode(encode(y)) == y_hat; encode in ONE batched call == the group-by-group schedule."""
+    from flashgmm_amd.latent_codecs import ChannelGroupsLatentCodec, CheckerboardLatentCodec, GaussianMixtureConditionalLatentCodec
+
+    groups, c_side, h, w = [16, 16, 32, 64, 192], 8, 136, 240
+    Ctx, Par = T.exact_modules()
+    seen = []  # (y_code, scales, means, weights) of every half, in coding order
+
+    class Spy(GaussianMixtureConditionalLatentCodec):
+        def coder_inputs(self, y, ctx_params):
+            out = super().coder_inputs(y, ctx_params)
+            seen.append(out)
+            return out
+
+    def build():
+        latent = {f"y{k}": CheckerboardLatentCodec(latent_codec={"y": Spy(K=4, mode="polya", param_dtype=torch.float16)},
+                                                   context_prediction=Ctx(g, 2 * g), entropy_parameters=Par(2 * g + (k > 0) * 2 * g + c_side, g))
+                  for k, g in enumerate(groups)}
+        chctx = {f"y{k}": Ctx(sum(groups[:k]), 2 * groups[k]) for k in range(1, len(groups))}
+        return ChannelGroupsLatentCodec(groups=groups, channel_context=chctx, latent_codec=latent)
+
+    y, side = T.exact_codec_inputs(61, sum(groups), c_side, h, w)
+    y[:, :2] = 0.3  # two dead channels in the first group
+    yd, sided = dv(y), dv(side)
+    codec = build()
+    enc = codec.compress(yd, sided)
+    assert len(enc["strings"]) == 10 and len(seen) == 10 and [tuple(s_) for s_ in enc["shape"]] == [(g, h, w) for g in groups]
+    assert all(p[1].dtype == torch.float16 and tuple(p[1].shape) == (1, 4 * g, h, w // 2) for p, g in zip(seen, [g for g in groups for _ in (0, 1)]))
+    for i in range(6):  # the three small groups, both halves: the reference path fed the widened planes
+        yc, sg, mu, pi = (t.cpu().numpy() for t in seen[i])
+        sym, s_, m_, w_, am, zbm, yqn = T.to_coder_inputs(yc, *(a.astype(np.float32) for a in (sg, mu, pi)))
+        b, abs_max, zb = enc["strings"][i]
+        assert b == oracle.encode_gmm("polya", sym, s_, m_, w_) and abs_max == am and zb.cpu().tolist() == zbm.tolist(), i
+    dec = codec.decompress(enc["strings"], enc["shape"], sided)
+    assert torch.equal(dec["y_hat"], enc["y_hat"]) and torch.equal(enc["y_hat"], torch.round(yd))
+    # the group-by-group schedule (ten encode calls) gives the same ten bitstreams
+    seq = build()
+    seq._one_call = lambda codecs: False
+    enc2 = seq.compress(yd, sided)
+    assert [(b, a) for b, a, _ in enc2["strings"]] == [(b, a) for b, a, _ in enc["strings"]] and torch.equal(enc2["y_hat"], enc["y_hat"])
+
+
 def test_config0_256x256_plumbing(oracle):
     """BASELINE configs[0]: one 256x256 image -> y [1,192,16,16], halves [1,192,16,8]; all three modes."""
     for mode in MODES:
@@ -806,6 +852,49 @@ def test_g7_codecs_equal_the_reference_classes(mode):
             s2, shape2 = Cn.unpack(blob, device="cuda")
             assert torch.equal(codec.decompress(s2, shape2, dv(side))["y_hat"], dec["y_hat"]), (name, "container")
             assert len(blob) - sum(len(t[0]) for t in enc["strings"]) == Cn.side_info_bytes(enc["strings"], enc["shape"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_g8_hyperprior_result_equals_the_reference_classes(mode):
+    """golden G8: the COMPLETE nested result of a hyperprior model around the GMM path — HyperpriorLatentCodec{y:
+    CheckerboardLatentCodec(GMM), hyper: HyperLatentCodec(EntropyBottleneck)} of the reference's own classes, run on
+    device-independent networks in the build container — from GPU tensors: strings [anchor, non-anchor, z], shape
+    {"y", "hyper"}, y_hat; and back."""
+    from flashgmm_amd import EntropyBottleneckCoder
+    from flashgmm_amd.latent_codecs import (CheckerboardLatentCodec, GaussianMixtureConditionalLatentCodec, HyperLatentCodec,
+                                            HyperpriorLatentCodec)
+
+    mg = _mg()
+    g8 = json.load(open(os.path.join(GOLD, "g8_hyperprior.json")))[mode]
+    Ctx, Par = T.exact_modules()
+    Ha, Hs = T.exact_hyper_modules()
+    for name, seed, c, cz, c_side, h, w, quantizer in mg.G8_HYPER:
+        ent = g8[name]
+        t = ent["tables"]
+        med = torch.from_numpy(np.array(t["medians_bits"], np.uint32).view(np.float32).copy())
+        coder = EntropyBottleneckCoder(torch.tensor(t["quantized_cdf"], dtype=torch.int32), torch.tensor(t["cdf_length"], dtype=torch.int32),
+                                       torch.tensor(t["offset"], dtype=torch.int32), med).to(DEV)
+        ycodec = CheckerboardLatentCodec(latent_codec={"y": GaussianMixtureConditionalLatentCodec(K=4, quantizer=quantizer, mode=mode)},
+                                         context_prediction=Ctx(c, 2 * c), entropy_parameters=Par(2 * c + c_side, c))
+        codec = HyperpriorLatentCodec(latent_codec={"y": ycodec, "hyper": HyperLatentCodec(entropy_bottleneck=coder, h_a=Ha(c, cz), h_s=Hs(cz, c_side))})
+        y, _ = T.exact_codec_inputs(seed, c, c_side, h, w)
+        enc = codec.compress(dv(y))
+        *ys_, zs_ = enc["strings"]
+        assert [b.hex() for b in zs_] == ent["z_strings"]
+        assert mg.strings_to_json([(b, a, zb.cpu()) for b, a, zb in ys_]) == ent["y_strings"]
+        assert list(enc["shape"]["y"]) == ent["shape"]["y"] and list(enc["shape"]["hyper"]) == ent["shape"]["hyper"]
+        assert enc["y_hat"].is_cuda
+        assert hashlib.sha256(enc["y_hat"].contiguous().cpu().numpy().tobytes()).hexdigest() == ent["y_hat_sha256"]
+        dec = codec.decompress(enc["strings"], enc["shape"])
+        assert hashlib.sha256(dec["y_hat"].contiguous().cpu().numpy().tobytes()).hexdigest() == ent["decompress_y_hat_sha256"]
+        # the container carries the whole nested result
+        from flashgmm_amd import container as Cn
+
+        blob = Cn.pack(enc["strings"], {"y": tuple(enc["shape"]["y"]), "hyper": tuple(enc["shape"]["hyper"])})
+        s2, shape2 = Cn.unpack(blob)
+        dec2 = codec.decompress([(b, a, zb.to(DEV)) if isinstance(zb, torch.Tensor) else (b, a, zb) for (b, a, zb) in s2[:-1]] + [s2[-1]],
+                                shape2)
+        assert torch.equal(dec2["y_hat"], dec["y_hat"])
 
 
 def test_rccl_collectives_single_rank():

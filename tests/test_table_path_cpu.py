@@ -102,3 +102,53 @@ def test_table_path_validation():
     b = ans.RansEncoder().encode_with_indexes([0, 1, 1, 0], [0, 0, 0, 0], cdfs, sizes, offsets)
     with pytest.raises(RuntimeError):
         ans.RansDecoder().decode_with_indexes(b, [0] * 400, cdfs, sizes, offsets)  # asks for more than the stream holds
+
+
+def _g8():
+    import json
+    import os
+
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8_hyperprior.json")))
+
+
+def g8_coder(ent):
+    """EntropyBottleneckCoder on the tables the reference's EntropyBottleneck.update() built (part of the fixture)"""
+    import torch
+    from flashgmm_amd import EntropyBottleneckCoder
+
+    t = ent["tables"]
+    med = torch.from_numpy(np.array(t["medians_bits"], np.uint32).view(np.float32).copy())
+    return EntropyBottleneckCoder(torch.tensor(t["quantized_cdf"], dtype=torch.int32), torch.tensor(t["cdf_length"], dtype=torch.int32),
+                                  torch.tensor(t["offset"], dtype=torch.int32), med)
+
+
+def test_g8_hyper_latent_z_stream_equals_the_reference_classes():
+    """golden G8, the `z` half: HyperLatentCodec over EntropyBottleneckCoder == the reference's HyperLatentCodec over its
+    own EntropyBottleneck (same tables): z strings (bypass-coded symbols included), shape, z_hat -> params"""
+    import hashlib
+
+    import torch
+    from flashgmm_amd import testing as T
+    from flashgmm_amd.latent_codecs import HyperLatentCodec
+    from golden.make_golden import G8_HYPER
+
+    g8 = _g8()["polya"]
+    Ha, Hs = T.exact_hyper_modules()
+    for name, seed, c, cz, c_side, h, w, quantizer in G8_HYPER:
+        ent = g8[name]
+        assert ent["z_bypass_symbols"] > 0
+        y, _ = T.exact_codec_inputs(seed, c, c_side, h, w)
+        hyper = HyperLatentCodec(entropy_bottleneck=g8_coder(ent), h_a=Ha(c, cz), h_s=Hs(cz, c_side))
+        z = hyper.h_a(torch.from_numpy(y))
+        assert hashlib.sha256(z.contiguous().numpy().tobytes()).hexdigest() == ent["z_sha256"]
+        out = hyper.compress(torch.from_numpy(y))
+        assert [b.hex() for b in out["strings"][0]] == ent["z_strings"] and list(out["shape"]) == ent["shape"]["hyper"]
+        dec = hyper.decompress(out["strings"], out["shape"])
+        assert torch.equal(dec["params"], out["params"]) and tuple(out["params"].shape) == (1, c_side, h, w)
+        # z_hat = round(z - medians) + medians, bit for bit
+        coder = hyper.entropy_bottleneck
+        z_hat = coder.decompress(out["strings"][0], out["shape"])
+        med = coder.medians.view(1, -1, 1, 1)
+        assert torch.equal(z_hat, torch.round(z - med) + med)
+        with pytest.raises(ValueError):
+            coder.compress(torch.zeros(1, cz + 1, 2, 2))
