@@ -17,6 +17,7 @@ FGMM_OK = 0
 FGMM_HOST, FGMM_DEVICE = 0, 1
 FGMM_K = 4
 FGMM_F32, FGMM_F16 = 0, 1
+FGMM_PARAMS_LOGITS = 1  # fgmm_params.flags: the weights planes hold logits, softmax over K runs in the kernels
 MODES = {"polya": 0, "as": 1, "logistic": 2}  # numbering of the reference CODE (rans_interface.cpp:224-232)
 
 STATUS_NAMES = {1: "FGMM_ERR_INVALID", 2: "FGMM_ERR_NO_DEVICE", 3: "FGMM_ERR_HIP", 4: "FGMM_ERR_NOMEM",
@@ -29,7 +30,7 @@ class FgmmError(RuntimeError):
 
 class fgmm_params(C.Structure):
     _fields_ = [("scales", C.c_void_p), ("means", C.c_void_p), ("weights", C.c_void_p),
-                ("stride_k", C.c_int64), ("stride_c", C.c_int64), ("dtype", C.c_int32), ("reserved", C.c_int32)]
+                ("stride_k", C.c_int64), ("stride_c", C.c_int64), ("dtype", C.c_int32), ("flags", C.c_int32)]
 
 
 class fgmm_item(C.Structure):
@@ -77,6 +78,7 @@ SIGNATURES = {
     "fgmm_gmc_compress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
     "fgmm_gmc_decompress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
     "fgmm_gmm_cdf_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p, _p]),
+    "fgmm_softmax4_hip": (_i, [_p, _p, _p, _p, _i64]),
     "fgmm_build_symtab_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "fgmm_build_cdftab_hip": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i32, _i, _p, _p, C.c_uint64, _p]),
     "fgmm_selftest_saturation": (_i, [_p, _i, C.POINTER(C.c_uint64)]),

@@ -369,6 +369,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     d.hw = it.hw;
     d.M = it.M;
     d.clamp = it.clamp;
+    d.logits = (it.prm.flags & FGMM_PARAMS_LOGITS) ? 1 : 0;
     d.yq = it.yq;
     d.chan_min = reinterpret_cast<float *>(ctx->d_ws + it.o_min);
     d.chan_max = reinterpret_cast<float *>(ctx->d_ws + it.o_max);
@@ -741,6 +742,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.n_ch = it.n_ch;
     d.max_bs = it.max_bs;
     d.clamp = it.clamp;
+    d.logits = (it.prm.flags & FGMM_PARAMS_LOGITS) ? 1 : 0;
     d.prune = 1;
     d.hdr_form = it.hdr_form;
     d.ef_min = ef_min;
@@ -1164,6 +1166,7 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
       return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
     if (s.params.dtype != items[0].params.dtype || (s.params.dtype != FGMM_F32 && s.params.dtype != FGMM_F16))
       return fail(FGMM_ERR_INVALID, "item %d: parameter dtype must be FGMM_F32 or FGMM_F16 and the same for a whole batch", i);
+    if (s.params.flags & ~FGMM_PARAMS_LOGITS) return fail(FGMM_ERR_INVALID, "item %d: unknown fgmm_params.flags %d", i, s.params.flags);
     EncItem &e = v[i];
     e.y = s.y;
     e.prm = s.params;
@@ -1218,6 +1221,7 @@ int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int
       return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
     if (s.params.dtype != items[0].params.dtype || (s.params.dtype != FGMM_F32 && s.params.dtype != FGMM_F16))
       return fail(FGMM_ERR_INVALID, "item %d: parameter dtype must be FGMM_F32 or FGMM_F16 and the same for a whole batch", i);
+    if (s.params.flags & ~FGMM_PARAMS_LOGITS) return fail(FGMM_ERR_INVALID, "item %d: unknown fgmm_params.flags %d", i, s.params.flags);
     DecItem &d = v[i];
     d.enc = s.bytes;
     d.enc_len = s.bytes_len;
@@ -1392,6 +1396,15 @@ int fgmm_gmm_cdf_hip(fgmm_ctx *ctx, void *stream, const int32_t *v, const float 
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   LAUNCH_TRY(launch_cdf_pair(v, scales, means, weights, n, stride_n, stride_k, mode, c1, c2, stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return FGMM_OK;
+}
+
+int fgmm_softmax4_hip(fgmm_ctx *ctx, void *stream, const float *logits, float *weights, int64_t n) {
+  if (!ctx || n < 0 || (n && (!logits || !weights))) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  LAUNCH_TRY(launch_softmax_probe(logits, weights, n, stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return FGMM_OK;
 }

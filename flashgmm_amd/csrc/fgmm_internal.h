@@ -23,6 +23,8 @@ struct EncDesc {
   int64_t hw;
   int32_t M;
   int32_t clamp;
+  int32_t logits;        // the weights planes hold LOGITS: pi = softmax4 over K in the kernel (fgmm_math.h)
+  int32_t pad_;
   // outputs (device)
   float *yq;             // [M*hw] round(y), or null
   float *chan_min;       // [M]  min over the channel of y
@@ -43,10 +45,10 @@ struct DecDesc {
   int32_t n_ch;
   int32_t max_bs;
   int32_t clamp;
+  int32_t logits;                // the weights planes hold logits: pi = softmax4 over K in the kernel (fgmm_math.h)
   int32_t prune;                 // 1: skip the saturated tails (exact, see tab_window); 0: evaluate all of F
   int32_t hdr_form;              // bytes per header as the host gets them: 2, 4 or 8 (format v4 below)
   uint32_t ef_min;               // rows with at least this many entries are Elias-Fano coded (kTabEfMin / kTabNoEf)
-  int32_t pad0_;
   int32_t tl;                    // tab_kernel: latents per block (rows of a block are contiguous, blocks are placed by a cursor)
   // ---- tab_kernel (single pass): the blocks [blk_begin, blk_end) of this item, into one launch's range
   int32_t blk_begin, blk_end;
@@ -139,6 +141,7 @@ int launch_tab(const DecDesc *d_descs, int count, int blocks_max, int tl_max, in
                void *stream);
 // y_hat[c, p] = rank[c] < 0 ? 0 : (float)sym[rank[c] * hw + p]; sym is int16 (wide = 0) or int32 and may live in pinned
 // host memory (read over PCIe)   (entropy_models.py:903-908)
+int launch_softmax_probe(const float *logits, float *pi, int64_t n, void *stream);
 int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y_hat, int M, int64_t hw, void *stream);
 // checkerboard split (embed = false: [planes,h,w] -> [2,planes,h,w/2]) / merge (embed = true); w even, elem_bytes 2 or 4
 int launch_ckbd(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes, int anchor_odd, bool embed,

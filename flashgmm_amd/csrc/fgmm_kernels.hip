@@ -217,6 +217,7 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
         mu[k] = Mu[k][e];
         pi[k] = Pi[k][e];
       }
+      if (d.logits) softmax4(pi);
       int bp;
       out[e] = sym_entry<MODE, CLAMPED>(vq[e], vi[e], mu, sg, pi, bp);
       nbypass += bp;
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
       mu[k] = ld1<PT>(d.means, base + k * d.stride_k);
       pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
     }
+    if (d.logits) softmax4(pi);
     int bp;
     stg<uint32_t>(d.packed + (int64_t)rank * hw + p0, sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp));
     nbypass = bp;
@@ -285,6 +287,16 @@ __global__ __launch_bounds__(kBlock) void yhat_scatter_kernel(const ST *__restri
   if (p >= hw) return;
   const int r = rank[c];
   y_hat[(int64_t)c * hw + p] = r < 0 ? 0.0f : (float)sym[(int64_t)r * hw + p];
+}
+
+// softmax_probe_kernel: the kernels' mixture-weight sequence on (n, 4) rows of logits (tests: against torch.softmax)
+__global__ __launch_bounds__(kBlock) void softmax_probe_kernel(const float *__restrict__ logits, float *__restrict__ pi, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float w[4] = {logits[4 * i], logits[4 * i + 1], logits[4 * i + 2], logits[4 * i + 3]};
+  softmax4(w);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pi[4 * i + k] = w[k];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -512,6 +524,12 @@ int launch_cdf_pair(const int32_t *v, const float *scales, const float *means, c
   case MODE_LOGISTIC: hipLaunchKernelGGL((cdf_pair_kernel<MODE_LOGISTIC>), grid, dim3(kBlock), 0, s, v, scales, means, weights, n, stride_n, stride_k, c1, c2); break;
   default: hipLaunchKernelGGL((cdf_pair_kernel<MODE_POLYA>), grid, dim3(kBlock), 0, s, v, scales, means, weights, n, stride_n, stride_k, c1, c2); break;
   }
+  return launch_err();
+}
+
+int launch_softmax_probe(const float *logits, float *pi, int64_t n, void *stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(softmax_probe_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, logits, pi, n);
   return launch_err();
 }
 

@@ -372,6 +372,32 @@ __device__ __forceinline__ f2 mix4_clamped2(f2 x, const float (&mu)[4], const Si
   return (p[0] + p[1]) + (p[2] + p[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Mixture weights from logits, in the kernels (the parameter head's softmax over K,
+// latent_codecs/gaussian_mixture_conditional.py:198-202, fused into the consumers of pi): ONE fixed sequence of
+// binary32 operations, the same in the encode-side and the decode-side kernel, so that a stream coded from logits
+// decodes from logits whatever device torch.softmax would have run on.
+//   m = max(l0..l3);  e_k = exp(l_k - m) (the Cephes sequence above), exactly 0 for l_k - m < -41 (e^-41 = 1.6e-18: nothing a
+//   16-bit CDF can see, and it keeps e_k inside the exact division core's domain);  s = (e0 + e1) + (e2 + e3) in [1, 4];
+//   pi_k = e_k / s, correctly rounded.          Within 2e-7 of torch.softmax (tests pin 1e-6).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void softmax4(float (&w)[4]) {
+  const float m = __builtin_fmaxf(__builtin_fmaxf(w[0], w[1]), __builtin_fmaxf(w[2], w[3]));
+  f2 d0 = {w[0] - m, w[1] - m}, d1 = {w[2] - m, w[3] - m};
+  const bool z0 = !(d0.x >= -41.0f), z1 = !(d0.y >= -41.0f), z2 = !(d1.x >= -41.0f), z3 = !(d1.y >= -41.0f); // also NaN
+  d0.x = __builtin_fmaxf(d0.x, -100.0f); d0.y = __builtin_fmaxf(d0.y, -100.0f);
+  d1.x = __builtin_fmaxf(d1.x, -100.0f); d1.y = __builtin_fmaxf(d1.y, -100.0f);
+  f2 e0 = exp_nonpos2(d0), e1 = exp_nonpos2(d1);
+  e0.x = z0 ? 0.0f : e0.x; e0.y = z1 ? 0.0f : e0.y;
+  e1.x = z2 ? 0.0f : e1.x; e1.y = z3 ? 0.0f : e1.y;
+  const float s = (e0.x + e0.y) + (e1.x + e1.y); // >= 1: the largest logit contributes exp(0) = 1 (all-NaN / all -inf rows: NaN)
+  const float r = rcp_refined(s);
+  const f2 p0 = div_core2(e0, s, r), p1 = div_core2(e1, s, r); // e in {0} U [2^-60, 1], s in [1, 4]: the core's domain
+  const bool ok = s >= 1.0f;                                    // false for NaN
+  w[0] = ok ? p0.x : e0.x / s; w[1] = ok ? p0.y : e0.y / s;
+  w[2] = ok ? p1.x : e1.x / s; w[3] = ok ? p1.y : e1.y / s;
+}
+
 // static_cast<uint16_t>(float) as x86-64 GCC emits it (cvttss2si r32 ; movzwl), rans_interface.cpp:509-510.
 // cvttss2si yields 0x80000000 for NaN / out-of-range, v_cvt_i32_f32 saturates: make the x86 answer explicit.
 __device__ __forceinline__ uint32_t quant16(float cdf) {

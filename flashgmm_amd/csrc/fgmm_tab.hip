@@ -45,6 +45,7 @@ template <int MODE, bool CLAMPED, typename PT> struct TabLatent {
       mu[k] = ld1<PT>(d.means, base + k * d.stride_k);
       pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
     }
+    if (d.logits) softmax4(pi);
     max_bs = d.max_bs;
   }
   __device__ __forceinline__ uint32_t edge(int j) const { // F[v = j - max_bs]
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       mu[k] = ld1<PT>(d.means, base + k * d.stride_k);
       pi[k] = ld1<PT>(d.weights, base + k * d.stride_k);
     }
+    if (d.logits) softmax4(pi);
     if constexpr (CLAMPED) {
       Sigma4 S4;
       S4.set(sg[0], sg[1], sg[2], sg[3]);

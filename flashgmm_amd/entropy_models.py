@@ -75,7 +75,7 @@ class GaussianMixtureConditional(nn.Module):
         return rs(scales).clamp(0.11, 256), rs(means), rs(weights)
 
     # ------------------------------------------------------------------------------------------------
-    def _item(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor, keep: list):
+    def _item(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor, keep: list, flags: int = 0):
         if not scales.is_cuda:
             raise RuntimeError(
                 "flashgmm_amd runs the GMM entropy-coding path on the GPU only: tensors must be on a HIP device "
@@ -96,7 +96,7 @@ class GaussianMixtureConditional(nn.Module):
         if not (s.dtype == m.dtype == w.dtype):
             raise RuntimeError("scales, means and weights must share one dtype")
         it.params = _lib.fgmm_params(s.data_ptr(), m.data_ptr(), w.data_ptr(), sk, sc,
-                                     _lib.FGMM_F16 if s.dtype == torch.float16 else _lib.FGMM_F32, 0)
+                                     _lib.FGMM_F16 if s.dtype == torch.float16 else _lib.FGMM_F32, flags)
         it.M, it.K, it.hw = M, self.K, hw
         keep += [s, m, w]
         if y is not None:
@@ -110,7 +110,7 @@ class GaussianMixtureConditional(nn.Module):
             keep.append(yc)
         return it, M, hw, s.device
 
-    def _stacked_items(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor):
+    def _stacked_items(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor, flags: int = 0):
         """``fgmm_item[N]`` (as a numpy record array) for N items given as ONE tensor each: y ``[N, M, h, w]``,
         parameters ``[N, K*M, h, w]``.  One validation and one set of strides for the whole batch; the item
         pointers are the batch-dimension offsets."""
@@ -138,6 +138,7 @@ class GaussianMixtureConditional(nn.Module):
         items["weights"] = np.uint64(weights.data_ptr()) + step
         items["stride_k"], items["stride_c"] = M * sc, sc
         items["dtype"] = _lib.FGMM_F16 if scales.dtype == torch.float16 else _lib.FGMM_F32
+        items["flags"] = flags
         items["M"], items["K"], items["hw"] = M, self.K, hw
         keep = [scales, means, weights]
         if y is not None:
@@ -150,8 +151,8 @@ class GaussianMixtureConditional(nn.Module):
             keep.append(y)
         return items, keep, N, M, h, w, scales.device
 
-    def _compress_stacked(self, y: Tensor, scales: Tensor, means: Tensor, weights: Tensor):
-        items, keep, N, M, h, w, dev = self._stacked_items(y, scales, means, weights)
+    def _compress_stacked(self, y: Tensor, scales: Tensor, means: Tensor, weights: Tensor, flags: int = 0):
+        items, keep, N, M, h, w, dev = self._stacked_items(y, scales, means, weights, flags)
         if N == 0:
             return []
         yq = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
@@ -173,8 +174,8 @@ class GaussianMixtureConditional(nn.Module):
         return out
 
     def _decompress_stacked(self, strings: Sequence[bytes], abs_maxes: Sequence[int], zero_bitmaps, scales: Tensor,
-                            means: Tensor, weights: Tensor) -> List[Tensor]:
-        items, keep, N, M, h, w, dev = self._stacked_items(None, scales, means, weights)
+                            means: Tensor, weights: Tensor, flags: int = 0) -> List[Tensor]:
+        items, keep, N, M, h, w, dev = self._stacked_items(None, scales, means, weights, flags)
         if len(strings) != N or len(abs_maxes) != N or len(zero_bitmaps) != N:
             raise RuntimeError(f"{N} items in the parameter tensors, {len(strings)} bitstreams")
         if N == 0:
@@ -202,24 +203,29 @@ class GaussianMixtureConditional(nn.Module):
         _lib.check(rc, "GaussianMixtureConditional.decompress")
         return list(y_hat.unbind(0))
 
-    def compress_batch(self, ys, scales, means, weights):
+    def compress_batch(self, ys, scales, means, weights, *, weights_are_logits: bool = False):
         """N independent ``compress`` calls in one native call (kernels batched over items, one host rANS worker
         per bitstream).  Returns a list of ``((bytes, abs_max, zero_bitmap_cpu), y_q)``.
 
         The items are given either as sequences of ``[1, M, h, w]`` / ``[1, K*M, h, w]`` tensors (any mix of shapes)
         or, for items of one shape, stacked: ``y [N, M, h, w]``, parameters ``[N, K*M, h, w]`` — what a network
-        evaluated on a batch of images produces, and the cheaper form (one check, one allocation per output)."""
+        evaluated on a batch of images produces, and the cheaper form (one check, one allocation per output).
+
+        ``weights_are_logits``: ``weights`` holds the parameter head's logits and the softmax over K
+        (latent_codecs/gaussian_mixture_conditional.py:198-202) runs inside the HIP kernels — the pi plane is never written
+        and read back.  ``decompress`` must then be given the logits too."""
         if self.K != _lib.FGMM_K:
             raise RuntimeError(f"K = {self.K}: the coder is bound for K = 4 only (as the reference's)")
+        flags = _lib.FGMM_PARAMS_LOGITS if weights_are_logits else 0
         if isinstance(ys, Tensor):
-            return self._compress_stacked(ys, scales, means, weights)
+            return self._compress_stacked(ys, scales, means, weights, flags)
         n_items = len(ys)
         items = (_lib.fgmm_item * n_items)()
         keep: list = []
         outs, bitmaps = [], []
         dev = None
         for i in range(n_items):
-            it, M, hw, d = self._item(ys[i], scales[i], means[i], weights[i], keep)
+            it, M, hw, d = self._item(ys[i], scales[i], means[i], weights[i], keep, flags)
             dev = dev or d
             if d != dev:
                 raise RuntimeError("all items of a batch must be on one device")
@@ -241,26 +247,27 @@ class GaussianMixtureConditional(nn.Module):
             res.append(((data, int(items[i].abs_max), bitmaps[i]), outs[i].view_as(ys[i])))
         return res
 
-    def compress(self, y: Tensor, scales: Tensor, means: Tensor, weights: Tensor):
+    def compress(self, y: Tensor, scales: Tensor, means: Tensor, weights: Tensor, *, weights_are_logits: bool = False):
         """-> ((bytes, abs_max, zero_bitmap), y_quantized)     (entropy_models.py:833-867)"""
-        ((data, abs_max, zb), yq), = self.compress_batch([y], [scales], [means], [weights])
+        ((data, abs_max, zb), yq), = self.compress_batch([y], [scales], [means], [weights], weights_are_logits=weights_are_logits)
         return (data, abs_max, zb.to(y.device)), yq
 
     def decompress_batch(self, strings: Sequence[bytes], abs_maxes: Sequence[int], zero_bitmaps, scales, means,
-                         weights) -> List[Tensor]:
+                         weights, *, weights_are_logits: bool = False) -> List[Tensor]:
         """N independent ``decompress`` calls in one native call; parameters as sequences of ``[1, K*M, h, w]``
         tensors or stacked ``[N, K*M, h, w]`` (see ``compress_batch``).  Returns N ``[1, M, h, w]`` tensors."""
         if self.K != _lib.FGMM_K:
             raise RuntimeError(f"K = {self.K}: the coder is bound for K = 4 only (as the reference's)")
+        flags = _lib.FGMM_PARAMS_LOGITS if weights_are_logits else 0
         if isinstance(scales, Tensor):
-            return self._decompress_stacked(strings, abs_maxes, zero_bitmaps, scales, means, weights)
+            return self._decompress_stacked(strings, abs_maxes, zero_bitmaps, scales, means, weights, flags)
         n_items = len(strings)
         items = (_lib.fgmm_item * n_items)()
         keep: list = []
         outs = []
         dev = None
         for i in range(n_items):
-            it, M, hw, d = self._item(None, scales[i], means[i], weights[i], keep)
+            it, M, hw, d = self._item(None, scales[i], means[i], weights[i], keep, flags)
             dev = dev or d
             if d != dev:
                 raise RuntimeError("all items of a batch must be on one device")
@@ -288,9 +295,10 @@ class GaussianMixtureConditional(nn.Module):
         return outs
 
     def decompress(self, strings: bytes, abs_max: int, zero_bitmap: Tensor, scales: Tensor, means: Tensor,
-                   weights: Tensor) -> Tensor:
+                   weights: Tensor, *, weights_are_logits: bool = False) -> Tensor:
         """-> y_hat [1, M, h, w] float32     (entropy_models.py:872-910)"""
-        return self.decompress_batch([strings], [abs_max], [zero_bitmap], [scales], [means], [weights])[0]
+        return self.decompress_batch([strings], [abs_max], [zero_bitmap], [scales], [means], [weights],
+                                     weights_are_logits=weights_are_logits)[0]
 
 
 class EntropyBottleneckCoder(nn.Module):

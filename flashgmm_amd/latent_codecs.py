@@ -41,11 +41,18 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
     def __init__(self, K: int = 4, gaussian_mixture_conditional: Optional[GaussianMixtureConditional] = None,
                  entropy_parameters: Optional[nn.Module] = None, quantizer: str = "noise",
                  chunks: Tuple[str, ...] = ("scales", "means", "weights"), mode=None, param_dtype: torch.dtype = torch.float32,
-                 **kwargs: Any):
+                 fuse_softmax: bool = False, **kwargs: Any):
         super().__init__()
         if param_dtype not in (torch.float32, torch.float16):
             raise ValueError("param_dtype must be torch.float32 or torch.float16")
         self.param_dtype = param_dtype  # float16: BASELINE configs[4], "fp16 (mu, sigma, pi) with fp32 CDF accumulate"
+        # fuse_softmax: the softmax over K (:198-202) runs inside the HIP kernels, on the head's logits in place — the pi
+        # plane (16 B / latent written, 16 read back) never exists.  One fixed fp32 sequence on both sides of the codec:
+        # streams are self-consistent on any device; they are NOT the streams of the un-fused path (torch.softmax's pi
+        # differs in the last bit), so encoder and decoder must agree on this switch like on the Phi approximation.
+        if fuse_softmax and (quantizer != "noise" or param_dtype != torch.float32):
+            raise ValueError("fuse_softmax needs quantizer='noise' (the re-centring quantizer uses pi itself) and float32 planes")
+        self.fuse_softmax = bool(fuse_softmax)
         if quantizer not in ("noise", "weighted_mean_ste"):
             raise ValueError(f"quantizer {quantizer} not supported")
         if tuple(chunks) != ("scales", "means", "weights"):
@@ -70,7 +77,7 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
 
     def _params(self, ctx_params: Tensor):
         scales_hat, means_hat, weights = self._chunk(self.entropy_parameters(ctx_params))
-        return scales_hat, means_hat, self._reshape_gmm_weight(weights)
+        return scales_hat, means_hat, (weights if self.fuse_softmax else self._reshape_gmm_weight(weights))
 
     def _planes(self, scales: Tensor, means: Tensor, weights: Tensor):
         """the planes as the entropy model gets them: float32 as they are, or float16 copies — weights rounded TOWARD ZERO,
@@ -104,13 +111,14 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
 
     def compress(self, y: Tensor, ctx_params: Tensor) -> Dict[str, Any]:
         y_code, scales_hat, means_hat, weights = self.coder_inputs(y, ctx_params)
-        y_strings, y_hat = self.gaussian_mixture_conditional.compress(y_code, scales_hat, means_hat, weights)
+        y_strings, y_hat = self.gaussian_mixture_conditional.compress(y_code, scales_hat, means_hat, weights,
+                                                                      weights_are_logits=self.fuse_softmax)
         return {"strings": [y_strings], "shape": y.shape[2:4], "y_hat": y_hat}
 
     def compress_many(self, prepared: List[Tuple[Tensor, Tensor, Tensor, Tensor]]) -> List[Dict[str, Any]]:
         """``compress`` of several ``coder_inputs`` results in one batched native call."""
         ys, ss, ms, ws = zip(*prepared)
-        res = self.gaussian_mixture_conditional.compress_batch(list(ys), list(ss), list(ms), list(ws))
+        res = self.gaussian_mixture_conditional.compress_batch(list(ys), list(ss), list(ms), list(ws), weights_are_logits=self.fuse_softmax)
         return [{"strings": [(b, a, zb.to(y.device))], "shape": y.shape[2:4], "y_hat": yq}
                 for ((b, a, zb), yq), y in zip(res, ys)]
 
@@ -118,7 +126,8 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
         (y_strings,) = strings
         scales_hat, means_hat, weights = self._params(ctx_params)
         if self.quantizer == "noise":
-            y_hat = self.gaussian_mixture_conditional.decompress(*y_strings, *self._planes(scales_hat, means_hat, weights))
+            y_hat = self.gaussian_mixture_conditional.decompress(*y_strings, *self._planes(scales_hat, means_hat, weights),
+                                                                 weights_are_logits=self.fuse_softmax)
         else:
             weighted_sum, means_rel = self._recentre(means_hat, weights)
             y_hat = self.gaussian_mixture_conditional.decompress(*y_strings, *self._planes(scales_hat, means_rel, weights)) + weighted_sum
@@ -255,7 +264,7 @@ class ChannelGroupsLatentCodec(nn.Module):
         setting and one parameter dtype: what a batch of the entropy model must share)"""
         try:
             keys = {(c.latent_codec["y"].gaussian_mixture_conditional._mode(), c.latent_codec["y"].gaussian_mixture_conditional.clamp_scales,
-                     c.latent_codec["y"].param_dtype) for c in codecs if hasattr(c, "prepare") and hasattr(c, "finish")}
+                     c.latent_codec["y"].param_dtype, c.latent_codec["y"].fuse_softmax) for c in codecs if hasattr(c, "prepare") and hasattr(c, "finish")}
         except (AttributeError, KeyError, TypeError):
             return False
         return len(keys) == 1 and all(hasattr(c, "prepare") for c in codecs)

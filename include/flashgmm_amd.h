@@ -139,8 +139,13 @@ typedef struct {
                                             float32 exactly on load, then the float32 path runs unchanged — the result
                                             is that of the reference fed the widened values (the reference itself
                                             rejects half tensors: accessor<float,2>, rans_interface.cpp:478-480) */
-  int32_t reserved;
+  int32_t flags;                         /* FGMM_PARAMS_LOGITS: `weights` holds the parameter head's LOGITS; the kernels compute
+                                            pi = softmax over K themselves (the pi plane is never
+                                            written and read back), with one fixed binary32 sequence shared by the encode- and
+                                            the decode-side kernel — streams coded this way decode this way, on any device;
+                                            they differ from streams coded from torch.softmax's pi in the last bit of pi */
 } fgmm_params;
+#define FGMM_PARAMS_LOGITS 1
 
 /* compress(y, scales, means, weights) -> ((bytes, abs_max, zero_bitmap), y_quantized)
  *   yq_out        device float32[M*hw]  = round(y) (round-half-even)                    entropy_models.py:839
@@ -186,6 +191,10 @@ int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int
 int fgmm_gmm_cdf_hip(fgmm_ctx *ctx, void *stream, const int32_t *v, const float *scales, const float *means,
                      const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode, float *c1,
                      float *c2);
+
+/* GPU: the kernels' softmax over K on (n, 4) rows of logits -> weights (what FGMM_PARAMS_LOGITS computes in place of
+ * torch.softmax, gaussian_mixture_conditional.py:198-202; within 2e-7 of it).  Both pointers device, row-major (n, 4). */
+int fgmm_softmax4_hip(fgmm_ctx *ctx, void *stream, const float *logits, float *weights, int64_t n);
 
 /* GPU: encode-side symbol table.  packed[i] = start | range << 16 with start = (uint16)(c1*65535),
  * range = (uint16)(end - start); range == 0 marks the reference's bypass escape (rans_interface.cpp:512-517) and

@@ -680,6 +680,62 @@ def test_elic_channel_group_shapes(oracle):
         assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(ys[i]))
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_softmax_over_k_fused_into_the_kernels(oracle, mode):
+    """the kernels take the parameter head's LOGITS and compute pi = softmax over K themselves.
+    (1) the device sequence is within 1e-6 of torch.softmax (in fact ~2e-7), exact on the {0, -inf} logits of the exact
+    networks; (2) a stream coded from logits == the un-fused kernels fed that same pi == the oracle fed it, byte for byte:
+    the fusion changes where pi is computed, nothing else; (3) it decodes from logits; (4) through the latent codec."""
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    rng = np.random.default_rng(91)
+    M, h, w = 24, 16, 12
+    y, sg, mu, pi = T.make_latent(92, M=M, h=h, w=w, clamp=False, zero_frac=0.1)
+    lg = (rng.standard_normal((1, 4 * M, h, w)) * 3).astype(np.float32)
+    lg[0, :M, :2] = -np.inf        # a dead component
+    lg[0, M:2 * M, 3] = 60.0       # one that takes everything
+    lg[0, 2 * M:3 * M, 5] = -45.0  # below the e^-41 cut
+    # (1) the probe: rows (n, 4) = the four logits of a latent
+    rows = torch.from_numpy(np.ascontiguousarray(lg.reshape(4, -1).T)).to(DEV)
+    out = torch.empty_like(rows)
+    torch.cuda.synchronize()
+    _lib.check(L.fgmm_softmax4_hip(ctx, None, rows.data_ptr(), out.data_ptr(), rows.size(0)))
+    ref = torch.softmax(rows.double(), dim=1)
+    assert float((out.double() - ref).abs().max()) < 1e-6
+    assert float((out.sum(1) - 1).abs().max()) < 3e-7
+    exact = torch.tensor([[0.0, -np.inf, -np.inf, -np.inf], [0.0, 0.0, -np.inf, -np.inf], [0.0, 0.0, 0.0, 0.0], [5.0, 5.0, -np.inf, 5.0]], device=DEV)
+    oute = torch.empty_like(exact)
+    _lib.check(L.fgmm_softmax4_hip(ctx, None, exact.data_ptr(), oute.data_ptr(), 4))
+    assert torch.equal(oute[:3].cpu(), torch.tensor([[1.0, 0, 0, 0], [0.5, 0.5, 0, 0], [0.25] * 4]))
+    assert float((oute[3].cpu() - torch.tensor([1 / 3, 1 / 3, 0, 1 / 3])).abs().max()) < 1e-7
+    # (2) fused == un-fused on the device's pi == oracle on the device's pi
+    pi_dev = out.T.reshape(1, 4 * M, h, w).contiguous()
+    gmc = GaussianMixtureConditional(K=4, mode=mode)
+    t = [dv(a) for a in (y, sg, mu)]
+    (b, abs_max, zb), yq = gmc.compress(*t, dv(lg), weights_are_logits=True)
+    (b2, abs_max2, zb2), yq2 = gmc.compress(*t, pi_dev)
+    assert b == b2 and abs_max == abs_max2 and torch.equal(zb, zb2) and torch.equal(yq, yq2)
+    sym, s_, m_, w_, am, zbm, yqn = T.to_coder_inputs(y, sg, mu, pi_dev.cpu().numpy())
+    assert b == oracle.encode_gmm(mode, sym, s_, m_, w_)
+    # (3) decode from logits (both table kernels: the batched path and, with a tiny LDS budget, the generic one)
+    assert torch.equal(gmc.decompress(b, abs_max, zb, t[1], t[2], dv(lg), weights_are_logits=True), yq)
+    saved = _lib.get_option(0, "tab_cap_e")
+    try:
+        _lib.set_option(0, "tab_cap_e", 256)
+        assert torch.equal(gmc.decompress(b, abs_max, zb, t[1], t[2], dv(lg), weights_are_logits=True), yq)
+    finally:
+        _lib.set_option(0, "tab_cap_e", saved)
+    # (4) the latent codec with fuse_softmax: [scales | means | logits] in, no pi plane
+    from flashgmm_amd.latent_codecs import GaussianMixtureConditionalLatentCodec
+
+    codec = GaussianMixtureConditionalLatentCodec(K=4, mode=mode, fuse_softmax=True)
+    head = torch.cat([dv(sg), dv(mu), dv(lg)], dim=1)
+    enc = codec.compress(dv(y), head)
+    assert enc["strings"][0][0] == b
+    assert torch.equal(codec.decompress(enc["strings"], enc["shape"], head)["y_hat"], yq)
+    with pytest.raises(ValueError):
+        GaussianMixtureConditionalLatentCodec(K=4, quantizer="weighted_mean_ste", fuse_softmax=True)
+
+
 def test_config4_elic_4k_fp16_through_the_group_codec(oracle):
     """BASELINE configs[4] as stated: ELIC on a 4K image — y [1, 320, 136, 240], channel groups 16/16/32/64/192, each a
     checkerboard codec over the GMM entropy model (models/elic_gmm.py:198-219) — with fp16 (mu, sigma, pi) planes and fp32
