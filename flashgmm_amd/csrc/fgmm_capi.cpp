@@ -157,11 +157,12 @@ struct fgmm_ctx {
   char *h_ws = nullptr; // pinned
   size_t h_cap = 0;
   std::vector<hipEvent_t> events;
+  std::vector<hipEvent_t> sleep_events; // hipEventBlockingSync: waited for by the host workers (see ensure_events)
   hipStream_t copy_stream = nullptr; // bulk D2H of the decode tables (overlaps the table kernels of later launches)
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t tail_items = 8, tail_pieces = 4, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0;
+    int64_t tail_items = 16, tail_pieces = 4, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -260,11 +261,20 @@ struct fgmm_ctx {
     h_cap = want;
     return FGMM_OK;
   }
-  int ensure_events(size_t n) {
+  // `events` are waited for by the calling thread for microseconds (spinning is right); `sleep_events` mark the landing
+  // of table copies and are waited for by up to 16 host workers for up to milliseconds: those must SLEEP — a GPU box gives
+  // the process a CPU quota of 16 cores, and sixteen spinning waiters plus the calling thread exceed it, which the
+  // scheduler answers by throttling the whole process for the rest of its period (measured: +-10 % from run to run).
+  int ensure_events(size_t n, size_t n_sleep = 0) {
     while (events.size() < n) {
       hipEvent_t e;
       HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       events.push_back(e);
+    }
+    while (sleep_events.size() < n_sleep) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
+      sleep_events.push_back(e);
     }
     return FGMM_OK;
   }
@@ -708,12 +718,12 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   const size_t o_descs = ar.take(sizeof(DecDesc) * std::max<size_t>(n_parts, 1));
   const size_t o_counters = ar.take(kCounterBytes * (size_t)std::max(n_units, 1), 256);
   const size_t upload_bytes = o_counters;
-  // events: per unit [kernel done][counters landed][tables landed]
-  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off)) || (rc = ctx->ensure_events(3 * (size_t)std::max(n_units, 1) + 2)) ||
-      (rc = ctx->ensure_stage(stage_total)))
+  // events: per unit [kernel done][counters landed] (this thread waits, briefly) and [tables landed] (the workers wait)
+  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off)) ||
+      (rc = ctx->ensure_events(2 * (size_t)std::max(n_units, 1), (size_t)n_units + 2)) || (rc = ctx->ensure_stage(stage_total)))
     return rc;
   ctx->chunks_reset();
-  hipEvent_t *ev_kernel = ctx->events.data(), *ev_counters = ev_kernel + n_units, *ev_landed = ev_counters + n_units;
+  hipEvent_t *ev_kernel = ctx->events.data(), *ev_counters = ev_kernel + n_units, *ev_landed = ctx->sleep_events.data();
 
   // ---- channel lists, descriptors ------------------------------------------------------------------------------------
   for (int i = 0; i < count; ++i) {
@@ -1077,6 +1087,7 @@ void fgmm_ctx_destroy(fgmm_ctx *ctx) {
     DeviceGuard g(ctx->device);
     delete ctx->pool;
     for (auto e : ctx->events) (void)hipEventDestroy(e);
+    for (auto e : ctx->sleep_events) (void)hipEventDestroy(e);
     for (auto &pr : ctx->prof)
       for (auto e : pr)
         if (e) (void)hipEventDestroy(e);

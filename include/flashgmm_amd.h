@@ -76,7 +76,7 @@ int fgmm_ctx_threads(const fgmm_ctx *ctx);
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
 
 /* Tuning knobs of a context (defaults in brackets).  Unknown names return FGMM_ERR_INVALID.
- *   "tail_items"  [8]   decode: how many trailing bitstreams of a call land in pieces (a bitstream decodes sequentially:
+ *   "tail_items"  [16]  decode: how many trailing bitstreams of a call land in pieces (a bitstream decodes sequentially:
  *                       whatever lands last leaves one item of host work behind it)
  *   "tail_pieces" [4]   ... and in how many pieces each (1: whole), at most 8
  *   "dec_group"   [0]   decode: bitstreams per launch / copy (0: automatic)
