@@ -580,6 +580,20 @@ static int table_args_ok(const int32_t *cdfs, int64_t cdf_stride, int32_t n_cdfs
   return 1;
 }
 
+// Escape code of the table coder (rans_interface.cpp:373-397): the magnitude travels as raw 4-bit digits, least
+// significant first, behind their count; a count of 15 or more continues in further digits of 15.
+static void push_escape_digits(SymBuf &sb, uint32_t magnitude) {
+  int digits = 0;
+  for (uint32_t rest = magnitude; rest != 0 && digits < 8; rest >>= kBypassBits) ++digits;
+  int count = digits;
+  for (; count >= (int)kMaxBypassVal; count -= (int)kMaxBypassVal) sb.push(kMaxBypassVal, kMaxBypassVal + 1, true);
+  sb.push((uint32_t)count, (uint32_t)count + 1, true);
+  for (int d = 0; d < digits; ++d) {
+    const uint32_t digit = (magnitude >> (d * kBypassBits)) & kMaxBypassVal;
+    sb.push(digit, digit + 1, true);
+  }
+}
+
 int symbuf_append_table(SymBuf &sb, const int32_t *symbols, const int32_t *indexes, int64_t n, const int32_t *cdfs,
                         int64_t cdf_stride, int32_t n_cdfs, const int32_t *cdfs_sizes, const int32_t *offsets) {
   if (n < 0 || (n > 0 && (!symbols || !indexes))) return FGMM_ERR_INVALID;
@@ -587,34 +601,18 @@ int symbuf_append_table(SymBuf &sb, const int32_t *symbols, const int32_t *index
   if (!table_args_ok(cdfs, cdf_stride, n_cdfs, cdfs_sizes, offsets)) return FGMM_ERR_INVALID;
   sb.e.reserve(sb.e.size() + (size_t)n + 16);
   for (int64_t i = 0; i < n; ++i) {
-    const int32_t k = indexes[i];
-    if (k < 0 || k >= n_cdfs) return FGMM_ERR_INVALID;
-    const int32_t *cdf = cdfs + (int64_t)k * cdf_stride;
-    const int32_t max_value = cdfs_sizes[k] - 2; // :350
-    int64_t value = (int64_t)symbols[i] - offsets[k];
-    uint32_t raw_val = 0;
-    if (value < 0) { // :357-363 (the reference computes in int32: identical while |value| < 2^30)
-      raw_val = (uint32_t)(-2 * value - 1);
-      value = max_value;
-    } else if (value >= max_value) {
-      raw_val = (uint32_t)(2 * (value - max_value));
-      value = max_value;
-    }
-    sb.push((uint32_t)cdf[value], (uint32_t)(cdf[value + 1] - cdf[value]), false); // :368-370
-    if (value == max_value) { // bypass: nibble count in base-15 continuation, then the nibbles (:373-397)
-      int32_t n_bypass = 0;
-      while (n_bypass < 8 && (raw_val >> (n_bypass * kBypassBits)) != 0) ++n_bypass;
-      int32_t val = n_bypass;
-      while (val >= (int32_t)kMaxBypassVal) {
-        sb.push(kMaxBypassVal, kMaxBypassVal + 1, true);
-        val -= (int32_t)kMaxBypassVal;
-      }
-      sb.push((uint32_t)val, (uint32_t)val + 1, true);
-      for (int32_t j = 0; j < n_bypass; ++j) {
-        const uint32_t nib = (raw_val >> (j * kBypassBits)) & kMaxBypassVal;
-        sb.push(nib, nib + 1, true);
-      }
-    }
+    const int32_t t = indexes[i];
+    if (t < 0 || t >= n_cdfs) return FGMM_ERR_INVALID;
+    const int32_t *row = cdfs + (int64_t)t * cdf_stride;
+    // Slots 0 .. last-1 of a table code in-range symbols; the last slot announces an escape.  An out-of-range symbol is
+    // folded into one unsigned magnitude, odd for the ones below the table, even for the ones above (:350-363; the
+    // reference computes in int32: identical while |symbol - offset| < 2^30).
+    const int64_t last = (int64_t)cdfs_sizes[t] - 2, rel = (int64_t)symbols[i] - offsets[t];
+    const bool below = rel < 0, above = rel >= last;
+    const int64_t slot = (below || above) ? last : rel;
+    sb.push((uint32_t)row[slot], (uint32_t)(row[slot + 1] - row[slot]), false); // :368-370
+    if (below) push_escape_digits(sb, (uint32_t)(-2 * rel - 1));
+    else if (above) push_escape_digits(sb, (uint32_t)(2 * (rel - last)));
   }
   return FGMM_OK;
 }
@@ -737,36 +735,41 @@ int decstream_decode(DecStream &ds, const int32_t *indexes, int64_t n, const int
   return FGMM_OK;
 }
 
-// compressai._CXX.pmf_to_quantized_cdf, ops.cpp:40-109 (runs once per model; float -> integer, host)
+// compressai._CXX.pmf_to_quantized_cdf (ops.cpp:40-109; runs once per model; float -> integer, host), restated on
+// FREQUENCIES: the reference edits the cumulative array in place (a symbol left without a count shifts every entry
+// between itself and the donor by one); shifting cdf[a+1 .. b] by one is moving one count from symbol a to symbol b, so
+// the same result is: scale the rounded masses to 2^precision (each floored, the last symbol takes what is left),
+// then, symbol by symbol, give every empty one a count from the rarest symbol that can spare it (the first such on
+// ties), and only then accumulate.
 int pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf) {
   if (n <= 0 || !pmf || !cdf || precision < 1 || precision > 16) return FGMM_ERR_INVALID;
-  for (int i = 0; i < n; ++i)
-    if (pmf[i] < 0 || !std::isfinite(pmf[i])) return FGMM_ERR_INVALID;
-  cdf[0] = 0;
-  for (int i = 0; i < n; ++i) cdf[i + 1] = (uint32_t)std::round(pmf[i] * (float)(1 << precision));
-  uint32_t total = 0;
-  for (int i = 0; i <= n; ++i) total += cdf[i];
-  if (total == 0) return FGMM_ERR_INVALID;
-  for (int i = 0; i <= n; ++i) cdf[i] = (uint32_t)(((uint64_t)(1 << precision) * cdf[i]) / total);
-  for (int i = 1; i <= n; ++i) cdf[i] += cdf[i - 1];
-  cdf[n] = 1u << precision;
+  const uint64_t full = 1ull << precision;
+  std::vector<uint64_t> mass((size_t)n);
+  uint64_t total = 0;
   for (int i = 0; i < n; ++i) {
-    if (cdf[i] != cdf[i + 1]) continue;
-    uint32_t best_freq = ~0u; // steal one count from the rarest symbol that can spare it
-    int best_steal = -1;
-    for (int j = 0; j < n; ++j) {
-      const uint32_t freq = cdf[j + 1] - cdf[j];
-      if (freq > 1 && freq < best_freq) {
-        best_freq = freq;
-        best_steal = j;
-      }
-    }
-    if (best_steal < 0) return FGMM_ERR_INVALID; // more symbols than 2^precision counts (the reference asserts)
-    if (best_steal < i)
-      for (int j = best_steal + 1; j <= i; ++j) cdf[j]--;
-    else
-      for (int j = i + 1; j <= best_steal; ++j) cdf[j]++;
+    if (!(pmf[i] >= 0) || !std::isfinite(pmf[i])) return FGMM_ERR_INVALID;
+    mass[(size_t)i] = (uint64_t)std::round(pmf[i] * (float)full);
+    total += mass[(size_t)i];
   }
+  if (total == 0) return FGMM_ERR_INVALID;
+  std::vector<uint32_t> freq((size_t)n);
+  uint64_t used = 0;
+  for (int i = 0; i + 1 < n; ++i) {
+    freq[(size_t)i] = (uint32_t)(full * mass[(size_t)i] / total);
+    used += freq[(size_t)i];
+  }
+  freq[(size_t)n - 1] = (uint32_t)(full - used); // the reference pins the last cumulative entry to 2^precision
+  for (int i = 0; i < n; ++i) {
+    if (freq[(size_t)i] != 0) continue;
+    int donor = -1;
+    for (int j = 0; j < n; ++j)
+      if (freq[(size_t)j] > 1 && (donor < 0 || freq[(size_t)j] < freq[(size_t)donor])) donor = j;
+    if (donor < 0) return FGMM_ERR_INVALID; // more symbols than 2^precision counts (the reference asserts)
+    --freq[(size_t)donor];
+    ++freq[(size_t)i];
+  }
+  cdf[0] = 0;
+  for (int i = 0; i < n; ++i) cdf[i + 1] = cdf[i] + freq[(size_t)i];
   return FGMM_OK;
 }
 
