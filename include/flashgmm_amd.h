@@ -184,6 +184,8 @@ int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int
 
 /* ------------------------------------------------------------------------------------------------------------
  * 3. Building blocks ("same tables => same bytes" surfaces; also what the parity tests probe).
+ *    SURVEY.md section 8(b) also lists fgmm_build_symtab_host / fgmm_build_cdftab_host: they do not exist on purpose —
+ *    this library has no CPU implementation of the float work; the GPU builders below are the only ones.
  * ---------------------------------------------------------------------------------------------------------- */
 
 /* GPU: float mixture-CDF pair per symbol, c1 = cdf(v - 0.5), c2 = cdf(v - 0.5 + 1.0)  (rans_interface.cpp:498-501).
