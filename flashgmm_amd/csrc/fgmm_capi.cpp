@@ -162,7 +162,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t tail_items = 16, tail_pieces = 4, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0;
+    int64_t pieces = 4, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -400,7 +400,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     if ((rc = ctx->prof_end(2, stream))) return rc;
   }
   if ((rc = ctx->prof_begin(0, stream))) return rc;
-  const int vec = vec4 ? (ctx->opt.enc_vec == 1 ? 1 : 4) : 1; // option "enc_vec" = 1: A/B the narrow loads
+  const int vec = vec4 ? (ctx->opt.enc_vec == 1 ? 1 : ctx->opt.enc_vec == 2 ? 2 : 4) : 1; // option "enc_vec" = 1, 2: A/B narrower loads
   int64_t n_max = 0;
   bool linear = ctx->opt.enc_linear != 0; // option "enc_linear" = 0: A/B the per-channel grid
   for (auto &it : items) {
@@ -554,12 +554,13 @@ struct DecItem {
   int32_t tl = 0;     // latents per block of the single-pass kernel; 0: generic two-pass path
   int64_t nblk = 0;   // blocks of tl latents
   uint64_t table_bytes = 0; // headers + block offsets + rows that crossed PCIe
-  // how the tables reach the host (see decode_batch): whole, or in n_piece pieces for the items of the tail window
+  // how the tables reach the host (see decode_batch): in n_piece pieces (block ranges)
   int n_piece = 1;
   TabPiece piece[kMaxPieces] = {};
   hipEvent_t piece_ev[kMaxPieces] = {}; // recorded (this call) before the item's job is submitted
   char *h_out = nullptr;                // pinned: decoded symbols (host-written, read by the scatter kernel)
   int wide = 0; // h_out holds int32 symbols (some symbol outside int16), else int16
+  int queued = 0;                       // pieces whose copy is queued (guarded by the call's mutex)
   std::atomic<int> done{0};
   double t_taken = 0, t_start = 0, t_end = 0; // trace level 2: job timeline
   DecItem() = default;
@@ -646,39 +647,43 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     size_t fixed = 0, rows_cap = 0; // bytes: headers + block offsets | provisioned rows
     size_t o_stage = 0;             // where the unit's range starts in the staging area
     char *d_range = nullptr;        // device: [fixed | rows]
-    bool tail = false;
   };
   std::vector<Unit> units;
+  // Every item crosses in `np` pieces (block ranges), PIECE-MAJOR: piece 0 of every item, then piece 1 ...  A host worker
+  // owns the items k, k + T, k + 2T ... (T workers) and follows them piece by piece, so all workers start on the first
+  // round and what is left after the last copy is one piece per owned item, not one item.  Within a round the items of
+  // the workers that own the most come first.  The first round is cut into small launches + copies (the first tables reach
+  // the host as early as possible), later rounds are one launch + one copy each.
+  const int T = std::max(ctx->pool->size(), 1);
+  int np = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.pieces, 1), kMaxPieces);
   {
-    const int n_piece = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tail_pieces, 1), kMaxPieces);
-    int tail_items = n_piece > 1 ? (int)std::min<int64_t>({std::max<int64_t>(ctx->opt.tail_items, 0), (int64_t)n_fast,
-                                                            (int64_t)std::max(ctx->pool->size(), 1)}) : 0;
-    if (tail_items) { // pieces only pay for rows that take a while to cross: a small tail travels whole
-      int64_t lat = 0;
-      for (int k = n_fast - tail_items; k < n_fast; ++k) lat += items[fast[k]].n;
-      if (lat < 65536) tail_items = 0;
-    }
-    const int tail_begin = n_fast - tail_items;
-    const int steady = ctx->opt.dec_group > 0 ? (int)ctx->opt.dec_group : (n_fast >= 16 ? std::max(2, n_fast / 8) : std::max(n_fast, 1));
-    int k = 0, sz = n_fast >= 16 ? (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.dec_first, 1), steady) : std::max(n_fast, 1);
-    while (k < tail_begin) {
-      Unit u;
-      const int k1 = std::min(k + sz, tail_begin);
-      for (; k < k1; ++k) u.parts.push_back(Part{fast[k], 0, items[fast[k]].nblk, 0, 0, 0});
-      units.push_back(std::move(u));
-      sz = std::min(steady, sz * 2);
-    }
-    for (int p = 0; p < n_piece && tail_items; ++p) {
-      Unit u;
-      u.tail = true;
-      for (int t = tail_begin; t < n_fast; ++t) {
-        const DecItem &it = items[fast[t]];
-        const int64_t b0 = it.nblk * p / n_piece, b1 = it.nblk * (p + 1) / n_piece;
-        u.parts.push_back(Part{fast[t], b0, b1, 0, 0, p});
+    int64_t lat = 0;
+    for (int k = 0; k < n_fast; ++k) lat += items[fast[k]].n;
+    if (lat < 65536) np = 1; // pieces only pay for rows that take a while to cross
+  }
+  std::vector<std::vector<int>> owned((size_t)T); // items of each worker, in coding order
+  for (int k = 0; k < n_fast; ++k) owned[(size_t)(k % T)].push_back(fast[k]);
+  std::vector<int> order; // landing order within a round
+  for (int load = (n_fast + T - 1) / T; load >= 1; --load)
+    for (int j = 0; j < T; ++j)
+      if ((int)owned[(size_t)j].size() == load)
+        for (int i : owned[(size_t)j]) order.push_back(i);
+  {
+    const int steady = ctx->opt.dec_group > 0 ? (int)ctx->opt.dec_group : std::max(n_fast, 1);
+    for (int p = 0; p < np && n_fast; ++p) {
+      int k = 0, sz = p == 0 && n_fast >= 8 ? (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.dec_first, 1), steady) : steady;
+      while (k < n_fast) {
+        Unit u;
+        const int k1 = std::min(k + sz, n_fast);
+        for (; k < k1; ++k) {
+          const DecItem &it = items[order[(size_t)k]];
+          u.parts.push_back(Part{order[(size_t)k], it.nblk * p / np, it.nblk * (p + 1) / np, 0, 0, p});
+        }
+        units.push_back(std::move(u));
+        sz = std::min(steady, sz * 2);
       }
-      units.push_back(std::move(u));
     }
-    for (int t = 0; t < n_fast; ++t) items[fast[t]].n_piece = (t >= tail_begin && tail_items) ? n_piece : 1;
+    for (int k = 0; k < n_fast; ++k) items[fast[k]].n_piece = np;
   }
   const int n_units = (int)units.size();
   size_t n_parts = 0, stage_total = 0, rows_worst_total = 0;
@@ -809,57 +814,101 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   if ((rc = ctx->prof_end(1, stream))) return rc; // brackets every table kernel of the call
   tr.mark("enqueued");
 
-  std::mutex done_mu;
-  std::condition_variable done_cv;
-  auto submit_job = [&](int i) { // the item's piece events have been recorded
-    DecItem *pit = &items[i];
-    pit->t_taken = tr.ms();
-    auto job = [pit, &done_mu, &done_cv, &tr] {
-      // decoded symbols: the caller's buffer, or a per-thread scratch (a fresh 600 KB malloc per stream is an mmap)
-      static thread_local std::vector<int32_t> scratch;
-      int32_t *sym = pit->sym_host_out;
-      if (!sym) {
-        try {
-          if (scratch.size() < (size_t)std::max<int64_t>(pit->n, 1)) scratch.resize((size_t)std::max<int64_t>(pit->n, 1));
-          sym = scratch.data();
-        } catch (const std::bad_alloc &) {
-          sym = nullptr;
-        }
-      }
-      if (pit->status != FGMM_OK) { // failed before its tables were built
-      } else if (!sym) {
-        pit->status = FGMM_ERR_NOMEM;
-      } else if (hipEventSynchronize(pit->piece_ev[0]) != hipSuccess) { // the item's (first) copy
-        pit->status = FGMM_ERR_HIP;
-      } else {
-        pit->t_start = tr.ms();
-        const TabView tv{pit->ef_min, pit->hdr_form, pit->tl, pit->n_piece, pit->piece, pit, [](void *arg, int k) -> int {
-                           return hipEventSynchronize(static_cast<DecItem *>(arg)->piece_ev[k]) == hipSuccess ? (int)FGMM_OK : (int)FGMM_ERR_HIP;
-                         }};
-        pit->status = rans_decode_tab(pit->enc, pit->enc_len, tv, pit->n, pit->max_bs, sym);
-        if (pit->status == FGMM_OK && pit->y_hat) {
-          // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
-          int16_t *s16 = reinterpret_cast<int16_t *>(pit->h_out);
-          int32_t acc = 0;
-          for (int64_t k = 0; k < pit->n; ++k) {
-            const int32_t v = sym[k];
-            s16[k] = (int16_t)v;
-            acc |= v ^ (int32_t)(int16_t)v;
+  std::mutex done_mu; // guards: items[].done, items[].queued, abandon
+  std::condition_variable done_cv, queued_cv;
+  bool abandon = false; // this call is returning early: jobs must not wait for copies that will never be queued
+  // one worker's share: its items followed piece by piece as their tables land
+  auto run_items = [&](const std::vector<int> &mine) {
+    static thread_local std::vector<int32_t> scratch; // decoded symbols (a fresh 600 KB malloc per stream is an mmap)
+    size_t need = 0;
+    for (int i : mine) need += items[i].sym_host_out ? 0 : (size_t)std::max<int64_t>(items[i].n, 1);
+    bool nomem = false;
+    try {
+      if (scratch.size() < need) scratch.resize(need);
+    } catch (const std::bad_alloc &) {
+      nomem = true;
+    }
+    std::vector<TabDecoder> dec(mine.size());
+    std::vector<TabView> views(mine.size());
+    std::vector<int32_t *> sym(mine.size(), nullptr);
+    size_t at = 0;
+    int np_max = 1;
+    for (size_t m = 0; m < mine.size(); ++m) {
+      DecItem &it = items[mine[m]];
+      it.t_taken = tr.ms();
+      sym[m] = it.sym_host_out ? it.sym_host_out : (nomem ? nullptr : scratch.data() + at);
+      if (!it.sym_host_out) at += (size_t)std::max<int64_t>(it.n, 1);
+      views[m] = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
+      if (it.status == FGMM_OK) it.status = !sym[m] ? (int)FGMM_ERR_NOMEM : dec[m].begin(it.enc, it.enc_len, &views[m], it.n, it.max_bs, sym[m]);
+      np_max = std::max(np_max, it.n_piece);
+    }
+    for (int p = 0; p < np_max; ++p)
+      for (size_t m = 0; m < mine.size(); ++m) {
+        DecItem &it = items[mine[m]];
+        if (it.status != FGMM_OK || p >= it.n_piece) continue;
+        {
+          std::unique_lock<std::mutex> l(done_mu); // the piece's copy is queued (its event recorded in THIS call)?
+          queued_cv.wait(l, [&] { return abandon || it.queued > p; });
+          if (it.queued <= p) {
+            it.status = FGMM_ERR_HIP;
+            continue;
           }
-          pit->wide = acc != 0;
-          if (pit->wide) memcpy(pit->h_out, sym, sizeof(int32_t) * (size_t)pit->n);
         }
+        if (hipEventSynchronize(it.piece_ev[p]) != hipSuccess) {
+          it.status = FGMM_ERR_HIP;
+          continue;
+        }
+        if (p == 0) it.t_start = tr.ms();
+        it.status = dec[m].piece(p);
       }
-      pit->t_end = tr.ms();
+    for (size_t m = 0; m < mine.size(); ++m) {
+      DecItem &it = items[mine[m]];
+      const int rf = dec[m].finish();
+      if (it.status == FGMM_OK) it.status = rf;
+      if (it.status == FGMM_OK && it.y_hat) {
+        // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
+        int16_t *s16 = reinterpret_cast<int16_t *>(it.h_out);
+        int32_t acc = 0;
+        for (int64_t k = 0; k < it.n; ++k) {
+          const int32_t v = sym[m][k];
+          s16[k] = (int16_t)v;
+          acc |= v ^ (int32_t)(int16_t)v;
+        }
+        it.wide = acc != 0;
+        if (it.wide) memcpy(it.h_out, sym[m], sizeof(int32_t) * (size_t)it.n);
+      }
+      it.t_end = tr.ms();
       {
         std::lock_guard<std::mutex> l(done_mu);
-        pit->done.store(1);
+        it.done.store(1);
       }
       done_cv.notify_all();
-    };
-    if (count == 1) job(); else ctx->pool->submit(job);
+    }
+  };
+  auto submit_job = [&](int i) { // a single item whose pieces are all queued (generic path, single-item calls)
+    if (count == 1) run_items({i}); else ctx->pool->submit([&run_items, i] { run_items({i}); });
+  };
+  auto mark_queued = [&](DecItem &it, int pieces) {
+    {
+      std::lock_guard<std::mutex> l(done_mu);
+      it.queued = pieces;
+    }
+    queued_cv.notify_all();
+  };
+  struct Abandon { // any return: release jobs that wait for copies (before PoolDrain waits for the jobs)
+    std::mutex &mu;
+    std::condition_variable &cv;
+    bool &flag;
+    ~Abandon() {
+      {
+        std::lock_guard<std::mutex> l(mu);
+        flag = true;
+      }
+      cv.notify_all();
+    }
   };
   PoolDrain drain{ctx->pool}; // on any return: wait for every job before the objects they use go away
+  Abandon abandon_on_exit{done_mu, queued_cv, abandon};
   TempDevice temp;
 
   // pinned output areas (decoded symbols) of all items
@@ -875,9 +924,12 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
   }
 
-  // ---- unit by unit: size known -> pinned range, ONE copy, jobs -------------------------------------------------------
+  if (count > 1)
+    for (int j = 0; j < T; ++j)
+      if (!owned[(size_t)j].empty()) ctx->pool->submit([&run_items, &owned, j] { run_items(owned[(size_t)j]); });
+
+  // ---- unit by unit: size known -> pinned range, ONE copy; the workers are told ----------------------------------------
   unsigned long long edges = 0;
-  std::vector<int> tail_jobs;
   for (int u = 0; u < n_units; ++u) {
     Unit &un = units[(size_t)u];
     HIP_TRY(hipEventSynchronize(ev_counters[u]));
@@ -917,13 +969,12 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.piece_ev[p.piece] = ev_landed[u];
       const int64_t lat = pc.end - std::min<int64_t>(p.blk_begin * it.tl, it.n);
       it.table_bytes += (uint64_t)it.hdr_form * (uint64_t)lat + sizeof(uint32_t) * (uint64_t)(p.blk_end - p.blk_begin);
-      if (!un.tail) submit_job(p.item); // its one copy is queued
-      else if (p.piece == 0) tail_jobs.push_back(p.item);
+      mark_queued(it, p.piece + 1); // pieces reach an item in order: rounds are piece-major
     }
     // rows are shared by the unit's items: account them once
     if (!un.parts.empty()) items[un.parts[0].item].table_bytes += used;
   }
-  for (int i : tail_jobs) submit_job(i); // every piece's copy is queued: the events the decoders wait on are this call's
+  if (count == 1 && n_fast == 1) run_items({fast[0]});
   tr.mark("sizes known, copies queued");
 
   // ---- generic path: items too wide for the single-pass kernel, one at a time ------------------------------------------
@@ -934,6 +985,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.piece[0] = TabPiece{ctx->h_ws, nullptr, reinterpret_cast<const uint8_t *>(ctx->h_ws), 0, 0};
       it.piece_ev[0] = ev_landed[n_units];
       HIP_TRY(hipEventRecord(ev_landed[n_units], stream));
+      mark_queued(it, 1);
       submit_job(i);
       continue;
     }
@@ -965,6 +1017,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.status = FGMM_ERR_UNSUPPORTED;
       it.piece_ev[0] = ev_landed[n_units];
       HIP_TRY(hipEventRecord(ev_landed[n_units], stream));
+      mark_queued(it, 1);
       submit_job(i);
       continue;
     }
@@ -982,6 +1035,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.piece_ev[0] = ev_landed[n_units]; // nothing left to wait for: the stream has just been synchronised
     HIP_TRY(hipEventRecord(ev_landed[n_units], stream));
     it.table_bytes = hdr_bytes + pool_bytes;
+    mark_queued(it, 1);
     submit_job(i);
   }
 
@@ -1043,8 +1097,7 @@ struct OptName {
   const char *env; // read once at context creation (compatibility with round-1 scripts)
 };
 const OptName kOpts[] = {
-    {"tail_items", &fgmm_ctx::Opts::tail_items, 0, 1 << 20, "FGMM_TAIL_ITEMS"},
-    {"tail_pieces", &fgmm_ctx::Opts::tail_pieces, 1, kMaxPieces, "FGMM_TAIL_PIECES"},
+    {"pieces", &fgmm_ctx::Opts::pieces, 1, kMaxPieces, "FGMM_PIECES"},
     {"dec_group", &fgmm_ctx::Opts::dec_group, 0, 1 << 20, "FGMM_DEC_GROUP"},
     {"dec_first", &fgmm_ctx::Opts::dec_first, 1, 1 << 20, "FGMM_DEC_FIRST"},
     {"tab_cap_e", &fgmm_ctx::Opts::tab_cap_e, 256, 32768, "FGMM_TAB_CAP_E"},

@@ -55,6 +55,14 @@ template <> __device__ __forceinline__ void ld4<_Float16>(const void *base, int6
   out[0] = (float)v[0]; out[1] = (float)v[1]; out[2] = (float)v[2]; out[3] = (float)v[3];
 }
 
+// N consecutive parameters (N = 2, 4), widened to float
+template <typename PT, int N> __device__ __forceinline__ void ldv(const void *base, int64_t idx, float (&out)[N]) {
+  typedef PT pvec_t __attribute__((ext_vector_type(N)));
+  const pvec_t v = ldg<pvec_t>(static_cast<const PT *>(base) + idx);
+#pragma unroll
+  for (int e = 0; e < N; ++e) out[e] = (float)v[e];
+}
+
 __device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t *s_tmp) { // kBlock threads, result in all
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

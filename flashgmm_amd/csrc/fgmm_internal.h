@@ -178,5 +178,21 @@ struct TabView {
   int (*wait)(void *arg, int k); // FGMM_OK or an error status; null when npiece == 1
 };
 int rans_decode_tab(const uint8_t *enc, size_t enc_len, const TabView &tv, int64_t n, int32_t max_bs, int32_t *out);
+// the same, one piece at a time: begin(), then piece(0), piece(1) ... each once its tables have landed, then finish()
+struct TabDecoder {
+  const TabView *tv = nullptr;
+  int64_t n = 0, i = 0;
+  int32_t max_bs = 0;
+  int32_t *out = nullptr;
+  int next_piece = 0, rc = 0;
+  uint64_t x = 0;            // rANS state
+  const uint32_t *ptr = nullptr, *end_ = nullptr;
+  uint32_t *copy = nullptr;  // aligned copy of a misaligned bitstream
+  uint16_t *scratch = nullptr;
+  size_t scratch_cap = 0;
+  int begin(const uint8_t *enc, size_t enc_len, const TabView *view, int64_t n, int32_t max_bs, int32_t *out);
+  int piece(int k);
+  int finish();
+};
 
 } // namespace fgmm

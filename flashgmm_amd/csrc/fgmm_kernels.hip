@@ -178,38 +178,39 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
   const int c = d.chan_list ? d.chan_list[rank] : rank;
   int nbypass = 0;
   if (!active) {
-  } else if constexpr (VEC == 4) {
-    // planar, aligned (checked by the host): one 4-wide load per plane per lane (16 B fp32 / 8 B fp16)
+  } else if constexpr (VEC > 1) {
+    // planar, aligned (checked by the host): one VEC-wide load per plane per lane (16 B fp32 / 8 B fp16 at VEC = 4)
+    typedef float fvec_t __attribute__((ext_vector_type(VEC)));
+    typedef int ivec_t __attribute__((ext_vector_type(VEC)));
+    typedef uint32_t uvec_t __attribute__((ext_vector_type(VEC)));
     const int64_t base = (int64_t)c * d.stride_c + p0;
-    float vq[4];
-    int vi[4];
+    float vq[VEC];
+    int vi[VEC];
     if (d.sym) {
-      typedef int int4_t __attribute__((ext_vector_type(4)));
-      const int4_t t = ldg<int4_t>(d.sym + (int64_t)c * hw + p0);
+      const ivec_t t = ldg<ivec_t>(d.sym + (int64_t)c * hw + p0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < VEC; ++e) {
         vi[e] = t[e];
         vq[e] = (float)vi[e];
       }
     } else {
-      const float4_t t = ldg<float4_t>(d.y + (int64_t)c * hw + p0);
+      const fvec_t t = ldg<fvec_t>(d.y + (int64_t)c * hw + p0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < VEC; ++e) {
         vq[e] = __builtin_rintf(t[e]);
         vi[e] = (int)vq[e];
       }
     }
-    float S[4][4], Mu[4][4], Pi[4][4];
+    float S[4][VEC], Mu[4][VEC], Pi[4][VEC];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      ld4<PT>(d.scales, base + k * d.stride_k, S[k]);
-      ld4<PT>(d.means, base + k * d.stride_k, Mu[k]);
-      ld4<PT>(d.weights, base + k * d.stride_k, Pi[k]);
+      ldv<PT, VEC>(d.scales, base + k * d.stride_k, S[k]);
+      ldv<PT, VEC>(d.means, base + k * d.stride_k, Mu[k]);
+      ldv<PT, VEC>(d.weights, base + k * d.stride_k, Pi[k]);
     }
-    typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
-    uint4_t out;
+    uvec_t out;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < VEC; ++e) {
       float mu[4], sg[4], pi[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
       out[e] = sym_entry<MODE, CLAMPED>(vq[e], vi[e], mu, sg, pi, bp);
       nbypass += bp;
     }
-    stg<uint4_t>(d.packed + (int64_t)rank * hw + p0, out);
+    stg<uvec_t>(d.packed + (int64_t)rank * hw + p0, out);
   } else {
     const int64_t base = (int64_t)c * d.stride_c + p0 * d.stride_p;
     float vq;
@@ -498,6 +499,8 @@ static int launch_symtab_t(const EncDesc *d, int count, int M_max, int64_t hw_ma
                            hipStream_t s) {
   if (vec == 4) return clamped ? launch_symtab_v<4, true, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s)
                                : launch_symtab_v<4, false, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s);
+  if (vec == 2) return clamped ? launch_symtab_v<2, true, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s)
+                               : launch_symtab_v<2, false, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s);
   return clamped ? launch_symtab_v<1, true, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s)
                  : launch_symtab_v<1, false, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s);
 }

@@ -406,156 +406,191 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow 
 
 } // namespace
 
-// The decoder proper: walks the latents in order; per latent the header gives (a, cnt, nonmono), the row follows in
-// the pool.  Every row extent is checked against the piece's row area before it is touched (a table is trusted to be
-// well-formed only as far as memory safety does not depend on it).
-int rans_decode_tab(const uint8_t *enc, size_t enc_len, const TabView &tv, int64_t n, int32_t max_bs, int32_t *out) {
-  if (n < 0 || !enc || (n > 0 && (!out || !tv.piece || tv.npiece < 1))) return FGMM_ERR_INVALID;
-  if (tv.hdr_form != 2 && tv.hdr_form != 4 && tv.hdr_form != 8) return FGMM_ERR_INVALID;
-  if (enc_len < 8 || (enc_len & 3)) return FGMM_ERR_STREAM;
+// The decoder proper, resumable piece by piece (a host worker may follow several bitstreams as their tables land):
+// walks the latents in order; per latent the header gives (a, cnt, nonmono), the row follows in the pool.  Every row
+// extent is checked against the piece's row area before it is touched (a table is trusted to be well-formed only as far
+// as memory safety does not depend on it).
+int TabDecoder::begin(const uint8_t *enc, size_t enc_len, const TabView *view, int64_t n_, int32_t max_bs_, int32_t *out_) {
+  tv = view;
+  n = n_;
+  max_bs = max_bs_;
+  out = out_;
+  i = 0;
+  next_piece = 0;
+  rc = FGMM_OK;
+  copy = nullptr;
+  scratch = nullptr;
+  scratch_cap = 0;
+  if (n < 0 || !enc || (n > 0 && (!out || !tv || !tv->piece || tv->npiece < 1))) return rc = FGMM_ERR_INVALID;
+  if (tv && tv->hdr_form != 2 && tv->hdr_form != 4 && tv->hdr_form != 8) return rc = FGMM_ERR_INVALID;
+  if (enc_len < 8 || (enc_len & 3)) return rc = FGMM_ERR_STREAM;
   const uint32_t *words;
-  uint32_t *copy = nullptr;
   if (reinterpret_cast<uintptr_t>(enc) & 3) { // Python bytes are aligned in practice; stay safe
     copy = (uint32_t *)malloc(enc_len);
-    if (!copy) return FGMM_ERR_NOMEM;
+    if (!copy) return rc = FGMM_ERR_NOMEM;
     memcpy(copy, enc, enc_len);
     words = copy;
   } else {
     words = reinterpret_cast<const uint32_t *>(enc);
   }
-  Dec d;
-  d.x = (uint64_t)words[0] | ((uint64_t)words[1] << 32); // Rans64DecInit
-  d.ptr = words + 2;
-  d.end = words + enc_len / 4;
-  uint16_t *scratch = nullptr; // an EF row expanded for the (rare) bisection replay
-  size_t scratch_cap = 0;
-  int rc = FGMM_OK;
-  const int64_t W = 2 * (int64_t)max_bs + 2;
+  x = (uint64_t)words[0] | ((uint64_t)words[1] << 32); // Rans64DecInit
+  ptr = words + 2;
+  end_ = words + enc_len / 4;
+  return FGMM_OK;
+}
 
-  int64_t i = 0;
-  for (int k = 0; k < tv.npiece && i < n && rc == FGMM_OK; ++k) {
-    if (k > 0 && tv.wait && (rc = tv.wait(tv.arg, k)) != FGMM_OK) break;
-    const TabPiece &pc = tv.piece[k];
-    const int64_t i_beg = i, i_end = pc.end < n ? pc.end : n;
-    const uint8_t *const rows_end = pc.rows + pc.rows_len;
-    const uint8_t *rowp = pc.rows; // sequential placement: a running sum, never stored
-    const int64_t tl = pc.blk_off ? (tv.tl > 0 ? tv.tl : 1) : (i_end - i_beg > 0 ? i_end - i_beg : 1);
-    for (int64_t blk = 0; i < i_end; ++blk) {
-      const int64_t b_end = i + tl < i_end ? i + tl : i_end;
-      if (pc.blk_off) {
-        rowp = pc.rows + 4 * (size_t)pc.blk_off[blk];
-        if (__builtin_expect(rowp > rows_end, 0)) { rc = FGMM_ERR_INVALID; break; }
-        // blocks lie in no particular order: the running prefetch below (1 KiB ahead of the row being searched) runs off
-        // the end of this block into someone else's rows, so the head of the NEXT block is fetched here, a block ahead
-        if (b_end < i_end) {
-          const uint8_t *nx = pc.rows + 4 * (size_t)pc.blk_off[blk + 1];
-          if (nx + 1024 <= rows_end)
-            for (int q = 0; q < 1024; q += 64) __builtin_prefetch(nx + q);
-        }
+// decodes the latents of piece k (pieces before it are done, its tables are on the host)
+int TabDecoder::piece(int k) {
+  if (rc != FGMM_OK) return rc;
+  if (k != next_piece || !tv || k >= tv->npiece) return rc = FGMM_ERR_INVALID;
+  ++next_piece;
+  if (i >= n) return FGMM_OK;
+  Dec dec;
+  dec.x = x;
+  dec.ptr = ptr;
+  dec.end = end_;
+  const int64_t W = 2 * (int64_t)max_bs + 2;
+  const TabPiece &pc = tv->piece[k];
+  const int64_t i_beg = i, i_end = pc.end < n ? pc.end : n;
+  const uint8_t *const rows_end = pc.rows + pc.rows_len;
+  const uint8_t *rowp = pc.rows; // sequential placement: a running sum, never stored
+  const int64_t tl = pc.blk_off ? (tv->tl > 0 ? tv->tl : 1) : (i_end - i_beg > 0 ? i_end - i_beg : 1);
+  for (int64_t blk = 0; i < i_end; ++blk) {
+    const int64_t b_end = i + tl < i_end ? i + tl : i_end;
+    if (pc.blk_off) {
+      rowp = pc.rows + 4 * (size_t)pc.blk_off[blk];
+      if (__builtin_expect(rowp > rows_end, 0)) { rc = FGMM_ERR_INVALID; break; }
+      // blocks lie in no particular order: the running prefetch below (1 KiB ahead of the row being searched) runs off
+      // the end of this block into someone else's rows, so the head of the NEXT block is fetched here, a block ahead
+      if (b_end < i_end) {
+        const uint8_t *nx = pc.rows + 4 * (size_t)pc.blk_off[blk + 1];
+        if (nx + 1024 <= rows_end)
+          for (int q = 0; q < 1024; q += 64) __builtin_prefetch(nx + q);
       }
-      for (; i < b_end; ++i) {
-        __builtin_prefetch(rowp + 1024);
-        __builtin_prefetch(rowp + 1024 + 64);
-        int64_t a;
-        int64_t cnt;
-        uint32_t nonmono;
-        const int64_t li = i - i_beg;
-        if (tv.hdr_form == 2) { // (a + max_bs) | cnt << 8; cnt 255: the row carries a 4-byte header
-          const uint32_t c = static_cast<const uint16_t *>(pc.hdr)[li];
-          a = (int64_t)(c & 0xFFu) - max_bs;
-          cnt = c >> 8;
-          nonmono = 0;
-          if (__builtin_expect(cnt == kHdr2Escape, 0)) {
-            if (rows_end - rowp < 4) { rc = FGMM_ERR_INVALID; break; }
-            uint32_t h;
-            memcpy(&h, rowp, 4);
-            rowp += 4;
-            a = tab_hdr_a(h);
-            cnt = tab_hdr_cnt(h);
-            nonmono = tab_hdr_nonmono(h);
-          }
-        } else if (tv.hdr_form == 4) {
-          const uint32_t h = static_cast<const uint32_t *>(pc.hdr)[li];
+    }
+    for (; i < b_end; ++i) {
+      __builtin_prefetch(rowp + 1024);
+      __builtin_prefetch(rowp + 1024 + 64);
+      int64_t a;
+      int64_t cnt;
+      uint32_t nonmono;
+      const int64_t li = i - i_beg;
+      if (tv->hdr_form == 2) { // (a + max_bs) | cnt << 8; cnt 255: the row carries a 4-byte header
+        const uint32_t c = static_cast<const uint16_t *>(pc.hdr)[li];
+        a = (int64_t)(c & 0xFFu) - max_bs;
+        cnt = c >> 8;
+        nonmono = 0;
+        if (__builtin_expect(cnt == kHdr2Escape, 0)) {
+          if (rows_end - rowp < 4) { rc = FGMM_ERR_INVALID; break; }
+          uint32_t h;
+          memcpy(&h, rowp, 4);
+          rowp += 4;
           a = tab_hdr_a(h);
           cnt = tab_hdr_cnt(h);
           nonmono = tab_hdr_nonmono(h);
-        } else {
-          const uint64_t h = static_cast<const uint64_t *>(pc.hdr)[li];
-          a = (int32_t)(uint32_t)h;
-          cnt = (int64_t)((h >> 32) & 0x7FFFFFFFu);
-          nonmono = (uint32_t)(h >> 63);
         }
-        // a row covers indices [a + max_bs, a + max_bs + cnt) of the W-entry virtual table
-        if (__builtin_expect(cnt < 1 || a < -(int64_t)max_bs || a + max_bs + cnt > W, 0)) { rc = FGMM_ERR_INVALID; break; }
-        const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono, tv.ef_min);
-        const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, tv.ef_min);
-        if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; break; }
-        const bool zero_before = a > -(int64_t)max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
-        const uint8_t *row_bytes = rowp;
-        rowp += rbytes;
+      } else if (tv->hdr_form == 4) {
+        const uint32_t h = static_cast<const uint32_t *>(pc.hdr)[li];
+        a = tab_hdr_a(h);
+        cnt = tab_hdr_cnt(h);
+        nonmono = tab_hdr_nonmono(h);
+      } else {
+        const uint64_t h = static_cast<const uint64_t *>(pc.hdr)[li];
+        a = (int32_t)(uint32_t)h;
+        cnt = (int64_t)((h >> 32) & 0x7FFFFFFFu);
+        nonmono = (uint32_t)(h >> 63);
+      }
+      // a row covers indices [a + max_bs, a + max_bs + cnt) of the W-entry virtual table
+      if (__builtin_expect(cnt < 1 || a < -(int64_t)max_bs || a + max_bs + cnt > W, 0)) { rc = FGMM_ERR_INVALID; break; }
+      const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono, tv->ef_min);
+      const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, tv->ef_min);
+      if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; break; }
+      const bool zero_before = a > -(int64_t)max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
+      const uint8_t *row_bytes = rowp;
+      rowp += rbytes;
 
-        const uint32_t cf = (uint32_t)(d.x & 0xFFFFu); // Rans64DecGet
-        int32_t value;
-        if (__builtin_expect(cf == kMaxCdf, 0)) {
-          value = d.bypass();
-        } else {
-          uint32_t start = 0, freq = 0;
-          bool done = false;
-          if (!is_ef) {
-            const uint16_t *row = reinterpret_cast<const uint16_t *>(row_bytes);
-            if (__builtin_expect(!nonmono, 1)) {
-              const int32_t j = upper_bound_u16(row, (int32_t)cnt, cf);
-              if (__builtin_expect(j >= 1 && j < cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
-                start = row[j - 1];
-                freq = (uint32_t)(row[j] - start) & 0xFFFFu;
-                value = (int32_t)(a + j - 1);
-                done = true;
-              } else if (j == 0 && zero_before) { // 0 <= cf < row[0]: the symbol whose lower edge is the implied zero
-                start = 0;
-                freq = row[0];
-                value = (int32_t)(a - 1);
-                done = true;
-              }
-            }
-            if (!done) value = bisect_reference(Row{row, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
-          } else {
-            const EfRow r{row_bytes, Up64{row_bytes + tab_ef_lows_bytes((uint32_t)cnt), (int32_t)tab_ef_words((uint32_t)cnt)}, (int32_t)cnt};
-            int32_t j;
-            const int br = ef_bracket(r, cf, zero_before, &j, &start, &freq);
-            if (__builtin_expect(br > 0, 1)) {
+      const uint32_t cf = (uint32_t)(dec.x & 0xFFFFu); // Rans64DecGet
+      int32_t value;
+      if (__builtin_expect(cf == kMaxCdf, 0)) {
+        value = dec.bypass();
+      } else {
+        uint32_t start = 0, freq = 0;
+        bool done = false;
+        if (!is_ef) {
+          const uint16_t *row = reinterpret_cast<const uint16_t *>(row_bytes);
+          if (__builtin_expect(!nonmono, 1)) {
+            const int32_t j = upper_bound_u16(row, (int32_t)cnt, cf);
+            if (__builtin_expect(j >= 1 && j < cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
+              start = row[j - 1];
+              freq = (uint32_t)(row[j] - start) & 0xFFFFu;
               value = (int32_t)(a + j - 1);
-            } else if (br < 0) {
-              rc = FGMM_ERR_INVALID;
-              break;
-            } else { // no interval contains cf: expand the row and replay the reference's bisection
-              if ((size_t)cnt > scratch_cap) {
-                free(scratch);
-                scratch_cap = (size_t)cnt + 64;
-                scratch = (uint16_t *)malloc(scratch_cap * sizeof(uint16_t));
-                if (!scratch) { rc = FGMM_ERR_NOMEM; break; }
-              }
-              for (int32_t q = 0; q < cnt && rc == FGMM_OK; ++q) {
-                const int32_t pos = ef_select1(r, (uint32_t)q);
-                if (pos < q) rc = FGMM_ERR_INVALID; else scratch[q] = (uint16_t)((((uint32_t)(pos - q)) << 8) | r.lows[q]);
-              }
-              if (rc != FGMM_OK) break;
-              value = bisect_reference(Row{scratch, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
+              done = true;
+            } else if (j == 0 && zero_before) { // 0 <= cf < row[0]: the symbol whose lower edge is the implied zero
+              start = 0;
+              freq = row[0];
+              value = (int32_t)(a - 1);
+              done = true;
             }
           }
-          if (__builtin_expect(freq == 0, 0)) { rc = FGMM_ERR_INVALID; break; } // cannot come out of a well-formed row
-          d.advance(start, freq);
+          if (!done) value = bisect_reference(Row{row, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
+        } else {
+          const EfRow r{row_bytes, Up64{row_bytes + tab_ef_lows_bytes((uint32_t)cnt), (int32_t)tab_ef_words((uint32_t)cnt)}, (int32_t)cnt};
+          int32_t j;
+          const int br = ef_bracket(r, cf, zero_before, &j, &start, &freq);
+          if (__builtin_expect(br > 0, 1)) {
+            value = (int32_t)(a + j - 1);
+          } else if (br < 0) {
+            rc = FGMM_ERR_INVALID;
+            break;
+          } else { // no interval contains cf: expand the row and replay the reference's bisection
+            if ((size_t)cnt > scratch_cap) {
+              free(scratch);
+              scratch_cap = (size_t)cnt + 64;
+              scratch = (uint16_t *)malloc(scratch_cap * sizeof(uint16_t));
+              if (!scratch) { rc = FGMM_ERR_NOMEM; break; }
+            }
+            for (int32_t q = 0; q < cnt && rc == FGMM_OK; ++q) {
+              const int32_t pos = ef_select1(r, (uint32_t)q);
+              if (pos < q) rc = FGMM_ERR_INVALID; else scratch[q] = (uint16_t)((((uint32_t)(pos - q)) << 8) | r.lows[q]);
+            }
+            if (rc != FGMM_OK) break;
+            value = bisect_reference(Row{scratch, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
+          }
         }
-        out[i] = value;
-        if (__builtin_expect(d.underrun, 0)) { rc = FGMM_ERR_STREAM; break; }
+        if (__builtin_expect(freq == 0, 0)) { rc = FGMM_ERR_INVALID; break; } // cannot come out of a well-formed row
+        dec.advance(start, freq);
       }
-      if (rc != FGMM_OK) break;
+      out[i] = value;
+      if (__builtin_expect(dec.underrun, 0)) { rc = FGMM_ERR_STREAM; break; }
     }
+    if (rc != FGMM_OK) break;
   }
+  x = dec.x;
+  ptr = dec.ptr;
+  return rc;
+}
+
+// after the last piece: FGMM_OK only if every latent was decoded
+int TabDecoder::finish() {
   if (rc == FGMM_OK && i < n) rc = FGMM_ERR_INVALID; // the pieces do not cover the latents
   free(copy);
   free(scratch);
+  copy = nullptr;
+  scratch = nullptr;
   return rc;
 }
+
+int rans_decode_tab(const uint8_t *enc, size_t enc_len, const TabView &tv, int64_t n, int32_t max_bs, int32_t *out) {
+  TabDecoder td;
+  int rc = td.begin(enc, enc_len, &tv, n, max_bs, out);
+  for (int k = 0; rc == FGMM_OK && k < tv.npiece; ++k) {
+    if (k > 0 && tv.wait && (rc = tv.wait(tv.arg, k)) != FGMM_OK) break;
+    rc = td.piece(k);
+  }
+  const int rf = td.finish();
+  return rc != FGMM_OK ? rc : rf;
+}
+
 
 // ============================================================================================================
 // Table path — CompressAI's original table rANS, used for the `z` hyper-latent:

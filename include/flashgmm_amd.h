@@ -76,11 +76,12 @@ int fgmm_ctx_threads(const fgmm_ctx *ctx);
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
 
 /* Tuning knobs of a context (defaults in brackets).  Unknown names return FGMM_ERR_INVALID.
- *   "tail_items"  [16]  decode: how many trailing bitstreams of a call land in pieces (a bitstream decodes sequentially:
- *                       whatever lands last leaves one item of host work behind it)
- *   "tail_pieces" [4]   ... and in how many pieces each (1: whole), at most 8
- *   "dec_group"   [0]   decode: bitstreams per launch / copy (0: automatic)
- *   "dec_first"   [2]   decode: size of the first group (the first tables reach the host as early as possible)
+ *   "pieces"      [4]   decode: the tables of every bitstream of a call reach the host in this many pieces (at most 8),
+ *                       piece-major, and each host worker follows its bitstreams piece by piece (a bitstream decodes
+ *                       sequentially: what lands last leaves one piece of host work behind it, not one bitstream)
+ *   "dec_group"   [0]   decode: bitstreams per launch / copy (0: automatic: a whole round of pieces)
+ *   "dec_first"   [2]   decode: size of the first launch of the first round (the first tables reach the host as early
+ *                       as possible; the following launches double)
  *   "tab_cap_e"   [8192] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2))
  *   "stage_max_mb" [0]  decode: cap of the device staging area for rows in MiB (0: a quarter of the free device memory).
  *                       A launch whose rows do not fit is re-run with the exact size its cursor reports.

@@ -521,13 +521,13 @@ def ctx_options():
         _lib.set_option(0, k, v)
 
 
-@pytest.mark.parametrize("tail", [None, 3, 0])
-def test_batch_of_ragged_empty_and_tiny_items(oracle, ctx_options, tail):
+@pytest.mark.parametrize("pieces", [None, 1, 7])
+def test_batch_of_ragged_empty_and_tiny_items(oracle, ctx_options, pieces):
     """one batch mixing full-size items with all-zero ones (empty streams), single-channel / single-position ones and
     odd sizes: every item must equal its own single-item result and the oracle, whatever part of the decode pipeline
-    (ordinary group, tail-window pieces with fewer channels than pieces) it falls into"""
-    if tail is not None:
-        ctx_options(tail_items=tail)
+    (whole tables, pieces with fewer blocks than pieces) it falls into"""
+    if pieces is not None:
+        ctx_options(pieces=pieces)
     gmc = GaussianMixtureConditional(K=4, mode="logistic")
     specs = [(1, (192, 32, 24), 0.1), (2, (5, 3, 3), 1.0), (3, (1, 1, 2), 0.0), (4, (3, 5, 7), 0.0), (5, (17, 1, 1), 0.3),
              (6, (192, 32, 24), 0.0), (7, (6, 4, 4), 1.0), (8, (2, 2, 2), 0.0), (9, (2, 64, 66), 0.0)]
@@ -573,11 +573,22 @@ def test_stacked_batch_equals_item_lists(dtype):
         gmc.decompress_batch([r[0][0] for r in a][:-1], [r[0][1] for r in a], [r[0][2] for r in a], sg, mu, pi)
 
 
-@pytest.mark.parametrize("tail,pieces", [(0, 4), (8, 1), (3, 2), (6, 3), (8, 8), (5, 7)])
-def test_decode_tail_window_settings(ctx_options, tail, pieces):
-    """The last items of a decode batch land on the host in pieces and their decoders follow the pieces
-    (fgmm_capi.cpp, decode_batch): every setting of the window must give the same symbols."""
-    ctx_options(tail_items=tail, tail_pieces=pieces)
+@pytest.mark.parametrize("pieces,first,group,threads", [(4, 2, 0, 0), (1, 2, 0, 0), (2, 1, 0, 3), (3, 9, 2, 0), (8, 2, 0, 2), (7, 1, 4, 16)])
+def test_decode_piece_schedule_settings(ctx_options, pieces, first, group, threads):
+    """The tables of a decode batch land on the host in pieces, piece-major, and each host worker follows its own bitstreams
+    piece by piece (fgmm_capi.cpp, decode_batch): every setting of the schedule, and any number of workers, must give
+    the same symbols."""
+    if threads:
+        _lib.set_threads(0, threads)  # a fresh context: before the options
+    try:
+        ctx_options(pieces=pieces, dec_first=first, dec_group=group)
+        _piece_schedule_case()
+    finally:
+        if threads:
+            _lib.set_threads(0, 0)
+
+
+def _piece_schedule_case():
     gmc = GaussianMixtureConditional(K=4, mode="polya")
     ys, ss, ms, ws = [], [], [], []
     for seed in range(9):
