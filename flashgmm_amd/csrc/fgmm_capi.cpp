@@ -214,7 +214,9 @@ struct fgmm_ctx {
     if (!aux_stream) HIP_TRY(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
     return FGMM_OK;
   }
+  std::vector<int32_t> h_sym; // decode: int32 symbols of every bitstream of a call (grown, kept)
   void trim() {
+    std::vector<int32_t>().swap(h_sym);
     if (d_ws) (void)hipFree(d_ws);
     if (h_ws) (void)hipHostFree(h_ws);
     if (d_stage) (void)hipFree(d_stage);
@@ -560,9 +562,15 @@ struct DecItem {
   hipEvent_t piece_ev[kMaxPieces] = {}; // recorded (this call) before the item's job is submitted
   char *h_out = nullptr;                // pinned: decoded symbols (host-written, read by the scatter kernel)
   int wide = 0; // h_out holds int32 symbols (some symbol outside int16), else int16
-  int queued = 0;                       // pieces whose copy is queued (guarded by the call's mutex)
+  // schedule state, guarded by the call's mutex: pieces whose copy is queued | next piece to decode | a worker holds the
+  // item | it is in the ready heap
+  int queued = 0, next_piece = 0;
+  bool busy = false, in_ready = false;
+  TabDecoder dec;
+  TabView view;
+  int32_t *sym = nullptr;               // int32 symbols (sym_host_out or a slice of the context's scratch)
   std::atomic<int> done{0};
-  double t_taken = 0, t_start = 0, t_end = 0; // trace level 2: job timeline
+  double t_taken = 0, t_start = 0, t_end = 0, t_waited = 0, t_lastland = 0, t_work = 0; // trace level 2: job timeline
   DecItem() = default;
   DecItem(const DecItem &) = delete;
 };
@@ -649,25 +657,22 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     char *d_range = nullptr;        // device: [fixed | rows]
   };
   std::vector<Unit> units;
-  // Every item crosses in `np` pieces (block ranges), PIECE-MAJOR: piece 0 of every item, then piece 1 ...  A host worker
-  // owns the items k, k + T, k + 2T ... (T workers) and follows them piece by piece, so all workers start on the first
-  // round and what is left after the last copy is one piece per owned item, not one item.  Within a round the items of
-  // the workers that own the most come first.  The first round is cut into small launches + copies (the first tables reach
-  // the host as early as possible), later rounds are one launch + one copy each.
-  const int T = std::max(ctx->pool->size(), 1);
+  // Every item crosses in `np` pieces (block ranges), PIECE-MAJOR: piece 0 of every item, then piece 1 ...  The host
+  // workers take (item, piece) tasks as they land - a bitstream decodes sequentially, but its coder state moves from worker
+  // to worker between pieces - so every worker starts on the first round, the load balances whatever count / workers is,
+  // and what is left after the last copy is the last piece of each item.  Pieces therefore shrink linearly (4 pieces: 40,
+  // 30, 20, 10 % of the blocks).  The first round is cut into small launches + copies (the first tables reach the host as
+  // early as possible), later rounds are one launch + one copy each.
   int np = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.pieces, 1), kMaxPieces);
   {
     int64_t lat = 0;
     for (int k = 0; k < n_fast; ++k) lat += items[fast[k]].n;
     if (lat < 65536) np = 1; // pieces only pay for rows that take a while to cross
   }
-  std::vector<std::vector<int>> owned((size_t)T); // items of each worker, in coding order
-  for (int k = 0; k < n_fast; ++k) owned[(size_t)(k % T)].push_back(fast[k]);
-  std::vector<int> order; // landing order within a round
-  for (int load = (n_fast + T - 1) / T; load >= 1; --load)
-    for (int j = 0; j < T; ++j)
-      if ((int)owned[(size_t)j].size() == load)
-        for (int i : owned[(size_t)j]) order.push_back(i);
+  auto piece_bound = [np](int64_t nblk, int p) { // first block of piece p: weights np, np-1 ... 1
+    const int64_t tot = (int64_t)np * (np + 1) / 2, cum = (int64_t)p * (2 * np - p + 1) / 2;
+    return (int64_t)((__int128)nblk * cum / tot);
+  };
   {
     const int steady = ctx->opt.dec_group > 0 ? (int)ctx->opt.dec_group : std::max(n_fast, 1);
     for (int p = 0; p < np && n_fast; ++p) {
@@ -676,8 +681,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         Unit u;
         const int k1 = std::min(k + sz, n_fast);
         for (; k < k1; ++k) {
-          const DecItem &it = items[order[(size_t)k]];
-          u.parts.push_back(Part{order[(size_t)k], it.nblk * p / np, it.nblk * (p + 1) / np, 0, 0, p});
+          const DecItem &it = items[fast[(size_t)k]];
+          u.parts.push_back(Part{fast[(size_t)k], piece_bound(it.nblk, p), piece_bound(it.nblk, p + 1), 0, 0, p});
         }
         units.push_back(std::move(u));
         sz = std::min(steady, sz * 2);
@@ -697,7 +702,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       p.o_blkoff = off;
       off += align_up(sizeof(uint32_t) * (size_t)(p.blk_end - p.blk_begin), 256);
       // worst case of a row: every edge of the window kept as a uint16, plus the 2-byte form's escape header
-      u.rows_cap += (size_t)lat * (2 * (size_t)(2 * (int64_t)it.max_bs + 2) + 4);
+      u.rows_cap += (size_t)lat * (2 * (size_t)(2 * (int64_t)it.max_bs + 2) + 4) + 2 * (size_t)(p.blk_end - p.blk_begin);
     }
     u.fixed = off;
     u.rows_cap = align_up(u.rows_cap, 256);
@@ -814,88 +819,102 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   if ((rc = ctx->prof_end(1, stream))) return rc; // brackets every table kernel of the call
   tr.mark("enqueued");
 
-  std::mutex done_mu; // guards: items[].done, items[].queued, abandon
-  std::condition_variable done_cv, queued_cv;
-  bool abandon = false; // this call is returning early: jobs must not wait for copies that will never be queued
-  // one worker's share: its items followed piece by piece as their tables land
-  auto run_items = [&](const std::vector<int> &mine) {
-    static thread_local std::vector<int32_t> scratch; // decoded symbols (a fresh 600 KB malloc per stream is an mmap)
+  // ---- the host side: (item, piece) tasks --------------------------------------------------------------------------------
+  std::mutex mu; // guards the schedule state of the items, the ready heap, `abandon`, `unfinished`
+  std::condition_variable work_cv, done_cv;
+  bool abandon = false; // this call is returning early: workers must not wait for copies that will never be queued
+  int unfinished = count;
+  using Key = std::pair<int64_t, int>; // (piece, item): the earliest-landing task first
+  std::priority_queue<Key, std::vector<Key>, std::greater<Key>> ready;
+  {
     size_t need = 0;
-    for (int i : mine) need += items[i].sym_host_out ? 0 : (size_t)std::max<int64_t>(items[i].n, 1);
-    bool nomem = false;
+    for (auto &it : items) need += it.sym_host_out ? 0 : (size_t)std::max<int64_t>(it.n, 1);
     try {
-      if (scratch.size() < need) scratch.resize(need);
+      if (ctx->h_sym.size() < need) ctx->h_sym.resize(need);
     } catch (const std::bad_alloc &) {
-      nomem = true;
+      return fail(FGMM_ERR_NOMEM, "out of memory (%zu decoded symbols)", need);
     }
-    std::vector<TabDecoder> dec(mine.size());
-    std::vector<TabView> views(mine.size());
-    std::vector<int32_t *> sym(mine.size(), nullptr);
     size_t at = 0;
-    int np_max = 1;
-    for (size_t m = 0; m < mine.size(); ++m) {
-      DecItem &it = items[mine[m]];
-      it.t_taken = tr.ms();
-      sym[m] = it.sym_host_out ? it.sym_host_out : (nomem ? nullptr : scratch.data() + at);
+    for (auto &it : items) {
+      it.sym = it.sym_host_out ? it.sym_host_out : ctx->h_sym.data() + at;
       if (!it.sym_host_out) at += (size_t)std::max<int64_t>(it.n, 1);
-      views[m] = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
-      if (it.status == FGMM_OK) it.status = !sym[m] ? (int)FGMM_ERR_NOMEM : dec[m].begin(it.enc, it.enc_len, &views[m], it.n, it.max_bs, sym[m]);
-      np_max = std::max(np_max, it.n_piece);
     }
-    for (int p = 0; p < np_max; ++p)
-      for (size_t m = 0; m < mine.size(); ++m) {
-        DecItem &it = items[mine[m]];
-        if (it.status != FGMM_OK || p >= it.n_piece) continue;
-        {
-          std::unique_lock<std::mutex> l(done_mu); // the piece's copy is queued (its event recorded in THIS call)?
-          queued_cv.wait(l, [&] { return abandon || it.queued > p; });
-          if (it.queued <= p) {
-            it.status = FGMM_ERR_HIP;
-            continue;
+  }
+  auto push_if_ready = [&](int i) { // under mu
+    DecItem &it = items[i];
+    if (!it.busy && !it.in_ready && !it.done.load() && it.next_piece < it.queued) {
+      it.in_ready = true;
+      ready.push(Key{it.next_piece, i});
+    }
+  };
+  auto worker = [&] {
+    std::unique_lock<std::mutex> l(mu);
+    for (;;) {
+      if (unfinished == 0) return;
+      if (ready.empty()) {
+        if (abandon) return;
+        work_cv.wait(l);
+        continue;
+      }
+      const int i = ready.top().second;
+      ready.pop();
+      DecItem &it = items[i];
+      it.in_ready = false;
+      it.busy = true;
+      const int p = it.next_piece;
+      l.unlock();
+      if (p == 0) {
+        it.t_taken = tr.ms();
+        it.view = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
+        if (it.status == FGMM_OK) it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
+      }
+      const double tw0 = tr.level > 1 ? tr.ms() : 0;
+      if (it.status == FGMM_OK && hipEventSynchronize(it.piece_ev[p]) != hipSuccess) it.status = FGMM_ERR_HIP;
+      const double tw1 = tr.level > 1 ? tr.ms() : 0;
+      it.t_waited += tw1 - tw0;
+      it.t_lastland = tw1;
+      if (p == 0) it.t_start = tw1;
+      if (it.status == FGMM_OK) it.status = it.dec.piece(p);
+      if (tr.level > 1) it.t_work += tr.ms() - tw1;
+      const bool last = it.status != FGMM_OK || p + 1 == it.n_piece;
+      if (last) {
+        const int rf = it.dec.finish();
+        if (it.status == FGMM_OK) it.status = rf;
+        if (it.status == FGMM_OK && it.y_hat) {
+          // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
+          int16_t *s16 = reinterpret_cast<int16_t *>(it.h_out);
+          int32_t acc = 0;
+          for (int64_t k = 0; k < it.n; ++k) {
+            const int32_t v = it.sym[k];
+            s16[k] = (int16_t)v;
+            acc |= v ^ (int32_t)(int16_t)v;
           }
+          it.wide = acc != 0;
+          if (it.wide) memcpy(it.h_out, it.sym, sizeof(int32_t) * (size_t)it.n);
         }
-        if (hipEventSynchronize(it.piece_ev[p]) != hipSuccess) {
-          it.status = FGMM_ERR_HIP;
-          continue;
-        }
-        if (p == 0) it.t_start = tr.ms();
-        it.status = dec[m].piece(p);
+        it.t_end = tr.ms();
       }
-    for (size_t m = 0; m < mine.size(); ++m) {
-      DecItem &it = items[mine[m]];
-      const int rf = dec[m].finish();
-      if (it.status == FGMM_OK) it.status = rf;
-      if (it.status == FGMM_OK && it.y_hat) {
-        // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
-        int16_t *s16 = reinterpret_cast<int16_t *>(it.h_out);
-        int32_t acc = 0;
-        for (int64_t k = 0; k < it.n; ++k) {
-          const int32_t v = sym[m][k];
-          s16[k] = (int16_t)v;
-          acc |= v ^ (int32_t)(int16_t)v;
-        }
-        it.wide = acc != 0;
-        if (it.wide) memcpy(it.h_out, sym[m], sizeof(int32_t) * (size_t)it.n);
-      }
-      it.t_end = tr.ms();
-      {
-        std::lock_guard<std::mutex> l(done_mu);
+      l.lock();
+      it.busy = false;
+      it.next_piece = p + 1;
+      if (last) {
         it.done.store(1);
+        if (--unfinished == 0) work_cv.notify_all();
+        done_cv.notify_all();
+      } else {
+        push_if_ready(i);
       }
-      done_cv.notify_all();
     }
   };
-  auto submit_job = [&](int i) { // a single item whose pieces are all queued (generic path, single-item calls)
-    if (count == 1) run_items({i}); else ctx->pool->submit([&run_items, i] { run_items({i}); });
-  };
-  auto mark_queued = [&](DecItem &it, int pieces) {
+  auto mark_queued = [&](int i, int pieces) {
     {
-      std::lock_guard<std::mutex> l(done_mu);
-      it.queued = pieces;
+      std::lock_guard<std::mutex> l(mu);
+      items[i].queued = pieces;
+      push_if_ready(i);
     }
-    queued_cv.notify_all();
+    work_cv.notify_one();
   };
-  struct Abandon { // any return: release jobs that wait for copies (before PoolDrain waits for the jobs)
+  struct Abandon { // any return: release workers that wait for copies (before PoolDrain waits for the workers)
     std::mutex &mu;
     std::condition_variable &cv;
     bool &flag;
@@ -908,7 +927,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
   };
   PoolDrain drain{ctx->pool}; // on any return: wait for every job before the objects they use go away
-  Abandon abandon_on_exit{done_mu, queued_cv, abandon};
+  Abandon abandon_on_exit{mu, work_cv, abandon};
   TempDevice temp;
 
   // pinned output areas (decoded symbols) of all items
@@ -924,9 +943,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
   }
 
-  if (count > 1)
-    for (int j = 0; j < T; ++j)
-      if (!owned[(size_t)j].empty()) ctx->pool->submit([&run_items, &owned, j] { run_items(owned[(size_t)j]); });
+  const int n_workers = count > 1 ? std::min(std::max(ctx->pool->size(), 1), count) : 0; // a single bitstream: this thread
+  for (int j = 0; j < n_workers; ++j) ctx->pool->submit(worker);
 
   // ---- unit by unit: size known -> pinned range, ONE copy; the workers are told ----------------------------------------
   unsigned long long edges = 0;
@@ -969,12 +987,11 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.piece_ev[p.piece] = ev_landed[u];
       const int64_t lat = pc.end - std::min<int64_t>(p.blk_begin * it.tl, it.n);
       it.table_bytes += (uint64_t)it.hdr_form * (uint64_t)lat + sizeof(uint32_t) * (uint64_t)(p.blk_end - p.blk_begin);
-      mark_queued(it, p.piece + 1); // pieces reach an item in order: rounds are piece-major
+      mark_queued(p.item, p.piece + 1); // pieces reach an item in order: rounds are piece-major
     }
     // rows are shared by the unit's items: account them once
     if (!un.parts.empty()) items[un.parts[0].item].table_bytes += used;
   }
-  if (count == 1 && n_fast == 1) run_items({fast[0]});
   tr.mark("sizes known, copies queued");
 
   // ---- generic path: items too wide for the single-pass kernel, one at a time ------------------------------------------
@@ -985,8 +1002,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.piece[0] = TabPiece{ctx->h_ws, nullptr, reinterpret_cast<const uint8_t *>(ctx->h_ws), 0, 0};
       it.piece_ev[0] = ev_landed[n_units];
       HIP_TRY(hipEventRecord(ev_landed[n_units], stream));
-      mark_queued(it, 1);
-      submit_job(i);
+      mark_queued(i, 1);
       continue;
     }
     const int32_t tiles = (int32_t)((it.hw + 255) / 256);
@@ -1017,8 +1033,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.status = FGMM_ERR_UNSUPPORTED;
       it.piece_ev[0] = ev_landed[n_units];
       HIP_TRY(hipEventRecord(ev_landed[n_units], stream));
-      mark_queued(it, 1);
-      submit_job(i);
+      mark_queued(i, 1);
       continue;
     }
     const size_t pool_bytes = (size_t)used4[0];
@@ -1035,8 +1050,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.piece_ev[0] = ev_landed[n_units]; // nothing left to wait for: the stream has just been synchronised
     HIP_TRY(hipEventRecord(ev_landed[n_units], stream));
     it.table_bytes = hdr_bytes + pool_bytes;
-    mark_queued(it, 1);
-    submit_job(i);
+    mark_queued(i, 1);
   }
 
   ctx->stat[1] = ctx->stat[2] = 0;
@@ -1046,12 +1060,14 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     ctx->stat[2] += (unsigned long long)it.n;
   }
 
+  if (n_workers == 0) worker(); // every piece is queued: returns when the bitstream is decoded
+
   // ---- symbols back to the GPU item by item: scatter kernel on the caller's stream ---------------------------
   int first_err = FGMM_OK;
   for (int i = 0; i < count; ++i) {
     DecItem &it = items[i];
     {
-      std::unique_lock<std::mutex> l(done_mu);
+      std::unique_lock<std::mutex> l(mu);
       done_cv.wait(l, [&it] { return it.done.load() != 0; });
     }
     if (it.status && !first_err) first_err = it.status;
@@ -1064,8 +1080,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   tr.mark("y_hat written");
   if (tr.level > 1)
     for (int i = 0; i < count; ++i)
-      fprintf(stderr, "[fgmm decode]   item %2d  pieces %d  taken %7.3f  job %7.3f .. %7.3f  (%.3f ms)\n", i, items[i].n_piece,
-              items[i].t_taken, items[i].t_start, items[i].t_end, items[i].t_end - items[i].t_start);
+      fprintf(stderr, "[fgmm decode]   item %2d  pieces %d  taken %7.3f  job %7.3f .. %7.3f  (decoding %.3f ms, waiting for copies %.3f, last piece at %.3f)\n",
+              i, items[i].n_piece, items[i].t_taken, items[i].t_start, items[i].t_end, items[i].t_work, items[i].t_waited, items[i].t_lastland);
   if (first_err)
     return fail(first_err, "host rANS decode failed (%d)%s", first_err,
                 first_err == FGMM_ERR_STREAM ? ": bitstream too short"

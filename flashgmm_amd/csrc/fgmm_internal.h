@@ -71,22 +71,24 @@ struct DecDesc {
   unsigned long long *blk_off;   // [n_ch*tiles] byte offset of each block's first row
 };
 
-// ---- decode-side table format v4 (documented in include/flashgmm_amd.h) -------------------------------------
+// ---- decode-side table format v5 (documented in include/flashgmm_amd.h) -------------------------------------
 //   header of latent i, one of three forms (per item):
 //     2 bytes: (a + max_bs) | cnt << 8, cnt in [1, 254]                    items with 2*max_bs + 2 <= 254
 //              cnt field 255 = escape: the row starts with a 4-byte header of the next form (non-monotone rows)
 //     4 bytes: int16 a | cnt << 16 (15 bits) | nonmono << 31                 items with max_bs <= 16382
 //     8 bytes: int32 a ; cnt (31 bits) | nonmono << 31                       any half-width
 //   row i = F_i[a .. a+cnt), starting at the first non-zero edge (F_i[v < a] = 0, F_i[v >= a+cnt] = last entry);
-//   rows 4-byte aligned:
-//     raw (cnt < kTabEfMin or nonmono): uint16[round2(cnt)], padded with the last value
-//     EF  (cnt >= kTabEfMin, monotone): uint8 lows[round4(cnt)] ; uint32 upper[U], U = ceil((cnt + 256) / 32),
-//                                       bit ((E_j >> 8) + j) set for every entry j
+//   rows 2-byte aligned:
+//     raw (cnt < kTabEfMin or nonmono): uint16[cnt]
+//     EF  (cnt >= kTabEfMin, monotone): Elias-Fano with l = tab_ef_l(cnt) low bits, ONE little-endian bit string (bit b of
+//                                       the row = bit (b & 7) of byte b >> 3), rounded up to 16 bits:
+//                                         bits [0, HB), HB = cnt + (65536 >> l): bit ((E_j >> l) + j) set for every entry j
+//                                         bits [HB + j * l, HB + (j + 1) * l): the low l bits of E_j
 //   placement: sequential in latent order (generic path, the building-block API), or per block of `tl` latents at
 //   rows + 4 * blk_off[block] (tab_kernel: blocks are placed by an atomic cursor, in no particular order)
 constexpr int kMaxPieces = 8; // FGMM_MAX_PIECES
 #ifndef FGMM_EF_MIN
-#define FGMM_EF_MIN 48
+#define FGMM_EF_MIN 14
 #endif
 constexpr uint32_t kTabEfMin = FGMM_EF_MIN; // rows with at least this many entries are Elias-Fano coded
 constexpr uint32_t kHdr2Escape = 255;
@@ -103,11 +105,18 @@ FGMM_HD static inline unsigned long long tab_hdr8_pack(int32_t a, uint32_t cnt, 
 // such row) when a call is bound by its host decoders: a uint16 row is searched faster, an Elias-Fano row is smaller
 constexpr uint32_t kTabNoEf = 0x7FFFFFFFu;
 FGMM_HD static inline bool tab_row_is_ef(uint32_t cnt, uint32_t nonmono, uint32_t ef_min) { return cnt >= ef_min && !nonmono; }
-FGMM_HD static inline uint32_t tab_ef_lows_bytes(uint32_t cnt) { return (cnt + 3u) & ~3u; }
-FGMM_HD static inline uint32_t tab_ef_words(uint32_t cnt) { return (cnt + 256u + 31u) >> 5; }
+// low bits of an Elias-Fano row: 16 - ceil(log2(cnt)) within [8, 12] (12 for cnt <= 16 ... 8 for cnt > 128): within a
+// few bytes of the best choice for every cnt, and always below the 2 * cnt bytes of the raw form from cnt = 14 on
+FGMM_HD static inline uint32_t tab_ef_l(uint32_t cnt) {
+  uint32_t lg = 0; // ceil(log2(cnt))
+  while (lg < 16 && (1u << lg) < cnt) ++lg;
+  const uint32_t l = 16u - lg;
+  return l < 8u ? 8u : (l > 12u ? 12u : l);
+}
+FGMM_HD static inline uint32_t tab_ef_hb(uint32_t cnt, uint32_t l) { return cnt + (65536u >> l); } // bits of the unary high part
+FGMM_HD static inline unsigned long long tab_ef_bits(uint32_t cnt, uint32_t l) { return (unsigned long long)cnt * (l + 1u) + (65536u >> l); }
 FGMM_HD static inline unsigned long long tab_row_bytes(uint32_t cnt, uint32_t nonmono, uint32_t ef_min) {
-  return tab_row_is_ef(cnt, nonmono, ef_min) ? (unsigned long long)tab_ef_lows_bytes(cnt) + 4ull * tab_ef_words(cnt)
-                                     : 2ull * (((unsigned long long)cnt + 1u) & ~1ull);
+  return tab_row_is_ef(cnt, nonmono, ef_min) ? 2ull * ((tab_ef_bits(cnt, tab_ef_l(cnt)) + 15ull) >> 4) : 2ull * (unsigned long long)cnt;
 }
 FGMM_HD static inline bool tab_hdr_fits16(int32_t max_bs) { return 2 * (int64_t)max_bs + 2 <= 254; }
 FGMM_HD static inline int tab_hdr_form(int32_t max_bs) { return tab_hdr_fits16(max_bs) ? 2 : (max_bs <= 16382 ? 4 : 8); }

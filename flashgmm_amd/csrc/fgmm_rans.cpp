@@ -281,46 +281,50 @@ __attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *r
   return cnt;
 }
 
-// ---- Elias-Fano rows (8 low bits): lows[round4(cnt)] then U 32-bit words whose bit ((E_j >> 8) + j) is set ----
-// Bucket b (entries whose high byte is b) is a run of ones followed by one zero; zero #b sits at bit
-// b + (number of entries with high byte <= b).  The words are read 64 bits at a time (they are only 4-byte aligned in
-// the pool); when U is odd the upper half of the last read lies past the row: it is forced to ones ("no zero there").
-struct Up64 {
+// ---- Elias-Fano rows (format v5): one bit string: HB = cnt + (65536 >> l) bits of unary high parts (bit (E_j >> l) + j
+// set for entry j), then the low l bits of every entry.  Bucket b (the entries whose high part is b) is a run of ones
+// followed by one zero; zero #b sits at bit b + (number of entries with high part <= b).  The unary part is read 64 bits
+// at a time (rows are only 2-byte aligned); bits from HB on - the low parts, the next row - read as ones ("no zero there").
+struct EfRow {
   const uint8_t *p;
-  int32_t U32; // valid 32-bit words
-  inline int32_t words() const { return (U32 + 1) >> 1; }
+  int32_t cnt;
+  uint32_t l, HB;
+  inline int32_t words() const { return (int32_t)((HB + 63u) >> 6); }
   inline uint64_t operator[](int64_t w) const {
     uint64_t v;
     memcpy(&v, p + 8 * w, 8);
-    if (__builtin_expect(2 * w + 1 >= U32, 0)) v |= 0xFFFFFFFF00000000ull;
+    const int64_t rem = (int64_t)HB - 64 * w; // valid bits of this word
+    if (__builtin_expect(rem < 64, 0)) v |= rem <= 0 ? ~0ull : (~0ull << rem);
     return v;
   }
+  inline uint32_t low(int32_t j) const {
+    const uint32_t b = HB + (uint32_t)j * l;
+    uint32_t v;
+    memcpy(&v, p + (b >> 3), 4);
+    return (v >> (b & 7u)) & ((1u << l) - 1u);
+  }
 };
-struct EfRow {
-  const uint8_t *lows;
-  Up64 up;
-  int32_t cnt;
-};
-// position of the k-th (0-based) ZERO bit, k <= 255 (always exists in a well-formed row: 32 U - cnt >= 256); -1 if not
+// position of the k-th (0-based) ZERO bit of the unary part, k < 65536 >> l (exists in a well-formed row); -1 if not
 __attribute__((target("bmi2,popcnt"))) inline int32_t ef_select0(const EfRow &r, uint32_t k) {
   uint32_t wsel = 0, zbase = 0, acc = 0;
-  const int32_t U = r.up.words();
+  const int32_t U = r.words();
   for (int32_t w = 0; w < U; ++w) {
-    acc += (uint32_t)__builtin_popcountll(~r.up[w]);
+    acc += (uint32_t)__builtin_popcountll(~r[w]);
     const bool le = acc <= k;
     wsel += le;
     zbase = le ? acc : zbase;
   }
   if (__builtin_expect((int32_t)wsel >= U, 0)) return -1; // malformed row
-  return (int32_t)(wsel * 64u + (uint32_t)__builtin_ctzll(_pdep_u64(1ull << (k - zbase), ~r.up[wsel])));
+  return (int32_t)(wsel * 64u + (uint32_t)__builtin_ctzll(_pdep_u64(1ull << (k - zbase), ~r[wsel])));
 }
 // position of the k-th (0-based) ONE bit, k < cnt (only used to expand a row for the bisection replay); -1 if not found
 __attribute__((target("bmi2,popcnt"))) inline int32_t ef_select1(const EfRow &r, uint32_t k) {
   int32_t base = 0;
-  const int32_t U = r.up.words();
+  const int32_t U = r.words();
   for (int32_t w = 0; w < U; ++w, base += 64) {
-    uint64_t o = r.up[w];
-    if (2 * w + 1 >= r.up.U32) o &= 0xFFFFFFFFull; // the forced ones are not entries
+    uint64_t o = r[w];
+    const int64_t rem = (int64_t)r.HB - base;
+    if (rem < 64) o &= (1ull << rem) - 1ull; // the forced ones are not entries (rem >= 1 here)
     const uint32_t c = (uint32_t)__builtin_popcountll(o);
     if (k < c) return base + (int32_t)__builtin_ctzll(_pdep_u64(1ull << k, o));
     k -= c;
@@ -328,18 +332,18 @@ __attribute__((target("bmi2,popcnt"))) inline int32_t ef_select1(const EfRow &r,
   return -1;
 }
 // Bracket search: 1 with (*j, *start, *freq) such that E[j-1] = start <= cf < E[j]; 0 when no entry pair brackets cf
-// (j would be 0 or cnt) — the caller replays the reference's bisection; -1 for a malformed row (hostile table).
+// (j would be 0 or cnt) - the caller replays the reference's bisection; -1 for a malformed row (hostile table).
 // zero_before: an (unstored) zero edge precedes the row, so cf below the first entry is the interval [0, E_0): j = 0.
-__attribute__((target("bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
-                                                                   uint32_t *start, uint32_t *freq) {
-  const uint32_t h = cf >> 8, l = cf & 0xFFu;
-  const int32_t nbits = r.up.U32 * 32;
+__attribute__((target("bmi2,popcnt"))) inline int ef_bracket(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
+                                                            uint32_t *start, uint32_t *freq) {
+  const uint32_t h = cf >> r.l, lcf = cf & ((1u << r.l) - 1u);
+  const int32_t nbits = (int32_t)r.HB;
   int32_t p_prev = -1; // zero that closes bucket h-1
   if (h) {
     p_prev = ef_select0(r, h - 1);
-    if (__builtin_expect(p_prev < 0, 0)) return -1;
+    if (__builtin_expect(p_prev < 0 || p_prev >= nbits, 0)) return -1;
   }
-  const int32_t lo = p_prev + 1 - (int32_t)h; // entries with high byte < h
+  const int32_t lo = p_prev + 1 - (int32_t)h; // entries with a high part < h
   if (__builtin_expect(lo < 0 || lo > r.cnt, 0)) return -1;
   // length of the run of ones that starts at bit p_prev + 1  (= size of bucket h)
   int32_t run = 0;
@@ -348,24 +352,25 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow 
     for (;;) {
       if (__builtin_expect((int32_t)s >= nbits, 0)) return -1; // no closing zero: malformed
       const uint32_t b = s & 63u;
-      const uint64_t t = ~(r.up[s >> 6] >> b); // shifted-in zeros become ones: the run ends at the word end at the latest
+      const uint64_t t = ~(r[s >> 6] >> b); // shifted-in zeros become ones: the run ends at the word end at the latest
       const int32_t len = t ? (int32_t)__builtin_ctzll(t) : 64;
       run += len;
       if (__builtin_expect(len < (int32_t)(64u - b), 1)) break;
       s += (uint32_t)len; // the run continues in the next word (rare)
     }
   }
-  if (__builtin_expect(lo + run > r.cnt, 0)) return -1;
-  // entries of bucket h whose low byte is <= l (low bytes ascend inside a bucket)
-  int32_t c;
-  if (__builtin_expect(run <= 16, 1)) {
-    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(r.lows + lo));
-    const __m128i key = _mm_set1_epi8((char)l);
-    const uint32_t le = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(v, key), v));
-    c = __builtin_popcount(le & ((1u << run) - 1u));
+  if (__builtin_expect(lo + run > r.cnt || p_prev + 1 + run >= nbits, 0)) return -1;
+  // entries of bucket h whose low part is <= lcf (low parts ascend inside a bucket): mostly one or two entries; the two
+  // tail buckets of a row hold many, a bisection bounds those
+  int32_t c = 0;
+  if (run <= 4) {
+    while (c < run && r.low(lo + c) <= lcf) ++c;
   } else {
-    c = 0;
-    while (c < run && r.lows[lo + c] <= l) ++c;
+    int32_t hi = run; // low(lo + c - 1) <= lcf < low(lo + hi)
+    while (c < hi) {
+      const int32_t mid = (c + hi) >> 1;
+      if (r.low(lo + mid) <= lcf) c = mid + 1; else hi = mid;
+    }
   }
   const int32_t j = lo + c;
   if (__builtin_expect((j < 1 && !zero_before) || j >= r.cnt, 0)) return 0;
@@ -373,30 +378,33 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow 
   if (j < 1) {
     e0 = 0; // the implied zero edge
   } else if (c > 0) {
-    e0 = (h << 8) | r.lows[j - 1];
+    e0 = (h << r.l) | r.low(j - 1);
   } else { // previous entry lives in an earlier bucket: the highest one below bit p_prev
     int32_t w = p_prev >> 6;
-    uint64_t m = r.up[w] & ((1ull << (p_prev & 63)) - 1ull);
+    uint64_t m = r[w] & ((1ull << (p_prev & 63)) - 1ull);
     while (!m) {
       if (__builtin_expect(--w < 0, 0)) return -1;
-      m = r.up[w];
+      m = r[w];
     }
     const int32_t pos = w * 64 + 63 - (int32_t)__builtin_clzll(m);
-    e0 = ((uint32_t)(pos - (j - 1)) << 8) | r.lows[j - 1];
+    e0 = ((uint32_t)(pos - (j - 1)) << r.l) | r.low(j - 1);
   }
   if (c < run) {
-    e1 = (h << 8) | r.lows[j];
+    e1 = (h << r.l) | r.low(j);
   } else { // next entry lives in a later bucket: the lowest one above the zero that closes bucket h
     const int32_t pz = p_prev + 1 + run;
     int32_t w = (pz + 1) >> 6;
-    if (__builtin_expect(w >= r.up.words(), 0)) return -1;
-    uint64_t m = r.up[w] & ~((1ull << ((pz + 1) & 63)) - 1ull);
-    while (!m) {
-      if (__builtin_expect(++w >= r.up.words(), 0)) return -1;
-      m = r.up[w];
+    if (__builtin_expect(pz + 1 >= nbits, 0)) return -1;
+    uint64_t m = r[w] & ~((1ull << ((pz + 1) & 63)) - 1ull);
+    for (;;) {
+      const int64_t rem = (int64_t)nbits - 64 * (int64_t)w;
+      if (rem < 64) m &= (1ull << rem) - 1ull; // not the forced ones past the unary part
+      if (m) break;
+      if (__builtin_expect(++w >= r.words(), 0)) return -1;
+      m = r[w];
     }
     const int32_t pos = w * 64 + (int32_t)__builtin_ctzll(m);
-    e1 = ((uint32_t)(pos - j) << 8) | r.lows[j];
+    e1 = ((uint32_t)(pos - j) << r.l) | r.low(j);
   }
   *jout = j;
   *start = e0;
@@ -452,7 +460,8 @@ int TabDecoder::piece(int k) {
   const int64_t W = 2 * (int64_t)max_bs + 2;
   const TabPiece &pc = tv->piece[k];
   const int64_t i_beg = i, i_end = pc.end < n ? pc.end : n;
-  const uint8_t *const rows_end = pc.rows + pc.rows_len;
+  // a search may read up to 32 bytes past its row: rows must end that far before the end of the area
+  const uint8_t *const rows_end = pc.rows + (pc.rows_len >= 32 ? pc.rows_len - 32 : 0);
   const uint8_t *rowp = pc.rows; // sequential placement: a running sum, never stored
   const int64_t tl = pc.blk_off ? (tv->tl > 0 ? tv->tl : 1) : (i_end - i_beg > 0 ? i_end - i_beg : 1);
   for (int64_t blk = 0; i < i_end; ++blk) {
@@ -534,7 +543,8 @@ int TabDecoder::piece(int k) {
           }
           if (!done) value = bisect_reference(Row{row, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
         } else {
-          const EfRow r{row_bytes, Up64{row_bytes + tab_ef_lows_bytes((uint32_t)cnt), (int32_t)tab_ef_words((uint32_t)cnt)}, (int32_t)cnt};
+          const uint32_t efl = tab_ef_l((uint32_t)cnt);
+          const EfRow r{row_bytes, (int32_t)cnt, efl, tab_ef_hb((uint32_t)cnt, efl)};
           int32_t j;
           const int br = ef_bracket(r, cf, zero_before, &j, &start, &freq);
           if (__builtin_expect(br > 0, 1)) {
@@ -551,7 +561,7 @@ int TabDecoder::piece(int k) {
             }
             for (int32_t q = 0; q < cnt && rc == FGMM_OK; ++q) {
               const int32_t pos = ef_select1(r, (uint32_t)q);
-              if (pos < q) rc = FGMM_ERR_INVALID; else scratch[q] = (uint16_t)((((uint32_t)(pos - q)) << 8) | r.lows[q]);
+              if (pos < q) rc = FGMM_ERR_INVALID; else scratch[q] = (uint16_t)((((uint32_t)(pos - q)) << r.l) | r.low(q));
             }
             if (rc != FGMM_OK) break;
             value = bisect_reference(Row{scratch, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);

@@ -258,43 +258,35 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
   __shared__ uint32_t s_tmp[kBlock / 64];
   const uint32_t ex = block_scan_excl(bytes, s_tmp);
   if (!active) return;
-  uint8_t *__restrict__ row = d.pool + d.blk_off[(int64_t)cj * d.tiles + blockIdx.x] + ex; // 4-byte aligned
+  uint16_t *__restrict__ row = reinterpret_cast<uint16_t *>(d.pool + d.blk_off[(int64_t)cj * d.tiles + blockIdx.x] + ex); // 2-byte aligned
 
   if (!tab_row_is_ef(cnt, nonmono, d.ef_min)) {
-    // raw: uint16 entries, padded to an even count with the last value
-    const uint32_t len2 = (cnt + 1u) & ~1u;
-    for (uint32_t j0 = 0; j0 < len2; j0 += 2) {
-      const uint32_t e0 = L.edge(a_idx + (int)j0);
-      const uint32_t e1 = (j0 + 1 < cnt) ? L.edge(a_idx + (int)j0 + 1) : e0;
-      *reinterpret_cast<uint32_t *>(row + 2 * j0) = e0 | (e1 << 16);
-    }
+    for (uint32_t j = 0; j < cnt; ++j) row[j] = (uint16_t)L.edge(a_idx + (int)j); // raw: uint16 entries
   } else {
-    // Elias-Fano, 8 low bits: lows[cnt] (padded to 4), then U 32-bit words with bit ((E_j >> 8) + j) set
-    const uint32_t lows_bytes = tab_ef_lows_bytes(cnt), U = tab_ef_words(cnt);
-    uint32_t *__restrict__ up = reinterpret_cast<uint32_t *>(row + lows_bytes);
-    uint32_t wcur = 0, widx = 0;
-    for (uint32_t j0 = 0; j0 < lows_bytes; j0 += 4) {
-      uint32_t lo = 0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (j0 + t < cnt) {
-          const uint32_t e = L.edge(a_idx + (int)(j0 + t));
-          lo |= (e & 0xFFu) << (8 * t);
-          const uint32_t pos = (e >> 8) + j0 + t; // strictly increasing: the row is monotone
-          const uint32_t wi = pos >> 5;
-          while (widx < wi) {
-            up[widx++] = wcur;
-            wcur = 0;
-          }
-          wcur |= 1u << (pos & 31u);
-        }
+    // Elias-Fano: one bit string written 16 bits at a time: the unary high parts, then the low parts (the lane walks its
+    // row twice; this path serves the rare items too wide for the single-pass kernel)
+    const uint32_t l = tab_ef_l(cnt), HB = tab_ef_hb(cnt, l);
+    unsigned long long acc = 0; // bits not yet stored, from bit 0 up
+    uint32_t nb = 0, at = 0;    // valid bits in acc | 16-bit units stored
+    auto put = [&](uint32_t v, uint32_t bits) { // bits <= 16
+      acc |= (unsigned long long)v << nb;
+      nb += bits;
+      while (nb >= 16) {
+        row[at++] = (uint16_t)acc;
+        acc >>= 16;
+        nb -= 16;
       }
-      *reinterpret_cast<uint32_t *>(row + j0) = lo;
+    };
+    uint32_t pos_next = 0; // first bit of the high part not yet emitted
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t pos = (L.edge(a_idx + (int)j) >> l) + j; // strictly increasing: the row is monotone
+      for (uint32_t gap = pos - pos_next; gap; gap -= gap < 16 ? gap : 16) put(0, gap < 16 ? gap : 16);
+      put(1, 1);
+      pos_next = pos + 1;
     }
-    while (widx < U) {
-      up[widx++] = wcur;
-      wcur = 0;
-    }
+    for (uint32_t gap = HB - pos_next; gap; gap -= gap < 16 ? gap : 16) put(0, gap < 16 ? gap : 16);
+    for (uint32_t j = 0; j < cnt; ++j) put(L.edge(a_idx + (int)j) & ((1u << l) - 1u), l);
+    if (nb) put(0, 16 - nb);
   }
 }
 
@@ -316,11 +308,11 @@ struct TabSmem { // carve-up of the dynamic LDS of one block (every offset a mul
   uint32_t *offP;    // [tl + 1] pairs of edges before latent l
   uint32_t *win;     // [tl] j_lo | (j_hi - j_lo) << 16
   uint32_t *meta;    // [tl] a_idx | cnt << 16   (tab_tl: W <= cap_e <= 32768, so both fit)
-  uint32_t *rowoff;  // [tl + 1] byte offset of row l within the block's rows
+  uint32_t *rowoff;  // [tl + 1] byte offset of row l within the block's rows (rows are 2-byte aligned)
   uint16_t *tsat;    // [tl]
   uint8_t *flags;    // [tl] bit 0: parameters tame (fast evaluation allowed), bit 1: row non-monotone
   uint32_t *scratch; // [16]
-  uint32_t *efoff;   // [tl + 1] Elias-Fano rows before latent l: entries (low 16 bits) | upper words (high 16 bits)
+  uint32_t *efoff;   // [tl + 1] Elias-Fano rows before latent l: entries (low 16 bits) | words of unary high parts (high 16 bits)
   uint32_t *bitmap;  // [cap_e / 32 + 9 * tl] the unary high parts of the block's Elias-Fano rows
   uint32_t *E32;     // [cap_e / 2] evaluated edges, two uint16 per word: entry k of latent l is uint16 2 * offP[l] + k
   __device__ __forceinline__ TabSmem(unsigned char *base, int tl, int cap_e) {
@@ -543,10 +535,11 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   // ---- phase 4: place the block's rows; Elias-Fano rows: entries and upper words before each ------------------------
   uint32_t B, EFT;
   const uint32_t exB = tab_scan(bytes, S.scratch, &B);
+  const uint32_t B4 = (B + 3u) & ~3u; // blocks start 4-byte aligned (blk_off counts 4-byte units)
   uint32_t ef_pack = 0;
   if (tid < nl) {
     const uint32_t cnt = S.meta[tid] >> 16, nm = (S.flags[tid] >> 1) & 1u;
-    if (tab_row_is_ef(cnt, nm, d.ef_min)) ef_pack = cnt | (tab_ef_words(cnt) << 16); // both sums stay below 2^16 (cap_e <= 32768)
+    if (tab_row_is_ef(cnt, nm, d.ef_min)) ef_pack = cnt | (((tab_ef_hb(cnt, tab_ef_l(cnt)) + 31u) >> 5) << 16); // both sums stay below 2^16 (cap_e <= 32768)
   }
   const uint32_t exEF = tab_scan(ef_pack, S.scratch, &EFT);
   if (tid < nl) {
@@ -558,11 +551,11 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     S.efoff[nl] = EFT;
 #if FGMM_TAB_EXPERIMENT >= 1
     const unsigned long long base = (unsigned long long)(b - d.blk_begin) * tl * (2ull * W + 4);
-    if (b == d.blk_end - 1) d.counters[0] = base + B;
+    if (b == d.blk_end - 1) d.counters[0] = base + B4;
 #else
-    const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)B);
+    const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)B4);
 #endif
-    const bool fits = base + B <= d.rows_cap;
+    const bool fits = base + B4 <= d.rows_cap;
     if (!fits) atomicMax(&d.counters[1], 1ull);
 #if FGMM_TAB_EXPERIMENT < 2
     if (d.count_edges) atomicAdd(&d.counters[2], 2ull * NP);
@@ -584,8 +577,9 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   struct RowRef {
     const uint16_t *e; // first evaluated edge of the latent
     int j_lo, j_hi, a_idx;
-    uint32_t cnt, nm, T_sat, aux; // aux: first entry / first upper word of the row among the block's Elias-Fano rows
-    __device__ __forceinline__ void load(const TabSmem &S, const uint16_t *E16, int l) {
+    uint32_t cnt, nm, T_sat, aux; // aux: first entry / first word of the unary part of the row among the block's Elias-Fano rows
+    uint32_t efl, HB, M;          // Elias-Fano row: low bits, bits of the unary part, 2^20 / efl rounded up; efl = 0: raw row
+    __device__ __forceinline__ void load(const TabSmem &S, const uint16_t *E16, int l, uint32_t ef_min) {
       const uint32_t w = S.win[l], mt = S.meta[l];
       j_lo = (int)(w & 0xFFFFu);
       j_hi = j_lo + (int)(w >> 16);
@@ -595,6 +589,9 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       T_sat = S.tsat[l];
       e = E16 + 2 * (size_t)S.offP[l] - j_lo; // e[idx] for j_lo <= idx < j_hi
       aux = S.efoff[l];
+      efl = tab_row_is_ef(cnt, nm, ef_min) ? tab_ef_l(cnt) : 0u;
+      HB = efl ? tab_ef_hb(cnt, efl) : 0u;
+      M = efl ? (1u << 20) / efl + 1u : 0u;
     }
     // entry k of the row: F[a_idx + k] — an evaluated edge, or one of the two constants outside the evaluation window
     __device__ __forceinline__ uint32_t entry(uint32_t k) const {
@@ -603,7 +600,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     }
   };
 
-  // ---- phase 5a: unary high parts of the Elias-Fano rows, FLATTENED over their entries: bit ((E_j >> 8) + j) ---------
+  // ---- phase 5a: unary high parts of the Elias-Fano rows, FLATTENED over their entries: bit ((E_j >> l) + j) ---------
   {
     const uint32_t NE = EFT & 0xFFFFu;
     const uint32_t Q = (((NE + 3) >> 2) + 63u) & ~63u;
@@ -619,7 +616,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
         if ((S.efoff[mid] & 0xFFFFu) <= t) lo = mid; else hi = mid;
       }
       l = lo;
-      R.load(S, E16, l);
+      R.load(S, E16, l, d.ef_min);
       l_beg = R.aux & 0xFFFFu;
       l_end = S.efoff[l + 1] & 0xFFFFu;
     }
@@ -630,59 +627,65 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
           l_beg = l_end;
           l_end = S.efoff[l + 1] & 0xFFFFu;
         } while (t >= l_end);
-        R.load(S, E16, l);
+        R.load(S, E16, l, d.ef_min);
       }
-      const uint32_t k = t - l_beg, pos = (R.entry(k) >> 8) + k;
+      const uint32_t k = t - l_beg, pos = (R.entry(k) >> R.efl) + k;
       atomicOr(&S.bitmap[(R.aux >> 16) + (pos >> 5)], 1u << (pos & 31u));
     }
   }
   __syncthreads();
 
-  // ---- phase 5b: FLATTENED over the 4-byte words of the block's rows, coalesced stores --------------------------------
+  // ---- phase 5b: FLATTENED over the 16-bit units of the block's rows; lane pairs store 4 bytes, coalesced ---------------
   {
-    const uint32_t NW = B >> 2;
-    const uint32_t Q = (((NW + 3) >> 2) + 63u) & ~63u;
-    const uint32_t q_end = std::min(NW, (uint32_t)(wave + 1) * Q);
-    uint32_t q = (uint32_t)wave * Q + (uint32_t)lane;
-    int l = 0;
+    const uint32_t NU = B4 >> 1; // even
+    const uint32_t Q = (((NU + 3) >> 2) + 63u) & ~63u;
+    const uint32_t u_end = std::min(NU, (uint32_t)(wave + 1) * Q);
+    int l = -1;
     uint32_t r_beg = 0, r_end = 0;
     RowRef R;
-    if (q < q_end) {
-      l = find_owner(S.rowoff, nl, 4 * q);
-      r_beg = S.rowoff[l];
-      r_end = S.rowoff[l + 1];
-      R.load(S, E16, l);
-    }
-    for (; q < q_end; q += 64) {
-      if (4 * q >= r_end) {
-        do {
-          ++l;
-          r_beg = r_end;
-          r_end = S.rowoff[l + 1];
-        } while (4 * q >= r_end);
-        R.load(S, E16, l);
-      }
-      uint32_t word = (4 * q - r_beg) >> 2; // word of the row
-      uint32_t val;
-      const bool escaped = d.hdr_form == 2 && R.nm;
-      if (escaped && word == 0) {
-        val = tab_hdr_pack(R.a_idx - max_bs, R.cnt, 1u);
-      } else if (!tab_row_is_ef(R.cnt, R.nm, d.ef_min)) {
-        if (escaped) --word;
-        const uint32_t k0 = 2 * word, e0 = R.entry(k0);
-        val = e0 | ((k0 + 1 < R.cnt ? R.entry(k0 + 1) : e0) << 16);
-      } else {
-        const uint32_t LW = tab_ef_lows_bytes(R.cnt) >> 2;
-        if (word < LW) {
-          val = 0;
-#pragma unroll
-          for (uint32_t t = 0; t < 4; ++t)
-            if (4 * word + t < R.cnt) val |= (R.entry(4 * word + t) & 0xFFu) << (8 * t);
+    for (uint32_t u0 = (uint32_t)wave * Q; u0 < u_end; u0 += 64) { // wave-uniform trip count: the lanes exchange halves
+      const uint32_t u = u0 + (uint32_t)lane;
+      uint32_t half = 0;
+      if (2 * u < B) { // (units past B: the block's padding to 4 bytes)
+        if (2 * u >= r_end) {
+          if (l < 0) {
+            l = find_owner(S.rowoff, nl, 2 * u);
+            r_beg = S.rowoff[l];
+            r_end = S.rowoff[l + 1];
+          } else {
+            do {
+              ++l;
+              r_beg = r_end;
+              r_end = S.rowoff[l + 1];
+            } while (2 * u >= r_end);
+          }
+          R.load(S, E16, l, d.ef_min);
+        }
+        uint32_t h = (2 * u - r_beg) >> 1; // 16-bit unit of the row
+        const bool escaped = d.hdr_form == 2 && R.nm;
+        if (escaped && h < 2) {
+          half = (tab_hdr_pack(R.a_idx - max_bs, R.cnt, 1u) >> (16 * h)) & 0xFFFFu;
+        } else if (!R.efl) {
+          half = R.entry(escaped ? h - 2 : h);
         } else {
-          val = S.bitmap[(R.aux >> 16) + (word - LW)];
+          const uint32_t bit0 = 16 * h;
+          if (bit0 < R.HB) half = (S.bitmap[(R.aux >> 16) + (h >> 1)] >> (16 * (h & 1u))) & 0xFFFFu; // zero from bit HB on
+          if (bit0 + 16 > R.HB) { // low parts that overlap bits [bit0, bit0 + 16)
+            const int rel = (int)bit0 - (int)R.HB; // of the low area
+            uint32_t j = rel > 0 ? ((uint32_t)rel * R.M) >> 20 : 0u; // rel / efl  (rel < 2^15: exact)
+            const uint32_t mask = (1u << R.efl) - 1u;
+            for (; j < R.cnt; ++j) {
+              const int sh = (int)(j * R.efl) - rel;
+              if (sh >= 16) break;
+              const uint32_t lowbits = R.entry(j) & mask;
+              half |= sh >= 0 ? lowbits << sh : lowbits >> -sh;
+            }
+            half &= 0xFFFFu;
+          }
         }
       }
-      stg<uint32_t>(out + 4 * (size_t)q, val);
+      const uint32_t other = (uint32_t)__shfl_down((int)half, 1, 64);
+      if (!(lane & 1) && u < u_end) stg<uint32_t>(out + 2 * (size_t)u, half | (other << 16));
     }
   }
 }

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 
-EF_MIN = 48
+EF_MIN = 14
 MAX_BS_H4 = 16382
 
 
@@ -20,10 +20,19 @@ def row_is_ef(cnt: int, nonmono: int) -> bool:
     return cnt >= EF_MIN and not nonmono
 
 
+def ef_l(cnt: int) -> int:
+    """low bits of an Elias-Fano row: 16 - ceil(log2(cnt)) within [8, 12]"""
+    lg = 0
+    while (1 << lg) < cnt:
+        lg += 1
+    return min(max(16 - lg, 8), 12)
+
+
 def row_bytes(cnt: int, nonmono: int) -> int:
     if row_is_ef(cnt, nonmono):
-        return ((cnt + 3) & ~3) + 4 * ((cnt + 256 + 31) >> 5)
-    return 2 * ((cnt + 1) & ~1)
+        l = ef_l(cnt)
+        return 2 * ((cnt * (l + 1) + (65536 >> l) + 15) >> 4)
+    return 2 * cnt
 
 
 def _trim_row(F: np.ndarray):
@@ -42,15 +51,15 @@ def _trim_row(F: np.ndarray):
 def _row_payload(row: np.ndarray, nonmono: int):
     cnt = len(row)
     if row_is_ef(cnt, nonmono):
-        lows = np.zeros((cnt + 3) & ~3, np.uint8)
-        lows[:cnt] = row & 0xFF
-        U = (cnt + 256 + 31) >> 5
-        bits = np.zeros(U * 32, np.uint8)
-        bits[(row >> 8) + np.arange(cnt)] = 1
-        up = np.packbits(bits.reshape(U, 32)[:, ::-1], axis=1).view(">u4").astype("<u4").reshape(-1)
-        return [lows, up.view(np.uint8)]
-    pad = (-cnt) % 2
-    return [np.concatenate([row, np.full(pad, row[-1])]).astype("<u2").view(np.uint8)]
+        l = ef_l(cnt)
+        HB = cnt + (65536 >> l)
+        nbytes = row_bytes(cnt, nonmono)
+        bits = np.zeros(8 * nbytes, np.uint8)
+        bits[(row >> l) + np.arange(cnt)] = 1
+        lows = ((row[:, None] >> np.arange(l)[None, :]) & 1).astype(np.uint8)  # [cnt, l], bit 0 first
+        bits[HB:HB + cnt * l] = lows.reshape(-1)
+        return [np.packbits(bits, bitorder="little")]
+    return [row.astype("<u2").view(np.uint8)]
 
 
 def _pack_hdr4(a: int, cnt: int, nonmono: int) -> int:
@@ -58,7 +67,7 @@ def _pack_hdr4(a: int, cnt: int, nonmono: int) -> int:
 
 
 def trim_full_table(tab: np.ndarray, max_bs: int, form: int = 4, tl: int = 0, shuffle_seed=None):
-    """full table [n, W=2*max_bs+2] (F_i[v], v=-max_bs..max_bs+1) -> (hdr, pool uint8[...], used bytes) in format v4 of
+    """full table [n, W=2*max_bs+2] (F_i[v], v=-max_bs..max_bs+1) -> (hdr, pool uint8[...], used bytes) in format v5 of
     include/flashgmm_amd.h: `form`-byte headers; rows sequential in latent order (tl = 0) or, with tl > 0, per block of tl
     latents at 4 * blk_off[block] — then (hdr, blk_off, pool, used) is returned, the blocks placed in a shuffled order
     when shuffle_seed is given (the single-pass kernel places them in no particular order)."""
@@ -98,6 +107,9 @@ def trim_full_table(tab: np.ndarray, max_bs: int, form: int = 4, tl: int = 0, sh
         for r in rows[b * tl:(b + 1) * tl]:
             parts.append(r)
             off += len(r)
+        if off % 4:  # blocks start 4-byte aligned
+            parts.append(np.zeros(2, np.uint8))
+            off += 2
     pool = np.concatenate(parts + [np.zeros(128, np.uint8)]) if parts else np.zeros(128, np.uint8)
     return hdr, blk_off, pool, off
 
@@ -132,16 +144,16 @@ def expand_trimmed(hdr: np.ndarray, pool: np.ndarray, max_bs: int, blk_off=None,
             a = a - (1 << 32) if a >= (1 << 31) else a
             cnt, nonmono = (h >> 32) & 0x7FFFFFFF, h >> 63
         if row_is_ef(cnt, nonmono):
-            lb = (cnt + 3) & ~3
-            U = (cnt + 256 + 31) >> 5
-            lows = pool[off:off + cnt].astype(np.int64)
-            up = pool[off + lb:off + lb + 4 * U].view("<u4")
-            bits = np.unpackbits(up.astype(">u4").view(np.uint8).reshape(U, 4), axis=1)[:, ::-1].reshape(-1)
-            pos = np.nonzero(bits)[0]
+            l = ef_l(cnt)
+            HB = cnt + (65536 >> l)
+            bits = np.unpackbits(pool[off:off + row_bytes(cnt, nonmono)], bitorder="little").astype(np.int64)
+            pos = np.nonzero(bits[:HB])[0]
             assert len(pos) == cnt, (i, len(pos), cnt)
-            row = ((pos - np.arange(cnt)) << 8) | lows
+            lows = (bits[HB:HB + cnt * l].reshape(cnt, l) << np.arange(l)[None, :]).sum(1)
+            assert not bits[HB + cnt * l:].any(), i  # the padding to 16 bits is zero
+            row = ((pos - np.arange(cnt)) << l) | lows
         else:
-            row = pool[off:off + 2 * cnt].view("<u2").astype(np.int64)
+            row = pool[off:off + 2 * cnt].copy().view("<u2").astype(np.int64)
         off += row_bytes(cnt, nonmono)
         j0 = a + max_bs
         out[i, j0:j0 + cnt] = row

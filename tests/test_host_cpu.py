@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from flashgmm_amd import _lib, testing as T
+import helpers
 from helpers import expand_trimmed, host_decode_cdftab, host_decode_tab, host_encode_symtab, trim_full_table
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -234,6 +235,52 @@ def test_host_decoder_elias_fano_rows(oracle):
     assert rc == 0 and np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("shape", ["uniform", "gaussian"])
+def test_host_decoder_elias_fano_rows_of_every_width(oracle, shape):
+    """format v5: the low part of an Elias-Fano row has 12 bits (14..16 entries) down to 8 bits (> 128 entries), rows are
+    2-byte aligned: rows of every count from 1 to the full window, uniform entries and CDF-shaped ones (dense tails)"""
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    max_bs = 99
+    W = 2 * max_bs + 2
+    n = 6 * W
+    tab = np.zeros((n, W), np.uint16)
+    for i in range(n):
+        cnt = 1 + i % W
+        a = int(rng.integers(0, W - cnt + 1))
+        if shape == "uniform":
+            row = np.sort(rng.integers(1, 65536, cnt))
+        else:
+            from math import erf
+            s = cnt / rng.uniform(3.0, 7.0)
+            row = np.array([32768 * (1 + erf((k - cnt / 2) / (s * 2 ** 0.5 + 1e-9))) for k in range(cnt)]).astype(np.int64)
+            row = np.clip(np.maximum.accumulate(row), 1, 65535)
+        tab[i, a:a + cnt] = row
+        tab[i, a + cnt:] = row[-1]
+    hdr, pool, used = trim_full_table(tab, max_bs)
+    cnts = (hdr >> 16) & 0x7FFF
+    from helpers import ef_l
+    assert {ef_l(int(k)) for k in cnts if k >= helpers.EF_MIN} == {8, 9, 10, 11, 12}
+    assert np.array_equal(expand_trimmed(hdr, pool, max_bs), tab)
+    enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+    want = oracle.rans_decode_cdftab(enc, tab, max_bs)
+    rc, out = host_decode_cdftab(L, enc, hdr, pool, max_bs)
+    assert rc == 0 and np.array_equal(out, want)
+    # and a real bitstream: symbols drawn from each row's own distribution (every row searched where its mass is)
+    t64 = tab.astype(np.int64)
+    sym = np.empty(n, np.int32)
+    packed = np.empty(n, np.uint32)
+    for i in range(n):
+        pmf = np.diff(t64[i])                      # symbol v = j - max_bs has the interval [F[j], F[j+1])
+        j = int(rng.choice(np.nonzero(pmf > 0)[0])) if (pmf > 0).any() else 0
+        sym[i] = j - max_bs
+        packed[i] = int(t64[i, j]) | (int(max(pmf[j], 1)) << 16)
+    enc2 = oracle.rans_encode_symtab(packed, sym)
+    rc, out = host_decode_cdftab(L, enc2, hdr, pool, max_bs)
+    assert rc == 0 and np.array_equal(out, oracle.rans_decode_cdftab(enc2, tab, max_bs))
+    assert np.array_equal(out[np.diff(t64, axis=1).max(1) > 0], sym[np.diff(t64, axis=1).max(1) > 0])
+
+
 @pytest.mark.parametrize("max_bs,tl", [(9, 16), (9, 48), (99, 32), (200, 32), (70000, 16)])
 def test_host_decoder_header_forms_and_block_placement(oracle, max_bs, tl):
     """format v4: 2-byte headers (with the escape for non-monotone rows), 4- and 8-byte headers, rows placed block by
@@ -317,10 +364,11 @@ def test_host_decoder_rejects_malformed_tables(oracle):
         off = 0
         for i in range(n):
             cnt = (int(hdr[i]) >> 16) & 0x7FFF
-            lb, U = (cnt + 3) & ~3, (cnt + 256 + 31) >> 5
+            assert helpers.row_is_ef(cnt, 0)
+            hb_bytes = (cnt + (65536 >> helpers.ef_l(cnt))) // 8
             if i % 2 == 0:
-                p2[off + lb: off + lb + 4 * U] = fill
-            off += lb + 4 * U
+                p2[off: off + hb_bytes] = fill
+            off += helpers.row_bytes(cnt, 0)
         rc, _ = host_decode_cdftab(L, enc, hdr, p2, max_bs)
         assert rc in (0, 1)  # no crash; whatever is decodable decodes, the rest is refused
 
