@@ -162,7 +162,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 4, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -620,7 +620,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   const bool clamped = items[0].clamp != 0, f16 = items[0].prm.dtype == FGMM_F16;
   // Elias-Fano rows are 30 % smaller than uint16 rows and 35 % slower to search: they pay when PCIe is the bottleneck of
   // the call (at least as many bitstreams as host workers), not when it is bound by its few sequential decoders
-  const uint32_t ef_min = ctx->opt.ef_rows == 1 || (ctx->opt.ef_rows == 0 && count >= ctx->pool->size()) ? kTabEfMin : kTabNoEf;
+  const uint32_t ef_min = ctx->opt.ef_rows == 1 || (ctx->opt.ef_rows == 0 && count >= ctx->pool->size()) ? (uint32_t)ctx->opt.ef_min : kTabNoEf;
 
   // ---- items: coded channels, header form, path --------------------------------------------------------------------
   Arena ar; // device workspace, mirrored in h_ws up to the counters
@@ -847,62 +847,107 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       ready.push(Key{it.next_piece, i});
     }
   };
+  // before / after a piece is decoded (no lock held)
+  auto prepare = [&](DecItem &it, int p) {
+    if (p == 0) {
+      it.t_taken = tr.ms();
+      it.view = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
+      if (it.status == FGMM_OK) it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
+    }
+    const double tw0 = tr.level > 1 ? tr.ms() : 0;
+    if (it.status == FGMM_OK && hipEventSynchronize(it.piece_ev[p]) != hipSuccess) it.status = FGMM_ERR_HIP;
+    const double tw1 = tr.level > 1 ? tr.ms() : 0;
+    it.t_waited += tw1 - tw0;
+    it.t_lastland = tw1;
+    if (p == 0) it.t_start = tw1;
+  };
+  auto complete = [&](DecItem &it, int p) { // true: the item is finished
+    const bool last = it.status != FGMM_OK || p + 1 == it.n_piece;
+    if (!last) return false;
+    const int rf = it.dec.finish();
+    if (it.status == FGMM_OK) it.status = rf;
+    if (it.status == FGMM_OK && it.y_hat) {
+      // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
+      int16_t *s16 = reinterpret_cast<int16_t *>(it.h_out);
+      int32_t acc = 0;
+      for (int64_t k = 0; k < it.n; ++k) {
+        const int32_t v = it.sym[k];
+        s16[k] = (int16_t)v;
+        acc |= v ^ (int32_t)(int16_t)v;
+      }
+      it.wide = acc != 0;
+      if (it.wide) memcpy(it.h_out, it.sym, sizeof(int32_t) * (size_t)it.n);
+    }
+    it.t_end = tr.ms();
+    return true;
+  };
+  int waiting = 0; // workers asleep on work_cv (under mu)
+  const bool pairing = ctx->opt.dec_pair != 0;
   auto worker = [&] {
     std::unique_lock<std::mutex> l(mu);
-    for (;;) {
-      if (unfinished == 0) return;
-      if (ready.empty()) {
-        if (abandon) return;
-        work_cv.wait(l);
-        continue;
-      }
+    auto take = [&](int *p_out) { // under mu: the earliest-landing ready task
       const int i = ready.top().second;
       ready.pop();
+      items[i].in_ready = false;
+      items[i].busy = true;
+      *p_out = items[i].next_piece;
+      return i;
+    };
+    auto give_back = [&](int i, int p, bool finished) { // under mu
       DecItem &it = items[i];
-      it.in_ready = false;
-      it.busy = true;
-      const int p = it.next_piece;
-      l.unlock();
-      if (p == 0) {
-        it.t_taken = tr.ms();
-        it.view = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
-        if (it.status == FGMM_OK) it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
-      }
-      const double tw0 = tr.level > 1 ? tr.ms() : 0;
-      if (it.status == FGMM_OK && hipEventSynchronize(it.piece_ev[p]) != hipSuccess) it.status = FGMM_ERR_HIP;
-      const double tw1 = tr.level > 1 ? tr.ms() : 0;
-      it.t_waited += tw1 - tw0;
-      it.t_lastland = tw1;
-      if (p == 0) it.t_start = tw1;
-      if (it.status == FGMM_OK) it.status = it.dec.piece(p);
-      if (tr.level > 1) it.t_work += tr.ms() - tw1;
-      const bool last = it.status != FGMM_OK || p + 1 == it.n_piece;
-      if (last) {
-        const int rf = it.dec.finish();
-        if (it.status == FGMM_OK) it.status = rf;
-        if (it.status == FGMM_OK && it.y_hat) {
-          // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
-          int16_t *s16 = reinterpret_cast<int16_t *>(it.h_out);
-          int32_t acc = 0;
-          for (int64_t k = 0; k < it.n; ++k) {
-            const int32_t v = it.sym[k];
-            s16[k] = (int16_t)v;
-            acc |= v ^ (int32_t)(int16_t)v;
-          }
-          it.wide = acc != 0;
-          if (it.wide) memcpy(it.h_out, it.sym, sizeof(int32_t) * (size_t)it.n);
-        }
-        it.t_end = tr.ms();
-      }
-      l.lock();
       it.busy = false;
       it.next_piece = p + 1;
-      if (last) {
+      if (finished) {
         it.done.store(1);
         if (--unfinished == 0) work_cv.notify_all();
         done_cv.notify_all();
       } else {
         push_if_ready(i);
+      }
+    };
+    for (;;) {
+      if (unfinished == 0) return;
+      if (ready.empty()) {
+        if (abandon) return;
+        ++waiting;
+        work_cv.wait(l);
+        --waiting;
+        continue;
+      }
+      int p0 = 0, p1 = 0;
+      const int i0 = take(&p0);
+      // a second bitstream for this thread (decoded latent by latent in turn with the first: two dependency chains share
+      // the core) - unless that would leave a sleeping worker without a task
+      const int i1 = pairing && !ready.empty() && (int)ready.size() > waiting ? take(&p1) : -1;
+      l.unlock();
+      DecItem &a = items[i0];
+      prepare(a, p0);
+      const double t0 = tr.level > 1 ? tr.ms() : 0;
+      if (i1 < 0) {
+        if (a.status == FGMM_OK) a.status = a.dec.piece(p0);
+        if (tr.level > 1) a.t_work += tr.ms() - t0;
+        const bool fa = complete(a, p0);
+        l.lock();
+        give_back(i0, p0, fa);
+      } else {
+        DecItem &b = items[i1];
+        prepare(b, p1);
+        const double t1 = tr.level > 1 ? tr.ms() : 0;
+        if (a.status == FGMM_OK && b.status == FGMM_OK) {
+          rans_decode_pieces2(a.dec, p0, b.dec, p1, &a.status, &b.status);
+        } else {
+          if (a.status == FGMM_OK) a.status = a.dec.piece(p0);
+          if (b.status == FGMM_OK) b.status = b.dec.piece(p1);
+        }
+        if (tr.level > 1) {
+          const double dt = tr.ms() - t1;
+          a.t_work += dt / 2;
+          b.t_work += dt / 2;
+        }
+        const bool fa = complete(a, p0), fb = complete(b, p1);
+        l.lock();
+        give_back(i0, p0, fa);
+        give_back(i1, p1, fb);
       }
     }
   };
@@ -1122,6 +1167,8 @@ const OptName kOpts[] = {
     {"enc_vec", &fgmm_ctx::Opts::enc_vec, 0, 4, "FGMM_VEC"},
     {"enc_linear", &fgmm_ctx::Opts::enc_linear, 0, 1, nullptr},
     {"ef_rows", &fgmm_ctx::Opts::ef_rows, 0, 2, "FGMM_EF_ROWS"},
+    {"ef_min", &fgmm_ctx::Opts::ef_min, kTabEfMin, 1 << 20, "FGMM_EF_MIN_ROWS"},
+    {"dec_pair", &fgmm_ctx::Opts::dec_pair, 0, 1, "FGMM_DEC_PAIR"},
 };
 } // namespace
 

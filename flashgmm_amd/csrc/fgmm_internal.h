@@ -80,17 +80,18 @@ struct DecDesc {
 //   row i = F_i[a .. a+cnt), starting at the first non-zero edge (F_i[v < a] = 0, F_i[v >= a+cnt] = last entry);
 //   rows 2-byte aligned:
 //     raw (cnt < kTabEfMin or nonmono): uint16[cnt]
-//     EF  (cnt >= kTabEfMin, monotone): Elias-Fano with l = tab_ef_l(cnt) low bits, ONE little-endian bit string (bit b of
+//     EF  (cnt >= kTabEfMin, monotone): Elias-Fano with l = tab_ef_l(cnt) low bits (12 up to 48 entries, else 8), ONE little-endian bit string (bit b of
 //                                       the row = bit (b & 7) of byte b >> 3), rounded up to 16 bits:
 //                                         bits [0, HB), HB = cnt + (65536 >> l): bit ((E_j >> l) + j) set for every entry j
-//                                         bits [HB + j * l, HB + (j + 1) * l): the low l bits of E_j
+//                                         bits [LB + j * l, LB + (j + 1) * l), LB = HB rounded up to 8: the low l bits of E_j
 //   placement: sequential in latent order (generic path, the building-block API), or per block of `tl` latents at
 //   rows + 4 * blk_off[block] (tab_kernel: blocks are placed by an atomic cursor, in no particular order)
 constexpr int kMaxPieces = 8; // FGMM_MAX_PIECES
 #ifndef FGMM_EF_MIN
 #define FGMM_EF_MIN 14
 #endif
-constexpr uint32_t kTabEfMin = FGMM_EF_MIN; // rows with at least this many entries are Elias-Fano coded
+constexpr uint32_t kTabEfMin = FGMM_EF_MIN; // rows with at least this many entries MAY be Elias-Fano coded (smaller than raw from here on)
+constexpr uint32_t kTabEfDefault = 49;     // ... and are, by default, in the batched decoder ("ef_min" option): see DESIGN.md section 5
 constexpr uint32_t kHdr2Escape = 255;
 FGMM_HD static inline uint32_t tab_hdr_pack(int32_t a, uint32_t cnt, uint32_t nonmono) {
   return (uint32_t)(uint16_t)(int16_t)a | ((cnt & 0x7FFFu) << 16) | (nonmono << 31);
@@ -105,16 +106,14 @@ FGMM_HD static inline unsigned long long tab_hdr8_pack(int32_t a, uint32_t cnt, 
 // such row) when a call is bound by its host decoders: a uint16 row is searched faster, an Elias-Fano row is smaller
 constexpr uint32_t kTabNoEf = 0x7FFFFFFFu;
 FGMM_HD static inline bool tab_row_is_ef(uint32_t cnt, uint32_t nonmono, uint32_t ef_min) { return cnt >= ef_min && !nonmono; }
-// low bits of an Elias-Fano row: 16 - ceil(log2(cnt)) within [8, 12] (12 for cnt <= 16 ... 8 for cnt > 128): within a
-// few bytes of the best choice for every cnt, and always below the 2 * cnt bytes of the raw form from cnt = 14 on
-FGMM_HD static inline uint32_t tab_ef_l(uint32_t cnt) {
-  uint32_t lg = 0; // ceil(log2(cnt))
-  while (lg < 16 && (1u << lg) < cnt) ++lg;
-  const uint32_t l = 16u - lg;
-  return l < 8u ? 8u : (l > 12u ? 12u : l);
-}
+// low bits of an Elias-Fano row: 12 up to 48 entries (16 buckets: the unary part is one 64-bit word for the host's
+// search), 8 beyond (256 buckets, low parts are bytes).  Within 2 % of the best choice per row on Kodak-like tables, and
+// below the 2 * cnt bytes of the raw form from cnt = 14 on.
+constexpr uint32_t kTabEf12Max = 48;
+FGMM_HD static inline uint32_t tab_ef_l(uint32_t cnt) { return cnt <= kTabEf12Max ? 12u : 8u; }
 FGMM_HD static inline uint32_t tab_ef_hb(uint32_t cnt, uint32_t l) { return cnt + (65536u >> l); } // bits of the unary high part
-FGMM_HD static inline unsigned long long tab_ef_bits(uint32_t cnt, uint32_t l) { return (unsigned long long)cnt * (l + 1u) + (65536u >> l); }
+FGMM_HD static inline uint32_t tab_ef_lb(uint32_t cnt, uint32_t l) { return (tab_ef_hb(cnt, l) + 7u) & ~7u; }       // first bit of the low parts
+FGMM_HD static inline unsigned long long tab_ef_bits(uint32_t cnt, uint32_t l) { return (unsigned long long)cnt * l + tab_ef_lb(cnt, l); }
 FGMM_HD static inline unsigned long long tab_row_bytes(uint32_t cnt, uint32_t nonmono, uint32_t ef_min) {
   return tab_row_is_ef(cnt, nonmono, ef_min) ? 2ull * ((tab_ef_bits(cnt, tab_ef_l(cnt)) + 15ull) >> 4) : 2ull * (unsigned long long)cnt;
 }
@@ -203,5 +202,7 @@ struct TabDecoder {
   int piece(int k);
   int finish();
 };
+// two pieces of two decoders on one thread, latent by latent in turn (two dependency chains share the core)
+void rans_decode_pieces2(TabDecoder &a, int ka, TabDecoder &b, int kb, int *rc_a, int *rc_b);
 
 } // namespace fgmm

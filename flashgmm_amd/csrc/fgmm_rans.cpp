@@ -282,13 +282,14 @@ __attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *r
 }
 
 // ---- Elias-Fano rows (format v5): one bit string: HB = cnt + (65536 >> l) bits of unary high parts (bit (E_j >> l) + j
-// set for entry j), then the low l bits of every entry.  Bucket b (the entries whose high part is b) is a run of ones
-// followed by one zero; zero #b sits at bit b + (number of entries with high part <= b).  The unary part is read 64 bits
-// at a time (rows are only 2-byte aligned); bits from HB on - the low parts, the next row - read as ones ("no zero there").
+// set for entry j), then, from the next byte boundary LB on, the low l bits of every entry.  Bucket b (the entries whose
+// high part is b) is a run of ones followed by one zero; zero #b sits at bit b + (number of entries with high part <= b).
+// The unary part is read 64 bits at a time (rows are only 2-byte aligned); bits from HB on - the low parts, the next row -
+// read as ones ("no zero there").
 struct EfRow {
   const uint8_t *p;
   int32_t cnt;
-  uint32_t l, HB;
+  uint32_t l, HB, LB;
   inline int32_t words() const { return (int32_t)((HB + 63u) >> 6); }
   inline uint64_t operator[](int64_t w) const {
     uint64_t v;
@@ -298,7 +299,7 @@ struct EfRow {
     return v;
   }
   inline uint32_t low(int32_t j) const {
-    const uint32_t b = HB + (uint32_t)j * l;
+    const uint32_t b = LB + (uint32_t)j * l;
     uint32_t v;
     memcpy(&v, p + (b >> 3), 4);
     return (v >> (b & 7u)) & ((1u << l) - 1u);
@@ -334,8 +335,68 @@ __attribute__((target("bmi2,popcnt"))) inline int32_t ef_select1(const EfRow &r,
 // Bracket search: 1 with (*j, *start, *freq) such that E[j-1] = start <= cf < E[j]; 0 when no entry pair brackets cf
 // (j would be 0 or cnt) - the caller replays the reference's bisection; -1 for a malformed row (hostile table).
 // zero_before: an (unstored) zero edge precedes the row, so cf below the first entry is the interval [0, E_0): j = 0.
-__attribute__((target("bmi2,popcnt"))) inline int ef_bracket(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
-                                                            uint32_t *start, uint32_t *freq) {
+// Rows of up to 48 entries (12 low bits, 16 buckets): the unary part is ONE 64-bit word and everything between cf and
+// (start, freq) is straight-line code on it - the decoder's dependency chain runs through this search, a mispredicted
+// branch costs as much as the whole of it, and so do the extra instructions of a general search.
+__attribute__((target("bmi2,popcnt,lzcnt"))) inline int ef_bracket64(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
+                                                                    uint32_t *start, uint32_t *freq) {
+  constexpr uint32_t l = 12, m = 0xFFFu;
+  uint64_t w;
+  memcpy(&w, r.p, 8);
+  const uint32_t HB = r.HB; // 30 .. 64
+  const uint64_t vm = _bzhi_u64(~0ull, HB), O = w & vm, Z = ~w & vm; // valid bits; entries; the zeros that close the buckets
+  const uint32_t h = cf >> l, lcf = cf & m;
+  // first bit of bucket h = one past the zero that closes bucket h - 1; with a zero imagined at bit -1 that is zero #h of
+  // Z << 1 | 1 (the zero that closes the last bucket is shifted out: never asked for)
+  const uint32_t s = (uint32_t)_tzcnt_u64(_pdep_u64(1ull << h, (Z << 1) | 1ull)); // 64 when the row is malformed
+  if (__builtin_expect(s >= HB, 0)) return -1;
+  const int32_t lo = (int32_t)s - (int32_t)h;                       // entries with a high part < h
+  const int32_t run = (int32_t)_tzcnt_u64(~((w | ~vm) >> s));        // size of bucket h (the shifted-in bits end any run)
+  if (__builtin_expect(lo < 0 || lo + run > r.cnt || s + (uint32_t)run >= HB, 0)) return -1;
+  // entries of bucket h whose low part is <= lcf (low parts ascend inside a bucket): four fields at once
+  const uint32_t b = r.LB + (uint32_t)lo * l;
+  uint64_t v;
+  memcpy(&v, r.p + (b >> 3), 8);
+  v >>= (b & 7u);
+  // (no && here: the compiler turns those into branches on run, which the predictor cannot learn)
+  const uint32_t le = (uint32_t)(((uint32_t)v & m) <= lcf) | ((uint32_t)(((uint32_t)(v >> l) & m) <= lcf) << 1) |
+                      ((uint32_t)(((uint32_t)(v >> (2 * l)) & m) <= lcf) << 2) | ((uint32_t)(((uint32_t)(v >> (3 * l)) & m) <= lcf) << 3);
+  int32_t c = __builtin_popcount(le & _bzhi_u32(15u, (uint32_t)run)); // among the first min(run, 4) entries of the bucket
+  if (__builtin_expect(run > 4 && c == 4, 0)) { // the two tail buckets of a row hold many entries and are rarely asked for
+    int32_t hi = run; // low(lo + c - 1) <= lcf < low(lo + hi)
+    while (c < hi) {
+      const int32_t mid = (c + hi) >> 1;
+      if (r.low(lo + mid) <= lcf) c = mid + 1; else hi = mid;
+    }
+  }
+  const int32_t j = lo + c;
+  if (__builtin_expect((j < 1 && !zero_before) || j >= r.cnt, 0)) return 0;
+  // Entries j - 1 and j in full.  Their high parts are h when they lie in bucket h, else those of the entries next to the
+  // bucket - which depend on (s, run) only and are ready by the time c is; their low parts are fields of v or the one before.
+  const uint32_t pos_prev = 63u - (uint32_t)_lzcnt_u64(_bzhi_u64(O, s));                         // entry lo - 1 (garbage if none: unused)
+  const uint32_t pos_next = s + (uint32_t)run + 1u + (uint32_t)_tzcnt_u64((O >> (s + (uint32_t)run)) >> 1); // entry lo + run
+  const uint32_t hp_prev = pos_prev - (uint32_t)(lo - 1), hp_next = pos_next - (uint32_t)(lo + run);
+  uint32_t low_j, low_f;
+  if (__builtin_expect(c <= 4, 1)) {
+    low_j = c < 4 ? (uint32_t)(v >> ((uint32_t)c * l)) & m : r.low(j);
+    low_f = (uint32_t)(v >> (((uint32_t)(c - 1) & 3u) * l)) & m; // entry j - 1 when it is one of the fields
+  } else {
+    low_j = r.low(j);
+    low_f = r.low(j - 1);
+  }
+  const uint32_t low_before = r.low(lo > 0 ? lo - 1 : 0); // entry lo - 1 (loaded whether needed or not)
+  const uint32_t in0 = 0u - (uint32_t)(c != 0), in1 = 0u - (uint32_t)(c < run); // masks: entry j - 1 / j lies in bucket h
+  const uint32_t e1 = (((h & in1) | (hp_next & ~in1)) << l) | low_j;
+  const uint32_t e0 = ((((h & in0) | (hp_prev & ~in0)) << l) | ((low_f & in0) | (low_before & ~in0))) & (0u - (uint32_t)(j >= 1)); // j = 0: the implied zero edge
+  *jout = j;
+  *start = e0;
+  *freq = (e1 - e0) & 0xFFFFu;
+  return 1;
+}
+
+__attribute__((target("bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
+                                                                   uint32_t *start, uint32_t *freq) {
+  if (r.l == 12 && r.HB <= 64) return ef_bracket64(r, cf, zero_before, jout, start, freq);
   const uint32_t h = cf >> r.l, lcf = cf & ((1u << r.l) - 1u);
   const int32_t nbits = (int32_t)r.HB;
   int32_t p_prev = -1; // zero that closes bucket h-1
@@ -360,12 +421,18 @@ __attribute__((target("bmi2,popcnt"))) inline int ef_bracket(const EfRow &r, uin
     }
   }
   if (__builtin_expect(lo + run > r.cnt || p_prev + 1 + run >= nbits, 0)) return -1;
-  // entries of bucket h whose low part is <= lcf (low parts ascend inside a bucket): mostly one or two entries; the two
-  // tail buckets of a row hold many, a bisection bounds those
-  int32_t c = 0;
-  if (run <= 4) {
+  // entries of bucket h whose low part is <= lcf (low parts ascend inside a bucket)
+  int32_t c;
+  if (r.l == 8 && __builtin_expect(run <= 16, 1)) { // the low parts are bytes
+    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(r.p + (r.LB >> 3) + lo));
+    const __m128i key = _mm_set1_epi8((char)lcf);
+    const uint32_t le = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(v, key), v));
+    c = __builtin_popcount(le & ((1u << run) - 1u));
+  } else if (run <= 4) {
+    c = 0;
     while (c < run && r.low(lo + c) <= lcf) ++c;
   } else {
+    c = 0;
     int32_t hi = run; // low(lo + c - 1) <= lcf < low(lo + hi)
     while (c < hi) {
       const int32_t mid = (c + hi) >> 1;
@@ -447,137 +514,226 @@ int TabDecoder::begin(const uint8_t *enc, size_t enc_len, const TabView *view, i
   return FGMM_OK;
 }
 
-// decodes the latents of piece k (pieces before it are done, its tables are on the host)
-int TabDecoder::piece(int k) {
-  if (rc != FGMM_OK) return rc;
-  if (k != next_piece || !tv || k >= tv->npiece) return rc = FGMM_ERR_INVALID;
-  ++next_piece;
-  if (i >= n) return FGMM_OK;
-  Dec dec;
-  dec.x = x;
-  dec.ptr = ptr;
-  dec.end = end_;
-  const int64_t W = 2 * (int64_t)max_bs + 2;
-  const TabPiece &pc = tv->piece[k];
-  const int64_t i_beg = i, i_end = pc.end < n ? pc.end : n;
-  // a search may read up to 32 bytes past its row: rows must end that far before the end of the area
-  const uint8_t *const rows_end = pc.rows + (pc.rows_len >= 32 ? pc.rows_len - 32 : 0);
-  const uint8_t *rowp = pc.rows; // sequential placement: a running sum, never stored
-  const int64_t tl = pc.blk_off ? (tv->tl > 0 ? tv->tl : 1) : (i_end - i_beg > 0 ? i_end - i_beg : 1);
-  for (int64_t blk = 0; i < i_end; ++blk) {
-    const int64_t b_end = i + tl < i_end ? i + tl : i_end;
-    if (pc.blk_off) {
-      rowp = pc.rows + 4 * (size_t)pc.blk_off[blk];
-      if (__builtin_expect(rowp > rows_end, 0)) { rc = FGMM_ERR_INVALID; break; }
-      // blocks lie in no particular order: the running prefetch below (1 KiB ahead of the row being searched) runs off
+namespace {
+
+// One decoder's walk through one piece, a latent per step() - so that one thread can advance two bitstreams in turn
+// (rans_decode_pieces2): a bitstream's decode is one long dependency chain (state -> search -> state), two chains
+// share a core's issue slots.
+struct PieceRun {
+  TabDecoder *td = nullptr;
+  const TabPiece *pc = nullptr;
+  Dec dec{};
+  int64_t i = 0, i_beg = 0, i_end = 0, b_end = 0, blk = 0, tl = 1, W = 0;
+  const uint8_t *rowp = nullptr, *rows_end = nullptr;
+  int32_t max_bs = 0;
+  int hdr_form = 4;
+  uint32_t ef_min = kTabEfMin;
+  int rc = FGMM_OK;
+
+  // false: nothing to do (rc says whether that is an error)
+  bool begin(TabDecoder &d, int k) {
+    td = &d;
+    rc = d.rc;
+    if (rc != FGMM_OK) return false;
+    if (k != d.next_piece || !d.tv || k >= d.tv->npiece) {
+      rc = d.rc = FGMM_ERR_INVALID;
+      return false;
+    }
+    ++d.next_piece;
+    pc = &d.tv->piece[k];
+    i = i_beg = d.i;
+    i_end = pc->end < d.n ? pc->end : d.n;
+    if (i >= i_end) return false;
+    dec.x = d.x;
+    dec.ptr = d.ptr;
+    dec.end = d.end_;
+    max_bs = d.max_bs;
+    W = 2 * (int64_t)max_bs + 2;
+    hdr_form = d.tv->hdr_form;
+    ef_min = d.tv->ef_min;
+    // a search may read up to 32 bytes past its row: rows must end that far before the end of the area
+    rows_end = pc->rows + (pc->rows_len >= 32 ? pc->rows_len - 32 : 0);
+    rowp = pc->rows; // sequential placement: a running sum, never stored
+    tl = pc->blk_off ? (d.tv->tl > 0 ? d.tv->tl : 1) : i_end - i_beg;
+    blk = 0;
+    b_end = i; // the first step opens block 0
+    return true;
+  }
+  inline bool active() const { return rc == FGMM_OK && i < i_end; }
+  void finish() { // the coder state goes back to the decoder (the next piece may run on another thread)
+    td->x = dec.x;
+    td->ptr = dec.ptr;
+    td->i = i;
+    if (rc != FGMM_OK) td->rc = rc;
+  }
+
+  inline void open_block() {
+    b_end = i + tl < i_end ? i + tl : i_end;
+    if (pc->blk_off) {
+      rowp = pc->rows + 4 * (size_t)pc->blk_off[blk];
+      if (__builtin_expect(rowp > rows_end, 0)) {
+        rc = FGMM_ERR_INVALID;
+        return;
+      }
+      // blocks lie in no particular order: the running prefetch of step() (1 KiB ahead of the row being searched) runs off
       // the end of this block into someone else's rows, so the head of the NEXT block is fetched here, a block ahead
       if (b_end < i_end) {
-        const uint8_t *nx = pc.rows + 4 * (size_t)pc.blk_off[blk + 1];
+        const uint8_t *nx = pc->rows + 4 * (size_t)pc->blk_off[blk + 1];
         if (nx + 1024 <= rows_end)
           for (int q = 0; q < 1024; q += 64) __builtin_prefetch(nx + q);
       }
     }
-    for (; i < b_end; ++i) {
-      __builtin_prefetch(rowp + 1024);
-      __builtin_prefetch(rowp + 1024 + 64);
-      int64_t a;
-      int64_t cnt;
-      uint32_t nonmono;
-      const int64_t li = i - i_beg;
-      if (tv->hdr_form == 2) { // (a + max_bs) | cnt << 8; cnt 255: the row carries a 4-byte header
-        const uint32_t c = static_cast<const uint16_t *>(pc.hdr)[li];
-        a = (int64_t)(c & 0xFFu) - max_bs;
-        cnt = c >> 8;
-        nonmono = 0;
-        if (__builtin_expect(cnt == kHdr2Escape, 0)) {
-          if (rows_end - rowp < 4) { rc = FGMM_ERR_INVALID; break; }
-          uint32_t h;
-          memcpy(&h, rowp, 4);
-          rowp += 4;
-          a = tab_hdr_a(h);
-          cnt = tab_hdr_cnt(h);
-          nonmono = tab_hdr_nonmono(h);
-        }
-      } else if (tv->hdr_form == 4) {
-        const uint32_t h = static_cast<const uint32_t *>(pc.hdr)[li];
+    ++blk;
+  }
+
+  // decodes latent i: the header gives (a, cnt, nonmono), the row follows at rowp
+  __attribute__((always_inline)) inline void step() {
+    if (__builtin_expect(i == b_end, 0)) {
+      open_block();
+      if (rc != FGMM_OK) return;
+    }
+    __builtin_prefetch(rowp + 1024);
+    __builtin_prefetch(rowp + 1024 + 64);
+    int64_t a;
+    int64_t cnt;
+    uint32_t nonmono;
+    const int64_t li = i - i_beg;
+    if (hdr_form == 2) { // (a + max_bs) | cnt << 8; cnt 255: the row carries a 4-byte header
+      const uint32_t c = static_cast<const uint16_t *>(pc->hdr)[li];
+      a = (int64_t)(c & 0xFFu) - max_bs;
+      cnt = c >> 8;
+      nonmono = 0;
+      if (__builtin_expect(cnt == kHdr2Escape, 0)) {
+        if (rows_end - rowp < 4) { rc = FGMM_ERR_INVALID; return; }
+        uint32_t h;
+        memcpy(&h, rowp, 4);
+        rowp += 4;
         a = tab_hdr_a(h);
         cnt = tab_hdr_cnt(h);
         nonmono = tab_hdr_nonmono(h);
-      } else {
-        const uint64_t h = static_cast<const uint64_t *>(pc.hdr)[li];
-        a = (int32_t)(uint32_t)h;
-        cnt = (int64_t)((h >> 32) & 0x7FFFFFFFu);
-        nonmono = (uint32_t)(h >> 63);
       }
-      // a row covers indices [a + max_bs, a + max_bs + cnt) of the W-entry virtual table
-      if (__builtin_expect(cnt < 1 || a < -(int64_t)max_bs || a + max_bs + cnt > W, 0)) { rc = FGMM_ERR_INVALID; break; }
-      const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono, tv->ef_min);
-      const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, tv->ef_min);
-      if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; break; }
-      const bool zero_before = a > -(int64_t)max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
-      const uint8_t *row_bytes = rowp;
-      rowp += rbytes;
+    } else if (hdr_form == 4) {
+      const uint32_t h = static_cast<const uint32_t *>(pc->hdr)[li];
+      a = tab_hdr_a(h);
+      cnt = tab_hdr_cnt(h);
+      nonmono = tab_hdr_nonmono(h);
+    } else {
+      const uint64_t h = static_cast<const uint64_t *>(pc->hdr)[li];
+      a = (int32_t)(uint32_t)h;
+      cnt = (int64_t)((h >> 32) & 0x7FFFFFFFu);
+      nonmono = (uint32_t)(h >> 63);
+    }
+    // a row covers indices [a + max_bs, a + max_bs + cnt) of the W-entry virtual table
+    if (__builtin_expect(cnt < 1 || a < -(int64_t)max_bs || a + max_bs + cnt > W, 0)) { rc = FGMM_ERR_INVALID; return; }
+    const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono, ef_min);
+    const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
+    if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; return; }
+    const bool zero_before = a > -(int64_t)max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
+    const uint8_t *row_bytes = rowp;
+    rowp += rbytes;
 
-      const uint32_t cf = (uint32_t)(dec.x & 0xFFFFu); // Rans64DecGet
-      int32_t value;
-      if (__builtin_expect(cf == kMaxCdf, 0)) {
-        value = dec.bypass();
-      } else {
-        uint32_t start = 0, freq = 0;
-        bool done = false;
-        if (!is_ef) {
-          const uint16_t *row = reinterpret_cast<const uint16_t *>(row_bytes);
-          if (__builtin_expect(!nonmono, 1)) {
-            const int32_t j = upper_bound_u16(row, (int32_t)cnt, cf);
-            if (__builtin_expect(j >= 1 && j < cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
-              start = row[j - 1];
-              freq = (uint32_t)(row[j] - start) & 0xFFFFu;
-              value = (int32_t)(a + j - 1);
-              done = true;
-            } else if (j == 0 && zero_before) { // 0 <= cf < row[0]: the symbol whose lower edge is the implied zero
-              start = 0;
-              freq = row[0];
-              value = (int32_t)(a - 1);
-              done = true;
-            }
-          }
-          if (!done) value = bisect_reference(Row{row, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
-        } else {
-          const uint32_t efl = tab_ef_l((uint32_t)cnt);
-          const EfRow r{row_bytes, (int32_t)cnt, efl, tab_ef_hb((uint32_t)cnt, efl)};
-          int32_t j;
-          const int br = ef_bracket(r, cf, zero_before, &j, &start, &freq);
-          if (__builtin_expect(br > 0, 1)) {
+    const uint32_t cf = (uint32_t)(dec.x & 0xFFFFu); // Rans64DecGet
+    int32_t value;
+    if (__builtin_expect(cf == kMaxCdf, 0)) {
+      value = dec.bypass();
+    } else {
+      uint32_t start = 0, freq = 0;
+      bool done = false;
+      if (!is_ef) {
+        const uint16_t *row = reinterpret_cast<const uint16_t *>(row_bytes);
+        if (__builtin_expect(!nonmono, 1)) {
+          const int32_t j = upper_bound_u16(row, (int32_t)cnt, cf);
+          if (__builtin_expect(j >= 1 && j < cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
+            start = row[j - 1];
+            freq = (uint32_t)(row[j] - start) & 0xFFFFu;
             value = (int32_t)(a + j - 1);
-          } else if (br < 0) {
-            rc = FGMM_ERR_INVALID;
-            break;
-          } else { // no interval contains cf: expand the row and replay the reference's bisection
-            if ((size_t)cnt > scratch_cap) {
-              free(scratch);
-              scratch_cap = (size_t)cnt + 64;
-              scratch = (uint16_t *)malloc(scratch_cap * sizeof(uint16_t));
-              if (!scratch) { rc = FGMM_ERR_NOMEM; break; }
-            }
-            for (int32_t q = 0; q < cnt && rc == FGMM_OK; ++q) {
-              const int32_t pos = ef_select1(r, (uint32_t)q);
-              if (pos < q) rc = FGMM_ERR_INVALID; else scratch[q] = (uint16_t)((((uint32_t)(pos - q)) << r.l) | r.low(q));
-            }
-            if (rc != FGMM_OK) break;
-            value = bisect_reference(Row{scratch, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
+            done = true;
+          } else if (j == 0 && zero_before) { // 0 <= cf < row[0]: the symbol whose lower edge is the implied zero
+            start = 0;
+            freq = row[0];
+            value = (int32_t)(a - 1);
+            done = true;
           }
         }
-        if (__builtin_expect(freq == 0, 0)) { rc = FGMM_ERR_INVALID; break; } // cannot come out of a well-formed row
-        dec.advance(start, freq);
+        if (!done) value = bisect_reference(Row{row, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
+      } else {
+        const uint32_t efl = tab_ef_l((uint32_t)cnt);
+        const EfRow r{row_bytes, (int32_t)cnt, efl, tab_ef_hb((uint32_t)cnt, efl), tab_ef_lb((uint32_t)cnt, efl)};
+        int32_t j;
+        const int br = ef_bracket(r, cf, zero_before, &j, &start, &freq);
+        if (__builtin_expect(br > 0, 1)) {
+          value = (int32_t)(a + j - 1);
+        } else if (br < 0) {
+          rc = FGMM_ERR_INVALID;
+          return;
+        } else { // no interval contains cf: expand the row and replay the reference's bisection
+          value = expand_and_bisect(r, a, cf, &start, &freq);
+          if (rc != FGMM_OK) return;
+        }
       }
-      out[i] = value;
-      if (__builtin_expect(dec.underrun, 0)) { rc = FGMM_ERR_STREAM; break; }
+      if (__builtin_expect(freq == 0, 0)) { rc = FGMM_ERR_INVALID; return; } // cannot come out of a well-formed row
+      dec.advance(start, freq);
     }
-    if (rc != FGMM_OK) break;
+    td->out[i] = value;
+    if (__builtin_expect(dec.underrun, 0)) { rc = FGMM_ERR_STREAM; return; }
+    ++i;
   }
-  x = dec.x;
-  ptr = dec.ptr;
+
+  __attribute__((noinline)) int32_t expand_and_bisect(const EfRow &r, int64_t a, uint32_t cf, uint32_t *start, uint32_t *freq) {
+    const int32_t cnt = r.cnt;
+    if ((size_t)cnt > td->scratch_cap) {
+      free(td->scratch);
+      td->scratch_cap = (size_t)cnt + 64;
+      td->scratch = (uint16_t *)malloc(td->scratch_cap * sizeof(uint16_t));
+      if (!td->scratch) {
+        td->scratch_cap = 0;
+        rc = FGMM_ERR_NOMEM;
+        return 0;
+      }
+    }
+    for (int32_t q = 0; q < cnt; ++q) {
+      const int32_t pos = ef_select1(r, (uint32_t)q);
+      if (pos < q) {
+        rc = FGMM_ERR_INVALID;
+        return 0;
+      }
+      td->scratch[q] = (uint16_t)((((uint32_t)(pos - q)) << r.l) | r.low(q));
+    }
+    return bisect_reference(Row{td->scratch, (int32_t)a, cnt}, cf, max_bs, start, freq);
+  }
+};
+
+} // namespace
+
+// decodes the latents of piece k (pieces before it are done, its tables are on the host)
+int TabDecoder::piece(int k) {
+  PieceRun r;
+  if (!r.begin(*this, k)) return r.rc;
+  while (r.active()) r.step();
+  r.finish();
   return rc;
+}
+
+// piece ka of decoder a and piece kb of decoder b, decoded by the calling thread latent by latent in turn; each decoder
+// ends exactly where its own piece() would have left it.  rc_a / rc_b: the decoders' status.
+void rans_decode_pieces2(TabDecoder &a, int ka, TabDecoder &b, int kb, int *rc_a, int *rc_b) {
+  PieceRun ra, rb;
+  const bool ga = ra.begin(a, ka), gb = rb.begin(b, kb);
+  if (ga && gb)
+    while (ra.active() && rb.active()) {
+      ra.step();
+      rb.step();
+    }
+  if (ga) {
+    while (ra.active()) ra.step();
+    ra.finish();
+  }
+  if (gb) {
+    while (rb.active()) rb.step();
+    rb.finish();
+  }
+  *rc_a = ga ? a.rc : ra.rc;
+  *rc_b = gb ? b.rc : rb.rc;
 }
 
 // after the last piece: FGMM_OK only if every latent was decoded
@@ -857,6 +1013,30 @@ int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void 
   const fgmm::TabPiece pc{hdr, blk_off, rows, (size_t)rows_len, n};
   const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, hdr_form, tl, 1, &pc, nullptr, nullptr};
   return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
+}
+
+int fgmm_rans_decode_tab2(const fgmm_tab_ref *a, const fgmm_tab_ref *b) {
+  if (!a || !b) return FGMM_ERR_INVALID;
+  const fgmm_tab_ref *t[2] = {a, b};
+  fgmm::TabPiece pc[2];
+  fgmm::TabView tv[2];
+  fgmm::TabDecoder td[2];
+  int rc[2];
+  for (int k = 0; k < 2; ++k) {
+    const fgmm_tab_ref &r = *t[k];
+    if (r.n > 0 && (!r.hdr || !r.rows)) return FGMM_ERR_INVALID;
+    if (r.max_bs < 0 || r.max_bs > FGMM_MAX_BS || (r.blk_off && r.tl < 1)) return FGMM_ERR_INVALID;
+    if ((r.hdr_form == 2 && !fgmm::tab_hdr_fits16(r.max_bs)) || (r.hdr_form == 4 && r.max_bs > FGMM_MAX_BS_H4)) return FGMM_ERR_INVALID;
+    pc[k] = fgmm::TabPiece{r.hdr, r.blk_off, r.rows, (size_t)r.rows_len, r.n};
+    tv[k] = fgmm::TabView{(r.flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, r.hdr_form, r.tl, 1, &pc[k], nullptr, nullptr};
+  }
+  for (int k = 0; k < 2; ++k) rc[k] = td[k].begin(t[k]->encoded, t[k]->encoded_len, &tv[k], t[k]->n, t[k]->max_bs, t[k]->out_symbols);
+  if (rc[0] == FGMM_OK && rc[1] == FGMM_OK) fgmm::rans_decode_pieces2(td[0], 0, td[1], 0, &rc[0], &rc[1]);
+  for (int k = 0; k < 2; ++k) {
+    const int rf = td[k].finish();
+    if (rc[k] == FGMM_OK) rc[k] = rf;
+  }
+  return rc[0] != FGMM_OK ? rc[0] : rc[1];
 }
 
 void fgmm_free(void *p) { free(p); }

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
   } else {
     // Elias-Fano: one bit string written 16 bits at a time: the unary high parts, then the low parts (the lane walks its
     // row twice; this path serves the rare items too wide for the single-pass kernel)
-    const uint32_t l = tab_ef_l(cnt), HB = tab_ef_hb(cnt, l);
+    const uint32_t l = tab_ef_l(cnt);
     unsigned long long acc = 0; // bits not yet stored, from bit 0 up
     uint32_t nb = 0, at = 0;    // valid bits in acc | 16-bit units stored
     auto put = [&](uint32_t v, uint32_t bits) { // bits <= 16
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_fill_kernel(const DecDesc *__re
       put(1, 1);
       pos_next = pos + 1;
     }
-    for (uint32_t gap = HB - pos_next; gap; gap -= gap < 16 ? gap : 16) put(0, gap < 16 ? gap : 16);
+    for (uint32_t gap = tab_ef_lb(cnt, l) - pos_next; gap; gap -= gap < 16 ? gap : 16) put(0, gap < 16 ? gap : 16);
     for (uint32_t j = 0; j < cnt; ++j) put(L.edge(a_idx + (int)j) & ((1u << l) - 1u), l);
     if (nb) put(0, 16 - nb);
   }
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     const uint16_t *e; // first evaluated edge of the latent
     int j_lo, j_hi, a_idx;
     uint32_t cnt, nm, T_sat, aux; // aux: first entry / first word of the unary part of the row among the block's Elias-Fano rows
-    uint32_t efl, HB, M;          // Elias-Fano row: low bits, bits of the unary part, 2^20 / efl rounded up; efl = 0: raw row
+    uint32_t efl, HB, LB, M;      // Elias-Fano row: low bits, bits of the unary part, first bit of the low parts, 2^20 / efl rounded up; efl = 0: raw row
     __device__ __forceinline__ void load(const TabSmem &S, const uint16_t *E16, int l, uint32_t ef_min) {
       const uint32_t w = S.win[l], mt = S.meta[l];
       j_lo = (int)(w & 0xFFFFu);
@@ -591,6 +591,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       aux = S.efoff[l];
       efl = tab_row_is_ef(cnt, nm, ef_min) ? tab_ef_l(cnt) : 0u;
       HB = efl ? tab_ef_hb(cnt, efl) : 0u;
+      LB = (HB + 7u) & ~7u;
       M = efl ? (1u << 20) / efl + 1u : 0u;
     }
     // entry k of the row: F[a_idx + k] — an evaluated edge, or one of the two constants outside the evaluation window
@@ -670,8 +671,8 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
         } else {
           const uint32_t bit0 = 16 * h;
           if (bit0 < R.HB) half = (S.bitmap[(R.aux >> 16) + (h >> 1)] >> (16 * (h & 1u))) & 0xFFFFu; // zero from bit HB on
-          if (bit0 + 16 > R.HB) { // low parts that overlap bits [bit0, bit0 + 16)
-            const int rel = (int)bit0 - (int)R.HB; // of the low area
+          if (bit0 + 16 > R.LB) { // low parts that overlap bits [bit0, bit0 + 16)
+            const int rel = (int)bit0 - (int)R.LB; // of the low area
             uint32_t j = rel > 0 ? ((uint32_t)rel * R.M) >> 20 : 0u; // rel / efl  (rel < 2^15: exact)
             const uint32_t mask = (1u << R.efl) - 1u;
             for (; j < R.cnt; ++j) {

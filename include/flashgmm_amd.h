@@ -76,17 +76,26 @@ int fgmm_ctx_threads(const fgmm_ctx *ctx);
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
 
 /* Tuning knobs of a context (defaults in brackets).  Unknown names return FGMM_ERR_INVALID.
- *   "pieces"      [4]   decode: the tables of every bitstream of a call reach the host in this many pieces (at most 8),
- *                       piece-major, and each host worker follows its bitstreams piece by piece (a bitstream decodes
- *                       sequentially: what lands last leaves one piece of host work behind it, not one bitstream)
+ *   "pieces"      [8]   decode: the tables of every bitstream of a call reach the host in this many pieces (at most 8),
+ *                       piece-major and shrinking (piece p of P carries P - p parts of P (P + 1) / 2); the host workers take
+ *                       (bitstream, piece) tasks as they land - a bitstream decodes sequentially, but its coder state
+ *                       moves from worker to worker between pieces: what lands last leaves one small piece of host
+ *                       work per bitstream behind it, not one bitstream
+ *   "dec_pair"    [0]   decode: 1 = a worker takes two ready tasks and decodes them latent by latent in turn
+ *                       (fgmm_rans_decode_tab2) unless that leaves a sleeping worker without one.  Pays on hosts
+ *                       whose cores are bound by the decoder's dependency chain (1.5x per thread on a 2.1 GHz Xeon), not on
+ *                       the 16-core MI355X box
  *   "dec_group"   [0]   decode: bitstreams per launch / copy (0: automatic: a whole round of pieces)
  *   "dec_first"   [2]   decode: size of the first launch of the first round (the first tables reach the host as early
  *                       as possible; the following launches double)
- *   "tab_cap_e"   [8192] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2))
+ *   "tab_cap_e"   [16384] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2))
  *   "stage_max_mb" [0]  decode: cap of the device staging area for rows in MiB (0: a quarter of the free device memory).
  *                       A launch whose rows do not fit is re-run with the exact size its cursor reports.
  *   "ef_rows"     [0]   decode: 0 = Elias-Fano rows when a call has at least as many bitstreams as host workers (PCIe is
  *                       the bottleneck), uint16 rows otherwise (the sequential host decoders are); 1 = always, 2 = never
+ *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor).
+ *                       14 gives the fewest bytes (55.7 B/latent on Kodak-like tables against 57.6) but costs the host
+ *                       decoders more than the PCIe time it saves when 16 threads serve one GPU
  *   "trace"       [0]   1: phase timestamps of every batched call on stderr, 2: + per-bitstream job timeline */
 int fgmm_ctx_set_option(fgmm_ctx *ctx, const char *name, int64_t value);
 int fgmm_ctx_get_option(fgmm_ctx *ctx, const char *name, int64_t *value_out);
@@ -206,7 +215,7 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
                           const float *means, const float *weights, int64_t n, int64_t stride_n, int64_t stride_k,
                           int mode, uint32_t *packed);
 
-/* GPU: decode-side edge tables (format v4).  For latent i the reference's bisection can only ever look at
+/* GPU: decode-side edge tables (format v5).  For latent i the reference's bisection can only ever look at
  *   F_i[v] = (uint16)(cdf_i(v - 0.5) * 65535),  v in [-max_bs, max_bs + 1]      (rans_interface.cpp:826-862).
  * The kernels find, exactly, the window outside which F_i is constant (evaluating F_i everywhere except where
  * every mixture component is provably saturated — fgmm_selftest_saturation) and store it:
@@ -216,24 +225,27 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
  *     4 bytes  int16 a | cnt << 16 (15 bits) | nonmono << 31        when max_bs <= FGMM_MAX_BS_H4
  *     8 bytes  int32 a ; cnt (31 bits) | nonmono << 31              any max_bs <= FGMM_MAX_BS
  *   row i  = F_i[a .. a+cnt), from the first non-zero edge to the start of the trailing constant run;
- *            F_i[v < a] = 0,   F_i[v >= a+cnt] = the row's last entry;  rows are 4-byte aligned:
- *     cnt < 48 or nonmono : uint16[round2(cnt)], padded with the last value              (2*round2(cnt) bytes)
- *     cnt >= 48, monotone : Elias-Fano with 8 low bits: uint8 lows[round4(cnt)], then uint32 upper[U],
- *                           U = ceil((cnt + 256) / 32), bit ((F >> 8) + j) set for entry j  (round4(cnt) + 4U bytes)
+ *            F_i[v < a] = 0,   F_i[v >= a+cnt] = the row's last entry;  rows are 2-byte aligned:
+ *     cnt < 14 or nonmono : uint16[cnt]                                                   (2*cnt bytes)
+ *     cnt >= 14, monotone : Elias-Fano with l low bits, l = 12 for cnt <= 48, else 8, as ONE little-endian bit string
+ *                           (bit b = bit (b & 7) of byte b >> 3) rounded up to 16 bits:
+ *                             bits [0, HB), HB = cnt + (65536 >> l) : bit ((F_j >> l) + j) set for entry j
+ *                             bits [LB + j*l, LB + (j+1)*l), LB = HB rounded up to 8 : the low l bits of entry j
+ *     (FGMM_TAB_RAW_ROWS: every row in the first form; the batched decoder raises the threshold 14: "ef_min" option)
  *   `nonmono` is set when the row decreases somewhere.
  * fgmm_build_cdftab_hip (generic two-pass kernels, lane = latent, any max_bs <= FGMM_MAX_BS_H4 here): 4-byte headers, rows
  *   in LATENT ORDER with no stored offset (row i+1 starts where row i ends).  hdr: device uint32[n]; pool: device bytes;
- *   pool_used: device uint64[1] = bytes written.  pool_cap >= n * 2 * round2(2*max_bs + 2) always suffices; a smaller
+ *   pool_used: device uint64[1] = bytes written.  pool_cap >= n * 2 * (2*max_bs + 2) always suffices; a smaller
  *   pool yields FGMM_ERR_NOMEM with *pool_used = the bytes needed.
  * fgmm_build_tab_hip (the single-pass kernel of the batched decode path: parameters staged in LDS, evaluation flattened
  *   over pairs of edges in packed fp32): headers in the form FGMM_HDR_FORM(max_bs) (device, n * form bytes); rows of each
  *   block of *tl_out consecutive latents are contiguous and start at rows + 4 * blk_off[block]  (blocks are placed by an
- *   atomic cursor: any order); blk_off: device uint32[ceil(n / tl)], provide ceil(n / 16) entries; rows_used: device
+ *   atomic cursor: any order, each padded to 4 bytes); blk_off: device uint32[ceil(n / tl)], provide ceil(n / 16) entries; rows_used: device
  *   uint64[1].  FGMM_ERR_UNSUPPORTED when 2*max_bs + 2 does not fit the kernel's LDS budget (use the generic kernels),
  *   FGMM_ERR_NOMEM (with *rows_used = the bytes needed) when rows_cap is too small. */
 #define FGMM_TAB_NO_PRUNE 1 /* flags: evaluate all of F_i instead of skipping its saturated tails (A/B testing) */
 #define FGMM_TAB_CLAMP 2    /* flags: clamp sigma to [0.11, 256] first (the entropy-model path's kernel variant) */
-#define FGMM_TAB_RAW_ROWS 4 /* flags: no Elias-Fano rows, every row as uint16 entries (30 % more bytes, 35 % faster to search:
+#define FGMM_TAB_RAW_ROWS 4 /* flags: no Elias-Fano rows, every row as uint16 entries (35 % more bytes, 2-3x faster to search:
                                what the batched decoder chooses for calls with fewer bitstreams than host workers) */
 #define FGMM_HDR_FORM(max_bs) ((2 * (int64_t)(max_bs) + 2 <= 254) ? 2 : ((max_bs) <= FGMM_MAX_BS_H4 ? 4 : 8))
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
@@ -278,6 +290,22 @@ int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const ui
 int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void *hdr, int hdr_form, const uint32_t *blk_off,
                          int32_t tl, const uint8_t *rows, uint64_t rows_len, int64_t n, int32_t max_bs, int flags,
                          int32_t *out_symbols);
+/* Two tables -> two symbol arrays, decoded by the calling thread latent by latent in turn (the batched decoder does this
+ * when there are more bitstreams than idle workers: a bitstream's decode is one dependency chain, two chains share a
+ * core).  Each output is exactly what fgmm_rans_decode_tab gives for its table; returns the first error of the two. */
+typedef struct fgmm_tab_ref {
+  const uint8_t *encoded;
+  size_t encoded_len;
+  const void *hdr;
+  int32_t hdr_form, tl;   /* tl: latents per block when blk_off != NULL */
+  const uint32_t *blk_off;
+  const uint8_t *rows;
+  uint64_t rows_len;
+  int64_t n;
+  int32_t max_bs, flags;
+  int32_t *out_symbols;
+} fgmm_tab_ref;
+int fgmm_rans_decode_tab2(const fgmm_tab_ref *a, const fgmm_tab_ref *b);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 4. Table path — the `z` hyper-latent coder: CompressAI's original table rANS, the other

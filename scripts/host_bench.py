@@ -7,9 +7,9 @@ from oracle import oracle as O
 from flashgmm_amd import _lib, testing as T
 import helpers
 from helpers import trim_full_table, host_decode_cdftab, host_decode_tab, host_encode_symtab
-helpers.EF_MIN = int(os.environ.get("EF_MIN", "48"))  # must match the library's FGMM_EF_MIN
+helpers.EF_MIN = int(os.environ.get("EF_MIN", str(helpers.EF_MIN)))  # must match the library's FGMM_EF_MIN
 
-cache = f"/tmp/host_bench_tables_{helpers.EF_MIN}.npz"
+cache = f"/tmp/host_bench_tables_v5_{helpers.EF_MIN}.npz"
 if os.path.exists(cache):
     z = np.load(cache); hdr, pool, sym, packed, max_bs = z["hdr"], z["pool"], z["sym"], z["packed"], int(z["max_bs"])
     enc = bytes(z["enc"])
@@ -36,4 +36,7 @@ for rep in range(3):
     assert b == enc
     t4 = time.perf_counter(); rc, out = host_decode_tab(L, enc, h2, pool2, max_bs, bo2, 96); t5 = time.perf_counter()
     assert rc == 0 and np.array_equal(out, sym)
+    t6 = time.perf_counter(); rc2, outs = helpers.host_decode_tab2(L, [(enc, h2, pool2, max_bs, bo2, 96), (enc, hdr, pool, max_bs, None, 0)]); t7 = time.perf_counter()
+    assert rc2 == 0 and np.array_equal(outs[0], sym) and np.array_equal(outs[1], sym)
+    print(f"two streams in turn on one thread {1e9*(t7-t6)/(2*n):.1f} ns/sym", end="   ")
     print(f"decode (4-byte headers, sequential) {1e9*(t1-t0)/n:.1f} ns/sym   decode (2-byte headers, blocks of 96) {1e9*(t5-t4)/n:.1f} ns/sym   encode {1e9*(t3-t2)/n:.1f} ns/sym")

@@ -21,17 +21,14 @@ def row_is_ef(cnt: int, nonmono: int) -> bool:
 
 
 def ef_l(cnt: int) -> int:
-    """low bits of an Elias-Fano row: 16 - ceil(log2(cnt)) within [8, 12]"""
-    lg = 0
-    while (1 << lg) < cnt:
-        lg += 1
-    return min(max(16 - lg, 8), 12)
+    """low bits of an Elias-Fano row: 12 up to 48 entries, 8 beyond"""
+    return 12 if cnt <= 48 else 8
 
 
 def row_bytes(cnt: int, nonmono: int) -> int:
     if row_is_ef(cnt, nonmono):
         l = ef_l(cnt)
-        return 2 * ((cnt * (l + 1) + (65536 >> l) + 15) >> 4)
+        return 2 * ((cnt * l + ((cnt + (65536 >> l) + 7) & ~7) + 15) >> 4)
     return 2 * cnt
 
 
@@ -57,7 +54,8 @@ def _row_payload(row: np.ndarray, nonmono: int):
         bits = np.zeros(8 * nbytes, np.uint8)
         bits[(row >> l) + np.arange(cnt)] = 1
         lows = ((row[:, None] >> np.arange(l)[None, :]) & 1).astype(np.uint8)  # [cnt, l], bit 0 first
-        bits[HB:HB + cnt * l] = lows.reshape(-1)
+        LB = (HB + 7) & ~7
+        bits[LB:LB + cnt * l] = lows.reshape(-1)
         return [np.packbits(bits, bitorder="little")]
     return [row.astype("<u2").view(np.uint8)]
 
@@ -149,8 +147,9 @@ def expand_trimmed(hdr: np.ndarray, pool: np.ndarray, max_bs: int, blk_off=None,
             bits = np.unpackbits(pool[off:off + row_bytes(cnt, nonmono)], bitorder="little").astype(np.int64)
             pos = np.nonzero(bits[:HB])[0]
             assert len(pos) == cnt, (i, len(pos), cnt)
-            lows = (bits[HB:HB + cnt * l].reshape(cnt, l) << np.arange(l)[None, :]).sum(1)
-            assert not bits[HB + cnt * l:].any(), i  # the padding to 16 bits is zero
+            LB = (HB + 7) & ~7
+            lows = (bits[LB:LB + cnt * l].reshape(cnt, l) << np.arange(l)[None, :]).sum(1)
+            assert not bits[HB:LB].any() and not bits[LB + cnt * l:].any(), i  # the padding is zero
             row = ((pos - np.arange(cnt)) << l) | lows
         else:
             row = pool[off:off + 2 * cnt].copy().view("<u2").astype(np.int64)
@@ -202,3 +201,22 @@ def host_decode_tab(lib, enc: bytes, hdr: np.ndarray, pool: np.ndarray, max_bs: 
                                   pool.ctypes.data_as(C.c_void_p), len(pool) if pool_len is None else pool_len, len(hdr), max_bs,
                                   _flags(), out.ctypes.data_as(C.c_void_p))
     return rc, out
+
+
+def host_decode_tab2(lib, tabs):
+    """fgmm_rans_decode_tab2: two (enc, hdr, pool, max_bs, blk_off, tl) tables decoded in turn by one thread"""
+    from flashgmm_amd._lib import fgmm_tab_ref
+    refs, keep, outs = [], [], []
+    for enc, hdr, pool, max_bs, blk_off, tl in tabs:
+        hdr = np.ascontiguousarray(hdr)
+        pool = np.ascontiguousarray(np.asarray(pool).view(np.uint8))
+        out = np.empty(len(hdr), np.int32)
+        bo = np.ascontiguousarray(blk_off, np.uint32) if blk_off is not None else None
+        buf = C.create_string_buffer(enc, len(enc))
+        keep += [hdr, pool, bo, buf]
+        outs.append(out)
+        refs.append(fgmm_tab_ref(C.cast(buf, C.c_void_p).value, len(enc), hdr.ctypes.data, hdr.dtype.itemsize, tl,
+                                 bo.ctypes.data if bo is not None else None, pool.ctypes.data, len(pool), len(hdr), max_bs, _flags(),
+                                 out.ctypes.data))
+    rc = lib.fgmm_rans_decode_tab2(C.byref(refs[0]), C.byref(refs[1]))
+    return rc, outs

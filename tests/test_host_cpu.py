@@ -237,7 +237,7 @@ def test_host_decoder_elias_fano_rows(oracle):
 
 @pytest.mark.parametrize("shape", ["uniform", "gaussian"])
 def test_host_decoder_elias_fano_rows_of_every_width(oracle, shape):
-    """format v5: the low part of an Elias-Fano row has 12 bits (14..16 entries) down to 8 bits (> 128 entries), rows are
+    """format v5: the low part of an Elias-Fano row has 12 bits (14..48 entries: a one-word unary part) or 8 bits (longer), rows are
     2-byte aligned: rows of every count from 1 to the full window, uniform entries and CDF-shaped ones (dense tails)"""
     L = _lib.lib()
     rng = np.random.default_rng(11)
@@ -260,7 +260,7 @@ def test_host_decoder_elias_fano_rows_of_every_width(oracle, shape):
     hdr, pool, used = trim_full_table(tab, max_bs)
     cnts = (hdr >> 16) & 0x7FFF
     from helpers import ef_l
-    assert {ef_l(int(k)) for k in cnts if k >= helpers.EF_MIN} == {8, 9, 10, 11, 12}
+    assert {ef_l(int(k)) for k in cnts if k >= helpers.EF_MIN} == {8, 12}
     assert np.array_equal(expand_trimmed(hdr, pool, max_bs), tab)
     enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
     want = oracle.rans_decode_cdftab(enc, tab, max_bs)
@@ -318,6 +318,37 @@ def test_host_decoder_header_forms_and_block_placement(oracle, max_bs, tl):
     hdr_s, pool_s, _ = trim_full_table(tab, max_bs, form=form)  # the same form, rows sequential
     rc, out = host_decode_tab(L, enc, hdr_s, pool_s, max_bs)
     assert rc == 0 and np.array_equal(out, want)
+
+
+def test_host_pair_decoder_equals_single(oracle):
+    """fgmm_rans_decode_tab2 (two bitstreams decoded in turn by one thread): each output == the single-stream decoder's;
+    unequal lengths, different header forms / placements, an empty table, a truncated stream in either slot"""
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    tabs = []
+    for n, max_bs, tl in ((700, 99, 0), (1500, 20, 32), (0, 9, 0), (300, 200, 16)):
+        W = 2 * max_bs + 2
+        tab = np.sort(rng.integers(0, 65536, (n, W)), axis=1).astype(np.uint16)
+        tab[::4, : W // 3] = 0
+        tab[1::4, W // 2:] = tab[1::4, W // 2 - 1: W // 2]
+        enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+        form = helpers.hdr_form(max_bs)
+        if tl:
+            hdr, bo, pool, _ = trim_full_table(tab, max_bs, form=form, tl=tl, shuffle_seed=3)
+        else:
+            hdr, pool, _ = trim_full_table(tab, max_bs, form=form)
+            bo = None
+        rc, want = host_decode_tab(L, enc, hdr, pool, max_bs, bo, tl)
+        assert rc == 0 and np.array_equal(want, oracle.rans_decode_cdftab(enc, tab, max_bs))
+        tabs.append(((enc, hdr, pool, max_bs, bo, tl), want))
+    for ia in range(len(tabs)):
+        for ib in range(len(tabs)):
+            rc, outs = helpers.host_decode_tab2(L, [tabs[ia][0], tabs[ib][0]])
+            assert rc == 0 and np.array_equal(outs[0], tabs[ia][1]) and np.array_equal(outs[1], tabs[ib][1]), (ia, ib)
+    short = (tabs[1][0][0][:40],) + tabs[1][0][1:]
+    assert helpers.host_decode_tab2(L, [tabs[0][0], short])[0] == 5  # FGMM_ERR_STREAM
+    rc, outs = helpers.host_decode_tab2(L, [short, tabs[0][0]])
+    assert rc == 5 and np.array_equal(outs[1], tabs[0][1])  # the other stream still decodes to the end
 
 
 def test_host_decoder_raw_rows_only(oracle, monkeypatch):
