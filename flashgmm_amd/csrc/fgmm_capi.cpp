@@ -988,7 +988,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
   }
 
-  const int n_workers = count > 1 ? std::min(std::max(ctx->pool->size(), 1), count) : 0; // a single bitstream: this thread
+  // (a single bitstream too: its decoder starts on piece 0 while this thread is still queuing the later pieces' copies)
+  const int n_workers = std::min(std::max(ctx->pool->size(), 1), count);
   for (int j = 0; j < n_workers; ++j) ctx->pool->submit(worker);
 
   // ---- unit by unit: size known -> pinned range, ONE copy; the workers are told ----------------------------------------
@@ -1104,8 +1105,6 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     ctx->stat[1] += it.table_bytes;
     ctx->stat[2] += (unsigned long long)it.n;
   }
-
-  if (n_workers == 0) worker(); // every piece is queued: returns when the bitstream is decoded
 
   // ---- symbols back to the GPU item by item: scatter kernel on the caller's stream ---------------------------
   int first_err = FGMM_OK;

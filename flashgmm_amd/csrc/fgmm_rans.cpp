@@ -514,6 +514,9 @@ int TabDecoder::begin(const uint8_t *enc, size_t enc_len, const TabView *view, i
   return FGMM_OK;
 }
 
+#ifndef FGMM_PREFETCH_AHEAD
+#define FGMM_PREFETCH_AHEAD 1024 // bytes: the rows were just DMA-written, they are in no cache
+#endif
 namespace {
 
 // One decoder's walk through one piece, a latent per step() - so that one thread can advance two bitstreams in turn
@@ -579,8 +582,8 @@ struct PieceRun {
       // the end of this block into someone else's rows, so the head of the NEXT block is fetched here, a block ahead
       if (b_end < i_end) {
         const uint8_t *nx = pc->rows + 4 * (size_t)pc->blk_off[blk + 1];
-        if (nx + 1024 <= rows_end)
-          for (int q = 0; q < 1024; q += 64) __builtin_prefetch(nx + q);
+        if (nx + FGMM_PREFETCH_AHEAD <= rows_end)
+          for (int q = 0; q < FGMM_PREFETCH_AHEAD; q += 64) __builtin_prefetch(nx + q);
       }
     }
     ++blk;
@@ -592,8 +595,8 @@ struct PieceRun {
       open_block();
       if (rc != FGMM_OK) return;
     }
-    __builtin_prefetch(rowp + 1024);
-    __builtin_prefetch(rowp + 1024 + 64);
+    __builtin_prefetch(rowp + FGMM_PREFETCH_AHEAD);
+    __builtin_prefetch(rowp + FGMM_PREFETCH_AHEAD + 64);
     int64_t a;
     int64_t cnt;
     uint32_t nonmono;

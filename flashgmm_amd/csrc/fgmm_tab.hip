@@ -636,57 +636,68 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   }
   __syncthreads();
 
-  // ---- phase 5b: FLATTENED over the 16-bit units of the block's rows; lane pairs store 4 bytes, coalesced ---------------
+  // ---- phase 5b: FLATTENED over the 4-byte words of the block's rows, coalesced stores; a word is two 16-bit units of one
+  // row, or - rows are 2-byte aligned - the last unit of a row and the first of the next --------------------------------
   {
-    const uint32_t NU = B4 >> 1; // even
-    const uint32_t Q = (((NU + 3) >> 2) + 63u) & ~63u;
-    const uint32_t u_end = std::min(NU, (uint32_t)(wave + 1) * Q);
-    int l = -1;
+    const uint32_t NW = B4 >> 2;
+    const uint32_t Q = (((NW + 3) >> 2) + 63u) & ~63u;
+    const uint32_t q_end = std::min(NW, (uint32_t)(wave + 1) * Q);
+    uint32_t q = (uint32_t)wave * Q + (uint32_t)lane;
+    int l = 0;
     uint32_t r_beg = 0, r_end = 0;
     RowRef R;
-    for (uint32_t u0 = (uint32_t)wave * Q; u0 < u_end; u0 += 64) { // wave-uniform trip count: the lanes exchange halves
-      const uint32_t u = u0 + (uint32_t)lane;
-      uint32_t half = 0;
-      if (2 * u < B) { // (units past B: the block's padding to 4 bytes)
-        if (2 * u >= r_end) {
-          if (l < 0) {
-            l = find_owner(S.rowoff, nl, 2 * u);
-            r_beg = S.rowoff[l];
+    if (q < q_end) {
+      l = find_owner(S.rowoff, nl, 4 * q);
+      r_beg = S.rowoff[l];
+      r_end = S.rowoff[l + 1];
+      R.load(S, E16, l, d.ef_min);
+    }
+    // 16-bit unit h of the row R describes
+    auto unit = [&](uint32_t h) -> uint32_t {
+      const bool escaped = d.hdr_form == 2 && R.nm;
+      if (escaped && h < 2) return (tab_hdr_pack(R.a_idx - max_bs, R.cnt, 1u) >> (16 * h)) & 0xFFFFu;
+      if (!R.efl) return R.entry(escaped ? h - 2 : h);
+      const uint32_t bit0 = 16 * h;
+      uint32_t v = 0;
+      if (bit0 < R.HB) v = (S.bitmap[(R.aux >> 16) + (h >> 1)] >> (16 * (h & 1u))) & 0xFFFFu; // zero from bit HB on
+      if (bit0 + 16 > R.LB) { // low parts that overlap bits [bit0, bit0 + 16)
+        const int rel = (int)bit0 - (int)R.LB; // of the low area
+        uint32_t j = rel > 0 ? ((uint32_t)rel * R.M) >> 20 : 0u; // rel / efl  (rel < 2^15: exact)
+        const uint32_t mask = (1u << R.efl) - 1u;
+        for (; j < R.cnt; ++j) {
+          const int sh = (int)(j * R.efl) - rel;
+          if (sh >= 16) break;
+          const uint32_t lowbits = R.entry(j) & mask;
+          v |= sh >= 0 ? lowbits << sh : lowbits >> -sh;
+        }
+        v &= 0xFFFFu;
+      }
+      return v;
+    };
+    for (; q < q_end; q += 64) {
+      uint32_t val = 0;
+      if (4 * q < B) { // (else: the block's padding to 4 bytes... cannot be a whole word, kept for safety)
+        if (4 * q >= r_end) {
+          do {
+            ++l;
+            r_beg = r_end;
             r_end = S.rowoff[l + 1];
-          } else {
-            do {
-              ++l;
-              r_beg = r_end;
-              r_end = S.rowoff[l + 1];
-            } while (2 * u >= r_end);
-          }
+          } while (4 * q >= r_end);
           R.load(S, E16, l, d.ef_min);
         }
-        uint32_t h = (2 * u - r_beg) >> 1; // 16-bit unit of the row
-        const bool escaped = d.hdr_form == 2 && R.nm;
-        if (escaped && h < 2) {
-          half = (tab_hdr_pack(R.a_idx - max_bs, R.cnt, 1u) >> (16 * h)) & 0xFFFFu;
-        } else if (!R.efl) {
-          half = R.entry(escaped ? h - 2 : h);
-        } else {
-          const uint32_t bit0 = 16 * h;
-          if (bit0 < R.HB) half = (S.bitmap[(R.aux >> 16) + (h >> 1)] >> (16 * (h & 1u))) & 0xFFFFu; // zero from bit HB on
-          if (bit0 + 16 > R.LB) { // low parts that overlap bits [bit0, bit0 + 16)
-            const int rel = (int)bit0 - (int)R.LB; // of the low area
-            uint32_t j = rel > 0 ? ((uint32_t)rel * R.M) >> 20 : 0u; // rel / efl  (rel < 2^15: exact)
-            const uint32_t mask = (1u << R.efl) - 1u;
-            for (; j < R.cnt; ++j) {
-              const int sh = (int)(j * R.efl) - rel;
-              if (sh >= 16) break;
-              const uint32_t lowbits = R.entry(j) & mask;
-              half |= sh >= 0 ? lowbits << sh : lowbits >> -sh;
-            }
-            half &= 0xFFFFu;
-          }
+        const uint32_t h = (4 * q - r_beg) >> 1;
+        val = unit(h);
+        if (4 * q + 2 < r_end) {
+          val |= unit(h + 1) << 16;
+        } else if (4 * q + 2 < B) { // the upper half belongs to the next row (rows have at least one unit: no skipping)
+          ++l;
+          r_beg = r_end;
+          r_end = S.rowoff[l + 1];
+          R.load(S, E16, l, d.ef_min);
+          val |= unit(0) << 16;
         }
       }
-      const uint32_t other = (uint32_t)__shfl_down((int)half, 1, 64);
-      if (!(lane & 1) && u < u_end) stg<uint32_t>(out + 2 * (size_t)u, half | (other << 16));
+      stg<uint32_t>(out + 4 * (size_t)q, val);
     }
   }
 }
