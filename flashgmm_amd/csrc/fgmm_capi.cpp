@@ -162,7 +162,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -436,6 +436,8 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   // ---- host side: per item side information, then one rANS job per item -----------------------------
   std::vector<std::vector<int32_t>> wide_syms(count); // only for bypass symbols beyond int16 (rare)
   PoolDrain drain{ctx->pool};
+  const int enc_T = std::max(ctx->pool->size(), 1);
+  const int enc_ways = ctx->opt.enc_ways > 0 ? (int)ctx->opt.enc_ways : (count > enc_T ? std::min(kMaxEncWays, (count + enc_T - 1) / enc_T) : 1);
   for (int i = 0; i < count; ++i) {
     EncItem &it = items[i];
     int64_t n = (int64_t)it.M * it.hw;
@@ -487,35 +489,50 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     it.job_syms = syms_for_bypass;
     it.job_n = n;
     it.job_bypass = (int64_t)n_bypass;
-    // More bitstreams than workers: consecutive items go to one worker two at a time, coded in turn symbol by symbol
-    // (rans_encode_symtab2) — 48 streams on 16 threads are then two rounds of a pair (2 x 1.5 ns/symbol) instead of
-    // three rounds of a single stream (2.4 ns/symbol).
-    const bool pairing = count > ctx->pool->size() && !it.symbuf;
-    if (pairing && (i & 1) == 0 && i + 1 < count && !items[i + 1].symbuf) continue; // submitted together with item i + 1
-    const bool pair = pairing && (i & 1) == 1 && !items[i - 1].symbuf;
-    HIP_TRY(hipEventSynchronize(ctx->events[group_of[i]])); // item i - 1 lies in the same or an earlier copy
+    // More bitstreams than workers: consecutive items go to one worker `ways` at a time, coded in turn symbol by symbol
+    // (rans_encode_symtab_ways) - 48 streams on 16 threads are one round of three streams per worker (3 x ~1.2 ns/symbol)
+    // instead of three rounds of a single stream (2.4 ns/symbol).
+    const int ways = it.symbuf ? 1 : enc_ways;
+    const int g0 = i - i % ways; // the group [g0, g0 + ways) is submitted with its last member
+    bool group_ok = ways > 1;
+    for (int q = g0; group_ok && q < std::min(g0 + ways, count); ++q) group_ok = !items[q].symbuf;
+    const int g_end = group_ok ? std::min(g0 + ways, count) : i + 1;
+    if (group_ok && i + 1 < g_end) continue;
+    const int g_begin = group_ok ? g0 : i;
+    HIP_TRY(hipEventSynchronize(ctx->events[group_of[i]])); // the earlier items lie in the same or an earlier copy
     const char *h_ws = ctx->h_ws;
-    EncItem *pa = pair ? &items[i - 1] : &it, *pb = pair ? &it : nullptr;
-    pa->t_sub = tr.ms();
-    if (pb) pb->t_sub = pa->t_sub;
-    auto job = [pa, pb, h_ws, &tr] {
-      pa->t_start = tr.ms();
-      const uint32_t *ta = reinterpret_cast<const uint32_t *>(h_ws + pa->o_packed);
-      if (pb) {
-        pb->t_start = pa->t_start;
-        const uint32_t *const packed[2] = {ta, reinterpret_cast<const uint32_t *>(h_ws + pb->o_packed)};
-        const int32_t *const syms[2] = {pa->job_syms, pb->job_syms};
-        const int64_t n2[2] = {pa->job_n, pb->job_n}, nb2[2] = {pa->job_bypass, pb->job_bypass};
-        uint8_t **out[2] = {&pa->bytes, &pb->bytes};
-        size_t *len[2] = {&pa->bytes_len, &pb->bytes_len};
-        pa->status = pb->status = rans_encode_symtab2(packed, syms, n2, nb2, out, len);
-        pb->t_end = tr.ms();
-      } else if (pa->symbuf) {
-        pa->status = fgmm_symbuf_append_symtab(pa->symbuf, ta, pa->job_syms, pa->job_n);
-      } else {
-        pa->status = rans_encode_symtab(ta, pa->job_syms, pa->job_n, pa->job_bypass, &pa->bytes, &pa->bytes_len);
+    EncItem *first = &items[g_begin];
+    const int n_in = g_end - g_begin;
+    const double t_sub = tr.ms();
+    for (int q = 0; q < n_in; ++q) first[q].t_sub = t_sub;
+    auto job = [first, n_in, h_ws, &tr] {
+      const double t_start = tr.ms();
+      if (n_in == 1 && first->symbuf) {
+        first->t_start = t_start;
+        first->status = fgmm_symbuf_append_symtab(first->symbuf, reinterpret_cast<const uint32_t *>(h_ws + first->o_packed), first->job_syms, first->job_n);
+        first->t_end = tr.ms();
+        return;
       }
-      pa->t_end = tr.ms();
+      const uint32_t *packed[kMaxEncWays];
+      const int32_t *syms[kMaxEncWays];
+      int64_t n[kMaxEncWays], nb[kMaxEncWays];
+      uint8_t **out[kMaxEncWays];
+      size_t *len[kMaxEncWays];
+      for (int q = 0; q < n_in; ++q) {
+        first[q].t_start = t_start;
+        packed[q] = reinterpret_cast<const uint32_t *>(h_ws + first[q].o_packed);
+        syms[q] = first[q].job_syms;
+        n[q] = first[q].job_n;
+        nb[q] = first[q].job_bypass;
+        out[q] = &first[q].bytes;
+        len[q] = &first[q].bytes_len;
+      }
+      const int rc = rans_encode_symtab_ways(n_in, packed, syms, n, nb, out, len);
+      const double t_end = tr.ms();
+      for (int q = 0; q < n_in; ++q) {
+        first[q].status = rc;
+        first[q].t_end = t_end;
+      }
     };
     if (count == 1) job(); else ctx->pool->submit(job);
   }
@@ -1168,6 +1185,7 @@ const OptName kOpts[] = {
     {"ef_rows", &fgmm_ctx::Opts::ef_rows, 0, 2, "FGMM_EF_ROWS"},
     {"ef_min", &fgmm_ctx::Opts::ef_min, kTabEfMin, 1 << 20, "FGMM_EF_MIN_ROWS"},
     {"dec_pair", &fgmm_ctx::Opts::dec_pair, 0, 1, "FGMM_DEC_PAIR"},
+    {"enc_ways", &fgmm_ctx::Opts::enc_ways, 0, kMaxEncWays, "FGMM_ENC_WAYS"},
 };
 } // namespace
 

@@ -163,6 +163,10 @@ int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len);
 // two streams by one thread, interleaved (each output identical to rans_encode_symtab's)
+constexpr int kMaxEncWays = 4;
+// `ways` (1..4) tables -> bitstreams, coded by the calling thread symbol by symbol in turn
+int rans_encode_symtab_ways(int ways, const uint32_t *const *packed, const int32_t *const *symbols, const int64_t *n,
+                            const int64_t *n_bypass_hint, uint8_t ***out, size_t **out_len);
 int rans_encode_symtab2(const uint32_t *const packed[2], const int32_t *const symbols[2], const int64_t n[2],
                         const int64_t n_bypass_hint[2], uint8_t **out[2], size_t *out_len[2]);
 // Decode-side tables as the host decoder sees them: `npiece` pieces in latent order; piece k holds the latents

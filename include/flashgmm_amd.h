@@ -81,6 +81,8 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *                       (bitstream, piece) tasks as they land - a bitstream decodes sequentially, but its coder state
  *                       moves from worker to worker between pieces: what lands last leaves one small piece of host
  *                       work per bitstream behind it, not one bitstream
+ *   "enc_ways"    [0]   encode: bitstreams one worker codes symbol by symbol in turn (1..4; 0 = ceil(bitstreams / workers),
+ *                       at most 4: several dependency chains share a core)
  *   "dec_pair"    [0]   decode: 1 = a worker takes two ready tasks and decodes them latent by latent in turn
  *                       (fgmm_rans_decode_tab2) unless that leaves a sleeping worker without one.  Pays on hosts
  *                       whose cores are bound by the decoder's dependency chain (1.5x per thread on a 2.1 GHz Xeon), not on
@@ -277,6 +279,10 @@ int fgmm_rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_nu
 int fgmm_rans_encode_symtab2(const uint32_t *packed0, const int32_t *symbols0_or_null, int64_t n0, const uint32_t *packed1,
                              const int32_t *symbols1_or_null, int64_t n1, uint8_t **out0, size_t *out0_len, uint8_t **out1,
                              size_t *out1_len);
+/* The same for `ways` (1..4) tables given as arrays: out[k] / out_len[k] receive bitstream k.  On an error no buffer is
+ * returned. */
+int fgmm_rans_encode_symtab_n(int ways, const uint32_t *const *packed, const int32_t *const *symbols_or_null, const int64_t *n,
+                              uint8_t **out, size_t *out_len);
 
 /* Host, integer only: edge tables (4-byte headers, rows sequential in latent order, as fgmm_build_cdftab_hip lays them
  * out) -> symbols; the reference's bisection with every float evaluation replaced by a look-up in F_i.  pool_len bounds

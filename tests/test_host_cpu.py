@@ -171,6 +171,22 @@ def test_host_pair_encoder_equals_single(oracle):
             b0, b1 = C.string_at(o0, l0.value), C.string_at(o1, l1.value)
             L.fgmm_free(o0); L.fgmm_free(o1)
             assert b0 == single[i] and b1 == single[j], (i, j)
+    # fgmm_rans_encode_symtab_n: one to four tables coded in turn (what the batched encoder does with ceil(streams / workers))
+    rng = np.random.default_rng(6)
+    for ways in (1, 2, 3, 4):
+        for _ in range(12):
+            pick = rng.integers(0, len(tabs), ways)
+            ps = [np.ascontiguousarray(tabs[k][0], np.uint32) for k in pick]
+            ss = [None if tabs[k][1] is None else np.ascontiguousarray(tabs[k][1], np.int32) for k in pick]
+            P = (C.c_void_p * ways)(*[p_.ctypes.data for p_ in ps])
+            S = (C.c_void_p * ways)(*[None if s_ is None else s_.ctypes.data for s_ in ss])
+            N = (C.c_int64 * ways)(*[len(p_) for p_ in ps])
+            O, LN = (C.c_void_p * ways)(), (C.c_size_t * ways)()
+            assert L.fgmm_rans_encode_symtab_n(ways, P, S, N, O, LN) == 0
+            for q in range(ways):
+                assert C.string_at(O[q], LN[q]) == single[pick[q]], (ways, pick)
+                L.fgmm_free(O[q])
+    assert L.fgmm_rans_encode_symtab_n(5, P, S, N, O, LN) == 1 and L.fgmm_rans_encode_symtab_n(0, P, S, N, O, LN) == 1
 
 
 @pytest.mark.parametrize("mode", MODES)
