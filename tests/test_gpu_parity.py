@@ -575,15 +575,17 @@ def test_stacked_batch_equals_item_lists(dtype):
         gmc.decompress_batch([r[0][0] for r in a][:-1], [r[0][1] for r in a], [r[0][2] for r in a], sg, mu, pi)
 
 
-@pytest.mark.parametrize("pieces,first,group,threads", [(4, 2, 0, 0), (1, 2, 0, 0), (2, 1, 0, 3), (3, 9, 2, 0), (8, 2, 0, 2), (7, 1, 4, 16)])
-def test_decode_piece_schedule_settings(ctx_options, pieces, first, group, threads):
+@pytest.mark.parametrize("pieces,first,group,threads,pair", [(4, 2, 0, 0, 0), (1, 2, 0, 0, 1), (2, 1, 0, 3, 1), (3, 9, 2, 0, 0), (8, 2, 0, 2, 1),
+                                                              (7, 1, 4, 16, 0), (8, 2, 0, 1, 1)])
+def test_decode_piece_schedule_settings(ctx_options, pieces, first, group, threads, pair):
     """The tables of a decode batch land on the host in pieces, piece-major, and each host worker follows its own bitstreams
-    piece by piece (fgmm_capi.cpp, decode_batch): every setting of the schedule, and any number of workers, must give
-    the same symbols."""
+    piece by piece (fgmm_capi.cpp, decode_batch), alone or two at a time in turn (dec_pair): every setting of the schedule,
+    and any number of workers, must give the same symbols; the encoder side codes ceil(9 / workers) bitstreams in turn per
+    worker (enc_ways), up to four."""
     if threads:
         _lib.set_threads(0, threads)  # a fresh context: before the options
     try:
-        ctx_options(pieces=pieces, dec_first=first, dec_group=group)
+        ctx_options(pieces=pieces, dec_first=first, dec_group=group, dec_pair=pair, ef_min=14 + 35 * (pieces & 1))
         _piece_schedule_case()
     finally:
         if threads:
