@@ -579,6 +579,7 @@ struct DecItem {
   hipEvent_t piece_ev[kMaxPieces] = {}; // recorded (this call) before the item's job is submitted
   char *h_out = nullptr;                // pinned: decoded symbols (host-written, read by the scatter kernel)
   int wide = 0; // h_out holds int32 symbols (some symbol outside int16), else int16
+  int64_t narrowed = 0; // symbols already converted to int16 in h_out (piece by piece)
   // schedule state, guarded by the call's mutex: pieces whose copy is queued | next piece to decode | a worker holds the
   // item | it is in the ready heap
   int queued = 0, next_piece = 0;
@@ -879,22 +880,24 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     if (p == 0) it.t_start = tw1;
   };
   auto complete = [&](DecItem &it, int p) { // true: the item is finished
-    const bool last = it.status != FGMM_OK || p + 1 == it.n_piece;
-    if (!last) return false;
-    const int rf = it.dec.finish();
-    if (it.status == FGMM_OK) it.status = rf;
     if (it.status == FGMM_OK && it.y_hat) {
-      // symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
+      // this piece's symbols -> pinned memory for the scatter kernel: int16 unless some (bypass-coded) symbol does not fit
       int16_t *s16 = reinterpret_cast<int16_t *>(it.h_out);
+      const int64_t k1 = std::min<int64_t>(it.dec.i, it.n);
       int32_t acc = 0;
-      for (int64_t k = 0; k < it.n; ++k) {
+      for (int64_t k = it.narrowed; k < k1; ++k) {
         const int32_t v = it.sym[k];
         s16[k] = (int16_t)v;
         acc |= v ^ (int32_t)(int16_t)v;
       }
-      it.wide = acc != 0;
-      if (it.wide) memcpy(it.h_out, it.sym, sizeof(int32_t) * (size_t)it.n);
+      it.narrowed = k1;
+      it.wide |= acc != 0;
     }
+    const bool last = it.status != FGMM_OK || p + 1 == it.n_piece;
+    if (!last) return false;
+    const int rf = it.dec.finish();
+    if (it.status == FGMM_OK) it.status = rf;
+    if (it.status == FGMM_OK && it.y_hat && it.wide) memcpy(it.h_out, it.sym, sizeof(int32_t) * (size_t)it.n);
     it.t_end = tr.ms();
     return true;
   };
