@@ -86,7 +86,7 @@ struct DecDesc {
 //                                         bits [LB + j * l, LB + (j + 1) * l), LB = HB rounded up to 8: the low l bits of E_j
 //   placement: sequential in latent order (generic path, the building-block API), or per block of `tl` latents at
 //   rows + 4 * blk_off[block] (tab_kernel: blocks are placed by an atomic cursor, in no particular order)
-constexpr int kMaxPieces = 8; // FGMM_MAX_PIECES
+constexpr int kMaxPieces = 16; // FGMM_MAX_PIECES
 #ifndef FGMM_EF_MIN
 #define FGMM_EF_MIN 14
 #endif

@@ -76,7 +76,7 @@ int fgmm_ctx_threads(const fgmm_ctx *ctx);
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
 
 /* Tuning knobs of a context (defaults in brackets).  Unknown names return FGMM_ERR_INVALID.
- *   "pieces"      [8]   decode: the tables of every bitstream of a call reach the host in this many pieces (at most 8),
+ *   "pieces"      [8]   decode: the tables of every bitstream of a call reach the host in this many pieces (at most 16),
  *                       piece-major and shrinking (piece p of P carries P - p parts of P (P + 1) / 2); the host workers take
  *                       (bitstream, piece) tasks as they land - a bitstream decodes sequentially, but its coder state
  *                       moves from worker to worker between pieces: what lands last leaves one small piece of host
