@@ -615,17 +615,17 @@ struct TempDevice {
 //   aux stream      : after unit u's kernel -> D2H of its four counters (cursor = bytes of rows placed)
 //   this thread     : unit u's size known -> a pinned range of exactly that size; copy stream: ONE copy per unit
 //                     (headers + block offsets + rows; few large copies reach 55.7 GB/s, a copy per item 51);
-//                     the unit's decode jobs go to the workers, each begins by waiting for its own copy
-//   host workers    : one bitstream each; symbols go to pinned memory as int16 (int32 if one does not fit)
+//                     the unit's pieces are marked queued: the workers' (bitstream, piece) tasks become ready
+//   host workers    : take the earliest-landing ready task, sleep on its copy's event, decode the piece, hand the
+//                     bitstream's coder state back; symbols go to pinned memory as int16 (int32 if one does not fit)
 //   caller's stream : yhat_scatter_kernel reads them from there and writes the full float latent, zero channels too
-// A launch unit is a group of items (small groups first: the first tables reach the host as early as possible) or, for
-// the tail window, one piece (block range) of each of the last few items.  The single-pass kernel needs no host
-// decision before its rows exist — they go to a provisioned staging area, placed by a cursor — so every kernel of the
-// call is enqueued up front and the PCIe transfer, the longest leg, starts as soon as the first small unit is done.
-// Tail window: a bitstream decodes sequentially (~9 ns/symbol), so whatever lands last leaves one whole item of
-// host work behind it.  The last few items therefore cross in pieces, piece k of all of them in one copy: their
-// decoders start on piece 0 and follow the pieces as they land, and what remains after the final copy is one piece of
-// work instead of one item.
+// A launch unit is one ROUND of pieces: block range p of every item of the call (the first round is cut into small
+// launches: the first tables reach the host as early as possible).  The single-pass kernel needs no host decision
+// before its rows exist - they go to a provisioned staging area, placed by a cursor - so every kernel of the call is
+// enqueued up front and the PCIe transfer, the longest leg, starts as soon as the first small unit is done.
+// Why pieces: a bitstream decodes sequentially (~9 ns/symbol), so whatever lands last leaves that much host work behind
+// it.  Every item therefore crosses in shrinking pieces, piece-major; its decoder follows the pieces as they land,
+// on whichever worker is free, and what remains after the final copy is 1/36 of each bitstream.
 // Items whose half-width does not fit the single-pass kernel (tab_tl() == 0) take the generic two-pass kernels, one
 // item at a time, synchronously (8-byte headers past max_bs 16382).
 int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items, int mode) {
@@ -686,6 +686,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     int64_t lat = 0;
     for (int k = 0; k < n_fast; ++k) lat += items[fast[k]].n;
     if (lat < 65536) np = 1; // pieces only pay for rows that take a while to cross
+    if (n_fast == 1) np = std::min(np, 3); // one decoder: pieces only let it start early, and each costs a hand-over (20 us)
   }
   auto piece_bound = [np](int64_t nblk, int p) { // first block of piece p: weights np, np-1 ... 1
     const int64_t tot = (int64_t)np * (np + 1) / 2, cum = (int64_t)p * (2 * np - p + 1) / 2;

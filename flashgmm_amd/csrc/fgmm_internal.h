@@ -47,7 +47,7 @@ struct DecDesc {
   int32_t clamp;
   int32_t logits;                // the weights planes hold logits: pi = softmax4 over K in the kernel (fgmm_math.h)
   int32_t prune;                 // 1: skip the saturated tails (exact, see tab_window); 0: evaluate all of F
-  int32_t hdr_form;              // bytes per header as the host gets them: 2, 4 or 8 (format v4 below)
+  int32_t hdr_form;              // bytes per header as the host gets them: 2, 4 or 8 (format v5 below)
   uint32_t ef_min;               // rows with at least this many entries are Elias-Fano coded (kTabEfMin / kTabNoEf)
   int32_t tl;                    // tab_kernel: latents per block (rows of a block are contiguous, blocks are placed by a cursor)
   // ---- tab_kernel (single pass): the blocks [blk_begin, blk_end) of this item, into one launch's range

@@ -2,7 +2,7 @@
 // (RansDecoder::decode_with_indexes_gmm, compressai/cpp_exts/rans/rans_interface.cpp:826-862) can ever look at,
 //     F_i[v] = (uint16)(cdf_i(v - 0.5) * 65535),   v in [-max_bs, max_bs + 1],
 // evaluated once on the GPU, trimmed losslessly to the window outside which it is constant, and laid out for the host
-// rANS decoder (format v4: fgmm_internal.h, include/flashgmm_amd.h).
+// rANS decoder (format v5: fgmm_internal.h, include/flashgmm_amd.h).
 //
 //   tab_kernel            single pass, the production path (items whose half-width fits: tab_tl() > 0).
 //                         Block = `tl` consecutive latents:
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       efl = tab_row_is_ef(cnt, nm, ef_min) ? tab_ef_l(cnt) : 0u;
       HB = efl ? tab_ef_hb(cnt, efl) : 0u;
       LB = (HB + 7u) & ~7u;
-      M = efl ? (1u << 20) / efl + 1u : 0u;
+      M = efl == 8u ? (1u << 20) / 8u + 1u : (efl == 12u ? (1u << 20) / 12u + 1u : (efl ? (1u << 20) / efl + 1u : 0u)); // no division for the two widths in use
     }
     // entry k of the row: F[a_idx + k] — an evaluated edge, or one of the two constants outside the evaluation window
     __device__ __forceinline__ uint32_t entry(uint32_t k) const {

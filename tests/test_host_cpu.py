@@ -299,7 +299,7 @@ def test_host_decoder_elias_fano_rows_of_every_width(oracle, shape):
 
 @pytest.mark.parametrize("max_bs,tl", [(9, 16), (9, 48), (99, 32), (200, 32), (70000, 16)])
 def test_host_decoder_header_forms_and_block_placement(oracle, max_bs, tl):
-    """format v4: 2-byte headers (with the escape for non-monotone rows), 4- and 8-byte headers, rows placed block by
+    """format v5: 2-byte headers (with the escape for non-monotone rows), 4- and 8-byte headers, rows placed block by
     block in a shuffled order behind blk_off — the decoder must give what the sequential 4-byte form gives, which is what
     the reference's bisection gives (garbage stream: every fallback is exercised)."""
     L = _lib.lib()
