@@ -636,9 +636,11 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   if ((rc = ctx->ensure_streams())) return rc;
   const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 32768) & ~31;
   const bool clamped = items[0].clamp != 0, f16 = items[0].prm.dtype == FGMM_F16;
-  // Elias-Fano rows are 30 % smaller than uint16 rows and 35 % slower to search: they pay when PCIe is the bottleneck of
-  // the call (at least as many bitstreams as host workers), not when it is bound by its few sequential decoders
-  const uint32_t ef_min = ctx->opt.ef_rows == 1 || (ctx->opt.ef_rows == 0 && count >= ctx->pool->size()) ? (uint32_t)ctx->opt.ef_min : kTabNoEf;
+  // Elias-Fano rows (long rows: ef_min) are 18 % fewer bytes than uint16 rows and 40 % more nanoseconds to search (57.6 B and
+  // 12 ns per latent against 70 B and 8.7 ns on the Kodak workload): with P = min(workers, bitstreams) decoders at work a
+  // latent costs max(bytes / 55.7 GB/s, ns / P) - Elias-Fano rows pay when 12 / P < 70 B / 55.7 GB/s = 1.26 ns, P >= 10.
+  const int decoders = std::min(std::max(ctx->pool->size(), 1), count);
+  const uint32_t ef_min = ctx->opt.ef_rows == 1 || (ctx->opt.ef_rows == 0 && decoders >= 10) ? (uint32_t)ctx->opt.ef_min : kTabNoEf;
 
   // ---- items: coded channels, header form, path --------------------------------------------------------------------
   Arena ar; // device workspace, mirrored in h_ws up to the counters

@@ -93,8 +93,8 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *   "tab_cap_e"   [16384] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2))
  *   "stage_max_mb" [0]  decode: cap of the device staging area for rows in MiB (0: a quarter of the free device memory).
  *                       A launch whose rows do not fit is re-run with the exact size its cursor reports.
- *   "ef_rows"     [0]   decode: 0 = Elias-Fano rows when a call has at least as many bitstreams as host workers (PCIe is
- *                       the bottleneck), uint16 rows otherwise (the sequential host decoders are); 1 = always, 2 = never
+ *   "ef_rows"     [0]   decode: 0 = Elias-Fano rows when min(host workers, bitstreams of the call) >= 10 (PCIe is the
+ *                       bottleneck), uint16 rows otherwise (the sequential host decoders are); 1 = always, 2 = never
  *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor).
  *                       14 gives the fewest bytes (55.7 B/latent on Kodak-like tables against 57.6) but costs the host
  *                       decoders more than the PCIe time it saves when 16 threads serve one GPU
