@@ -905,7 +905,9 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     return true;
   };
   int waiting = 0; // workers asleep on work_cv (under mu)
-  const bool pairing = ctx->opt.dec_pair != 0;
+  // two bitstreams in turn per worker: 8.9 -> 5.9 ns/symbol per thread with uint16 rows, nothing with Elias-Fano rows, and a
+  // loss whenever it leaves workers idle - automatic only with at least two bitstreams per worker
+  const bool pairing = ctx->opt.dec_pair == 1 || (ctx->opt.dec_pair == 0 && count >= 2 * std::max(ctx->pool->size(), 1) && ef_min == kTabNoEf);
   auto worker = [&] {
     std::unique_lock<std::mutex> l(mu);
     auto take = [&](int *p_out) { // under mu: the earliest-landing ready task
@@ -1190,7 +1192,7 @@ const OptName kOpts[] = {
     {"enc_linear", &fgmm_ctx::Opts::enc_linear, 0, 1, nullptr},
     {"ef_rows", &fgmm_ctx::Opts::ef_rows, 0, 2, "FGMM_EF_ROWS"},
     {"ef_min", &fgmm_ctx::Opts::ef_min, kTabEfMin, 1 << 20, "FGMM_EF_MIN_ROWS"},
-    {"dec_pair", &fgmm_ctx::Opts::dec_pair, 0, 1, "FGMM_DEC_PAIR"},
+    {"dec_pair", &fgmm_ctx::Opts::dec_pair, 0, 2, "FGMM_DEC_PAIR"},
     {"enc_ways", &fgmm_ctx::Opts::enc_ways, 0, kMaxEncWays, "FGMM_ENC_WAYS"},
 };
 } // namespace

@@ -83,13 +83,11 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *                       work per bitstream behind it, not one bitstream
  *   "enc_ways"    [0]   encode: bitstreams one worker codes symbol by symbol in turn (1..4; 0 = ceil(bitstreams / workers),
  *                       at most 4: several dependency chains share a core)
- *   "dec_pair"    [0]   decode: 1 = a worker takes two ready tasks and decodes them latent by latent in turn
- *                       (fgmm_rans_decode_tab2) unless that leaves a sleeping worker without one.  Pays on hosts
- *                       whose cores are bound by the decoder's dependency chain (1.5x per thread on a 2.1 GHz Xeon), not on
- *                       the 16-core MI355X box
- *   "dec_group"   [0]   decode: bitstreams per launch / copy (0: automatic: a whole round of pieces)
- *   "dec_first"   [2]   decode: size of the first launch of the first round (the first tables reach the host as early
- *                       as possible; the following launches double)
+ *   "dec_pair"    [0]   decode: a worker takes two ready tasks and decodes them latent by latent in turn
+ *                       (fgmm_rans_decode_tab2: 8.9 -> 5.9 ns/symbol per thread with uint16 rows) unless that leaves a
+ *                       sleeping worker without one.  0 = when the call has at least two bitstreams per worker and ships
+ *                       uint16 rows (hosts with few threads), 1 = always, 2 = never.  With 24 bitstreams on 16 workers it
+ *                       loses: it trades parallel workers for ILP
  *   "tab_cap_e"   [16384] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2))
  *   "stage_max_mb" [0]  decode: cap of the device staging area for rows in MiB (0: a quarter of the free device memory).
  *                       A launch whose rows do not fit is re-run with the exact size its cursor reports.

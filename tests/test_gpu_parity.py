@@ -585,7 +585,7 @@ def test_decode_piece_schedule_settings(ctx_options, pieces, first, group, threa
     if threads:
         _lib.set_threads(0, threads)  # a fresh context: before the options
     try:
-        ctx_options(pieces=pieces, dec_first=first, dec_group=group, dec_pair=pair, ef_min=14 + 35 * (pieces & 1), ef_rows=(pieces >> 1) & 1)
+        ctx_options(pieces=pieces, dec_first=first, dec_group=group, dec_pair=2 - pair, ef_min=14 + 35 * (pieces & 1), ef_rows=(pieces >> 1) & 1)
         _piece_schedule_case()
     finally:
         if threads:
