@@ -437,7 +437,9 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   std::vector<std::vector<int32_t>> wide_syms(count); // only for bypass symbols beyond int16 (rare)
   PoolDrain drain{ctx->pool};
   const int enc_T = std::max(ctx->pool->size(), 1);
-  const int enc_ways = ctx->opt.enc_ways > 0 ? (int)ctx->opt.enc_ways : (count > enc_T ? std::min(kMaxEncWays, (count + enc_T - 1) / enc_T) : 1);
+  // automatic: pairs as soon as there are more bitstreams than workers (measured on the box, 48 bitstreams on 16 workers:
+  // pairs 1.78 ms per call, threes 2.28, workers pulling one or two as the tables land 1.95-2.04)
+  const int enc_ways = ctx->opt.enc_ways > 0 ? (int)ctx->opt.enc_ways : (count > enc_T ? 2 : 1);
   for (int i = 0; i < count; ++i) {
     EncItem &it = items[i];
     int64_t n = (int64_t)it.M * it.hw;
@@ -490,8 +492,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     it.job_n = n;
     it.job_bypass = (int64_t)n_bypass;
     // More bitstreams than workers: consecutive items go to one worker `ways` at a time, coded in turn symbol by symbol
-    // (rans_encode_symtab_ways) - 48 streams on 16 threads are one round of three streams per worker (3 x ~1.2 ns/symbol)
-    // instead of three rounds of a single stream (2.4 ns/symbol).
+    // (rans_encode_symtab_ways) - two dependency chains share a core: 1.5 instead of 2.4 ns/symbol.
     const int ways = it.symbuf ? 1 : enc_ways;
     const int g0 = i - i % ways; // the group [g0, g0 + ways) is submitted with its last member
     bool group_ok = ways > 1;

@@ -81,8 +81,8 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *                       (bitstream, piece) tasks as they land - a bitstream decodes sequentially, but its coder state
  *                       moves from worker to worker between pieces: what lands last leaves one small piece of host
  *                       work per bitstream behind it, not one bitstream
- *   "enc_ways"    [0]   encode: bitstreams one worker codes symbol by symbol in turn (1..4; 0 = ceil(bitstreams / workers),
- *                       at most 4: several dependency chains share a core)
+ *   "enc_ways"    [0]   encode: consecutive bitstreams one worker codes symbol by symbol in turn (several dependency chains
+ *                       share a core): 1..4; 0 = two when the call has more bitstreams than workers, else one
  *   "dec_pair"    [0]   decode: a worker takes two ready tasks and decodes them latent by latent in turn
  *                       (fgmm_rans_decode_tab2: 8.9 -> 5.9 ns/symbol per thread with uint16 rows) unless that leaves a
  *                       sleeping worker without one.  0 = when the call has at least two bitstreams per worker and ships
