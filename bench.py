@@ -404,36 +404,41 @@ def main(argv=None):
         outs = decode_codec(res, record) if schedule == "codec" else decode_all(res, record)
         return res, outs
 
+    last = {}
+
     def timed(schedule, steps, record):
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(schedule, record=record)
+            last["res"], last["outs"] = step(schedule, record=record)
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
         return time.perf_counter() - t0
 
+    # a generational GC pass of the interpreter (tens of ms with torch loaded) is not part of the path: collect now, keep
+    # the collector off from the warm-up on.  Warm-up and timed region run back to back: 150 ms of idling between them (the
+    # result check used to sit there) costs the following steps 4 % (scripts/step_drift.py: the clocks have come down), so
+    # what is checked is the LAST TIMED step's result, after the clock has stopped.
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for _ in range(max(a.warmup, 1)):
-        res, outs = step(a.schedule)
-    # correctness of what is being timed: decode(encode(y)) == round(y) for every stream of this rank
+        step(a.schedule)
+    dt = timed(a.schedule, a.steps, record=True)
+    gc.enable()
+    res, outs = last["res"], last["outs"]
+    # correctness of what was timed: decode(encode(y)) == round(y) for every stream of this rank
     for i in range(n_streams):
         y_i = ys[i:i + 1] if stacked else ys[i]
         assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(y_i)), f"stream {i} mismatch"
     n_coded = sum(int(r[0][2].sum()) * hw for r, hw in zip(res, hw_of))
     total_bytes = sum(len(r[0][0]) for r in res)
     enc_table_bytes = _lib.ctx_stat(local_rank, 0)
-
-    # a generational GC pass of the interpreter (tens of ms with torch loaded) is not part of the path
-    import gc
-
-    gc.collect()
-    gc.freeze()
-    gc.disable()
-    dt = timed(a.schedule, a.steps, record=True)
-    gc.enable()
     per_rank = [dt]
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
