@@ -210,28 +210,104 @@ def pmc_traffic(workload: str, mode: str, f16: bool):
 
 def launch_ranks(a, argv):
     """`python bench.py --gpus N` with N > 1 and no torch.distributed.run around it: start N fresh child processes, one
-    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), BEFORE anything in this process touches the
-    GPU; forward rank 0's JSON line; exit non-zero if any rank fails.  Children are started as children (never exec'ed
-    over this process)."""
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_* in their environment), BEFORE anything in this
+    process touches the GPU, and SUPERVISE them: rank 0's stdout is read by a thread, every child is polled; the first rank
+    that exits non-zero (or the overall timeout, or SIGTERM / SIGINT to this process) ends the others within seconds —
+    SIGTERM to each child's process group, SIGKILL after a grace period — and the launcher exits non-zero.  A rank that
+    dies at start-up can therefore not leave rank 0 waiting in the rendezvous until the collective's own timeout.
+    Children are started as children (never exec'ed over this process)."""
+    import signal
     import socket
     import subprocess
+    import threading
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), FGMM_BENCH_CHILD="1")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FGMM_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+
+    def stop_all(grace_s: float = 3.0):
+        for sig, wait_s in ((signal.SIGTERM, grace_s), (signal.SIGKILL, 5.0)):
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, sig)  # the child leads its own session: its helpers go with it
+                    except (ProcessLookupError, PermissionError):
+                        pass
+            t_end = time.monotonic() + wait_s
+            while time.monotonic() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.02)
+
+    interrupted = []
+
+    def on_signal(signum, _frame):
+        interrupted.append(signum)
+
+    old_handlers = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    deadline = time.monotonic() + a.launch_timeout
+    failed = None
+    try:
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+                break
+            if all(rc == 0 for rc in rcs):
+                break
+            if interrupted:
+                failed = f"interrupted by signal {interrupted[0]}"
+                break
+            if time.monotonic() > deadline:
+                failed = f"no result within --launch-timeout {a.launch_timeout:.0f} s"
+                break
+            time.sleep(0.05)
+    finally:
+        if failed:
+            stop_all()
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
+    reader.join(timeout=5.0)
+    rcs = [p.poll() for p in procs]
+    if failed:
+        print(f"bench.py: {failed}; the other ranks were stopped (exit codes {rcs})", file=sys.stderr)
+        raise SystemExit(1)
+    sys.stdout.write((out0[0] if out0 else b"").decode())
     sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+
+
+def cpu_throttle_counters():
+    """(nr_periods, nr_throttled, throttled_usec) of this process's cgroup (v2 cpu.stat, v1 cpu/cpu.stat), or None.
+    A timed region during which nr_throttled grows ran with the CPU quota exhausted: the number is the host's, not the path's."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            kv = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+            if "nr_throttled" in kv:
+                t = kv.get("throttled_usec") or str(int(kv.get("throttled_time", "0")) // 1000)
+                return int(kv.get("nr_periods", 0)), int(kv["nr_throttled"]), int(t)
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def step_stats(step_s, before, after):
+    """per-step wall times of a timed region + what the cgroup's CPU controller did to the process meanwhile"""
+    ms = np.asarray(step_s) * 1e3
+    out = {"min": round(float(ms.min()), 3), "median": round(float(np.median(ms)), 3), "p90": round(float(np.percentile(ms, 90)), 3),
+           "max": round(float(ms.max()), 3)}
+    if before and after:
+        out["cpu_throttled"] = {"periods": after[0] - before[0], "nr_throttled": after[1] - before[1],
+                                "throttled_ms": round((after[2] - before[2]) / 1e3, 1)}
+    return out
 
 
 _REAL_STDOUT = None
@@ -248,11 +324,17 @@ def dryrun(a, world, rank):
     group (gloo), the per-step all-gather of stream lengths, barriers, max-over-ranks timing, rank 0's one JSON line.
     The line says so ("data": "dryrun-no-gpu", value 0): it is never a measurement."""
     import torch.distributed as dist
+    from flashgmm_amd import _lib
     from flashgmm_amd import parallel as P
 
+    if os.environ.get("FGMM_BENCH_DRYRUN_FAIL_RANK") == str(rank):  # test hook: this rank dies before the rendezvous
+        raise SystemExit(3)
+    if os.environ.get("FGMM_BENCH_DRYRUN_HANG_RANK") == str(rank):  # test hook: this rank never reaches the rendezvous
+        time.sleep(3600)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     n_streams = 2 * (a.images or 24)
+    threads = _lib.lib().fgmm_host_thread_budget(_lib.ranks_on_node())  # what this rank's context would get
     t_gather = []
 
     def step():
@@ -273,19 +355,22 @@ def dryrun(a, world, rank):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    per_rank = [dt]
+    per_rank, per_rank_threads = [dt], [threads]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64)
+        tt = torch.tensor([dt, float(threads)], dtype=torch.float64)
         gathered = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(gathered, tt)
-        per_rank = [float(t) for t in gathered]
+        per_rank = [float(t[0]) for t in gathered]
+        per_rank_threads = [int(t[1]) for t in gathered]
         dt = max(per_rank)
     if rank == 0:
         emit({"metric": "dryrun", "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
               "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dryrun-no-gpu",
               "config": {"workload": a.workload, "streams_per_gpu": n_streams},
-              "ranks": {"backend": "gloo" if world > 1 else None, "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
+              "ranks": {"backend": "gloo" if world > 1 else None, "rccl_ranks": 0,
+                        "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
+                        "host_threads_per_gpu": per_rank_threads, "host_cpu_budget": _lib.host_cpu_budget(),
                         "allgather_ms": round(float(np.mean(t_gather[-a.steps:])) * 1e3, 4)}})
     if world > 1:
         dist.destroy_process_group()
@@ -303,6 +388,9 @@ def main(argv=None):
     ap.add_argument("--mode", default="polya", choices=["polya", "as", "logistic"])
     ap.add_argument("--schedule", default="codec", choices=["codec", "all-at-once"],
                     help="codec (default): decode stage by stage as the codec's dependencies demand; all-at-once: round 1's")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("FGMM_BENCH_LAUNCH_TIMEOUT", "1500")),
+                    help="self-launch (N > 1): seconds after which the ranks are stopped and the launch fails")
+    ap.add_argument("--host-threads", type=int, default=0, help="host rANS workers per GPU (0: this rank's share of the CPU budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip upper_bound / latency / per-thread legs (profiling runs)")
     a = ap.parse_args(argv)
@@ -323,6 +411,13 @@ def main(argv=None):
         return dryrun(a, world, rank)
     if os.environ.get("FGMM_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 code path on a 1-GPU box (dev aid)
         local_rank = 0
+    if os.environ.get("FGMM_BENCH_BLIT_WG"):  # experiment (scripts/blit_wg_ab.sh): exported here, after `import torch`, before the first GPU call
+        os.environ["DEBUG_CLR_LIMIT_BLIT_WG"] = os.environ["FGMM_BENCH_BLIT_WG"]
+    from flashgmm_amd import parallel as P
+
+    # first of all (the PCI address comes from sysfs): every thread this process creates from here on — the HIP runtime's
+    # own, torch's, the host rANS workers — starts on the GPU's NUMA node
+    numa = P.bind_to_gpu_numa_node(local_rank) if os.environ.get("FGMM_BENCH_BIND", "1") != "0" else "not bound (FGMM_BENCH_BIND=0)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -339,9 +434,6 @@ def main(argv=None):
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from flashgmm_amd import GaussianMixtureConditional, _lib
-    from flashgmm_amd import parallel as P
-
-    numa = P.bind_to_gpu_numa_node(local_rank)  # before the worker threads and pinned buffers exist
 
     if a.images is None:
         a.images = 24 if a.workload == "kodak24" else 1
@@ -355,6 +447,7 @@ def main(argv=None):
     shapes = sorted({tuple(t[0].shape) for t in devt})
     stacked = len(shapes) == 1
     gmc = GaussianMixtureConditional(K=4, mode=a.mode)
+    _lib.ctx(local_rank, a.host_threads)
     _lib.set_profiling(local_rank, True)
 
     # streams in coding order: image-major, stage-minor.  Stage s of the decode schedule = stream s of every image.
@@ -407,16 +500,21 @@ def main(argv=None):
     last = {}
 
     def timed(schedule, steps, record):
+        """-> (wall time of the whole region, step_ms statistics).  The per-step clock reads sit between steps, after the step's
+        own stream synchronisation (decompress returns with y_hat complete): they add nothing to the region."""
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        c0 = cpu_throttle_counters()
+        marks = [time.perf_counter()]
         for _ in range(steps):
             last["res"], last["outs"] = step(schedule, record=record)
+            marks.append(time.perf_counter())
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
-        return time.perf_counter() - t0
+        t1 = time.perf_counter()
+        return t1 - marks[0], step_stats(np.diff(marks), c0, cpu_throttle_counters())
 
     # a generational GC pass of the interpreter (tens of ms with torch loaded) is not part of the path: collect now, keep
     # the collector off from the warm-up on.  Warm-up and timed region run back to back: 150 ms of idling between them (the
@@ -429,7 +527,7 @@ def main(argv=None):
     gc.disable()
     for _ in range(max(a.warmup, 1)):
         step(a.schedule)
-    dt = timed(a.schedule, a.steps, record=True)
+    dt, step_ms = timed(a.schedule, a.steps, record=True)
     gc.enable()
     res, outs = last["res"], last["outs"]
     # correctness of what was timed: decode(encode(y)) == round(y) for every stream of this rank
@@ -439,12 +537,14 @@ def main(argv=None):
     n_coded = sum(int(r[0][2].sum()) * hw for r, hw in zip(res, hw_of))
     total_bytes = sum(len(r[0][0]) for r in res)
     enc_table_bytes = _lib.ctx_stat(local_rank, 0)
-    per_rank = [dt]
+    host_threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
+    per_rank, per_rank_threads = [dt], [host_threads]
     if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        tt = torch.tensor([dt, float(host_threads)], dtype=torch.float64, device=coll_dev)
         gathered = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(gathered, tt)
-        per_rank = [float(t.item()) for t in gathered]
+        per_rank = [float(t[0].item()) for t in gathered]
+        per_rank_threads = [int(t[1].item()) for t in gathered]
         dt = max(per_rank)
 
     extras = {}
@@ -453,7 +553,7 @@ def main(argv=None):
         n_ub = max(3, min(a.steps, 10))
         step(other)
         gc.disable()
-        dt_o = timed(other, n_ub, record=False)
+        dt_o, step_ms_o = timed(other, n_ub, record=False)
         gc.enable()
         if dist:
             tt = torch.tensor([dt_o], dtype=torch.float64, device=coll_dev)
@@ -461,7 +561,7 @@ def main(argv=None):
             dt_o = float(tt.item())
         extras["upper_bound" if other == "all-at-once" else "as_codec"] = {
             "schedule": other, "value": round(world * a.images * pix_per_image * n_ub / dt_o / 1e6, 2), "unit": "Mpixels/s",
-            "ms_per_step": round(dt_o / n_ub * 1e3, 3), "steps": n_ub}
+            "ms_per_step": round(dt_o / n_ub * 1e3, 3), "steps": n_ub, "step_ms": step_ms_o}
         if rank == 0 and world == 1:
             # latency of ONE image (its spi streams): encode in one call, decode stage by stage / in one call
             def one_image(codec: bool):
@@ -490,7 +590,7 @@ def main(argv=None):
             step(a.schedule)
             n1 = 3
             gc.disable()
-            dt1 = timed(a.schedule, n1, record=False)
+            dt1, _ = timed(a.schedule, n1, record=False)
             gc.enable()
             extras["one_host_thread"] = {"value": round(a.images * pix_per_image * n1 / dt1 / 1e6, 2), "unit": "Mpixels/s",
                                          "ms_per_step": round(dt1 / n1 * 1e3, 2), "host_threads": 1}
@@ -515,6 +615,7 @@ def main(argv=None):
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3),
+            "step_ms": step_ms,  # rank 0's per-step wall times of the timed region + the cgroup's throttling meanwhile
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -525,7 +626,8 @@ def main(argv=None):
                        "streams_per_gpu": n_streams, "stream_shapes": shapes, "stacked_input": stacked, "K": 4, "approx_mode": a.mode,
                        "param_dtype": "f16" if f16 else "f32",
                        "coded_symbols_per_gpu": n_coded, "bitstream_bytes_per_gpu": total_bytes,
-                       "host_threads_per_gpu": _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank)), "numa": numa,
+                       "host_threads_per_gpu": host_threads, "host_cpu_budget": _lib.host_cpu_budget(),
+                       "ranks_on_node": _lib.ranks_on_node(), "numa": numa,
                        "parallelism": f"images sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "symtab_kernel (encode-side GMM-CDF)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -551,6 +653,7 @@ def main(argv=None):
                      "decode_table_bytes_per_latent": round(tbytes / max(1, n_coded), 2), "bitstream_bytes": total_bytes},
             "ranks": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                       "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
+                      "host_threads_per_gpu": per_rank_threads,
                       "allgather_ms": round(float(np.mean(t_gather)) * 1e3, 4) if t_gather else None},
         }
         out.update(extras)

@@ -69,10 +69,13 @@ _pp, _psz = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
 SIGNATURES = {
     "fgmm_abi_version": (_i, []),
     "fgmm_last_error": (C.c_char_p, []),
+    "fgmm_host_cpu_budget": (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double)]),
+    "fgmm_host_thread_budget": (_i, [_i]),
     "fgmm_ctx_create": (_i, [_i, _i, _pp]),
     "fgmm_ctx_destroy": (None, [_p]),
     "fgmm_ctx_device": (_i, [_p]),
     "fgmm_ctx_threads": (_i, [_p]),
+    "fgmm_ctx_set_threads": (_i, [_p, _i]),
     "fgmm_free": (None, [_p]),
     "fgmm_ctx_set_profiling": (_i, [_p, _i]),
     "fgmm_ctx_kernel_ms": (_i, [_p, _i, C.POINTER(C.c_float)]),
@@ -155,6 +158,8 @@ def ctx(device: int = -1, n_threads: int = 0) -> C.c_void_p:
         h = _ctxs.get(key)
     if h is None:
         out = C.c_void_p()
+        if n_threads <= 0:  # this process's share of the host's CPU budget (affinity mask, cgroup quota, ranks on the node)
+            n_threads = L.fgmm_host_thread_budget(ranks_on_node())
         check(L.fgmm_ctx_create(key, int(n_threads), C.byref(out)), "fgmm_ctx_create")
         with _lock:
             if key in _ctxs:  # lost a race: keep the first
@@ -204,14 +209,32 @@ def trim(device: int) -> None:
     check(lib().fgmm_ctx_trim(ctx(device)), "fgmm_ctx_trim")
 
 
+def ranks_on_node() -> int:
+    """processes (one per GPU) that share this host's CPU budget: LOCAL_WORLD_SIZE as torch.distributed.run exports it (bench.py's
+    own launcher exports it too), FGMM_RANKS_ON_NODE to say it by hand; 1 otherwise"""
+    for name in ("FGMM_RANKS_ON_NODE", "LOCAL_WORLD_SIZE"):
+        try:
+            v = int(os.environ.get(name, ""))
+            if v >= 1:
+                return v
+        except ValueError:
+            pass
+    return 1
+
+
+def host_cpu_budget() -> dict:
+    """-> {"cpus", "affinity", "quota"} (fgmm_host_cpu_budget; quota None when the cgroup sets none)"""
+    cpus, aff, quota = C.c_double(), C.c_int(), C.c_double()
+    check(lib().fgmm_host_cpu_budget(C.byref(cpus), C.byref(aff), C.byref(quota)), "fgmm_host_cpu_budget")
+    return {"cpus": cpus.value, "affinity": aff.value, "quota": quota.value if quota.value > 0 else None}
+
+
 def set_threads(device: int, n_threads: int) -> None:
-    """Re-create the device's context with `n_threads` host rANS workers (0: default).  Measurement aid."""
-    L = lib()
-    with _lock:
-        h = _ctxs.pop(int(device), None)
-    if h is not None:
-        L.fgmm_ctx_destroy(h)
-    ctx(device, n_threads)
+    """Resize the pool of host rANS workers of the device's context in place (0: the default for this process's share of the
+    host).  Options, profiling state and buffers of the context are kept; the handle from ``ctx()`` stays valid."""
+    if n_threads <= 0:
+        n_threads = lib().fgmm_host_thread_budget(ranks_on_node())
+    check(lib().fgmm_ctx_set_threads(ctx(device), int(n_threads)), "fgmm_ctx_set_threads")
 
 
 def set_profiling(device: int, enable: bool) -> None:

@@ -94,17 +94,62 @@ def gather_containers(local: Sequence[bytes], n_units: int, device=None, group=N
     return out
 
 
-def bind_to_gpu_numa_node(device_index: int) -> str:
-    """Pin this process (and the threads / pinned buffers it creates afterwards) to the NUMA node the GPU hangs off.
+def _visible_filter(n_gpus: int) -> List[int]:
+    """KFD GPU ordinals HIP enumerates, in HIP's order, when ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES hold plain indices"""
+    import os
 
-    The decode-side tables cross PCIe at ~57 GB/s per GPU into pinned host memory and are then read by the host
-    rANS workers; with 8 GPUs on a 2-socket host that traffic should stay on the GPU's own socket.  Best effort:
-    returns a short description, never raises."""
+    idx = list(range(n_gpus))
+    for name in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(name)
+        if v is None or v.strip() == "":
+            continue
+        try:
+            pick = [int(t) for t in v.split(",") if t.strip() != ""]
+        except ValueError:  # UUIDs: not resolvable from sysfs alone
+            raise LookupError(f"{name}={v!r}")
+        idx = [idx[i] for i in pick if 0 <= i < len(idx)]
+    return idx
+
+
+def gpu_pci_address(device_index: int) -> str:
+    """PCI address of HIP device `device_index` WITHOUT initialising HIP: the KFD topology lists the GPUs in the order the
+    runtime enumerates them (nodes with SIMDs; ``domain`` and ``location_id`` = bus << 8 | devfn).  Raises LookupError when
+    the topology is unreadable (the caller then asks the runtime)."""
+    import os
+
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    gpus = []
+    try:
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(line.split()[:2] for line in open(f"{base}/{n}/properties") if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+                gpus.append(f"{dom:04x}:{(loc >> 8) & 0xFF:02x}:{(loc >> 3) & 0x1F:02x}.{loc & 7}")
+    except (OSError, ValueError, KeyError) as e:
+        raise LookupError(f"KFD topology: {e}")
+    order = _visible_filter(len(gpus))
+    if not 0 <= device_index < len(order):
+        raise LookupError(f"device {device_index} of {len(order)} visible GPUs")
+    return gpus[order[device_index]]
+
+
+def bind_to_gpu_numa_node(device_index: int, all_threads: bool = True) -> str:
+    """Pin this process to the CPUs of the NUMA node the GPU hangs off: every thread it has NOW (``all_threads``: the HIP
+    runtime's signal / interrupt handling threads exist from the first GPU call on, and ``sched_setaffinity(0, ...)`` alone
+    moves the calling thread only) and, by inheritance, every thread created afterwards (the host rANS workers).
+
+    The decode-side tables cross PCIe at ~57 GB/s per GPU into pinned host memory (which the runtime places on the GPU's
+    node by itself) and are then read by the host rANS workers; with 8 GPUs on a 2-socket host that traffic — and the
+    wake-ups that follow every copy — should stay on the GPU's own socket.  Best effort: returns a short description,
+    never raises.  Call it as early as possible (the PCI address comes from sysfs: no GPU call is needed first)."""
     import os
 
     try:
-        p = torch.cuda.get_device_properties(device_index)
-        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        try:
+            bdf = gpu_pci_address(device_index)
+        except LookupError:
+            p = torch.cuda.get_device_properties(device_index)
+            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
         node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
         if node < 0:
             return f"gpu {device_index} ({bdf}): no NUMA affinity reported"
@@ -116,6 +161,15 @@ def bind_to_gpu_numa_node(device_index: int) -> str:
         if not cpus:
             return f"gpu {device_index} ({bdf}): node {node} has no allowed CPUs"
         os.sched_setaffinity(0, cpus)
-        return f"gpu {device_index} ({bdf}) -> NUMA node {node}, {len(cpus)} CPUs"
+        moved = 1
+        if all_threads:
+            moved = 0
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    os.sched_setaffinity(int(tid), cpus)
+                    moved += 1
+                except OSError:  # the thread has gone, or may not be moved
+                    pass
+        return f"gpu {device_index} ({bdf}) -> NUMA node {node}, {len(cpus)} CPUs, {moved} thread(s) bound"
     except Exception as e:  # pragma: no cover - topology files differ between hosts
         return f"gpu {device_index}: not bound ({e})"

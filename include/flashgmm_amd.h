@@ -67,11 +67,23 @@ typedef struct fgmm_ctx fgmm_ctx; /* one per process per GPU: streams, pinned st
 int fgmm_abi_version(void);
 const char *fgmm_last_error(void); /* thread-local text of the last failure on this thread */
 
-/* device < 0: current HIP device.  n_threads <= 0: min(hardware threads, 16) host rANS workers. */
+/* What this process may use of the host: *cpus_out = min(CPUs of its affinity mask, CPUs per period of its cgroup quota —
+ * cpu.max of cgroup v2 / cpu.cfs_quota_us of v1, ancestors included); *affinity_out / *quota_out the two terms (quota < 0:
+ * none).  Any out-pointer may be NULL. */
+int fgmm_host_cpu_budget(double *cpus_out, int *affinity_out, double *quota_out);
+/* Host rANS workers a context gets by default when `ranks_sharing` processes (one per GPU) share that budget:
+ * floor(budget / ranks_sharing) - 2, within [1, 16].  The two CPUs left out are the calling thread and the HIP runtime's own
+ * threads: a pool as large as the quota exceeds it by construction and the whole process is throttled. */
+int fgmm_host_thread_budget(int ranks_sharing);
+
+/* device < 0: current HIP device.  n_threads <= 0: fgmm_host_thread_budget(1) host rANS workers. */
 int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out);
 void fgmm_ctx_destroy(fgmm_ctx *ctx);
 int fgmm_ctx_device(const fgmm_ctx *ctx);
 int fgmm_ctx_threads(const fgmm_ctx *ctx);
+/* Resizes the context's pool of host rANS workers in place (n_threads <= 0: the default); options, profiling state and
+ * buffers are kept.  Must not race with a call on the same context (it takes the context's lock like every call). */
+int fgmm_ctx_set_threads(fgmm_ctx *ctx, int n_threads);
 
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
 
@@ -96,6 +108,13 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor).
  *                       14 gives the fewest bytes (55.7 B/latent on Kodak-like tables against 57.6) but costs the host
  *                       decoders more than the PCIe time it saves when 16 threads serve one GPU
+ *   "tab_direct"  [1]   decode: the table kernels store headers, block offsets and rows STRAIGHT INTO PINNED HOST MEMORY
+ *                       (coalesced stores across PCIe) instead of a device staging area that a copy then fetches: no staging
+ *                       write + read in HBM, no copy kernels sharing the CUs with the table kernels, and a launch's tables
+ *                       are on the host when the launch is over.  0 = staging area + one copy per launch (round 2's path)
+ *   "host_stage_max_mb" [4096] decode, tab_direct: cap of that pinned area in MiB.  It is provisioned for the worst case of a
+ *                       call (every edge of every window as a uint16) when the cap allows, else every launch's row area
+ *                       shrinks by the same factor; a launch whose rows do not fit is re-run with the exact size
  *   "trace"       [0]   1: phase timestamps of every batched call on stderr, 2: + per-bitstream job timeline */
 int fgmm_ctx_set_option(fgmm_ctx *ctx, const char *name, int64_t value);
 int fgmm_ctx_get_option(fgmm_ctx *ctx, const char *name, int64_t *value_out);

@@ -29,6 +29,12 @@ def test_self_launch_prints_one_line(n):
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["steps"] == 4 and d["warmup"] == 1 and d["data"] == "dryrun-no-gpu"
     assert len(d["ranks"]["ms_per_step"]) == n and d["ms_per_step"] == max(d["ranks"]["ms_per_step"])
+    # what the first hardware run with N > 1 will report per rank: the collective's share, the rank's step time, its share
+    # of the host's CPU budget (the budget divided by the ranks on the node, two CPUs kept free, at least one worker)
+    assert d["ranks"]["backend"] == "gloo" and d["ranks"]["rccl_ranks"] == 0 and d["ranks"]["allgather_ms"] > 0
+    threads = d["ranks"]["host_threads_per_gpu"]
+    budget = d["ranks"]["host_cpu_budget"]
+    assert len(threads) == n and all(t == max(1, min(16, int(budget["cpus"] / n) - 2)) for t in threads)
     for key in ("metric", "value", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "config"):
         assert key in d
 
@@ -56,3 +62,47 @@ def test_a_failing_rank_fails_the_launch():
                                                                   "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
     # without the dry-run switch the children need a GPU; here there is none, so they fail and so must the launcher
     assert r.returncode != 0
+
+
+def test_one_rank_dying_at_startup_ends_the_launch_within_seconds():
+    """Rank 1 exits before the rendezvous; rank 0 would sit in init_process_group until the store's timeout (minutes).
+    The launcher polls every child: it stops rank 0 and fails."""
+    import time
+
+    t0 = time.monotonic()
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--images", "2"], {"FGMM_BENCH_DRYRUN_FAIL_RANK": "1"})
+    dt = time.monotonic() - t0
+    assert r.returncode != 0 and "rank 1 exited with code 3" in r.stderr, r.stderr[-2000:]
+    assert r.stdout.strip() == ""
+    assert dt < 60, f"the launcher took {dt:.0f} s to notice a dead rank"
+
+
+def test_launch_timeout_stops_every_rank():
+    """A rank that never finishes (here: rank 0 waiting for a rank that is held back) is stopped by --launch-timeout."""
+    import time
+
+    t0 = time.monotonic()
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--images", "2", "--launch-timeout", "8"],
+             {"FGMM_BENCH_DRYRUN_HANG_RANK": "1"})
+    dt = time.monotonic() - t0
+    assert r.returncode != 0 and "--launch-timeout" in r.stderr, r.stderr[-2000:]
+    assert dt < 60
+
+
+def test_sigterm_to_the_launcher_stops_the_ranks():
+    import signal
+    import time
+
+    env = dict(os.environ, FGMM_BENCH_DRYRUN="1", FGMM_BENCH_DRYRUN_HANG_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(6.0)  # both children are up (rank 1 sleeping, rank 0 in the rendezvous)
+    kids = subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()
+    p.send_signal(signal.SIGTERM)
+    _, err = p.communicate(timeout=60)
+    assert p.returncode != 0 and "interrupted by signal" in err, err[-2000:]
+    time.sleep(0.5)
+    for k in kids:  # no rank survives its launcher
+        assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z"
