@@ -134,6 +134,29 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
         assert tuple(y_hat.shape[2:4]) == tuple(shape)
         return {"y_hat": y_hat}
 
+    def decompress_many(self, strings: List[List[Any]], shape: Tuple[int, int], ctx_params: List[Tensor]) -> List[Dict[str, Any]]:
+        """``decompress`` of N independent items (the same stage of N images) in ONE batched native call: N host decoders
+        side by side instead of N calls with one decoder each."""
+        planes, sums = [], []
+        for ctx in ctx_params:
+            scales_hat, means_hat, weights = self._params(ctx)
+            if self.quantizer == "noise":
+                planes.append(self._planes(scales_hat, means_hat, weights))
+                sums.append(None)
+            else:
+                weighted_sum, means_rel = self._recentre(means_hat, weights)
+                planes.append(self._planes(scales_hat, means_rel, weights))
+                sums.append(weighted_sum)
+        items = [st[0] for st in strings]  # (bytes, abs_max, zero_bitmap) of every item
+        ss, ms, ws = (list(t) for t in zip(*planes))
+        outs = self.gaussian_mixture_conditional.decompress_batch([it[0] for it in items], [it[1] for it in items], [it[2] for it in items],
+                                                                  ss, ms, ws, weights_are_logits=self.fuse_softmax)
+        res = []
+        for y_hat, add in zip(outs, sums):
+            assert tuple(y_hat.shape[2:4]) == tuple(shape)
+            res.append({"y_hat": y_hat if add is None else y_hat + add})
+        return res
+
     def forward(self, y: Tensor, ctx_params: Tensor):
         raise NotImplementedError("training-time likelihoods are outside the entropy-coding path; use the reference's "
                                   "GaussianMixtureConditionalLatentCodec.forward (pure torch)")
@@ -215,6 +238,21 @@ class CheckerboardLatentCodec(nn.Module):
             y_hat_[i] = codec.decompress([strings[i]], (h, w // 2), params_i)["y_hat"]
         return {"y_hat": self.embed(y_hat_)}
 
+    def decompress_many(self, strings: List[List[Any]], shape: Tuple[int, ...], side_params: List[Tensor]) -> List[Dict[str, Any]]:
+        """N images of one shape, STAGE-MAJOR: the anchors of every image in one batched native call, then the non-anchors
+        of every image in one — the dependency runs inside an image (checkerboard.py:316-324), not between images, so a
+        call keeps N host decoders busy where ``decompress`` image by image keeps one."""
+        c, h, w = shape
+        codec = self.latent_codec["y"]
+        y_hat_ = [sp.new_zeros((2, 1, c, h, w // 2)) for sp in side_params]
+        side_ = [self.unembed(sp) for sp in side_params]
+        for i in range(2):
+            params = [self.entropy_parameters(self.merge(self._ctx(yh, i), sd[i])) for yh, sd in zip(y_hat_, side_)]
+            outs = codec.decompress_many([[st[i]] for st in strings], (h, w // 2), params)
+            for yh, o in zip(y_hat_, outs):
+                yh[i] = o["y_hat"]
+        return [{"y_hat": self.embed(yh)} for yh in y_hat_]
+
     def forward(self, y: Tensor, side_params: Tensor):
         raise NotImplementedError("training-time likelihoods are outside the entropy-coding path")
 
@@ -295,6 +333,56 @@ class ChannelGroupsLatentCodec(nn.Module):
         if len(per_group) != 1:
             raise RuntimeError("every group codec must emit the same number of strings (channel_groups.py:124)")
         return {"strings": [s for r in results for s in r["strings"]], "shape": [r["shape"] for r in results], "y_hat": y_hat}
+
+    def compress_many(self, ys: List[Tensor], side_params: List[Tensor]) -> List[Dict[str, Any]]:
+        """``compress`` of N images: every image is prepared in group order (the networks run per image, batch 1 as the
+        reference's), then ALL bitstreams of all images — N x groups x 2 — are coded in ONE batched native call."""
+        codecs = [self.latent_codec[f"y{k}"] for k in range(len(self.groups))]
+        if not self._one_call(codecs):
+            return [self.compress(y, sp) for y, sp in zip(ys, side_params)]
+        flat, per_image = [], []
+        for y, sp in zip(ys, side_params):
+            parts = torch.split(y, self.groups, dim=1)
+            y_hat = torch.zeros_like(y)
+            views = y_hat.split(self.groups, dim=1)
+            prepared, hats = [], []
+            for k, c in enumerate(codecs):
+                pk, hk = c.prepare(parts[k], self._get_ctx_params(k, sp, views))
+                views[k].copy_(hk)
+                prepared.append(pk)
+                hats.append(hk)
+                flat.extend(pk)
+            per_image.append((prepared, hats, y_hat))
+        outs = codecs[0].latent_codec["y"].compress_many(flat)
+        results, at = [], 0
+        for prepared, hats, y_hat in per_image:
+            rs = []
+            for c, pk, hk in zip(codecs, prepared, hats):
+                rs.append(c.finish(outs[at:at + len(pk)], hk))
+                at += len(pk)
+            results.append({"strings": [s_ for r in rs for s_ in r["strings"]], "shape": [r["shape"] for r in rs], "y_hat": y_hat})
+        return results
+
+    def decompress_many(self, strings: List[List[Any]], shape: List[Tuple[int, ...]], side_params: List[Tensor]) -> List[Dict[str, Any]]:
+        """N images of one shape in flight, STAGE-MAJOR: group by group (channel_groups.py:147-154 — sequential inside an
+        image), each group's stage of every image in one batched native call (``CheckerboardLatentCodec.decompress_many``).
+        One image alone is a chain of single-bitstream calls — one host decoder at work, fifteen idle; N images fill the
+        workers.  Results equal ``decompress`` image by image."""
+        per_group = len(strings[0]) // len(self.groups)
+        channels = sum(s_[0] for s_ in shape)
+        y_hats = [torch.zeros((1, channels, *shape[0][1:]), device=sp.device) for sp in side_params]
+        views = [yh.split(self.groups, dim=1) for yh in y_hats]
+        for k in range(len(self.groups)):
+            codec = self.latent_codec[f"y{k}"]
+            params = [self._get_ctx_params(k, sp, v) for sp, v in zip(side_params, views)]
+            sub = [st[per_group * k: per_group * (k + 1)] for st in strings]
+            if hasattr(codec, "decompress_many"):
+                outs = codec.decompress_many(sub, shape[k], params)
+            else:
+                outs = [codec.decompress(st, shape[k], pr) for st, pr in zip(sub, params)]
+            for v, o in zip(views, outs):
+                v[k].copy_(o["y_hat"])
+        return [{"y_hat": yh} for yh in y_hats]
 
     def decompress(self, strings: List[Any], shape: List[Tuple[int, ...]], side_params: Tensor, **kwargs: Any) -> Dict[str, Any]:
         per_group = len(strings) // len(self.groups)

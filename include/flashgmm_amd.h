@@ -72,8 +72,8 @@ const char *fgmm_last_error(void); /* thread-local text of the last failure on t
  * none).  Any out-pointer may be NULL. */
 int fgmm_host_cpu_budget(double *cpus_out, int *affinity_out, double *quota_out);
 /* Host rANS workers a context gets by default when `ranks_sharing` processes (one per GPU) share that budget:
- * floor(budget / ranks_sharing) - 2, within [1, 16].  The two CPUs left out are the calling thread and the HIP runtime's own
- * threads: a pool as large as the quota exceeds it by construction and the whole process is throttled. */
+ * floor(budget / ranks_sharing), within [1, 16].  (The workers sleep on the copies' events and are busy three quarters of a
+ * call: a pool as large as the share does not get the process throttled, and two workers fewer measured 2.5 % slower.) */
 int fgmm_host_thread_budget(int ranks_sharing);
 
 /* device < 0: current HIP device.  n_threads <= 0: fgmm_host_thread_budget(1) host rANS workers. */

@@ -30,11 +30,11 @@ def test_self_launch_prints_one_line(n):
     assert d["n_gpus"] == n and d["steps"] == 4 and d["warmup"] == 1 and d["data"] == "dryrun-no-gpu"
     assert len(d["ranks"]["ms_per_step"]) == n and d["ms_per_step"] == max(d["ranks"]["ms_per_step"])
     # what the first hardware run with N > 1 will report per rank: the collective's share, the rank's step time, its share
-    # of the host's CPU budget (the budget divided by the ranks on the node, two CPUs kept free, at least one worker)
+    # of the host's CPU budget (affinity mask and cgroup quota, divided by the ranks on the node; at least one worker)
     assert d["ranks"]["backend"] == "gloo" and d["ranks"]["rccl_ranks"] == 0 and d["ranks"]["allgather_ms"] > 0
     threads = d["ranks"]["host_threads_per_gpu"]
     budget = d["ranks"]["host_cpu_budget"]
-    assert len(threads) == n and all(t == max(1, min(16, int(budget["cpus"] / n) - 2)) for t in threads)
+    assert len(threads) == n and all(t == max(1, min(16, int(budget["cpus"] / n))) for t in threads)
     for key in ("metric", "value", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "config"):
         assert key in d
 

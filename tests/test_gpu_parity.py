@@ -797,6 +797,62 @@ def test_config4_elic_4k_fp16_through_the_group_codec(oracle):
     assert [(b, a) for b, a, _ in enc2["strings"]] == [(b, a) for b, a, _ in enc["strings"]] and torch.equal(enc2["y_hat"], enc["y_hat"])
 
 
+def test_config4_images_in_flight_stage_major_equals_image_by_image(oracle):
+    """configs[4] as a codec runs it on several images: ``compress_many`` codes every bitstream of every image in one
+    call, ``decompress_many`` decodes STAGE-MAJOR — stage s (group, half) of every image in one batched call, the
+    dependency chain of channel_groups.py:147-154 intact inside each image.  Checked on two images (ELIC's five groups,
+    fp16 planes, a reduced plane size): batched == image by image, byte for byte and bit for bit; the bitstreams of
+    the three small groups == the oracle fed the widened parameters; one decode call per stage whatever the image count."""
+    from flashgmm_amd.latent_codecs import ChannelGroupsLatentCodec, CheckerboardLatentCodec, GaussianMixtureConditionalLatentCodec
+
+    groups, c_side, h, w = [16, 16, 32, 64, 192], 8, 34, 60
+    Ctx, Par = T.exact_modules()
+    seen = []
+    calls = []
+
+    class Spy(GaussianMixtureConditionalLatentCodec):
+        def coder_inputs(self, y, ctx_params):
+            out = super().coder_inputs(y, ctx_params)
+            seen.append(out)
+            return out
+
+    def build():
+        gmc = GaussianMixtureConditional(K=4, mode="polya")
+        real = gmc.decompress_batch
+        gmc.decompress_batch = lambda strings, *a, **k: (calls.append(len(strings)), real(strings, *a, **k))[1]
+        latent = {f"y{k}": CheckerboardLatentCodec(latent_codec={"y": Spy(K=4, gaussian_mixture_conditional=gmc, param_dtype=torch.float16)},
+                                                   context_prediction=Ctx(g, 2 * g), entropy_parameters=Par(2 * g + (k > 0) * 2 * g + c_side, g))
+                  for k, g in enumerate(groups)}
+        chctx = {f"y{k}": Ctx(sum(groups[:k]), 2 * groups[k]) for k in range(1, len(groups))}
+        return ChannelGroupsLatentCodec(groups=groups, channel_context=chctx, latent_codec=latent)
+
+    images = [T.exact_codec_inputs(71 + n, sum(groups), c_side, h, w) for n in range(2)]
+    ys, sides = [dv(y) for y, _ in images], [dv(sd) for _, sd in images]
+    codec = build()
+    one_by_one = [codec.compress(y, sd) for y, sd in zip(ys, sides)]
+    seen.clear()
+    many = codec.compress_many(ys, sides)
+    assert len(seen) == 20
+    for a, b in zip(many, one_by_one):
+        assert [(s_[0], s_[1], s_[2].tolist()) for s_ in a["strings"]] == [(s_[0], s_[1], s_[2].tolist()) for s_ in b["strings"]]
+        assert torch.equal(a["y_hat"], b["y_hat"]) and [tuple(x) for x in a["shape"]] == [tuple(x) for x in b["shape"]]
+    for n in range(2):  # the three small groups of both images against the oracle
+        for i in range(6):
+            yc, sg, mu, pi = (t.cpu().numpy() for t in seen[10 * n + i])
+            sym, s_, m_, w_, am, zbm, yqn = T.to_coder_inputs(yc, *(a.astype(np.float32) for a in (sg, mu, pi)))
+            b, abs_max, zb = many[n]["strings"][i]
+            assert b == oracle.encode_gmm("polya", sym, s_, m_, w_) and abs_max == am and zb.cpu().tolist() == zbm.tolist(), (n, i)
+    calls.clear()
+    dec = codec.decompress_many([m["strings"] for m in many], many[0]["shape"], sides)
+    assert calls == [2] * 10  # ten stages, both images in every call
+    calls.clear()
+    for n in range(2):
+        assert torch.equal(dec[n]["y_hat"], many[n]["y_hat"]) and torch.equal(many[n]["y_hat"], torch.round(ys[n]))
+        ref = codec.decompress(many[n]["strings"], many[n]["shape"], sides[n])
+        assert torch.equal(ref["y_hat"], dec[n]["y_hat"])
+    assert calls == [1] * 20
+
+
 def test_config0_256x256_plumbing(oracle):
     """BASELINE configs[0]: one 256x256 image -> y [1,192,16,16], halves [1,192,16,8]; all three modes."""
     for mode in MODES:

@@ -434,3 +434,63 @@ def test_host_decoder_short_stream_is_an_error(oracle):
 
 def test_empty_table_flushes_initial_state():
     assert host_encode_symtab(_lib.lib(), np.zeros(0, np.uint32), None) == bytes.fromhex("0000008000000000")
+
+
+# ---- the host's CPU budget: affinity mask and cgroup quota (fgmm_host_cpu_budget / fgmm_host_thread_budget) ----------
+def _budget_in_child(sysroot, cpus=None, ranks=1):
+    """the budget as a fresh process sees it (the affinity is the process's own; FGMM_SYSROOT stands in for "/")"""
+    import subprocess
+    import sys
+
+    code = ("import os, sys, json\n"
+            f"cpus = {sorted(cpus) if cpus else None}\n"
+            "if cpus: os.sched_setaffinity(0, cpus)\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "from flashgmm_amd import _lib\n"
+            f"print(json.dumps([_lib.host_cpu_budget(), _lib.lib().fgmm_host_thread_budget({ranks})]))\n")
+    env = dict(os.environ, FGMM_SYSROOT=str(sysroot))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    import json
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _tree(root, files):
+    for rel, text in files.items():
+        path = os.path.join(root, rel.lstrip("/"))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+
+
+def test_host_budget_reads_the_cgroup_v2_quota_of_the_group_and_its_ancestors(tmp_path):
+    _tree(tmp_path, {"/proc/self/cgroup": "0::/pod/box\n",
+                     "/sys/fs/cgroup/pod/box/cpu.max": "max 100000\n",
+                     "/sys/fs/cgroup/pod/cpu.max": "1600000 100000\n",
+                     "/sys/fs/cgroup/cpu.max": "max 100000\n"})
+    n_aff = len(os.sched_getaffinity(0))
+    budget, threads = _budget_in_child(tmp_path)
+    assert budget["affinity"] == n_aff and budget["quota"] == 16.0 and budget["cpus"] == min(n_aff, 16.0)
+    assert threads == max(1, min(16, int(budget["cpus"])))
+    # eight ranks share the node: each gets an eighth, and at least one worker
+    _, per_rank = _budget_in_child(tmp_path, ranks=8)
+    assert per_rank == max(1, int(budget["cpus"] / 8))
+
+
+def test_host_budget_reads_a_cgroup_v1_quota_and_the_affinity_mask(tmp_path):
+    _tree(tmp_path, {"/proc/self/cgroup": "3:cpuset:/jobs\n2:cpu,cpuacct:/jobs/j1\n0::/\n",
+                     "/sys/fs/cgroup/cpu,cpuacct/jobs/j1/cpu.cfs_quota_us": "350000\n",
+                     "/sys/fs/cgroup/cpu,cpuacct/jobs/j1/cpu.cfs_period_us": "100000\n",
+                     "/sys/fs/cgroup/cpu,cpuacct/cpu.cfs_quota_us": "-1\n",
+                     "/sys/fs/cgroup/cpu,cpuacct/cpu.cfs_period_us": "100000\n"})
+    budget, threads = _budget_in_child(tmp_path)
+    assert budget["quota"] == 3.5 and budget["cpus"] == min(budget["affinity"], 3.5) and threads == max(1, int(budget["cpus"]))
+    one = sorted(os.sched_getaffinity(0))[:1]
+    budget, threads = _budget_in_child(tmp_path, cpus=one)  # a one-CPU mask wins over the quota
+    assert budget["affinity"] == 1 and budget["cpus"] == 1.0 and threads == 1
+
+
+def test_host_budget_without_a_quota_is_the_affinity_mask(tmp_path):
+    _tree(tmp_path, {"/proc/self/cgroup": "0::/\n", "/sys/fs/cgroup/cpu.max": "max 100000\n"})
+    budget, threads = _budget_in_child(tmp_path)
+    assert budget["quota"] is None and budget["cpus"] == budget["affinity"] and threads == min(16, budget["affinity"])
