@@ -90,5 +90,21 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s_tmp)
   return base + incl - v;
 }
 
+// the same with 64-bit sums (values that may add up past 2^32 within one block)
+__device__ __forceinline__ unsigned long long block_scan_excl64(unsigned long long v, unsigned long long *s_tmp) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_tmp[w] = incl;
+  __syncthreads();
+  unsigned long long base = 0;
+  for (int i = 0; i < w; ++i) base += s_tmp[i];
+  __syncthreads();
+  return base + incl - v;
+}
 
 } // namespace fgmm

@@ -298,10 +298,22 @@ inline int32_t bisect_reference(const Row &r, uint32_t cum_freq, int32_t max_bs,
 // first index j in [0, cnt) with row[j] > cf, or cnt; row is non-decreasing; reads up to 30 bytes past the row.
 // One vector at a time with an early exit: measured faster than four vectors at a time without a data-dependent branch
 // (the compares of the vectors are independent and run ahead anyway; rounds 1 and 2, scripts/host_bench.py).
+// Rows beyond 256 entries (wide items of the generic path, up to 2^20 entries: max_bs comes out of a bitstream's side
+// information) are first narrowed by bisection to a window of at most 256 entries: the cost per symbol stays logarithmic in
+// the row length whatever a stream announces.
 __attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *row, int32_t cnt, uint32_t cf) {
   const __m256i bias = _mm256_set1_epi16((short)0x8000);
   const __m256i key = _mm256_set1_epi16((short)(cf ^ 0x8000u));
-  for (int32_t k = 0; k < cnt; k += 16) {
+  int32_t k0 = 0;
+  if (__builtin_expect(cnt > 256, 0)) {
+    int32_t lo = 0, hi = cnt; // every entry before lo is <= cf, the first entry > cf (if any) lies in [lo, hi)
+    while (hi - lo > 256) {
+      const int32_t mid = lo + ((hi - lo) >> 1);
+      if (row[mid] <= cf) lo = mid + 1; else hi = mid + 1;
+    }
+    k0 = lo;
+  }
+  for (int32_t k = k0; k < cnt; k += 16) {
     const __m256i v = _mm256_xor_si256(_mm256_loadu_si256((const __m256i *)(row + k)), bias);
     const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi16(v, key));
     if (m) {

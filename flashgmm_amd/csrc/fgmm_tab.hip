@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void cdftab_count_kernel(const DecDesc *__r
 __global__ __launch_bounds__(kBlock) void cdftab_scan_kernel(const DecDesc *__restrict__ descs) {
   const DecDesc &d = descs[blockIdx.x];
   const int64_t nb = (int64_t)d.n_ch * d.tiles;
-  __shared__ uint32_t s_tmp[kBlock / 64];
+  __shared__ unsigned long long s_tmp[kBlock / 64];
   __shared__ unsigned long long s_carry;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
@@ -206,7 +206,8 @@ __global__ __launch_bounds__(kBlock) void cdftab_scan_kernel(const DecDesc *__re
     const uint32_t raw = b < nb ? d.blk_sums[b] : 0u;
     flagged |= raw >> 31;
     const uint32_t v = raw & 0x7FFFFFFFu;
-    const uint32_t ex = block_scan_excl(v, s_tmp);
+    // 64-bit prefix: one block holds up to 2^29 bytes of rows (256 rows of a 2^20-edge window), 256 of them exceed 2^32
+    const unsigned long long ex = block_scan_excl64(v, s_tmp);
     const unsigned long long carry = s_carry;
     if (b < nb) d.blk_off[b] = carry + ex;
     __syncthreads();
@@ -367,9 +368,6 @@ __device__ __forceinline__ uint32_t tab_scan(uint32_t v, uint32_t *scratch, uint
 #ifndef FGMM_TAB_WAVES
 #define FGMM_TAB_WAVES 4
 #endif
-#ifndef FGMM_TAB_EXPERIMENT
-#define FGMM_TAB_EXPERIMENT 0 // timing experiments only: 1 = no cursor atomic (rows at block-indexed worst-case slots), 2 = also no edge counter
-#endif
 template <int MODE, bool CLAMPED, typename PT>
 __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDesc *__restrict__ descs, int tl_max, int cap_e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -447,9 +445,6 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       l_beg = S.offP[l];
       l_end = S.offP[l + 1];
     }
-#if FGMM_TAB_EXPERIMENT == 3
-    for (; t < t_end; t += 64) S.E32[t] = t;
-#endif
     for (; t < t_end; t += 64) {
       while (t >= l_end) { // next latent with a non-empty window
         ++l;
@@ -488,12 +483,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
 
   // ---- phase 3: trim every row, header, row size ------------------------------------------------------------------
   uint32_t bytes = 0;
-#if FGMM_TAB_EXPERIMENT == 4
-  if (tid < nl) { S.meta[tid] = 1u << 16; bytes = 4; }
-  if (false) {
-#else
   if (tid < nl) {
-#endif
     const uint32_t w = S.win[tid];
     const int j_lo = (int)(w & 0xFFFFu), len = (int)(w >> 16), j_hi = j_lo + len;
     const uint16_t *e = E16 + 2 * (size_t)S.offP[tid];
@@ -551,17 +541,10 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   if (tid == 0) {
     S.rowoff[nl] = B;
     S.efoff[nl] = EFT;
-#if FGMM_TAB_EXPERIMENT >= 1
-    const unsigned long long base = (unsigned long long)(b - d.blk_begin) * tl * (2ull * W + 4);
-    if (b == d.blk_end - 1) d.counters[0] = base + B4;
-#else
     const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)BA);
-#endif
     const bool fits = base + BA <= d.rows_cap;
     if (!fits) atomicMax(&d.counters[1], 1ull);
-#if FGMM_TAB_EXPERIMENT < 2
     if (d.count_edges) atomicAdd(&d.counters[2], 2ull * NP);
-#endif
     d.blkoff_out[b - d.blk_begin] = (uint32_t)(base >> 2);
     S.scratch[8] = (uint32_t)base;
     S.scratch[9] = (uint32_t)(base >> 32);

@@ -340,12 +340,21 @@ class EntropyBottleneckCoder(nn.Module):
             self._index_cache[spatial] = idx
         return idx
 
-    def compress(self, x: Tensor) -> List[bytes]:
+    def compress(self, x: Tensor, return_dequantized: bool = False):
+        """-> list of bytes, one per batch element; with ``return_dequantized`` also what ``decompress`` of those strings
+        yields — ``quantize(x) + medians`` computed where ``x`` lives (:158-176, :197-204: the coder is lossless on the
+        int32 symbols, so decoding them back is one elementwise op, not a host encode -> host decode -> upload)."""
         if x.dim() < 2 or x.size(1) != self.channels:
             raise ValueError(f"expected [N, {self.channels}, ...], got {tuple(x.shape)}")
         med = self.medians.to(x.device).reshape(1, -1, *([1] * (x.dim() - 2)))
         # quantize(inputs, "symbols", means): round(x - means).int()  (:158-176) — on the tensor's device, ONE copy out
-        sym = torch.round(x - med).to(torch.int32).reshape(x.size(0), -1).cpu().numpy()
+        sym_dev = torch.round(x - med).to(torch.int32)
+        sym = sym_dev.reshape(x.size(0), -1).cpu().numpy()
+        if return_dequantized:
+            return self._encode_rows(sym), sym_dev.to(torch.float32) + med  # dequantize: outputs.type_as(means) + means
+        return self._encode_rows(sym)
+
+    def _encode_rows(self, sym: np.ndarray) -> List[bytes]:
         idx = self._indexes(sym.shape[1] // self.channels)
         L = _lib.lib()
         out = []

@@ -30,7 +30,7 @@ from torch import Tensor
 
 from itertools import accumulate
 
-from .entropy_models import GaussianMixtureConditional
+from .entropy_models import EntropyBottleneckCoder, GaussianMixtureConditional
 from .ops import ckbd_embed, ckbd_unembed
 
 __all__ = ["GaussianMixtureConditionalLatentCodec", "CheckerboardLatentCodec", "ChannelGroupsLatentCodec", "HyperLatentCodec",
@@ -414,8 +414,14 @@ class HyperLatentCodec(nn.Module):
     def compress(self, y: Tensor) -> Dict[str, Any]:  # hyper.py:94-100
         z = self.h_a(y)
         shape = z.size()[-2:]
-        z_strings = self.entropy_bottleneck.compress(z)
-        z_hat = self.entropy_bottleneck.decompress(z_strings, shape)
+        eb = self.entropy_bottleneck
+        if isinstance(eb, EntropyBottleneckCoder):
+            # the reference decodes the strings it has just written to get z_hat (hyper.py:97-98); the table coder is lossless on
+            # the symbols, so that is round(z - medians) + medians: one elementwise op where z lives, bit for bit the same
+            z_strings, z_hat = eb.compress(z, return_dequantized=True)
+        else:  # any other entropy bottleneck with the reference's contract
+            z_strings = eb.compress(z)
+            z_hat = eb.decompress(z_strings, shape)
         return {"strings": [z_strings], "shape": shape, "params": self.h_s(z_hat)}
 
     def decompress(self, strings: List[List[bytes]], shape: Tuple[int, int], **kwargs: Any) -> Dict[str, Any]:  # hyper.py:102-108

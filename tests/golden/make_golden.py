@@ -178,7 +178,11 @@ def import_reference_hyper_codecs():
 
 # G8: the complete nested result of a hyperprior model around the GMM path (models/ckbd_gmm.py:109-123):
 # (name, seed, c, cz, c_side, h, w, quantizer)
-G8_HYPER = [("hyperprior_ckbd", 31, 6, 4, 8, 8, 12, "noise")]
+# the second case has the MODEL's geometry (Cheng2020AnchorCheckerboardGMMv2, N = 192, on a Kodak image: y [1, 192, 32, 48], the
+# EntropyBottleneck over N = 192 channels, 2 N = 384 side channels, models/ckbd_gmm.py:78-131); its bitstreams are stored as
+# length + sha256 (G8_HASHED), not verbatim
+G8_HYPER = [("hyperprior_ckbd", 31, 6, 4, 8, 8, 12, "noise"), ("hyperprior_ckbd_kodak_n192", 32, 192, 192, 384, 32, 48, "noise")]
+G8_HASHED = {"hyperprior_ckbd_kodak_n192"}
 
 
 def build_entropy_bottleneck(EB, cz: int):
@@ -218,7 +222,13 @@ def build_codecs(Ckbd, Groups, Gmm, Ctx, Par, kind, cfg):
     return Groups(groups=groups, channel_context=chctx, latent_codec=latent)
 
 
-def strings_to_json(strings):
+def bytes_to_json(b: bytes, hashed: bool):
+    return {"len": len(b), "sha256": hashlib.sha256(b).hexdigest()} if hashed else b.hex()
+
+
+def strings_to_json(strings, hashed: bool = False):
+    if hashed:
+        return [{**bytes_to_json(b, True), "abs_max": int(a), "zero_bitmap": [int(v) for v in zb.tolist()]} for (b, a, zb) in strings]
     return [{"hex": b.hex(), "abs_max": int(a), "zero_bitmap": [int(v) for v in zb.tolist()]} for (b, a, zb) in strings]
 
 
@@ -335,7 +345,7 @@ def worker(mode: int, flavour: str):
                 g8[name] = {
                     "tables": {"quantized_cdf": eb._quantized_cdf.tolist(), "cdf_length": eb._cdf_length.tolist(),
                                "offset": eb._offset.tolist(), "medians_bits": eb.quantiles[:, 0, 1].detach().numpy().view(np.uint32).tolist()},
-                    "y_strings": strings_to_json(ys_), "z_strings": [b.hex() for b in zs_],
+                    "y_strings": strings_to_json(ys_, name in G8_HASHED), "z_strings": [bytes_to_json(b, name in G8_HASHED) for b in zs_],
                     "shape": {"y": list(enc["shape"]["y"]), "hyper": list(enc["shape"]["hyper"])},
                     "z_sha256": hashlib.sha256(z.contiguous().numpy().tobytes()).hexdigest(),
                     "z_bypass_symbols": int(sum(int(((zs < o) | (zs >= o + ln - 2)).sum()) for zs, o, ln in zip(

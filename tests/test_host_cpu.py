@@ -388,6 +388,46 @@ def test_host_decoder_raw_rows_only(oracle, monkeypatch):
     assert rc == 0 and np.array_equal(out, want)
 
 
+def test_host_decoder_long_raw_rows_are_searched_in_logarithmic_time(oracle, monkeypatch):
+    """Raw uint16 rows far beyond one vector (wide items of the generic path: max_bs comes out of a stream's side
+    information): the search narrows by bisection before its SIMD compare — same symbols as the reference's bisection on
+    random garbage streams, for rows of up to 3002 entries incl. long runs of equal entries, and no per-symbol cost
+    proportional to the row length (a 2^16-entry row decodes as fast per symbol as a 300-entry one, within a factor)."""
+    import time
+
+    import helpers
+
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    monkeypatch.setattr(helpers, "EF_MIN", 1 << 30)
+    for max_bs, n in ((1500, 300), (140, 600)):
+        W = 2 * max_bs + 2
+        tab = np.sort(rng.integers(0, 65536, (n, W)), axis=1).astype(np.uint16)
+        tab[::3] = np.sort(rng.integers(0, 40, (len(tab[::3]), W)) * 1600, axis=1).astype(np.uint16)  # long runs of equal entries
+        enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+        want = oracle.rans_decode_cdftab(enc, tab, max_bs)
+        hdr4, pool4, _ = trim_full_table(tab, max_bs)
+        rc, out = host_decode_cdftab(L, enc, hdr4, pool4, max_bs)
+        assert rc == 0 and np.array_equal(out, want), max_bs
+    # cost per symbol against the row length (8-byte headers carry rows this long)
+    per_symbol = {}
+    for max_bs in (150, 32766):
+        W, n = 2 * max_bs + 2, 400
+        tab = np.sort(rng.integers(0, 65536, (n, W)), axis=1).astype(np.uint16)
+        tab[:, 0], tab[:, -1] = 0, 65535
+        enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+        form = helpers.hdr_form(max_bs)
+        hdr, bo, pool, used = trim_full_table(tab, max_bs, form=form, tl=16)
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            rc, out = host_decode_tab(L, enc, hdr, pool, max_bs, bo, 16)
+            best = min(best, time.perf_counter() - t0)
+        assert rc == 0 and np.array_equal(out, oracle.rans_decode_cdftab(enc, tab, max_bs))
+        per_symbol[max_bs] = best / n
+    assert per_symbol[32766] < 20 * per_symbol[150] + 2e-6, per_symbol  # a linear search would be ~200x
+
+
 def test_host_decoder_rejects_malformed_tables(oracle):
     """memory safety does not depend on the table being well-formed (include/flashgmm_amd.h): cnt = 0, a window outside the
     half-width, rows past the pool, inconsistent Elias-Fano rows -> FGMM_ERR_INVALID (1), never a wild read"""

@@ -130,7 +130,7 @@ def test_g8_hyper_latent_z_stream_equals_the_reference_classes():
     import torch
     from flashgmm_amd import testing as T
     from flashgmm_amd.latent_codecs import HyperLatentCodec
-    from golden.make_golden import G8_HYPER
+    from golden.make_golden import G8_HASHED, G8_HYPER, bytes_to_json
 
     g8 = _g8()["polya"]
     Ha, Hs = T.exact_hyper_modules()
@@ -142,9 +142,12 @@ def test_g8_hyper_latent_z_stream_equals_the_reference_classes():
         z = hyper.h_a(torch.from_numpy(y))
         assert hashlib.sha256(z.contiguous().numpy().tobytes()).hexdigest() == ent["z_sha256"]
         out = hyper.compress(torch.from_numpy(y))
-        assert [b.hex() for b in out["strings"][0]] == ent["z_strings"] and list(out["shape"]) == ent["shape"]["hyper"]
+        assert [bytes_to_json(b, name in G8_HASHED) for b in out["strings"][0]] == ent["z_strings"] and list(out["shape"]) == ent["shape"]["hyper"]
         dec = hyper.decompress(out["strings"], out["shape"])
         assert torch.equal(dec["params"], out["params"]) and tuple(out["params"].shape) == (1, c_side, h, w)
+        # compress() gets z_hat without decoding what it has just written: the same bits as decoding it
+        zs2, z_hat_short = hyper.entropy_bottleneck.compress(z, return_dequantized=True)
+        assert zs2 == out["strings"][0] and torch.equal(z_hat_short, hyper.entropy_bottleneck.decompress(zs2, out["shape"]))
         # z_hat = round(z - medians) + medians, bit for bit
         coder = hyper.entropy_bottleneck
         z_hat = coder.decompress(out["strings"][0], out["shape"])
