@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
       if (d.logits) softmax4(pi);
       int bp;
       out[e] = sym_entry<MODE, CLAMPED>(vq[e], vi[e], mu, sg, pi, bp);
-      nbypass += bp;
+      nbypass += __popcll(__ballot(bp)); // the wave's count on the scalar unit: no lane-wise sum, no cross-lane reduction
     }
     stg<uvec_t>(d.packed + (int64_t)rank * hw + p0, out);
   } else {
@@ -245,11 +245,11 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
     if (d.logits) softmax4(pi);
     int bp;
     stg<uint32_t>(d.packed + (int64_t)rank * hw + p0, sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp));
-    nbypass = bp;
+    nbypass = __popcll(__ballot(bp));
   }
-  // bypass census (the host sizes its output buffer from it): one plain store per wave that saw any, no atomics
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) nbypass += __shfl_xor(nbypass, o, 64);
+  // bypass census (the host sizes its output buffer from it): one plain store per wave that saw any, no atomics.  nbypass is
+  // the same on every active lane (ballots); lanes past the end of a channel are the wave's last ones, so lane 0 is active
+  // whenever any lane is
   if ((threadIdx.x & 63) == 0 && nbypass)
     d.meta[slot] = (uint32_t)nbypass;
 }

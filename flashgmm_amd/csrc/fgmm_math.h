@@ -291,9 +291,11 @@ __device__ __forceinline__ f2 rcp_ge1_tame2(f2 d) {
 }
 // sqrt_unit per half: x in {+0} U [2^-24, 1]
 __device__ __forceinline__ f2 sqrt_unit2(f2 x) {
-  // x == 0: rsq gives +inf and 0 * inf would be NaN; with the seed capped (any x >= 2^-24 has rsq <= 2^12) every step
-  // below yields +0, which is sqrt(0)
-  const f2 y = {__builtin_fminf(__builtin_amdgcn_rsqf(x.x), 0x1p100f), __builtin_fminf(__builtin_amdgcn_rsqf(x.y), 0x1p100f)};
+  // x == 0: rsq gives +inf and 0 * inf would be NaN.  The seed is taken of x + 2^-100 instead - ONE packed add for both halves
+  // (it was a v_min per half): any x >= 2^-24 absorbs the addend exactly (its ulp is >= 2^-47), and for x == 0 the seed
+  // is 2^50, with which every step below yields +0, which is sqrt(0)
+  const f2 xs = x + splat(0x1p-100f);
+  const f2 y = {__builtin_amdgcn_rsqf(xs.x), __builtin_amdgcn_rsqf(xs.y)};
   const f2 s0 = x * y, h = splat(0.5f) * y;
   const f2 r = fma2(-s0, s0, x);
   return fma2(r, h, s0);
@@ -400,10 +402,14 @@ __device__ __forceinline__ void softmax4(float (&w)[4]) {
 
 // static_cast<uint16_t>(float) as x86-64 GCC emits it (cvttss2si r32 ; movzwl), rans_interface.cpp:509-510.
 // cvttss2si yields 0x80000000 for NaN / out-of-range, v_cvt_i32_f32 saturates: make the x86 answer explicit.
+// Only the low 16 bits are kept, so only ONE case needs the explicit answer: f >= 2^31 saturates to 0x7FFFFFFF (low half
+// 0xFFFF) where x86 gives 0x80000000 (low half 0).  NaN converts to 0 and f < -2^31 saturates to 0x80000000: low half 0 like
+// x86's; everything in range truncates toward zero on both.
 __device__ __forceinline__ uint32_t quant16(float cdf) {
   const float f = cdf * 65535.0f;
-  const bool in_range = (f >= -2147483648.0f) && (f < 2147483648.0f);
-  const int t = in_range ? (int)f : (int)0x80000000;
+  int t; // the instruction itself (a C++ cast of an out-of-range float is undefined, and the optimizer may use that)
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(t) : "v"(f));
+  t = (f >= 2147483648.0f) ? 0 : t;
   return (uint32_t)t & 0xFFFFu;
 }
 
