@@ -297,6 +297,53 @@ def test_host_decoder_elias_fano_rows_of_every_width(oracle, shape):
     assert np.array_equal(out[np.diff(t64, axis=1).max(1) > 0], sym[np.diff(t64, axis=1).max(1) > 0])
 
 
+def test_host_decoder_long_elias_fano_rows_mixture_shaped(oracle):
+    """rows of 49 .. 254 entries with 8 low bits (a 256-bucket unary part of up to eight words: the straight-line search on
+    popcount prefixes): CDFs of two-component mixtures - a wide component under a narrow heavy one, so that one symbol jumps
+    over dozens of EMPTY buckets (its neighbours lie words away) while the tails crowd many entries into one bucket - searched
+    with the cum_freq values of garbage streams and of real streams; every answer is the reference bisection's."""
+    from math import erf
+
+    L = _lib.lib()
+    rng = np.random.default_rng(33)
+    max_bs = 126
+    W = 2 * max_bs + 2  # 254: the longest row the 2-byte headers carry
+    n = 6000
+    tab = np.zeros((n, W), np.uint16)
+    v = np.arange(W) - max_bs - 0.5
+    for i in range(n):
+        s_wide, s_nar = rng.uniform(8.0, 45.0), rng.uniform(0.11, 1.5)
+        m_wide, m_nar = rng.uniform(-20, 20), rng.uniform(-30, 30)
+        w_nar = rng.choice([0.0, 0.2, 0.6, 0.95])
+        cdf = np.array([(1 - w_nar) * 0.5 * (1 + erf((x - m_wide) / (s_wide * 2 ** 0.5))) + w_nar * 0.5 * (1 + erf((x - m_nar) / (s_nar * 2 ** 0.5))) for x in v])
+        tab[i] = np.minimum((cdf * 65535).astype(np.int64), 65535)
+    hdr, bo, pool, used = trim_full_table(tab, max_bs, form=2, tl=32, shuffle_seed=7)
+    cnts = (hdr >> 8).astype(np.int64)
+    assert (cnts >= 49).mean() > 0.8 and cnts.max() > 200  # the rows this test is about
+    assert np.array_equal(expand_trimmed(hdr, pool, max_bs, bo, 32), tab)
+    for seed in (1, 2):
+        enc = np.random.default_rng(seed).integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
+        rc, out = host_decode_tab(L, enc, hdr, pool, max_bs, bo, 32)
+        assert rc == 0 and np.array_equal(out, oracle.rans_decode_cdftab(enc, tab, max_bs))
+    t64 = tab.astype(np.int64)
+    sym = np.empty(n, np.int32)
+    packed = np.empty(n, np.uint32)
+    for i in range(n):  # a real stream: every row asked where its mass is (the big jump most of the time)
+        pmf = np.diff(t64[i])
+        j = int(rng.choice(np.nonzero(pmf > 0)[0], p=pmf[pmf > 0] / pmf[pmf > 0].sum()))
+        sym[i] = j - max_bs
+        packed[i] = int(t64[i, j]) | (int(pmf[j]) << 16)
+    enc2 = oracle.rans_encode_symtab(packed, sym)
+    rc, out = host_decode_tab(L, enc2, hdr, pool, max_bs, bo, 32)
+    assert rc == 0 and np.array_equal(out, sym)
+    # a corrupted unary part is refused or decodes to garbage, never reads out of bounds (run under ASan: scripts/asan_host.sh)
+    bad = pool.copy()
+    flip = rng.integers(0, used, 4000)
+    bad[flip] ^= (1 << rng.integers(0, 8, 4000)).astype(np.uint8)
+    rc, _ = host_decode_tab(L, enc2, hdr, bad, max_bs, bo, 32)
+    assert rc in (0, 1, 5)
+
+
 @pytest.mark.parametrize("max_bs,tl", [(9, 16), (9, 48), (99, 32), (200, 32), (70000, 16)])
 def test_host_decoder_header_forms_and_block_placement(oracle, max_bs, tl):
     """format v5: 2-byte headers (with the escape for non-monotone rows), 4- and 8-byte headers, rows placed block by
