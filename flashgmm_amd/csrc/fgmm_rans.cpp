@@ -437,91 +437,13 @@ __attribute__((target("bmi2,popcnt,lzcnt"))) inline int ef_bracket64(const EfRow
   return 1;
 }
 
-// Rows of 49 .. 256 entries (8 low bits, 256 buckets): the unary part is at most 512 bits = EIGHT 64-bit words, and the search
-// is straight-line code on their popcount prefixes.  Such rows are a quarter of the rows and more than half of the table
-// bytes of a Kodak-like batch, and most of their buckets hold no entry or one: the general search below takes a different,
-// data-dependent branch for "the neighbour lies in another bucket" on almost every symbol and pays a misprediction for it
-// (32 ns per symbol against 9.5 for a uint16 row).  Here every case is the same code:
-//   zeros / ones before each word (independent of cf: computed while the coder state of the previous symbol is still in flight)
-//   s   = select0(h - 1) + 1, z = select0(h)       first bit of bucket h, the zero that closes it; run = z - s entries
-//   c   = entries of the bucket with a low byte <= cf & 255 (one 16-byte compare), j = (s - h) + c
-//   E_q = (select1(q) - q) << 8 | low[q]  for q = j - 1 and q = j, wherever those entries live
-// select_b(k): the word is found by ONE vector compare of the eight prefixes with k, the bit by pdep + tzcnt.
-struct EfPrefix8 {
-  alignas(32) uint32_t z[8], o[8]; // zeros / ones in the words 0 .. i (inclusive prefixes)
-};
-__attribute__((target("avx2,bmi2,popcnt"))) static inline void ef_word8(const EfRow &r, uint32_t i, uint64_t *ones, uint64_t *zeros) {
-  uint64_t v;
-  memcpy(&v, r.p + 8 * i, 8);
-  int32_t rem = (int32_t)r.HB - 64 * (int32_t)i; // bits of this word that belong to the unary part
-  rem = rem < 0 ? 0 : (rem > 64 ? 64 : rem);
-  const uint64_t valid = _bzhi_u64(~0ull, (uint32_t)rem);
-  *ones = v & valid;
-  *zeros = ~v & valid;
-}
-// position of the k-th (0-based) set bit of the words' `zeros` (which = 0) or `ones` (which = 1); k below the total
-template <int WHICH>
-__attribute__((target("avx2,bmi2,popcnt"))) static inline uint32_t ef_select8(const EfRow &r, const EfPrefix8 &P, uint32_t k) {
-  const uint32_t *pre = WHICH ? P.o : P.z;
-  const __m256i v = _mm256_load_si256(reinterpret_cast<const __m256i *>(pre));
-  const uint32_t gt = (uint32_t)_mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(v, _mm256_set1_epi32((int)k)))); // prefix > k
-  const uint32_t wsel = (uint32_t)__builtin_popcount(~gt & 0xFFu); // words that end at or before the k-th bit: 0 .. 7 (the last prefix > k)
-  const uint32_t base = wsel ? pre[wsel - 1] : 0u;
-  uint64_t ones, zeros;
-  ef_word8(r, wsel, &ones, &zeros);
-  return wsel * 64u + (uint32_t)_tzcnt_u64(_pdep_u64(1ull << (k - base), WHICH ? ones : zeros));
-}
-__attribute__((target("avx2,bmi2,popcnt,sse4.1"))) inline int ef_bracket_l8(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
-                                                                           uint32_t *start, uint32_t *freq) {
-  // r.l == 8, 49 <= cnt, HB = cnt + 256 <= 512: the row is at least 39 + 49 bytes long, eight words of it may be read
-  EfPrefix8 P;
-  uint32_t az = 0, ao = 0;
-#pragma GCC unroll 8
-  for (uint32_t i = 0; i < 8; ++i) {
-    uint64_t ones, zeros;
-    ef_word8(r, i, &ones, &zeros);
-    az += (uint32_t)__builtin_popcountll(zeros);
-    ao += (uint32_t)__builtin_popcountll(ones);
-    P.z[i] = az;
-    P.o[i] = ao;
-  }
-  if (__builtin_expect(az != 256u || ao != (uint32_t)r.cnt, 0)) return -1; // not 256 buckets / cnt entries: malformed
-  const uint32_t h = cf >> 8, lcf = cf & 0xFFu;
-  const uint32_t z = ef_select8<0>(r, P, h);                      // the zero that closes bucket h
-  const uint32_t s = h ? ef_select8<0>(r, P, h - 1) + 1u : 0u;    // its first bit (cf < 256 is rare: a predictable branch)
-  const int32_t lo = (int32_t)s - (int32_t)h, run = (int32_t)(z - s); // entries before the bucket / in it (consistent by construction)
-  const uint8_t *lows = r.p + (r.LB >> 3);
-  int32_t c;
-  if (__builtin_expect(run <= 16, 1)) {
-    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(lows + lo));
-    const __m128i key = _mm_set1_epi8((char)lcf);
-    const uint32_t le = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(v, key), v));
-    c = __builtin_popcount(le & _bzhi_u32(0xFFFFu, (uint32_t)run));
-  } else { // a tail bucket of a flat row: rarely asked for
-    c = 0;
-    int32_t hi = run; // low(lo + c - 1) <= lcf < low(lo + hi)
-    while (c < hi) {
-      const int32_t mid = (c + hi) >> 1;
-      if (lows[lo + mid] <= lcf) c = mid + 1; else hi = mid;
-    }
-  }
-  const int32_t j = lo + c;
-  if (__builtin_expect((j < 1 && !zero_before) || j >= r.cnt, 0)) return 0;
-  const uint32_t e1 = ((ef_select8<1>(r, P, (uint32_t)j) - (uint32_t)j) << 8) | lows[j];
-  const uint32_t jp = j >= 1 ? (uint32_t)(j - 1) : 0u;
-  const uint32_t e0 = (((ef_select8<1>(r, P, jp) - jp) << 8) | lows[jp]) & (0u - (uint32_t)(j >= 1)); // j = 0: the implied zero edge
-  *jout = j;
-  *start = e0;
-  *freq = (e1 - e0) & 0xFFFFu;
-  return 1;
-}
-
-__attribute__((target("avx2,bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
+// (Rows of 49 .. 256 entries - 8 low bits, an unary part of up to eight words - were also given a straight-line search on the
+// popcount prefixes of those words, select0 / select1 by one vector compare + pdep each: correct, and SLOWER than the general
+// search below on the decode hosts' EPYC 9575F - 14.5 against 12.7 ns/symbol over a Kodak half at ef_min 49, 16.5 against 14.6
+// at 14: twice the instructions for the two mispredictions it saves.  Commit ee79904, profiles/r03_host_decoder_epyc9575f.txt.)
+__attribute__((target("bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow &r, uint32_t cf, bool zero_before, int32_t *jout,
                                                                    uint32_t *start, uint32_t *freq) {
   if (r.l == 12 && r.HB <= 64) return ef_bracket64(r, cf, zero_before, jout, start, freq);
-#ifndef FGMM_NO_EF_L8 // (A/B builds: scripts/host_bench.py)
-  if (r.l == 8 && r.HB <= 512) return ef_bracket_l8(r, cf, zero_before, jout, start, freq);
-#endif
   const uint32_t h = cf >> r.l, lcf = cf & ((1u << r.l) - 1u);
   const int32_t nbits = (int32_t)r.HB;
   int32_t p_prev = -1; // zero that closes bucket h-1

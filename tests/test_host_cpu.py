@@ -298,8 +298,7 @@ def test_host_decoder_elias_fano_rows_of_every_width(oracle, shape):
 
 
 def test_host_decoder_long_elias_fano_rows_mixture_shaped(oracle):
-    """rows of 49 .. 254 entries with 8 low bits (a 256-bucket unary part of up to eight words: the straight-line search on
-    popcount prefixes): CDFs of two-component mixtures - a wide component under a narrow heavy one, so that one symbol jumps
+    """rows of 49 .. 254 entries with 8 low bits (a 256-bucket unary part of up to eight words): CDFs of two-component mixtures - a wide component under a narrow heavy one, so that one symbol jumps
     over dozens of EMPTY buckets (its neighbours lie words away) while the tails crowd many entries into one bucket - searched
     with the cum_freq values of garbage streams and of real streams; every answer is the reference bisection's."""
     from math import erf
