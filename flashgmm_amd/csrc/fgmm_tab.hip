@@ -587,47 +587,58 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   };
 
   // ---- phase 5a: unary high parts of the Elias-Fano rows, FLATTENED over their entries: bit ((E_j >> l) + j) ---------
+  // Every lane takes a run of CONSECUTIVE entries (not every 64th): it stays inside one row for nearly all of them - the
+  // row's description is loaded once, not once per entry - and the bits of entries that fall into one bitmap word are
+  // gathered in a register and set with one LDS atomic (consecutive entries of a row are a few bits apart).
   {
     const uint32_t NE = EFT & 0xFFFFu;
-    const uint32_t Q = (((NE + 3) >> 2) + 63u) & ~63u;
-    const uint32_t t_end = std::min(NE, (uint32_t)(wave + 1) * Q);
-    uint32_t t = (uint32_t)wave * Q + (uint32_t)lane;
-    int l = 0;
-    uint32_t l_beg = 0, l_end = 0;
-    RowRef R;
-    if (t < t_end) { // largest l with entries-before(l) <= t
-      int lo = 0, hi = nl;
+    const uint32_t per = (NE + kBlock - 1u) / kBlock;
+    uint32_t t = (uint32_t)tid * per;
+    const uint32_t t_end = std::min(NE, t + per);
+    if (t < t_end) {
+      int lo = 0, hi = nl; // largest l with entries-before(l) <= t
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if ((S.efoff[mid] & 0xFFFFu) <= t) lo = mid; else hi = mid;
       }
-      l = lo;
+      int l = lo;
+      RowRef R;
       R.load(S, E16, l, d.ef_min);
-      l_beg = R.aux & 0xFFFFu;
-      l_end = S.efoff[l + 1] & 0xFFFFu;
-    }
-    for (; t < t_end; t += 64) {
-      if (t >= l_end) {
-        do {
-          ++l;
-          l_beg = l_end;
-          l_end = S.efoff[l + 1] & 0xFFFFu;
-        } while (t >= l_end);
-        R.load(S, E16, l, d.ef_min);
+      uint32_t l_beg = R.aux & 0xFFFFu, l_end = S.efoff[l + 1] & 0xFFFFu;
+      uint32_t acc_w = ~0u, acc = 0; // bitmap word the gathered bits belong to | the bits
+      for (; t < t_end; ++t) {
+        if (t >= l_end) {
+          do {
+            ++l;
+            l_beg = l_end;
+            l_end = S.efoff[l + 1] & 0xFFFFu;
+          } while (t >= l_end);
+          R.load(S, E16, l, d.ef_min);
+        }
+        const uint32_t k = t - l_beg, pos = (R.entry(k) >> R.efl) + k;
+        const uint32_t wi = (R.aux >> 16) + (pos >> 5);
+        if (wi != acc_w) {
+          if (acc) atomicOr(&S.bitmap[acc_w], acc);
+          acc_w = wi;
+          acc = 0;
+        }
+        acc |= 1u << (pos & 31u);
       }
-      const uint32_t k = t - l_beg, pos = (R.entry(k) >> R.efl) + k;
-      atomicOr(&S.bitmap[(R.aux >> 16) + (pos >> 5)], 1u << (pos & 31u));
+      if (acc) atomicOr(&S.bitmap[acc_w], acc);
     }
   }
   __syncthreads();
 
-  // ---- phase 5b: FLATTENED over the 4-byte words of the block's rows, coalesced stores; a word is two 16-bit units of one
-  // row, or - rows are 2-byte aligned - the last unit of a row and the first of the next --------------------------------
+  // ---- phase 5b: FLATTENED over the 4-byte words of the block's rows; a word is two 16-bit units of one row, or - rows
+  // are 2-byte aligned - the last unit of a row and the first of the next.  Every lane formats a run of CONSECUTIVE words
+  // (a wave used to take 64 consecutive words per step, every lane landing in another row at every step: a search of the
+  // row offsets and seven LDS reads of row description per word).  Now a lane meets one or two rows in all; its stores
+  // are strided across the wave (each touches the lines its neighbours touch a step later: the L2 merges them).
   {
     const uint32_t NW = B4 >> 2;
-    const uint32_t Q = (((NW + 3) >> 2) + 63u) & ~63u;
-    const uint32_t q_end = std::min(NW, (uint32_t)(wave + 1) * Q);
-    uint32_t q = (uint32_t)wave * Q + (uint32_t)lane;
+    const uint32_t per = (NW + kBlock - 1u) / kBlock;
+    uint32_t q = (uint32_t)tid * per;
+    const uint32_t q_end = std::min(NW, q + per);
     int l = 0;
     uint32_t r_beg = 0, r_end = 0;
     RowRef R;
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       }
       return v;
     };
-    for (; q < q_end; q += 64) {
+    for (; q < q_end; ++q) {
       uint32_t val = 0;
       if (4 * q < B) { // (else: the block's padding to 4 bytes... cannot be a whole word, kept for safety)
         if (4 * q >= r_end) {

@@ -32,7 +32,7 @@ ts = []
 for it in range(8):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
-    rc = L.fgmm_build_tab_hip(ctx, None, s.data_ptr(), m.data_ptr(), w.data_ptr(), n, s.stride(0), s.stride(1), 0, mb, 2,
+    rc = L.fgmm_build_tab_hip(ctx, None, s.data_ptr(), m.data_ptr(), w.data_ptr(), n, s.stride(0), s.stride(1), 0, mb, int(os.environ.get('TAB_AB_FLAGS', '2')),
                               hdr.data_ptr(), bo.data_ptr(), rows.data_ptr(), cap, used.data_ptr(), C.byref(tl))
     e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
