@@ -242,17 +242,17 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
     return out
 
 
-def pmc_traffic(workload: str, mode: str, f16: bool):
+def pmc_traffic(workload: str, mode: str, f16: bool, images: int):
     """roofline.traffic: HBM bytes per symtab launch from rocprofv3 PMC passes (scripts/collect_pmc.sh, committed under
     profiles/), gfx950-corrected as MI355X_MICROARCH.md prescribes.  PMC collection needs the profiler, so bench.py
-    reports the committed measurement of this same workload (with the file it came from), or null when there is none."""
-    if workload != "kodak24" or f16:
-        return None, None
+    reports the LATEST COMMITTED measurement of this same workload (same mode, parameter dtype and image count) with the
+    file it came from — a recorded value, not this run's — or null when there is none."""
     best = src = None
-    for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_symtab.json"))):
+    for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_symtab*.json"))):
         try:
             d = json.load(open(f))
-            if d.get("workload") == workload and d.get("mode") == mode:
+            same = d.get("workload") == workload and d.get("mode") == mode and d.get("param_dtype", "f32") == ("f16" if f16 else "f32")
+            if same and d.get("images_per_gpu", 24 if workload == "kodak24" else 1) == images:
                 best, src = d["symtab"]["hbm_bytes_corrected"], os.path.relpath(f, ROOT)
         except Exception:
             pass
@@ -354,7 +354,7 @@ def step_stats(step_s, before, after):
     """per-step wall times of a timed region + what the cgroup's CPU controller did to the process meanwhile"""
     ms = np.asarray(step_s) * 1e3
     out = {"min": round(float(ms.min()), 3), "median": round(float(np.median(ms)), 3), "p90": round(float(np.percentile(ms, 90)), 3),
-           "max": round(float(ms.max()), 3)}
+           "max": round(float(ms.max()), 3), "all": [round(float(v), 2) for v in ms]}
     if before and after:
         out["cpu_throttled"] = {"periods": after[0] - before[0], "nr_throttled": after[1] - before[1],
                                 "throttled_ms": round((after[2] - before[2]) / 1e3, 1)}
@@ -655,7 +655,7 @@ def main(argv=None):
         sym_ms = float(np.mean(k_sym))
         achieved = n_coded * bytes_per_symbol / (sym_ms * 1e-3) / 1e9
         tab_ms, n_edges, tbytes = float(np.mean(k_tab)), float(np.mean(edges)), float(np.mean(tab_bytes))
-        traffic, traffic_src = pmc_traffic(a.workload, a.mode, f16)
+        traffic, traffic_src = pmc_traffic(a.workload, a.mode, f16, a.images)
         tab_alg_bytes = n_coded * (12 * (2 if f16 else 4)) + tbytes  # parameters in, headers + block offsets + rows out
         slots = n_edges * TAB_SLOTS_PER_EDGE[a.mode]
         out = {
@@ -685,6 +685,7 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "kernel": "symtab_kernel (encode-side GMM-CDF)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": "recorded PMC measurement of this workload (file in traffic_source), not collected in this run",
                          "launch_ms": round(sym_ms, 4), "bytes_per_launch": n_coded * bytes_per_symbol,
                          "bytes_per_symbol": bytes_per_symbol},
             # the decode-side table kernel against BOTH of its rooflines: VALU issue and HBM

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FGMM_ABI_VERSION 2
+#define FGMM_ABI_VERSION 3
 
 typedef enum {
   FGMM_OK = 0,
