@@ -462,8 +462,6 @@ def main(argv=None):
         return dryrun(a, world, rank)
     if os.environ.get("FGMM_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 code path on a 1-GPU box (dev aid)
         local_rank = 0
-    if os.environ.get("FGMM_BENCH_BLIT_WG"):  # experiment (scripts/blit_wg_ab.sh): exported here, after `import torch`, before the first GPU call
-        os.environ["DEBUG_CLR_LIMIT_BLIT_WG"] = os.environ["FGMM_BENCH_BLIT_WG"]
     from flashgmm_amd import parallel as P
 
     # first of all (the PCI address comes from sysfs): every thread this process creates from here on — the HIP runtime's

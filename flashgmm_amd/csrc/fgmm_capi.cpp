@@ -162,11 +162,9 @@ struct fgmm_ctx {
   std::vector<hipEvent_t> sleep_events; // hipEventBlockingSync: waited for by the host workers (see ensure_events)
   hipStream_t copy_stream = nullptr; // bulk D2H of the decode tables (overlaps the table kernels of later launches)
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
-  hipStream_t lane_stream[2] = {nullptr, nullptr}; // tab_direct: the table kernels of a call alternate between two streams - a
-                                     // launch that stores across PCIe has a tail during which the bus idles unless the next one is already running
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, tab_direct = 0, host_stage_max_mb = 4096, tab_lanes = 2, tab_align = 64, copy_cus = 0, copy_blocks = 0, copy_prio = 0;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -207,61 +205,22 @@ struct fgmm_ctx {
     d_stage_cap = bytes;
     return FGMM_OK;
   }
-  // "tab_direct": the same area in PINNED HOST memory — the table kernels store headers, block offsets and rows straight
-  // across PCIe (coalesced 256-byte stores reach the copy engines' rate), no staging write + read in HBM, no blit kernels
-  // competing with the table kernels for the CUs, nothing to wait for once a launch is done
-  char *h_stage = nullptr;
-  size_t h_stage_cap = 0;
-  int ensure_hstage(size_t bytes) {
-    if (bytes <= h_stage_cap) return FGMM_OK;
-    if (h_stage) HIP_TRY(hipHostFree(h_stage));
-    h_stage = nullptr;
-    h_stage_cap = 0;
-    const size_t want = align_up(bytes + bytes / 8, 2 << 20);
-    HIP_TRY(hipHostMalloc((void **)&h_stage, want, hipHostMallocDefault));
-    h_stage_cap = want;
-    return FGMM_OK;
-  }
   size_t stage_budget() const { // bytes the staging area may take
     if (opt.stage_max_mb > 0) return (size_t)opt.stage_max_mb << 20;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)4 << 30;
     return std::max((free_b + d_stage_cap) / 4, (size_t)64 << 20);
   }
-  int64_t copy_stream_cus = 0, copy_stream_prio = 0; // what the copy stream was created with (options "copy_cus", "copy_prio")
   int ensure_streams() {
-    if (copy_stream && (copy_stream_cus != opt.copy_cus || copy_stream_prio != opt.copy_prio)) { // the option changed: a stream keeps the mask it was created with
-      HIP_TRY(hipStreamSynchronize(copy_stream));
-      HIP_TRY(hipStreamDestroy(copy_stream));
-      copy_stream = nullptr;
-    }
-    if (!copy_stream && opt.copy_cus > 0) {
-      // the table copies are shader copies on this runtime (see below): confine them to `copy_cus` CUs spread evenly over the
-      // chip, so that the table kernels of the later launches keep the others to themselves
-      hipDeviceProp_t prop;
-      HIP_TRY(hipGetDeviceProperties(&prop, device));
-      const int n_cu = std::max(prop.multiProcessorCount, 1), want = (int)std::min<int64_t>(opt.copy_cus, n_cu);
-      std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
-      for (int k = 0; k < want; ++k) {
-        const int cu = (int)((int64_t)k * n_cu / want);
-        mask[(size_t)cu / 32] |= 1u << (cu % 32);
-      }
-      HIP_TRY(hipExtStreamCreateWithCUMask(&copy_stream, (uint32_t)mask.size(), mask.data()));
-      copy_stream_cus = opt.copy_cus;
-    }
     if (!copy_stream) {
-      copy_stream_cus = 0;
       // the table copies are shader copies on this runtime: they share the CUs with the table kernels of the later launches,
       // and PCIe - the longest leg of a decode call - must not wait for a CU: highest priority (10.05 against 10.17 ms per
       // step at the default priority and 10.6 at the lowest, four runs each)
       int lo = 0, hi = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      HIP_TRY(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, opt.copy_prio == 0 ? hi : (opt.copy_prio == 2 ? lo : (lo + hi) / 2)));
-      copy_stream_prio = opt.copy_prio;
+      HIP_TRY(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, hi));
     }
     if (!aux_stream) HIP_TRY(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
-    for (auto &ls : lane_stream) // only with "tab_direct": streams share a few hardware queues, an idle one still takes its place
-      if (!ls && opt.tab_direct && opt.tab_lanes > 1) HIP_TRY(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
     return FGMM_OK;
   }
   std::vector<int32_t> h_sym; // decode: int32 symbols of every bitstream of a call (grown, kept)
@@ -270,11 +229,10 @@ struct fgmm_ctx {
     if (d_ws) (void)hipFree(d_ws);
     if (h_ws) (void)hipHostFree(h_ws);
     if (d_stage) (void)hipFree(d_stage);
-    if (h_stage) (void)hipHostFree(h_stage);
     for (auto &c : chunks) (void)hipHostFree(c.p);
     chunks.clear();
-    d_ws = h_ws = d_stage = h_stage = nullptr;
-    d_cap = h_cap = d_stage_cap = h_stage_cap = 0;
+    d_ws = h_ws = d_stage = nullptr;
+    d_cap = h_cap = d_stage_cap = 0;
   }
   bool profiling = false;
   unsigned long long stat[4] = {0, 0, 0, 0}; // last batched call: [0] encode table bytes D2H, [1] decode table bytes D2H,
@@ -688,9 +646,6 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   if ((rc = ctx->ensure_streams())) return rc;
   const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 32768) & ~31;
   const bool clamped = items[0].clamp != 0, f16 = items[0].prm.dtype == FGMM_F16;
-  const bool direct = ctx->opt.tab_direct != 0; // the table kernels store straight into pinned host memory
-  int blk_align = 4; // a power of two
-  while (direct && blk_align * 2 <= (int)ctx->opt.tab_align) blk_align *= 2;
   // Elias-Fano rows (long rows: ef_min) are 18 % fewer bytes than uint16 rows and 40 % more nanoseconds to search (57.6 B and
   // 12 ns per latent against 70 B and 8.7 ns on the Kodak workload): with P = min(workers, bitstreams) decoders at work a
   // latent costs max(bytes / 55.7 GB/s, ns / P) - Elias-Fano rows pay when 12 / P < 70 B / 55.7 GB/s = 1.26 ns, P >= 10.
@@ -729,8 +684,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     std::vector<Part> parts;
     size_t fixed = 0, rows_cap = 0; // bytes: headers + block offsets | provisioned rows
     size_t o_stage = 0;             // where the unit's range starts in the staging area
-    char *d_range = nullptr;        // what the kernel writes: [fixed | rows] - device memory, or (direct) pinned host memory
-    bool in_host = false;           // d_range is pinned host memory: nothing to copy
+    char *d_range = nullptr;        // device: [fixed | rows]
   };
   std::vector<Unit> units;
   // Every item crosses in `np` pieces (block ranges), PIECE-MAJOR: piece 0 of every item, then piece 1 ...  The host
@@ -779,7 +733,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       p.o_blkoff = off;
       off += align_up(sizeof(uint32_t) * (size_t)(p.blk_end - p.blk_begin), 256);
       // worst case of a row: every edge of the window kept as a uint16, plus the 2-byte form's escape header
-      u.rows_cap += (size_t)lat * (2 * (size_t)(2 * (int64_t)it.max_bs + 2) + 4) + (size_t)(blk_align - 2) * (size_t)(p.blk_end - p.blk_begin);
+      u.rows_cap += (size_t)lat * (2 * (size_t)(2 * (int64_t)it.max_bs + 2) + 4) + 2 * (size_t)(p.blk_end - p.blk_begin);
     }
     u.fixed = off;
     u.rows_cap = align_up(u.rows_cap, 256);
@@ -791,8 +745,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   {
     size_t fixed_total = 0;
     for (auto &u : units) fixed_total += u.fixed + 512;
-    const size_t budget = direct ? std::max((size_t)ctx->opt.host_stage_max_mb << 20, (size_t)1 << 20)
-                          : fixed_total + rows_worst_total + 256 * (size_t)n_units <= ctx->d_stage_cap && ctx->opt.stage_max_mb <= 0
+    const size_t budget = fixed_total + rows_worst_total + 256 * (size_t)n_units <= ctx->d_stage_cap && ctx->opt.stage_max_mb <= 0
                               ? ctx->d_stage_cap : ctx->stage_budget(); // the device is asked only when the area has to grow
     if (fixed_total + rows_worst_total + 256 * (size_t)n_units > budget && rows_worst_total) {
       const double f = budget > fixed_total ? (double)(budget - fixed_total) / (double)rows_worst_total : 0.0;
@@ -808,8 +761,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   const size_t upload_bytes = o_counters;
   // events: per unit [kernel done][counters landed] (this thread waits, briefly) and [tables landed] (the workers wait)
   if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off)) ||
-      (rc = ctx->ensure_events(2 * (size_t)std::max(n_units, 1), (size_t)n_units + 2)) ||
-      (rc = direct ? ctx->ensure_hstage(stage_total) : ctx->ensure_stage(stage_total)))
+      (rc = ctx->ensure_events(2 * (size_t)std::max(n_units, 1), (size_t)n_units + 2)) || (rc = ctx->ensure_stage(stage_total)))
     return rc;
   ctx->chunks_reset();
   hipEvent_t *ev_kernel = ctx->events.data(), *ev_counters = ev_kernel + n_units, *ev_landed = ctx->sleep_events.data();
@@ -847,7 +799,6 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.ef_min = ef_min;
     d.tl = it.tl;
     d.count_edges = ctx->profiling ? 1 : 0; // measurement aid only (bench.py's roofline_decode)
-    d.blk_align = blk_align;
     return d;
   };
   DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws + o_descs);
@@ -870,14 +821,12 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   };
   for (int u = 0; u < n_units; ++u) {
     unit_desc0[(size_t)u + 1] = unit_desc0[(size_t)u] + units[(size_t)u].parts.size();
-    units[(size_t)u].d_range = (direct ? ctx->h_stage : ctx->d_stage) + units[(size_t)u].o_stage;
-    units[(size_t)u].in_host = direct;
+    units[(size_t)u].d_range = ctx->d_stage + units[(size_t)u].o_stage;
     fill_unit_descs(u);
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + o_counters, 0, kCounterBytes * (size_t)std::max(n_units, 1), stream));
-  const int n_lanes = direct && n_units > 1 && ctx->opt.tab_lanes > 1 ? 2 : 1;
-  auto launch_unit = [&](int u, hipStream_t stream) -> int {
+  auto launch_unit = [&](int u) -> int {
     const Unit &un = units[(size_t)u];
     int64_t blocks_max = 0;
     int tl_max = 16;
@@ -890,15 +839,9 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   };
   unsigned long long *h_counters = reinterpret_cast<unsigned long long *>(ctx->h_ws + o_counters);
   if ((rc = ctx->prof_begin(1, stream))) return rc;
-  if (n_lanes > 1) { // the lanes start after the upload (and after whatever the caller's stream carries before it)
-    HIP_TRY(hipEventRecord(ctx->sleep_events[(size_t)n_units + 1], stream));
-    for (auto ls : ctx->lane_stream) HIP_TRY(hipStreamWaitEvent(ls, ctx->sleep_events[(size_t)n_units + 1], 0));
-  }
   for (int u = 0; u < n_units; ++u) {
-    hipStream_t su = n_lanes > 1 ? ctx->lane_stream[u & 1] : stream;
-    if ((rc = launch_unit(u, su))) return rc;
-    HIP_TRY(hipEventRecord(ev_kernel[u], su));
-    if (n_lanes > 1 && u + 2 >= n_units) HIP_TRY(hipStreamWaitEvent(stream, ev_kernel[u], 0)); // the caller's stream joins the lanes
+    if ((rc = launch_unit(u))) return rc;
+    HIP_TRY(hipEventRecord(ev_kernel[u], stream));
     HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_kernel[u], 0));
     HIP_TRY(hipMemcpyAsync(h_counters + 4 * (size_t)u, ctx->d_ws + o_counters + kCounterBytes * (size_t)u, kCounterBytes, hipMemcpyDeviceToHost,
                            ctx->aux_stream));
@@ -943,7 +886,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       if (it.status == FGMM_OK) it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
     }
     const double tw0 = tr.level > 1 ? tr.ms() : 0;
-    if (it.status == FGMM_OK && it.piece_ev[p] && hipEventSynchronize(it.piece_ev[p]) != hipSuccess) it.status = FGMM_ERR_HIP;
+    if (it.status == FGMM_OK && hipEventSynchronize(it.piece_ev[p]) != hipSuccess) it.status = FGMM_ERR_HIP;
     const double tw1 = tr.level > 1 ? tr.ms() : 0;
     it.t_waited += tw1 - tw0;
     it.t_lastland = tw1;
@@ -1095,13 +1038,12 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       char *d_new = nullptr;
       if ((rc = temp.alloc(un.fixed + need + 256, &d_new))) return rc;
       un.d_range = d_new;
-      un.in_host = false;
       un.rows_cap = need;
       fill_unit_descs(u);
       HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs + sizeof(DecDesc) * unit_desc0[(size_t)u], hd + unit_desc0[(size_t)u],
                              sizeof(DecDesc) * un.parts.size(), hipMemcpyHostToDevice, stream));
       HIP_TRY(hipMemsetAsync(ctx->d_ws + o_counters + kCounterBytes * (size_t)u, 0, kCounterBytes, stream));
-      if ((rc = launch_unit(u, stream))) return rc;
+      if ((rc = launch_unit(u))) return rc;
       HIP_TRY(hipEventRecord(ev_kernel[u], stream));
       HIP_TRY(hipMemcpyAsync(cn, ctx->d_ws + o_counters + kCounterBytes * (size_t)u, kCounterBytes, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
@@ -1110,22 +1052,11 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     const size_t used = (size_t)cn[0];
     edges += cn[2];
     char *h_range = nullptr;
-    hipEvent_t landed = nullptr; // null: nothing to wait for
-    if (un.in_host) {
-      // the launch is over (its counters came after it): headers, block offsets and rows ARE in host memory
-      h_range = un.d_range;
-      memset(h_range + un.fixed + used, 0, 256); // slack: the host's SIMD search reads a little past a row
-    } else {
-      if ((rc = ctx->chunk_alloc(un.fixed + used + 256, &h_range))) return rc;
-      memset(h_range + un.fixed + used, 0, 256);
-      HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_kernel[u], 0));
-      if (un.fixed + used) {
-        if (ctx->opt.copy_blocks > 0) LAUNCH_TRY(launch_table_copy(un.d_range, h_range, un.fixed + used, (int)ctx->opt.copy_blocks, ctx->copy_stream));
-        else HIP_TRY(hipMemcpyAsync(h_range, un.d_range, un.fixed + used, hipMemcpyDeviceToHost, ctx->copy_stream));
-      }
-      HIP_TRY(hipEventRecord(ev_landed[u], ctx->copy_stream));
-      landed = ev_landed[u];
-    }
+    if ((rc = ctx->chunk_alloc(un.fixed + used + 256, &h_range))) return rc;
+    memset(h_range + un.fixed + used, 0, 256); // slack: the host's SIMD search reads a little past a row
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_kernel[u], 0));
+    if (un.fixed + used) HIP_TRY(hipMemcpyAsync(h_range, un.d_range, un.fixed + used, hipMemcpyDeviceToHost, ctx->copy_stream));
+    HIP_TRY(hipEventRecord(ev_landed[u], ctx->copy_stream));
     for (auto &p : un.parts) {
       DecItem &it = items[p.item];
       TabPiece &pc = it.piece[p.piece];
@@ -1134,7 +1065,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       pc.rows = reinterpret_cast<const uint8_t *>(h_range + un.fixed);
       pc.rows_len = used + 256;
       pc.end = std::min<int64_t>(p.blk_end * it.tl, it.n);
-      it.piece_ev[p.piece] = landed;
+      it.piece_ev[p.piece] = ev_landed[u];
       const int64_t lat = pc.end - std::min<int64_t>(p.blk_begin * it.tl, it.n);
       it.table_bytes += (uint64_t)it.hdr_form * (uint64_t)lat + sizeof(uint32_t) * (uint64_t)(p.blk_end - p.blk_begin);
       mark_queued(p.item, p.piece + 1); // pieces reach an item in order: rounds are piece-major
@@ -1273,13 +1204,6 @@ const OptName kOpts[] = {
     {"ef_min", &fgmm_ctx::Opts::ef_min, kTabEfMin, 1 << 20, "FGMM_EF_MIN_ROWS"},
     {"dec_pair", &fgmm_ctx::Opts::dec_pair, 0, 2, "FGMM_DEC_PAIR"},
     {"enc_ways", &fgmm_ctx::Opts::enc_ways, 0, kMaxEncWays, "FGMM_ENC_WAYS"},
-    {"tab_direct", &fgmm_ctx::Opts::tab_direct, 0, 1, "FGMM_TAB_DIRECT"},
-    {"tab_lanes", &fgmm_ctx::Opts::tab_lanes, 1, 2, "FGMM_TAB_LANES"},
-    {"tab_align", &fgmm_ctx::Opts::tab_align, 4, 4096, "FGMM_TAB_ALIGN"},
-    {"copy_cus", &fgmm_ctx::Opts::copy_cus, 0, 1024, "FGMM_COPY_CUS"},
-    {"copy_blocks", &fgmm_ctx::Opts::copy_blocks, 0, 4096, "FGMM_COPY_BLOCKS"},
-    {"copy_prio", &fgmm_ctx::Opts::copy_prio, 0, 2, "FGMM_COPY_PRIO"},
-    {"host_stage_max_mb", &fgmm_ctx::Opts::host_stage_max_mb, 1, 1 << 20, "FGMM_HOST_STAGE_MAX_MB"},
 };
 } // namespace
 
@@ -1405,8 +1329,6 @@ void fgmm_ctx_destroy(fgmm_ctx *ctx) {
     ctx->trim();
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-    for (auto ls : ctx->lane_stream)
-      if (ls) (void)hipStreamDestroy(ls);
   }
   delete ctx;
 }

@@ -59,9 +59,7 @@ struct DecDesc {
   unsigned long long *counters;  // shared by the launch: [0] cursor = bytes of rows placed, [1] overflow (a block did not fit),
                                  // [2] edges evaluated (only when count_edges: one more same-address atomic per block),
                                  // [3] blocks with a non-monotone row
-  int32_t count_edges;
-  int32_t blk_align;             // bytes a block's rows are aligned to (a power of two >= 4; 0 = 4).  64 when the rows go straight
-                                 // to pinned host memory: a wave's 256-byte store then covers four whole 64-byte lines of the bus
+  int32_t count_edges, pad2_;
   // ---- generic two-pass path (cdftab_count / scan / fill): any half-width, rows sequential in latent order
   void *hdr;                     // [n] headers, 4-byte form (8-byte form when hdr_form == 8)
   int32_t tiles;                 // blocks per channel = ceil(hw / 256)
@@ -156,8 +154,6 @@ int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y
 // checkerboard split (embed = false: [planes,h,w] -> [2,planes,h,w/2]) / merge (embed = true); w even, elem_bytes 2 or 4
 int launch_ckbd(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes, int anchor_odd, bool embed,
                 void *stream);
-// device -> pinned host copy by a shader copy of OUR OWN on `blocks` workgroups (both pointers 16-byte aligned)
-int launch_table_copy(const void *src_dev, void *dst_host, size_t bytes, int blocks, void *stream);
 int launch_fastmath_selftest(int which, unsigned long long n, unsigned long long seed, unsigned long long *n_bad, void *stream);
 // exhaustive check of the saturation lemmas behind the pruning; *n_bad (device) receives the number of violations
 int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream);

@@ -550,41 +550,6 @@ static void launch_ckbd_t(const void *src, void *dst, int64_t rows, int64_t h, i
   if (embed) hipLaunchKernelGGL((ckbd_kernel<T, true, V>), grid, dim3(kBlock), 0, s, (const T *)src, (T *)dst, rows, h, w2, anchor_odd);
   else hipLaunchKernelGGL((ckbd_kernel<T, false, V>), grid, dim3(kBlock), 0, s, (const T *)src, (T *)dst, rows, h, w2, anchor_odd);
 }
-// ---------------------------------------------------------------------------------------------------------
-// table copy, device staging -> pinned host memory, on a FEW workgroups.  hipMemcpyAsync moves device -> pinned memory
-// with a shader copy on this runtime (__amd_rocclr_copyBuffer) that spreads over the whole chip: 42.8 % of the GPU time of
-// a bench step, and the table kernels of the later launches lose a third of their speed to it.  PCIe needs 56 GB/s, not
-// 8 TB/s: `blocks` workgroups with four 16-byte loads in flight per lane saturate the bus and leave the other CUs alone.
-// Both pointers 16-byte aligned (the staging ranges are 256-byte aligned); the tail of < 16 bytes goes byte by byte.
-// ---------------------------------------------------------------------------------------------------------
-typedef uint32_t copy_u4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(kBlock) void table_copy_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t bytes) {
-  const size_t n16 = bytes / 16;
-  const FGMM_GLOBAL copy_u4 *s = (const FGMM_GLOBAL copy_u4 *)src;
-  FGMM_GLOBAL copy_u4 *d = (FGMM_GLOBAL copy_u4 *)dst;
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {
-    const copy_u4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + stride),
-                  c = __builtin_nontemporal_load(s + i + 2 * stride), e = __builtin_nontemporal_load(s + i + 3 * stride);
-    d[i] = a;
-    d[i + stride] = b;
-    d[i + 2 * stride] = c;
-    d[i + 3 * stride] = e;
-  }
-  for (; i < n16; i += stride) d[i] = __builtin_nontemporal_load(s + i);
-  if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) dst[n16 * 16 + threadIdx.x] = src[n16 * 16 + threadIdx.x];
-}
-int launch_table_copy(const void *src_dev, void *dst_host, size_t bytes, int blocks, void *stream) {
-  if (!bytes) return 0;
-  if ((reinterpret_cast<uintptr_t>(src_dev) | reinterpret_cast<uintptr_t>(dst_host)) & 15) return (int)hipErrorInvalidValue;
-  const size_t per_pass = (size_t)kBlock * 16 * 4; // bytes one workgroup moves per iteration
-  const int grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(blocks, 1), (bytes + per_pass - 1) / per_pass));
-  hipLaunchKernelGGL(table_copy_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, (const uint8_t *)src_dev,
-                     (uint8_t *)dst_host, bytes);
-  return launch_err();
-}
-
 int launch_ckbd(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes, int anchor_odd, bool embed,
                 void *stream) {
   const int64_t rows = planes * h, w2 = w / 2;

@@ -525,9 +525,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   // ---- phase 4: place the block's rows; Elias-Fano rows: entries and upper words before each ------------------------
   uint32_t B, EFT;
   const uint32_t exB = tab_scan(bytes, S.scratch, &B);
-  const uint32_t B4 = (B + 3u) & ~3u; // blocks start 4-byte aligned (blk_off counts 4-byte units) ...
-  const uint32_t al = d.blk_align > 4 ? (uint32_t)d.blk_align : 4u;
-  const uint32_t BA = (B + al - 1u) & ~(al - 1u); // ... or on the launch's alignment: what the block takes of the row area
+  const uint32_t B4 = (B + 3u) & ~3u; // blocks start 4-byte aligned (blk_off counts 4-byte units)
   uint32_t ef_pack = 0;
   if (tid < nl) {
     const uint32_t cnt = S.meta[tid] >> 16, nm = (S.flags[tid] >> 1) & 1u;
@@ -541,8 +539,8 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   if (tid == 0) {
     S.rowoff[nl] = B;
     S.efoff[nl] = EFT;
-    const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)BA);
-    const bool fits = base + BA <= d.rows_cap;
+    const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)B4);
+    const bool fits = base + B4 <= d.rows_cap;
     if (!fits) atomicMax(&d.counters[1], 1ull);
     if (d.count_edges) atomicAdd(&d.counters[2], 2ull * NP);
     d.blkoff_out[b - d.blk_begin] = (uint32_t)(base >> 2);

@@ -108,13 +108,6 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor).
  *                       14 gives the fewest bytes (55.7 B/latent on Kodak-like tables against 57.6) but costs the host
  *                       decoders more than the PCIe time it saves when 16 threads serve one GPU
- *   "tab_direct"  [1]   decode: the table kernels store headers, block offsets and rows STRAIGHT INTO PINNED HOST MEMORY
- *                       (coalesced stores across PCIe) instead of a device staging area that a copy then fetches: no staging
- *                       write + read in HBM, no copy kernels sharing the CUs with the table kernels, and a launch's tables
- *                       are on the host when the launch is over.  0 = staging area + one copy per launch (round 2's path)
- *   "host_stage_max_mb" [4096] decode, tab_direct: cap of that pinned area in MiB.  It is provisioned for the worst case of a
- *                       call (every edge of every window as a uint16) when the cap allows, else every launch's row area
- *                       shrinks by the same factor; a launch whose rows do not fit is re-run with the exact size
  *   "trace"       [0]   1: phase timestamps of every batched call on stderr, 2: + per-bitstream job timeline */
 int fgmm_ctx_set_option(fgmm_ctx *ctx, const char *name, int64_t value);
 int fgmm_ctx_get_option(fgmm_ctx *ctx, const char *name, int64_t *value_out);

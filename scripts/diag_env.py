@@ -1,6 +1,6 @@
 """Dev aid (GPU box): what the process may use and where its memory lands — CPU affinity, cgroup quota + throttling counters,
 NUMA node of the GPU, and (after a few steps of the Kodak batch) on which NUMA nodes the big mappings of this process live.
-python scripts/diag_env.py [--no-bind] [--threads N] [--steps K]"""
+python scripts/diag_env.py [--bind all|thread|none|other|early] [--threads N] [--steps K]"""
 import argparse, os, re, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
