@@ -175,9 +175,9 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
     process may use, one stream at a time per process (the reference is single-threaded and holds the GIL), then its
     USE_SIMD=0 path on a smaller sample."""
     kind, prepare, code = _cpu_coder()
-    # a bounded sample of the same workload: whole images, about 12 M symbols (all 24 Kodak images; one 4K image)
+    # a bounded sample of the same workload: whole images, up to about 8 M latents (all 24 Kodak images; one 4K image)
     n_sample, n_sym_acc = 0, 0
-    while n_sample < len(host) // streams_per_image and (n_sample == 0 or n_sym_acc < 6_000_000):
+    while n_sample < len(host) // streams_per_image and (n_sample == 0 or n_sym_acc < 7_000_000):
         n_sym_acc += sum(int(np.prod(st[0].shape)) for st in host[n_sample * streams_per_image:(n_sample + 1) * streams_per_image])
         n_sample += 1
     host = host[: n_sample * streams_per_image]

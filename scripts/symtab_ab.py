@@ -14,10 +14,13 @@ from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
 dev = torch.device("cuda:0")
 _lib.set_profiling(0, True)
 res_txt = []
+ELIC = [(g, 136, 120) for g in (16, 16, 32, 64, 192) for _ in range(2)]  # the ten bitstreams of one 4K image
 for name, n_items, shape, f16, mode in (("kodak f32 polya", 48, (192, 32, 24), False, "polya"), ("kodak f32 as", 48, (192, 32, 24), False, "as"),
-                                         ("kodak f32 logistic", 48, (192, 32, 24), False, "logistic"), ("elic f16 polya", 4, (192, 136, 120), True, "polya")):
+                                         ("kodak f32 logistic", 48, (192, 32, 24), False, "logistic"), ("elic f16 polya", 4, (192, 136, 120), True, "polya"),
+                                         ("elic 2 images f16", 20, None, True, "polya")):
     devt = []
     for i in range(n_items):
+        shape = ELIC[i % 10] if name.startswith("elic 2") else shape
         y, sg, mu, pi = T.make_latent(i, M=shape[0], h=shape[1], w=shape[2])
         if f16:
             sg, mu, pi = T.to_float16_planes(sg, mu, pi)
@@ -28,7 +31,7 @@ for name, n_items, shape, f16, mode in (("kodak f32 polya", 48, (192, 32, 24), F
     for it in range(10):
         res = gmc.compress_batch(ys, ss, ms, ws)
         sym.append(_lib.kernel_ms(0, 0))
-    n = sum(int(r[0][2].sum()) * shape[1] * shape[2] for r in res)
+    n = sum(int(r[0][2].sum()) * t[0].shape[2] * t[0].shape[3] for r, t in zip(res, devt))
     s = float(np.median(sym[3:]))
     bps = 32 if f16 else 56
     res_txt.append(f"{name}: {s*1e3:6.1f} us {n/s/1e6:6.1f} Gsym/s {n*bps/s/1e6/8000:.3f}")
