@@ -635,6 +635,29 @@ def main(argv=None):
             extras["latency_ms"] = {"images": 1, "streams": spi,
                                     "as_codec": round(float(np.median([one_image(True) for _ in range(reps)])), 3),
                                     "all_at_once": round(float(np.median([one_image(False) for _ in range(reps)])), 3)}
+            # the same image with CHECKPOINTED streams (GaussianMixtureConditional(checkpoint_stride=...): the reference's
+            # bitstreams + out-of-band notes of the coder state every 4096 symbols, 16 bytes each): one bitstream decodes on
+            # all host workers instead of one.  Not the reference's interface alone - its decoder has no such notes.
+            gmc_plain, gmc_ck = gmc, GaussianMixtureConditional(K=4, mode=a.mode, checkpoint_stride=4096)
+            gmc = gmc_ck
+            r_ck = gmc_ck.compress_batch(ys[:spi], *[t[:spi] for t in (ss, ms, ws)])
+            assert all(bytes(x[0][0]) == bytes(y_[0][0]) for x, y_ in zip(r_ck, last["res"][:spi])), "checkpointed streams differ"
+            for codec in (True, False):
+                one_image(codec)
+            extras["latency_ms"]["as_codec_checkpointed"] = round(float(np.median([one_image(True) for _ in range(reps)])), 3)
+            extras["latency_ms"]["all_at_once_checkpointed"] = round(float(np.median([one_image(False) for _ in range(reps)])), 3)
+            extras["latency_ms"]["checkpoint_bytes"] = int(sum(16 * len(x[0][0].ckpt) for x in r_ck))
+            # ... and the whole step on checkpointed streams (they matter when a call has fewer bitstreams than host workers:
+            # ELIC's stages; the Kodak batch has a bitstream per worker and ignores them)
+            step(a.schedule)
+            n_ck = max(3, min(a.steps, 10))
+            gc.disable()
+            dt_ck, step_ms_ck = timed(a.schedule, n_ck, record=False)
+            gc.enable()
+            extras["checkpointed"] = {"schedule": a.schedule, "value": round(a.images * pix_per_image * n_ck / dt_ck / 1e6, 2), "unit": "Mpixels/s",
+                                      "ms_per_step": round(dt_ck / n_ck * 1e3, 3), "steps": n_ck, "step_ms": step_ms_ck, "checkpoint_stride": 4096,
+                                      "note": "same bitstreams + out-of-band checkpoints (16 B per 4096 symbols): a bitstream decodes on all host workers"}
+            gmc = gmc_plain
             # one host thread instead of the pool: what the GPU path is worth per host core
             threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
             _lib.set_threads(local_rank, 1)

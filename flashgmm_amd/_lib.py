@@ -39,10 +39,15 @@ class fgmm_tab_ref(C.Structure):
                 ("flags", C.c_int32), ("out_symbols", C.c_void_p)]
 
 
+class fgmm_ckpt(C.Structure):
+    _fields_ = [("x", C.c_uint64), ("pos", C.c_uint64)]
+
+
 class fgmm_item(C.Structure):
     _fields_ = [("y", C.c_void_p), ("params", fgmm_params), ("M", C.c_int32), ("K", C.c_int32), ("hw", C.c_int64),
                 ("yq_out", C.c_void_p), ("zero_bitmap", C.c_void_p), ("abs_max", C.c_int32),
-                ("bytes", C.c_void_p), ("bytes_len", C.c_size_t), ("status", C.c_int32)]
+                ("bytes", C.c_void_p), ("bytes_len", C.c_size_t), ("status", C.c_int32), ("ckpt_stride", C.c_int32),
+                ("ckpt", C.c_void_p), ("n_ckpt", C.c_int64)]
 
 
 def _item_dtype():
@@ -93,6 +98,9 @@ SIGNATURES = {
     "fgmm_selftest_saturation": (_i, [_p, _i, C.POINTER(C.c_uint64)]),
     "fgmm_selftest_fastmath": (_i, [_p, _i, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "fgmm_rans_encode_symtab": (_i, [_p, _p, _i64, _pp, _psz]),
+    "fgmm_ckpt_count": (_i64, [_i64, _i64]),
+    "fgmm_rans_encode_symtab_ckpt": (_i, [_p, _p, _i64, _i64, _pp, _psz, _p]),
+    "fgmm_rans_decode_tab_ckpt": (_i, [_p, _sz, _p, _i, _p, _i32, _p, C.c_uint64, _i64, _i32, _i, _p, _i64, _i64, _p, C.POINTER(_i32)]),
     "fgmm_rans_encode_symtab2": (_i, [_p, _p, _i64, _p, _p, _i64, _pp, _psz, _pp, _psz]),
     "fgmm_rans_encode_symtab_n": (_i, [_i, _p, _p, _p, _p, _p]),
     "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, C.c_uint64, _i64, _i32, _i, _p]),

@@ -13,6 +13,9 @@ ranks (``flashgmm_amd.parallel.gather_containers``):
              kind 0 (plain strings, e.g. the hyper-latent's ``[z_bytes]``): u32 n | (u32 len | bytes)*
              kind 1 (GMM stream ``(bytes, abs_max, zero_bitmap)``): u32 abs_max | u16 M | ceil(M/8) bitmap bytes
                     (channel c = bit c%8 of byte c//8) | u32 len | bytes
+             kind 2 (the same with the stream's out-of-band checkpoints, ``flashgmm_amd.CheckpointedBytes``): as kind 1, then
+                    u32 stride | u32 n | (u64 state | u64 position)*  — ``unpack`` gives a ``CheckpointedBytes`` back, which
+                    ``GaussianMixtureConditional.decompress`` decodes on all host workers; 16 bytes per `stride` symbols
     shape  = a tagged tree: u8 tag; 0 int (i32) | 1 list (u16 n, items) | 2 tuple (u16 n, items) |
              3 dict (u16 n, (u16 klen | utf-8 key | value)*) | 4 None
 
@@ -62,7 +65,11 @@ def pack(strings: Sequence[Any], shape: Any = None) -> bytes:
         if isinstance(s, tuple) and len(s) == 3 and isinstance(s[0], (bytes, bytearray)):
             data, abs_max, zb = s
             m, bits = _bitmap_to_bytes(zb)
-            out.append(struct.pack(">BIH", 1, int(abs_max), m) + bits + struct.pack(">I", len(data)) + bytes(data))
+            ck = getattr(data, "ckpt", None)
+            kind = 2 if ck is not None and len(ck) else 1
+            out.append(struct.pack(">BIH", kind, int(abs_max), m) + bits + struct.pack(">I", len(data)) + bytes(data))
+            if kind == 2:
+                out.append(struct.pack(">II", int(data.ckpt_stride), len(ck)) + np.ascontiguousarray(ck).astype([("x", ">u8"), ("pos", ">u8")]).tobytes())
         elif isinstance(s, (list, tuple)) and all(isinstance(b, (bytes, bytearray)) for b in s):
             out.append(struct.pack(">BI", 0, len(s)))
             for b in s:
@@ -121,12 +128,19 @@ def unpack(buf: bytes, device=None):
     strings: List[Any] = []
     for _ in range(n):
         (kind,) = r.unpack(">B")
-        if kind == 1:
+        if kind in (1, 2):
             abs_max, m = r.unpack(">IH")
             bits = np.frombuffer(r.take((m + 7) // 8), np.uint8)
             zb = torch.from_numpy(np.unpackbits(bits, bitorder="little")[:m].astype(np.int64))
             (ln,) = r.unpack(">I")
-            strings.append((r.take(ln), int(abs_max), zb.to(device) if device is not None else zb))
+            data = r.take(ln)
+            if kind == 2:
+                from .entropy_models import CKPT_DTYPE, CheckpointedBytes
+
+                stride, n_ck = r.unpack(">II")
+                ck = np.frombuffer(r.take(16 * n_ck), dtype=[("x", ">u8"), ("pos", ">u8")]).astype(CKPT_DTYPE)
+                data = CheckpointedBytes(data, ck, stride)
+            strings.append((data, int(abs_max), zb.to(device) if device is not None else zb))
         elif kind == 0:
             (k,) = r.unpack(">I")
             strings.append([r.take(r.unpack(">I")[0]) for _ in range(k)])

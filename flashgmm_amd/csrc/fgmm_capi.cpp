@@ -164,7 +164,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -332,7 +332,10 @@ struct EncItem {
   int clamp = 0;
   float *yq = nullptr; // device out
   fgmm_symbuf *symbuf = nullptr; // raw boundary, buffered form: append the symbols instead of flushing a stream
+  int64_t ckpt_stride = 0;       // note a checkpoint every this many symbols (fgmm_ckpt; 0: none)
   // outputs
+  fgmm_ckpt *ckpt = nullptr;     // malloc'ed, n_ckpt entries
+  int64_t n_ckpt = 0;
   int64_t *zero_bitmap = nullptr; // host [M] or null
   int32_t abs_max = 0;
   uint8_t *bytes = nullptr;
@@ -528,6 +531,9 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
       int64_t n[kMaxEncWays], nb[kMaxEncWays];
       uint8_t **out[kMaxEncWays];
       size_t *len[kMaxEncWays];
+      fgmm_ckpt *ck[kMaxEncWays];
+      const int64_t stride = first->ckpt_stride; // one stride per call (checked at the boundary)
+      int rc = FGMM_OK;
       for (int q = 0; q < n_in; ++q) {
         first[q].t_start = t_start;
         packed[q] = reinterpret_cast<const uint32_t *>(h_ws + first[q].o_packed);
@@ -536,8 +542,21 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
         nb[q] = first[q].job_bypass;
         out[q] = &first[q].bytes;
         len[q] = &first[q].bytes_len;
+        ck[q] = nullptr;
+        const int64_t n_ck = stride > 0 && n[q] > 0 ? (n[q] - 1) / stride : 0;
+        if (n_ck > 0) {
+          ck[q] = first[q].ckpt = static_cast<fgmm_ckpt *>(malloc(sizeof(fgmm_ckpt) * (size_t)n_ck));
+          if (!ck[q]) rc = FGMM_ERR_NOMEM;
+          first[q].n_ckpt = ck[q] ? n_ck : 0;
+        }
       }
-      const int rc = rans_encode_symtab_ways(n_in, packed, syms, n, nb, out, len);
+      if (rc == FGMM_OK) rc = rans_encode_symtab_ways(n_in, packed, syms, n, nb, out, len, stride, ck);
+      if (rc != FGMM_OK)
+        for (int q = 0; q < n_in; ++q) {
+          free(first[q].ckpt);
+          first[q].ckpt = nullptr;
+          first[q].n_ckpt = 0;
+        }
       const double t_end = tr.ms();
       for (int q = 0; q < n_in; ++q) {
         first[q].status = rc;
@@ -573,6 +592,8 @@ struct DecItem {
   const int64_t *zero_bitmap = nullptr; // host [M] or null (= all channels coded)
   float *y_hat = nullptr;               // device [M*hw] or null
   int32_t *sym_host_out = nullptr;      // host [n] or null
+  const fgmm_ckpt *ckpt = nullptr;      // checkpoints of the bitstream (out-of-band notes of its encoder) or null
+  int64_t n_ckpt = 0, ckpt_stride = 0;
   int status = FGMM_OK;
   // derived
   int32_t n_ch = 0;
@@ -598,6 +619,10 @@ struct DecItem {
   TabView view;
   int32_t *sym = nullptr;               // int32 symbols (sym_host_out or a slice of the context's scratch)
   std::atomic<int> done{0};
+  // checkpointed streams decode as independent SEGMENTS (n_seg = n_ckpt + 1; 0: sequentially, piece by piece)
+  int n_seg = 0, next_seg_push = 0;       // next_seg_push: guarded by the call's mutex
+  int64_t piece_end[kMaxPieces] = {};     // one past the last latent of every piece (known when the call is planned)
+  std::atomic<int> segs_left{0}, ckpt_bad{0}, wide_any{0};
   double t_taken = 0, t_start = 0, t_end = 0, t_waited = 0, t_lastland = 0, t_work = 0; // trace level 2: job timeline
   DecItem() = default;
   DecItem(const DecItem &) = delete;
@@ -649,7 +674,17 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   // Elias-Fano rows (long rows: ef_min) are 18 % fewer bytes than uint16 rows and 40 % more nanoseconds to search (57.6 B and
   // 12 ns per latent against 70 B and 8.7 ns on the Kodak workload): with P = min(workers, bitstreams) decoders at work a
   // latent costs max(bytes / 55.7 GB/s, ns / P) - Elias-Fano rows pay when 12 / P < 70 B / 55.7 GB/s = 1.26 ns, P >= 10.
-  const int decoders = std::min(std::max(ctx->pool->size(), 1), count);
+  // (a checkpointed bitstream keeps as many decoders busy as it has segments)
+  // Segments pay when a call has fewer bitstreams than workers (one image, ELIC's stages of a few images); a call with a
+  // bitstream per worker or more keeps them all busy piece by piece and would only pay the segments' bookkeeping
+  // (24 Kodak halves on 16 workers: 8.57 ms of decode per step sequentially, 8.73 in segments): the notes are ignored there.
+  const bool use_ckpt = ctx->opt.ckpt_decode == 1 || (ctx->opt.ckpt_decode == 0 && count < std::max(ctx->pool->size(), 1));
+  int64_t streams_of_work = 0;
+  for (auto &it : items) {
+    if (!use_ckpt) it.ckpt = nullptr, it.n_ckpt = 0;
+    streams_of_work += it.ckpt && it.n_ckpt > 0 ? it.n_ckpt + 1 : 1;
+  }
+  const int decoders = (int)std::min<int64_t>(std::max(ctx->pool->size(), 1), streams_of_work);
   const uint32_t ef_min = ctx->opt.ef_rows == 1 || (ctx->opt.ef_rows == 0 && decoders >= 10) ? (uint32_t)ctx->opt.ef_min : kTabNoEf;
 
   // ---- items: coded channels, header form, path --------------------------------------------------------------------
@@ -698,7 +733,10 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     int64_t lat = 0;
     for (int k = 0; k < n_fast; ++k) lat += items[fast[k]].n;
     if (lat < 65536) np = 1; // pieces only pay for rows that take a while to cross
-    if (n_fast == 1) np = std::min(np, 3); // one decoder: pieces only let it start early, and each costs a hand-over (20 us)
+    if (decoders == 1) np = std::min(np, 3); // one decoder: pieces only let it start early, and each costs a hand-over (20 us)
+    // every round costs this thread ~60 us of launch / counter / copy round trips: no more rounds than the tables' time on the bus
+    // is worth (a lone Kodak half: 7.7 MB = 0.14 ms -> 2 pieces; measured 0.45 ms per call against 0.72 with 8)
+    np = (int)std::min<int64_t>(np, std::max<int64_t>(1, lat * 58 / 55700 / 60)); // lat * 58 B / 55.7 GB/s in units of 60 us
   }
   auto piece_bound = [np](int64_t nblk, int p) { // first block of piece p: weights np, np-1 ... 1
     const int64_t tot = (int64_t)np * (np + 1) / 2, cum = (int64_t)p * (2 * np - p + 1) / 2;
@@ -719,7 +757,16 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         sz = std::min(steady, sz * 2);
       }
     }
-    for (int k = 0; k < n_fast; ++k) items[fast[k]].n_piece = np;
+    for (int k = 0; k < n_fast; ++k) {
+      DecItem &it = items[fast[k]];
+      it.n_piece = np;
+      for (int p = 0; p < np; ++p) it.piece_end[p] = std::min<int64_t>(piece_bound(it.nblk, p + 1) * it.tl, it.n);
+      // segments: the notes must be exactly the ones an encoder writes for this many symbols (anything else: sequential)
+      const bool seekable = it.ckpt && it.n_ckpt > 0 && it.ckpt_stride >= 256 && !(it.ckpt_stride & (it.ckpt_stride - 1)) &&
+                            it.n_ckpt == (it.n - 1) / it.ckpt_stride && it.n_ckpt < (1 << 24);
+      it.n_seg = seekable ? (int)it.n_ckpt + 1 : 0;
+      it.segs_left.store(it.n_seg);
+    }
   }
   const int n_units = (int)units.size();
   size_t n_parts = 0, stage_total = 0, rows_worst_total = 0;
@@ -855,7 +902,13 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   std::condition_variable work_cv, done_cv;
   bool abandon = false; // this call is returning early: workers must not wait for copies that will never be queued
   int unfinished = count;
-  using Key = std::pair<int64_t, int>; // (piece, item): the earliest-landing task first
+  // a task: piece `piece` of a sequentially decoded item (seg < 0), or segment `seg` of a checkpointed one whose last table
+  // piece is `piece`; the earliest-landing task first
+  struct Key {
+    int64_t piece;
+    int item, seg;
+    bool operator>(const Key &o) const { return piece != o.piece ? piece > o.piece : (item != o.item ? item > o.item : seg > o.seg); }
+  };
   std::priority_queue<Key, std::vector<Key>, std::greater<Key>> ready;
   {
     size_t need = 0;
@@ -871,12 +924,30 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       if (!it.sym_host_out) at += (size_t)std::max<int64_t>(it.n, 1);
     }
   }
+  auto seg_last_piece = [&](const DecItem &it, int sg) { // the piece that holds the last latent of segment sg
+    const int64_t hi = sg + 1 == it.n_seg ? it.n : (int64_t)(sg + 1) * it.ckpt_stride;
+    int p = 0;
+    while (p + 1 < it.n_piece && it.piece_end[p] < hi) ++p;
+    return p;
+  };
   auto push_if_ready = [&](int i) { // under mu
     DecItem &it = items[i];
+    if (it.n_seg) { // every segment whose tables are queued by now; segments are independent of one another
+      int pushed = 0;
+      while (it.next_seg_push < it.n_seg) {
+        const int lp = seg_last_piece(it, it.next_seg_push);
+        if (lp >= it.queued) break;
+        ready.push(Key{lp, i, it.next_seg_push++});
+        ++pushed;
+      }
+      return pushed;
+    }
     if (!it.busy && !it.in_ready && !it.done.load() && it.next_piece < it.queued) {
       it.in_ready = true;
-      ready.push(Key{it.next_piece, i});
+      ready.push(Key{it.next_piece, i, -1});
+      return 1;
     }
+    return 0;
   };
   // before / after a piece is decoded (no lock held)
   auto prepare = [&](DecItem &it, int p) {
@@ -914,14 +985,82 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.t_end = tr.ms();
     return true;
   };
+  // One segment of a checkpointed bitstream, start to end on this thread (no lock held): from its checkpoint - the stream's
+  // own head for segment 0 - to the next one, which it must hit exactly.  The last segment to finish closes the item; if any
+  // segment missed its checkpoint the whole bitstream is decoded sequentially then (the notes were wrong: nothing of what the
+  // segments wrote is kept).  -> true: the item is finished
+  auto run_segment = [&](DecItem &it, int sg) {
+    const int64_t lo = (int64_t)sg * it.ckpt_stride, hi = sg + 1 == it.n_seg ? it.n : (int64_t)(sg + 1) * it.ckpt_stride;
+    int p0 = 0;
+    while (p0 + 1 < it.n_piece && it.piece_end[p0] <= lo) ++p0;
+    const int p1 = seg_last_piece(it, sg);
+    const double tw0 = tr.level > 1 ? tr.ms() : 0;
+    bool ok = !it.ckpt_bad.load(std::memory_order_relaxed);
+    for (int p = p0; p <= p1 && ok; ++p)
+      if (hipEventSynchronize(it.piece_ev[p]) != hipSuccess) ok = false;
+    const double tw1 = tr.level > 1 ? tr.ms() : 0;
+    if (ok) {
+      TabDecoder td;
+      int rc2 = td.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
+      uint64_t x1 = 0, pos1 = 0;
+      if (rc2 == FGMM_OK) rc2 = td.segment(lo, hi, sg ? it.ckpt[sg - 1].x : td.x, sg ? it.ckpt[sg - 1].pos : 0, &x1, &pos1);
+      td.rc = FGMM_OK;
+      td.i = it.n;
+      (void)td.finish();
+      ok = rc2 == FGMM_OK && (sg + 1 == it.n_seg || (x1 == it.ckpt[sg].x && pos1 == it.ckpt[sg].pos));
+    }
+    if (!ok) {
+      it.ckpt_bad.store(1);
+    } else if (it.y_hat) { // this segment's symbols -> pinned memory for the scatter kernel, int16 unless one does not fit
+      int16_t *s16 = reinterpret_cast<int16_t *>(it.h_out);
+      int32_t acc = 0;
+      for (int64_t k = lo; k < hi; ++k) {
+        const int32_t v = it.sym[k];
+        s16[k] = (int16_t)v;
+        acc |= v ^ (int32_t)(int16_t)v;
+      }
+      if (acc) it.wide_any.store(1);
+    }
+    if (tr.level > 1) {
+      std::lock_guard<std::mutex> l(mu);
+      it.t_waited += tw1 - tw0;
+      it.t_work += tr.ms() - tw1;
+      if (sg == 0) it.t_taken = it.t_start = tw0;
+    }
+    if (it.segs_left.fetch_sub(1) != 1) return false;
+    // the last segment: close the item
+    if (it.ckpt_bad.load()) { // sequential decode of the whole bitstream (every piece is queued: the last segment needed the last one)
+      it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
+      for (int p = 0; p < it.n_piece && it.status == FGMM_OK; ++p) {
+        if (hipEventSynchronize(it.piece_ev[p]) != hipSuccess) it.status = FGMM_ERR_HIP;
+        else it.status = it.dec.piece(p);
+      }
+      const int rf = it.dec.finish();
+      if (it.status == FGMM_OK) it.status = rf;
+      if (it.status == FGMM_OK && it.y_hat) {
+        int16_t *s16 = reinterpret_cast<int16_t *>(it.h_out);
+        int32_t acc = 0;
+        for (int64_t k = 0; k < it.n; ++k) {
+          const int32_t v = it.sym[k];
+          s16[k] = (int16_t)v;
+          acc |= v ^ (int32_t)(int16_t)v;
+        }
+        it.wide_any.store(acc != 0);
+      }
+    }
+    it.wide = it.wide_any.load();
+    if (it.status == FGMM_OK && it.y_hat && it.wide) memcpy(it.h_out, it.sym, sizeof(int32_t) * (size_t)it.n);
+    it.t_end = tr.ms();
+    return true;
+  };
   int waiting = 0; // workers asleep on work_cv (under mu)
   // two bitstreams in turn per worker: 8.9 -> 5.9 ns/symbol per thread with uint16 rows, nothing with Elias-Fano rows, and a
   // loss whenever it leaves workers idle - automatic only with at least two bitstreams per worker
   const bool pairing = ctx->opt.dec_pair == 1 || (ctx->opt.dec_pair == 0 && count >= 2 * std::max(ctx->pool->size(), 1) && ef_min == kTabNoEf);
   auto worker = [&] {
     std::unique_lock<std::mutex> l(mu);
-    auto take = [&](int *p_out) { // under mu: the earliest-landing ready task
-      const int i = ready.top().second;
+    auto take = [&](int *p_out) { // under mu: the earliest-landing ready task of a sequentially decoded item
+      const int i = ready.top().item;
       ready.pop();
       items[i].in_ready = false;
       items[i].busy = true;
@@ -949,11 +1088,24 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         --waiting;
         continue;
       }
+      if (ready.top().seg >= 0) { // a segment of a checkpointed bitstream: independent of every other task
+        const Key k = ready.top();
+        ready.pop();
+        l.unlock();
+        const bool fin = run_segment(items[k.item], k.seg);
+        l.lock();
+        if (fin) {
+          items[k.item].done.store(1);
+          if (--unfinished == 0) work_cv.notify_all();
+          done_cv.notify_all();
+        }
+        continue;
+      }
       int p0 = 0, p1 = 0;
       const int i0 = take(&p0);
       // a second bitstream for this thread (decoded latent by latent in turn with the first: two dependency chains share
       // the core) - unless that would leave a sleeping worker without a task
-      const int i1 = pairing && !ready.empty() && (int)ready.size() > waiting ? take(&p1) : -1;
+      const int i1 = pairing && !ready.empty() && ready.top().seg < 0 && (int)ready.size() > waiting ? take(&p1) : -1;
       l.unlock();
       DecItem &a = items[i0];
       prepare(a, p0);
@@ -987,12 +1139,13 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
   };
   auto mark_queued = [&](int i, int pieces) {
+    int pushed;
     {
       std::lock_guard<std::mutex> l(mu);
       items[i].queued = pieces;
-      push_if_ready(i);
+      pushed = push_if_ready(i);
     }
-    work_cv.notify_one();
+    if (pushed > 1) work_cv.notify_all(); else work_cv.notify_one();
   };
   struct Abandon { // any return: release workers that wait for copies (before PoolDrain waits for the workers)
     std::mutex &mu;
@@ -1023,8 +1176,10 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
   }
 
+  for (auto &it : items)
+    if (it.n_seg) it.view = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
   // (a single bitstream too: its decoder starts on piece 0 while this thread is still queuing the later pieces' copies)
-  const int n_workers = std::min(std::max(ctx->pool->size(), 1), count);
+  const int n_workers = (int)std::min<int64_t>(std::max(ctx->pool->size(), 1), streams_of_work);
   for (int j = 0; j < n_workers; ++j) ctx->pool->submit(worker);
 
   // ---- unit by unit: size known -> pinned range, ONE copy; the workers are told ----------------------------------------
@@ -1204,6 +1359,7 @@ const OptName kOpts[] = {
     {"ef_min", &fgmm_ctx::Opts::ef_min, kTabEfMin, 1 << 20, "FGMM_EF_MIN_ROWS"},
     {"dec_pair", &fgmm_ctx::Opts::dec_pair, 0, 2, "FGMM_DEC_PAIR"},
     {"enc_ways", &fgmm_ctx::Opts::enc_ways, 0, kMaxEncWays, "FGMM_ENC_WAYS"},
+    {"ckpt_decode", &fgmm_ctx::Opts::ckpt_decode, 0, 2, "FGMM_CKPT_DECODE"},
 };
 } // namespace
 
@@ -1434,6 +1590,9 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
     e.clamp = clamp_scales;
     e.yq = s.yq_out;
     e.zero_bitmap = s.zero_bitmap;
+    if (s.ckpt_stride != items[0].ckpt_stride || s.ckpt_stride < 0 || (s.ckpt_stride && (s.ckpt_stride < 256 || (s.ckpt_stride & (s.ckpt_stride - 1)))))
+      return fail(FGMM_ERR_INVALID, "item %d: ckpt_stride must be 0 or a power of two >= 256, the same for a whole batch", i);
+    e.ckpt_stride = s.ckpt_stride;
   }
   const int rc = encode_batch(ctx, (hipStream_t)stream, v, mode);
   for (int i = 0; i < count; ++i) {
@@ -1441,6 +1600,8 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
     items[i].bytes = v[i].bytes;
     items[i].bytes_len = v[i].bytes_len;
     items[i].status = v[i].status;
+    items[i].ckpt = v[i].ckpt;
+    items[i].n_ckpt = v[i].n_ckpt;
   }
   return rc;
 }
@@ -1491,6 +1652,11 @@ int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int
     d.max_bs = s.abs_max + 1; // entropy_models.py:888
     d.zero_bitmap = s.zero_bitmap;
     d.y_hat = s.yq_out;
+    if (s.ckpt && s.n_ckpt > 0 && s.ckpt_stride > 0) { // (notes that do not fit the stream are ignored: sequential decode)
+      d.ckpt = s.ckpt;
+      d.n_ckpt = s.n_ckpt;
+      d.ckpt_stride = s.ckpt_stride;
+    }
   }
   const int rc = decode_batch(ctx, (hipStream_t)stream, v, mode);
   for (int i = 0; i < count; ++i) items[i].status = v[i].status;

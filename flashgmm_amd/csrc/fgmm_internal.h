@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "../../include/flashgmm_amd.h"
+
 #if defined(__HIPCC__)
 #define FGMM_HD __host__ __device__
 #else
@@ -162,11 +164,16 @@ int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream
 // returns 0 or an fgmm_status; *out malloc'ed
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len);
+// ... noting a checkpoint (include/flashgmm_amd.h: fgmm_ckpt) every `stride` symbols (a power of two; 0: none):
+// ckpt[(n - 1) / stride] entries, entry k for symbol (k + 1) * stride
+int rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint, uint8_t **out,
+                            size_t *out_len, int64_t stride, fgmm_ckpt *ckpt);
 // two streams by one thread, interleaved (each output identical to rans_encode_symtab's)
 constexpr int kMaxEncWays = 4;
 // `ways` (1..4) tables -> bitstreams, coded by the calling thread symbol by symbol in turn
 int rans_encode_symtab_ways(int ways, const uint32_t *const *packed, const int32_t *const *symbols, const int64_t *n,
-                            const int64_t *n_bypass_hint, uint8_t ***out, size_t **out_len);
+                            const int64_t *n_bypass_hint, uint8_t ***out, size_t **out_len, int64_t ckpt_stride = 0,
+                            fgmm_ckpt *const *ckpt = nullptr);
 int rans_encode_symtab2(const uint32_t *const packed[2], const int32_t *const symbols[2], const int64_t n[2],
                         const int64_t n_bypass_hint[2], uint8_t **out[2], size_t *out_len[2]);
 // Decode-side tables as the host decoder sees them: `npiece` pieces in latent order; piece k holds the latents
@@ -198,12 +205,13 @@ struct TabDecoder {
   int32_t *out = nullptr;
   int next_piece = 0, rc = 0;
   uint64_t x = 0;            // rANS state
-  const uint32_t *ptr = nullptr, *end_ = nullptr;
+  const uint32_t *ptr = nullptr, *end_ = nullptr, *base_ = nullptr; // base_: the first renormalisation word
   uint32_t *copy = nullptr;  // aligned copy of a misaligned bitstream
   uint16_t *scratch = nullptr;
   size_t scratch_cap = 0;
   int begin(const uint8_t *enc, size_t enc_len, const TabView *view, int64_t n, int32_t max_bs, int32_t *out);
   int piece(int k);
+  int segment(int64_t lo, int64_t hi, uint64_t x0, uint64_t pos0, uint64_t *x1, uint64_t *pos1); // checkpointed streams
   int finish();
 };
 // two pieces of two decoders on one thread, latent by latent in turn (two dependency chains share the core)

@@ -119,6 +119,28 @@ static int64_t count_bypass(const uint32_t *packed, int64_t n) {
 // every entry of the reference's _syms emits at most one 32-bit word; a bypassed symbol is 1 + 1 + <=8 entries;
 // +16: the flush words and the word the branch-free renormalisation always stores below the pointer
 static inline size_t encode_words(int64_t n, int64_t nb) { return (size_t)n + (size_t)nb * 10 + 16; }
+// ---- checkpoints (seekable streams) ----------------------------------------------------------------------
+// The decoder's state before it decodes symbol i IS the encoder's state after it has encoded symbol i on its reversed walk
+// (decoding inverts encoding step by step, renormalisation included), and the words the decoder has consumed by then are
+// the ones the encoder emits AFTER that point.  So the encoder can note, every `stride` symbols, (state, words emitted so far)
+// - out of band: the bitstream stays the reference's, byte for byte - and a decoder that is handed the notes may start at
+// any of them.  A segment that ends exactly in the next note's (state, position) is the sequential decoder's work on that
+// range, by induction from the stream's head: the notes are VERIFIED by the decoder, never trusted.
+struct CkRec { // while encoding: words emitted so far; finish_ckpt turns that into the decoder's word position
+  fgmm_ckpt *out = nullptr;
+  int64_t stride = 0, n_out = 0;
+  inline void note(const Enc &e, const uint32_t *end, int64_t i) { // the encoder has just encoded symbol i (i % stride == 0, i > 0)
+    fgmm_ckpt &c = out[i / stride - 1];
+    c.x = e.x;
+    c.pos = (uint64_t)(end - e.ptr);
+  }
+  inline void finish(const Enc &e, const uint32_t *end) { // before the flush: e.ptr = start of the renormalisation words
+    const uint64_t total = (uint64_t)(end - e.ptr);
+    for (int64_t k = 0; k < n_out; ++k) out[k].pos = total - out[k].pos; // words the decoder has read before that symbol
+  }
+};
+static inline int64_t ckpt_count(int64_t n, int64_t stride) { return stride > 0 && n > 0 ? (n - 1) / stride : 0; }
+
 static int finish_stream(Enc &e, uint32_t *end, uint8_t **out, size_t *out_len) { // Rans64EncFlush + copy out
   e.ptr -= 2;
   e.ptr[0] = (uint32_t)(e.x >> 0);
@@ -134,8 +156,15 @@ static int finish_stream(Enc &e, uint32_t *end, uint8_t **out, size_t *out_len) 
 
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len) {
+  return rans_encode_symtab_ckpt(packed, symbols, n, n_bypass_hint, out, out_len, 0, nullptr);
+}
+
+// the same, noting a checkpoint every `stride` symbols (a power of two; 0: none) into ckpt[ckpt_count(n, stride)]
+int rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols, int64_t n, int64_t n_bypass_hint, uint8_t **out,
+                            size_t *out_len, int64_t stride, fgmm_ckpt *ckpt) {
   std::call_once(g_rcp_once, init_rcp);
-  if (n < 0 || !out || !out_len || (n > 0 && !packed)) return FGMM_ERR_INVALID;
+  if (n < 0 || !out || !out_len || (n > 0 && !packed) || stride < 0 || (stride & (stride - 1)) || (ckpt_count(n, stride) && !ckpt))
+    return FGMM_ERR_INVALID;
   const size_t nwords = encode_words(n, n_bypass_hint < 0 ? count_bypass(packed, n) : n_bypass_hint);
   // worst-case sized scratch, kept per thread: a fresh 600 KB malloc per stream is an mmap + page faults + munmap
   static thread_local std::vector<uint32_t> scratch;
@@ -146,10 +175,18 @@ int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n
   }
   uint32_t *const end = scratch.data() + nwords;
   Enc e{kRansL, end}; // Rans64EncInit
-  for (int64_t i = n - 1; i >= 0; --i) { // reversed _syms (rans_interface.cpp:569)
-    if ((i & 15) == 15) __builtin_prefetch(packed + i - 512); // the table was just DMA-written: not in any cache
-    encode_entry(e, packed[i], symbols, i);
+  CkRec ck{ckpt, stride, ckpt_count(n, stride)};
+  const int64_t seg = ck.n_out ? stride : (n > 0 ? n : 1); // the walk in runs that end on a checkpoint
+  for (int64_t hi = n; hi > 0;) {
+    const int64_t lo = (hi - 1) / seg * seg;
+    for (int64_t i = hi - 1; i >= lo; --i) { // reversed _syms (rans_interface.cpp:569)
+      if ((i & 15) == 15) __builtin_prefetch(packed + i - 512); // the table was just DMA-written: not in any cache
+      encode_entry(e, packed[i], symbols, i);
+    }
+    if (ck.n_out && lo > 0) ck.note(e, end, lo);
+    hi = lo;
   }
+  ck.finish(e, end);
   return finish_stream(e, end, out, out_len);
 }
 
@@ -158,7 +195,7 @@ int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n
 // one stream alone (Zen 5, scripts/enc_ilp.cpp).  Each stream's output is exactly what rans_encode_symtab gives.
 template <int N>
 static int encode_ways(const uint32_t *const *packed, const int32_t *const *symbols, const int64_t *n, const int64_t *n_bypass_hint,
-                       uint8_t ***out, size_t **out_len) {
+                       uint8_t ***out, size_t **out_len, int64_t stride, fgmm_ckpt *const *ckpt) {
   size_t nwords[N], total = 0;
   for (int k = 0; k < N; ++k) {
     if (n[k] < 0 || !out[k] || !out_len[k] || (n[k] > 0 && !packed[k])) return FGMM_ERR_INVALID;
@@ -173,6 +210,7 @@ static int encode_ways(const uint32_t *const *packed, const int32_t *const *symb
   }
   uint32_t *end[N];
   Enc e[N];
+  CkRec ck[N];
   int64_t i[N], common = INT64_MAX;
   {
     uint32_t *at = scratch.data();
@@ -182,19 +220,28 @@ static int encode_ways(const uint32_t *const *packed, const int32_t *const *symb
       e[k] = Enc{kRansL, at};
       i[k] = n[k] - 1;
       common = std::min(common, n[k]);
+      ck[k] = CkRec{ckpt ? ckpt[k] : nullptr, stride, ckpt && ckpt[k] ? ckpt_count(n[k], stride) : 0};
     }
   }
+  // (a checkpoint is due when a stream has just encoded a symbol whose index is a non-zero multiple of the stride: one
+  // well-predicted test per symbol; the stride is a power of two)
+  const uint64_t smask = stride > 0 ? (uint64_t)stride - 1 : ~0ull;
   for (int64_t s = 0; s < common; ++s) { // all streams have a symbol left
     if ((s & 15) == 0)
       for (int k = 0; k < N; ++k) __builtin_prefetch(packed[k] + i[k] - 512); // the tables were just DMA-written
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       encode_entry(e[k], packed[k][i[k]], symbols[k], i[k]);
+      if (__builtin_expect(((uint64_t)i[k] & smask) == 0 && ck[k].n_out && i[k] > 0, 0)) ck[k].note(e[k], end[k], i[k]);
       --i[k];
     }
   }
   for (int k = 0; k < N; ++k) // the longer streams' remainders
-    for (; i[k] >= 0; --i[k]) encode_entry(e[k], packed[k][i[k]], symbols[k], i[k]);
+    for (; i[k] >= 0; --i[k]) {
+      encode_entry(e[k], packed[k][i[k]], symbols[k], i[k]);
+      if (__builtin_expect(((uint64_t)i[k] & smask) == 0 && ck[k].n_out && i[k] > 0, 0)) ck[k].note(e[k], end[k], i[k]);
+    }
+  for (int k = 0; k < N; ++k) ck[k].finish(e[k], end[k]);
   int rc = FGMM_OK;
   for (int k = 0; k < N && rc == FGMM_OK; ++k)
     if ((rc = finish_stream(e[k], end[k], out[k], out_len[k])) != FGMM_OK)
@@ -206,20 +253,21 @@ static int encode_ways(const uint32_t *const *packed, const int32_t *const *symb
 }
 
 int rans_encode_symtab_ways(int ways, const uint32_t *const *packed, const int32_t *const *symbols, const int64_t *n,
-                            const int64_t *n_bypass_hint, uint8_t ***out, size_t **out_len) {
+                            const int64_t *n_bypass_hint, uint8_t ***out, size_t **out_len, int64_t stride, fgmm_ckpt *const *ckpt) {
   std::call_once(g_rcp_once, init_rcp);
+  if (stride < 0 || (stride & (stride - 1))) return FGMM_ERR_INVALID;
   switch (ways) {
-  case 1: return rans_encode_symtab(packed[0], symbols[0], n[0], n_bypass_hint[0], out[0], out_len[0]);
-  case 2: return encode_ways<2>(packed, symbols, n, n_bypass_hint, out, out_len);
-  case 3: return encode_ways<3>(packed, symbols, n, n_bypass_hint, out, out_len);
-  case 4: return encode_ways<4>(packed, symbols, n, n_bypass_hint, out, out_len);
+  case 1: return rans_encode_symtab_ckpt(packed[0], symbols[0], n[0], n_bypass_hint[0], out[0], out_len[0], ckpt && ckpt[0] ? stride : 0, ckpt ? ckpt[0] : nullptr);
+  case 2: return encode_ways<2>(packed, symbols, n, n_bypass_hint, out, out_len, stride, ckpt);
+  case 3: return encode_ways<3>(packed, symbols, n, n_bypass_hint, out, out_len, stride, ckpt);
+  case 4: return encode_ways<4>(packed, symbols, n, n_bypass_hint, out, out_len, stride, ckpt);
   default: return FGMM_ERR_INVALID;
   }
 }
 
 int rans_encode_symtab2(const uint32_t *const packed[2], const int32_t *const symbols[2], const int64_t n[2],
                         const int64_t n_bypass_hint[2], uint8_t **out[2], size_t *out_len[2]) {
-  return rans_encode_symtab_ways(2, packed, symbols, n, n_bypass_hint, out, out_len);
+  return rans_encode_symtab_ways(2, packed, symbols, n, n_bypass_hint, out, out_len, 0, nullptr);
 }
 
 namespace {
@@ -556,7 +604,7 @@ int TabDecoder::begin(const uint8_t *enc, size_t enc_len, const TabView *view, i
     words = reinterpret_cast<const uint32_t *>(enc);
   }
   x = (uint64_t)words[0] | ((uint64_t)words[1] << 32); // Rans64DecInit
-  ptr = words + 2;
+  ptr = base_ = words + 2;
   end_ = words + enc_len / 4;
   return FGMM_OK;
 }
@@ -608,6 +656,68 @@ struct PieceRun {
     blk = 0;
     b_end = i; // the first step opens block 0
     return true;
+  }
+  // The same for a SEGMENT of a checkpointed stream: piece k from latent d.i on (anywhere inside the piece), at most up to
+  // i_stop; d.x / d.ptr hold the checkpoint's coder state.  Rows inside a block are sequential, so the rows of the block's
+  // latents before d.i are skipped header by header (fewer than tl of them).  Block-placed tables only.
+  bool begin_at(TabDecoder &d, int k, int64_t i_stop) {
+    td = &d;
+    rc = d.rc;
+    if (rc != FGMM_OK) return false;
+    if (!d.tv || k < 0 || k >= d.tv->npiece || !d.tv->piece[k].blk_off || d.tv->tl <= 0) {
+      rc = d.rc = FGMM_ERR_INVALID;
+      return false;
+    }
+    pc = &d.tv->piece[k];
+    i_beg = k ? d.tv->piece[k - 1].end : 0;
+    i_end = std::min(std::min<int64_t>(pc->end, d.n), i_stop);
+    if (d.i < i_beg || d.i >= i_end) return false;
+    dec.x = d.x;
+    dec.ptr = d.ptr;
+    dec.end = d.end_;
+    max_bs = d.max_bs;
+    W = 2 * (int64_t)max_bs + 2;
+    hdr_form = d.tv->hdr_form;
+    ef_min = d.tv->ef_min;
+    rows_end = pc->rows + (pc->rows_len >= 32 ? pc->rows_len - 32 : 0);
+    tl = d.tv->tl;
+    blk = (d.i - i_beg) / tl;
+    i = b_end = i_beg + blk * tl; // the first step / skip opens this block
+    while (rc == FGMM_OK && i < d.i) skip();
+    return rc == FGMM_OK;
+  }
+  // passes latent i without decoding it: its row's extent from its header
+  void skip() {
+    if (i == b_end) {
+      open_block();
+      if (rc != FGMM_OK) return;
+    }
+    const int64_t li = i - i_beg;
+    int64_t cnt;
+    uint32_t nonmono = 0;
+    if (hdr_form == 2) {
+      cnt = static_cast<const uint16_t *>(pc->hdr)[li] >> 8;
+      if (cnt == kHdr2Escape) {
+        if (rows_end - rowp < 4) { rc = FGMM_ERR_INVALID; return; }
+        uint32_t h;
+        memcpy(&h, rowp, 4);
+        rowp += 4;
+        cnt = tab_hdr_cnt(h);
+        nonmono = tab_hdr_nonmono(h);
+      }
+    } else if (hdr_form == 4) {
+      const uint32_t h = static_cast<const uint32_t *>(pc->hdr)[li];
+      cnt = tab_hdr_cnt(h);
+      nonmono = tab_hdr_nonmono(h);
+    } else {
+      const uint64_t h = static_cast<const uint64_t *>(pc->hdr)[li];
+      cnt = (int64_t)((h >> 32) & 0x7FFFFFFFu);
+      nonmono = (uint32_t)(h >> 63);
+    }
+    const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
+    if (cnt < 1 || (uint64_t)(rows_end - rowp) < rbytes) { rc = FGMM_ERR_INVALID; return; }
+    rowp += rbytes;
+    ++i;
   }
   inline bool active() const { return rc == FGMM_OK && i < i_end; }
   void finish() { // the coder state goes back to the decoder (the next piece may run on another thread)
@@ -761,6 +871,32 @@ int TabDecoder::piece(int k) {
   if (!r.begin(*this, k)) return r.rc;
   while (r.active()) r.step();
   r.finish();
+  return rc;
+}
+
+// Latents [lo, hi) of a checkpointed stream, from the checkpoint (x0 = coder state before symbol lo, pos0 = renormalisation
+// words read by then); every piece the range touches has landed.  *x1 / *pos1: where the coder stands after symbol hi - 1 -
+// the caller compares that with the NEXT checkpoint: a segment that ends exactly there did the sequential decoder's work.
+int TabDecoder::segment(int64_t lo, int64_t hi, uint64_t x0, uint64_t pos0, uint64_t *x1, uint64_t *pos1) {
+  if (rc != FGMM_OK) return rc;
+  if (!tv || lo < 0 || hi > n || lo > hi || pos0 > (uint64_t)(end_ - base_)) return rc = FGMM_ERR_INVALID;
+  x = x0;
+  ptr = base_ + pos0;
+  i = lo;
+  int k = 0;
+  while (k < tv->npiece && tv->piece[k].end <= lo) ++k;
+  for (; i < hi && k < tv->npiece && rc == FGMM_OK; ++k) {
+    PieceRun r;
+    if (!r.begin_at(*this, k, hi)) {
+      if (r.rc != FGMM_OK) rc = r.rc;
+      break;
+    }
+    while (r.active()) r.step();
+    r.finish();
+  }
+  if (rc == FGMM_OK && i < hi) rc = FGMM_ERR_INVALID; // the pieces do not cover the range
+  *x1 = x;
+  *pos1 = (uint64_t)(ptr - base_);
   return rc;
 }
 
@@ -1031,6 +1167,52 @@ extern "C" {
 int fgmm_rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, uint8_t **out,
                             size_t *out_len) {
   return fgmm::rans_encode_symtab(packed, symbols_or_null, n, -1, out, out_len);
+}
+int64_t fgmm_ckpt_count(int64_t n, int64_t stride) { return stride > 0 && n > 0 ? (n - 1) / stride : 0; }
+int fgmm_rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t stride, uint8_t **out,
+                                 size_t *out_len, fgmm_ckpt *ckpt_out) {
+  if (stride < 0 || (stride & (stride - 1))) return FGMM_ERR_INVALID;
+  return fgmm::rans_encode_symtab_ckpt(packed, symbols_or_null, n, -1, out, out_len, stride, ckpt_out);
+}
+// Segment by segment on the calling thread (the batched decoder runs the segments on its workers): every segment starts from
+// its checkpoint and must end in the next one's (state, position); the first mismatch makes the whole stream a sequential decode.
+int fgmm_rans_decode_tab_ckpt(const uint8_t *encoded, size_t encoded_len, const void *hdr, int hdr_form, const uint32_t *blk_off,
+                              int32_t tl, const uint8_t *rows, uint64_t rows_len, int64_t n, int32_t max_bs, int flags,
+                              const fgmm_ckpt *ckpt, int64_t n_ckpt, int64_t stride, int32_t *out_symbols, int32_t *verified_out) {
+  if (verified_out) *verified_out = 0;
+  if (!ckpt || n_ckpt == 0 || !blk_off || stride <= 0 || (stride & (stride - 1)) || n_ckpt != fgmm_ckpt_count(n, stride))
+    return fgmm_rans_decode_tab(encoded, encoded_len, hdr, hdr_form, blk_off, tl, rows, rows_len, n, max_bs, flags, out_symbols);
+  if (n > 0 && (!hdr || !rows)) return FGMM_ERR_INVALID;
+  if (max_bs < 0 || max_bs > FGMM_MAX_BS || tl < 1) return FGMM_ERR_INVALID;
+  if (hdr_form == 2 && !fgmm::tab_hdr_fits16(max_bs)) return FGMM_ERR_INVALID;
+  if (hdr_form == 4 && max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_INVALID;
+  const fgmm::TabPiece pc{hdr, blk_off, rows, (size_t)rows_len, n};
+  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, hdr_form, tl, 1, &pc, nullptr, nullptr};
+  bool ok = true;
+  int hard = FGMM_OK; // an error that is not the notes' fault
+  for (int64_t sgm = 0; sgm <= n_ckpt && ok; ++sgm) {
+    fgmm::TabDecoder td;
+    int rc = td.begin(encoded, encoded_len, &tv, n, max_bs, out_symbols);
+    if (rc != FGMM_OK) {
+      td.finish();
+      return rc;
+    }
+    const int64_t lo = sgm * stride, hi = sgm == n_ckpt ? n : (sgm + 1) * stride;
+    const uint64_t x0 = sgm ? ckpt[sgm - 1].x : td.x, pos0 = sgm ? ckpt[sgm - 1].pos : 0;
+    uint64_t x1 = 0, pos1 = 0;
+    rc = td.segment(lo, hi, x0, pos0, &x1, &pos1);
+    td.rc = FGMM_OK; // (finish() reports a range as "not covered" otherwise)
+    td.i = n;
+    td.finish();
+    if (rc != FGMM_OK) ok = false, hard = sgm == 0 ? rc : hard; // segment 0 starts from the stream's own head: its errors are real
+    else if (sgm < n_ckpt && (x1 != ckpt[sgm].x || pos1 != ckpt[sgm].pos)) ok = false;
+  }
+  if (ok) {
+    if (verified_out) *verified_out = 1;
+    return FGMM_OK;
+  }
+  if (hard != FGMM_OK) return hard;
+  return fgmm_rans_decode_tab(encoded, encoded_len, hdr, hdr_form, blk_off, tl, rows, rows_len, n, max_bs, flags, out_symbols);
 }
 
 int fgmm_rans_encode_symtab2(const uint32_t *packed0, const int32_t *symbols0_or_null, int64_t n0, const uint32_t *packed1,

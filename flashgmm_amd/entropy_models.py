@@ -27,7 +27,41 @@ from torch import Tensor
 
 from . import _lib
 
-__all__ = ["GaussianMixtureConditional", "EntropyBottleneckCoder"]
+__all__ = ["GaussianMixtureConditional", "EntropyBottleneckCoder", "CheckpointedBytes"]
+
+CKPT_DTYPE = np.dtype([("x", "<u8"), ("pos", "<u8")])  # fgmm_ckpt
+
+class CheckpointedBytes(bytes):
+    """A bitstream — the reference's, byte for byte: it IS a ``bytes`` object and compares equal to one — that also carries
+    its encoder's out-of-band CHECKPOINTS (``include/flashgmm_amd.h``: ``fgmm_ckpt``): the coder state and the stream
+    position before every ``stride``-th symbol.  ``GaussianMixtureConditional.decompress`` decodes the segments between them
+    on all host workers instead of one (every segment is verified against the next checkpoint; wrong ones cost a
+    sequential decode, never a wrong symbol).  Anything that only knows ``bytes`` — the reference's decoder, a file — sees
+    the plain stream; ``flashgmm_amd.container`` stores the checkpoints next to it."""
+
+    def __new__(cls, data: bytes, ckpt: np.ndarray, stride: int):
+        self = super().__new__(cls, data)
+        if not (isinstance(ckpt, np.ndarray) and ckpt.dtype == CKPT_DTYPE and ckpt.flags.c_contiguous):
+            ckpt = np.ascontiguousarray(ckpt, dtype=CKPT_DTYPE)
+        self.ckpt = ckpt  # [(x: u64, pos: u64)], entry k = before symbol (k + 1) * stride
+        self.ckpt_stride = int(stride)
+        self._ckpt_addr = ckpt.ctypes.data if len(ckpt) else 0  # (ndarray.ctypes is slow: taken once)
+        return self
+
+    def __reduce__(self):
+        return (CheckpointedBytes, (bytes(self), self.ckpt, self.ckpt_stride))
+
+
+def _take_ckpt(ptr: int, n: int) -> np.ndarray:
+    """copy a library-allocated fgmm_ckpt[n] out and free it"""
+    if not ptr or n <= 0:
+        return _NO_CKPT
+    a = np.frombuffer((C.c_char * (16 * n)).from_address(ptr), dtype=CKPT_DTYPE).copy()
+    _lib.lib().fgmm_free(ptr)
+    return a
+
+
+_NO_CKPT = np.zeros(0, CKPT_DTYPE)
 
 
 def _plane_view(t: Tensor, K: int) -> Tuple[Tensor, int, int]:
@@ -54,11 +88,16 @@ class GaussianMixtureConditional(nn.Module):
     """Entropy model of a K-component Gaussian mixture conditional; ``compress`` / ``decompress`` only need K = 4
     (the reference's coder is bound for K = 4 only, rans_interface.cpp:60,982)."""
 
-    def __init__(self, K: int = 4, mode=None, clamp_scales: bool = True):
+    def __init__(self, K: int = 4, mode=None, clamp_scales: bool = True, checkpoint_stride: int = 0):
         super().__init__()
         self.K = int(K)
         self.mode = mode  # None -> APPROX_MODE env var at call time
         self.clamp_scales = bool(clamp_scales)  # entropy_models.py:817 clamp(0.11, 256)
+        # > 0: compress() returns CheckpointedBytes (the same bytes + out-of-band checkpoints every that many symbols, a power
+        # of two >= 256), which decompress() decodes on all host workers; 0 (the default): plain bytes, as the reference's
+        self.checkpoint_stride = int(checkpoint_stride)
+        if self.checkpoint_stride and (self.checkpoint_stride < 256 or self.checkpoint_stride & (self.checkpoint_stride - 1)):
+            raise ValueError("checkpoint_stride must be 0 or a power of two >= 256")
 
     # ------------------------------------------------------------------------------------------------
     def _mode(self) -> int:
@@ -159,6 +198,7 @@ class GaussianMixtureConditional(nn.Module):
         zb = torch.empty((N, M), dtype=torch.int64)
         items["yq_out"] = np.uint64(yq.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * h * w * 4)
         items["zero_bitmap"] = np.uint64(zb.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * 8)
+        items["ckpt_stride"] = self.checkpoint_stride
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = _lib.lib().fgmm_gmc_compress_batch(_lib.ctx(dev.index if dev.index is not None else -1), stream,
                                                 C.cast(items.ctypes.data, C.POINTER(_lib.fgmm_item)), N, self._mode(),
@@ -166,10 +206,13 @@ class GaussianMixtureConditional(nn.Module):
         _lib.check(rc, "GaussianMixtureConditional.compress")
         ptrs, lens, amax = items["bytes"].tolist(), items["bytes_len"].tolist(), items["abs_max"].tolist()
         string_at, free = C.string_at, _lib.lib().fgmm_free
+        cks = list(zip(items["ckpt"].tolist(), items["n_ckpt"].tolist())) if self.checkpoint_stride else None
         out = []
         for i, (q, b) in enumerate(zip(yq.unbind(0), zb.unbind(0))):
             data = string_at(ptrs[i], lens[i])
             free(ptrs[i])
+            if cks is not None:
+                data = CheckpointedBytes(data, _take_ckpt(*cks[i]), self.checkpoint_stride)
             out.append(((data, amax[i], b), q))
         return out
 
@@ -193,6 +236,9 @@ class GaussianMixtureConditional(nn.Module):
         y_hat = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
         items["bytes"] = np.frombuffer(bufs, dtype=np.uint64)
         items["bytes_len"] = [len(d) for d in data]
+        if any(isinstance(d, CheckpointedBytes) for d in data):  # out-of-band checkpoints of the streams that carry them
+            cks = [(d._ckpt_addr, len(d.ckpt), d.ckpt_stride) if isinstance(d, CheckpointedBytes) else (0, 0, 0) for d in data]
+            items["ckpt"], items["n_ckpt"], items["ckpt_stride"] = (np.array(c, dtype=np.uint64) for c in zip(*cks))
         items["abs_max"] = np.asarray(abs_maxes, dtype=np.int64)
         items["yq_out"] = np.uint64(y_hat.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * h * w * 4)
         items["zero_bitmap"] = np.uint64(zb.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * 8)
@@ -232,6 +278,7 @@ class GaussianMixtureConditional(nn.Module):
             yq = torch.empty_like(keep[-1])
             zb = torch.empty(M, dtype=torch.int64)
             it.yq_out, it.zero_bitmap = yq.data_ptr(), zb.data_ptr()
+            it.ckpt_stride = self.checkpoint_stride
             items[i] = it
             outs.append(yq)
             bitmaps.append(zb)
@@ -244,6 +291,8 @@ class GaussianMixtureConditional(nn.Module):
         res = []
         for i in range(n_items):
             data = _lib.take_bytes(items[i].bytes, items[i].bytes_len)
+            if self.checkpoint_stride:
+                data = CheckpointedBytes(data, _take_ckpt(items[i].ckpt, int(items[i].n_ckpt)), self.checkpoint_stride)
             res.append(((data, int(items[i].abs_max), bitmaps[i]), outs[i].view_as(ys[i])))
         return res
 
@@ -283,6 +332,8 @@ class GaussianMixtureConditional(nn.Module):
             it.yq_out, it.zero_bitmap = y_hat.data_ptr(), zb.data_ptr()
             it.abs_max = int(abs_maxes[i])
             it.bytes, it.bytes_len = C.cast(buf, C.c_void_p), len(data)
+            if isinstance(data, CheckpointedBytes) and len(data.ckpt):
+                it.ckpt, it.n_ckpt, it.ckpt_stride = data._ckpt_addr, len(data.ckpt), data.ckpt_stride
             items[i] = it
             keep += [zb, buf, data]
             outs.append(y_hat)

@@ -108,6 +108,9 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor).
  *                       14 gives the fewest bytes (55.7 B/latent on Kodak-like tables against 57.6) but costs the host
  *                       decoders more than the PCIe time it saves when 16 threads serve one GPU
+ *   "ckpt_decode" [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded in segments, on all workers: 0 = when the
+ *                       call has fewer bitstreams than workers (else every worker has a bitstream anyway), 1 = always,
+ *                       2 = never (the notes are ignored)
  *   "trace"       [0]   1: phase timestamps of every batched call on stderr, 2: + per-bitstream job timeline */
 int fgmm_ctx_set_option(fgmm_ctx *ctx, const char *name, int64_t value);
 int fgmm_ctx_get_option(fgmm_ctx *ctx, const char *name, int64_t *value_out);
@@ -185,6 +188,20 @@ int fgmm_gmc_decompress(fgmm_ctx *ctx, void *stream, const uint8_t *encoded, siz
                         const int64_t *zero_bitmap, const fgmm_params *params, int M, int K, int64_t hw, int mode,
                         int clamp_scales, float *y_hat_out);
 
+/* Checkpoints: a SEEKABLE bitstream without touching the bitstream.  A rANS stream decodes sequentially - symbol i needs the
+ * coder state symbol i-1 left - which makes ONE bitstream one host thread's work (1.1 - 1.5 ms for a Kodak half, 27 ms for
+ * ELIC's largest group of a 4K image) however many threads idle.  The decoder's state before symbol i is the encoder's state
+ * after it has encoded symbol i on its reversed walk, so the encoder can note (state, words the decoder has read by then)
+ * every `stride` symbols, OUT OF BAND: `bytes` stays the reference's stream, byte for byte.  A decoder handed the notes
+ * decodes the segments between them on as many host workers as it has; a stream without notes (the reference's own) decodes
+ * sequentially as ever.  The notes are VERIFIED, never trusted: a segment must end exactly in the next note's state and
+ * position - then, by induction from the stream's head, it did the sequential decoder's work; one mismatch and the whole
+ * stream is decoded sequentially instead.  16 bytes per `stride` symbols (stride 4096: 0.3 % of a Kodak stream). */
+typedef struct {
+  uint64_t x;   /* coder state before decoding symbol (k + 1) * stride */
+  uint64_t pos; /* 32-bit renormalisation words read by then (the stream's 8-byte head not counted) */
+} fgmm_ckpt;
+
 /* Batched forms: `count` independent streams (images / checkerboard halves) in one call.  Kernels for all
  * items are enqueued first on the context's HIP streams, tables come back by pinned async copies, and the host
  * worker threads run one rANS state machine per item.  Item i uses y[i], params[i], ... ; outputs as above. */
@@ -199,6 +216,11 @@ typedef struct {
   uint8_t *bytes;          /* compress: out (fgmm_free);  decompress: in */
   size_t bytes_len;
   int32_t status;          /* per-item fgmm_status */
+  int32_t ckpt_stride;     /* compress in: note a checkpoint every this many symbols (a power of two >= 256; 0 = none).
+                              decompress in: the stride `ckpt` was noted with (0 / ckpt NULL: sequential decode) */
+  fgmm_ckpt *ckpt;         /* compress out (fgmm_free; NULL when none): (coded symbols - 1) / ckpt_stride entries;
+                              decompress in */
+  int64_t n_ckpt;          /* compress out / decompress in */
 } fgmm_item;
 
 int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
@@ -294,6 +316,12 @@ int fgmm_rans_encode_symtab2(const uint32_t *packed0, const int32_t *symbols0_or
 int fgmm_rans_encode_symtab_n(int ways, const uint32_t *const *packed, const int32_t *const *symbols_or_null, const int64_t *n,
                               uint8_t **out, size_t *out_len);
 
+/* ... noting checkpoints every `stride` symbols (a power of two; see fgmm_ckpt): ckpt_out[fgmm_ckpt_count(n, stride)].  The
+ * bitstream is the one fgmm_rans_encode_symtab returns. */
+int64_t fgmm_ckpt_count(int64_t n, int64_t stride); /* (n - 1) / stride, 0 for stride <= 0 */
+int fgmm_rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t stride, uint8_t **out,
+                                 size_t *out_len, fgmm_ckpt *ckpt_out);
+
 /* Host, integer only: edge tables (4-byte headers, rows sequential in latent order, as fgmm_build_cdftab_hip lays them
  * out) -> symbols; the reference's bisection with every float evaluation replaced by a look-up in F_i.  pool_len bounds
  * every row access: a malformed table (cnt = 0, a row past the pool, an inconsistent Elias-Fano row) yields
@@ -306,6 +334,13 @@ int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const ui
 int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void *hdr, int hdr_form, const uint32_t *blk_off,
                          int32_t tl, const uint8_t *rows, uint64_t rows_len, int64_t n, int32_t max_bs, int flags,
                          int32_t *out_symbols);
+/* The same from a checkpointed stream (block-placed rows: blk_off != NULL), segment by segment on the calling thread - the
+ * batched decoder runs the segments on its workers.  Every segment is verified against the next checkpoint; the first mismatch
+ * (wrong or hostile notes) makes the whole stream a sequential decode: the symbols are fgmm_rans_decode_tab's in every case.
+ * *verified_out (may be NULL): 1 when every checkpoint held. */
+int fgmm_rans_decode_tab_ckpt(const uint8_t *encoded, size_t encoded_len, const void *hdr, int hdr_form, const uint32_t *blk_off,
+                              int32_t tl, const uint8_t *rows, uint64_t rows_len, int64_t n, int32_t max_bs, int flags,
+                              const fgmm_ckpt *ckpt, int64_t n_ckpt, int64_t stride, int32_t *out_symbols, int32_t *verified_out);
 /* Two tables -> two symbol arrays, decoded by the calling thread latent by latent in turn (the batched decoder does this
  * when there are more bitstreams than idle workers: a bitstream's decode is one dependency chain, two chains share a
  * core).  Each output is exactly what fgmm_rans_decode_tab gives for its table; returns the first error of the two. */

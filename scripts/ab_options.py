@@ -9,7 +9,7 @@ schedule = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("codec", "all") 
 cfgs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv) for a in sys.argv[2:]] or [{}]
 lat = [T.make_latent(i) for i in range(48)]
 ys, ss, ms, ws = (torch.cat([torch.from_numpy(l[k]) for l in lat]).to(dev) for k in range(4))
-gmc = GaussianMixtureConditional(K=4, mode="polya")
+gmc = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=int(os.environ.get("CKPT", "0")))
 defaults = {k: _lib.get_option(0, k) for c in cfgs for k in c}
 def step():
     t0 = time.perf_counter()

@@ -5,11 +5,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
 dev = torch.device("cuda:0")
+ck_stride = 0
 for kv in sys.argv[1:]:
-    _lib.set_option(0, kv.split("=")[0], int(kv.split("=")[1]))
+    if kv.startswith("ckpt="):
+        ck_stride = int(kv.split("=")[1])
+    else:
+        _lib.set_option(0, kv.split("=")[0], int(kv.split("=")[1]))
 lat = [T.make_latent(i) for i in range(2)]
 ys, ss, ms, ws = (torch.cat([torch.from_numpy(l[k]) for l in lat]).to(dev) for k in range(4))
-gmc = GaussianMixtureConditional(K=4, mode="polya")
+gmc = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=ck_stride)
 L = _lib.lib()
 native = {"c": [], "d": []}
 for name, key in (("fgmm_gmc_compress_batch", "c"), ("fgmm_gmc_decompress_batch", "d")):

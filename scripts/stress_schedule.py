@@ -1,5 +1,5 @@
 """Dev aid (GPU): randomized stress of the decode scheduler - random batches (1..40 items, tiny to Kodak-sized, some empty,
-occasionally one truncated bitstream) under random pipeline options and worker counts; every result is checked against the
+occasionally one truncated bitstream, plain or checkpointed streams) under random pipeline options and worker counts; every result is checked against the
 encoder's y_q, every truncated batch must raise.  python scripts/stress_schedule.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,10 +23,11 @@ while time.time() < t_end:
     _lib.set_threads(0, threads)
     opts = dict(pieces=int(rng.integers(1, 17)), dec_first=int(rng.integers(1, 10)), dec_group=int(rng.choice([0, 0, 1, 3, 7])),
                 dec_pair=int(rng.integers(0, 2)), ef_min=int(rng.choice([14, 33, 49, 200])), ef_rows=int(rng.integers(0, 3)),
-                enc_ways=int(rng.integers(0, 5)))
+                enc_ways=int(rng.integers(0, 5)), ckpt_decode=int(rng.integers(0, 3)))
+    ck_stride = int(rng.choice([0, 0, 256, 1024, 4096]))  # checkpointed streams: segments on the workers
     for k, v in opts.items(): _lib.set_option(0, k, v)
     for mode in ("polya", "as", "logistic"):
-        gmc = GaussianMixtureConditional(K=4, mode=mode)
+        gmc = GaussianMixtureConditional(K=4, mode=mode, checkpoint_stride=ck_stride)
         n = int(rng.integers(1, 41))
         items = [latent(int(rng.integers(0, 12)), shapes[int(rng.choice(len(shapes), p=[.3, .2, .1, .1, .1, .1, .1]))], float(rng.choice([0.0, 0.1, 1.0], p=[.2, .6, .2])))
                  for _ in range(n)]
@@ -38,7 +39,8 @@ while time.time() < t_end:
             assert torch.equal(outs[i], res[i][1]), (opts, threads, mode, i)
         victims = [i for i in range(n) if len(strings[i]) > 64]
         if victims and rng.random() < 0.5:
-            bad = list(strings); v = int(rng.choice(victims)); bad[v] = bad[v][:16]
+            bad = list(strings); v = int(rng.choice(victims))
+            bad[v] = type(bad[v])(bad[v][:16], bad[v].ckpt, bad[v].ckpt_stride) if ck_stride and rng.random() < 0.5 else bytes(bad[v][:16])
             try:
                 gmc.decompress_batch(bad, [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
                 raise SystemExit(f"truncated stream decoded: {opts} {threads} {mode}")

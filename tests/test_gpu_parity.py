@@ -853,6 +853,123 @@ def test_config4_images_in_flight_stage_major_equals_image_by_image(oracle):
     assert calls == [1] * 20
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_checkpointed_streams_are_the_same_bytes_and_decode_on_all_workers(oracle, mode):
+    """``GaussianMixtureConditional(checkpoint_stride=S)``: ``compress`` returns ``CheckpointedBytes`` — the reference's
+    bitstream (== plain ``compress``, == the oracle) plus out-of-band checkpoints; ``decompress`` decodes the segments between
+    them on all host workers and gives the sequential decoder's result: for a batch, for ONE bitstream (the case checkpoints
+    exist for), with zero channels, with bypass-coded symbols, for stacked and listed inputs; plain bytes still decode."""
+    from flashgmm_amd import CheckpointedBytes
+
+    lat = [T.make_latent(300 + i, M=M, h=h, w=w, zero_frac=zf) for i, (M, h, w, zf) in
+           enumerate([(192, 32, 24, 0.15), (48, 16, 8, 0.0), (192, 32, 24, 0.0), (7, 5, 3, 0.3), (64, 16, 12, 0.5)])]
+    lat[2] = (lat[2][0] * np.float32(1.0), *lat[2][1:])
+    lat[2][0].reshape(-1)[::53] *= 50  # bypass-coded symbols between the checkpoints
+    dev = [[dv(a) for a in l] for l in lat]
+    ys, ss, ms, ws = ([d[k] for d in dev] for k in range(4))
+    plain = GaussianMixtureConditional(K=4, mode=mode)
+    ck = GaussianMixtureConditional(K=4, mode=mode, checkpoint_stride=1024)
+    r0 = plain.compress_batch(ys, ss, ms, ws)
+    r1 = ck.compress_batch(ys, ss, ms, ws)
+    for (a, b, l) in zip(r0, r1, lat):
+        assert type(a[0][0]) is bytes and isinstance(b[0][0], CheckpointedBytes) and b[0][0] == a[0][0]
+        assert a[0][1] == b[0][1] and torch.equal(a[0][2], b[0][2]) and torch.equal(a[1], b[1])
+        n = int(b[0][2].sum()) * l[0].shape[2] * l[0].shape[3]
+        assert len(b[0][0].ckpt) == max(n - 1, 0) // 1024 and b[0][0].ckpt_stride == 1024
+    sym, s_, m_, w_, am, zbm, yqn = T.to_coder_inputs(*lat[1])
+    assert bytes(r1[1][0][0]) == oracle.encode_gmm(mode, sym, s_, m_, w_)
+    strings, ams, zbs = [r[0][0] for r in r1], [r[0][1] for r in r1], [r[0][2] for r in r1]
+    # (threads, option ckpt_decode: 0 = segments when the call has fewer bitstreams than workers, 1 = always, 2 = never)
+    for threads, how in ((16, 0), (3, 1), (1, 1), (3, 0), (16, 2)):
+        _lib.set_threads(0, threads)
+        _lib.set_option(0, "ckpt_decode", how)
+        try:
+            out = ck.decompress_batch(strings, ams, zbs, ss, ms, ws)  # segments on the workers
+            for o, r in zip(out, r1):
+                assert torch.equal(o, r[1])
+            one = ck.decompress(strings[0], ams[0], zbs[0], ss[0], ms[0], ws[0])  # ONE bitstream, 124 segments
+            assert torch.equal(one, r1[0][1])
+        finally:
+            _lib.set_threads(0, 0)
+            _lib.set_option(0, "ckpt_decode", 0)
+    out = plain.decompress_batch([bytes(b) for b in strings], ams, zbs, ss, ms, ws)  # the same streams without their notes
+    for o, r in zip(out, r1):
+        assert torch.equal(o, r[1])
+    # stacked input (one tensor per operand)
+    st = [torch.cat([dev[0][k], dev[2][k]]) for k in range(4)]
+    rs = ck.compress_batch(*st)
+    assert [bytes(x[0][0]) for x in rs] == [bytes(r1[0][0][0]), bytes(r1[2][0][0])] and all(isinstance(x[0][0], CheckpointedBytes) for x in rs)
+    outs = ck.decompress_batch([x[0][0] for x in rs], [x[0][1] for x in rs], [x[0][2] for x in rs], *st[1:])
+    assert torch.equal(outs[0], rs[0][1]) and torch.equal(outs[1], rs[1][1])
+
+
+def test_checkpointed_codec_result_through_the_container():
+    """the group codec over checkpointed entropy models: the ten strings of an ELIC-shaped latent are CheckpointedBytes
+    equal to the plain codec's, decode to the same y_hat (one bitstream per call: the segments run on all workers), and
+    survive the byte container with their checkpoints"""
+    from flashgmm_amd import CheckpointedBytes, container as Cn
+    from flashgmm_amd.latent_codecs import ChannelGroupsLatentCodec, CheckerboardLatentCodec, GaussianMixtureConditionalLatentCodec
+
+    groups, c_side, h, w = [16, 16, 32, 64, 192], 8, 34, 60
+    Ctx, Par = T.exact_modules()
+
+    def build(stride):
+        latent = {f"y{k}": CheckerboardLatentCodec(latent_codec={"y": GaussianMixtureConditionalLatentCodec(K=4, mode="polya", checkpoint_stride=stride)},
+                                                   context_prediction=Ctx(g, 2 * g), entropy_parameters=Par(2 * g + (k > 0) * 2 * g + c_side, g))
+                  for k, g in enumerate(groups)}
+        chctx = {f"y{k}": Ctx(sum(groups[:k]), 2 * groups[k]) for k in range(1, len(groups))}
+        return ChannelGroupsLatentCodec(groups=groups, channel_context=chctx, latent_codec=latent)
+
+    y, side = T.exact_codec_inputs(81, sum(groups), c_side, h, w)
+    yd, sided = dv(y), dv(side)
+    plain, noted = build(0), build(256)
+    e0, e1 = plain.compress(yd, sided), noted.compress(yd, sided)
+    assert all(type(a[0]) is bytes and isinstance(b[0], CheckpointedBytes) and a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2])
+               for a, b in zip(e0["strings"], e1["strings"]))
+    assert sum(len(b[0].ckpt) for b in e1["strings"]) > 100 and torch.equal(e0["y_hat"], e1["y_hat"])
+    d1 = noted.decompress(e1["strings"], e1["shape"], sided)
+    assert torch.equal(d1["y_hat"], e1["y_hat"])
+    blob = Cn.pack(e1["strings"], e1["shape"])
+    s2, shape2 = Cn.unpack(blob, device="cuda")
+    assert all(isinstance(s_[0], CheckpointedBytes) for s_ in s2)
+    assert torch.equal(plain.decompress(s2, shape2, sided)["y_hat"], e1["y_hat"])  # any decoder of this library uses the notes it is given
+    assert Cn.side_info_bytes(e1["strings"], e1["shape"]) - Cn.side_info_bytes(e0["strings"], e0["shape"]) == sum(8 + 16 * len(b[0].ckpt) for b in e1["strings"])
+
+
+def test_wrong_checkpoints_cost_a_sequential_decode_never_a_wrong_symbol():
+    """checkpoints are verified against one another segment by segment: flipped states, shifted positions, another stream's
+    notes, a wrong stride — the result is the sequential decoder's every time; a truncated stream is still an error"""
+    from flashgmm_amd import CheckpointedBytes
+
+    rng = np.random.default_rng(77)
+    y, sg, mu, pi = T.make_latent(311, M=96, h=32, w=24, zero_frac=0.1)
+    t = [dv(a) for a in (y, sg, mu, pi)]
+    y2, sg2, mu2, pi2 = T.make_latent(312, M=96, h=32, w=24, zero_frac=0.1)
+    gmc = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=512)
+    (b, am, zb), yq = gmc.compress(*t)
+    (b2, _, _), _ = gmc.compress(*[dv(a) for a in (y2, sg2, mu2, pi2)])
+    assert len(b.ckpt) > 50
+    for trial in range(10):
+        ck = b.ckpt.copy()
+        k = int(rng.integers(0, len(ck)))
+        if trial % 5 == 0:
+            ck["x"][k] ^= np.uint64(1 << int(rng.integers(0, 62)))
+        elif trial % 5 == 1:
+            ck["pos"][k] += np.uint64(1)
+        elif trial % 5 == 2:
+            ck["pos"][k] = np.uint64(1 << 45)
+        elif trial % 5 == 3:
+            ck = b2.ckpt[:len(ck)].copy() if len(b2.ckpt) >= len(ck) else ck[::-1].copy()
+        else:
+            ck["x"][:] = ck["x"][::-1].copy()
+        bad = CheckpointedBytes(bytes(b), ck, 512)
+        assert torch.equal(gmc.decompress(bad, am, zb, *t[1:]), yq), trial
+    assert torch.equal(gmc.decompress(CheckpointedBytes(bytes(b), b.ckpt, 1024), am, zb, *t[1:]), yq)  # wrong stride: ignored
+    assert torch.equal(gmc.decompress(CheckpointedBytes(bytes(b), b.ckpt[:-1], 512), am, zb, *t[1:]), yq)  # wrong count: ignored
+    with pytest.raises(RuntimeError):
+        gmc.decompress(CheckpointedBytes(bytes(b)[: len(b) // 2 & ~3], b.ckpt, 512), am, zb, *t[1:])
+
+
 def test_config0_256x256_plumbing(oracle):
     """BASELINE configs[0]: one 256x256 image -> y [1,192,16,16], halves [1,192,16,8]; all three modes."""
     for mode in MODES:

@@ -5,6 +5,7 @@
   * the integer-only host rANS coder (fgmm_rans_encode_symtab / fgmm_rans_decode_cdftab) reproduces the
     reference's streams / symbols from tables — tables here come from the oracle, formatted by tests/helpers.py.
 """
+import ctypes as C
 import hashlib
 import json
 import os
@@ -580,3 +581,101 @@ def test_host_budget_without_a_quota_is_the_affinity_mask(tmp_path):
     _tree(tmp_path, {"/proc/self/cgroup": "0::/\n", "/sys/fs/cgroup/cpu.max": "max 100000\n"})
     budget, threads = _budget_in_child(tmp_path)
     assert budget["quota"] is None and budget["cpus"] == budget["affinity"] and threads == min(16, budget["affinity"])
+
+
+# ---- checkpoints: seekable streams without touching the bitstream (fgmm_ckpt) ---------------------------------
+def _ckpt_encode(L, packed, symbols, stride):
+    from flashgmm_amd._lib import fgmm_ckpt
+    n = len(packed)
+    n_ck = L.fgmm_ckpt_count(n, stride)
+    ck = (fgmm_ckpt * max(n_ck, 1))()
+    out, ln = C.c_void_p(), C.c_size_t()
+    packed = np.ascontiguousarray(packed, np.uint32)
+    sy = np.ascontiguousarray(symbols, np.int32) if symbols is not None else None
+    rc = L.fgmm_rans_encode_symtab_ckpt(packed.ctypes.data_as(C.c_void_p), sy.ctypes.data_as(C.c_void_p) if sy is not None else None, n, stride,
+                                        C.byref(out), C.byref(ln), C.cast(ck, C.c_void_p))
+    assert rc == 0
+    data = C.string_at(out, ln.value)
+    L.fgmm_free(out)
+    return data, ck, n_ck
+
+
+def _ckpt_decode(L, enc, hdr, pool, max_bs, bo, tl, ck, n_ck, stride):
+    hdr = np.ascontiguousarray(hdr)
+    pool = np.ascontiguousarray(np.asarray(pool).view(np.uint8))
+    bo = np.ascontiguousarray(bo, np.uint32)
+    out = np.empty(len(hdr), np.int32)
+    ok = C.c_int32(-1)
+    rc = L.fgmm_rans_decode_tab_ckpt(enc, len(enc), hdr.ctypes.data_as(C.c_void_p), hdr.dtype.itemsize, bo.ctypes.data_as(C.c_void_p), tl,
+                                     pool.ctypes.data_as(C.c_void_p), len(pool), len(hdr), max_bs, 0, C.cast(ck, C.c_void_p), n_ck, stride,
+                                     out.ctypes.data_as(C.c_void_p), C.byref(ok))
+    return rc, out, ok.value
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_checkpoints_leave_the_bitstream_alone_and_make_it_seekable(oracle, mode):
+    """The encoder notes (coder state, words read) every `stride` symbols OUT OF BAND: the bitstream is the reference's, byte
+    for byte, whatever the stride; a decoder that starts every segment from its note and ends it in the next one reproduces
+    the sequential decoder's symbols (bypass-coded symbols and the ragged last segment included); block-placed tables in
+    shuffled order, every header form."""
+    L = _lib.lib()
+    y, sg, mu, pi = T.make_latent(5, M=40, h=16, w=8)
+    y = y.copy()
+    y.reshape(-1)[::37] *= 40  # bypass-coded symbols (several renormalisation words each) between the notes
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    enc = oracle.encode_gmm(mode, sym, s, m, w)
+    packed = oracle.symtab(mode, sym, s, m, w)
+    max_bs = abs_max + 1
+    tab = oracle.cdftab(mode, s, m, w, max_bs)
+    n = len(sym)
+    for stride, tl in ((256, 16), (1024, 48), (4096, 32)):
+        data, ck, n_ck = _ckpt_encode(L, packed, sym, stride)
+        assert data == enc and n_ck == (n - 1) // stride and n_ck >= 1
+        assert all(ck[k].x >= (1 << 31) for k in range(n_ck)) and all(ck[k].pos <= ck[k + 1].pos for k in range(n_ck - 1))
+        hdr, bo, pool, used = trim_full_table(tab, max_bs, form=helpers.hdr_form(max_bs), tl=tl, shuffle_seed=3)
+        rc, out, ok = _ckpt_decode(L, enc, hdr, pool, max_bs, bo, tl, ck, n_ck, stride)
+        assert rc == 0 and ok == 1 and np.array_equal(out, sym), (stride, tl)
+    # the interleaved encoders note the same checkpoints
+    from flashgmm_amd._lib import fgmm_ckpt
+    assert C.sizeof(fgmm_ckpt) == 16
+
+
+def test_checkpoints_are_verified_never_trusted(oracle):
+    """Wrong notes - a flipped state bit, a shifted position, notes of ANOTHER stream, a wrong count - cannot change the result:
+    the segment that starts from a wrong note does not end in the next one, and the stream is decoded sequentially."""
+    from flashgmm_amd._lib import fgmm_ckpt
+
+    L = _lib.lib()
+    rng = np.random.default_rng(4)
+    y, sg, mu, pi = T.make_latent(6, M=24, h=16, w=8)
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    packed = oracle.symtab("polya", sym, s, m, w)
+    max_bs = abs_max + 1
+    tab = oracle.cdftab("polya", s, m, w, max_bs)
+    hdr, bo, pool, used = trim_full_table(tab, max_bs, form=helpers.hdr_form(max_bs), tl=32, shuffle_seed=9)
+    stride = 512
+    enc, ck, n_ck = _ckpt_encode(L, packed, sym, stride)
+    assert n_ck >= 4
+    rc, out, ok = _ckpt_decode(L, enc, hdr, pool, max_bs, bo, 32, ck, n_ck, stride)
+    assert rc == 0 and ok == 1 and np.array_equal(out, sym)
+    for trial in range(12):
+        bad = (fgmm_ckpt * n_ck)()
+        for k in range(n_ck):
+            bad[k].x, bad[k].pos = ck[k].x, ck[k].pos
+        k = int(rng.integers(0, n_ck))
+        if trial % 4 == 0:
+            bad[k].x ^= 1 << int(rng.integers(0, 63))
+        elif trial % 4 == 1:
+            bad[k].pos = max(0, bad[k].pos + int(rng.choice([-1, 1, 7])))
+        elif trial % 4 == 2:
+            bad[k].pos = 1 << 40  # far outside the stream
+        else:
+            bad[k].x = int(rng.integers(1 << 31, 1 << 62))
+        rc, out, ok = _ckpt_decode(L, enc, hdr, pool, max_bs, bo, 32, bad, n_ck, stride)
+        assert rc == 0 and ok == 0 and np.array_equal(out, sym), trial
+    # a wrong count / stride is not even tried
+    rc, out, ok = _ckpt_decode(L, enc, hdr, pool, max_bs, bo, 32, ck, n_ck - 1, stride)
+    assert rc == 0 and ok == 0 and np.array_equal(out, sym)
+    # a truncated stream is an error with or without notes
+    rc, out, ok = _ckpt_decode(L, enc[:len(enc) // 2 & ~3], hdr, pool, max_bs, bo, 32, ck, n_ck, stride)
+    assert rc == 5
