@@ -164,7 +164,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -807,11 +807,18 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   const size_t o_counters = ar.take(kCounterBytes * (size_t)std::max(n_units, 1), 256);
   const size_t upload_bytes = o_counters;
   // events: per unit [kernel done][counters landed] (this thread waits, briefly) and [tables landed] (the workers wait)
+  // Workers SLEEP on the copies' events (sixteen spinning waiters exceed the box's CPU quota: ensure_events) - except in a small
+  // call (one image: a few hundred microseconds in all), where being woken by an interrupt costs as much as the work itself:
+  // there they wait on plain events, which the runtime polls
+  int64_t lat_total = 0;
+  for (auto &it : items) lat_total += it.n;
+  const bool spin = ctx->opt.spin_lat < 0 ? false : lat_total <= ctx->opt.spin_lat;
   if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off)) ||
-      (rc = ctx->ensure_events(2 * (size_t)std::max(n_units, 1), (size_t)n_units + 2)) || (rc = ctx->ensure_stage(stage_total)))
+      (rc = ctx->ensure_events((spin ? 3 : 2) * (size_t)std::max(n_units, 1) + 2, (size_t)n_units + 2)) || (rc = ctx->ensure_stage(stage_total)))
     return rc;
   ctx->chunks_reset();
-  hipEvent_t *ev_kernel = ctx->events.data(), *ev_counters = ev_kernel + n_units, *ev_landed = ctx->sleep_events.data();
+  hipEvent_t *ev_kernel = ctx->events.data(), *ev_counters = ev_kernel + n_units,
+             *ev_landed = spin ? ev_counters + n_units : ctx->sleep_events.data();
 
   // ---- channel lists, descriptors ------------------------------------------------------------------------------------
   for (int i = 0; i < count; ++i) {
@@ -1360,6 +1367,7 @@ const OptName kOpts[] = {
     {"dec_pair", &fgmm_ctx::Opts::dec_pair, 0, 2, "FGMM_DEC_PAIR"},
     {"enc_ways", &fgmm_ctx::Opts::enc_ways, 0, kMaxEncWays, "FGMM_ENC_WAYS"},
     {"ckpt_decode", &fgmm_ctx::Opts::ckpt_decode, 0, 2, "FGMM_CKPT_DECODE"},
+    {"spin_lat", &fgmm_ctx::Opts::spin_lat, -1, 1ll << 40, "FGMM_SPIN_LAT"},
 };
 } // namespace
 
