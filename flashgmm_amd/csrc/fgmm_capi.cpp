@@ -164,7 +164,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -663,9 +663,147 @@ struct TempDevice {
 // on whichever worker is free, and what remains after the final copy is 1/36 of each bitstream.
 // Items whose half-width does not fit the single-pass kernel (tab_tl() == 0) take the generic two-pass kernels, one
 // item at a time, synchronously (8-byte headers past max_bs 16382).
+// can this item be decoded by the GPU's segment decoder?  (checkpoints exactly as an encoder notes them for this many symbols;
+// a float latent to write; a half-width whose window fits the kernel's 16-bit fields)
+static bool gpu_decodable(const DecItem &it, int64_t n) {
+  return it.y_hat && !it.sym_host_out && it.ckpt && it.n_ckpt > 0 && it.ckpt_stride >= 256 && !(it.ckpt_stride & (it.ckpt_stride - 1)) &&
+         n > 0 && it.n_ckpt == (n - 1) / it.ckpt_stride && it.n_ckpt < (1 << 24) && it.max_bs >= 0 && it.max_bs <= FGMM_MAX_BS_H4 &&
+         it.enc_len >= 8 && !(it.enc_len & 3) && it.stride_p == 1;
+}
+
+// Checkpointed bitstreams decoded ON THE GPU (segdec_kernel: one wave per segment, no tables, nothing but the bitstreams and
+// their notes crosses PCIe).  `which`: the items to decode; on return `redo` holds those whose segments did not all verify
+// (a row the kernel leaves to the reference's bisection, wrong notes): the caller sends them through the table path.
+int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items, const std::vector<int> &which, int mode,
+                     std::vector<int> &redo) {
+  Trace tr("decode-gpu", (int)ctx->opt.trace);
+  const int count = (int)which.size();
+  const bool clamped = items[which[0]].clamp != 0, f16 = items[which[0]].prm.dtype == FGMM_F16;
+  // ---- device workspace: [descs][segment list][per item: channel list | status | checkpoints | bitstream]
+  Arena ar;
+  int64_t n_segs = 0;
+  for (int k = 0; k < count; ++k) n_segs += items[which[k]].n_ckpt + 1;
+  const size_t o_descs = ar.take(sizeof(SegDesc) * (size_t)count);
+  const size_t o_segs = ar.take(sizeof(SegRef) * (size_t)n_segs);
+  struct Off {
+    size_t list, ckpt, words, status;
+  };
+  std::vector<Off> off((size_t)count);
+  for (int k = 0; k < count; ++k) {
+    DecItem &it = items[which[k]];
+    off[(size_t)k].list = ar.take(sizeof(int32_t) * (size_t)std::max(it.n_ch, 1), 16);
+    off[(size_t)k].ckpt = ar.take(sizeof(fgmm_ckpt) * (size_t)it.n_ckpt, 16);
+    off[(size_t)k].words = ar.take(it.enc_len, 16);
+  }
+  const size_t upload_bytes = ar.off;
+  const size_t o_status = ar.take(sizeof(uint32_t) * (size_t)n_segs, 256);
+  {
+    size_t at = o_status;
+    for (int k = 0; k < count; ++k) {
+      off[(size_t)k].status = at;
+      at += sizeof(uint32_t) * (size_t)(items[which[k]].n_ckpt + 1);
+    }
+  }
+  int rc;
+  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off))) return rc;
+  SegDesc *hd = reinterpret_cast<SegDesc *>(ctx->h_ws + o_descs);
+  SegRef *hs = reinterpret_cast<SegRef *>(ctx->h_ws + o_segs);
+  int64_t sat = 0;
+  for (int k = 0; k < count; ++k) {
+    DecItem &it = items[which[k]];
+    int32_t *list = reinterpret_cast<int32_t *>(ctx->h_ws + off[(size_t)k].list);
+    int r = 0;
+    for (int c = 0; c < it.M; ++c)
+      if (!it.zero_bitmap || it.zero_bitmap[c] != 0) list[r++] = c;
+    memcpy(ctx->h_ws + off[(size_t)k].ckpt, it.ckpt, sizeof(fgmm_ckpt) * (size_t)it.n_ckpt);
+    memcpy(ctx->h_ws + off[(size_t)k].words, it.enc, it.enc_len);
+    SegDesc &d = hd[k];
+    memset(&d, 0, sizeof d);
+    d.scales = it.prm.scales;
+    d.means = it.prm.means;
+    d.weights = it.prm.weights;
+    d.stride_k = it.prm.stride_k;
+    d.stride_c = it.prm.stride_c;
+    d.stride_p = it.stride_p;
+    d.hw = it.hw;
+    d.n = it.n;
+    d.chan_list = reinterpret_cast<const int32_t *>(ctx->d_ws + off[(size_t)k].list);
+    d.max_bs = it.max_bs;
+    d.clamp = it.clamp;
+    d.logits = (it.prm.flags & FGMM_PARAMS_LOGITS) ? 1 : 0;
+    d.words = reinterpret_cast<const uint32_t *>(ctx->d_ws + off[(size_t)k].words);
+    d.n_words = (int64_t)(it.enc_len / 4);
+    d.ckpt = reinterpret_cast<const fgmm_ckpt *>(ctx->d_ws + off[(size_t)k].ckpt);
+    d.n_ckpt = it.n_ckpt;
+    d.stride = it.ckpt_stride;
+    d.y_hat = it.y_hat;
+    d.status = reinterpret_cast<uint32_t *>(ctx->d_ws + off[(size_t)k].status);
+    for (int64_t sgm = 0; sgm <= it.n_ckpt; ++sgm) hs[sat++] = SegRef{k, (int32_t)sgm};
+    // channels without a coded symbol are zero in y_hat (entropy_models.py:903-908)
+    if (it.n_ch < it.M) HIP_TRY(hipMemsetAsync(it.y_hat, 0, sizeof(float) * (size_t)it.M * (size_t)it.hw, stream));
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
+  if ((rc = ctx->prof_begin(3, stream))) return rc;
+  LAUNCH_TRY(launch_segdec(reinterpret_cast<const SegDesc *>(ctx->d_ws + o_descs), reinterpret_cast<const SegRef *>(ctx->d_ws + o_segs), n_segs, mode,
+                           clamped, f16, stream));
+  if ((rc = ctx->prof_end(3, stream))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_status, ctx->d_ws + o_status, sizeof(uint32_t) * (size_t)n_segs, hipMemcpyDeviceToHost, stream));
+  tr.mark("enqueued");
+  HIP_TRY(hipStreamSynchronize(stream));
+  tr.mark("segments decoded");
+  for (int k = 0; k < count; ++k) {
+    DecItem &it = items[which[k]];
+    const uint32_t *st = reinterpret_cast<const uint32_t *>(ctx->h_ws + off[(size_t)k].status);
+    uint32_t worst = 0;
+    for (int64_t sgm = 0; sgm <= it.n_ckpt; ++sgm) worst = std::max(worst, st[sgm]);
+    if (worst != kSegOk) redo.push_back(which[k]);
+    else it.status = FGMM_OK, it.done.store(1);
+  }
+  ctx->stat[1] = 0; // no decode-side tables at all
+  ctx->stat[2] = ctx->stat[3] = 0;
+  for (int k = 0; k < count; ++k) ctx->stat[2] += (unsigned long long)items[which[k]].n;
+  return FGMM_OK;
+}
+
 int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items, int mode) {
   const int count = (int)items.size();
   if (count == 0) return FGMM_OK;
+  // ---- checkpointed bitstreams go to the GPU's segment decoder; whatever it does not take or cannot finish, and everything
+  // else, takes the table path below (option "gpu_decode": 0 / 1 = when possible, 2 = never)
+  if (ctx->opt.gpu_decode != 2) {
+    std::vector<int> gpu, rest;
+    for (int i = 0; i < count; ++i) {
+      DecItem &it = items[i];
+      int n_ch = 0;
+      for (int c = 0; c < it.M; ++c) n_ch += it.zero_bitmap ? (it.zero_bitmap[c] != 0) : 1;
+      it.n_ch = n_ch;
+      it.n = (int64_t)n_ch * it.hw;
+      (gpu_decodable(it, it.n) && it.clamp == items[0].clamp && it.prm.dtype == items[0].prm.dtype ? gpu : rest).push_back(i);
+    }
+    if (!gpu.empty()) {
+      std::vector<int> redo;
+      int rc = decode_batch_gpu(ctx, stream, items, gpu, mode, redo);
+      if (rc) return rc;
+      for (int i : redo) rest.push_back(i);
+      if (rest.empty()) return FGMM_OK;
+      // the rest through the table path, as a batch of its own (the notes of a bitstream that failed them are dropped)
+      std::vector<DecItem> sub(rest.size());
+      for (size_t k = 0; k < rest.size(); ++k) {
+        const DecItem &s0 = items[rest[k]];
+        DecItem &t = sub[k];
+        t.enc = s0.enc, t.enc_len = s0.enc_len, t.prm = s0.prm, t.stride_p = s0.stride_p, t.M = s0.M, t.hw = s0.hw, t.clamp = s0.clamp;
+        t.max_bs = s0.max_bs, t.zero_bitmap = s0.zero_bitmap, t.y_hat = s0.y_hat, t.sym_host_out = s0.sym_host_out;
+        const bool failed = std::find(redo.begin(), redo.end(), rest[k]) != redo.end();
+        if (!failed) t.ckpt = s0.ckpt, t.n_ckpt = s0.n_ckpt, t.ckpt_stride = s0.ckpt_stride;
+      }
+      const int64_t saved = ctx->opt.gpu_decode;
+      ctx->opt.gpu_decode = 2;
+      rc = decode_batch(ctx, stream, sub, mode);
+      ctx->opt.gpu_decode = saved;
+      for (size_t k = 0; k < rest.size(); ++k) items[rest[k]].status = sub[k].status;
+      return rc;
+    }
+  }
   Trace tr("decode", (int)ctx->opt.trace);
   int rc;
   if ((rc = ctx->ensure_streams())) return rc;
@@ -1368,6 +1506,7 @@ const OptName kOpts[] = {
     {"enc_ways", &fgmm_ctx::Opts::enc_ways, 0, kMaxEncWays, "FGMM_ENC_WAYS"},
     {"ckpt_decode", &fgmm_ctx::Opts::ckpt_decode, 0, 2, "FGMM_CKPT_DECODE"},
     {"spin_lat", &fgmm_ctx::Opts::spin_lat, -1, 1ll << 40, "FGMM_SPIN_LAT"},
+    {"gpu_decode", &fgmm_ctx::Opts::gpu_decode, 0, 2, "FGMM_GPU_DECODE"},
 };
 } // namespace
 

@@ -73,6 +73,27 @@ struct DecDesc {
   unsigned long long *blk_off;   // [n_ch*tiles] byte offset of each block's first row
 };
 
+// ---- GPU-side decode of CHECKPOINTED bitstreams (segdec_kernel): one wave per segment ---------------------------
+struct SegDesc {
+  const void *scales, *means, *weights; // float32 or float16 planes
+  int64_t stride_k, stride_c, stride_p;
+  int64_t hw;
+  int64_t n;                     // coded latents = n_ch * hw
+  const int32_t *chan_list;      // device [n_ch] source channel of compact channel j; null: identity
+  int32_t max_bs, clamp, logits, pad_;
+  const uint32_t *words;         // device copy of the bitstream: words[0..1] the coder's initial state, then the renormalisation words
+  int64_t n_words;               // all of them (>= 2)
+  const fgmm_ckpt *ckpt;         // device [n_ckpt]
+  int64_t n_ckpt, stride;
+  float *y_hat;                  // device [M * hw]: decoded symbols of the coded channels as floats (the others are zeroed by the host)
+  uint32_t *status;              // device [n_ckpt + 1], per segment: 0 = decoded and ended in the next checkpoint; else why not
+};
+struct SegRef { // one wave's work
+  int32_t item, seg;
+};
+enum : uint32_t { kSegOk = 0, kSegMismatch = 1, kSegHard = 2, kSegStream = 3 }; // hard: a row the wave does not decode itself
+int launch_segdec(const SegDesc *d_descs, const SegRef *d_segs, int64_t n_segs, int mode, bool clamped, bool f16, void *stream);
+
 // ---- decode-side table format v5 (documented in include/flashgmm_amd.h) -------------------------------------
 //   header of latent i, one of three forms (per item):
 //     2 bytes: (a + max_bs) | cnt << 8, cnt in [1, 254]                    items with 2*max_bs + 2 <= 254

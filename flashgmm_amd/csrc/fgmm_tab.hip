@@ -696,10 +696,235 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   }
 }
 
+// =========================================================================================================
+// segdec_kernel — rANS decode of CHECKPOINTED bitstreams on the GPU: one WAVE per segment, no tables at all
+// =========================================================================================================
+// A checkpointed bitstream (include/flashgmm_amd.h: fgmm_ckpt) falls into segments that can be decoded independently, each
+// from its note of the coder state.  A Kodak batch call has thousands of them - enough to give every SIMD of the chip a few
+// waves - so the per-symbol chain  cf = x & 0xFFFF -> which symbol's interval holds cf -> advance the state  can run ON the
+// GPU, next to the parameters, and the decode-side tables (57.6 B/latent across PCIe, the bound of the table path) need not
+// exist: for every symbol the wave evaluates the latent's edges F[v] ACROSS ITS LANES (lane = one edge of the window between
+// the saturated tails, the same arithmetic as tab_kernel), one compare + ballot counts the edges <= cf - the wavefront-ballot
+// form of the reference's bisection (rans_interface.cpp:826-862) - and the coder state is advanced on the scalar unit.
+//   per 64 latents: lane = latent: twelve parameters, clamp + reciprocals, evaluation window (vectorised, as tab_kernel phase 0)
+//   per symbol    : broadcast that latent's parameters (v_readlane), lane = edge: F, count(F <= cf), F[J], F[J+1] -> advance
+// The wave only accepts what it can decide exactly as the reference does: a MONOTONE window with one interval around cf.
+// Anything else (a non-monotone row, cf beyond every edge) flags the segment "hard"; a segment that does not end in the next
+// checkpoint's (state, position) flags "mismatch" - the host then decodes that bitstream through the table path, so the
+// result is the sequential decoder's in every case and a wrong note costs time, never a symbol.
+template <int MODE, bool CLAMPED, typename PT>
+__global__ __launch_bounds__(kBlock) void segdec_kernel(const SegDesc *__restrict__ descs, const SegRef *__restrict__ segs, int64_t n_segs) {
+  const int64_t wid = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (wid >= n_segs) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const SegRef ref = segs[wid];
+  const SegDesc &d = descs[ref.item];
+  const int64_t sg = ref.seg;
+  const int64_t lo = sg * d.stride, hi = sg == d.n_ckpt ? d.n : lo + d.stride;
+  const int32_t max_bs = d.max_bs;
+  const int W = 2 * max_bs + 2;
+  auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  auto bcast = [](uint32_t v, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)k); };
+  auto bcastf = [](float v, uint32_t k) { return bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(v), (int)k)); };
+  // ---- the coder at symbol lo: the stream's own head (segment 0) or the checkpoint before this segment
+  const uint32_t *__restrict__ w = d.words + 2;
+  const int64_t nw = d.n_words - 2;
+  uint32_t x_lo, x_hi;
+  int64_t wbase;
+  if (sg == 0) {
+    x_lo = uni(d.words[0]);
+    x_hi = uni(d.words[1]);
+    wbase = 0;
+  } else {
+    const fgmm_ckpt c = d.ckpt[sg - 1];
+    x_lo = uni((uint32_t)c.x);
+    x_hi = uni((uint32_t)(c.x >> 32));
+    wbase = (int64_t)c.pos;
+  }
+  uint32_t err = (wbase < 0 || wbase > nw) ? kSegMismatch : kSegOk;
+  if (err) wbase = 0;
+  // the next 64 words of the bitstream across the lanes; `wp` of them are consumed
+  uint32_t wv = wbase + lane < nw ? w[wbase + lane] : 0u;
+  uint32_t wp = 0;
+  auto next_word = [&]() -> uint32_t { // wave-uniform
+    if (wp == 64) {
+      wbase += 64;
+      wv = wbase + lane < nw ? w[wbase + lane] : 0u;
+      wp = 0;
+    }
+    if (wbase + wp >= nw) err = kSegStream;
+    const uint32_t r = bcast(wv, wp);
+    ++wp;
+    return r;
+  };
+
+  for (int64_t base = lo; base < hi && !err; base += 64) {
+    // ---- lane = latent base + lane: parameters, window (once per 64 symbols, all lanes at work)
+    const int64_t i = std::min(base + lane, hi - 1);
+    const int64_t cj = i / d.hw, p = i - cj * d.hw;
+    const int c = d.chan_list ? d.chan_list[cj] : (int)cj;
+    const int64_t pbase = (int64_t)c * d.stride_c + p * d.stride_p;
+    float mu[4], sgm[4], pi[4], rs[4];
+    bool tame = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sgm[k] = ld1<PT>(d.scales, pbase + k * d.stride_k);
+      mu[k] = ld1<PT>(d.means, pbase + k * d.stride_k);
+      pi[k] = ld1<PT>(d.weights, pbase + k * d.stride_k);
+    }
+    if (d.logits) softmax4(pi);
+    if constexpr (CLAMPED) {
+      Sigma4 S4;
+      S4.set(sgm[0], sgm[1], sgm[2], sgm[3]);
+      tame = S4.tame;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sgm[k] = tame ? S4.sg[k] : clamp_scale(sgm[k]);
+        rs[k] = S4.rs[k];
+      }
+    } else {
+      tame = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rs[k] = 0.0f;
+    }
+    int j_lo, j_hi;
+    uint32_t T_sat;
+    tab_window<MODE>(mu, sgm, pi, 1, max_bs, W, j_lo, j_hi, T_sat);
+    const uint32_t win = (uint32_t)j_lo | ((uint32_t)(j_hi - j_lo) << 16);
+    const uint32_t tsf = T_sat | (tame ? 0x10000u : 0u);
+    const int64_t oidx = (int64_t)c * d.hw + p;
+    int32_t myval = 0;
+    const int nk = (int)std::min<int64_t>(64, hi - base);
+
+    // ---- symbol by symbol: lane = edge of latent base + k
+    for (int k = 0; k < nk && !err; ++k) {
+      const uint32_t cf = x_lo & 0xFFFFu;
+      int32_t value;
+      if (__builtin_expect(cf == 0xFFFFu, 0)) { // bypass escape: Rans64DecAdvance(65535, 1), then the nibbles (rans_interface.cpp:808-824)
+        uint64_t xx = ((((uint64_t)x_hi << 32) | x_lo) >> 16) + cf - 0xFFFFu;
+        auto renorm = [&]() {
+          if (xx < (1ull << 31)) xx = (xx << 32) | next_word();
+        };
+        renorm();
+        auto get_bits = [&]() {
+          const uint32_t v = (uint32_t)xx & 15u;
+          xx >>= 4;
+          renorm();
+          return v;
+        };
+        int32_t val = (int32_t)get_bits(), nn = val;
+        while (val == 15 && !err) {
+          val = (int32_t)get_bits();
+          nn += val;
+        }
+        uint32_t raw = 0;
+        for (int j = 0; j < nn && !err; ++j) raw |= get_bits() << ((j * 4) & 31);
+        value = (int32_t)raw;
+        x_lo = uni((uint32_t)xx);
+        x_hi = uni((uint32_t)(xx >> 32));
+      } else {
+        const float m4[4] = {bcastf(mu[0], k), bcastf(mu[1], k), bcastf(mu[2], k), bcastf(mu[3], k)};
+        const float s4[4] = {bcastf(sgm[0], k), bcastf(sgm[1], k), bcastf(sgm[2], k), bcastf(sgm[3], k)};
+        const float r4[4] = {bcastf(rs[0], k), bcastf(rs[1], k), bcastf(rs[2], k), bcastf(rs[3], k)};
+        const float p4[4] = {bcastf(pi[0], k), bcastf(pi[1], k), bcastf(pi[2], k), bcastf(pi[3], k)};
+        const uint32_t wk = bcast(win, k), tk = bcast(tsf, k);
+        const int jl = (int)(wk & 0xFFFFu), len = (int)(wk >> 16), jh = jl + len;
+        const uint32_t tsat = tk & 0xFFFFu;
+        const bool fastok = (tk >> 16) != 0;
+        // edges of the window, 64 per pass: count those <= cf.  That count is the interval only in a MONOTONE row, and the
+        // reference's bisection may answer differently when the row decreases ANYWHERE (rans_interface.cpp:833-854): every
+        // pass is evaluated and checked, also the ones after the interval has been found (windows beyond 64 edges are few)
+        uint32_t below = 0, last = 0, start = 0, next = 0; // `last`: the edge before this pass (F below the window is 0)
+        bool found = false, bad = false;
+        for (int off = 0; off < len; off += 64) {
+          const int q = off + (int)lane;
+          const bool valid = q < len;
+          const float xe = (float)(jl + q - max_bs) - 0.5f;
+          float cdf;
+          if constexpr (CLAMPED) {
+            bool ok = fastok;
+            cdf = mix4_clamped<MODE>(xe, m4, s4, r4, p4, ok);
+            if (__builtin_expect(!ok, 0)) cdf = mix4_slow<MODE>(xe, m4[0], m4[1], m4[2], m4[3], s4[0], s4[1], s4[2], s4[3], p4[0], p4[1], p4[2], p4[3]);
+          } else {
+            cdf = mix4<MODE>(xe, m4, s4, p4);
+          }
+          const uint32_t E = valid ? quant16(cdf) : 0x10000u; // lanes past the window never count as <= cf
+          uint32_t Ep = (uint32_t)__shfl_up((int)E, 1, 64);
+          Ep = lane == 0 ? last : Ep;
+          bad = bad || __ballot(valid && Ep > E) != 0;
+          const uint32_t n_valid = (uint32_t)std::min(64, len - off);
+          if (!found) {
+            const uint32_t n_le = (uint32_t)__popcll(__ballot(valid && E <= cf));
+            if (n_le < n_valid) { // the first edge > cf lies in this pass: F[J] = the edge before it, F[J + 1] = that edge
+              next = bcast(E, n_le);
+              start = n_le ? bcast(E, n_le - 1) : last;
+              found = true;
+            }
+            below += n_le;
+          }
+          last = bcast(E, n_valid - 1);
+        }
+        bad = bad || (jh < W && tsat < last); // ... and into the saturated tail
+        if (!found) { // every edge of the window is <= cf: the interval ends at the saturated tail, if there is one above cf
+          start = last;
+          next = tsat;
+          bad = bad || !(jh < W && tsat > cf);
+        }
+        // F[J] <= cf < F[J + 1] with J = jl + below - 1 >= 0  (J = jl - 1: the zeros below the window; the reference's range is
+        // J in [0, W - 2]: rans_interface.cpp:826-833)
+        const int J = jl + (int)below - 1;
+        const uint32_t freq = next - start;
+        if (__builtin_expect(bad || J < 0 || J > W - 2 || freq == 0 || freq > 0xFFFFu, 0)) {
+          err = kSegHard;
+          break;
+        }
+        value = J - max_bs;
+        // x = freq * (x >> 16) + (cf - start), 64 bits, on the scalar unit (Rans64DecAdvance)
+        const uint32_t s_lo = (x_lo >> 16) | (x_hi << 16), s_hi = x_hi >> 16;
+        const uint64_t pr = (uint64_t)freq * s_lo + (((uint64_t)(freq * s_hi)) << 32) + (uint64_t)(cf - start);
+        uint32_t n_lo = (uint32_t)pr, n_hi = (uint32_t)(pr >> 32);
+        if (n_hi == 0 && n_lo < 0x80000000u) { // x < 2^31: one more word
+          n_hi = n_lo;
+          n_lo = next_word();
+        }
+        x_lo = uni(n_lo);
+        x_hi = uni(n_hi);
+      }
+      if (lane == (uint32_t)k) myval = value;
+    }
+    if (!err && base + lane < hi) d.y_hat[oidx] = (float)myval;
+  }
+  // ---- the segment must end exactly where the next checkpoint says the coder stands
+  if (!err && sg < d.n_ckpt) {
+    const fgmm_ckpt c = d.ckpt[sg];
+    const uint64_t x = ((uint64_t)x_hi << 32) | x_lo;
+    if (x != c.x || (uint64_t)(wbase + wp) != c.pos) err = kSegMismatch;
+  }
+  if (lane == 0) d.status[sg] = err;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 static inline int launch_err() { return (int)hipGetLastError(); }
+
+template <bool CLAMPED, typename PT>
+static int launch_segdec_c(const SegDesc *d, const SegRef *segs, int64_t n_segs, int mode, hipStream_t s) {
+  const dim3 grid((unsigned)((n_segs + kBlock / 64 - 1) / (kBlock / 64)));
+  switch (mode) {
+  case MODE_AS: hipLaunchKernelGGL((segdec_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d, segs, n_segs); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((segdec_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d, segs, n_segs); break;
+  default: hipLaunchKernelGGL((segdec_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d, segs, n_segs); break;
+  }
+  return launch_err();
+}
+int launch_segdec(const SegDesc *d_descs, const SegRef *d_segs, int64_t n_segs, int mode, bool clamped, bool f16, void *stream) {
+  if (n_segs <= 0) return 0;
+  if (n_segs > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  if (f16) return clamped ? launch_segdec_c<true, _Float16>(d_descs, d_segs, n_segs, mode, s) : launch_segdec_c<false, _Float16>(d_descs, d_segs, n_segs, mode, s);
+  return clamped ? launch_segdec_c<true, float>(d_descs, d_segs, n_segs, mode, s) : launch_segdec_c<false, float>(d_descs, d_segs, n_segs, mode, s);
+}
 
 template <bool CLAMPED, typename PT>
 static int launch_cdftab_c(const DecDesc *d_descs, int count, int n_ch_max, int64_t hw_max, int mode, int pass, hipStream_t s) {
