@@ -235,7 +235,8 @@ struct fgmm_ctx {
     d_cap = h_cap = d_stage_cap = 0;
   }
   bool profiling = false;
-  unsigned long long stat[4] = {0, 0, 0, 0}; // last batched call: [0] encode table bytes D2H, [1] decode table bytes D2H,
+  unsigned long long stat[6] = {0, 0, 0, 0, 0, 0}; // [4] bitstreams the GPU's segment decoder decoded, [5] ... handed back to the table path;
+                                                   // last batched call: [0] encode table bytes D2H, [1] decode table bytes D2H,
                                              // [2] decode latents, [3] edges the decode-side kernels evaluated
   hipEvent_t prof[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool prof_valid[4] = {false, false, false, false};
@@ -667,7 +668,7 @@ struct TempDevice {
 // a float latent to write; a half-width whose window fits the kernel's 16-bit fields)
 static bool gpu_decodable(const DecItem &it, int64_t n) {
   return it.y_hat && !it.sym_host_out && it.ckpt && it.n_ckpt > 0 && it.ckpt_stride >= 256 && !(it.ckpt_stride & (it.ckpt_stride - 1)) &&
-         n > 0 && it.n_ckpt == (n - 1) / it.ckpt_stride && it.n_ckpt < (1 << 24) && it.max_bs >= 0 && it.max_bs <= FGMM_MAX_BS_H4 &&
+         n > 0 && it.n_ckpt == (n - 1) / it.ckpt_stride && it.n_ckpt < (1 << 24) && it.max_bs >= 0 && 2 * (int64_t)it.max_bs + 2 <= 2048 /* kSegCapE: a latent's window in the wave's LDS */ &&
          it.enc_len >= 8 && !(it.enc_len & 3) && it.stride_p == 1;
 }
 
@@ -758,9 +759,18 @@ int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &it
     for (int64_t sgm = 0; sgm <= it.n_ckpt; ++sgm) worst = std::max(worst, st[sgm]);
     if (worst != kSegOk) redo.push_back(which[k]);
     else it.status = FGMM_OK, it.done.store(1);
+    if (tr.on && worst != kSegOk) {
+      int64_t first = 0, n_bad = 0;
+      for (int64_t sgm = it.n_ckpt; sgm >= 0; --sgm)
+        if (st[sgm] != kSegOk) first = sgm, ++n_bad;
+      fprintf(stderr, "[fgmm decode-gpu]   item %d: %lld of %lld segments not ok, the first: segment %lld status %u\n", which[k], (long long)n_bad,
+              (long long)it.n_ckpt + 1, (long long)first, st[first]);
+    }
   }
   ctx->stat[1] = 0; // no decode-side tables at all
   ctx->stat[2] = ctx->stat[3] = 0;
+  ctx->stat[4] = (unsigned long long)(count - (int)redo.size());
+  ctx->stat[5] = (unsigned long long)redo.size();
   for (int k = 0; k < count; ++k) ctx->stat[2] += (unsigned long long)items[which[k]].n;
   return FGMM_OK;
 }
@@ -1691,7 +1701,7 @@ int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out) {
 }
 
 int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out) {
-  if (!ctx || which < 0 || which > 3 || !out) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (!ctx || which < 0 || which > 5 || !out) return fail(FGMM_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lock(ctx->mu);
   *out = ctx->stat[which];
   return FGMM_OK;
@@ -1805,6 +1815,7 @@ int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int
       d.ckpt_stride = s.ckpt_stride;
     }
   }
+  ctx->stat[4] = ctx->stat[5] = 0;
   const int rc = decode_batch(ctx, (hipStream_t)stream, v, mode);
   for (int i = 0; i < count; ++i) items[i].status = v[i].status;
   return rc;

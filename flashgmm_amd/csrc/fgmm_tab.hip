@@ -712,20 +712,30 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
 // Anything else (a non-monotone row, cf beyond every edge) flags the segment "hard"; a segment that does not end in the next
 // checkpoint's (state, position) flags "mismatch" - the host then decodes that bitstream through the table path, so the
 // result is the sequential decoder's in every case and a wrong note costs time, never a symbol.
+constexpr int kSegCapE = 2048;  // edges (uint16) one wave keeps in LDS for the latents of a batch (the less LDS a wave takes the
+                                // more waves a SIMD holds, and the decode chain of a wave is latency: 9.3 KB -> 17 waves per CU)
+constexpr int kSegLds = 64 * 64 + 2 * kSegCapE + 4 * 68 + 3 * 4 * 64; // parameters of 64 latents | edges | pair offsets | windows, tails, flags
 template <int MODE, bool CLAMPED, typename PT>
-__global__ __launch_bounds__(kBlock) void segdec_kernel(const SegDesc *__restrict__ descs, const SegRef *__restrict__ segs, int64_t n_segs) {
-  const int64_t wid = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+__global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ descs, const SegRef *__restrict__ segs, int64_t n_segs) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kSegLds];
+  float4_t *const P = reinterpret_cast<float4_t *>(lds);                       // [64][4]: mu, sigma (clamped), pi, refined 1/sigma
+  uint32_t *const E32 = reinterpret_cast<uint32_t *>(lds + 64 * 64);           // [kSegCapE / 2] two edges per word
+  const uint16_t *const E16 = reinterpret_cast<const uint16_t *>(E32);
+  uint32_t *const offP = reinterpret_cast<uint32_t *>(lds + 64 * 64 + 2 * kSegCapE); // [65] pairs before latent l of the batch
+  uint32_t *const winL = offP + 68, *const tsfL = winL + 64; // [64] j_lo | len << 16;  T_sat | tame << 16  (read by OTHER lanes in
+                                                             // phase B, some of which have left the loop: not a cross-lane register read)
+  uint32_t *const nmL = tsfL + 64;                           // [64] the latent's row decreases somewhere
+  const int64_t wid = blockIdx.x;
   if (wid >= n_segs) return;
-  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t lane = threadIdx.x;
   const SegRef ref = segs[wid];
   const SegDesc &d = descs[ref.item];
   const int64_t sg = ref.seg;
   const int64_t lo = sg * d.stride, hi = sg == d.n_ckpt ? d.n : lo + d.stride;
   const int32_t max_bs = d.max_bs;
-  const int W = 2 * max_bs + 2;
+  const int W = 2 * max_bs + 2; // <= kSegCapE (the host sends wider items through the table path)
   auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   auto bcast = [](uint32_t v, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)k); };
-  auto bcastf = [](float v, uint32_t k) { return bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(v), (int)k)); };
   // ---- the coder at symbol lo: the stream's own head (segment 0) or the checkpoint before this segment
   const uint32_t *__restrict__ w = d.words + 2;
   const int64_t nw = d.n_words - 2;
@@ -758,8 +768,8 @@ __global__ __launch_bounds__(kBlock) void segdec_kernel(const SegDesc *__restric
     return r;
   };
 
-  for (int64_t base = lo; base < hi && !err; base += 64) {
-    // ---- lane = latent base + lane: parameters, window (once per 64 symbols, all lanes at work)
+  for (int64_t base = lo; base < hi && !err;) {
+    // ---- A. lane = latent base + lane: parameters -> LDS, evaluation window; how many latents fit the edge budget
     const int64_t i = std::min(base + lane, hi - 1);
     const int64_t cj = i / d.hw, p = i - cj * d.hw;
     const int c = d.chan_list ? d.chan_list[cj] : (int)cj;
@@ -790,14 +800,113 @@ __global__ __launch_bounds__(kBlock) void segdec_kernel(const SegDesc *__restric
     int j_lo, j_hi;
     uint32_t T_sat;
     tab_window<MODE>(mu, sgm, pi, 1, max_bs, W, j_lo, j_hi, T_sat);
+    P[4 * lane + 0] = (float4_t){mu[0], mu[1], mu[2], mu[3]};
+    P[4 * lane + 1] = (float4_t){sgm[0], sgm[1], sgm[2], sgm[3]};
+    P[4 * lane + 2] = (float4_t){pi[0], pi[1], pi[2], pi[3]};
+    P[4 * lane + 3] = (float4_t){rs[0], rs[1], rs[2], rs[3]};
     const uint32_t win = (uint32_t)j_lo | ((uint32_t)(j_hi - j_lo) << 16);
     const uint32_t tsf = T_sat | (tame ? 0x10000u : 0u);
+    const int nk_max = (int)std::min<int64_t>(64, hi - base);
+    const uint32_t pairs = (int)lane < nk_max ? (uint32_t)(j_hi - j_lo + 1) >> 1 : 0u;
+    uint32_t incl = pairs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+      if (lane >= (uint32_t)o) incl += t;
+    }
+    // latents 0 .. nk - 1 of the batch fit kSegCapE edges (one latent always does: W <= kSegCapE)
+    const int nk = std::max(1, (int)__popcll(__ballot((int)lane < nk_max && 2 * incl <= (uint32_t)kSegCapE)));
+    const uint32_t excl = incl - pairs;
+    offP[lane] = excl;
+    winL[lane] = win;
+    tsfL[lane] = tsf;
+    nmL[lane] = 0;
+    const uint32_t NP = bcast(incl, (uint32_t)(nk - 1));
+    if (lane == 0) offP[64] = NP; // (offP[nk] is what a walk past the last latent reads: lanes' own entries hold it for nk < 64)
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wave are done (one wave per workgroup: no barrier)
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- B. flattened over (latent, pair of consecutive edges): the tab_kernel's evaluation, edges -> LDS
+    {
+      int l = 0;
+      uint32_t l_beg = 0, l_end = 0;
+      uint32_t t = lane;
+      if (t < NP) {
+        l = find_owner(offP, nk, t);
+        l_beg = offP[l];
+        l_end = l + 1 < nk ? offP[l + 1] : NP;
+      }
+      for (; t < NP; t += 64) {
+        while (t >= l_end) { // next latent with a non-empty window
+          ++l;
+          l_beg = l_end;
+          l_end = l + 1 < nk ? offP[l + 1] : NP;
+        }
+        const float4_t m4 = P[4 * l + 0], s4 = P[4 * l + 1], p4 = P[4 * l + 2], r4 = P[4 * l + 3];
+        const float mu_[4] = {m4[0], m4[1], m4[2], m4[3]}, pi_[4] = {p4[0], p4[1], p4[2], p4[3]};
+        const uint32_t wl = winL[l], tl_ = tsfL[l];
+        const int j = (int)(wl & 0xFFFFu) + 2 * (int)(t - l_beg);
+        const float x0 = (float)(j - max_bs) - 0.5f, x1 = (float)(j + 1 - max_bs) - 0.5f;
+        float c0 = 0.0f, c1 = 0.0f;
+        bool fast = false;
+        if constexpr (CLAMPED) {
+          Sigma4 S4;
+          S4.tame = true;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            S4.sg[k] = s4[k];
+            S4.rs[k] = r4[k];
+          }
+          bool ok = (tl_ >> 16) != 0;
+          const f2 cc = mix4_clamped2<MODE>((f2){x0, x1}, mu_, S4, pi_, ok);
+          c0 = cc.x;
+          c1 = cc.y;
+          fast = ok;
+        }
+        if (__builtin_expect(!fast, 0)) { // un-clamped sigma, NaN sigma, far-off or non-finite mean: IEEE evaluation
+          c0 = mix4_slow<MODE>(x0, mu_[0], mu_[1], mu_[2], mu_[3], s4[0], s4[1], s4[2], s4[3], pi_[0], pi_[1], pi_[2], pi_[3]);
+          c1 = mix4_slow<MODE>(x1, mu_[0], mu_[1], mu_[2], mu_[3], s4[0], s4[1], s4[2], s4[3], pi_[0], pi_[1], pi_[2], pi_[3]);
+        }
+        E32[t] = quant16(c0) | (quant16(c1) << 16);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // ... and which rows DECREASE somewhere (flattened too: off the sequential chain below).  A count of the edges <= cf is the
+    // symbol's interval only in a monotone row; the reference's bisection may answer differently when the row decreases
+    // anywhere (rans_interface.cpp:833-854), so such a latent is left to the table path.  An odd window's last pair holds
+    // F[j_hi] as well: a real edge, checked like the others.
+    {
+      int l = 0;
+      uint32_t l_beg = 0, l_end = 0;
+      uint32_t t = lane;
+      if (t < NP) {
+        l = find_owner(offP, nk, t);
+        l_beg = offP[l];
+        l_end = l + 1 < nk ? offP[l + 1] : NP;
+      }
+      for (; t < NP; t += 64) {
+        while (t >= l_end) {
+          ++l;
+          l_beg = l_end;
+          l_end = l + 1 < nk ? offP[l + 1] : NP;
+        }
+        const uint32_t cur = E32[t], prev = t > l_beg ? E32[t - 1] >> 16 : 0u; // F below the window is 0
+        if (prev > (cur & 0xFFFFu) || (cur & 0xFFFFu) > (cur >> 16)) nmL[l] = 1;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nm = nmL[lane];
+
+    // ---- C. symbol by symbol, lane = edge of latent base + k, edges from LDS
     const int64_t oidx = (int64_t)c * d.hw + p;
     int32_t myval = 0;
-    const int nk = (int)std::min<int64_t>(64, hi - base);
-
-    // ---- symbol by symbol: lane = edge of latent base + k
     for (int k = 0; k < nk && !err; ++k) {
+      // the coder's state is wave-uniform; saying so at the top of every symbol keeps this body on the scalar unit
+      x_lo = uni(x_lo);
+      x_hi = uni(x_hi);
+      wp = uni(wp);
       const uint32_t cf = x_lo & 0xFFFFu;
       int32_t value;
       if (__builtin_expect(cf == 0xFFFFu, 0)) { // bypass escape: Rans64DecAdvance(65535, 1), then the nibbles (rans_interface.cpp:808-824)
@@ -823,35 +932,16 @@ __global__ __launch_bounds__(kBlock) void segdec_kernel(const SegDesc *__restric
         x_lo = uni((uint32_t)xx);
         x_hi = uni((uint32_t)(xx >> 32));
       } else {
-        const float m4[4] = {bcastf(mu[0], k), bcastf(mu[1], k), bcastf(mu[2], k), bcastf(mu[3], k)};
-        const float s4[4] = {bcastf(sgm[0], k), bcastf(sgm[1], k), bcastf(sgm[2], k), bcastf(sgm[3], k)};
-        const float r4[4] = {bcastf(rs[0], k), bcastf(rs[1], k), bcastf(rs[2], k), bcastf(rs[3], k)};
-        const float p4[4] = {bcastf(pi[0], k), bcastf(pi[1], k), bcastf(pi[2], k), bcastf(pi[3], k)};
-        const uint32_t wk = bcast(win, k), tk = bcast(tsf, k);
+        const uint32_t wk = bcast(win, (uint32_t)k), tk = bcast(tsf, (uint32_t)k), e0 = 2u * bcast(excl, (uint32_t)k);
         const int jl = (int)(wk & 0xFFFFu), len = (int)(wk >> 16), jh = jl + len;
         const uint32_t tsat = tk & 0xFFFFu;
-        const bool fastok = (tk >> 16) != 0;
-        // edges of the window, 64 per pass: count those <= cf.  That count is the interval only in a MONOTONE row, and the
-        // reference's bisection may answer differently when the row decreases ANYWHERE (rans_interface.cpp:833-854): every
-        // pass is evaluated and checked, also the ones after the interval has been found (windows beyond 64 edges are few)
+        // count the edges <= cf, 64 per pass (monotone rows only: phase B's flag)
         uint32_t below = 0, last = 0, start = 0, next = 0; // `last`: the edge before this pass (F below the window is 0)
-        bool found = false, bad = false;
+        bool found = false, bad = bcast(nm, (uint32_t)k) != 0;
         for (int off = 0; off < len; off += 64) {
           const int q = off + (int)lane;
           const bool valid = q < len;
-          const float xe = (float)(jl + q - max_bs) - 0.5f;
-          float cdf;
-          if constexpr (CLAMPED) {
-            bool ok = fastok;
-            cdf = mix4_clamped<MODE>(xe, m4, s4, r4, p4, ok);
-            if (__builtin_expect(!ok, 0)) cdf = mix4_slow<MODE>(xe, m4[0], m4[1], m4[2], m4[3], s4[0], s4[1], s4[2], s4[3], p4[0], p4[1], p4[2], p4[3]);
-          } else {
-            cdf = mix4<MODE>(xe, m4, s4, p4);
-          }
-          const uint32_t E = valid ? quant16(cdf) : 0x10000u; // lanes past the window never count as <= cf
-          uint32_t Ep = (uint32_t)__shfl_up((int)E, 1, 64);
-          Ep = lane == 0 ? last : Ep;
-          bad = bad || __ballot(valid && Ep > E) != 0;
+          const uint32_t E = valid ? (uint32_t)E16[e0 + (uint32_t)q] : 0x10000u; // lanes past the window never count as <= cf
           const uint32_t n_valid = (uint32_t)std::min(64, len - off);
           if (!found) {
             const uint32_t n_le = (uint32_t)__popcll(__ballot(valid && E <= cf));
@@ -863,8 +953,12 @@ __global__ __launch_bounds__(kBlock) void segdec_kernel(const SegDesc *__restric
             below += n_le;
           }
           last = bcast(E, n_valid - 1);
+          if (found) { // (the rest of a long window is only needed for its last edge)
+            if (off + 64 < len) last = (uint32_t)E16[e0 + (uint32_t)len - 1u];
+            break;
+          }
         }
-        bad = bad || (jh < W && tsat < last); // ... and into the saturated tail
+        bad = bad || (jh < W && tsat < last); // ... monotone into the saturated tail too
         if (!found) { // every edge of the window is <= cf: the interval ends at the saturated tail, if there is one above cf
           start = last;
           next = tsat;
@@ -892,7 +986,9 @@ __global__ __launch_bounds__(kBlock) void segdec_kernel(const SegDesc *__restric
       }
       if (lane == (uint32_t)k) myval = value;
     }
-    if (!err && base + lane < hi) d.y_hat[oidx] = (float)myval;
+    if (!err && (int)lane < nk) d.y_hat[oidx] = (float)myval;
+    base += nk;
+    __builtin_amdgcn_wave_barrier(); // the next batch overwrites the LDS this one read
   }
   // ---- the segment must end exactly where the next checkpoint says the coder stands
   if (!err && sg < d.n_ckpt) {
@@ -910,11 +1006,11 @@ static inline int launch_err() { return (int)hipGetLastError(); }
 
 template <bool CLAMPED, typename PT>
 static int launch_segdec_c(const SegDesc *d, const SegRef *segs, int64_t n_segs, int mode, hipStream_t s) {
-  const dim3 grid((unsigned)((n_segs + kBlock / 64 - 1) / (kBlock / 64)));
+  const dim3 grid((unsigned)n_segs); // one wave per workgroup: its own 12.6 KB of LDS, no barriers
   switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((segdec_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d, segs, n_segs); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((segdec_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d, segs, n_segs); break;
-  default: hipLaunchKernelGGL((segdec_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(kBlock), 0, s, d, segs, n_segs); break;
+  case MODE_AS: hipLaunchKernelGGL((segdec_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(64), 0, s, d, segs, n_segs); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((segdec_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(64), 0, s, d, segs, n_segs); break;
+  default: hipLaunchKernelGGL((segdec_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(64), 0, s, d, segs, n_segs); break;
   }
   return launch_err();
 }

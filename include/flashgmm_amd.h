@@ -108,7 +108,11 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor).
  *                       14 gives the fewest bytes (55.7 B/latent on Kodak-like tables against 57.6) but costs the host
  *                       decoders more than the PCIe time it saves when 16 threads serve one GPU
- *   "ckpt_decode" [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded in segments, on all workers: 0 = when the
+ *   "gpu_decode"  [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded ON THE GPU, one wave per segment, the edges of a
+ *                       latent across the lanes (no decode-side tables, nothing but the bitstreams crosses PCIe); a bitstream
+ *                       with a segment the kernel does not settle itself (a non-monotone row, a note that does not verify)
+ *                       goes through the table path.  0 / 1 = whenever a bitstream carries valid notes, 2 = never
+ *   "ckpt_decode" [0]   decode, table path: checkpointed bitstreams are decoded in segments on all host workers: 0 = when the
  *                       call has fewer bitstreams than workers (else every worker has a bitstream anyway), 1 = always,
  *                       2 = never (the notes are ignored)
  *   "trace"       [0]   1: phase timestamps of every batched call on stderr, 2: + per-bitstream job timeline */
@@ -123,7 +127,8 @@ int fgmm_ctx_trim(fgmm_ctx *ctx);
  * last), 2: quant_stats kernel, 3: unused (0). */
 int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable);
 /* Counters of the most recent batched call: which = 0 encode tables copied D2H (bytes), 1 decode headers + block offsets
- * + rows copied D2H (bytes), 2 latents those decode tables describe, 3 edges the decode-side kernels evaluated. */
+ * + rows copied D2H (bytes), 2 latents those decode tables describe, 3 edges the decode-side kernels evaluated, 4 bitstreams
+ * the GPU's segment decoder decoded (checkpointed ones), 5 bitstreams it handed back to the table path. */
 int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out);
 int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out);
 

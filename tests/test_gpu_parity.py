@@ -879,19 +879,34 @@ def test_checkpointed_streams_are_the_same_bytes_and_decode_on_all_workers(oracl
     sym, s_, m_, w_, am, zbm, yqn = T.to_coder_inputs(*lat[1])
     assert bytes(r1[1][0][0]) == oracle.encode_gmm(mode, sym, s_, m_, w_)
     strings, ams, zbs = [r[0][0] for r in r1], [r[0][1] for r in r1], [r[0][2] for r in r1]
+    # on the GPU (the default for checkpointed bitstreams): one wave per segment, no tables; all five bitstreams decode there
+    out = ck.decompress_batch(strings, ams, zbs, ss, ms, ws)
+    for o, r in zip(out, r1):
+        assert torch.equal(o, r[1])
+    # (a bitstream shorter than the stride has no note, and a half-width whose window does not fit the kernel's LDS budget -
+    # 2 * (abs_max + 2) + 2 > 2048 edges - is not the kernel's: both take the table path)
+    n_gpu = sum(len(b.ckpt) > 0 and 2 * (a + 1) + 2 <= 2048 for b, a in zip(strings, ams))
+    assert n_gpu >= 3 and (_lib.ctx_stat(0, 4), _lib.ctx_stat(0, 5)) == (n_gpu, 0)
+    one = ck.decompress(strings[0], ams[0], zbs[0], ss[0], ms[0], ws[0])
+    assert torch.equal(one, r1[0][1]) and _lib.ctx_stat(0, 4) == 1
+    assert 2 * (ams[2] + 1) + 2 > 2048  # the outliers' item is the one with the wide window (bypass-coded symbols on the table path)
+    # through the table path, segments on the host workers (gpu_decode = 2):
     # (threads, option ckpt_decode: 0 = segments when the call has fewer bitstreams than workers, 1 = always, 2 = never)
     for threads, how in ((16, 0), (3, 1), (1, 1), (3, 0), (16, 2)):
         _lib.set_threads(0, threads)
         _lib.set_option(0, "ckpt_decode", how)
+        _lib.set_option(0, "gpu_decode", 2)
         try:
             out = ck.decompress_batch(strings, ams, zbs, ss, ms, ws)  # segments on the workers
             for o, r in zip(out, r1):
                 assert torch.equal(o, r[1])
+            assert _lib.ctx_stat(0, 4) == 0 and _lib.ctx_stat(0, 1) > 0
             one = ck.decompress(strings[0], ams[0], zbs[0], ss[0], ms[0], ws[0])  # ONE bitstream, 124 segments
             assert torch.equal(one, r1[0][1])
         finally:
             _lib.set_threads(0, 0)
             _lib.set_option(0, "ckpt_decode", 0)
+            _lib.set_option(0, "gpu_decode", 0)
     out = plain.decompress_batch([bytes(b) for b in strings], ams, zbs, ss, ms, ws)  # the same streams without their notes
     for o, r in zip(out, r1):
         assert torch.equal(o, r[1])
@@ -936,6 +951,70 @@ def test_checkpointed_codec_result_through_the_container():
     assert Cn.side_info_bytes(e1["strings"], e1["shape"]) - Cn.side_info_bytes(e0["strings"], e0["shape"]) == sum(8 + 16 * len(b[0].ckpt) for b in e1["strings"])
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_gpu_segment_decoder_equals_the_table_path_in_every_variant(oracle, mode):
+    """segdec_kernel (checkpointed bitstreams decoded ON the GPU, edges across the lanes, count + ballot for the reference's
+    bisection) against the table path and the oracle: fp32 / fp16 planes, sigma clamped or not, weights as logits,
+    windows beyond 64 edges (several passes per symbol), bypass-coded symbols (the synthetic latents have ~0.2 % of them), dead channels, tiny items (one segment,
+    fewer than 64 latents), and parameters the kernel must hand back (decreasing rows, NaN sigma)."""
+    rng = np.random.default_rng(91)
+    cases = []
+    for f16, clamp, logits in ((False, True, False), (True, True, False), (False, False, False), (False, True, True)):
+        y, sg, mu, pi = T.make_latent(400 + len(cases), M=40, h=16, w=12, clamp=False, zero_frac=0.2)
+        if not clamp:
+            sg = np.maximum(sg, np.float32(0.02))
+        w_in = np.log(np.maximum(pi, 1e-6)).astype(np.float32) if logits else pi
+        if f16:
+            sg, mu, w_in = T.to_float16_planes(sg, mu, w_in)
+        cases.append((y, sg, mu, w_in, clamp, logits))
+    # wide windows: sigma up to 60 -> more than 64 edges between the saturated tails; and bypass-coded outliers
+    y, sg, mu, pi = T.make_latent(410, M=24, h=16, w=12, clamp=False)
+    sg = (sg * np.float32(12.0)).astype(np.float32)
+    y = (y * np.float32(6.0)).astype(np.float32)
+    y.reshape(-1)[::41] *= 2
+    cases.append((y, sg, mu, pi, True, False))
+    y, sg, mu, pi = T.make_latent(411, M=3, h=3, w=5, clamp=False)  # 45 latents: one short segment
+    cases.append((y, sg, mu, pi, True, False))
+    for ci, (y, sg, mu, w_in, clamp, logits) in enumerate(cases):
+        t = [dv(a) for a in (y, sg, mu, w_in)]
+        plain = GaussianMixtureConditional(K=4, mode=mode, clamp_scales=clamp)
+        ck = GaussianMixtureConditional(K=4, mode=mode, clamp_scales=clamp, checkpoint_stride=256)
+        (b0, am0, zb0), yq0 = plain.compress(*t, weights_are_logits=logits)
+        (b1, am1, zb1), yq1 = ck.compress(*t, weights_are_logits=logits)
+        assert bytes(b1) == b0 and am0 == am1 and torch.equal(yq0, yq1)
+        want = plain.decompress(b0, am0, zb0, *t[1:], weights_are_logits=logits)
+        got = ck.decompress(b1, am1, zb1, *t[1:], weights_are_logits=logits)
+        assert torch.equal(got, want) and torch.equal(got, yq1), ci
+        on_gpu = len(b1.ckpt) > 0 and 2 * (am1 + 1) + 2 <= 2048
+        assert (_lib.ctx_stat(0, 4), _lib.ctx_stat(0, 5)) == ((1, 0) if on_gpu else (0, 0)), ci  # decoded by the GPU's segment decoder
+        assert on_gpu or ci == 5, ci  # (only the 45-latent item has no note)
+    # rows the kernel does not settle itself: negative weights make the CDF decrease, a NaN sigma poisons a latent; a garbage
+    # stream asks for intervals that do not exist.  Whatever the kernel does with them, the result is the table path's
+    y, sg, mu, pi = T.make_latent(420, M=16, h=16, w=12, clamp=False)
+    pi = pi.copy()
+    pi[:, 0::4][..., ::3, :] *= np.float32(-0.7)  # some components with negative weight
+    sg = sg.copy()
+    sg.reshape(-1)[::997] = np.nan
+    t = [dv(a) for a in (y, sg, mu, pi)]
+    plain = GaussianMixtureConditional(K=4, mode=mode)
+    ck = GaussianMixtureConditional(K=4, mode=mode, checkpoint_stride=256)
+    (b0, am0, zb0), yq0 = plain.compress(*t)
+    (b1, am1, zb1), yq1 = ck.compress(*t)
+    assert bytes(b1) == b0
+    assert torch.equal(ck.decompress(b1, am1, zb1, *t[1:]), plain.decompress(b0, am0, zb0, *t[1:]))
+    from flashgmm_amd import CheckpointedBytes
+    junk = bytes(rng.integers(0, 256, len(b0) & ~3, dtype=np.uint8))
+    try:
+        want = plain.decompress(junk, am0, zb0, *t[1:])
+    except RuntimeError:
+        want = None
+    try:
+        got = ck.decompress(CheckpointedBytes(junk, b1.ckpt, 256), am1, zb1, *t[1:])
+    except RuntimeError:
+        got = None
+    assert (want is None and got is None) or torch.equal(got, want)
+
+
 def test_wrong_checkpoints_cost_a_sequential_decode_never_a_wrong_symbol():
     """checkpoints are verified against one another segment by segment: flipped states, shifted positions, another stream's
     notes, a wrong stride — the result is the sequential decoder's every time; a truncated stream is still an error"""
@@ -963,7 +1042,13 @@ def test_wrong_checkpoints_cost_a_sequential_decode_never_a_wrong_symbol():
         else:
             ck["x"][:] = ck["x"][::-1].copy()
         bad = CheckpointedBytes(bytes(b), ck, 512)
-        assert torch.equal(gmc.decompress(bad, am, zb, *t[1:]), yq), trial
+        for gpu in (0, 2):  # the GPU's segment decoder hands the bitstream back; the host's segments fall back to a sequential decode
+            _lib.set_option(0, "gpu_decode", gpu)
+            try:
+                assert torch.equal(gmc.decompress(bad, am, zb, *t[1:]), yq), (trial, gpu)
+                assert gpu == 2 or (_lib.ctx_stat(0, 4), _lib.ctx_stat(0, 5)) == (0, 1)
+            finally:
+                _lib.set_option(0, "gpu_decode", 0)
     assert torch.equal(gmc.decompress(CheckpointedBytes(bytes(b), b.ckpt, 1024), am, zb, *t[1:]), yq)  # wrong stride: ignored
     assert torch.equal(gmc.decompress(CheckpointedBytes(bytes(b), b.ckpt[:-1], 512), am, zb, *t[1:]), yq)  # wrong count: ignored
     with pytest.raises(RuntimeError):
