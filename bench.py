@@ -441,6 +441,8 @@ def main(argv=None):
                     help="codec (default): decode stage by stage as the codec's dependencies demand; all-at-once: round 1's")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("FGMM_BENCH_LAUNCH_TIMEOUT", "1500")),
                     help="self-launch (N > 1): seconds after which the ranks are stopped and the launch fails")
+    ap.add_argument("--checkpoint-stride", type=int, default=1024,
+                    help="stride of the `checkpointed` extra legs: symbols between the out-of-band notes of the coder state (16 B each)")
     ap.add_argument("--host-threads", type=int, default=0, help="host rANS workers per GPU (0: this rank's share of the CPU budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip upper_bound / latency / per-thread legs (profiling runs)")
@@ -636,9 +638,11 @@ def main(argv=None):
                                     "as_codec": round(float(np.median([one_image(True) for _ in range(reps)])), 3),
                                     "all_at_once": round(float(np.median([one_image(False) for _ in range(reps)])), 3)}
             # the same image with CHECKPOINTED streams (GaussianMixtureConditional(checkpoint_stride=...): the reference's
-            # bitstreams + out-of-band notes of the coder state every 4096 symbols, 16 bytes each): one bitstream decodes on
-            # all host workers instead of one.  Not the reference's interface alone - its decoder has no such notes.
-            gmc_plain, gmc_ck = gmc, GaussianMixtureConditional(K=4, mode=a.mode, checkpoint_stride=4096)
+            # bitstreams + out-of-band notes of the coder state every `stride` symbols, 16 bytes each): the segments between
+            # notes are independent, so the decode runs ON THE GPU, one wave per segment (segdec_kernel; no decode-side tables,
+            # nothing but the bitstreams crosses PCIe), every segment verified against the next note.  Not the reference's
+            # interface alone - its decoder has no such notes.
+            gmc_plain, gmc_ck = gmc, GaussianMixtureConditional(K=4, mode=a.mode, checkpoint_stride=a.checkpoint_stride)
             gmc = gmc_ck
             r_ck = gmc_ck.compress_batch(ys[:spi], *[t[:spi] for t in (ss, ms, ws)])
             assert all(bytes(x[0][0]) == bytes(y_[0][0]) for x, y_ in zip(r_ck, last["res"][:spi])), "checkpointed streams differ"
@@ -647,6 +651,7 @@ def main(argv=None):
             extras["latency_ms"]["as_codec_checkpointed"] = round(float(np.median([one_image(True) for _ in range(reps)])), 3)
             extras["latency_ms"]["all_at_once_checkpointed"] = round(float(np.median([one_image(False) for _ in range(reps)])), 3)
             extras["latency_ms"]["checkpoint_bytes"] = int(sum(16 * len(x[0][0].ckpt) for x in r_ck))
+            extras["latency_ms"]["checkpoint_stride"] = a.checkpoint_stride
             # ... and the whole step on checkpointed streams (they matter when a call has fewer bitstreams than host workers:
             # ELIC's stages; the Kodak batch has a bitstream per worker and ignores them)
             step(a.schedule)
@@ -654,9 +659,16 @@ def main(argv=None):
             gc.disable()
             dt_ck, step_ms_ck = timed(a.schedule, n_ck, record=False)
             gc.enable()
+            res_ck = last["res"]
+            ck_bytes = int(sum(16 * len(r[0][0].ckpt) for r in res_ck))
             extras["checkpointed"] = {"schedule": a.schedule, "value": round(a.images * pix_per_image * n_ck / dt_ck / 1e6, 2), "unit": "Mpixels/s",
-                                      "ms_per_step": round(dt_ck / n_ck * 1e3, 3), "steps": n_ck, "step_ms": step_ms_ck, "checkpoint_stride": 4096,
-                                      "note": "same bitstreams + out-of-band checkpoints (16 B per 4096 symbols): a bitstream decodes on all host workers"}
+                                      "ms_per_step": round(dt_ck / n_ck * 1e3, 3), "steps": n_ck, "step_ms": step_ms_ck,
+                                      "checkpoint_stride": a.checkpoint_stride, "checkpoint_bytes": ck_bytes,
+                                      "checkpoint_bytes_over_bitstream_bytes": round(ck_bytes / max(total_bytes, 1), 4),
+                                      "bitstreams_decoded_on_gpu_last_call": _lib.ctx_stat(local_rank, 4),
+                                      "bitstreams_handed_back_last_call": _lib.ctx_stat(local_rank, 5),
+                                      "note": "the same bitstreams + out-of-band checkpoints: decoded on the GPU, one wave per segment "
+                                              "(segdec_kernel), every segment verified against the next checkpoint"}
             gmc = gmc_plain
             # one host thread instead of the pool: what the GPU path is worth per host core
             threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))

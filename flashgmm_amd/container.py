@@ -14,8 +14,9 @@ ranks (``flashgmm_amd.parallel.gather_containers``):
              kind 1 (GMM stream ``(bytes, abs_max, zero_bitmap)``): u32 abs_max | u16 M | ceil(M/8) bitmap bytes
                     (channel c = bit c%8 of byte c//8) | u32 len | bytes
              kind 2 (the same with the stream's out-of-band checkpoints, ``flashgmm_amd.CheckpointedBytes``): as kind 1, then
-                    u32 stride | u32 n | (u64 state | u64 position)*  — ``unpack`` gives a ``CheckpointedBytes`` back, which
-                    ``GaussianMixtureConditional.decompress`` decodes on all host workers; 16 bytes per `stride` symbols
+                    u32 stride | u32 n | (u64 state | u32 position)*  — ``unpack`` gives a ``CheckpointedBytes`` back, which
+                    ``GaussianMixtureConditional.decompress`` decodes in segments (on the GPU, or on all host workers);
+                    12 bytes per `stride` symbols
     shape  = a tagged tree: u8 tag; 0 int (i32) | 1 list (u16 n, items) | 2 tuple (u16 n, items) |
              3 dict (u16 n, (u16 klen | utf-8 key | value)*) | 4 None
 
@@ -69,7 +70,11 @@ def pack(strings: Sequence[Any], shape: Any = None) -> bytes:
             kind = 2 if ck is not None and len(ck) else 1
             out.append(struct.pack(">BIH", kind, int(abs_max), m) + bits + struct.pack(">I", len(data)) + bytes(data))
             if kind == 2:
-                out.append(struct.pack(">II", int(data.ckpt_stride), len(ck)) + np.ascontiguousarray(ck).astype([("x", ">u8"), ("pos", ">u8")]).tobytes())
+                if len(ck) and int(ck["pos"].max()) >= 1 << 32:
+                    raise ValueError("checkpoint position beyond 2^32 words")
+                rec = np.zeros(len(ck), dtype=[("x", ">u8"), ("pos", ">u4")])
+                rec["x"], rec["pos"] = ck["x"], ck["pos"]
+                out.append(struct.pack(">II", int(data.ckpt_stride), len(ck)) + rec.tobytes())
         elif isinstance(s, (list, tuple)) and all(isinstance(b, (bytes, bytearray)) for b in s):
             out.append(struct.pack(">BI", 0, len(s)))
             for b in s:
@@ -138,7 +143,9 @@ def unpack(buf: bytes, device=None):
                 from .entropy_models import CKPT_DTYPE, CheckpointedBytes
 
                 stride, n_ck = r.unpack(">II")
-                ck = np.frombuffer(r.take(16 * n_ck), dtype=[("x", ">u8"), ("pos", ">u8")]).astype(CKPT_DTYPE)
+                rec = np.frombuffer(r.take(12 * n_ck), dtype=[("x", ">u8"), ("pos", ">u4")])
+                ck = np.zeros(n_ck, CKPT_DTYPE)
+                ck["x"], ck["pos"] = rec["x"], rec["pos"]
                 data = CheckpointedBytes(data, ck, stride)
             strings.append((data, int(abs_max), zb.to(device) if device is not None else zb))
         elif kind == 0:

@@ -790,6 +790,26 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.n = (int64_t)n_ch * it.hw;
       (gpu_decodable(it, it.n) && it.clamp == items[0].clamp && it.prm.dtype == items[0].prm.dtype ? gpu : rest).push_back(i);
     }
+    // Is the GPU the faster decoder for this call?  One wave decodes its segment at ~1.7 us per symbol however empty the chip is,
+    // and the chip as a whole at ~0.56 ns per symbol (Kodak-like latents); the host decodes at ~12 ns per symbol and worker and
+    // is fed at 58 B per latent over PCIe.  Many segments (a batch, a 4K image's group): the GPU, by 2-4x; one Kodak half
+    // in a few hundred long segments: the host workers.  ("gpu_decode" = 1: always)
+    if (!gpu.empty() && ctx->opt.gpu_decode == 0) {
+      double syms = 0, stride_max = 0, work = 0;
+      for (int i : gpu) {
+        syms += (double)items[i].n;
+        stride_max = std::max(stride_max, (double)std::min<int64_t>(items[i].ckpt_stride, items[i].n));
+        work += (double)(items[i].n_ckpt + 1);
+      }
+      const double t_gpu = std::max(stride_max * 1.7, syms * 0.00056) + 100.0;
+      const double workers = std::min<double>(std::max(ctx->pool->size(), 1), work);
+      const double t_host = std::max(syms * 0.012 / workers, syms * 58.0 / 55700.0) + 450.0 + 3.0 * work / workers; // + a segment's set-up
+      if (t_gpu >= t_host) {
+        for (int i : gpu) rest.push_back(i);
+        gpu.clear();
+        std::sort(rest.begin(), rest.end());
+      }
+    }
     if (!gpu.empty()) {
       std::vector<int> redo;
       int rc = decode_batch_gpu(ctx, stream, items, gpu, mode, redo);

@@ -111,7 +111,9 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *   "gpu_decode"  [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded ON THE GPU, one wave per segment, the edges of a
  *                       latent across the lanes (no decode-side tables, nothing but the bitstreams crosses PCIe); a bitstream
  *                       with a segment the kernel does not settle itself (a non-monotone row, a note that does not verify)
- *                       goes through the table path.  0 / 1 = whenever a bitstream carries valid notes, 2 = never
+ *                       goes through the table path.  0 = when the call has enough segments for the GPU to be the faster
+ *                       decoder (a batch, a 4K image's channel group; one Kodak half in long segments decodes faster on the
+ *                       host's workers), 1 = whenever a bitstream carries valid notes, 2 = never
  *   "ckpt_decode" [0]   decode, table path: checkpointed bitstreams are decoded in segments on all host workers: 0 = when the
  *                       call has fewer bitstreams than workers (else every worker has a bitstream anyway), 1 = always,
  *                       2 = never (the notes are ignored)

@@ -879,7 +879,9 @@ def test_checkpointed_streams_are_the_same_bytes_and_decode_on_all_workers(oracl
     sym, s_, m_, w_, am, zbm, yqn = T.to_coder_inputs(*lat[1])
     assert bytes(r1[1][0][0]) == oracle.encode_gmm(mode, sym, s_, m_, w_)
     strings, ams, zbs = [r[0][0] for r in r1], [r[0][1] for r in r1], [r[0][2] for r in r1]
-    # on the GPU (the default for checkpointed bitstreams): one wave per segment, no tables; all five bitstreams decode there
+    # on the GPU (option gpu_decode = 1; by default the library takes it when a call has enough segments to make it the
+    # faster decoder - these few small items would go to the host's workers): one wave per segment, no tables
+    _lib.set_option(0, "gpu_decode", 1)
     out = ck.decompress_batch(strings, ams, zbs, ss, ms, ws)
     for o, r in zip(out, r1):
         assert torch.equal(o, r[1])
@@ -890,6 +892,13 @@ def test_checkpointed_streams_are_the_same_bytes_and_decode_on_all_workers(oracl
     one = ck.decompress(strings[0], ams[0], zbs[0], ss[0], ms[0], ws[0])
     assert torch.equal(one, r1[0][1]) and _lib.ctx_stat(0, 4) == 1
     assert 2 * (ams[2] + 1) + 2 > 2048  # the outliers' item is the one with the wide window (bypass-coded symbols on the table path)
+    _lib.set_option(0, "gpu_decode", 0)
+    # a whole Kodak-sized batch is the GPU's by default: 24 bitstreams x 125 segments
+    big = [T.make_latent(700 + i) for i in range(24)]
+    bt = [torch.cat([dv(l[k]) for l in big]) for k in range(4)]
+    rb = ck.compress_batch(*bt)
+    ob = ck.decompress_batch([x[0][0] for x in rb], [x[0][1] for x in rb], [x[0][2] for x in rb], *bt[1:])
+    assert all(torch.equal(o, x[1]) for o, x in zip(ob, rb)) and (_lib.ctx_stat(0, 4), _lib.ctx_stat(0, 5)) == (24, 0)
     # through the table path, segments on the host workers (gpu_decode = 2):
     # (threads, option ckpt_decode: 0 = segments when the call has fewer bitstreams than workers, 1 = always, 2 = never)
     for threads, how in ((16, 0), (3, 1), (1, 1), (3, 0), (16, 2)):
@@ -948,7 +957,7 @@ def test_checkpointed_codec_result_through_the_container():
     s2, shape2 = Cn.unpack(blob, device="cuda")
     assert all(isinstance(s_[0], CheckpointedBytes) for s_ in s2)
     assert torch.equal(plain.decompress(s2, shape2, sided)["y_hat"], e1["y_hat"])  # any decoder of this library uses the notes it is given
-    assert Cn.side_info_bytes(e1["strings"], e1["shape"]) - Cn.side_info_bytes(e0["strings"], e0["shape"]) == sum(8 + 16 * len(b[0].ckpt) for b in e1["strings"])
+    assert Cn.side_info_bytes(e1["strings"], e1["shape"]) - Cn.side_info_bytes(e0["strings"], e0["shape"]) == sum(8 + 12 * len(b[0].ckpt) for b in e1["strings"])
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -958,6 +967,7 @@ def test_gpu_segment_decoder_equals_the_table_path_in_every_variant(oracle, mode
     windows beyond 64 edges (several passes per symbol), bypass-coded symbols (the synthetic latents have ~0.2 % of them), dead channels, tiny items (one segment,
     fewer than 64 latents), and parameters the kernel must hand back (decreasing rows, NaN sigma)."""
     rng = np.random.default_rng(91)
+    _lib.set_option(0, "gpu_decode", 1)  # (small items: by default they would be the host workers')
     cases = []
     for f16, clamp, logits in ((False, True, False), (True, True, False), (False, False, False), (False, True, True)):
         y, sg, mu, pi = T.make_latent(400 + len(cases), M=40, h=16, w=12, clamp=False, zero_frac=0.2)
@@ -1013,6 +1023,7 @@ def test_gpu_segment_decoder_equals_the_table_path_in_every_variant(oracle, mode
     except RuntimeError:
         got = None
     assert (want is None and got is None) or torch.equal(got, want)
+    _lib.set_option(0, "gpu_decode", 0)
 
 
 def test_wrong_checkpoints_cost_a_sequential_decode_never_a_wrong_symbol():
@@ -1042,7 +1053,7 @@ def test_wrong_checkpoints_cost_a_sequential_decode_never_a_wrong_symbol():
         else:
             ck["x"][:] = ck["x"][::-1].copy()
         bad = CheckpointedBytes(bytes(b), ck, 512)
-        for gpu in (0, 2):  # the GPU's segment decoder hands the bitstream back; the host's segments fall back to a sequential decode
+        for gpu in (1, 2):  # the GPU's segment decoder hands the bitstream back; the host's segments fall back to a sequential decode
             _lib.set_option(0, "gpu_decode", gpu)
             try:
                 assert torch.equal(gmc.decompress(bad, am, zb, *t[1:]), yq), (trial, gpu)

@@ -103,18 +103,18 @@ def test_container_carries_checkpointed_streams():
     from flashgmm_amd.entropy_models import CKPT_DTYPE
 
     ck = np.zeros(3, CKPT_DTYPE)
-    ck["x"], ck["pos"] = [1 << 31, (1 << 63) + 5, 12345678901234], [0, 7, 1 << 33]
+    ck["x"], ck["pos"] = [1 << 31, (1 << 63) + 5, 12345678901234], [0, 7, (1 << 32) - 1]
     data = bytes(range(200)) * 3
     zb = torch.tensor([1, 0, 1, 1, 0], dtype=torch.int64)
     plain = [(data, 17, zb), [b"zz"]]
     noted = [(CheckpointedBytes(data, ck, 1024), 17, zb), [b"zz"]]
     b0, b1 = Cn.pack(plain, (5, 4, 6)), Cn.pack(noted, (5, 4, 6))
-    assert len(b1) == len(b0) + 8 + 16 * 3
+    assert len(b1) == len(b0) + 8 + 12 * 3
     s0, _ = Cn.unpack(b0)
     s1, shape = Cn.unpack(b1)
     assert type(s0[0][0]) is bytes and isinstance(s1[0][0], CheckpointedBytes) and s1[0][0] == data == s0[0][0]
     assert s1[0][0].ckpt_stride == 1024 and np.array_equal(s1[0][0].ckpt, ck) and shape == (5, 4, 6)
-    assert Cn.side_info_bytes(noted, (5, 4, 6)) == Cn.side_info_bytes(plain, (5, 4, 6)) + 8 + 48  # counted as side information
+    assert Cn.side_info_bytes(noted, (5, 4, 6)) == Cn.side_info_bytes(plain, (5, 4, 6)) + 8 + 36  # counted as side information
     with pytest.raises(ValueError):
         Cn.unpack(b1[:-30] + b1[-10:])
 
