@@ -8,7 +8,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-OUT=../libflashgmm_amd.so
+OUT=${OUT:-../libflashgmm_amd.so}
 COMMON="-O3 -fPIC -std=c++17 -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math"
 $HIPCC $COMMON --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc -Xarch_device -fno-slp-vectorize \
     -march=x86-64-v3 -shared -o $OUT fgmm_kernels.hip fgmm_tab.hip fgmm_rans.cpp fgmm_capi.cpp -lpthread "$@"

@@ -712,6 +712,14 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
 // Anything else (a non-monotone row, cf beyond every edge) flags the segment "hard"; a segment that does not end in the next
 // checkpoint's (state, position) flags "mismatch" - the host then decodes that bitstream through the table path, so the
 // result is the sequential decoder's in every case and a wrong note costs time, never a symbol.
+#ifdef FGMM_SEG_PROF // dev aid: cycles per phase, summed over the waves of every launch (read with fgmm_debug_segprof)
+__device__ unsigned long long g_segprof[8];
+#define SEG_T(v) const unsigned long long v = clock64()
+#define SEG_ACC(i, v) seg_acc[i] += (unsigned long long)(v)
+#else
+#define SEG_T(v)
+#define SEG_ACC(i, v)
+#endif
 constexpr int kSegCapE = 2048;  // edges (uint16) one wave keeps in LDS for the latents of a batch (the less LDS a wave takes the
                                 // more waves a SIMD holds, and the decode chain of a wave is latency: 9.3 KB -> 17 waves per CU)
 constexpr int kSegLds = 64 * 64 + 2 * kSegCapE + 4 * 68 + 3 * 4 * 64; // parameters of 64 latents | edges | pair offsets | windows, tails, flags
@@ -741,25 +749,28 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
   const int64_t nw = d.n_words - 2;
   uint32_t x_lo, x_hi;
   int64_t wbase;
+  // (the descriptor's pointers are generic: a load through one counts as divergent, and everything computed from it leaves the
+  // scalar unit - hence global loads and an explicit "this is uniform" on what the coder starts from)
+  auto uni64 = [&](uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); };
   if (sg == 0) {
-    x_lo = uni(d.words[0]);
-    x_hi = uni(d.words[1]);
+    x_lo = uni(ldg<uint32_t>(d.words));
+    x_hi = uni(ldg<uint32_t>(d.words + 1));
     wbase = 0;
   } else {
-    const fgmm_ckpt c = d.ckpt[sg - 1];
-    x_lo = uni((uint32_t)c.x);
-    x_hi = uni((uint32_t)(c.x >> 32));
-    wbase = (int64_t)c.pos;
+    const uint64_t cx = ldg<uint64_t>(&d.ckpt[sg - 1].x), cp = ldg<uint64_t>(&d.ckpt[sg - 1].pos);
+    x_lo = uni((uint32_t)cx);
+    x_hi = uni((uint32_t)(cx >> 32));
+    wbase = (int64_t)uni64(cp);
   }
   uint32_t err = (wbase < 0 || wbase > nw) ? kSegMismatch : kSegOk;
   if (err) wbase = 0;
   // the next 64 words of the bitstream across the lanes; `wp` of them are consumed
-  uint32_t wv = wbase + lane < nw ? w[wbase + lane] : 0u;
+  uint32_t wv = wbase + lane < nw ? ldg<uint32_t>(w + wbase + lane) : 0u;
   uint32_t wp = 0;
   auto next_word = [&]() -> uint32_t { // wave-uniform
     if (wp == 64) {
       wbase += 64;
-      wv = wbase + lane < nw ? w[wbase + lane] : 0u;
+      wv = wbase + lane < nw ? ldg<uint32_t>(w + wbase + lane) : 0u;
       wp = 0;
     }
     if (wbase + wp >= nw) err = kSegStream;
@@ -768,11 +779,16 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
     return r;
   };
 
+#ifdef FGMM_SEG_PROF
+  unsigned long long seg_acc[6] = {};
+#endif
+  SEG_T(t_begin);
   for (int64_t base = lo; base < hi && !err;) {
+    SEG_T(t_a);
     // ---- A. lane = latent base + lane: parameters -> LDS, evaluation window; how many latents fit the edge budget
     const int64_t i = std::min(base + lane, hi - 1);
     const int64_t cj = i / d.hw, p = i - cj * d.hw;
-    const int c = d.chan_list ? d.chan_list[cj] : (int)cj;
+    const int c = d.chan_list ? ldg<int32_t>(d.chan_list + cj) : (int)cj;
     const int64_t pbase = (int64_t)c * d.stride_c + p * d.stride_p;
     float mu[4], sgm[4], pi[4], rs[4];
     bool tame = true;
@@ -826,6 +842,7 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wave are done (one wave per workgroup: no barrier)
     __builtin_amdgcn_wave_barrier();
 
+    SEG_T(t_b);
     // ---- B. flattened over (latent, pair of consecutive edges): the tab_kernel's evaluation, edges -> LDS
     {
       int l = 0;
@@ -836,6 +853,7 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
         l_beg = offP[l];
         l_end = l + 1 < nk ? offP[l + 1] : NP;
       }
+      uint32_t carry = 0; // the pair before lane 0's: lane 63's of the step before
       for (; t < NP; t += 64) {
         while (t >= l_end) { // next latent with a non-empty window
           ++l;
@@ -867,49 +885,88 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
           c0 = mix4_slow<MODE>(x0, mu_[0], mu_[1], mu_[2], mu_[3], s4[0], s4[1], s4[2], s4[3], pi_[0], pi_[1], pi_[2], pi_[3]);
           c1 = mix4_slow<MODE>(x1, mu_[0], mu_[1], mu_[2], mu_[3], s4[0], s4[1], s4[2], s4[3], pi_[0], pi_[1], pi_[2], pi_[3]);
         }
-        E32[t] = quant16(c0) | (quant16(c1) << 16);
+        const uint32_t q0 = quant16(c0), q1 = quant16(c1), pk = q0 | (q1 << 16);
+        E32[t] = pk;
+        // ... and which rows DECREASE somewhere.  A count of the edges <= cf is the symbol's interval only in a monotone row; the
+        // reference's bisection may answer differently when the row decreases anywhere (rans_interface.cpp:833-854), so such a
+        // latent is left to the table path.  The pair before this one sits in the lane below (wave_shr:1; lane 0: `carry`); an
+        // odd window's last pair holds F[j_hi] as well: a real edge, checked like the others.
+        const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)pk, 0x138, 0xF, 0xF, false);
+        const uint32_t prev = t > l_beg ? before >> 16 : 0u; // F below the window is 0
+        if (prev > q0 || q0 > q1) nmL[l] = 1;
+        carry = bcast(pk, 63u);
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    // ... and which rows DECREASE somewhere (flattened too: off the sequential chain below).  A count of the edges <= cf is the
-    // symbol's interval only in a monotone row; the reference's bisection may answer differently when the row decreases
-    // anywhere (rans_interface.cpp:833-854), so such a latent is left to the table path.  An odd window's last pair holds
-    // F[j_hi] as well: a real edge, checked like the others.
-    {
-      int l = 0;
-      uint32_t l_beg = 0, l_end = 0;
-      uint32_t t = lane;
-      if (t < NP) {
-        l = find_owner(offP, nk, t);
-        l_beg = offP[l];
-        l_end = l + 1 < nk ? offP[l + 1] : NP;
-      }
-      for (; t < NP; t += 64) {
-        while (t >= l_end) {
-          ++l;
-          l_beg = l_end;
-          l_end = l + 1 < nk ? offP[l + 1] : NP;
-        }
-        const uint32_t cur = E32[t], prev = t > l_beg ? E32[t - 1] >> 16 : 0u; // F below the window is 0
-        if (prev > (cur & 0xFFFFu) || (cur & 0xFFFFu) > (cur >> 16)) nmL[l] = 1;
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nm = nmL[lane];
+    SEG_T(t_m);
+    SEG_T(t_c);
+    // ---- per latent, lane = latent: everything of the search that does not depend on cf.  A latent is "plain" when its window is
+    // monotone - into the saturated tail too - and fits one pass of the wave; its symbol is then decoded on the straight path below
+    const uint32_t len_l = win >> 16, jl_l = win & 0xFFFFu;
+    const bool tail_l = (int)(jl_l + len_l) < W;
+    const uint32_t last_l = len_l ? (uint32_t)E16[2u * excl + len_l - 1u] : 0u; // (F below the window is 0)
+    const bool slow_l = nmL[lane] != 0 || len_l > 64u || (tail_l && T_sat < last_l);
+    const uint32_t pa = (2u * excl) | ((len_l & 0x7Fu) << 12) | (jl_l << 19); // first edge in LDS (<= 2048) | edges (<= 64) | j_lo (<= 2048)
+    const uint32_t pb = (tail_l ? T_sat : 0u) | (slow_l ? 0x10000u : 0u);      // F beyond the window (none: 0 = "no interval up there")
 
     // ---- C. symbol by symbol, lane = edge of latent base + k, edges from LDS
     const int64_t oidx = (int64_t)c * d.hw + p;
     int32_t myval = 0;
+    auto put = [&](int32_t v, int k) { // myval of lane k = v (both wave-uniform; two SGPR operands exceed the constant bus: the lane goes through m0)
+      asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myval) : "s"(v), "s"(k) : "m0");
+    };
+    // x = freq * (x >> 16) + bias, 64 bits, spelled out for the scalar unit (the compiler multiplies 64-bit values on the VALU)
+    auto advance = [&](uint32_t freq, uint32_t bias, uint32_t &lo, uint32_t &hi) {
+      const uint64_t xs = (((uint64_t)x_hi << 32) | x_lo) >> 16;
+      const uint32_t s_lo = (uint32_t)xs, s_hi = (uint32_t)(xs >> 32);
+      uint32_t t;
+      asm("s_mul_hi_u32 %1, %3, %4\n\ts_mul_i32 %2, %3, %5\n\ts_mul_i32 %0, %3, %4\n\ts_add_u32 %1, %1, %2\n\ts_add_u32 %0, %0, %6\n\ts_addc_u32 %1, %1, 0"
+          : "=&s"(lo), "=&s"(hi), "=&s"(t)
+          : "s"(freq), "s"(s_lo), "s"(s_hi), "s"(bias)
+          : "scc");
+    };
+    uint32_t bad_acc = 0; // hard cases of the straight path, looked at once per batch (nothing below can leave the stream or the LDS)
+    // (the edges of symbol k + 1 do not depend on the coder: they are read from LDS while symbol k is searched and advanced)
+    uint32_t a_n = bcast(pa, 0u), b_n = bcast(pb, 0u);
+    uint32_t E_n = (uint32_t)E16[(a_n & 0xFFFu) + lane]; // (lanes past the window read their neighbours' edges: masked out below)
     for (int k = 0; k < nk && !err; ++k) {
       // the coder's state is wave-uniform; saying so at the top of every symbol keeps this body on the scalar unit
       x_lo = uni(x_lo);
       x_hi = uni(x_hi);
       wp = uni(wp);
       const uint32_t cf = x_lo & 0xFFFFu;
+      const uint32_t a = a_n, b = b_n, E = E_n;
+      {
+        const uint32_t k1 = (uint32_t)std::min(k + 1, nk - 1);
+        a_n = bcast(pa, k1);
+        b_n = bcast(pb, k1);
+        E_n = (uint32_t)E16[(a_n & 0xFFFu) + lane];
+      }
+      if (__builtin_expect(cf != 0xFFFFu && !(b >> 16), 1)) {
+        // count the edges <= cf: the wavefront form of the reference's bisection (rans_interface.cpp:826-862) in a monotone row
+        const uint32_t len = (a >> 12) & 0x7Fu, jl = a >> 19;
+        const uint32_t n = (uint32_t)__popcll(__ballot(lane < len && E <= cf));
+        const uint32_t st_raw = bcast(E, n - 1u), nx_raw = bcast(E, n);
+        const uint32_t start = n ? st_raw : 0u, next = n < len ? nx_raw : (b & 0xFFFFu);
+        // F[J] <= cf < F[J + 1], J = jl + n - 1 in [0, W - 2] (rans_interface.cpp:826-833; J = W - 1 has next = 0: freq <= 0)
+        const uint32_t freq = next - start;
+        const int32_t J = (int32_t)(jl + n) - 1;
+        bad_acc |= (uint32_t)(J >> 31) | ((freq - 1u) >> 16);
+        // x = freq * (x >> 16) + (cf - start), 64 bits, on the scalar unit (Rans64DecAdvance, rans64.h:124-142)
+        uint32_t n_lo, n_hi;
+        advance(freq, cf - start, n_lo, n_hi);
+        if (n_hi == 0 && n_lo < 0x80000000u) { // x < 2^31: one more word
+          n_hi = n_lo;
+          n_lo = next_word();
+        }
+        x_lo = n_lo;
+        x_hi = n_hi;
+        put(J - max_bs, k);
+        continue;
+      }
       int32_t value;
-      if (__builtin_expect(cf == 0xFFFFu, 0)) { // bypass escape: Rans64DecAdvance(65535, 1), then the nibbles (rans_interface.cpp:808-824)
+      if (cf == 0xFFFFu) { // bypass escape: Rans64DecAdvance(65535, 1), then the nibbles (rans_interface.cpp:808-824)
         uint64_t xx = ((((uint64_t)x_hi << 32) | x_lo) >> 16) + cf - 0xFFFFu;
         auto renorm = [&]() {
           if (xx < (1ull << 31)) xx = (xx << 32) | next_word();
@@ -931,13 +988,12 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
         value = (int32_t)raw;
         x_lo = uni((uint32_t)xx);
         x_hi = uni((uint32_t)(xx >> 32));
-      } else {
-        const uint32_t wk = bcast(win, (uint32_t)k), tk = bcast(tsf, (uint32_t)k), e0 = 2u * bcast(excl, (uint32_t)k);
+      } else { // a window longer than the wave, or a row that decreases somewhere: 64 edges per pass / left to the table path
+        const uint32_t wk = bcast(win, (uint32_t)k), tk = bcast(tsf, (uint32_t)k), e0 = a & 0xFFFu;
         const int jl = (int)(wk & 0xFFFFu), len = (int)(wk >> 16), jh = jl + len;
         const uint32_t tsat = tk & 0xFFFFu;
-        // count the edges <= cf, 64 per pass (monotone rows only: phase B's flag)
         uint32_t below = 0, last = 0, start = 0, next = 0; // `last`: the edge before this pass (F below the window is 0)
-        bool found = false, bad = bcast(nm, (uint32_t)k) != 0;
+        bool found = false, bad = bcast(nmL[lane], (uint32_t)k) != 0;
         for (int off = 0; off < len; off += 64) {
           const int q = off + (int)lane;
           const bool valid = q < len;
@@ -964,8 +1020,6 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
           next = tsat;
           bad = bad || !(jh < W && tsat > cf);
         }
-        // F[J] <= cf < F[J + 1] with J = jl + below - 1 >= 0  (J = jl - 1: the zeros below the window; the reference's range is
-        // J in [0, W - 2]: rans_interface.cpp:826-833)
         const int J = jl + (int)below - 1;
         const uint32_t freq = next - start;
         if (__builtin_expect(bad || J < 0 || J > W - 2 || freq == 0 || freq > 0xFFFFu, 0)) {
@@ -973,7 +1027,6 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
           break;
         }
         value = J - max_bs;
-        // x = freq * (x >> 16) + (cf - start), 64 bits, on the scalar unit (Rans64DecAdvance)
         const uint32_t s_lo = (x_lo >> 16) | (x_hi << 16), s_hi = x_hi >> 16;
         const uint64_t pr = (uint64_t)freq * s_lo + (((uint64_t)(freq * s_hi)) << 32) + (uint64_t)(cf - start);
         uint32_t n_lo = (uint32_t)pr, n_hi = (uint32_t)(pr >> 32);
@@ -986,18 +1039,38 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
       }
       if (lane == (uint32_t)k) myval = value;
     }
-    if (!err && (int)lane < nk) d.y_hat[oidx] = (float)myval;
+    if (bad_acc && !err) err = kSegHard;
+    SEG_T(t_e);
+    SEG_ACC(0, t_b - t_a); SEG_ACC(1, t_m - t_b); SEG_ACC(2, t_c - t_m); SEG_ACC(3, t_e - t_c); SEG_ACC(4, nk); SEG_ACC(5, 1);
+    if (!err && (int)lane < nk) stg<float>(d.y_hat + oidx, (float)myval);
     base += nk;
     __builtin_amdgcn_wave_barrier(); // the next batch overwrites the LDS this one read
   }
   // ---- the segment must end exactly where the next checkpoint says the coder stands
   if (!err && sg < d.n_ckpt) {
-    const fgmm_ckpt c = d.ckpt[sg];
+    const uint64_t cx = ldg<uint64_t>(&d.ckpt[sg].x), cp = ldg<uint64_t>(&d.ckpt[sg].pos);
     const uint64_t x = ((uint64_t)x_hi << 32) | x_lo;
-    if (x != c.x || (uint64_t)(wbase + wp) != c.pos) err = kSegMismatch;
+    if (x != cx || (uint64_t)(wbase + wp) != cp) err = kSegMismatch;
   }
-  if (lane == 0) d.status[sg] = err;
+  if (lane == 0) stg<uint32_t>(d.status + sg, err);
+#ifdef FGMM_SEG_PROF
+  if (lane == 0) {
+    for (int q = 0; q < 6; ++q) atomicAdd(&g_segprof[q], seg_acc[q]);
+    atomicAdd(&g_segprof[6], (unsigned long long)(clock64() - t_begin));
+    atomicAdd(&g_segprof[7], 1ull);
+  }
+#endif
 }
+#ifdef FGMM_SEG_PROF
+extern "C" int fgmm_debug_segprof(unsigned long long *out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_segprof), sizeof(g_segprof));
+  if (reset) {
+    unsigned long long z[8] = {};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_segprof), z, sizeof(z));
+  }
+  return rc;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // launchers

@@ -1,0 +1,31 @@
+"""Dev aid (GPU): where a segdec_kernel wave spends its cycles.  Needs a library built with -DFGMM_SEG_PROF:
+    OUT=$PWD/ab/lib_segprof.so bash flashgmm_amd/csrc/build.sh -DFGMM_SEG_PROF
+    FGMM_LIB=ab/lib_segprof.so python scripts/segprof.py [stride] [images]"""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+stride = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+nimg = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+dev = torch.device("cuda:0")
+L = _lib.lib()
+L.fgmm_debug_segprof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+lat = [T.make_latent(i) for i in range(nimg)]
+ys, ss, ms, ws = (torch.cat([torch.from_numpy(l[k]) for l in lat]).to(dev) for k in range(4))
+gmc = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=stride)
+_lib.set_option(0, "gpu_decode", 1)
+res = gmc.compress_batch(ys, ss, ms, ws)
+args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+for _ in range(3): gmc.decompress_batch(*args)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 8)()
+L.fgmm_debug_segprof(buf, 1)
+n = 5
+t0 = time.perf_counter()
+for _ in range(n): gmc.decompress_batch(*args)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n * 1e3
+L.fgmm_debug_segprof(buf, 0)
+a, b, m, c, syms, batches, total, waves = (int(v) / n for v in buf)
+print(f"stride {stride} items {nimg}: call {dt:.3f} ms; waves {waves:.0f}, batches/wave {batches / waves:.1f}, symbols/batch {syms / batches:.1f}")
+print(f"cycles per symbol: A {a / syms:.0f}  B {b / syms:.0f}  monotone {m / syms:.0f}  C {c / syms:.0f}  whole wave {total / syms:.0f}   (per wave {total / waves / 1e3:.0f} k cycles)")
