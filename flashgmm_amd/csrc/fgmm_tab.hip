@@ -714,28 +714,49 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
 // result is the sequential decoder's in every case and a wrong note costs time, never a symbol.
 #ifdef FGMM_SEG_PROF // dev aid: cycles per phase, summed over the waves of every launch (read with fgmm_debug_segprof)
 __device__ unsigned long long g_segprof[8];
+__device__ unsigned long long g_segtimes[2 * 16384]; // begin, end of the first 16384 segments of the last launch
 #define SEG_T(v) const unsigned long long v = clock64()
 #define SEG_ACC(i, v) seg_acc[i] += (unsigned long long)(v)
 #else
 #define SEG_T(v)
 #define SEG_ACC(i, v)
 #endif
-constexpr int kSegCapE = 2048;  // edges (uint16) one wave keeps in LDS for the latents of a batch (the less LDS a wave takes the
-                                // more waves a SIMD holds, and the decode chain of a wave is latency: 9.3 KB -> 17 waves per CU)
-constexpr int kSegLds = 64 * 64 + 2 * kSegCapE + 4 * 68 + 3 * 4 * 64; // parameters of 64 latents | edges | pair offsets | windows, tails, flags
+constexpr int kSegCapE = 2048; // edges (uint16) of one batch of latents in LDS
+// One batch as the producer wave hands it to the consumer wave (two of them: one being filled while the other is decoded)
+constexpr int kSegBufE = 0;                       // uint16[kSegCapE] edges, latent after latent (each from an even index on)
+constexpr int kSegBufPa = 2 * kSegCapE;           // uint32[64] first edge (12 bits) | edges (7) | j_lo - 1 - max_bs (13, signed)
+constexpr int kSegBufPb = kSegBufPa + 256;        // uint32[64] F beyond the window (16; 0: nothing up there) | slow | decreases | has a tail
+constexpr int kSegBufPc = kSegBufPb + 256;        // uint32[64] j_lo | edges << 16 (the slow path's: windows beyond 63 edges)
+constexpr int kSegBufOut = kSegBufPc + 256;       // int64[64] where the latent's value goes in y_hat
+constexpr int kSegBufNk = kSegBufOut + 512;       // uint32 latents in the batch
+constexpr int kSegBufBytes = kSegBufNk + 16;
+constexpr int kSegLdsP = 0;                       // producer's own: parameters of 64 latents | pair offsets | windows, tails, flags
+constexpr int kSegLdsOff = 64 * 64;
+constexpr int kSegLdsCtrl = kSegLdsOff + 4 * 68 + 3 * 4 * 64;
+constexpr int kSegLdsBuf = kSegLdsCtrl + 16;
+constexpr int kSegLds = kSegLdsBuf + 2 * kSegBufBytes; // 15.9 KB per segment: ten segments = twenty waves per CU
+// Two waves per segment.  The PRODUCER (wave 1) does what needs no coder state, a batch of up to 64 latents ahead:
+//   A lane = latent: twelve parameters, clamp + reciprocals, the window between the saturated tails (tab_kernel's phase 0);
+//     as many latents as fit kSegCapE edges form the batch
+//   B flattened over (latent, pair of consecutive edges): tab_kernel's phase 2, the same packed arithmetic, edges -> LDS; the
+//     pair in the lane below tells whether the row decreases there
+//   per latent: everything of the search that does not depend on cf, packed into two words
+// The CONSUMER (wave 0) walks the batch symbol by symbol on the scalar unit: lane = edge, one compare + popcount is the
+// reference's bisection in a monotone row, two v_readlane pick F[J] and F[J + 1], the 64-bit state advances in SGPRs.  While it
+// decodes batch n the producer evaluates batch n + 1 (on another SIMD of the CU): the sequential chain never waits for edges.
 template <int MODE, bool CLAMPED, typename PT>
-__global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ descs, const SegRef *__restrict__ segs, int64_t n_segs) {
+__global__ __launch_bounds__(128) void segdec_kernel(const SegDesc *__restrict__ descs, const SegRef *__restrict__ segs, int64_t n_segs) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kSegLds];
-  float4_t *const P = reinterpret_cast<float4_t *>(lds);                       // [64][4]: mu, sigma (clamped), pi, refined 1/sigma
-  uint32_t *const E32 = reinterpret_cast<uint32_t *>(lds + 64 * 64);           // [kSegCapE / 2] two edges per word
-  const uint16_t *const E16 = reinterpret_cast<const uint16_t *>(E32);
-  uint32_t *const offP = reinterpret_cast<uint32_t *>(lds + 64 * 64 + 2 * kSegCapE); // [65] pairs before latent l of the batch
+  float4_t *const P = reinterpret_cast<float4_t *>(lds + kSegLdsP);         // [64][4]: mu, sigma (clamped), pi, refined 1/sigma
+  uint32_t *const offP = reinterpret_cast<uint32_t *>(lds + kSegLdsOff);    // [65] pairs before latent l of the batch
   uint32_t *const winL = offP + 68, *const tsfL = winL + 64; // [64] j_lo | len << 16;  T_sat | tame << 16  (read by OTHER lanes in
                                                              // phase B, some of which have left the loop: not a cross-lane register read)
   uint32_t *const nmL = tsfL + 64;                           // [64] the latent's row decreases somewhere
+  volatile uint32_t *const ctrl = reinterpret_cast<volatile uint32_t *>(lds + kSegLdsCtrl); // [2] the consumer has given up (per batch parity)
   const int64_t wid = blockIdx.x;
   if (wid >= n_segs) return;
-  const uint32_t lane = threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool producer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
   const SegRef ref = segs[wid];
   const SegDesc &d = descs[ref.item];
   const int64_t sg = ref.seg;
@@ -744,47 +765,17 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
   const int W = 2 * max_bs + 2; // <= kSegCapE (the host sends wider items through the table path)
   auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   auto bcast = [](uint32_t v, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)k); };
-  // ---- the coder at symbol lo: the stream's own head (segment 0) or the checkpoint before this segment
-  const uint32_t *__restrict__ w = d.words + 2;
-  const int64_t nw = d.n_words - 2;
-  uint32_t x_lo, x_hi;
-  int64_t wbase;
-  // (the descriptor's pointers are generic: a load through one counts as divergent, and everything computed from it leaves the
-  // scalar unit - hence global loads and an explicit "this is uniform" on what the coder starts from)
-  auto uni64 = [&](uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); };
-  if (sg == 0) {
-    x_lo = uni(ldg<uint32_t>(d.words));
-    x_hi = uni(ldg<uint32_t>(d.words + 1));
-    wbase = 0;
-  } else {
-    const uint64_t cx = ldg<uint64_t>(&d.ckpt[sg - 1].x), cp = ldg<uint64_t>(&d.ckpt[sg - 1].pos);
-    x_lo = uni((uint32_t)cx);
-    x_hi = uni((uint32_t)(cx >> 32));
-    wbase = (int64_t)uni64(cp);
-  }
-  uint32_t err = (wbase < 0 || wbase > nw) ? kSegMismatch : kSegOk;
-  if (err) wbase = 0;
-  // the next 64 words of the bitstream across the lanes; `wp` of them are consumed
-  uint32_t wv = wbase + lane < nw ? ldg<uint32_t>(w + wbase + lane) : 0u;
-  uint32_t wp = 0;
-  auto next_word = [&]() -> uint32_t { // wave-uniform
-    if (wp == 64) {
-      wbase += 64;
-      wv = wbase + lane < nw ? ldg<uint32_t>(w + wbase + lane) : 0u;
-      wp = 0;
-    }
-    if (wbase + wp >= nw) err = kSegStream;
-    const uint32_t r = bcast(wv, wp);
-    ++wp;
-    return r;
-  };
-
+  auto buf = [&](int n) { return lds + kSegLdsBuf + (n & 1) * kSegBufBytes; };
 #ifdef FGMM_SEG_PROF
   unsigned long long seg_acc[6] = {};
 #endif
   SEG_T(t_begin);
-  for (int64_t base = lo; base < hi && !err;) {
+
+  // =============================== producer: batch [base, base + nk) -> B ===============================
+  auto produce = [&](int64_t base, unsigned char *B) {
     SEG_T(t_a);
+    uint32_t *const E32 = reinterpret_cast<uint32_t *>(B + kSegBufE);
+    const uint16_t *const E16 = reinterpret_cast<const uint16_t *>(E32);
     // ---- A. lane = latent base + lane: parameters -> LDS, evaluation window; how many latents fit the edge budget
     const int64_t i = std::min(base + lane, hi - 1);
     const int64_t cj = i / d.hw, p = i - cj * d.hw;
@@ -821,7 +812,6 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
     P[4 * lane + 2] = (float4_t){pi[0], pi[1], pi[2], pi[3]};
     P[4 * lane + 3] = (float4_t){rs[0], rs[1], rs[2], rs[3]};
     const uint32_t win = (uint32_t)j_lo | ((uint32_t)(j_hi - j_lo) << 16);
-    const uint32_t tsf = T_sat | (tame ? 0x10000u : 0u);
     const int nk_max = (int)std::min<int64_t>(64, hi - base);
     const uint32_t pairs = (int)lane < nk_max ? (uint32_t)(j_hi - j_lo + 1) >> 1 : 0u;
     uint32_t incl = pairs;
@@ -835,13 +825,12 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
     const uint32_t excl = incl - pairs;
     offP[lane] = excl;
     winL[lane] = win;
-    tsfL[lane] = tsf;
+    tsfL[lane] = T_sat | (tame ? 0x10000u : 0u);
     nmL[lane] = 0;
     const uint32_t NP = bcast(incl, (uint32_t)(nk - 1));
     if (lane == 0) offP[64] = NP; // (offP[nk] is what a walk past the last latent reads: lanes' own entries hold it for nk < 64)
-    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wave are done (one wave per workgroup: no barrier)
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS writes are done (its own arrays: no barrier)
     __builtin_amdgcn_wave_barrier();
-
     SEG_T(t_b);
     // ---- B. flattened over (latent, pair of consecutive edges): the tab_kernel's evaluation, edges -> LDS
     {
@@ -899,72 +888,125 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    SEG_T(t_m);
-    SEG_T(t_c);
     // ---- per latent, lane = latent: everything of the search that does not depend on cf.  A latent is "plain" when its window is
-    // monotone - into the saturated tail too - and fits one pass of the wave; its symbol is then decoded on the straight path below
+    // monotone - into the saturated tail too -, fits one pass of the wave with a lane to spare, and cannot put cf below F[0]
     const uint32_t len_l = win >> 16, jl_l = win & 0xFFFFu;
     const bool tail_l = (int)(jl_l + len_l) < W;
-    const uint32_t last_l = len_l ? (uint32_t)E16[2u * excl + len_l - 1u] : 0u; // (F below the window is 0)
-    const bool slow_l = nmL[lane] != 0 || len_l > 64u || (tail_l && T_sat < last_l);
-    const uint32_t pa = (2u * excl) | ((len_l & 0x7Fu) << 12) | (jl_l << 19); // first edge in LDS (<= 2048) | edges (<= 64) | j_lo (<= 2048)
-    const uint32_t pb = (tail_l ? T_sat : 0u) | (slow_l ? 0x10000u : 0u);      // F beyond the window (none: 0 = "no interval up there")
+    const bool mine = (int)lane < nk && len_l != 0; // (lanes past the batch would read past its edges)
+    const uint32_t first_l = mine ? (uint32_t)E16[2u * excl] : 1u, last_l = mine ? (uint32_t)E16[2u * excl + len_l - 1u] : 0u;
+    const uint32_t nm_l = nmL[lane];
+    const bool slow_l = nm_l != 0 || len_l > 63u || (tail_l && T_sat < last_l) || (jl_l == 0 && first_l != 0);
+    uint32_t *const Bw = reinterpret_cast<uint32_t *>(B);
+    Bw[kSegBufPa / 4 + lane] = (2u * excl) | ((len_l & 0x7Fu) << 12) | ((uint32_t)((int)jl_l - 1 - max_bs) << 19);
+    Bw[kSegBufPb / 4 + lane] = (tail_l ? T_sat : 0u) | (slow_l ? 0x10000u : 0u) | (nm_l ? 0x20000u : 0u) | (tail_l ? 0x40000u : 0u);
+    Bw[kSegBufPc / 4 + lane] = win;
+    reinterpret_cast<int64_t *>(B + kSegBufOut)[lane] = (int64_t)c * d.hw + p;
+    if (lane == 0) Bw[kSegBufNk / 4] = (uint32_t)nk;
+    SEG_T(t_e);
+    SEG_ACC(0, t_b - t_a);
+    SEG_ACC(1, t_e - t_b);
+  };
 
-    // ---- C. symbol by symbol, lane = edge of latent base + k, edges from LDS
-    const int64_t oidx = (int64_t)c * d.hw + p;
+  // =============================== consumer: the coder ===============================
+  // the coder at symbol lo: the stream's own head (segment 0) or the checkpoint before this segment.  (The descriptor's pointers
+  // are generic: a load through one counts as divergent and everything computed from it leaves the scalar unit - hence global
+  // loads and an explicit "this is uniform" on what the coder starts from.)
+  const uint32_t *__restrict__ w = d.words + 2;
+  const int64_t nw = d.n_words - 2;
+  uint32_t x_lo = 0, x_hi = 0, err = kSegOk, wv = 0, wp = 0, wleft = 0;
+  int64_t wbase = 0;
+  auto uni64 = [&](uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); };
+  if (!producer) {
+    if (sg == 0) {
+      x_lo = uni(ldg<uint32_t>(d.words));
+      x_hi = uni(ldg<uint32_t>(d.words + 1));
+    } else {
+      const uint64_t cx = ldg<uint64_t>(&d.ckpt[sg - 1].x), cp = ldg<uint64_t>(&d.ckpt[sg - 1].pos);
+      x_lo = uni((uint32_t)cx);
+      x_hi = uni((uint32_t)(cx >> 32));
+      wbase = (int64_t)uni64(cp);
+    }
+    if (wbase < 0 || wbase > nw) {
+      err = kSegMismatch;
+      wbase = 0;
+    }
+    // the next 64 words of the bitstream across the lanes; `wp` of them are consumed, `wleft` are left in the stream
+    wv = wbase + lane < nw ? ldg<uint32_t>(w + wbase + lane) : 0u;
+    wleft = (uint32_t)std::min<int64_t>(nw - wbase, 0x7FFFFFFF);
+    if (lane == 0) ctrl[1] = 0;
+  }
+  uint32_t sout = 0; // the stream ran out
+  auto next_word = [&]() -> uint32_t { // wave-uniform
+    if (wp == 64) {
+      wbase += 64;
+      wv = wbase + lane < nw ? ldg<uint32_t>(w + wbase + lane) : 0u;
+      wp = 0;
+    }
+    if (wleft == 0) sout = 1; else --wleft;
+    const uint32_t r = bcast(wv, wp);
+    ++wp;
+    return r;
+  };
+  // x = freq * (x >> 16) + bias, 64 bits, spelled out for the scalar unit (the compiler multiplies 64-bit values on the VALU)
+  auto advance = [&](uint32_t freq, uint32_t bias) {
+    const uint64_t xs = (((uint64_t)x_hi << 32) | x_lo) >> 16;
+    const uint32_t s_lo = (uint32_t)xs, s_hi = (uint32_t)(xs >> 32);
+    uint32_t lo_, hi_, t;
+    asm("s_mul_hi_u32 %1, %3, %4\n\ts_mul_i32 %2, %3, %5\n\ts_mul_i32 %0, %3, %4\n\ts_add_u32 %1, %1, %2\n\ts_add_u32 %0, %0, %6\n\ts_addc_u32 %1, %1, 0"
+        : "=&s"(lo_), "=&s"(hi_), "=&s"(t)
+        : "s"(freq), "s"(s_lo), "s"(s_hi), "s"(bias)
+        : "scc");
+    if (hi_ == 0 && lo_ < 0x80000000u) { // x < 2^31: one more word (Rans64DecRenorm, rans64.h:136-142)
+      hi_ = lo_;
+      lo_ = next_word();
+    }
+    x_lo = lo_;
+    x_hi = hi_;
+  };
+  auto consume = [&](const unsigned char *B, int nk) {
+    SEG_T(t_c);
+    const uint16_t *const E16 = reinterpret_cast<const uint16_t *>(B + kSegBufE);
+    const uint32_t *const Bw = reinterpret_cast<const uint32_t *>(B);
+    const uint32_t pa = Bw[kSegBufPa / 4 + lane], pb = Bw[kSegBufPb / 4 + lane], pc = Bw[kSegBufPc / 4 + lane];
     int32_t myval = 0;
-    auto put = [&](int32_t v, int k) { // myval of lane k = v (both wave-uniform; two SGPR operands exceed the constant bus: the lane goes through m0)
-      asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myval) : "s"(v), "s"(k) : "m0");
-    };
-    // x = freq * (x >> 16) + bias, 64 bits, spelled out for the scalar unit (the compiler multiplies 64-bit values on the VALU)
-    auto advance = [&](uint32_t freq, uint32_t bias, uint32_t &lo, uint32_t &hi) {
-      const uint64_t xs = (((uint64_t)x_hi << 32) | x_lo) >> 16;
-      const uint32_t s_lo = (uint32_t)xs, s_hi = (uint32_t)(xs >> 32);
-      uint32_t t;
-      asm("s_mul_hi_u32 %1, %3, %4\n\ts_mul_i32 %2, %3, %5\n\ts_mul_i32 %0, %3, %4\n\ts_add_u32 %1, %1, %2\n\ts_add_u32 %0, %0, %6\n\ts_addc_u32 %1, %1, 0"
-          : "=&s"(lo), "=&s"(hi), "=&s"(t)
-          : "s"(freq), "s"(s_lo), "s"(s_hi), "s"(bias)
-          : "scc");
-    };
+    // myval of lane k = v (both wave-uniform; two SGPR operands exceed the constant bus: the lane goes through m0, which the
+    // compiler sets up itself before each of its own uses - the clobber keeps the statement out of such a pair)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    auto put = [&](int32_t v, int k) { asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myval) : "s"(v), "s"(k) : "m0"); };
+#pragma clang diagnostic pop
     uint32_t bad_acc = 0; // hard cases of the straight path, looked at once per batch (nothing below can leave the stream or the LDS)
     // (the edges of symbol k + 1 do not depend on the coder: they are read from LDS while symbol k is searched and advanced)
     uint32_t a_n = bcast(pa, 0u), b_n = bcast(pb, 0u);
     uint32_t E_n = (uint32_t)E16[(a_n & 0xFFFu) + lane]; // (lanes past the window read their neighbours' edges: masked out below)
-    for (int k = 0; k < nk && !err; ++k) {
-      // the coder's state is wave-uniform; saying so at the top of every symbol keeps this body on the scalar unit
-      x_lo = uni(x_lo);
-      x_hi = uni(x_hi);
-      wp = uni(wp);
-      const uint32_t cf = x_lo & 0xFFFFu;
-      const uint32_t a = a_n, b = b_n, E = E_n;
-      {
+    for (int k = 0; k < nk; ++k) {
+      // ---- a run of plain symbols: one exit, nothing but the straight path inside
+      uint32_t a, b, E, cf;
+      for (;;) {
+        a = a_n, b = b_n, E = E_n;
         const uint32_t k1 = (uint32_t)std::min(k + 1, nk - 1);
         a_n = bcast(pa, k1);
         b_n = bcast(pb, k1);
         E_n = (uint32_t)E16[(a_n & 0xFFFu) + lane];
-      }
-      if (__builtin_expect(cf != 0xFFFFu && !(b >> 16), 1)) {
-        // count the edges <= cf: the wavefront form of the reference's bisection (rans_interface.cpp:826-862) in a monotone row
-        const uint32_t len = (a >> 12) & 0x7Fu, jl = a >> 19;
-        const uint32_t n = (uint32_t)__popcll(__ballot(lane < len && E <= cf));
-        const uint32_t st_raw = bcast(E, n - 1u), nx_raw = bcast(E, n);
-        const uint32_t start = n ? st_raw : 0u, next = n < len ? nx_raw : (b & 0xFFFFu);
-        // F[J] <= cf < F[J + 1], J = jl + n - 1 in [0, W - 2] (rans_interface.cpp:826-833; J = W - 1 has next = 0: freq <= 0)
+        cf = x_lo & 0xFFFFu;
+        if (__builtin_expect((((cf + 1u) | b) & 0x10000u) != 0, 0)) break; // a bypass escape (cf = 0xFFFF) or a latent that is not plain
+        // count the edges <= cf: the wavefront form of the reference's bisection (rans_interface.cpp:826-862) in a monotone row.
+        // Lanes past the window hold 0x10000 for the count and for "the edge before the first" (& 0xFFFF: F below the window is 0;
+        // lane 63 is never inside a plain window), and F beyond the window for "the edge after the last".
+        const bool inside = lane < ((a >> 12) & 0x7Fu);
+        const uint32_t Ec = inside ? E : 0x10000u, Ey = inside ? E : (b & 0xFFFFu);
+        const uint32_t n = (uint32_t)__popcll(__ballot(Ec <= cf));
+        const uint32_t start = bcast(Ec, n - 1u) & 0xFFFFu, next = bcast(Ey, n);
+        // F[J] <= cf < F[J + 1], J = j_lo + n - 1 in [0, W - 2] (rans_interface.cpp:826-833): J >= 0 by the producer's choice of
+        // plain latents; J = W - 1 has next = 0 and so a freq <= 0
         const uint32_t freq = next - start;
-        const int32_t J = (int32_t)(jl + n) - 1;
-        bad_acc |= (uint32_t)(J >> 31) | ((freq - 1u) >> 16);
-        // x = freq * (x >> 16) + (cf - start), 64 bits, on the scalar unit (Rans64DecAdvance, rans64.h:124-142)
-        uint32_t n_lo, n_hi;
-        advance(freq, cf - start, n_lo, n_hi);
-        if (n_hi == 0 && n_lo < 0x80000000u) { // x < 2^31: one more word
-          n_hi = n_lo;
-          n_lo = next_word();
-        }
-        x_lo = n_lo;
-        x_hi = n_hi;
-        put(J - max_bs, k);
-        continue;
+        bad_acc |= (freq - 1u) >> 16;
+        advance(freq, cf - start); // Rans64DecAdvance, rans64.h:124-134
+        put(((int32_t)a >> 19) + (int32_t)n, k);
+        if (++k >= nk) break;
       }
+      if (k >= nk) break;
+      if (bad_acc | sout) break; // (the paths below loop over the stream: not with a state that is already known to be wrong)
       int32_t value;
       if (cf == 0xFFFFu) { // bypass escape: Rans64DecAdvance(65535, 1), then the nibbles (rans_interface.cpp:808-824)
         uint64_t xx = ((((uint64_t)x_hi << 32) | x_lo) >> 16) + cf - 0xFFFFu;
@@ -979,85 +1021,111 @@ __global__ __launch_bounds__(64) void segdec_kernel(const SegDesc *__restrict__ 
           return v;
         };
         int32_t val = (int32_t)get_bits(), nn = val;
-        while (val == 15 && !err) {
+        while (val == 15 && !sout) {
           val = (int32_t)get_bits();
           nn += val;
         }
         uint32_t raw = 0;
-        for (int j = 0; j < nn && !err; ++j) raw |= get_bits() << ((j * 4) & 31);
+        for (int j = 0; j < nn && !sout; ++j) raw |= get_bits() << ((j * 4) & 31);
         value = (int32_t)raw;
         x_lo = uni((uint32_t)xx);
         x_hi = uni((uint32_t)(xx >> 32));
-      } else { // a window longer than the wave, or a row that decreases somewhere: 64 edges per pass / left to the table path
-        const uint32_t wk = bcast(win, (uint32_t)k), tk = bcast(tsf, (uint32_t)k), e0 = a & 0xFFFu;
-        const int jl = (int)(wk & 0xFFFFu), len = (int)(wk >> 16), jh = jl + len;
-        const uint32_t tsat = tk & 0xFFFFu;
+      } else { // a window of 64 edges and more, or a row the reference's bisection must see itself (left to the table path)
+        const uint32_t wk = bcast(pc, (uint32_t)k), e0 = a & 0xFFFu;
+        const int jl = (int)(wk & 0xFFFFu), len = (int)(wk >> 16);
+        const bool tail = (b & 0x40000u) != 0;
+        const uint32_t tsat = b & 0xFFFFu;
         uint32_t below = 0, last = 0, start = 0, next = 0; // `last`: the edge before this pass (F below the window is 0)
-        bool found = false, bad = bcast(nmL[lane], (uint32_t)k) != 0;
+        bool found = false, bad = (b & 0x20000u) != 0;
         for (int off = 0; off < len; off += 64) {
           const int q = off + (int)lane;
           const bool valid = q < len;
-          const uint32_t E = valid ? (uint32_t)E16[e0 + (uint32_t)q] : 0x10000u; // lanes past the window never count as <= cf
+          const uint32_t Eq = valid ? (uint32_t)E16[e0 + (uint32_t)q] : 0x10000u; // lanes past the window never count as <= cf
           const uint32_t n_valid = (uint32_t)std::min(64, len - off);
           if (!found) {
-            const uint32_t n_le = (uint32_t)__popcll(__ballot(valid && E <= cf));
+            const uint32_t n_le = (uint32_t)__popcll(__ballot(valid && Eq <= cf));
             if (n_le < n_valid) { // the first edge > cf lies in this pass: F[J] = the edge before it, F[J + 1] = that edge
-              next = bcast(E, n_le);
-              start = n_le ? bcast(E, n_le - 1) : last;
+              next = bcast(Eq, n_le);
+              start = n_le ? bcast(Eq, n_le - 1) : last;
               found = true;
             }
             below += n_le;
           }
-          last = bcast(E, n_valid - 1);
+          last = bcast(Eq, n_valid - 1);
           if (found) { // (the rest of a long window is only needed for its last edge)
             if (off + 64 < len) last = (uint32_t)E16[e0 + (uint32_t)len - 1u];
             break;
           }
         }
-        bad = bad || (jh < W && tsat < last); // ... monotone into the saturated tail too
+        bad = bad || (tail && tsat < last); // ... monotone into the saturated tail too
         if (!found) { // every edge of the window is <= cf: the interval ends at the saturated tail, if there is one above cf
           start = last;
           next = tsat;
-          bad = bad || !(jh < W && tsat > cf);
+          bad = bad || !(tail && tsat > cf);
         }
+        // F[J] <= cf < F[J + 1] with J = jl + below - 1 >= 0  (J = jl - 1: the zeros below the window; the reference's range is
+        // J in [0, W - 2]: rans_interface.cpp:826-833)
         const int J = jl + (int)below - 1;
         const uint32_t freq = next - start;
         if (__builtin_expect(bad || J < 0 || J > W - 2 || freq == 0 || freq > 0xFFFFu, 0)) {
-          err = kSegHard;
+          bad_acc = 1;
           break;
         }
         value = J - max_bs;
-        const uint32_t s_lo = (x_lo >> 16) | (x_hi << 16), s_hi = x_hi >> 16;
-        const uint64_t pr = (uint64_t)freq * s_lo + (((uint64_t)(freq * s_hi)) << 32) + (uint64_t)(cf - start);
-        uint32_t n_lo = (uint32_t)pr, n_hi = (uint32_t)(pr >> 32);
-        if (n_hi == 0 && n_lo < 0x80000000u) { // x < 2^31: one more word
-          n_hi = n_lo;
-          n_lo = next_word();
-        }
-        x_lo = uni(n_lo);
-        x_hi = uni(n_hi);
+        advance(freq, cf - start);
+        x_lo = uni(x_lo);
+        x_hi = uni(x_hi);
       }
       if (lane == (uint32_t)k) myval = value;
     }
-    if (bad_acc && !err) err = kSegHard;
+    if (sout) err = kSegStream;
+    else if (bad_acc) err = kSegHard;
+    if (!err && (int)lane < nk) stg<float>(d.y_hat + reinterpret_cast<const int64_t *>(B + kSegBufOut)[lane], (float)myval);
     SEG_T(t_e);
-    SEG_ACC(0, t_b - t_a); SEG_ACC(1, t_m - t_b); SEG_ACC(2, t_c - t_m); SEG_ACC(3, t_e - t_c); SEG_ACC(4, nk); SEG_ACC(5, 1);
-    if (!err && (int)lane < nk) stg<float>(d.y_hat + oidx, (float)myval);
-    base += nk;
-    __builtin_amdgcn_wave_barrier(); // the next batch overwrites the LDS this one read
+    SEG_ACC(3, t_e - t_c);
+    SEG_ACC(4, nk);
+    SEG_ACC(5, 1);
+  };
+
+  // =============================== the two in step: batch n is decoded while batch n + 1 is evaluated ===============================
+  if (producer) produce(lo, buf(0));
+  else if (lane == 0) ctrl[0] = err;
+  __syncthreads();
+  int64_t base = lo;
+  for (int n = 0;; ++n) {
+    unsigned char *const B = buf(n);
+    if (ctrl[n & 1]) break; // (batch 0: a note that points outside the stream)
+    const int nk = (int)uni(reinterpret_cast<const uint32_t *>(B)[kSegBufNk / 4]);
+    const int64_t next = base + nk;
+    if (producer) {
+      if (next < hi) produce(next, buf(n + 1));
+    } else {
+      consume(B, nk);
+      if (lane == 0) ctrl[(n + 1) & 1] = err;
+    }
+    SEG_T(t_w);
+    __syncthreads();
+    SEG_ACC(2, clock64() - t_w);
+    if (next >= hi) break;
+    base = next;
   }
-  // ---- the segment must end exactly where the next checkpoint says the coder stands
-  if (!err && sg < d.n_ckpt) {
-    const uint64_t cx = ldg<uint64_t>(&d.ckpt[sg].x), cp = ldg<uint64_t>(&d.ckpt[sg].pos);
-    const uint64_t x = ((uint64_t)x_hi << 32) | x_lo;
-    if (x != cx || (uint64_t)(wbase + wp) != cp) err = kSegMismatch;
+  if (!producer) {
+    // ---- the segment must end exactly where the next checkpoint says the coder stands
+    if (!err && sg < d.n_ckpt) {
+      const uint64_t cx = ldg<uint64_t>(&d.ckpt[sg].x), cp = ldg<uint64_t>(&d.ckpt[sg].pos);
+      const uint64_t x = ((uint64_t)x_hi << 32) | x_lo;
+      if (x != cx || (uint64_t)(wbase + wp) != cp) err = kSegMismatch;
+    }
+    if (lane == 0) stg<uint32_t>(d.status + sg, err);
   }
-  if (lane == 0) stg<uint32_t>(d.status + sg, err);
 #ifdef FGMM_SEG_PROF
   if (lane == 0) {
     for (int q = 0; q < 6; ++q) atomicAdd(&g_segprof[q], seg_acc[q]);
-    atomicAdd(&g_segprof[6], (unsigned long long)(clock64() - t_begin));
-    atomicAdd(&g_segprof[7], 1ull);
+    if (!producer) {
+      atomicAdd(&g_segprof[6], (unsigned long long)(clock64() - t_begin));
+      atomicAdd(&g_segprof[7], 1ull);
+      if (wid < 16384) g_segtimes[2 * wid] = t_begin, g_segtimes[2 * wid + 1] = clock64();
+    }
   }
 #endif
 }
@@ -1070,6 +1138,7 @@ extern "C" int fgmm_debug_segprof(unsigned long long *out, int reset) {
   }
   return rc;
 }
+extern "C" int fgmm_debug_segtimes(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_segtimes), sizeof(g_segtimes)); }
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1079,11 +1148,11 @@ static inline int launch_err() { return (int)hipGetLastError(); }
 
 template <bool CLAMPED, typename PT>
 static int launch_segdec_c(const SegDesc *d, const SegRef *segs, int64_t n_segs, int mode, hipStream_t s) {
-  const dim3 grid((unsigned)n_segs); // one wave per workgroup: its own 12.6 KB of LDS, no barriers
+  const dim3 grid((unsigned)n_segs); // one segment per workgroup of two waves
   switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((segdec_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(64), 0, s, d, segs, n_segs); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((segdec_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(64), 0, s, d, segs, n_segs); break;
-  default: hipLaunchKernelGGL((segdec_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(64), 0, s, d, segs, n_segs); break;
+  case MODE_AS: hipLaunchKernelGGL((segdec_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(128), 0, s, d, segs, n_segs); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((segdec_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(128), 0, s, d, segs, n_segs); break;
+  default: hipLaunchKernelGGL((segdec_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(128), 0, s, d, segs, n_segs); break;
   }
   return launch_err();
 }

@@ -28,4 +28,16 @@ dt = (time.perf_counter() - t0) / n * 1e3
 L.fgmm_debug_segprof(buf, 0)
 a, b, m, c, syms, batches, total, waves = (int(v) / n for v in buf)
 print(f"stride {stride} items {nimg}: call {dt:.3f} ms; waves {waves:.0f}, batches/wave {batches / waves:.1f}, symbols/batch {syms / batches:.1f}")
-print(f"cycles per symbol: A {a / syms:.0f}  B {b / syms:.0f}  monotone {m / syms:.0f}  C {c / syms:.0f}  whole wave {total / syms:.0f}   (per wave {total / waves / 1e3:.0f} k cycles)")
+print(f"cycles per symbol: producer A {a / syms:.0f}  B+per-latent {b / syms:.0f} | consumer C {c / syms:.0f} | both, at the barrier {m / syms:.0f} | whole segment {total / syms:.0f}   (per segment {total / waves / 1e3:.0f} k cycles)")
+
+if hasattr(L, "fgmm_debug_segtimes") and len(sys.argv) > 3:
+    tb = (C.c_ulonglong * (2 * 16384))()
+    L.fgmm_debug_segtimes(tb)
+    t = np.array(tb, dtype=np.float64).reshape(-1, 2)[: int(min(waves, 16384))]
+    t0 = t[:, 0].min()
+    beg, end = (t[:, 0] - t0) / 2.4e6, (t[:, 1] - t0) / 2.4e6   # ms at 2.4 GHz ticks
+    dur = end - beg
+    print(f"segments: duration ms min {dur.min():.3f} p10 {np.percentile(dur, 10):.3f} median {np.median(dur):.3f} p90 {np.percentile(dur, 90):.3f} max {dur.max():.3f}; last start {beg.max():.3f}, last end {end.max():.3f}")
+    order = np.argsort(beg)
+    print("start time of every 500th segment in start order:", np.round(beg[order][::500], 3).tolist())
+    print("durations of segments 0..4095 by id, averaged over runs of 127 (one bitstream):", np.round(dur[: 127 * 32].reshape(32, 127).mean(1), 3).tolist())
