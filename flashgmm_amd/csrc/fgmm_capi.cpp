@@ -709,7 +709,6 @@ int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &it
   if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off))) return rc;
   SegDesc *hd = reinterpret_cast<SegDesc *>(ctx->h_ws + o_descs);
   SegRef *hs = reinterpret_cast<SegRef *>(ctx->h_ws + o_segs);
-  int64_t sat = 0;
   for (int k = 0; k < count; ++k) {
     DecItem &it = items[which[k]];
     int32_t *list = reinterpret_cast<int32_t *>(ctx->h_ws + off[(size_t)k].list);
@@ -739,9 +738,38 @@ int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &it
     d.stride = it.ckpt_stride;
     d.y_hat = it.y_hat;
     d.status = reinterpret_cast<uint32_t *>(ctx->d_ws + off[(size_t)k].status);
-    for (int64_t sgm = 0; sgm <= it.n_ckpt; ++sgm) hs[sat++] = SegRef{k, (int32_t)sgm};
     // channels without a coded symbol are zero in y_hat (entropy_models.py:903-908)
     if (it.n_ch < it.M) HIP_TRY(hipMemsetAsync(it.y_hat, 0, sizeof(float) * (size_t)it.M * (size_t)it.hw, stream));
+  }
+  // The segments in the order of the launch's workgroups: HEAVIEST FIRST.  A segment costs its symbols plus its edges, and a latent's
+  // window is wide where its symbol is expensive - so the words a segment takes of the bitstream (the distance between its notes) rank
+  // the segments by weight; with the heavy ones (3x the median on Kodak-like latents) in front, the launch does not end on one that
+  // started last.  (The notes are not trusted: a wrong one spoils an order, nothing else.)
+  {
+    constexpr int kBuckets = 256;
+    std::vector<uint32_t> wgt((size_t)n_segs);
+    uint32_t w_max = 1;
+    int64_t at = 0;
+    for (int k = 0; k < count; ++k) {
+      const DecItem &it = items[which[k]];
+      const uint64_t end_all = it.enc_len / 4 - 2;
+      uint64_t prev = 0;
+      for (int64_t sgm = 0; sgm <= it.n_ckpt; ++sgm) {
+        const uint64_t pos = sgm < it.n_ckpt ? it.ckpt[sgm].pos : end_all;
+        const uint64_t wds = pos >= prev ? pos - prev : 0;
+        wgt[(size_t)at] = (uint32_t)std::min<uint64_t>(wds, 0x7FFFFFFFu);
+        w_max = std::max(w_max, wgt[(size_t)at]);
+        prev = pos;
+        ++at;
+      }
+    }
+    int64_t first[kBuckets + 1] = {};
+    auto bucket = [&](uint32_t wv) { return kBuckets - 1 - (int)((uint64_t)wv * (kBuckets - 1) / w_max); }; // heavy -> bucket 0
+    for (int64_t q = 0; q < n_segs; ++q) ++first[bucket(wgt[(size_t)q]) + 1];
+    for (int b = 0; b < kBuckets; ++b) first[b + 1] += first[b];
+    at = 0;
+    for (int k = 0; k < count; ++k)
+      for (int64_t sgm = 0; sgm <= items[which[k]].n_ckpt; ++sgm, ++at) hs[first[bucket(wgt[(size_t)at])]++] = SegRef{k, (int32_t)sgm};
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
   if ((rc = ctx->prof_begin(3, stream))) return rc;
@@ -790,8 +818,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.n = (int64_t)n_ch * it.hw;
       (gpu_decodable(it, it.n) && it.clamp == items[0].clamp && it.prm.dtype == items[0].prm.dtype ? gpu : rest).push_back(i);
     }
-    // Is the GPU the faster decoder for this call?  One wave decodes its segment at ~1.7 us per symbol however empty the chip is,
-    // and the chip as a whole at ~0.56 ns per symbol (Kodak-like latents); the host decodes at ~12 ns per symbol and worker and
+    // Is the GPU the faster decoder for this call?  A segment's two waves decode it at ~1.0 us per symbol however empty the chip is
+    // (its widest rows included), and the chip as a whole at ~0.41 ns per symbol (Kodak-like latents); the host decodes at ~12 ns per symbol and worker and
     // is fed at 58 B per latent over PCIe.  Many segments (a batch, a 4K image's group): the GPU, by 2-4x; one Kodak half
     // in a few hundred long segments: the host workers.  ("gpu_decode" = 1: always)
     if (!gpu.empty() && ctx->opt.gpu_decode == 0) {
@@ -801,7 +829,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         stride_max = std::max(stride_max, (double)std::min<int64_t>(items[i].ckpt_stride, items[i].n));
         work += (double)(items[i].n_ckpt + 1);
       }
-      const double t_gpu = std::max(stride_max * 1.7, syms * 0.00056) + 100.0;
+      const double t_gpu = std::max(stride_max * 1.0, syms * 0.00041) + 100.0;
       const double workers = std::min<double>(std::max(ctx->pool->size(), 1), work);
       const double t_host = std::max(syms * 0.012 / workers, syms * 58.0 / 55700.0) + 450.0 + 3.0 * work / workers; // + a segment's set-up
       if (t_gpu >= t_host) {
