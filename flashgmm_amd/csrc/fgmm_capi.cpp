@@ -818,8 +818,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.n = (int64_t)n_ch * it.hw;
       (gpu_decodable(it, it.n) && it.clamp == items[0].clamp && it.prm.dtype == items[0].prm.dtype ? gpu : rest).push_back(i);
     }
-    // Is the GPU the faster decoder for this call?  A segment's two waves decode it at ~1.0 us per symbol however empty the chip is
-    // (its widest rows included), and the chip as a whole at ~0.41 ns per symbol (Kodak-like latents); the host decodes at ~12 ns per symbol and worker and
+    // Is the GPU the faster decoder for this call?  A segment's waves decode it at ~0.65 us per symbol however empty the chip is
+    // (its widest rows included), and the chip as a whole at ~0.35 ns per symbol (Kodak-like latents); the host decodes at ~12 ns per symbol and worker and
     // is fed at 58 B per latent over PCIe.  Many segments (a batch, a 4K image's group): the GPU, by 2-4x; one Kodak half
     // in a few hundred long segments: the host workers.  ("gpu_decode" = 1: always)
     if (!gpu.empty() && ctx->opt.gpu_decode == 0) {
@@ -829,7 +829,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
         stride_max = std::max(stride_max, (double)std::min<int64_t>(items[i].ckpt_stride, items[i].n));
         work += (double)(items[i].n_ckpt + 1);
       }
-      const double t_gpu = std::max(stride_max * 1.0, syms * 0.00041) + 100.0;
+      const double t_gpu = std::max(stride_max * 0.65, syms * 0.00035) + 100.0;
       const double workers = std::min<double>(std::max(ctx->pool->size(), 1), work);
       const double t_host = std::max(syms * 0.012 / workers, syms * 58.0 / 55700.0) + 450.0 + 3.0 * work / workers; // + a segment's set-up
       if (t_gpu >= t_host) {

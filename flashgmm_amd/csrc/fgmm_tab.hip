@@ -733,7 +733,7 @@ constexpr int kSegBufBytes = kSegBufNk + 16;
 constexpr int kSegLdsP = 0;                       // producer's own: parameters of 64 latents | pair offsets | windows, tails, flags
 constexpr int kSegLdsOff = 64 * 64;
 constexpr int kSegLdsCtrl = kSegLdsOff + 4 * 68 + 3 * 4 * 64;
-constexpr int kSegLdsBuf = kSegLdsCtrl + 16;
+constexpr int kSegLdsBuf = kSegLdsCtrl + 32;
 constexpr int kSegLds = kSegLdsBuf + 2 * kSegBufBytes; // 15.9 KB per segment: ten segments = twenty waves per CU
 // Two waves per segment.  The PRODUCER (wave 1) does what needs no coder state, a batch of up to 64 latents ahead:
 //   A lane = latent: twelve parameters, clamp + reciprocals, the window between the saturated tails (tab_kernel's phase 0);
@@ -745,18 +745,22 @@ constexpr int kSegLds = kSegLdsBuf + 2 * kSegBufBytes; // 15.9 KB per segment: t
 // reference's bisection in a monotone row, two v_readlane pick F[J] and F[J + 1], the 64-bit state advances in SGPRs.  While it
 // decodes batch n the producer evaluates batch n + 1 (on another SIMD of the CU): the sequential chain never waits for edges.
 template <int MODE, bool CLAMPED, typename PT>
-__global__ __launch_bounds__(128) void segdec_kernel(const SegDesc *__restrict__ descs, const SegRef *__restrict__ segs, int64_t n_segs) {
+__global__ __launch_bounds__(192) void segdec_kernel(const SegDesc *__restrict__ descs, const SegRef *__restrict__ segs, int64_t n_segs) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kSegLds];
   float4_t *const P = reinterpret_cast<float4_t *>(lds + kSegLdsP);         // [64][4]: mu, sigma (clamped), pi, refined 1/sigma
   uint32_t *const offP = reinterpret_cast<uint32_t *>(lds + kSegLdsOff);    // [65] pairs before latent l of the batch
   uint32_t *const winL = offP + 68, *const tsfL = winL + 64; // [64] j_lo | len << 16;  T_sat | tame << 16  (read by OTHER lanes in
                                                              // phase B, some of which have left the loop: not a cross-lane register read)
   uint32_t *const nmL = tsfL + 64;                           // [64] the latent's row decreases somewhere
-  volatile uint32_t *const ctrl = reinterpret_cast<volatile uint32_t *>(lds + kSegLdsCtrl); // [2] the consumer has given up (per batch parity)
+  // [0..1] the consumer has given up (per batch parity) | [2] producer 0 has laid out batch seq | [3] producer 1 has evaluated its share
+  // of batch seq | [4] latents, [5] pairs of that batch | [6] a producer waited in vain
+  volatile uint32_t *const ctrl = reinterpret_cast<volatile uint32_t *>(lds + kSegLdsCtrl);
   const int64_t wid = blockIdx.x;
   if (wid >= n_segs) return;
   const uint32_t lane = threadIdx.x & 63u;
-  const bool producer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: the consumer, 1 / 2: producers
+  const bool producer = role != 0;
+  const bool two_producers = blockDim.x > 128; // (the launch's choice: see launch_segdec)
   const SegRef ref = segs[wid];
   const SegDesc &d = descs[ref.item];
   const int64_t sg = ref.seg;
@@ -772,7 +776,86 @@ __global__ __launch_bounds__(128) void segdec_kernel(const SegDesc *__restrict__
   SEG_T(t_begin);
 
   // =============================== producer: batch [base, base + nk) -> B ===============================
-  auto produce = [&](int64_t base, unsigned char *B) {
+  // (producers meet at LDS flags: a partial barrier does not exist, and the consumer must not wait for them inside a batch)
+  auto publish = [&](int slot, uint32_t v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) ctrl[slot] = v;
+  };
+  auto await = [&](int slot, uint32_t v) {
+    for (int spins = 0; uni(ctrl[slot]) != v; ++spins) {
+      __builtin_amdgcn_s_sleep(2);
+      if (spins > (1 << 20)) { // (never seen; a segment that gives up is decoded by the table path)
+        if (lane == 0) ctrl[6] = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  // B. flattened over (latent, pair of consecutive edges), pairs [t0 + lane, t_end) in steps of 64: the tab_kernel's evaluation
+  auto eval_pairs = [&](uint32_t t0, uint32_t t_end, int nk, uint32_t NP, uint32_t *E32) {
+    int l = 0;
+    uint32_t l_beg = 0, l_end = 0;
+    uint32_t t = t0 + lane;
+    if (t < t_end) {
+      l = find_owner(offP, nk, t);
+      l_beg = offP[l];
+      l_end = l + 1 < nk ? offP[l + 1] : NP;
+    }
+    uint32_t carry = 0; // the pair before lane 0's: lane 63's of the step before (none before the first step: see the seam below)
+    for (; t < t_end; t += 64) {
+      while (t >= l_end) { // next latent with a non-empty window
+        ++l;
+        l_beg = l_end;
+        l_end = l + 1 < nk ? offP[l + 1] : NP;
+      }
+      const float4_t m4 = P[4 * l + 0], s4 = P[4 * l + 1], p4 = P[4 * l + 2], r4 = P[4 * l + 3];
+      const float mu_[4] = {m4[0], m4[1], m4[2], m4[3]}, pi_[4] = {p4[0], p4[1], p4[2], p4[3]};
+      const uint32_t wl = winL[l], tl_ = tsfL[l];
+      const int j = (int)(wl & 0xFFFFu) + 2 * (int)(t - l_beg);
+      const float x0 = (float)(j - max_bs) - 0.5f, x1 = (float)(j + 1 - max_bs) - 0.5f;
+      float c0 = 0.0f, c1 = 0.0f;
+      bool fast = false;
+      if constexpr (CLAMPED) {
+        Sigma4 S4;
+        S4.tame = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          S4.sg[k] = s4[k];
+          S4.rs[k] = r4[k];
+        }
+        bool ok = (tl_ >> 16) != 0;
+        const f2 cc = mix4_clamped2<MODE>((f2){x0, x1}, mu_, S4, pi_, ok);
+        c0 = cc.x;
+        c1 = cc.y;
+        fast = ok;
+      }
+      if (__builtin_expect(!fast, 0)) { // un-clamped sigma, NaN sigma, far-off or non-finite mean: IEEE evaluation
+        c0 = mix4_slow<MODE>(x0, mu_[0], mu_[1], mu_[2], mu_[3], s4[0], s4[1], s4[2], s4[3], pi_[0], pi_[1], pi_[2], pi_[3]);
+        c1 = mix4_slow<MODE>(x1, mu_[0], mu_[1], mu_[2], mu_[3], s4[0], s4[1], s4[2], s4[3], pi_[0], pi_[1], pi_[2], pi_[3]);
+      }
+      const uint32_t q0 = quant16(c0), q1 = quant16(c1), pk = q0 | (q1 << 16);
+      E32[t] = pk;
+      // ... and which rows DECREASE somewhere.  A count of the edges <= cf is the symbol's interval only in a monotone row; the
+      // reference's bisection may answer differently when the row decreases anywhere (rans_interface.cpp:833-854), so such a
+      // latent is left to the table path.  The pair before this one sits in the lane below (wave_shr:1; lane 0: `carry`); an
+      // odd window's last pair holds F[j_hi] as well: a real edge, checked like the others.
+      const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)pk, 0x138, 0xF, 0xF, false);
+      const uint32_t prev = t > l_beg ? before >> 16 : 0u; // F below the window is 0
+      if (prev > q0 || q0 > q1) nmL[l] = 1;
+      carry = bcast(pk, 63u);
+    }
+  };
+  // producer 0 evaluates the pairs below the seam (it also does A and the per-latent pass), producer 1 those from the seam on
+  auto seam = [](uint32_t NP) { return std::min(NP, ((NP * 7u) / 16u + 63u) & ~63u); };
+  auto produce1 = [&](unsigned char *B, uint32_t seq) {
+    await(2, seq);
+    const int nk = (int)uni(ctrl[4]);
+    const uint32_t NP = uni(ctrl[5]);
+    eval_pairs(seam(NP), NP, nk, NP, reinterpret_cast<uint32_t *>(B + kSegBufE));
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    publish(3, seq);
+  };
+  auto produce = [&](int64_t base, unsigned char *B, uint32_t seq) {
     SEG_T(t_a);
     uint32_t *const E32 = reinterpret_cast<uint32_t *>(B + kSegBufE);
     const uint16_t *const E16 = reinterpret_cast<const uint16_t *>(E32);
@@ -828,63 +911,23 @@ __global__ __launch_bounds__(128) void segdec_kernel(const SegDesc *__restrict__
     tsfL[lane] = T_sat | (tame ? 0x10000u : 0u);
     nmL[lane] = 0;
     const uint32_t NP = bcast(incl, (uint32_t)(nk - 1));
-    if (lane == 0) offP[64] = NP; // (offP[nk] is what a walk past the last latent reads: lanes' own entries hold it for nk < 64)
-    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS writes are done (its own arrays: no barrier)
+    if (lane == 0) {
+      offP[64] = NP; // (offP[nk] is what a walk past the last latent reads: lanes' own entries hold it for nk < 64)
+      ctrl[4] = (uint32_t)nk;
+      ctrl[5] = NP;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS writes are done
     __builtin_amdgcn_wave_barrier();
+    if (two_producers) publish(2, seq); // producer 1 may start
     SEG_T(t_b);
-    // ---- B. flattened over (latent, pair of consecutive edges): the tab_kernel's evaluation, edges -> LDS
-    {
-      int l = 0;
-      uint32_t l_beg = 0, l_end = 0;
-      uint32_t t = lane;
-      if (t < NP) {
-        l = find_owner(offP, nk, t);
-        l_beg = offP[l];
-        l_end = l + 1 < nk ? offP[l + 1] : NP;
-      }
-      uint32_t carry = 0; // the pair before lane 0's: lane 63's of the step before
-      for (; t < NP; t += 64) {
-        while (t >= l_end) { // next latent with a non-empty window
-          ++l;
-          l_beg = l_end;
-          l_end = l + 1 < nk ? offP[l + 1] : NP;
-        }
-        const float4_t m4 = P[4 * l + 0], s4 = P[4 * l + 1], p4 = P[4 * l + 2], r4 = P[4 * l + 3];
-        const float mu_[4] = {m4[0], m4[1], m4[2], m4[3]}, pi_[4] = {p4[0], p4[1], p4[2], p4[3]};
-        const uint32_t wl = winL[l], tl_ = tsfL[l];
-        const int j = (int)(wl & 0xFFFFu) + 2 * (int)(t - l_beg);
-        const float x0 = (float)(j - max_bs) - 0.5f, x1 = (float)(j + 1 - max_bs) - 0.5f;
-        float c0 = 0.0f, c1 = 0.0f;
-        bool fast = false;
-        if constexpr (CLAMPED) {
-          Sigma4 S4;
-          S4.tame = true;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            S4.sg[k] = s4[k];
-            S4.rs[k] = r4[k];
-          }
-          bool ok = (tl_ >> 16) != 0;
-          const f2 cc = mix4_clamped2<MODE>((f2){x0, x1}, mu_, S4, pi_, ok);
-          c0 = cc.x;
-          c1 = cc.y;
-          fast = ok;
-        }
-        if (__builtin_expect(!fast, 0)) { // un-clamped sigma, NaN sigma, far-off or non-finite mean: IEEE evaluation
-          c0 = mix4_slow<MODE>(x0, mu_[0], mu_[1], mu_[2], mu_[3], s4[0], s4[1], s4[2], s4[3], pi_[0], pi_[1], pi_[2], pi_[3]);
-          c1 = mix4_slow<MODE>(x1, mu_[0], mu_[1], mu_[2], mu_[3], s4[0], s4[1], s4[2], s4[3], pi_[0], pi_[1], pi_[2], pi_[3]);
-        }
-        const uint32_t q0 = quant16(c0), q1 = quant16(c1), pk = q0 | (q1 << 16);
-        E32[t] = pk;
-        // ... and which rows DECREASE somewhere.  A count of the edges <= cf is the symbol's interval only in a monotone row; the
-        // reference's bisection may answer differently when the row decreases anywhere (rans_interface.cpp:833-854), so such a
-        // latent is left to the table path.  The pair before this one sits in the lane below (wave_shr:1; lane 0: `carry`); an
-        // odd window's last pair holds F[j_hi] as well: a real edge, checked like the others.
-        const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)pk, 0x138, 0xF, 0xF, false);
-        const uint32_t prev = t > l_beg ? before >> 16 : 0u; // F below the window is 0
-        if (prev > q0 || q0 > q1) nmL[l] = 1;
-        carry = bcast(pk, 63u);
-      }
+    // ---- B. this producer's share of the pairs
+    const uint32_t H = two_producers ? seam(NP) : NP;
+    eval_pairs(0u, H, nk, NP, E32);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (two_producers) await(3, seq); // producer 1's share is in LDS
+    if (lane == 0 && H < NP) { // the seam: producer 1's first pair against the one before it
+      const int l = find_owner(offP, nk, H);
+      if (H > offP[l] && (E32[H - 1] >> 16) > (E32[H] & 0xFFFFu)) nmL[l] = 1;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -933,7 +976,6 @@ __global__ __launch_bounds__(128) void segdec_kernel(const SegDesc *__restrict__
     // the next 64 words of the bitstream across the lanes; `wp` of them are consumed, `wleft` are left in the stream
     wv = wbase + lane < nw ? ldg<uint32_t>(w + wbase + lane) : 0u;
     wleft = (uint32_t)std::min<int64_t>(nw - wbase, 0x7FFFFFFF);
-    if (lane == 0) ctrl[1] = 0;
   }
   uint32_t sout = 0; // the stream ran out
   auto next_word = [&]() -> uint32_t { // wave-uniform
@@ -1088,7 +1130,10 @@ __global__ __launch_bounds__(128) void segdec_kernel(const SegDesc *__restrict__
   };
 
   // =============================== the two in step: batch n is decoded while batch n + 1 is evaluated ===============================
-  if (producer) produce(lo, buf(0));
+  if (threadIdx.x < 8) ctrl[threadIdx.x] = 0;
+  __syncthreads();
+  if (role == 1) produce(lo, buf(0), 1u);
+  else if (role == 2) produce1(buf(0), 1u);
   else if (lane == 0) ctrl[0] = err;
   __syncthreads();
   int64_t base = lo;
@@ -1098,7 +1143,10 @@ __global__ __launch_bounds__(128) void segdec_kernel(const SegDesc *__restrict__
     const int nk = (int)uni(reinterpret_cast<const uint32_t *>(B)[kSegBufNk / 4]);
     const int64_t next = base + nk;
     if (producer) {
-      if (next < hi) produce(next, buf(n + 1));
+      if (next < hi) {
+        if (role == 1) produce(next, buf(n + 1), (uint32_t)n + 2u);
+        else produce1(buf(n + 1), (uint32_t)n + 2u);
+      }
     } else {
       consume(B, nk);
       if (lane == 0) ctrl[(n + 1) & 1] = err;
@@ -1111,6 +1159,7 @@ __global__ __launch_bounds__(128) void segdec_kernel(const SegDesc *__restrict__
   }
   if (!producer) {
     // ---- the segment must end exactly where the next checkpoint says the coder stands
+    if (!err && ctrl[6]) err = kSegHard;
     if (!err && sg < d.n_ckpt) {
       const uint64_t cx = ldg<uint64_t>(&d.ckpt[sg].x), cp = ldg<uint64_t>(&d.ckpt[sg].pos);
       const uint64_t x = ((uint64_t)x_hi << 32) | x_lo;
@@ -1146,13 +1195,16 @@ extern "C" int fgmm_debug_segtimes(unsigned long long *out) { return (int)hipMem
 // ---------------------------------------------------------------------------------------------------------
 static inline int launch_err() { return (int)hipGetLastError(); }
 
+// Two or three waves per segment: a second producer shortens a segment by a fifth (its widest rows by more) and costs the chip
+// a tenth of its throughput (the producers' handshake, fewer segments per CU).  A launch that fills the chip less than twice over
+// ends when its slowest segment does - three waves; a larger one is bound by the work - two.
 template <bool CLAMPED, typename PT>
 static int launch_segdec_c(const SegDesc *d, const SegRef *segs, int64_t n_segs, int mode, hipStream_t s) {
-  const dim3 grid((unsigned)n_segs); // one segment per workgroup of two waves
+  const dim3 grid((unsigned)n_segs), block(n_segs <= 4096 ? 192 : 128); // one segment per workgroup
   switch (mode) {
-  case MODE_AS: hipLaunchKernelGGL((segdec_kernel<MODE_AS, CLAMPED, PT>), grid, dim3(128), 0, s, d, segs, n_segs); break;
-  case MODE_LOGISTIC: hipLaunchKernelGGL((segdec_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, dim3(128), 0, s, d, segs, n_segs); break;
-  default: hipLaunchKernelGGL((segdec_kernel<MODE_POLYA, CLAMPED, PT>), grid, dim3(128), 0, s, d, segs, n_segs); break;
+  case MODE_AS: hipLaunchKernelGGL((segdec_kernel<MODE_AS, CLAMPED, PT>), grid, block, 0, s, d, segs, n_segs); break;
+  case MODE_LOGISTIC: hipLaunchKernelGGL((segdec_kernel<MODE_LOGISTIC, CLAMPED, PT>), grid, block, 0, s, d, segs, n_segs); break;
+  default: hipLaunchKernelGGL((segdec_kernel<MODE_POLYA, CLAMPED, PT>), grid, block, 0, s, d, segs, n_segs); break;
   }
   return launch_err();
 }
