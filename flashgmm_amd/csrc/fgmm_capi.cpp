@@ -672,7 +672,7 @@ static bool gpu_decodable(const DecItem &it, int64_t n) {
          it.enc_len >= 8 && !(it.enc_len & 3) && it.stride_p == 1;
 }
 
-// Checkpointed bitstreams decoded ON THE GPU (segdec_kernel: one wave per segment, no tables, nothing but the bitstreams and
+// Checkpointed bitstreams decoded ON THE GPU (segdec_kernel: one workgroup of two or three waves per segment, no tables, nothing but the bitstreams and
 // their notes crosses PCIe).  `which`: the items to decode; on return `redo` holds those whose segments did not all verify
 // (a row the kernel leaves to the reference's bisection, wrong notes): the caller sends them through the table path.
 int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items, const std::vector<int> &which, int mode,

@@ -108,7 +108,7 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor).
  *                       14 gives the fewest bytes (55.7 B/latent on Kodak-like tables against 57.6) but costs the host
  *                       decoders more than the PCIe time it saves when 16 threads serve one GPU
- *   "gpu_decode"  [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded ON THE GPU, one wave per segment, the edges of a
+ *   "gpu_decode"  [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded ON THE GPU, a workgroup per segment, the edges of a
  *                       latent across the lanes (no decode-side tables, nothing but the bitstreams crosses PCIe); a bitstream
  *                       with a segment the kernel does not settle itself (a non-monotone row, a note that does not verify)
  *                       goes through the table path.  0 = when the call has enough segments for the GPU to be the faster

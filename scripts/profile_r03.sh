@@ -21,3 +21,10 @@ head -6 "$out/kernel_stats.csv" | cut -c1-160; cat "$out/pmc_symtab.json" "$out/
 python3 -c 'import json,sys
 for f in sys.argv[1:]:
     d=json.load(open(f));print(f.split("/")[-1], d["value"],d["ms_per_step"],d["step_ms"],d["roofline"]["frac"],d["roofline_decode"]["ms_per_step"],d.get("upper_bound",{}).get("value"),d.get("latency_ms"))' "$out/bench_unprofiled.json" "$out/bench_elic4k.json"
+# the checkpointed path: the bench's kodak24 step on checkpointed streams under the profiler (segdec_kernel), its SQ counters
+CKPT=1024 ROUNDS=2 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_ck" -- python3 scripts/ab_options.py codec > "$out/ck_codec_1024.txt" 2> "$out/prof_ck.err"
+f=$(ls $out/prof_ck/*/*kernel_stats.csv | head -1); cp "$f" "$out/kernel_stats_checkpointed.csv"; rm -rf "$out/prof_ck"
+bash scripts/pmc_segdec.sh 1024 "${1:-r03prof}/pmc_segdec" > "$out/segdec_counters.txt" 2>&1
+rm -rf "$out/pmc_segdec"
+for st in 256 512 1024 4096; do CKPT=$st ROUNDS=3 python3 scripts/ab_options.py codec 2>&1 | tail -1 | sed "s/^/stride $st: /" >> "$out/ck_strides.txt"; done
+cat "$out/ck_strides.txt"; tail -3 "$out/segdec_counters.txt"
