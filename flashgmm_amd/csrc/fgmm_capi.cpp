@@ -692,7 +692,7 @@ int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &it
   std::vector<Off> off((size_t)count);
   for (int k = 0; k < count; ++k) {
     DecItem &it = items[which[k]];
-    off[(size_t)k].list = ar.take(sizeof(int32_t) * (size_t)std::max(it.n_ch, 1), 16);
+    off[(size_t)k].list = ar.take(sizeof(int32_t) * (size_t)std::max(it.M, 1), 16); // live channels, then dead ones
     off[(size_t)k].ckpt = ar.take(sizeof(fgmm_ckpt) * (size_t)it.n_ckpt, 16);
     off[(size_t)k].words = ar.take(it.enc_len, 16);
   }
@@ -709,12 +709,16 @@ int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &it
   if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off))) return rc;
   SegDesc *hd = reinterpret_cast<SegDesc *>(ctx->h_ws + o_descs);
   SegRef *hs = reinterpret_cast<SegRef *>(ctx->h_ws + o_segs);
+  int64_t max_dead = 0;
   for (int k = 0; k < count; ++k) {
     DecItem &it = items[which[k]];
     int32_t *list = reinterpret_cast<int32_t *>(ctx->h_ws + off[(size_t)k].list);
-    int r = 0;
-    for (int c = 0; c < it.M; ++c)
+    int r = 0, dead = it.n_ch;
+    for (int c = 0; c < it.M; ++c) {
       if (!it.zero_bitmap || it.zero_bitmap[c] != 0) list[r++] = c;
+      else list[dead++] = c;
+    }
+    max_dead = std::max<int64_t>(max_dead, it.M - it.n_ch);
     memcpy(ctx->h_ws + off[(size_t)k].ckpt, it.ckpt, sizeof(fgmm_ckpt) * (size_t)it.n_ckpt);
     memcpy(ctx->h_ws + off[(size_t)k].words, it.enc, it.enc_len);
     SegDesc &d = hd[k];
@@ -738,8 +742,8 @@ int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &it
     d.stride = it.ckpt_stride;
     d.y_hat = it.y_hat;
     d.status = reinterpret_cast<uint32_t *>(ctx->d_ws + off[(size_t)k].status);
-    // channels without a coded symbol are zero in y_hat (entropy_models.py:903-908)
-    if (it.n_ch < it.M) HIP_TRY(hipMemsetAsync(it.y_hat, 0, sizeof(float) * (size_t)it.M * (size_t)it.hw, stream));
+    d.dead_list = d.chan_list + it.n_ch; // channels without a coded symbol are zero in y_hat (entropy_models.py:903-908)
+    d.n_dead = it.M - it.n_ch;
   }
   // The segments in the order of the launch's workgroups: HEAVIEST FIRST.  A segment costs its symbols plus its edges, and a latent's
   // window is wide where its symbol is expensive - so the words a segment takes of the bitstream (the distance between its notes) rank
@@ -772,6 +776,7 @@ int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &it
       for (int64_t sgm = 0; sgm <= items[which[k]].n_ckpt; ++sgm, ++at) hs[first[bucket(wgt[(size_t)at])]++] = SegRef{k, (int32_t)sgm};
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
+  LAUNCH_TRY(launch_segzero(reinterpret_cast<const SegDesc *>(ctx->d_ws + o_descs), count, max_dead, stream));
   if ((rc = ctx->prof_begin(3, stream))) return rc;
   LAUNCH_TRY(launch_segdec(reinterpret_cast<const SegDesc *>(ctx->d_ws + o_descs), reinterpret_cast<const SegRef *>(ctx->d_ws + o_segs), n_segs, mode,
                            clamped, f16, stream));

@@ -85,14 +85,17 @@ struct SegDesc {
   int64_t n_words;               // all of them (>= 2)
   const fgmm_ckpt *ckpt;         // device [n_ckpt]
   int64_t n_ckpt, stride;
-  float *y_hat;                  // device [M * hw]: decoded symbols of the coded channels as floats (the others are zeroed by the host)
+  float *y_hat;                  // device [M * hw]: decoded symbols of the coded channels as floats; the others: zero (segzero_kernel)
   uint32_t *status;              // device [n_ckpt + 1], per segment: 0 = decoded and ended in the next checkpoint; else why not
+  const int32_t *dead_list;      // device [n_dead] channels without a coded symbol
+  int64_t n_dead;
 };
 struct SegRef { // one wave's work
   int32_t item, seg;
 };
 enum : uint32_t { kSegOk = 0, kSegMismatch = 1, kSegHard = 2, kSegStream = 3 }; // hard: a row the wave does not decode itself
 int launch_segdec(const SegDesc *d_descs, const SegRef *d_segs, int64_t n_segs, int mode, bool clamped, bool f16, void *stream);
+int launch_segzero(const SegDesc *d_descs, int count, int64_t max_dead, void *stream); // zeroes every item's dead channels in y_hat
 
 // ---- decode-side table format v5 (documented in include/flashgmm_amd.h) -------------------------------------
 //   header of latent i, one of three forms (per item):

@@ -1208,6 +1208,19 @@ static int launch_segdec_c(const SegDesc *d, const SegRef *segs, int64_t n_segs,
   }
   return launch_err();
 }
+// channels without a coded symbol are zero in y_hat (entropy_models.py:903-908): one launch for all items of a call
+__global__ __launch_bounds__(kBlock) void segzero_kernel(const SegDesc *__restrict__ descs) {
+  const SegDesc &d = descs[blockIdx.y];
+  if ((int64_t)blockIdx.x >= d.n_dead) return;
+  float *out = d.y_hat + (int64_t)ldg<int32_t>(d.dead_list + blockIdx.x) * d.hw;
+  for (int64_t i = threadIdx.x; i < d.hw; i += kBlock) stg<float>(out + i, 0.0f);
+}
+int launch_segzero(const SegDesc *d_descs, int count, int64_t max_dead, void *stream) {
+  if (count <= 0 || max_dead <= 0) return 0;
+  if (max_dead > 0x7FFFFFFFll || count > 65535) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(segzero_kernel, dim3((unsigned)max_dead, (unsigned)count), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_descs);
+  return launch_err();
+}
 int launch_segdec(const SegDesc *d_descs, const SegRef *d_segs, int64_t n_segs, int mode, bool clamped, bool f16, void *stream) {
   if (n_segs <= 0) return 0;
   if (n_segs > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;

@@ -880,7 +880,7 @@ def test_checkpointed_streams_are_the_same_bytes_and_decode_on_all_workers(oracl
     assert bytes(r1[1][0][0]) == oracle.encode_gmm(mode, sym, s_, m_, w_)
     strings, ams, zbs = [r[0][0] for r in r1], [r[0][1] for r in r1], [r[0][2] for r in r1]
     # on the GPU (option gpu_decode = 1; by default the library takes it when a call has enough segments to make it the
-    # faster decoder - these few small items would go to the host's workers): one wave per segment, no tables
+    # faster decoder - these few small items would go to the host's workers): one workgroup per segment, no tables
     _lib.set_option(0, "gpu_decode", 1)
     out = ck.decompress_batch(strings, ams, zbs, ss, ms, ws)
     for o, r in zip(out, r1):
@@ -899,6 +899,13 @@ def test_checkpointed_streams_are_the_same_bytes_and_decode_on_all_workers(oracl
     rb = ck.compress_batch(*bt)
     ob = ck.decompress_batch([x[0][0] for x in rb], [x[0][1] for x in rb], [x[0][2] for x in rb], *bt[1:])
     assert all(torch.equal(o, x[1]) for o, x in zip(ob, rb)) and (_lib.ctx_stat(0, 4), _lib.ctx_stat(0, 5)) == (24, 0)
+    # ... that launch had 3 048 segments: three waves each (two producers).  With a note every 256 symbols it has 12 120 and takes
+    # the two-wave shape (launch_segdec: more than 4 096 segments); the order of the segments (heaviest first) is the host's
+    ck256 = GaussianMixtureConditional(K=4, mode=mode, checkpoint_stride=256)
+    rb2 = ck256.compress_batch(*bt)
+    assert all(bytes(a[0][0]) == bytes(b[0][0]) for a, b in zip(rb2, rb)) and sum(len(x[0][0].ckpt) + 1 for x in rb2) > 4096
+    ob2 = ck256.decompress_batch([x[0][0] for x in rb2], [x[0][1] for x in rb2], [x[0][2] for x in rb2], *bt[1:])
+    assert all(torch.equal(o, x[1]) for o, x in zip(ob2, rb)) and (_lib.ctx_stat(0, 4), _lib.ctx_stat(0, 5)) == (24, 0)
     # through the table path, segments on the host workers (gpu_decode = 2):
     # (threads, option ckpt_decode: 0 = segments when the call has fewer bitstreams than workers, 1 = always, 2 = never)
     for threads, how in ((16, 0), (3, 1), (1, 1), (3, 0), (16, 2)):
