@@ -6,7 +6,7 @@ from flashgmm_amd import GaussianMixtureConditional, testing as T
 dev = torch.device("cuda:0")
 devt = [[torch.from_numpy(a).to(dev) for a in T.make_latent(i)] for i in range(48)]
 ys, ss, ms, ws = (torch.cat([t[k] for t in devt]) for k in range(4))
-gmc = GaussianMixtureConditional(K=4, mode="polya")
+gmc = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=int(os.environ.get("CKPT", "0")))  # CKPT=1024: the GPU segment decoder
 def rss(): return int(open("/proc/self/statm").read().split()[1]) * 4096 / 2**20
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 t_last = time.perf_counter()
