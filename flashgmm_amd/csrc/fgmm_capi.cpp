@@ -371,7 +371,13 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     hw_max = std::max(hw_max, it.hw);
   }
   const size_t small_bytes = ar.off - o_small;
-  for (auto &it : items) it.o_packed = ar.take(sizeof(uint32_t) * (size_t)it.M * (size_t)it.hw + 64);
+  // The bitstreams of a call in the order of their size, LARGEST FIRST (equal sizes: as given): their tables cross PCIe in that
+  // order and their host jobs are handed out in that order - the long jobs start first and the short ones fill the workers'
+  // tails (ELIC's groups differ 12x in size: in the order given the largest tables landed last and their jobs ended the call)
+  std::vector<int> order((size_t)count);
+  for (int i = 0; i < count; ++i) order[(size_t)i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (int64_t)items[a].M * items[a].hw > (int64_t)items[b].M * items[b].hw; });
+  for (int i : order) items[i].o_packed = ar.take(sizeof(uint32_t) * (size_t)items[i].M * (size_t)items[i].hw + 64);
   const size_t total = ar.off;
   int rc;
   if ((rc = ctx->ensure_device(total)) || (rc = ctx->ensure_host(total)) || (rc = ctx->ensure_events(count + 1))) return rc;
@@ -428,17 +434,27 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   // ---- tables back to the host: small region first, then one copy + event per item ----------------
   HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_small, ctx->d_ws + o_small, small_bytes, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipEventRecord(ctx->events[count], stream));
-  // the per-item tables are contiguous in the workspace: a handful of large copies instead of one per item
-  const int group_size = count >= 16 ? std::max(2, count / 6) : 1;
+  // the per-item tables are contiguous in the workspace (in `order`): a handful of large copies instead of one per item
   std::vector<int> group_of(count);
   int n_groups = 0;
-  for (int i0 = 0; i0 < count; i0 += group_size, ++n_groups) {
-    const int i1 = std::min(count, i0 + group_size);
-    const size_t beg = items[i0].o_packed;
-    const size_t end = items[i1 - 1].o_packed + sizeof(uint32_t) * (size_t)items[i1 - 1].M * (size_t)items[i1 - 1].hw;
-    if (end > beg) HIP_TRY(hipMemcpyAsync(ctx->h_ws + beg, ctx->d_ws + beg, end - beg, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(ctx->events[n_groups], stream));
-    for (int i = i0; i < i1; ++i) group_of[i] = n_groups;
+  {
+    size_t table_bytes = 0;
+    for (auto &it : items) table_bytes += sizeof(uint32_t) * (size_t)it.M * (size_t)it.hw;
+    const size_t per_group = count >= 16 ? table_bytes / 6 + 1 : 0; // (fewer than 16 bitstreams: a copy each)
+    for (int p0 = 0; p0 < count; ++n_groups) {
+      int p1 = p0;
+      size_t got = 0;
+      do {
+        got += sizeof(uint32_t) * (size_t)items[order[(size_t)p1]].M * (size_t)items[order[(size_t)p1]].hw;
+        ++p1;
+      } while (p1 < count && got < per_group);
+      const EncItem &a = items[order[(size_t)p0]], &b = items[order[(size_t)p1 - 1]];
+      const size_t beg = a.o_packed, end = b.o_packed + sizeof(uint32_t) * (size_t)b.M * (size_t)b.hw;
+      if (end > beg) HIP_TRY(hipMemcpyAsync(ctx->h_ws + beg, ctx->d_ws + beg, end - beg, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipEventRecord(ctx->events[n_groups], stream));
+      for (int p = p0; p < p1; ++p) group_of[order[(size_t)p]] = n_groups;
+      p0 = p1;
+    }
   }
   tr.mark("enqueued");
   HIP_TRY(hipEventSynchronize(ctx->events[count]));
@@ -453,7 +469,27 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   // automatic: pairs as soon as there are more bitstreams than workers (measured on the box, 48 bitstreams on 16 workers:
   // pairs 1.78 ms per call, threes 2.28, workers pulling one or two as the tables land 1.95-2.04)
   const int enc_ways = ctx->opt.enc_ways > 0 ? (int)ctx->opt.enc_ways : (count > enc_T ? 2 : 1);
-  for (int i = 0; i < count; ++i) {
+  // jobs: runs of up to `enc_ways` bitstreams adjacent in `order` (similar sizes), coded in turn by one worker; a bitstream that
+  // is a worker's fair share by itself (>= 1 / (2 * workers) of the call) is a job of its own - sixteen large pairs on eight
+  // workers would leave the other eight idle
+  std::vector<int> job_last((size_t)count, 0), job_first((size_t)count, 0); // by position in `order`
+  {
+    int64_t n_total = 0;
+    for (auto &it : items) n_total += (int64_t)it.M * it.hw;
+    const int64_t big = ctx->opt.enc_ways > 0 ? INT64_MAX : n_total / (2 * (int64_t)enc_T) + 1;
+    for (int p = 0; p < count;) {
+      int q = p + 1;
+      const EncItem &a = items[order[(size_t)p]];
+      if (!a.symbuf && (int64_t)a.M * a.hw < big)
+        while (q < count && q - p < enc_ways && !items[order[(size_t)q]].symbuf && (int64_t)items[order[(size_t)q]].M * items[order[(size_t)q]].hw < big) ++q;
+      for (int r = p; r < q; ++r) job_first[(size_t)r] = p, job_last[(size_t)r] = q - 1;
+      p = q;
+    }
+  }
+  std::vector<EncItem *> job_items((size_t)count);
+  for (int p = 0; p < count; ++p) job_items[(size_t)p] = &items[order[(size_t)p]];
+  for (int pos = 0; pos < count; ++pos) {
+    const int i = order[(size_t)pos];
     EncItem &it = items[i];
     int64_t n = (int64_t)it.M * it.hw;
     unsigned long long n_bypass = 0;
@@ -504,27 +540,24 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     it.job_syms = syms_for_bypass;
     it.job_n = n;
     it.job_bypass = (int64_t)n_bypass;
-    // More bitstreams than workers: consecutive items go to one worker `ways` at a time, coded in turn symbol by symbol
-    // (rans_encode_symtab_ways) - two dependency chains share a core: 1.5 instead of 2.4 ns/symbol.
-    const int ways = it.symbuf ? 1 : enc_ways;
-    const int g0 = i - i % ways; // the group [g0, g0 + ways) is submitted with its last member
-    bool group_ok = ways > 1;
-    for (int q = g0; group_ok && q < std::min(g0 + ways, count); ++q) group_ok = !items[q].symbuf;
-    const int g_end = group_ok ? std::min(g0 + ways, count) : i + 1;
-    if (group_ok && i + 1 < g_end) continue;
-    const int g_begin = group_ok ? g0 : i;
-    HIP_TRY(hipEventSynchronize(ctx->events[group_of[i]])); // the earlier items lie in the same or an earlier copy
+    // More bitstreams than workers: the members of a job go to one worker, coded in turn symbol by symbol
+    // (rans_encode_symtab_ways) - two dependency chains share a core: 1.5 instead of 2.4 ns/symbol.  The job is submitted with
+    // its last member (the later copies hold the smaller tables)
+    if (pos < job_last[(size_t)pos]) continue;
+    const int g_begin = job_first[(size_t)pos], n_in = pos - g_begin + 1;
+    int last_group = 0;
+    for (int r = g_begin; r <= pos; ++r) last_group = std::max(last_group, group_of[order[(size_t)r]]);
+    HIP_TRY(hipEventSynchronize(ctx->events[last_group])); // copies complete in the order they were queued
     const char *h_ws = ctx->h_ws;
-    EncItem *first = &items[g_begin];
-    const int n_in = g_end - g_begin;
+    EncItem *const *first = &job_items[(size_t)g_begin];
     const double t_sub = tr.ms();
-    for (int q = 0; q < n_in; ++q) first[q].t_sub = t_sub;
+    for (int q = 0; q < n_in; ++q) first[q]->t_sub = t_sub;
     auto job = [first, n_in, h_ws, &tr] {
       const double t_start = tr.ms();
-      if (n_in == 1 && first->symbuf) {
-        first->t_start = t_start;
-        first->status = fgmm_symbuf_append_symtab(first->symbuf, reinterpret_cast<const uint32_t *>(h_ws + first->o_packed), first->job_syms, first->job_n);
-        first->t_end = tr.ms();
+      if (n_in == 1 && first[0]->symbuf) {
+        first[0]->t_start = t_start;
+        first[0]->status = fgmm_symbuf_append_symtab(first[0]->symbuf, reinterpret_cast<const uint32_t *>(h_ws + first[0]->o_packed), first[0]->job_syms, first[0]->job_n);
+        first[0]->t_end = tr.ms();
         return;
       }
       const uint32_t *packed[kMaxEncWays];
@@ -533,35 +566,35 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
       uint8_t **out[kMaxEncWays];
       size_t *len[kMaxEncWays];
       fgmm_ckpt *ck[kMaxEncWays];
-      const int64_t stride = first->ckpt_stride; // one stride per call (checked at the boundary)
+      const int64_t stride = first[0]->ckpt_stride; // one stride per call (checked at the boundary)
       int rc = FGMM_OK;
       for (int q = 0; q < n_in; ++q) {
-        first[q].t_start = t_start;
-        packed[q] = reinterpret_cast<const uint32_t *>(h_ws + first[q].o_packed);
-        syms[q] = first[q].job_syms;
-        n[q] = first[q].job_n;
-        nb[q] = first[q].job_bypass;
-        out[q] = &first[q].bytes;
-        len[q] = &first[q].bytes_len;
+        first[q]->t_start = t_start;
+        packed[q] = reinterpret_cast<const uint32_t *>(h_ws + first[q]->o_packed);
+        syms[q] = first[q]->job_syms;
+        n[q] = first[q]->job_n;
+        nb[q] = first[q]->job_bypass;
+        out[q] = &first[q]->bytes;
+        len[q] = &first[q]->bytes_len;
         ck[q] = nullptr;
         const int64_t n_ck = stride > 0 && n[q] > 0 ? (n[q] - 1) / stride : 0;
         if (n_ck > 0) {
-          ck[q] = first[q].ckpt = static_cast<fgmm_ckpt *>(malloc(sizeof(fgmm_ckpt) * (size_t)n_ck));
+          ck[q] = first[q]->ckpt = static_cast<fgmm_ckpt *>(malloc(sizeof(fgmm_ckpt) * (size_t)n_ck));
           if (!ck[q]) rc = FGMM_ERR_NOMEM;
-          first[q].n_ckpt = ck[q] ? n_ck : 0;
+          first[q]->n_ckpt = ck[q] ? n_ck : 0;
         }
       }
       if (rc == FGMM_OK) rc = rans_encode_symtab_ways(n_in, packed, syms, n, nb, out, len, stride, ck);
       if (rc != FGMM_OK)
         for (int q = 0; q < n_in; ++q) {
-          free(first[q].ckpt);
-          first[q].ckpt = nullptr;
-          first[q].n_ckpt = 0;
+          free(first[q]->ckpt);
+          first[q]->ckpt = nullptr;
+          first[q]->n_ckpt = 0;
         }
       const double t_end = tr.ms();
       for (int q = 0; q < n_in; ++q) {
-        first[q].status = rc;
-        first[q].t_end = t_end;
+        first[q]->status = rc;
+        first[q]->t_end = t_end;
       }
     };
     if (count == 1) job(); else ctx->pool->submit(job);
