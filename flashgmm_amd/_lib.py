@@ -82,6 +82,7 @@ SIGNATURES = {
     "fgmm_ctx_threads": (_i, [_p]),
     "fgmm_ctx_set_threads": (_i, [_p, _i]),
     "fgmm_free": (None, [_p]),
+    "fgmm_ctx_take_buffers": (_i, [_p, _p, _p, _p, _i]),
     "fgmm_ctx_set_profiling": (_i, [_p, _i]),
     "fgmm_ctx_kernel_ms": (_i, [_p, _i, C.POINTER(C.c_float)]),
     "fgmm_ctx_stat": (_i, [_p, _i, C.POINTER(C.c_uint64)]),
@@ -182,6 +183,34 @@ def take_bytes(ptr: C.c_void_p, length: int) -> bytes:
     data = C.string_at(ptr, length)
     lib().fgmm_free(ptr)
     return data
+
+
+_py = C.pythonapi
+_py.PyBytes_FromStringAndSize.restype = C.py_object
+_py.PyBytes_FromStringAndSize.argtypes = [C.c_void_p, C.c_ssize_t]
+_py.PyBytes_AsString.restype = C.c_void_p
+_py.PyBytes_AsString.argtypes = [C.py_object]
+
+
+def take_bytes_many(device: int, ptrs, lens, cls=None) -> list:
+    """library-allocated buffers -> ``bytes`` objects (or instances of the bytes subclass ``cls``), the buffers released.
+    The copies are done by the context's host workers, straight into the objects' own storage: ``bytes`` objects allocated
+    uninitialised (``PyBytes_FromStringAndSize(NULL, n)``: the C API's way to fill a bytes object before anyone else sees it),
+    subclass instances as ``bytes.__new__(cls, n)`` (zero pages until written) - one copy, not one per layer of glue."""
+    n = len(ptrs)
+    if n == 0:
+        return []
+    if cls is None:
+        if sum(lens) < (1 << 18):
+            return [take_bytes(p, l) for p, l in zip(ptrs, lens)]
+        objs = [_py.PyBytes_FromStringAndSize(None, int(l)) for l in lens]
+    else:
+        objs = [bytes.__new__(cls, int(l)) for l in lens]
+    dst = (C.c_void_p * n)(*[_py.PyBytes_AsString(o) if l else None for o, l in zip(objs, lens)])
+    src = (C.c_void_p * n)(*ptrs)
+    ln = (C.c_size_t * n)(*lens)
+    check(lib().fgmm_ctx_take_buffers(ctx(device), dst, src, ln, n), "fgmm_ctx_take_buffers")
+    return objs
 
 
 def mode_id(mode) -> int:

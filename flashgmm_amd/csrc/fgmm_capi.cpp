@@ -1806,6 +1806,27 @@ int fgmm_ctx_set_threads(fgmm_ctx *ctx, int n_threads) {
   return FGMM_OK;
 }
 
+int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, const size_t *len, int count) {
+  if (!ctx || count < 0 || (count && (!dst || !src || !len))) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  constexpr size_t kChunk = 1u << 20; // (a 3 MB bitstream is three workers' copies)
+  {
+    PoolDrain drain{ctx->pool};
+    for (int i = 0; i < count; ++i)
+      for (size_t at = 0; at < len[i]; at += kChunk) {
+        if (!dst[i] || !src[i]) return fail(FGMM_ERR_INVALID, "buffer %d is NULL", i);
+        char *d = static_cast<char *>(dst[i]) + at;
+        const char *s_ = static_cast<const char *>(src[i]) + at;
+        const size_t nb = std::min(kChunk, len[i] - at);
+        if (count == 1 && len[i] <= kChunk) memcpy(d, s_, nb);
+        else ctx->pool->submit([d, s_, nb] { memcpy(d, s_, nb); });
+      }
+    ctx->pool->wait_all();
+  }
+  for (int i = 0; i < count; ++i) free(src[i]);
+  return FGMM_OK;
+}
+
 int fgmm_ctx_device(const fgmm_ctx *ctx) { return ctx ? ctx->device : -1; }
 int fgmm_ctx_threads(const fgmm_ctx *ctx) { return ctx && ctx->pool ? ctx->pool->size() : 0; }
 

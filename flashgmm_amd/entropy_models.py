@@ -48,6 +48,15 @@ class CheckpointedBytes(bytes):
         self._ckpt_addr = ckpt.ctypes.data if len(ckpt) else 0  # (ndarray.ctypes is slow: taken once)
         return self
 
+    @classmethod
+    def _adopt(cls, blank: "CheckpointedBytes", ckpt: np.ndarray, stride: int) -> "CheckpointedBytes":
+        """attach the notes to an instance whose bytes are already in place (``_lib.take_bytes_many(..., cls=CheckpointedBytes)``:
+        the library's workers copied the bitstream into it - no second copy through ``__new__``)"""
+        blank.ckpt = ckpt
+        blank.ckpt_stride = int(stride)
+        blank._ckpt_addr = ckpt.ctypes.data if len(ckpt) else 0
+        return blank
+
     def __reduce__(self):
         return (CheckpointedBytes, (bytes(self), self.ckpt, self.ckpt_stride))
 
@@ -205,14 +214,13 @@ class GaussianMixtureConditional(nn.Module):
             int(self.clamp_scales))
         _lib.check(rc, "GaussianMixtureConditional.compress")
         ptrs, lens, amax = items["bytes"].tolist(), items["bytes_len"].tolist(), items["abs_max"].tolist()
-        string_at, free = C.string_at, _lib.lib().fgmm_free
+        datas = _lib.take_bytes_many(dev.index if dev.index is not None else -1, ptrs, lens, CheckpointedBytes if self.checkpoint_stride else None)
         cks = list(zip(items["ckpt"].tolist(), items["n_ckpt"].tolist())) if self.checkpoint_stride else None
         out = []
         for i, (q, b) in enumerate(zip(yq.unbind(0), zb.unbind(0))):
-            data = string_at(ptrs[i], lens[i])
-            free(ptrs[i])
+            data = datas[i]
             if cks is not None:
-                data = CheckpointedBytes(data, _take_ckpt(*cks[i]), self.checkpoint_stride)
+                data = CheckpointedBytes._adopt(data, _take_ckpt(*cks[i]), self.checkpoint_stride)
             out.append(((data, amax[i], b), q))
         return out
 
@@ -289,10 +297,12 @@ class GaussianMixtureConditional(nn.Module):
                                                 n_items, self._mode(), int(self.clamp_scales))
         _lib.check(rc, "GaussianMixtureConditional.compress")
         res = []
+        datas = _lib.take_bytes_many(dev.index if dev.index is not None else -1, [items[i].bytes for i in range(n_items)],
+                                     [int(items[i].bytes_len) for i in range(n_items)], CheckpointedBytes if self.checkpoint_stride else None)
         for i in range(n_items):
-            data = _lib.take_bytes(items[i].bytes, items[i].bytes_len)
+            data = datas[i]
             if self.checkpoint_stride:
-                data = CheckpointedBytes(data, _take_ckpt(items[i].ckpt, int(items[i].n_ckpt)), self.checkpoint_stride)
+                data = CheckpointedBytes._adopt(data, _take_ckpt(items[i].ckpt, int(items[i].n_ckpt)), self.checkpoint_stride)
             res.append(((data, int(items[i].abs_max), bitmaps[i]), outs[i].view_as(ys[i])))
         return res
 

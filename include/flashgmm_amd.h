@@ -86,6 +86,10 @@ int fgmm_ctx_threads(const fgmm_ctx *ctx);
 int fgmm_ctx_set_threads(fgmm_ctx *ctx, int n_threads);
 
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
+/* Moves `count` buffers this library returned (src[i], len[i] bytes: bitstreams of a batched compress) into the caller's own
+ * storage dst[i] and releases them - the copies run on the context's host workers.  What a binding does instead of `count`
+ * single-threaded copies when its language wants to own the bytes (Python: 30 MB of bitstreams of eight 4K images, 3 ms). */
+int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, const size_t *len, int count);
 
 /* Tuning knobs of a context (defaults in brackets).  Unknown names return FGMM_ERR_INVALID.
  *   "pieces"      [8]   decode: the tables of every bitstream of a call reach the host in this many pieces (at most 16),
