@@ -697,18 +697,17 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
 }
 
 // =========================================================================================================
-// segdec_kernel — rANS decode of CHECKPOINTED bitstreams on the GPU: one WAVE per segment, no tables at all
+// segdec_kernel — rANS decode of CHECKPOINTED bitstreams on the GPU: one WORKGROUP per segment, no tables at all
 // =========================================================================================================
 // A checkpointed bitstream (include/flashgmm_amd.h: fgmm_ckpt) falls into segments that can be decoded independently, each
-// from its note of the coder state.  A Kodak batch call has thousands of them - enough to give every SIMD of the chip a few
-// waves - so the per-symbol chain  cf = x & 0xFFFF -> which symbol's interval holds cf -> advance the state  can run ON the
-// GPU, next to the parameters, and the decode-side tables (57.6 B/latent across PCIe, the bound of the table path) need not
-// exist: for every symbol the wave evaluates the latent's edges F[v] ACROSS ITS LANES (lane = one edge of the window between
-// the saturated tails, the same arithmetic as tab_kernel), one compare + ballot counts the edges <= cf - the wavefront-ballot
-// form of the reference's bisection (rans_interface.cpp:826-862) - and the coder state is advanced on the scalar unit.
-//   per 64 latents: lane = latent: twelve parameters, clamp + reciprocals, evaluation window (vectorised, as tab_kernel phase 0)
-//   per symbol    : broadcast that latent's parameters (v_readlane), lane = edge: F, count(F <= cf), F[J], F[J+1] -> advance
-// The wave only accepts what it can decide exactly as the reference does: a MONOTONE window with one interval around cf.
+// from its note of the coder state.  A Kodak batch call has thousands of them - enough to give every SIMD of the chip
+// several waves - so the per-symbol chain  cf = x & 0xFFFF -> which symbol's interval holds cf -> advance the state  can run
+// ON the GPU, next to the parameters, and the decode-side tables (57.6 B/latent across PCIe, the bound of the table path)
+// need not exist.  Per segment a PRODUCER wave (two in small launches) evaluates the edges F[v] of the next batch of latents
+// into LDS - the window between the saturated tails, the same arithmetic as tab_kernel - while the CONSUMER wave decodes the
+// current batch: lane = one edge of the symbol's latent, one compare + popcount counts the edges <= cf - the wavefront form
+// of the reference's bisection (rans_interface.cpp:826-862) - and the coder state is advanced on the scalar unit.
+// The kernel only accepts what it can decide exactly as the reference does: a MONOTONE window with one interval around cf.
 // Anything else (a non-monotone row, cf beyond every edge) flags the segment "hard"; a segment that does not end in the next
 // checkpoint's (state, position) flags "mismatch" - the host then decodes that bitstream through the table path, so the
 // result is the sequential decoder's in every case and a wrong note costs time, never a symbol.
@@ -734,8 +733,9 @@ constexpr int kSegLdsP = 0;                       // producer's own: parameters 
 constexpr int kSegLdsOff = 64 * 64;
 constexpr int kSegLdsCtrl = kSegLdsOff + 4 * 68 + 3 * 4 * 64;
 constexpr int kSegLdsBuf = kSegLdsCtrl + 32;
-constexpr int kSegLds = kSegLdsBuf + 2 * kSegBufBytes; // 15.9 KB per segment: ten segments = twenty waves per CU
-// Two waves per segment.  The PRODUCER (wave 1) does what needs no coder state, a batch of up to 64 latents ahead:
+constexpr int kSegLds = kSegLdsBuf + 2 * kSegBufBytes; // 15.9 KB per segment: ten segments per CU
+// Two or three waves per segment (launch_segdec).  The PRODUCER (wave 1; wave 2 takes a share of B) does what needs no coder
+// state, a batch of up to 64 latents ahead:
 //   A lane = latent: twelve parameters, clamp + reciprocals, the window between the saturated tails (tab_kernel's phase 0);
 //     as many latents as fit kSegCapE edges form the batch
 //   B flattened over (latent, pair of consecutive edges): tab_kernel's phase 2, the same packed arithmetic, edges -> LDS; the
