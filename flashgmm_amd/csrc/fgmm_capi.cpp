@@ -477,11 +477,15 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     int64_t n_total = 0;
     for (auto &it : items) n_total += (int64_t)it.M * it.hw;
     const int64_t big = ctx->opt.enc_ways > 0 ? INT64_MAX : n_total / (2 * (int64_t)enc_T) + 1;
+    // ... and the streams that would form a last, half-empty round of pairs (48 on 16 workers: 16 pairs, then 8 pairs on 8
+    // workers while 8 idle) are singles instead: every worker gets a pair and a single
+    const int tail = ctx->opt.enc_ways > 0 || enc_ways != 2 ? 0 : count % (2 * enc_T);
+    const int first_single = tail <= enc_T ? count - tail : count;
     for (int p = 0; p < count;) {
       int q = p + 1;
       const EncItem &a = items[order[(size_t)p]];
-      if (!a.symbuf && (int64_t)a.M * a.hw < big)
-        while (q < count && q - p < enc_ways && !items[order[(size_t)q]].symbuf && (int64_t)items[order[(size_t)q]].M * items[order[(size_t)q]].hw < big) ++q;
+      if (!a.symbuf && (int64_t)a.M * a.hw < big && p < first_single)
+        while (q < first_single && q - p < enc_ways && !items[order[(size_t)q]].symbuf && (int64_t)items[order[(size_t)q]].M * items[order[(size_t)q]].hw < big) ++q;
       for (int r = p; r < q; ++r) job_first[(size_t)r] = p, job_last[(size_t)r] = q - 1;
       p = q;
     }
