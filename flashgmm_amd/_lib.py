@@ -213,6 +213,14 @@ def take_bytes_many(device: int, ptrs, lens, cls=None) -> list:
     return objs
 
 
+def take_buffers_into(device: int, dst_addrs, src_ptrs, lens) -> None:
+    """library-allocated buffers copied to the given addresses and released (one native call)"""
+    n = len(src_ptrs)
+    if n:
+        check(lib().fgmm_ctx_take_buffers(ctx(device), (C.c_void_p * n)(*dst_addrs), (C.c_void_p * n)(*src_ptrs), (C.c_size_t * n)(*lens), n),
+              "fgmm_ctx_take_buffers")
+
+
 def mode_id(mode) -> int:
     if isinstance(mode, str):
         return MODES[mode.lower()]

@@ -1814,16 +1814,22 @@ int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, con
   if (!ctx || count < 0 || (count && (!dst || !src || !len))) return fail(FGMM_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lock(ctx->mu);
   constexpr size_t kChunk = 1u << 20; // (a 3 MB bitstream is three workers' copies)
-  {
+  size_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    if (len[i] && (!dst[i] || !src[i])) return fail(FGMM_ERR_INVALID, "buffer %d is NULL", i);
+    total += len[i];
+  }
+  if (total < (8u << 20)) { // (a Kodak batch's 2.5 MB: waking the workers costs more than the copy)
+    for (int i = 0; i < count; ++i)
+      if (len[i]) memcpy(dst[i], src[i], len[i]);
+  } else {
     PoolDrain drain{ctx->pool};
     for (int i = 0; i < count; ++i)
       for (size_t at = 0; at < len[i]; at += kChunk) {
-        if (!dst[i] || !src[i]) return fail(FGMM_ERR_INVALID, "buffer %d is NULL", i);
         char *d = static_cast<char *>(dst[i]) + at;
         const char *s_ = static_cast<const char *>(src[i]) + at;
         const size_t nb = std::min(kChunk, len[i] - at);
-        if (count == 1 && len[i] <= kChunk) memcpy(d, s_, nb);
-        else ctx->pool->submit([d, s_, nb] { memcpy(d, s_, nb); });
+        ctx->pool->submit([d, s_, nb] { memcpy(d, s_, nb); });
       }
     ctx->pool->wait_all();
   }

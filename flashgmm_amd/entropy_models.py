@@ -49,28 +49,39 @@ class CheckpointedBytes(bytes):
         return self
 
     @classmethod
-    def _adopt(cls, blank: "CheckpointedBytes", ckpt: np.ndarray, stride: int) -> "CheckpointedBytes":
+    def _adopt(cls, blank: "CheckpointedBytes", ckpt: np.ndarray, stride: int, addr: int = -1) -> "CheckpointedBytes":
         """attach the notes to an instance whose bytes are already in place (``_lib.take_bytes_many(..., cls=CheckpointedBytes)``:
         the library's workers copied the bitstream into it - no second copy through ``__new__``)"""
         blank.ckpt = ckpt
         blank.ckpt_stride = int(stride)
-        blank._ckpt_addr = ckpt.ctypes.data if len(ckpt) else 0
+        blank._ckpt_addr = addr if addr >= 0 else (ckpt.ctypes.data if len(ckpt) else 0)
         return blank
 
     def __reduce__(self):
         return (CheckpointedBytes, (bytes(self), self.ckpt, self.ckpt_stride))
 
 
-def _take_ckpt(ptr: int, n: int) -> np.ndarray:
-    """copy a library-allocated fgmm_ckpt[n] out and free it"""
-    if not ptr or n <= 0:
-        return _NO_CKPT
-    a = np.frombuffer((C.c_char * (16 * n)).from_address(ptr), dtype=CKPT_DTYPE).copy()
-    _lib.lib().fgmm_free(ptr)
-    return a
-
-
 _NO_CKPT = np.zeros(0, CKPT_DTYPE)
+
+
+def _take_ckpts_many(device: int, ptrs, counts):
+    """the library-allocated fgmm_ckpt arrays of a batch -> [(ndarray view, its address)], the arrays released: ONE array for the
+    batch and one native call instead of a copy and a free per bitstream"""
+    total = int(sum(counts))
+    if total == 0:
+        return [(_NO_CKPT, 0)] * len(ptrs)
+    pool = np.empty(total, CKPT_DTYPE)
+    base = pool.ctypes.data
+    out, dst, src, lens, at = [], [], [], [], 0
+    for p, n in zip(ptrs, counts):
+        if p and n > 0:
+            out.append((pool[at:at + n], base + 16 * at))
+            dst.append(base + 16 * at); src.append(p); lens.append(16 * n)
+            at += n
+        else:
+            out.append((_NO_CKPT, 0))
+    _lib.take_buffers_into(device, dst, src, lens)
+    return out
 
 
 def _plane_view(t: Tensor, K: int) -> Tuple[Tensor, int, int]:
@@ -215,12 +226,12 @@ class GaussianMixtureConditional(nn.Module):
         _lib.check(rc, "GaussianMixtureConditional.compress")
         ptrs, lens, amax = items["bytes"].tolist(), items["bytes_len"].tolist(), items["abs_max"].tolist()
         datas = _lib.take_bytes_many(dev.index if dev.index is not None else -1, ptrs, lens, CheckpointedBytes if self.checkpoint_stride else None)
-        cks = list(zip(items["ckpt"].tolist(), items["n_ckpt"].tolist())) if self.checkpoint_stride else None
+        cks = _take_ckpts_many(dev.index if dev.index is not None else -1, items["ckpt"].tolist(), items["n_ckpt"].tolist()) if self.checkpoint_stride else None
         out = []
         for i, (q, b) in enumerate(zip(yq.unbind(0), zb.unbind(0))):
             data = datas[i]
             if cks is not None:
-                data = CheckpointedBytes._adopt(data, _take_ckpt(*cks[i]), self.checkpoint_stride)
+                data = CheckpointedBytes._adopt(data, cks[i][0], self.checkpoint_stride, cks[i][1])
             out.append(((data, amax[i], b), q))
         return out
 
@@ -299,10 +310,12 @@ class GaussianMixtureConditional(nn.Module):
         res = []
         datas = _lib.take_bytes_many(dev.index if dev.index is not None else -1, [items[i].bytes for i in range(n_items)],
                                      [int(items[i].bytes_len) for i in range(n_items)], CheckpointedBytes if self.checkpoint_stride else None)
+        cks = _take_ckpts_many(dev.index if dev.index is not None else -1, [items[i].ckpt for i in range(n_items)],
+                               [int(items[i].n_ckpt) for i in range(n_items)]) if self.checkpoint_stride else None
         for i in range(n_items):
             data = datas[i]
-            if self.checkpoint_stride:
-                data = CheckpointedBytes._adopt(data, _take_ckpt(items[i].ckpt, int(items[i].n_ckpt)), self.checkpoint_stride)
+            if cks is not None:
+                data = CheckpointedBytes._adopt(data, cks[i][0], self.checkpoint_stride, cks[i][1])
             res.append(((data, int(items[i].abs_max), bitmaps[i]), outs[i].view_as(ys[i])))
         return res
 

@@ -1,0 +1,44 @@
+"""Dev aid (GPU): the sections of the Python glue of one stacked compress_batch of 48 Kodak halves (CKPT=stride for checkpointed
+streams), timed in place.   CKPT=1024 python scripts/glue_sections.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, ctypes as C
+from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T, entropy_models as EM
+dev = torch.device("cuda:0")
+lat = [T.make_latent(i) for i in range(48)]
+ys, ss, ms, ws = (torch.cat([torch.from_numpy(l[k]) for l in lat]).to(dev) for k in range(4))
+gmc = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=int(os.environ.get("CKPT", "1024")))
+import gc; gc.disable()
+self = gmc
+acc = {}
+def tick(name, t0):
+    t = time.perf_counter(); acc.setdefault(name, []).append(t - t0); return t
+for it in range(30):
+    t = time.perf_counter()
+    items, keep, N, M, h, w, d = self._stacked_items(ys, ss, ms, ws, 0)
+    t = tick("stacked_items", t)
+    yq = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=d)
+    zb = torch.empty((N, M), dtype=torch.int64)
+    items["yq_out"] = np.uint64(yq.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * h * w * 4)
+    items["zero_bitmap"] = np.uint64(zb.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * 8)
+    items["ckpt_stride"] = self.checkpoint_stride
+    stream = torch.cuda.current_stream(d).cuda_stream
+    t = tick("alloc+fields", t)
+    rc = _lib.lib().fgmm_gmc_compress_batch(_lib.ctx(d.index if d.index is not None else -1), stream, C.cast(items.ctypes.data, C.POINTER(_lib.fgmm_item)), N, self._mode(), int(self.clamp_scales))
+    t = tick("native", t)
+    ptrs, lens, amax = items["bytes"].tolist(), items["bytes_len"].tolist(), items["abs_max"].tolist()
+    t = tick("tolist", t)
+    datas = _lib.take_bytes_many(d.index if d.index is not None else -1, ptrs, lens, EM.CheckpointedBytes if self.checkpoint_stride else None)
+    t = tick("take_bytes_many", t)
+    cks = EM._take_ckpts_many(d.index if d.index is not None else -1, items["ckpt"].tolist(), items["n_ckpt"].tolist()) if self.checkpoint_stride else None
+    out = []
+    qs, bs = yq.unbind(0), zb.unbind(0)
+    t = tick("unbind", t)
+    for i, (q, b) in enumerate(zip(qs, bs)):
+        data = datas[i]
+        if cks is not None:
+            data = EM.CheckpointedBytes._adopt(data, cks[i][0], self.checkpoint_stride, cks[i][1])
+        out.append(((data, amax[i], b), q))
+    t = tick("ckpt+tuples", t)
+for k, v in acc.items():
+    print(f"{k:18s} {np.median(v[5:]) * 1e3:7.3f} ms")

@@ -6,7 +6,7 @@ from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
 dev = torch.device("cuda:0")
 lat = [T.make_latent(i) for i in range(48)]
 ys, ss, ms, ws = (torch.cat([torch.from_numpy(l[k]) for l in lat]).to(dev) for k in range(4))
-gmc = GaussianMixtureConditional(K=4, mode="polya")
+gmc = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=int(os.environ.get("CKPT", "0")))
 L = _lib.lib()
 native = {"c": [], "d": []}
 for name, key in (("fgmm_gmc_compress_batch", "c"), ("fgmm_gmc_decompress_batch", "d")):
