@@ -907,7 +907,13 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   Trace tr("decode", (int)ctx->opt.trace);
   int rc;
   if ((rc = ctx->ensure_streams())) return rc;
-  const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 32768) & ~31;
+  int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 32768) & ~31;
+  if (ctx->opt.tab_cap_e == kTabCapE) // (the default: a half-width that only fits the wider budget gets it)
+    for (const DecItem &it : items)
+      if (!tab_tl(it.max_bs, cap_e) && tab_tl(it.max_bs, kTabCapEWide)) {
+        cap_e = kTabCapEWide;
+        break;
+      }
   const bool clamped = items[0].clamp != 0, f16 = items[0].prm.dtype == FGMM_F16;
   // Elias-Fano rows (long rows: ef_min) are 18 % fewer bytes than uint16 rows and 40 % more nanoseconds to search (57.6 B and
   // 12 ns per latent against 70 B and 8.7 ns on the Kodak workload): with P = min(workers, bitstreams) decoders at work a
@@ -2193,7 +2199,8 @@ int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const f
   if (max_bs < 0 || max_bs > FGMM_MAX_BS) return fail(FGMM_ERR_UNSUPPORTED, "max_bs %d outside [0, %d]", max_bs, FGMM_MAX_BS);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
-  const int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 32768) & ~31;
+  int cap_e = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.tab_cap_e, 256), 32768) & ~31;
+  if (ctx->opt.tab_cap_e == kTabCapE && !tab_tl(max_bs, cap_e) && tab_tl(max_bs, kTabCapEWide)) cap_e = kTabCapEWide;
   const int tl = tab_tl(max_bs, cap_e);
   *tl_out = tl;
   if (!tl) return fail(FGMM_ERR_UNSUPPORTED, "2*max_bs+2 = %lld edges per latent do not fit the single-pass kernel (tab_cap_e = %d)", 2ll * max_bs + 2, cap_e);

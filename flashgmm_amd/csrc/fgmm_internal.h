@@ -146,7 +146,9 @@ FGMM_HD static inline unsigned long long tab_row_bytes(uint32_t cnt, uint32_t no
 FGMM_HD static inline bool tab_hdr_fits16(int32_t max_bs) { return 2 * (int64_t)max_bs + 2 <= 254; }
 FGMM_HD static inline int tab_hdr_form(int32_t max_bs) { return tab_hdr_fits16(max_bs) ? 2 : (max_bs <= 16382 ? 4 : 8); }
 // tab_kernel: entries of evaluated edges one block may keep in LDS, and the latents per block that guarantees it
-constexpr int kTabCapE = 16384; // default of the "tab_cap_e" option (upper limit 32768: 16-bit prefix sums in the kernel)
+constexpr int kTabCapE = 12288; // default of the "tab_cap_e" option (upper limit 32768: 16-bit prefix sums in the kernel): 80 latents of
+                                // Kodak's half-width per block, four blocks per CU - the kernel alone 1.29 ms against 1.44 at 16384
+constexpr int kTabCapEWide = 16384; // ... and what a call gets by default when an item's window only fits that (383 < max_bs <= 511)
 constexpr int kTabMaxTl = 256;
 FGMM_HD static inline int tab_tl(int32_t max_bs, int cap_e) { // 0: the item does not fit the single-pass kernel
   const int64_t W = 2 * (int64_t)max_bs + 2;

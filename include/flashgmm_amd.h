@@ -104,7 +104,8 @@ int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, con
  *                       sleeping worker without one.  0 = when the call has at least two bitstreams per worker and ships
  *                       uint16 rows (hosts with few threads), 1 = always, 2 = never.  With 24 bitstreams on 16 workers it
  *                       loses: it trades parallel workers for ILP
- *   "tab_cap_e"   [16384] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2))
+ *   "tab_cap_e"   [12288] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2));
+ *                       at the default a call with a half-width that only fits 16384 edges (383 < max_bs <= 511) gets that
  *   "stage_max_mb" [0]  decode: cap of the device staging area for rows in MiB (0: a quarter of the free device memory).
  *                       A launch whose rows do not fit is re-run with the exact size its cursor reports.
  *   "ef_rows"     [0]   decode: 0 = Elias-Fano rows when min(host workers, bitstreams of the call) >= 10 (PCIe is the
