@@ -35,4 +35,4 @@ for rnd in range(int(os.environ.get("ROUNDS", "8"))):
         for _ in range(5): times[ci].append(step())
 for c, t in zip(cfgs, times):
     e, d = np.array(t).T
-    print(f"{schedule:6s} {str(c):60s} encode {np.median(e):6.3f}  decode {np.median(d):6.3f}  step median {np.median(e + d):6.3f} ms  (p25 {np.percentile(e + d, 25):.3f}, min {np.min(e + d):.3f})")
+    print(f"{schedule:6s} {str(c):60s} encode {np.median(e):6.3f}  decode {np.median(d):6.3f}  step median {np.median(e + d):6.3f} ms  (p25 {np.percentile(e + d, 25):.3f}, min {np.min(e + d):.3f}, p90 {np.percentile(e + d, 90):.3f}, max {np.max(e + d):.3f}, mean {np.mean(e + d):.3f})")
