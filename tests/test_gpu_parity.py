@@ -816,8 +816,8 @@ def test_config4_images_in_flight_stage_major_equals_image_by_image(oracle):
             seen.append(out)
             return out
 
-    def build():
-        gmc = GaussianMixtureConditional(K=4, mode="polya")
+    def build(checkpoint_stride=0):
+        gmc = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=checkpoint_stride)
         real = gmc.decompress_batch
         gmc.decompress_batch = lambda strings, *a, **k: (calls.append(len(strings)), real(strings, *a, **k))[1]
         latent = {f"y{k}": CheckerboardLatentCodec(latent_codec={"y": Spy(K=4, gaussian_mixture_conditional=gmc, param_dtype=torch.float16)},
@@ -851,6 +851,23 @@ def test_config4_images_in_flight_stage_major_equals_image_by_image(oracle):
         ref = codec.decompress(many[n]["strings"], many[n]["shape"], sides[n])
         assert torch.equal(ref["y_hat"], dec[n]["y_hat"])
     assert calls == [1] * 20
+    # ... and with checkpointed bitstreams: the same bytes (groups of five sizes in one encode call: the library orders its jobs by
+    # size), every stage's call decoded by the GPU's segment decoder (fp16 planes; forced: the reduced planes are small)
+    from flashgmm_amd import CheckpointedBytes
+    ck = build(checkpoint_stride=256)
+    many_ck = ck.compress_many(ys, sides)
+    for a, b in zip(many_ck, many):
+        assert all(isinstance(x[0], CheckpointedBytes) for x in a["strings"])
+        assert [(bytes(s_[0]), s_[1], s_[2].tolist()) for s_ in a["strings"]] == [(s_[0], s_[1], s_[2].tolist()) for s_ in b["strings"]]
+        assert torch.equal(a["y_hat"], b["y_hat"])
+    _lib.set_option(0, "gpu_decode", 1)
+    try:
+        dec_ck = ck.decompress_many([m["strings"] for m in many_ck], many_ck[0]["shape"], sides)
+        assert (_lib.ctx_stat(0, 4), _lib.ctx_stat(0, 5)) == (2, 0)  # (the last stage's call)
+    finally:
+        _lib.set_option(0, "gpu_decode", 0)
+    for n in range(2):
+        assert torch.equal(dec_ck[n]["y_hat"], many[n]["y_hat"])
 
 
 @pytest.mark.parametrize("mode", MODES)
