@@ -368,6 +368,20 @@ __device__ __forceinline__ uint32_t tab_scan(uint32_t v, uint32_t *scratch, uint
 #ifndef FGMM_TAB_WAVES
 #define FGMM_TAB_WAVES 4
 #endif
+#ifdef FGMM_TAB_PROF // dev aid: cycles per phase of tab_kernel, summed over the blocks of every launch (fgmm_debug_tabprof)
+__device__ unsigned long long g_tabprof[8];
+#define TAB_T(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_tabprof[i], t_ - tab_t0); tab_t0 = t_; } } while (0)
+extern "C" int fgmm_debug_tabprof(unsigned long long *out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tabprof), sizeof(g_tabprof));
+  if (reset) {
+    unsigned long long z[8] = {};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tabprof), z, sizeof(z));
+  }
+  return rc;
+}
+#else
+#define TAB_T(i)
+#endif
 template <int MODE, bool CLAMPED, typename PT>
 __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDesc *__restrict__ descs, int tl_max, int cap_e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -382,6 +396,9 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   const int max_bs = d.max_bs;
   const int W = 2 * max_bs + 2;
 
+#ifdef FGMM_TAB_PROF
+  unsigned long long tab_t0 = clock64();
+#endif
   // ---- phase 0: parameters -> LDS, evaluation window ------------------------------------------------------------
   uint32_t pairs = 0;
   if (tid < nl) {
@@ -431,6 +448,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   if (tid == 0) S.offP[nl] = NP;
   __syncthreads();
 
+  TAB_T(0); // phases 0 + 1
   // ---- phase 2: flattened evaluation, two consecutive edges per lane and step ------------------------------------
   {
     // each wave takes a contiguous quarter of the pairs (in steps of 64), so that from one step to the next a lane
@@ -481,6 +499,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   __syncthreads();
   const uint16_t *E16 = reinterpret_cast<const uint16_t *>(S.E32);
 
+  TAB_T(1); // phase 2
   // ---- phase 3: trim every row, header, row size ------------------------------------------------------------------
   uint32_t bytes = 0;
   if (tid < nl) {
@@ -522,6 +541,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       static_cast<unsigned long long *>(d.hdr_out)[li] = tab_hdr8_pack(a_idx - max_bs, cnt, nm);
     }
   }
+  TAB_T(2); // phase 3
   // ---- phase 4: place the block's rows; Elias-Fano rows: entries and upper words before each ------------------------
   uint32_t B, EFT;
   const uint32_t exB = tab_scan(bytes, S.scratch, &B);
@@ -584,6 +604,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     }
   };
 
+  TAB_T(3); // phase 4
   // ---- phase 5a: unary high parts of the Elias-Fano rows, FLATTENED over their entries: bit ((E_j >> l) + j) ---------
   // Every lane takes a run of CONSECUTIVE entries (not every 64th): it stays inside one row for nearly all of them - the
   // row's description is loaded once, not once per entry - and the bits of entries that fall into one bitmap word are
@@ -627,6 +648,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   }
   __syncthreads();
 
+  TAB_T(4); // phase 5a
   // ---- phase 5b: FLATTENED over the 4-byte words of the block's rows; a word is two 16-bit units of one row, or - rows
   // are 2-byte aligned - the last unit of a row and the first of the next.  Every lane formats a run of CONSECUTIVE words
   // (a wave used to take 64 consecutive words per step, every lane landing in another row at every step: a search of the
@@ -694,6 +716,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       stg<uint32_t>(out + 4 * (size_t)q, val);
     }
   }
+  TAB_T(5); // phase 5b
 }
 
 // =========================================================================================================
