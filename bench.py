@@ -441,7 +441,12 @@ def main(argv=None):
                     help="codec (default): decode stage by stage as the codec's dependencies demand; all-at-once: round 1's")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("FGMM_BENCH_LAUNCH_TIMEOUT", "1500")),
                     help="self-launch (N > 1): seconds after which the ranks are stopped and the launch fails")
-    ap.add_argument("--checkpoint-stride", type=int, default=1024,
+    def _stride(v):
+        v = int(v)
+        if v < 256 or v & (v - 1):
+            raise argparse.ArgumentTypeError("a power of two >= 256 (what the segment decoders take)")
+        return v
+    ap.add_argument("--checkpoint-stride", type=_stride, default=1024,
                     help="stride of the `checkpointed` extra legs: symbols between the out-of-band notes of the coder state (16 B each)")
     ap.add_argument("--host-threads", type=int, default=0, help="host rANS workers per GPU (0: this rank's share of the CPU budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
