@@ -27,6 +27,11 @@ One JSON line is printed by rank 0; besides the driver's contract it carries
   latency_ms       one image (two bitstreams), encode + decode, as the codec schedules it and all at once
   upper_bound      the step with every stream in one decode call
   ranks            per-rank step times and the all-gather's share (N > 1)
+  modes            BASELINE configs[2] in the same run (N = 1): the A&S and logistic approximations on the same batch, a few steps each,
+                   the first four bitstreams checked against the reference's md5s (tests/golden/ka1.json: fixtures made from the
+                   compiled reference)
+  elic4k           BASELINE configs[4] in the same run (N = 1): eight 4K images, fp16 parameter planes, a few steps
+  checkpointed     the step on checkpointed bitstreams (segments decoded on the GPU), every rank, max over ranks
 """
 from __future__ import annotations
 
@@ -64,21 +69,38 @@ def stream_seed(rank: int, image: int, stream: int, streams_per_image: int) -> i
     return 1000 * rank + image * streams_per_image + stream
 
 
-def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: bool = False):
-    """-> (host arrays per stream, device tensors per stream, pixels per image).
-    kodak24: 2 streams per image, [1,192,32,24]; elic4k: 10 streams per image (5 channel groups x 2 halves of a
-    3840x2160 image padded to 2176 rows -> y [1,320,136,240], SURVEY.md §8 sizes)."""
+def _make_stream(args):
+    seed, M, h, w, f16 = args
     from flashgmm_amd import testing as T
 
+    y, sg, mu, pi = T.make_latent(seed, M=M, h=h, w=w)  # sigma pre-clamped as KA-1
+    if f16:
+        sg, mu, pi = T.to_float16_planes(sg, mu, pi)
+    return y, sg, mu, pi
+
+
+def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: bool = False, keep_host_images: int = 1 << 30):
+    """-> (host arrays per stream, device tensors per stream, pixels per image).
+    kodak24: 2 streams per image, [1,192,32,24]; elic4k: 10 streams per image (5 channel groups x 2 halves of a
+    3840x2160 image padded to 2176 rows -> y [1,320,136,240], SURVEY.md §8 sizes).  Large workloads (ELIC: seven seconds of
+    numpy per image) are generated by a pool of processes, stream by stream from their seeds - the same arrays either way."""
     host, devt = [], []
     shapes, pix = workload_shapes(workload)
-    for i in range(images):
-        for j, (M, h, w) in enumerate(shapes):
-            y, sg, mu, pi = T.make_latent(stream_seed(rank, i, j, len(shapes)), M=M, h=h, w=w)  # sigma pre-clamped as KA-1
-            if f16:
-                sg, mu, pi = T.to_float16_planes(sg, mu, pi)
-            host.append((y, sg, mu, pi))
-            devt.append([torch.from_numpy(a).to(dev) for a in (y, sg, mu, pi)])
+    jobs = [(stream_seed(rank, i, j, len(shapes)), M, h, w, f16) for i in range(images) for j, (M, h, w) in enumerate(shapes)]
+    n_elem = sum(M * h * w for _, M, h, w, _ in jobs)
+    procs = min(len(os.sched_getaffinity(0)), 8, len(jobs)) if n_elem > 8_000_000 else 1
+    if procs > 1:
+        import multiprocessing as mp
+
+        with mp.get_context("spawn").Pool(procs) as pool:
+            for k, st in enumerate(pool.imap(_make_stream, jobs, chunksize=1)):
+                host.append(st if k < keep_host_images * len(shapes) else None)  # (host copies feed the CPU baseline only)
+                devt.append([torch.from_numpy(a).to(dev) for a in st])
+    else:
+        for k, jb in enumerate(jobs):
+            st = _make_stream(jb)
+            host.append(st if k < keep_host_images * len(shapes) else None)
+            devt.append([torch.from_numpy(a).to(dev) for a in st])
     return host, devt, pix
 
 
@@ -175,6 +197,7 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
     process may use, one stream at a time per process (the reference is single-threaded and holds the GIL), then its
     USE_SIMD=0 path on a smaller sample."""
     kind, prepare, code = _cpu_coder()
+    host = host[: next((k for k, st in enumerate(host) if st is None), len(host))]  # (legs that kept the first image(s) only)
     # a bounded sample of the same workload: whole images, up to about 8 M latents (all 24 Kodak images; one 4K image)
     n_sample, n_sym_acc = 0, 0
     while n_sample < len(host) // streams_per_image and (n_sample == 0 or n_sym_acc < 7_000_000):
@@ -205,6 +228,36 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
                   f"{best * 1e3:.0f} ms/pass = {best / n_sym * 1e9:.0f} ns/symbol",
         "ms_per_image": round(best / n_img * 1e3, 2),
     }
+    # how this repo's C restatement (what `kind: "port"` runs would time) compares with the reference extension on this host:
+    # the first image, both coders, so that a line from a checkout without oracle/_ref stays comparable
+    if kind == "reference":
+        try:
+            from flashgmm_amd import testing as T
+            from oracle import oracle as O
+
+            t_port = t_ref = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                for st in host[:streams_per_image]:
+                    sym, s, m, w, am, zb, yq = T.to_coder_inputs(st[0], *(x.astype(np.float32) for x in st[1:]))
+                    b = O.encode_gmm(0, sym, s, m, w)
+                    assert np.array_equal(O.decode_gmm(0, b, s, m, w, am + 1), sym)
+                dtp = time.perf_counter() - t0
+                # (to_coder_inputs is part of the loop above and not of the reference's: taken out below)
+                t0 = time.perf_counter()
+                for st in host[:streams_per_image]:
+                    T.to_coder_inputs(st[0], *(x.astype(np.float32) for x in st[1:]))
+                dtp -= time.perf_counter() - t0
+                t0 = time.perf_counter()
+                for st in prepared[:streams_per_image]:
+                    code(st)
+                dtr = time.perf_counter() - t0
+                t_port, t_ref = (dtp if t_port is None else min(t_port, dtp)), (dtr if t_ref is None else min(t_ref, dtr))
+            out["port_over_reference"] = {"time_ratio": round(t_port / t_ref, 2), "port_ms_per_image": round(t_port * 1e3, 1),
+                                          "reference_ms_per_image": round(t_ref * 1e3, 1),
+                                          "note": "oracle/fgmm_oracle.c (scalar C restatement, what kind=port times) over the reference extension's SIMD path, first image, best of 2"}
+        except Exception as e:  # pragma: no cover
+            out["port_over_reference"] = {"time_ratio": None, "error": str(e)[:200]}
     # all cores: processes, not threads; each regenerates its share of the streams from their seeds
     try:
         import multiprocessing as mp
@@ -259,6 +312,18 @@ def pmc_traffic(workload: str, mode: str, f16: bool, images: int):
     return best, src
 
 
+def _die_with_parent():
+    """runs in a rank between fork and exec: SIGTERM when the launcher dies (even of SIGKILL: prctl PR_SET_PDEATHSIG), so a
+    killed launcher cannot leave ranks holding the GPUs"""
+    try:
+        import ctypes
+        import signal
+
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG = 1
+    except Exception:
+        pass
+
+
 def launch_ranks(a, argv):
     """`python bench.py --gpus N` with N > 1 and no torch.distributed.run around it: start N fresh child processes, one
     per GPU (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_* in their environment), BEFORE anything in this
@@ -281,7 +346,7 @@ def launch_ranks(a, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FGMM_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      preexec_fn=_die_with_parent, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0 = []
     reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
     reader.start()
@@ -322,8 +387,12 @@ def launch_ranks(a, argv):
                 failed = f"no result within --launch-timeout {a.launch_timeout:.0f} s"
                 break
             time.sleep(0.05)
+    except BaseException as e:  # anything unexpected in the supervision loop: the ranks must not outlive it
+        failed = failed or f"launcher error: {type(e).__name__}: {e}"
+        raise
     finally:
-        if failed:
+        # each rank leads its own session (a terminal's Ctrl-C does not reach it): whatever ended the loop, no rank is left behind
+        if failed or any(p.poll() is None for p in procs):
             stop_all()
         for sg, h in old_handlers.items():
             signal.signal(sg, h)
@@ -418,13 +487,195 @@ def dryrun(a, world, rank):
         emit({"metric": "dryrun", "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
               "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dryrun-no-gpu",
-              "config": {"workload": a.workload, "streams_per_gpu": n_streams},
+              "config": {"workload": a.workload, "streams_per_gpu": n_streams, "checkpoint_stride": a.checkpoint_stride,
+                         "one_device_rehearsal": bool(os.environ.get("FGMM_BENCH_ONE_DEVICE"))},
               "ranks": {"backend": "gloo" if world > 1 else None, "rccl_ranks": 0,
                         "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
                         "host_threads_per_gpu": per_rank_threads, "host_cpu_budget": _lib.host_cpu_budget(),
                         "allgather_ms": round(float(np.mean(t_gather[-a.steps:])) * 1e3, 4)}})
     if world > 1:
         dist.destroy_process_group()
+
+
+class Env:
+    """what every leg of a run shares: the rank's place in the job, its device, the process group"""
+
+    def __init__(self, rank, world, local_rank, dev, dist, coll_dev, backend):
+        self.rank, self.world, self.local_rank, self.dev, self.dist, self.coll_dev, self.backend = rank, world, local_rank, dev, dist, coll_dev, backend
+
+    def max_over_ranks(self, v: float) -> float:
+        if not self.dist:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+class Leg:
+    """One workload resident in HBM and the schedules that are timed over it.  Streams in coding order: image-major,
+    stage-minor; stage s of the decode schedule = stream s of every image."""
+
+    def __init__(self, env: Env, workload: str, images: int, mode: str, f16: bool, keep_host_images: int = 1 << 30, share=None):
+        from flashgmm_amd import GaussianMixtureConditional
+
+        self.env, self.workload, self.images, self.mode, self.f16 = env, workload, images, mode, f16
+        self.shapes1, _ = workload_shapes(workload)
+        self.spi = len(self.shapes1)  # streams per image = stages of the codec's decode schedule
+        if share is None:
+            self.host, devt, self.pix_per_image = make_workload(env.rank, images, env.dev, workload, f16, keep_host_images)
+            self.n_streams = len(devt)
+            self.hw_of = [t[0].shape[2] * t[0].shape[3] for t in devt]
+            self.shapes = sorted({tuple(t[0].shape) for t in devt})
+            self.stacked = len(self.shapes) == 1
+            if self.stacked:  # items of one shape go in as ONE tensor each, [N, ., h, w]: what a network run on a batch produces
+                self.ys, self.ss, self.ms, self.ws = (torch.cat([t[k] for t in devt]) for k in range(4))
+            else:
+                self.ys, self.ss, self.ms, self.ws = ([t[k] for t in devt] for k in range(4))
+        else:  # the same tensors under another approximation mode
+            for k in ("host", "pix_per_image", "n_streams", "hw_of", "shapes", "stacked", "ys", "ss", "ms", "ws"):
+                setattr(self, k, getattr(share, k))
+        spi, n = self.spi, self.n_streams
+        self.stage_params = [(self.ss[s::spi], self.ms[s::spi], self.ws[s::spi]) for s in range(spi)]  # strided batch views / sub-lists
+        self.stage_idx = [list(range(s, n, spi)) for s in range(spi)]
+        self.bytes_per_symbol = 32 if f16 else 56  # SURVEY.md §8d
+        self.gmc = GaussianMixtureConditional(K=4, mode=mode)
+        self.k_sym, self.k_tab, self.k_qs, self.t_gather, self.edges, self.tab_bytes = [], [], [], [], [], []
+        self.last = {}
+
+    def with_mode(self, mode: str):
+        return Leg(self.env, self.workload, self.images, mode, self.f16, share=self)
+
+    # ---- one step ----------------------------------------------------------------------------------------------------
+    def decode_codec(self, res, record=False):
+        """stage by stage; every image's stream of a stage in one call"""
+        from flashgmm_amd import _lib
+
+        lr = self.env.local_rank
+        outs = [None] * self.n_streams
+        tk = eg = tb = 0.0
+        for s in range(self.spi):
+            idx = self.stage_idx[s]
+            sp, mp_, wp = self.stage_params[s]
+            o = self.gmc.decompress_batch([res[i][0][0] for i in idx], [res[i][0][1] for i in idx], [res[i][0][2] for i in idx], sp, mp_, wp)
+            for i, t in zip(idx, o):
+                outs[i] = t
+            if record:
+                tk += _lib.kernel_ms(lr, 1)
+                eg += _lib.ctx_stat(lr, 3)
+                tb += _lib.ctx_stat(lr, 1)
+        if record:
+            self.k_tab.append(tk), self.edges.append(eg), self.tab_bytes.append(tb)
+        return outs
+
+    def decode_all(self, res, record=False):
+        from flashgmm_amd import _lib
+
+        lr = self.env.local_rank
+        outs = self.gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], self.ss, self.ms, self.ws)
+        if record:
+            self.k_tab.append(_lib.kernel_ms(lr, 1)), self.edges.append(_lib.ctx_stat(lr, 3)), self.tab_bytes.append(_lib.ctx_stat(lr, 1))
+        return outs
+
+    def step(self, schedule, record=False):
+        from flashgmm_amd import _lib
+        from flashgmm_amd import parallel as P
+
+        res = self.gmc.compress_batch(self.ys, self.ss, self.ms, self.ws)
+        if record:
+            self.k_sym.append(_lib.kernel_ms(self.env.local_rank, 0))
+            self.k_qs.append(_lib.kernel_ms(self.env.local_rank, 2))
+        if self.env.world > 1:  # the path's one exchange: per-stream bitstream lengths (SURVEY.md §8e), RCCL all-gather
+            t0 = time.perf_counter()
+            P.all_gather_stream_lengths([len(r[0][0]) for r in res], len(res), device=self.env.coll_dev)
+            if record:
+                self.t_gather.append(time.perf_counter() - t0)
+        outs = self.decode_codec(res, record) if schedule == "codec" else self.decode_all(res, record)
+        return res, outs
+
+    def timed(self, schedule, steps, record=False):
+        """-> (wall time of the whole region, step_ms statistics).  The per-step clock reads sit between steps, after the step's
+        own stream synchronisation (decompress returns with y_hat complete): they add nothing to the region.
+        (main() keeps the interpreter's generational GC off for the whole run: a pass takes tens of ms with torch loaded and
+        is not part of the path.)"""
+        dist = self.env.dist
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        c0 = cpu_throttle_counters()
+        marks = [time.perf_counter()]
+        for _ in range(steps):
+            self.last["res"], self.last["outs"] = self.step(schedule, record=record)
+            marks.append(time.perf_counter())
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        t1 = time.perf_counter()
+        return t1 - marks[0], step_stats(np.diff(marks), c0, cpu_throttle_counters())
+
+    def check_last(self):
+        """correctness of what was timed: decode(encode(y)) == round(y) for every stream of this rank"""
+        res, outs = self.last["res"], self.last["outs"]
+        for i in range(self.n_streams):
+            y_i = self.ys[i:i + 1] if self.stacked else self.ys[i]
+            assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(y_i)), f"stream {i} mismatch"
+        return res
+
+    def coded_symbols(self, res):
+        return sum(int(r[0][2].sum()) * hw for r, hw in zip(res, self.hw_of))
+
+    def symtab_roofline(self, res):
+        n_coded = self.coded_symbols(res)
+        sym_ms = float(np.mean(self.k_sym))
+        achieved = n_coded * self.bytes_per_symbol / (sym_ms * 1e-3) / 1e9
+        return n_coded, sym_ms, achieved
+
+    def mpix(self, steps, dt):
+        return self.env.world * self.images * self.pix_per_image * steps / dt / 1e6
+
+    def checkpointed(self, schedule, stride, steps, total_bytes):
+        """the whole step on CHECKPOINTED streams (GaussianMixtureConditional(checkpoint_stride=...): the reference's bitstreams +
+        out-of-band notes of the coder state every `stride` symbols, 16 bytes each): the segments between notes are independent, so
+        the decode runs ON THE GPU, one workgroup per segment (segdec_kernel; no decode-side tables, nothing but the bitstreams
+        crosses PCIe), every segment verified against the next note.  Not the reference's interface alone - its decoder has no
+        such notes.  Every rank runs it; the time is the slowest rank's."""
+        from flashgmm_amd import GaussianMixtureConditional, _lib
+
+        lr = self.env.local_rank
+        plain, self.gmc = self.gmc, GaussianMixtureConditional(K=4, mode=self.mode, checkpoint_stride=stride)
+        try:
+            self.step(schedule)
+            dt_ck, step_ms_ck = self.timed(schedule, steps)
+            res_ck = self.check_last()
+            on_gpu, back = _lib.ctx_stat(lr, 4), _lib.ctx_stat(lr, 5)
+        finally:
+            self.gmc = plain
+        dt_ck = self.env.max_over_ranks(dt_ck)
+        ck_bytes = int(sum(16 * len(r[0][0].ckpt) for r in res_ck))
+        return {"schedule": schedule, "value": round(self.mpix(steps, dt_ck), 2), "unit": "Mpixels/s",
+                "ms_per_step": round(dt_ck / steps * 1e3, 3), "steps": steps, "step_ms": step_ms_ck,
+                "checkpoint_stride": stride, "checkpoint_bytes": ck_bytes,
+                "checkpoint_bytes_over_bitstream_bytes": round(ck_bytes / max(total_bytes, 1), 4),
+                "bitstreams_decoded_on_gpu_last_call": on_gpu, "bitstreams_handed_back_last_call": back,
+                "note": "the same bitstreams + out-of-band checkpoints: decoded on the GPU, one workgroup per segment "
+                        "(segdec_kernel), every segment verified against the next checkpoint"}
+
+
+def ka1_check(leg: Leg, res):
+    """The first four bitstreams of rank 0 are SURVEY.md §8c's known-answer streams (seeds 0..3 = images 0 and 1 of the Kodak
+    batch): their md5s against tests/golden/ka1.json — fixtures made from the reference compiled in the build container
+    (tests/golden/make_golden.py).  -> dict, or None when the workload is not the one the fixtures were made for."""
+    import hashlib
+
+    if leg.workload != "kodak24" or leg.f16 or leg.env.rank != 0 or leg.n_streams < 2:
+        return None
+    try:
+        ka = json.load(open(os.path.join(ROOT, "tests", "golden", "ka1.json")))[leg.mode]
+    except (OSError, KeyError, ValueError):
+        return None
+    n = min(4, leg.n_streams)
+    got = [hashlib.md5(bytes(res[i][0][0])).hexdigest() for i in range(n)]
+    want = [ka[str(i)]["md5"] for i in range(n)]
+    return {"streams": n, "md5_equal_reference": got == want, "md5": got, "source": "tests/golden/ka1.json"}
 
 
 def main(argv=None):
@@ -441,16 +692,20 @@ def main(argv=None):
                     help="codec (default): decode stage by stage as the codec's dependencies demand; all-at-once: round 1's")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("FGMM_BENCH_LAUNCH_TIMEOUT", "1500")),
                     help="self-launch (N > 1): seconds after which the ranks are stopped and the launch fails")
+
     def _stride(v):
         v = int(v)
         if v < 256 or v & (v - 1):
             raise argparse.ArgumentTypeError("a power of two >= 256 (what the segment decoders take)")
         return v
+
     ap.add_argument("--checkpoint-stride", type=_stride, default=1024,
                     help="stride of the `checkpointed` extra legs: symbols between the out-of-band notes of the coder state (16 B each)")
     ap.add_argument("--host-threads", type=int, default=0, help="host rANS workers per GPU (0: this rank's share of the CPU budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip upper_bound / latency / per-thread legs (profiling runs)")
+    ap.add_argument("--no-sublegs", action="store_true",
+                    help="skip the `modes` (configs[2]) and `elic4k` (configs[4]) legs of the default kodak24 line")
     a = ap.parse_args(argv)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -465,9 +720,10 @@ def main(argv=None):
     sys.stdout.flush()
     _REAL_STDOUT = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    one_device = bool(os.environ.get("FGMM_BENCH_ONE_DEVICE"))  # rehearsal of the N > 1 code path on a 1-GPU box: every rank on GPU 0, gloo
     if os.environ.get("FGMM_BENCH_DRYRUN"):  # no GPU: the launcher, the collective and the JSON contract only (CPU test)
         return dryrun(a, world, rank)
-    if os.environ.get("FGMM_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 code path on a 1-GPU box (dev aid)
+    if one_device:
         local_rank = 0
     from flashgmm_amd import parallel as P
 
@@ -482,146 +738,82 @@ def main(argv=None):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("FGMM_BENCH_ONE_DEVICE"):  # RCCL refuses two ranks on one GPU: rehearse with gloo
+        if one_device:  # RCCL refuses two ranks on one GPU: rehearse with gloo
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         backend = dist.get_backend()
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    env = Env(rank, world, local_rank, dev, dist, coll_dev, backend)
 
-    from flashgmm_amd import GaussianMixtureConditional, _lib
+    from flashgmm_amd import GaussianMixtureConditional, _lib, container as Cn
 
     if a.images is None:
         # elic4k: EIGHT 4K images in flight, decoded stage-major (stage s of every image in one call, as kodak24 does with
         # its 24 images); one image alone is a chain of ten single-bitstream calls - that is the latency_ms leg
         a.images = 24 if a.workload == "kodak24" else 8
     f16 = (a.param_dtype or ("f32" if a.workload == "kodak24" else "f16")) == "f16"
-    shapes1, _ = workload_shapes(a.workload)
-    host, devt, pix_per_image = make_workload(rank, a.images, dev, a.workload, f16)
-    spi = len(shapes1)  # streams per image = stages of the codec's decode schedule
-    bytes_per_symbol = 32 if f16 else 56
-    n_streams = len(devt)
-    hw_of = [t[0].shape[2] * t[0].shape[3] for t in devt]
-    shapes = sorted({tuple(t[0].shape) for t in devt})
-    stacked = len(shapes) == 1
-    gmc = GaussianMixtureConditional(K=4, mode=a.mode)
     _lib.ctx(local_rank, a.host_threads)
     _lib.set_profiling(local_rank, True)
+    leg = Leg(env, a.workload, a.images, a.mode, f16)
+    spi, n_streams, pix_per_image = leg.spi, leg.n_streams, leg.pix_per_image
+    ys, ss, ms, ws = leg.ys, leg.ss, leg.ms, leg.ws
 
-    # streams in coding order: image-major, stage-minor.  Stage s of the decode schedule = stream s of every image.
-    if stacked:  # items of one shape go in as ONE tensor each, [N, ., h, w]: what a network run on a batch produces
-        ys, ss, ms, ws = (torch.cat([t[k] for t in devt]) for k in range(4))
-    else:
-        ys, ss, ms, ws = ([t[k] for t in devt] for k in range(4))
-    stage_params = [(ss[s::spi], ms[s::spi], ws[s::spi]) for s in range(spi)]  # strided batch views / sub-lists
-    stage_idx = [list(range(s, n_streams, spi)) for s in range(spi)]
-
-    k_sym, k_tab, k_qs, t_gather, edges, tab_bytes = [], [], [], [], [], []
-
-    def decode_codec(res, record=False):
-        """stage by stage; every image's stream of a stage in one call"""
-        outs = [None] * n_streams
-        tk = eg = tb = 0.0
-        for s in range(spi):
-            idx = stage_idx[s]
-            sp, mp_, wp = stage_params[s]
-            o = gmc.decompress_batch([res[i][0][0] for i in idx], [res[i][0][1] for i in idx], [res[i][0][2] for i in idx], sp, mp_, wp)
-            for i, t in zip(idx, o):
-                outs[i] = t
-            if record:
-                tk += _lib.kernel_ms(local_rank, 1)
-                eg += _lib.ctx_stat(local_rank, 3)
-                tb += _lib.ctx_stat(local_rank, 1)
-        if record:
-            k_tab.append(tk), edges.append(eg), tab_bytes.append(tb)
-        return outs
-
-    def decode_all(res, record=False):
-        outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
-        if record:
-            k_tab.append(_lib.kernel_ms(local_rank, 1)), edges.append(_lib.ctx_stat(local_rank, 3)), tab_bytes.append(_lib.ctx_stat(local_rank, 1))
-        return outs
-
-    def step(schedule, record=False):
-        res = gmc.compress_batch(ys, ss, ms, ws)
-        if record:
-            k_sym.append(_lib.kernel_ms(local_rank, 0))
-            k_qs.append(_lib.kernel_ms(local_rank, 2))
-        if world > 1:  # the path's one exchange: per-stream bitstream lengths (SURVEY.md §8e), RCCL all-gather
-            t0 = time.perf_counter()
-            P.all_gather_stream_lengths([len(r[0][0]) for r in res], len(res), device=coll_dev)
-            if record:
-                t_gather.append(time.perf_counter() - t0)
-        outs = decode_codec(res, record) if schedule == "codec" else decode_all(res, record)
-        return res, outs
-
-    last = {}
-
-    def timed(schedule, steps, record):
-        """-> (wall time of the whole region, step_ms statistics).  The per-step clock reads sit between steps, after the step's
-        own stream synchronisation (decompress returns with y_hat complete): they add nothing to the region."""
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        c0 = cpu_throttle_counters()
-        marks = [time.perf_counter()]
-        for _ in range(steps):
-            last["res"], last["outs"] = step(schedule, record=record)
-            marks.append(time.perf_counter())
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        t1 = time.perf_counter()
-        return t1 - marks[0], step_stats(np.diff(marks), c0, cpu_throttle_counters())
-
-    # a generational GC pass of the interpreter (tens of ms with torch loaded) is not part of the path: collect now, keep
-    # the collector off from the warm-up on.  Warm-up and timed region run back to back: 150 ms of idling between them (the
-    # result check used to sit there) costs the following steps 4 % (scripts/step_drift.py: the clocks have come down), so
-    # what is checked is the LAST TIMED step's result, after the clock has stopped.
+    # Warm-up and timed region run back to back: 150 ms of idling between them (the result check used to sit there) costs the
+    # following steps 4 % (scripts/step_drift.py: the clocks have come down), so what is checked is the LAST TIMED step's
+    # result, after the clock has stopped.
     import gc
 
     gc.collect()
     gc.freeze()
-    gc.disable()
+    gc.disable()  # for the whole run (what a step allocates is freed by reference counting)
     for _ in range(max(a.warmup, 1)):
-        step(a.schedule)
-    dt, step_ms = timed(a.schedule, a.steps, record=True)
-    gc.enable()
-    res, outs = last["res"], last["outs"]
-    # correctness of what was timed: decode(encode(y)) == round(y) for every stream of this rank
-    for i in range(n_streams):
-        y_i = ys[i:i + 1] if stacked else ys[i]
-        assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(y_i)), f"stream {i} mismatch"
-    n_coded = sum(int(r[0][2].sum()) * hw for r, hw in zip(res, hw_of))
+        leg.step(a.schedule)
+    dt, step_ms = leg.timed(a.schedule, a.steps, record=True)
+    res = leg.check_last()
+    n_coded = leg.coded_symbols(res)
     total_bytes = sum(len(r[0][0]) for r in res)
     enc_table_bytes = _lib.ctx_stat(local_rank, 0)
     host_threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
-    per_rank, per_rank_threads = [dt], [host_threads]
+    per_rank, per_rank_threads, checked = [dt], [host_threads], 1
     if dist:
-        tt = torch.tensor([dt, float(host_threads)], dtype=torch.float64, device=coll_dev)
+        tt = torch.tensor([dt, float(host_threads), 1.0], dtype=torch.float64, device=coll_dev)
         gathered = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(gathered, tt)
         per_rank = [float(t[0].item()) for t in gathered]
         per_rank_threads = [int(t[1].item()) for t in gathered]
+        checked = int(sum(t[2].item() for t in gathered))
         dt = max(per_rank)
+    ka1 = ka1_check(leg, res)
 
     extras = {}
+    payload_ms = None
+    if world > 1:
+        # the containers themselves, once per run (the timed step exchanges the LENGTHS; a deployment that assembles every
+        # image's container on every rank would pay this as well): rank r owns the images r, r + world, ...
+        local = [Cn.pack([res[i * spi + s][0] for s in range(spi)], {"y": list(leg.shapes1[0])}) for i in range(a.images)]
+        P.gather_containers(local, a.images * world, device=coll_dev)  # (the first use of a collective sets up its connections)
+        dist.barrier()
+        t0 = time.perf_counter()
+        allc = P.gather_containers(local, a.images * world, device=coll_dev)
+        payload_ms = env.max_over_ranks((time.perf_counter() - t0) * 1e3)
+        assert len(allc) == a.images * world and allc[rank] == local[0]
     if not a.no_extras:
         other = "all-at-once" if a.schedule == "codec" else "codec"
         n_ub = max(3, min(a.steps, 10))
-        step(other)
-        gc.disable()
-        dt_o, step_ms_o = timed(other, n_ub, record=False)
-        gc.enable()
-        if dist:
-            tt = torch.tensor([dt_o], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_o = float(tt.item())
+        leg.step(other)
+        dt_o, step_ms_o = leg.timed(other, n_ub)
+        dt_o = env.max_over_ranks(dt_o)
         extras["upper_bound" if other == "all-at-once" else "as_codec"] = {
-            "schedule": other, "value": round(world * a.images * pix_per_image * n_ub / dt_o / 1e6, 2), "unit": "Mpixels/s",
+            "schedule": other, "value": round(leg.mpix(n_ub, dt_o), 2), "unit": "Mpixels/s",
             "ms_per_step": round(dt_o / n_ub * 1e3, 3), "steps": n_ub, "step_ms": step_ms_o}
+        # the whole step on checkpointed streams: EVERY rank (this is the decode path that needs neither decode tables on
+        # the bus nor host decoders - the one that scales with GPUs, not with host cores)
+        extras["checkpointed"] = leg.checkpointed(a.schedule, a.checkpoint_stride, max(3, min(a.steps, 10)), total_bytes)
         if rank == 0 and world == 1:
             # latency of ONE image (its spi streams): encode in one call, decode stage by stage / in one call
+            gmc = leg.gmc
+
             def one_image(codec: bool):
                 y1 = ys[:spi]
                 p1 = [t[:spi] for t in (ss, ms, ws)]
@@ -642,15 +834,11 @@ def main(argv=None):
             extras["latency_ms"] = {"images": 1, "streams": spi,
                                     "as_codec": round(float(np.median([one_image(True) for _ in range(reps)])), 3),
                                     "all_at_once": round(float(np.median([one_image(False) for _ in range(reps)])), 3)}
-            # the same image with CHECKPOINTED streams (GaussianMixtureConditional(checkpoint_stride=...): the reference's
-            # bitstreams + out-of-band notes of the coder state every `stride` symbols, 16 bytes each): the segments between
-            # notes are independent, so the decode runs ON THE GPU, one workgroup per segment (segdec_kernel; no decode-side tables,
-            # nothing but the bitstreams crosses PCIe), every segment verified against the next note.  Not the reference's
-            # interface alone - its decoder has no such notes.
-            gmc_plain, gmc_ck = gmc, GaussianMixtureConditional(K=4, mode=a.mode, checkpoint_stride=a.checkpoint_stride)
+            # the same image with checkpointed streams
+            gmc_ck = GaussianMixtureConditional(K=4, mode=a.mode, checkpoint_stride=a.checkpoint_stride)
             gmc = gmc_ck
             r_ck = gmc_ck.compress_batch(ys[:spi], *[t[:spi] for t in (ss, ms, ws)])
-            assert all(bytes(x[0][0]) == bytes(y_[0][0]) for x, y_ in zip(r_ck, last["res"][:spi])), "checkpointed streams differ"
+            assert all(bytes(x[0][0]) == bytes(y_[0][0]) for x, y_ in zip(r_ck, res[:spi])), "checkpointed streams differ"
             for codec in (True, False):
                 one_image(codec)
             extras["latency_ms"]["as_codec_checkpointed"] = round(float(np.median([one_image(True) for _ in range(reps)])), 3)
@@ -664,46 +852,83 @@ def main(argv=None):
                 one_image(True)
                 extras["latency_ms"]["as_codec_checkpointed_stride_256"] = round(float(np.median([one_image(True) for _ in range(reps)])), 3)
                 extras["latency_ms"]["checkpoint_bytes_stride_256"] = int(sum(16 * len(x[0][0].ckpt) for x in r_256))
-                gmc = gmc_ck
-            # ... and the whole step on checkpointed streams (they matter when a call has fewer bitstreams than host workers:
-            # ELIC's stages; the Kodak batch has a bitstream per worker and ignores them)
-            step(a.schedule)
-            n_ck = max(3, min(a.steps, 10))
-            gc.disable()
-            dt_ck, step_ms_ck = timed(a.schedule, n_ck, record=False)
-            gc.enable()
-            res_ck = last["res"]
-            ck_bytes = int(sum(16 * len(r[0][0].ckpt) for r in res_ck))
-            extras["checkpointed"] = {"schedule": a.schedule, "value": round(a.images * pix_per_image * n_ck / dt_ck / 1e6, 2), "unit": "Mpixels/s",
-                                      "ms_per_step": round(dt_ck / n_ck * 1e3, 3), "steps": n_ck, "step_ms": step_ms_ck,
-                                      "checkpoint_stride": a.checkpoint_stride, "checkpoint_bytes": ck_bytes,
-                                      "checkpoint_bytes_over_bitstream_bytes": round(ck_bytes / max(total_bytes, 1), 4),
-                                      "bitstreams_decoded_on_gpu_last_call": _lib.ctx_stat(local_rank, 4),
-                                      "bitstreams_handed_back_last_call": _lib.ctx_stat(local_rank, 5),
-                                      "note": "the same bitstreams + out-of-band checkpoints: decoded on the GPU, one workgroup per segment "
-                                              "(segdec_kernel), every segment verified against the next checkpoint"}
-            gmc = gmc_plain
             # one host thread instead of the pool: what the GPU path is worth per host core
             threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
             _lib.set_threads(local_rank, 1)
-            step(a.schedule)
+            leg.step(a.schedule)
             n1 = 3
-            gc.disable()
-            dt1, _ = timed(a.schedule, n1, record=False)
-            gc.enable()
+            dt1, _ = leg.timed(a.schedule, n1)
             extras["one_host_thread"] = {"value": round(a.images * pix_per_image * n1 / dt1 / 1e6, 2), "unit": "Mpixels/s",
                                          "ms_per_step": round(dt1 / n1 * 1e3, 2), "host_threads": 1}
             _lib.set_threads(local_rank, threads)
 
+    # ---- BASELINE configs[2] and configs[4] in the default line (N = 1): a few steps each, so that the driver's own run witnesses them
+    sublegs = world == 1 and a.workload == "kodak24" and a.mode == "polya" and not f16 and not a.no_sublegs and not a.no_extras
+    if sublegs:
+        t_sub = time.perf_counter()
+        modes = {}
+        for m in ("as", "logistic"):
+            lm = leg.with_mode(m)
+            lm.step(a.schedule)
+            dt_m, st_m = lm.timed(a.schedule, 3, record=True)
+            res_m = lm.check_last()
+            nc_m, sym_ms_m, ach_m = lm.symtab_roofline(res_m)
+            modes[m] = {"value": round(lm.mpix(3, dt_m), 2), "unit": "Mpixels/s", "steps": 3, "ms_per_step": round(dt_m / 3 * 1e3, 3),
+                        "step_ms": st_m["all"], "bitstream_bytes": sum(len(r[0][0]) for r in res_m),
+                        "symtab": {"launch_ms": round(sym_ms_m, 4), "achieved": round(ach_m, 1), "unit": "GB/s", "frac": round(ach_m / HBM_PEAK_GBS, 4)},
+                        "tab_kernels_ms_per_step": round(float(np.mean(lm.k_tab)), 4),
+                        "reference_md5": ka1_check(lm, res_m)}
+        extras["modes"] = modes
+        try:
+            el = Leg(env, "elic4k", 8, "polya", True, keep_host_images=1)
+            el.step("codec")
+            dt_e, st_e = el.timed("codec", 3, record=True)
+            res_e = el.check_last()
+            nc_e, sym_ms_e, ach_e = el.symtab_roofline(res_e)
+            tb_e = float(np.mean(el.tab_bytes))
+            elic = {"config": {"workload": "elic4k", "images_per_gpu": 8, "param_dtype": "f16", "schedule": "codec", "decode_calls_per_step": el.spi,
+                               "coded_symbols_per_gpu": nc_e, "approx_mode": "polya"},
+                    "value": round(el.mpix(3, dt_e), 2), "unit": "Mpixels/s", "steps": 3, "ms_per_step": round(dt_e / 3 * 1e3, 3), "step_ms": st_e["all"],
+                    "symtab": {"launch_ms": round(sym_ms_e, 4), "achieved": round(ach_e, 1), "unit": "GB/s", "frac": round(ach_e / HBM_PEAK_GBS, 4),
+                               "bytes_per_symbol": el.bytes_per_symbol},
+                    "decode_table_bytes_per_latent": round(tb_e / max(1, nc_e), 2),
+                    "checkpointed": el.checkpointed("codec", a.checkpoint_stride, 3, sum(len(r[0][0]) for r in res_e))}
+            if not a.no_cpu_baseline:  # the reference's own coder on ONE of these images, one pass
+                kind, prepare, code = _cpu_coder()
+                prepared = [prepare(s) for s in el.host[:el.spi]]
+                t0 = time.perf_counter()
+                for st in prepared:
+                    got, want = code(st)
+                    assert np.array_equal(got, want)
+                t_ref = time.perf_counter() - t0
+                elic["cpu_baseline"] = {"value": round(el.pix_per_image / t_ref / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+                                        "sample": f"1 image x {el.spi} streams ({sum(len(p[-1]) for p in prepared)} symbols), encode+decode, one pass, {t_ref * 1e3:.0f} ms"}
+            del el
+            torch.cuda.empty_cache()
+            _lib.trim(local_rank)
+            extras["elic4k"] = elic
+        except Exception as e:  # pragma: no cover - the headline must not die of a sub-leg (e.g. out of memory on a shared card)
+            extras["elic4k"] = {"value": None, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+        extras["sublegs_s"] = round(time.perf_counter() - t_sub, 1)
+
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * a.images * pix_per_image * a.steps / dt / 1e6
-        sym_ms = float(np.mean(k_sym))
-        achieved = n_coded * bytes_per_symbol / (sym_ms * 1e-3) / 1e9
-        tab_ms, n_edges, tbytes = float(np.mean(k_tab)), float(np.mean(edges)), float(np.mean(tab_bytes))
+        _, sym_ms, achieved = leg.symtab_roofline(res)
+        tab_ms, n_edges, tbytes = float(np.mean(leg.k_tab)), float(np.mean(leg.edges)), float(np.mean(leg.tab_bytes))
         traffic, traffic_src = pmc_traffic(a.workload, a.mode, f16, a.images)
         tab_alg_bytes = n_coded * (12 * (2 if f16 else 4)) + tbytes  # parameters in, headers + block offsets + rows out
         slots = n_edges * TAB_SLOTS_PER_EDGE[a.mode]
+        budget = _lib.host_cpu_budget()
+        # host memory traffic of the plain path per rank: every table byte is written once by the DMA and read once by a host
+        # worker (encode tables + decode tables), per second of stepping
+        host_traffic = 2.0 * (enc_table_bytes + tbytes) / (ms_per_step * 1e-3) / 1e9
+        note = (f"{host_threads} host rANS workers for this GPU = min(affinity {budget.get('affinity')}, cgroup quota "
+                f"{budget.get('quota')}) / {_lib.ranks_on_node()} rank(s) on the node, at most 16")
+        if host_threads < 8:
+            note += ("; FEWER THAN 8 WORKERS: the plain (table) path is host-bound by configuration here - its rate follows the "
+                     "workers (one_host_thread x workers), the `checkpointed` leg does not need them")
+            print(f"[bench] {note}", file=sys.stderr)
         out = {
             # BASELINE.json's metric, verbatim: `value` is its Mpixels/s half, the `roofline` object its GMM-CDF HBM half
             "metric": "encode+decode Mpixels/s (Kodak, K=4 N=192) + GMM-CDF HBM GB/s vs roofline" if a.workload == "kodak24"
@@ -722,18 +947,20 @@ def main(argv=None):
             "data": "synthetic",
             "config": {"workload": a.workload, "schedule": a.schedule,
                        "decode_calls_per_step": spi if a.schedule == "codec" else 1, "images_per_gpu": a.images,
-                       "streams_per_gpu": n_streams, "stream_shapes": shapes, "stacked_input": stacked, "K": 4, "approx_mode": a.mode,
+                       "streams_per_gpu": n_streams, "stream_shapes": leg.shapes, "stacked_input": leg.stacked, "K": 4, "approx_mode": a.mode,
                        "param_dtype": "f16" if f16 else "f32",
                        "coded_symbols_per_gpu": n_coded, "bitstream_bytes_per_gpu": total_bytes,
-                       "host_threads_per_gpu": host_threads, "host_cpu_budget": _lib.host_cpu_budget(),
+                       "host_threads_per_gpu": host_threads, "host_cpu_budget": budget,
                        "ranks_on_node": _lib.ranks_on_node(), "numa": numa,
+                       "host_mem_traffic_GBps_per_rank": round(host_traffic, 1), "cpu_budget_note": note,
+                       "one_device_rehearsal": one_device,
                        "parallelism": f"images sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "symtab_kernel (encode-side GMM-CDF)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": "recorded PMC measurement of this workload (file in traffic_source), not collected in this run",
-                         "launch_ms": round(sym_ms, 4), "bytes_per_launch": n_coded * bytes_per_symbol,
-                         "bytes_per_symbol": bytes_per_symbol},
+                         "launch_ms": round(sym_ms, 4), "bytes_per_launch": n_coded * leg.bytes_per_symbol,
+                         "bytes_per_symbol": leg.bytes_per_symbol},
             # the decode-side table kernel against BOTH of its rooflines: VALU issue and HBM
             "roofline_decode": {"kernel": "tab_kernel (decode-side edge tables, all launches of a step)", "bound": "valu",
                                 "ms_per_step": round(tab_ms, 4), "edges_evaluated": int(n_edges),
@@ -745,26 +972,37 @@ def main(argv=None):
                                 "hbm_bytes_algorithmic": int(tab_alg_bytes),
                                 "hbm_achieved": round(tab_alg_bytes / (tab_ms * 1e-3) / 1e9, 1),
                                 "hbm_frac": round(tab_alg_bytes / (tab_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "note": "in situ: the launches share the GPU with the blit kernels of the table copies"},
+                                "note": "in situ: the launches share the GPU with the table copies"},
             "kernels_ms": {"symtab": round(sym_ms, 4), "tab_kernels_all_launches": round(tab_ms, 4),
-                           "quant_stats": round(float(np.mean(k_qs)), 4)},
+                           "quant_stats": round(float(np.mean(leg.k_qs)), 4)},
             # what crosses PCIe per step and rank (the decode-side tables are the longest leg of a step)
             "pcie": {"encode_tables_bytes": enc_table_bytes, "decode_tables_bytes": int(tbytes),
                      "decode_table_bytes_per_latent": round(tbytes / max(1, n_coded), 2), "bitstream_bytes": total_bytes},
             "ranks": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                       "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
-                      "host_threads_per_gpu": per_rank_threads,
-                      "allgather_ms": round(float(np.mean(t_gather)) * 1e3, 4) if t_gather else None},
+                      "host_threads_per_gpu": per_rank_threads, "result_checked_ranks": checked,
+                      "allgather_ms": round(float(np.mean(leg.t_gather)) * 1e3, 4) if leg.t_gather else None,
+                      "allgather_payload_ms": round(payload_ms, 4) if payload_ms is not None else None},
+            "reference_md5": ka1,
         }
         out.update(extras)
         if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(host, shapes1, pix_per_image, spi, rank, f16)
+            cb = cpu_baseline(leg.host, leg.shapes1, pix_per_image, spi, rank, f16)
             if "one_host_thread" in extras and cb.get("value"):
                 cb["per_thread_speedup"] = round(extras["one_host_thread"]["value"] / cb["value"], 1)
             if cb.get("all_cores", {}).get("value"):
                 cb["speedup_vs_all_cores"] = round(value / cb["all_cores"]["value"], 1)
+            if cb.get("value"):
+                cb["speedup"] = round(value / cb["value"], 1)  # whole GPU path (all host workers) over ONE reference thread
             if "latency_ms" in out:
-                out["latency_ms"]["reference_cpu"] = cb["ms_per_image"]
+                lt = out["latency_ms"]
+                lt["reference_cpu"] = cb["ms_per_image"]
+                # one image, the reference's coder on one core over this path: through the reference's interface alone
+                # (plain streams), and with checkpointed streams (the same bytes + out-of-band notes: not the reference's format)
+                lt["speedup_plain"] = round(cb["ms_per_image"] / lt["as_codec"], 1)
+                ck_key = "as_codec_checkpointed_stride_256" if "as_codec_checkpointed_stride_256" in lt else "as_codec_checkpointed"
+                lt["speedup_checkpointed"] = round(cb["ms_per_image"] / lt[ck_key], 1)
+                lt["speedup_checkpointed_basis"] = ck_key
             out["cpu_baseline"] = cb
         emit(out)
     if dist:

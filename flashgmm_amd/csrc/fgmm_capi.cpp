@@ -164,7 +164,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, tab_place = 0, tab_spin = kTabSpinLimit;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -235,7 +235,7 @@ struct fgmm_ctx {
     d_cap = h_cap = d_stage_cap = 0;
   }
   bool profiling = false;
-  unsigned long long stat[6] = {0, 0, 0, 0, 0, 0}; // [4] bitstreams the GPU's segment decoder decoded, [5] ... handed back to the table path;
+  unsigned long long stat[7] = {0, 0, 0, 0, 0, 0, 0}; // [6] table launches re-run with the cursor after a look-back gave up (since the context exists); [4] bitstreams the GPU's segment decoder decoded, [5] ... handed back to the table path;
                                                    // last batched call: [0] encode table bytes D2H, [1] decode table bytes D2H,
                                              // [2] decode latents, [3] edges the decode-side kernels evaluated
   hipEvent_t prof[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
@@ -661,12 +661,13 @@ struct DecItem {
   int n_seg = 0, next_seg_push = 0;       // next_seg_push: guarded by the call's mutex
   int64_t piece_end[kMaxPieces] = {};     // one past the last latent of every piece (known when the call is planned)
   std::atomic<int> segs_left{0}, ckpt_bad{0}, wide_any{0};
+  std::vector<uint32_t> enc_aligned;      // a misaligned bitstream of a checkpointed item, copied ONCE (every segment starts a decoder on it)
   double t_taken = 0, t_start = 0, t_end = 0, t_waited = 0, t_lastland = 0, t_work = 0; // trace level 2: job timeline
   DecItem() = default;
   DecItem(const DecItem &) = delete;
 };
 
-constexpr size_t kCounterBytes = 4 * sizeof(unsigned long long); // per launch unit, see DecDesc::counters
+constexpr size_t kCounterBytes = kTabCounters * sizeof(unsigned long long); // per launch unit, see DecDesc::counters
 
 // frees what a call allocated outside the context's reusable buffers (rare paths: overflow re-runs, generic items)
 struct TempDevice {
@@ -964,6 +965,9 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     size_t fixed = 0, rows_cap = 0; // bytes: headers + block offsets | provisioned rows
     size_t o_stage = 0;             // where the unit's range starts in the staging area
     char *d_range = nullptr;        // device: [fixed | rows]
+    size_t o_scan = 0;              // the unit's look-back states in the workspace (one word per block, launch order)
+    int64_t scan_total = 0;         // blocks of the launch
+    int placement = 1;              // DecDesc::placement
   };
   std::vector<Unit> units;
   // Every item crosses in `np` pieces (block ranges), PIECE-MAJOR: piece 0 of every item, then piece 1 ...  The host
@@ -1010,6 +1014,17 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
                             it.n_ckpt == (it.n - 1) / it.ckpt_stride && it.n_ckpt < (1 << 24);
       it.n_seg = seekable ? (int)it.n_ckpt + 1 : 0;
       it.segs_left.store(it.n_seg);
+      // TabDecoder::begin copies a bitstream that is not 4-byte aligned (a C caller's; Python's bytes are aligned): once per
+      // item here, not once per segment there
+      if (it.n_seg && (reinterpret_cast<uintptr_t>(it.enc) & 3) && it.enc_len >= 8 && !(it.enc_len & 3)) {
+        try {
+          it.enc_aligned.resize(it.enc_len / 4);
+        } catch (const std::bad_alloc &) {
+          return fail(FGMM_ERR_NOMEM, "out of memory (%zu bytes of bitstream)", it.enc_len);
+        }
+        memcpy(it.enc_aligned.data(), it.enc, it.enc_len);
+        it.enc = reinterpret_cast<const uint8_t *>(it.enc_aligned.data());
+      }
     }
   }
   const int n_units = (int)units.size();
@@ -1050,6 +1065,13 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   const size_t o_descs = ar.take(sizeof(DecDesc) * std::max<size_t>(n_parts, 1));
   const size_t o_counters = ar.take(kCounterBytes * (size_t)std::max(n_units, 1), 256);
   const size_t upload_bytes = o_counters;
+  // look-back states of every launch, right behind the counters: zeroed with them in one memset
+  for (auto &u : units) {
+    for (auto &p : u.parts) u.scan_total += p.blk_end - p.blk_begin;
+    u.placement = ctx->opt.tab_place == 0 ? 1 : 0;
+    u.o_scan = ar.take(sizeof(unsigned long long) * (size_t)std::max<int64_t>(u.scan_total, 1), 8);
+  }
+  const size_t zero_bytes = ar.off - o_counters;
   // events: per unit [kernel done][counters landed] (this thread waits, briefly) and [tables landed] (the workers wait)
   // Workers SLEEP on the copies' events (sixteen spinning waiters exceed the box's CPU quota: ensure_events) - except in a small
   // call (one image: a few hundred microseconds in all), where being woken by an interrupt costs as much as the work itself:
@@ -1057,7 +1079,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   int64_t lat_total = 0;
   for (auto &it : items) lat_total += it.n;
   const bool spin = ctx->opt.spin_lat < 0 ? false : lat_total <= ctx->opt.spin_lat;
-  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off)) ||
+  if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(upload_bytes + kCounterBytes * (size_t)std::max(n_units, 1))) ||
       (rc = ctx->ensure_events((spin ? 3 : 2) * (size_t)std::max(n_units, 1) + 2, (size_t)n_units + 2)) || (rc = ctx->ensure_stage(stage_total)))
     return rc;
   ctx->chunks_reset();
@@ -1104,12 +1126,19 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   std::vector<size_t> unit_desc0((size_t)n_units + 1, 0);
   auto fill_unit_descs = [&](int u) {
     Unit &un = units[(size_t)u];
+    int64_t scan_base = 0;
     for (size_t k = 0; k < un.parts.size(); ++k) {
       const Part &p = un.parts[k];
       DecDesc &d = hd[unit_desc0[(size_t)u] + k];
       d = base_desc(items[p.item]);
       d.blk_begin = (int32_t)p.blk_begin;
       d.blk_end = (int32_t)p.blk_end;
+      d.placement = un.placement;
+      d.scan = reinterpret_cast<unsigned long long *>(ctx->d_ws + un.o_scan);
+      d.scan_base = scan_base;
+      d.scan_total = un.scan_total;
+      d.spin_limit = (int32_t)ctx->opt.tab_spin;
+      scan_base += p.blk_end - p.blk_begin;
       d.hdr_out = un.d_range + p.o_hdr;
       d.blkoff_out = reinterpret_cast<uint32_t *>(un.d_range + p.o_blkoff);
       d.rows = reinterpret_cast<uint8_t *>(un.d_range + un.fixed);
@@ -1123,7 +1152,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     fill_unit_descs(u);
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(ctx->d_ws + o_counters, 0, kCounterBytes * (size_t)std::max(n_units, 1), stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_ws + o_counters, 0, zero_bytes, stream));
   auto launch_unit = [&](int u) -> int {
     const Unit &un = units[(size_t)u];
     int64_t blocks_max = 0;
@@ -1141,7 +1170,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     if ((rc = launch_unit(u))) return rc;
     HIP_TRY(hipEventRecord(ev_kernel[u], stream));
     HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_kernel[u], 0));
-    HIP_TRY(hipMemcpyAsync(h_counters + 4 * (size_t)u, ctx->d_ws + o_counters + kCounterBytes * (size_t)u, kCounterBytes, hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(h_counters + kTabCounters * (size_t)u, ctx->d_ws + o_counters + kCounterBytes * (size_t)u, kCounterBytes, hipMemcpyDeviceToHost,
                            ctx->aux_stream));
     HIP_TRY(hipEventRecord(ev_counters[u], ctx->aux_stream));
   }
@@ -1438,25 +1467,33 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   for (int u = 0; u < n_units; ++u) {
     Unit &un = units[(size_t)u];
     HIP_TRY(hipEventSynchronize(ev_counters[u]));
-    unsigned long long *cn = h_counters + 4 * (size_t)u;
-    if (cn[1]) { // the provisioned row area was too small: once more, into an area of exactly the size the cursor asks for
-      const size_t need = align_up((size_t)cn[0], 256);
-      char *d_new = nullptr;
-      if ((rc = temp.alloc(un.fixed + need + 256, &d_new))) return rc;
-      un.d_range = d_new;
-      un.rows_cap = need;
+    unsigned long long *cn = h_counters + kTabCounters * (size_t)u;
+    // Not placed as launched: a look-back gave up (bit 1; never seen outside the test that forces it) - once more with the
+    // cursor -, or the provisioned row area was too small (bit 0) - once more into an area of exactly the size asked for
+    for (int attempt = 0; cn[1] && attempt < 3; ++attempt) {
+      if (cn[1] & 2) {
+        un.placement = 0;
+        ++ctx->stat[6];
+      } else {
+        const size_t need = align_up((size_t)cn[0], 256);
+        char *d_new = nullptr;
+        if ((rc = temp.alloc(un.fixed + need + 256, &d_new))) return rc;
+        un.d_range = d_new;
+        un.rows_cap = need;
+      }
       fill_unit_descs(u);
       HIP_TRY(hipMemcpyAsync(ctx->d_ws + o_descs + sizeof(DecDesc) * unit_desc0[(size_t)u], hd + unit_desc0[(size_t)u],
                              sizeof(DecDesc) * un.parts.size(), hipMemcpyHostToDevice, stream));
       HIP_TRY(hipMemsetAsync(ctx->d_ws + o_counters + kCounterBytes * (size_t)u, 0, kCounterBytes, stream));
+      HIP_TRY(hipMemsetAsync(ctx->d_ws + un.o_scan, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(un.scan_total, 1), stream));
       if ((rc = launch_unit(u))) return rc;
       HIP_TRY(hipEventRecord(ev_kernel[u], stream));
       HIP_TRY(hipMemcpyAsync(cn, ctx->d_ws + o_counters + kCounterBytes * (size_t)u, kCounterBytes, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
-      if (cn[1]) return fail(FGMM_ERR_HIP, "decode tables overflow their exactly sized area (unit %d: %llu of %zu bytes)", u, cn[0], need);
     }
+    if (cn[1]) return fail(FGMM_ERR_HIP, "decode tables could not be placed (unit %d: flags %llu, %llu of %zu bytes)", u, cn[1], cn[0], un.rows_cap);
     const size_t used = (size_t)cn[0];
-    edges += cn[2];
+    for (int q = 0; q < kTabEdgeSlots; ++q) edges += cn[4 + q];
     char *h_range = nullptr;
     if ((rc = ctx->chunk_alloc(un.fixed + used + 256, &h_range))) return rc;
     memset(h_range + un.fixed + used, 0, 256); // slack: the host's SIMD search reads a little past a row
@@ -1613,6 +1650,10 @@ const OptName kOpts[] = {
     {"ckpt_decode", &fgmm_ctx::Opts::ckpt_decode, 0, 2, "FGMM_CKPT_DECODE"},
     {"spin_lat", &fgmm_ctx::Opts::spin_lat, -1, 1ll << 40, "FGMM_SPIN_LAT"},
     {"gpu_decode", &fgmm_ctx::Opts::gpu_decode, 0, 2, "FGMM_GPU_DECODE"},
+    // tab_kernel's placement of a block's rows: 0 = decoupled look-back (launch order, no same-address atomics), 1 = one atomic
+    // add per block on a cursor (round 1-3; also what a launch is re-run with should a look-back ever give up)
+    {"tab_place", &fgmm_ctx::Opts::tab_place, 0, 1, "FGMM_TAB_PLACE"},
+    {"tab_spin", &fgmm_ctx::Opts::tab_spin, 0, 1 << 30, nullptr}, // look-back polls before giving up (tests set 0: every wait gives up)
 };
 } // namespace
 
@@ -1797,7 +1838,7 @@ int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out) {
 }
 
 int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out) {
-  if (!ctx || which < 0 || which > 5 || !out) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (!ctx || which < 0 || which > 6 || !out) return fail(FGMM_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lock(ctx->mu);
   *out = ctx->stat[which];
   return FGMM_OK;
@@ -2207,7 +2248,8 @@ int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const f
   const int64_t nblk = (n + tl - 1) / tl;
   if (nblk > 0x7FFFFFFFll) return fail(FGMM_ERR_UNSUPPORTED, "too many blocks");
   int rc;
-  if ((rc = ctx->ensure_device(4096)) || (rc = ctx->ensure_host(4096))) return rc;
+  const size_t o_scan = 1024 + align_up(kCounterBytes, 256);
+  if ((rc = ctx->ensure_device(o_scan + sizeof(unsigned long long) * (size_t)std::max<int64_t>(nblk, 1))) || (rc = ctx->ensure_host(4096))) return rc;
   hipStream_t s = (hipStream_t)stream;
   DecDesc *hd = reinterpret_cast<DecDesc *>(ctx->h_ws);
   memset(hd, 0, sizeof *hd);
@@ -2233,14 +2275,25 @@ int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const f
   hd->rows_cap = rows_cap;
   hd->counters = reinterpret_cast<unsigned long long *>(ctx->d_ws + 1024);
   hd->count_edges = 1;
-  HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, 32, s));
-  if (n) LAUNCH_TRY(launch_tab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, (int)nblk, tl, cap_e, mode, (flags & FGMM_TAB_CLAMP) != 0, false, s));
-  unsigned long long cn[4] = {0, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(cn, ctx->d_ws + 1024, 32, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  hd->scan = reinterpret_cast<unsigned long long *>(ctx->d_ws + o_scan);
+  hd->scan_base = 0;
+  hd->scan_total = nblk;
+  hd->spin_limit = (int32_t)ctx->opt.tab_spin;
+  unsigned long long cn[kTabCounters] = {};
+  for (int placement = ctx->opt.tab_place == 0 ? 1 : 0; placement >= 0; --placement) { // look-back; the cursor should a look-back give up
+    hd->placement = placement;
+    HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, o_scan - 1024 + sizeof(unsigned long long) * (size_t)std::max<int64_t>(nblk, 1), s));
+    if (n) LAUNCH_TRY(launch_tab(reinterpret_cast<const DecDesc *>(ctx->d_ws), 1, (int)nblk, tl, cap_e, mode, (flags & FGMM_TAB_CLAMP) != 0, false, s));
+    HIP_TRY(hipMemcpyAsync(cn, ctx->d_ws + 1024, sizeof cn, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (!(cn[1] & 2)) break;
+    ++ctx->stat[6];
+  }
   HIP_TRY(hipMemcpy(rows_used, cn, sizeof(uint64_t), hipMemcpyHostToDevice));
-  ctx->stat[3] = cn[2];
+  ctx->stat[3] = 0;
+  for (int q = 0; q < kTabEdgeSlots; ++q) ctx->stat[3] += cn[4 + q];
+  if (cn[1] & 2) return fail(FGMM_ERR_HIP, "tab_kernel: placement failed");
   if (cn[1]) return fail(FGMM_ERR_NOMEM, "rows_cap %llu bytes too small (need %llu)", (unsigned long long)rows_cap, cn[0]);
   return FGMM_OK;
 }

@@ -58,10 +58,21 @@ struct DecDesc {
   uint32_t *blkoff_out;          // [blk_end - blk_begin] byte offset / 4 of each block's first row, from `rows`
   uint8_t *rows;                 // the launch's row area (device staging)
   unsigned long long rows_cap;   // bytes
-  unsigned long long *counters;  // shared by the launch: [0] cursor = bytes of rows placed, [1] overflow (a block did not fit),
-                                 // [2] edges evaluated (only when count_edges: one more same-address atomic per block),
-                                 // [3] blocks with a non-monotone row
-  int32_t count_edges, pad2_;
+  unsigned long long *counters;  // shared by the launch (kTabCounters words): [0] bytes of rows placed (the cursor; with look-back
+                                 // placement: written once, by the launch's last block), [1] bit 0: overflow (a block did not
+                                 // fit), bit 1: a look-back gave up (the host re-runs the launch with the cursor), [2] unused,
+                                 // [3] blocks with a non-monotone row, [4 .. 4 + kTabEdgeSlots) edges evaluated, summed by the
+                                 // host (only when count_edges; spread over slots: same-address atomics serialise chip-wide)
+  int32_t count_edges;
+  // placement of a block's rows in the launch's row area: 0 = ONE returning atomic add per block on counters[0] (blocks land
+  // in arrival order; the chip does ~38 of those per microsecond, which bounds the kernel up to 64 latents per block);
+  // 1 = decoupled look-back over `scan` (blocks land in launch order: deterministic tables, no same-address atomics)
+  int32_t placement;
+  unsigned long long *scan;      // [scan_total] per block of the LAUNCH, in launch order (part-major): state << 62 | bytes; 0 = not there
+                                 // yet, 1 = the block's own bytes, 2 = bytes of all blocks up to and including it; zeroed by the host
+  int64_t scan_base;             // index of this part's block blk_begin in `scan`
+  int64_t scan_total;            // blocks of the launch
+  int32_t spin_limit, pad3_;     // polls of one look-back step before it gives up (a stalled predecessor: never seen)
   // ---- generic two-pass path (cdftab_count / scan / fill): any half-width, rows sequential in latent order
   void *hdr;                     // [n] headers, 4-byte form (8-byte form when hdr_form == 8)
   int32_t tiles;                 // blocks per channel = ceil(hw / 256)
@@ -113,6 +124,9 @@ int launch_segzero(const SegDesc *d_descs, int count, int64_t max_dead, void *st
 //   placement: sequential in latent order (generic path, the building-block API), or per block of `tl` latents at
 //   rows + 4 * blk_off[block] (tab_kernel: blocks are placed by an atomic cursor, in no particular order)
 constexpr int kMaxPieces = 16; // FGMM_MAX_PIECES
+constexpr int kTabEdgeSlots = 64;               // DecDesc::counters
+constexpr int kTabCounters = 4 + kTabEdgeSlots;
+constexpr int kTabSpinLimit = 1 << 21;          // look-back polls (a microsecond or two each) before a block gives up
 #ifndef FGMM_EF_MIN
 #define FGMM_EF_MIN 14
 #endif

@@ -1190,23 +1190,25 @@ int fgmm_rans_decode_tab_ckpt(const uint8_t *encoded, size_t encoded_len, const 
   const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, hdr_form, tl, 1, &pc, nullptr, nullptr};
   bool ok = true;
   int hard = FGMM_OK; // an error that is not the notes' fault
+  // ONE decoder for all segments: begin() copies a misaligned bitstream whole, which must not happen once per segment
+  fgmm::TabDecoder td;
+  int rc = td.begin(encoded, encoded_len, &tv, n, max_bs, out_symbols);
+  if (rc != FGMM_OK) {
+    td.finish();
+    return rc;
+  }
+  const uint64_t x_head = td.x;
   for (int64_t sgm = 0; sgm <= n_ckpt && ok; ++sgm) {
-    fgmm::TabDecoder td;
-    int rc = td.begin(encoded, encoded_len, &tv, n, max_bs, out_symbols);
-    if (rc != FGMM_OK) {
-      td.finish();
-      return rc;
-    }
     const int64_t lo = sgm * stride, hi = sgm == n_ckpt ? n : (sgm + 1) * stride;
-    const uint64_t x0 = sgm ? ckpt[sgm - 1].x : td.x, pos0 = sgm ? ckpt[sgm - 1].pos : 0;
+    const uint64_t x0 = sgm ? ckpt[sgm - 1].x : x_head, pos0 = sgm ? ckpt[sgm - 1].pos : 0;
     uint64_t x1 = 0, pos1 = 0;
     rc = td.segment(lo, hi, x0, pos0, &x1, &pos1);
-    td.rc = FGMM_OK; // (finish() reports a range as "not covered" otherwise)
-    td.i = n;
-    td.finish();
+    td.rc = FGMM_OK; // (the next segment starts from its own note; finish() reports a range as "not covered" otherwise)
     if (rc != FGMM_OK) ok = false, hard = sgm == 0 ? rc : hard; // segment 0 starts from the stream's own head: its errors are real
     else if (sgm < n_ckpt && (x1 != ckpt[sgm].x || pos1 != ckpt[sgm].pos)) ok = false;
   }
+  td.i = n;
+  td.finish();
   if (ok) {
     if (verified_out) *verified_out = 1;
     return FGMM_OK;

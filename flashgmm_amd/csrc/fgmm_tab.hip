@@ -556,25 +556,33 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     S.rowoff[tid] = exB;
     S.efoff[tid] = exEF;
   }
+  // The block's place in the launch's row area.  Cursor placement (d.placement == 0): ONE returning atomic add on the launch's
+  // cursor - the chip does ~38 of those per microsecond, which is the kernel's floor up to 64 latents per block.  Look-back
+  // placement: this block's bytes are published now, the sum over its predecessors is collected AFTER phase 5a (which needs no
+  // address), by which time most of them have arrived.
+  const int64_t scan_idx = d.scan_base + (b - d.blk_begin);
   if (tid == 0) {
     S.rowoff[nl] = B;
     S.efoff[nl] = EFT;
-    const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)B4);
-    const bool fits = base + B4 <= d.rows_cap;
-    if (!fits) atomicMax(&d.counters[1], 1ull);
-    if (d.count_edges) atomicAdd(&d.counters[2], 2ull * NP);
-    d.blkoff_out[b - d.blk_begin] = (uint32_t)(base >> 2);
-    S.scratch[8] = (uint32_t)base;
-    S.scratch[9] = (uint32_t)(base >> 32);
-    S.scratch[10] = fits ? 1u : 0u;
+    if (d.placement) {
+      __hip_atomic_store(&d.scan[scan_idx], (1ull << 62) | (unsigned long long)B4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)B4);
+      const bool fits = base + B4 <= d.rows_cap;
+      if (!fits) atomicOr(&d.counters[1], 1ull);
+      d.blkoff_out[b - d.blk_begin] = (uint32_t)(base >> 2);
+      S.scratch[8] = (uint32_t)base;
+      S.scratch[9] = (uint32_t)(base >> 32);
+      S.scratch[10] = fits ? 1u : 0u;
+    }
+    if (d.count_edges) atomicAdd(&d.counters[4 + (scan_idx & (kTabEdgeSlots - 1))], 2ull * NP);
   }
   for (uint32_t q = tid; q < (EFT >> 16); q += kBlock) S.bitmap[q] = 0;
   {
     const int any_nm = __syncthreads_or(tid < nl && (S.flags[tid] & 2)); // also publishes rowoff / efoff / scratch / bitmap
     if (tid == 0 && any_nm) atomicAdd(&d.counters[3], 1ull);
   }
-  if (!S.scratch[10]) return; // the launch's row area is too small: the host re-runs it with what the cursor asks for
-  uint8_t *__restrict__ out = d.rows + (((unsigned long long)S.scratch[9] << 32) | S.scratch[8]);
+  if (!d.placement && !S.scratch[10]) return; // the launch's row area is too small: the host re-runs it with what the cursor asks for
 
   // what a lane keeps of the row it is working on (reloaded from LDS only when it moves on to another latent)
   struct RowRef {
@@ -646,7 +654,58 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       if (acc) atomicOr(&S.bitmap[acc_w], acc);
     }
   }
+  // ---- look-back (d.placement): bytes of all blocks before this one in launch order = where its rows start ------------------
+  // Wave 0, lane k reads the state of block scan_idx - 1 - k (- 64 per round): the nearest predecessor that already knows its
+  // inclusive sum ends the walk, the blocks between contribute their own bytes.  Blocks are dispatched in launch order and wait
+  // for nothing once they have published, so the lowest unpublished block never waits: no deadlock.  A look-back that polls
+  // spin_limit times in vain (never seen) gives up: the block reports it in counters[1], publishes a sum so that its
+  // successors end too, and the host re-runs the launch with the cursor.
+  if (d.placement && wave == 0) {
+    unsigned long long excl = 0;
+    bool gave_up = false;
+    const unsigned long long vmask = (1ull << 62) - 1ull;
+    for (int64_t pos = scan_idx - 1;; pos -= 64) {
+      const int64_t q = pos - lane;
+      unsigned long long v = 2ull << 62; // before the launch's first block: nothing
+      int spins = 0;
+      unsigned long long incl, missing;
+      for (;;) {
+        if (q >= 0 && (v >> 62) != 2) v = __hip_atomic_load(&d.scan[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        incl = __ballot((v >> 62) == 2);
+        missing = __ballot((v >> 62) == 0);
+        // needed: every lane below the first one that holds an inclusive sum (all 64 when none does)
+        const unsigned long long need = incl ? ((incl & (0ull - incl)) - 1ull) : ~0ull;
+        if (!(missing & need)) break;
+        if (++spins > d.spin_limit) {
+          gave_up = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (gave_up) break;
+      const int first = incl ? (int)__builtin_ctzll(incl) : 64;
+      unsigned long long c = lane <= first ? (v & vmask) : 0ull;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+      excl += c;
+      if (incl) break;
+    }
+    if (lane == 0) {
+      if (gave_up) atomicOr(&d.counters[1], 2ull);
+      const unsigned long long incl_sum = excl + B4;
+      __hip_atomic_store(&d.scan[scan_idx], (2ull << 62) | (incl_sum & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool fits = !gave_up && incl_sum <= d.rows_cap;
+      if (!fits) atomicOr(&d.counters[1], 1ull);
+      if (scan_idx == d.scan_total - 1) d.counters[0] = incl_sum; // the launch's total, as the cursor would report it
+      d.blkoff_out[b - d.blk_begin] = (uint32_t)(excl >> 2);
+      S.scratch[8] = (uint32_t)excl;
+      S.scratch[9] = (uint32_t)(excl >> 32);
+      S.scratch[10] = fits ? 1u : 0u;
+    }
+  }
   __syncthreads();
+  if (!S.scratch[10]) return; // (look-back placement: known only now)
+  uint8_t *__restrict__ out = d.rows + (((unsigned long long)S.scratch[9] << 32) | S.scratch[8]);
 
   TAB_T(4); // phase 5a
   // ---- phase 5b: FLATTENED over the 4-byte words of the block's rows; a word is two 16-bit units of one row, or - rows
@@ -1065,7 +1124,10 @@ __global__ __launch_bounds__(192) void segdec_kernel(const SegDesc *__restrict__
         // F[J] <= cf < F[J + 1], J = j_lo + n - 1 in [0, W - 2] (rans_interface.cpp:826-833): J >= 0 by the producer's choice of
         // plain latents; J = W - 1 has next = 0 and so a freq <= 0
         const uint32_t freq = next - start;
-        bad_acc |= (freq - 1u) >> 16;
+        // ... and the interval must HOLD cf: with every window edge <= cf the walk ends at the saturated tail, next = T_sat, and
+        // a cf in [T_sat, 0xFFFF) - weights that sum to just under 1; only a corrupt stream asks for it - lies beyond it: the
+        // reference's bisection ends elsewhere (rans_interface.cpp:865-875), so the segment goes back to the table path
+        bad_acc |= ((freq - 1u) >> 16) | (uint32_t)(cf - start >= freq);
         advance(freq, cf - start); // Rans64DecAdvance, rans64.h:124-134
         put(((int32_t)a >> 19) + (int32_t)n, k);
         if (++k >= nk) break;
@@ -1240,9 +1302,13 @@ __global__ __launch_bounds__(kBlock) void segzero_kernel(const SegDesc *__restri
 }
 int launch_segzero(const SegDesc *d_descs, int count, int64_t max_dead, void *stream) {
   if (count <= 0 || max_dead <= 0) return 0;
-  if (max_dead > 0x7FFFFFFFll || count > 65535) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(segzero_kernel, dim3((unsigned)max_dead, (unsigned)count), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_descs);
-  return launch_err();
+  if (max_dead > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;
+  for (int c0 = 0; c0 < count; c0 += 65535) { // grid.y holds 65535 items: a larger call is zeroed in several launches
+    hipLaunchKernelGGL(segzero_kernel, dim3((unsigned)max_dead, (unsigned)std::min(count - c0, 65535)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), d_descs + c0);
+    if (const int e = launch_err()) return e;
+  }
+  return 0;
 }
 int launch_segdec(const SegDesc *d_descs, const SegRef *d_segs, int64_t n_segs, int mode, bool clamped, bool f16, void *stream) {
   if (n_segs <= 0) return 0;

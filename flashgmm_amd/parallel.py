@@ -99,8 +99,12 @@ def _visible_filter(n_gpus: int) -> List[int]:
     import os
 
     idx = list(range(n_gpus))
-    for name in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(name)
+    # ROCR_VISIBLE_DEVICES filters at the ROCr level and COMPOSES with the HIP-level filter; HIP_VISIBLE_DEVICES and
+    # CUDA_VISIBLE_DEVICES are two names of that ONE HIP-level filter (launchers often export both): the first one set is
+    # applied, once
+    hip_level = next((nm for nm in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if (os.environ.get(nm) or "").strip() != ""), None)
+    for name in ("ROCR_VISIBLE_DEVICES", hip_level):
+        v = os.environ.get(name) if name else None
         if v is None or v.strip() == "":
             continue
         try:

@@ -135,7 +135,8 @@ int fgmm_ctx_trim(fgmm_ctx *ctx);
 int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable);
 /* Counters of the most recent batched call: which = 0 encode tables copied D2H (bytes), 1 decode headers + block offsets
  * + rows copied D2H (bytes), 2 latents those decode tables describe, 3 edges the decode-side kernels evaluated, 4 bitstreams
- * the GPU's segment decoder decoded (checkpointed ones), 5 bitstreams it handed back to the table path. */
+ * the GPU's segment decoder decoded (checkpointed ones), 5 bitstreams it handed back to the table path; 6 (since the context
+ * was created) table-kernel launches that were re-run with cursor placement because a look-back gave up (expected: 0). */
 int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out);
 int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out);
 

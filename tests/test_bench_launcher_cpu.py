@@ -106,3 +106,37 @@ def test_sigterm_to_the_launcher_stops_the_ranks():
     time.sleep(0.5)
     for k in kids:  # no rank survives its launcher
         assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z"
+
+
+def test_rehearsal_switch_and_checkpoint_stride_are_parsed_in_the_dry_run():
+    """FGMM_BENCH_ONE_DEVICE (the N > 1 rehearsal on a 1-GPU box: tests/test_gpu_parity.py runs it for real) and
+    --checkpoint-stride reach the line; a stride the segment decoders do not take is refused at the command line."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--images", "2", "--checkpoint-stride", "512"], {"FGMM_BENCH_ONE_DEVICE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip())
+    assert d["config"]["one_device_rehearsal"] is True and d["config"]["checkpoint_stride"] == 512 and d["n_gpus"] == 2
+    for bad in ("300", "128", "x"):
+        r = _run(["--gpus", "1", "--steps", "1", "--checkpoint-stride", bad])
+        assert r.returncode == 2 and "checkpoint-stride" in r.stderr
+
+
+def test_a_launcher_killed_outright_takes_its_ranks_with_it():
+    """SIGKILL leaves the launcher no chance to stop anything: the ranks are told by the kernel (PR_SET_PDEATHSIG)."""
+    import signal
+    import time
+
+    env = dict(os.environ, FGMM_BENCH_DRYRUN="1", FGMM_BENCH_DRYRUN_HANG_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                         env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    time.sleep(6.0)
+    kids = subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()
+    assert len(kids) == 2
+    p.send_signal(signal.SIGKILL)
+    p.wait(timeout=30)
+    deadline = time.monotonic() + 30
+    while time.monotonic() < deadline and any(os.path.exists(f"/proc/{k}") and open(f"/proc/{k}/stat").read().split()[2] != "Z" for k in kids):
+        time.sleep(0.2)
+    for k in kids:
+        assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z"

@@ -1273,3 +1273,79 @@ def test_rccl_collectives_single_rank():
         port = so.getsockname()[1]
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "nccl_worker.py"), str(port)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_gpu_segment_decoder_on_a_corrupt_last_segment_equals_the_sequential_decoder(mode):
+    """The LAST segment of a checkpointed bitstream is verified against no note.  With every note valid and only the words
+    of the last segment corrupted, the GPU's segment decoder, the host's segments and the plain sequential decode must still
+    agree symbol for symbol.  Weights that sum to 0.9 put T_sat near 58 981: a corrupt stream then asks, one time in ten, for
+    a cf in [T_sat, 0xFFFF) that no interval of a saturated window holds - the case the straight path of segdec_kernel must
+    hand back to the table path (which replays the reference's bisection) instead of walking on."""
+    from flashgmm_amd import CheckpointedBytes
+
+    rng = np.random.default_rng(5)
+    for seed, (M, h, w), stride in ((431, (24, 16, 12), 256), (432, (2, 16, 12), 256), (433, (24, 16, 12), 1024)):
+        y, sg, mu, pi = T.make_latent(seed, M=M, h=h, w=w)
+        pi = (pi * np.float32(0.9)).astype(np.float32)
+        t = [dv(a) for a in (y, sg, mu, pi)]
+        plain = GaussianMixtureConditional(K=4, mode=mode)
+        ck = GaussianMixtureConditional(K=4, mode=mode, checkpoint_stride=stride)
+        (b0, am, zb), yq = plain.compress(*t)
+        (b1, _, _), _ = ck.compress(*t)
+        assert bytes(b1) == b0 and len(b1.ckpt) >= 1
+        if seed == 432:
+            assert len(b1.ckpt) == 1  # n_ckpt == 1: two segments, the second unverified
+        first = 8 + 4 * int(b1.ckpt["pos"][-1])  # the words the decoder has not read when it stands at the last note
+        assert first < len(b0)
+        for trial in range(4):
+            bad = bytearray(b0)
+            k0 = first if trial < 2 else int(rng.integers(first, len(b0) - 3)) & ~3
+            bad[k0:] = bytes(rng.integers(0, 256, len(b0) - k0, dtype=np.uint8))
+            bad = bytes(bad)
+            results = []
+            for how, stream in ((None, bad), (1, CheckpointedBytes(bad, b1.ckpt, stride)), (2, CheckpointedBytes(bad, b1.ckpt, stride))):
+                if how is not None:
+                    _lib.set_option(0, "gpu_decode", how)
+                try:
+                    results.append((plain if how is None else ck).decompress(stream, am, zb, *t[1:]).cpu().numpy())
+                except RuntimeError:  # (a corrupt stream may also run out of words: then it must for every decoder)
+                    results.append(None)
+                finally:
+                    _lib.set_option(0, "gpu_decode", 0)
+            want = results[0]
+            for got in results[1:]:
+                assert (want is None and got is None) or (want is not None and got is not None and np.array_equal(got, want)), (seed, trial)
+
+
+def test_bench_two_ranks_rehearsed_on_one_device():
+    """BASELINE configs[3]'s code path in the one form a 1-GPU box allows (FGMM_BENCH_ONE_DEVICE): `bench.py --gpus 2` starts two
+    fresh rank processes before anything touches the GPU (never a re-exec), both code on GPU 0, the process group is gloo, the
+    per-step all-gather of bitstream lengths and one gather of the containers run, every rank checks its results, and rank 0
+    prints one line that carries the max-over-ranks legs (upper_bound, checkpointed).  A rehearsal, not a scaling point."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FGMM_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FGMM_BENCH_DRYRUN"):
+        env.pop(k, None)
+    torch.cuda.synchronize()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--images", "4", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--launch-timeout", "400"], env=env, capture_output=True, text=True, timeout=480)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    out_dir = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "n2_one_device.json"), "w").write(lines[0] + "\n")
+    assert d["n_gpus"] == 2 and d["config"]["one_device_rehearsal"] is True and d["config"]["images_per_gpu"] == 4
+    rk = d["ranks"]
+    assert rk["backend"] == "gloo" and rk["rccl_ranks"] == 0 and len(rk["ms_per_step"]) == 2 and rk["result_checked_ranks"] == 2
+    budget = d["config"]["host_cpu_budget"]
+    assert rk["host_threads_per_gpu"] == [max(1, min(16, int(budget["cpus"] / 2)))] * 2
+    assert rk["allgather_ms"] is not None and rk["allgather_ms"] > 0 and rk["allgather_payload_ms"] > 0
+    assert d["ms_per_step"] == max(rk["ms_per_step"]) and d["value"] > 0
+    assert d["upper_bound"]["value"] > 0 and d["checkpointed"]["value"] > 0 and d["checkpointed"]["bitstreams_handed_back_last_call"] == 0
+    assert "latency_ms" not in d and "modes" not in d  # (N = 1 legs)

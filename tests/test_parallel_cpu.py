@@ -149,3 +149,22 @@ def test_gather_containers_world2(n_units):
     want = [Cn.pack(*_fake_strings(u)) for u in range(n_units)]
     assert got[0] == want and got[1] == want  # every rank holds every unit's container, in unit order
     assert P.gather_containers(want[:1], 1) == want[:1]  # world size 1 degenerates to the identity
+
+
+def test_visible_device_filters_compose_as_the_runtime_composes_them(monkeypatch):
+    """ROCR_VISIBLE_DEVICES re-indexes first; HIP_VISIBLE_DEVICES and CUDA_VISIBLE_DEVICES are two names of ONE HIP-level
+    filter (launchers export both): applied once, not twice"""
+    for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    assert P._visible_filter(4) == [0, 1, 2, 3]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "1,0")
+    assert P._visible_filter(4) == [1, 0]  # (applied twice it would read [0, 1])
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2,3,1")
+    assert P._visible_filter(4) == [3, 2]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "2")
+    assert P._visible_filter(4) == [1]
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "GPU-deadbeef")
+    with pytest.raises(LookupError):
+        P._visible_filter(4)
