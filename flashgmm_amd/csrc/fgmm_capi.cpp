@@ -8,6 +8,8 @@
 // come back by pinned hipMemcpyAsync, and the workers start on item i as soon as its copy has landed, so the
 // PCIe transfer of item i+1 overlaps the host coding of item i.
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <math.h>
 #include <sched.h>
 #include <stdarg.h>
@@ -148,10 +150,82 @@ struct Arena {
   }
 };
 
+// Device -> pinned-host copies issued straight to the SDMA engines (hsa_amd_memory_async_copy_on_engine): what this
+// runtime's hipMemcpyAsync does with shader ("blit") kernels on the CUs - next to the table kernels of the later launches
+// (profiles/r03_bench_kernel_stats.csv: __amd_rocclr_copyBuffer, 43 % of the GPU time of a step).  The caller has seen the
+// producing kernel complete (it needs the launch's byte count anyway), so a copy has no dependency; completion is an HSA
+// signal the host workers sleep on.  HIP sits on the same HSA runtime: hsa_init() only takes another reference.
+struct HsaCopier {
+  bool tried = false, ok = false;
+  hsa_agent_t gpu{}, cpu{};
+  uint32_t engine[2] = {0, 0}; // two engines in turn: 56.9 GB/s against 55.4 on one (scripts/proto/sdma_copy.cpp)
+  std::vector<hsa_signal_t> sigs;
+  unsigned next = 0;
+  // agents from the buffers themselves: `dptr` device memory of the context's GPU, `hptr` pinned host memory
+  bool init(const void *dptr, const void *hptr) {
+    if (tried) return ok;
+    tried = true;
+    if (hsa_init() != HSA_STATUS_SUCCESS) return false;
+    hsa_amd_pointer_info_t pd, ph;
+    memset(&pd, 0, sizeof pd);
+    memset(&ph, 0, sizeof ph);
+    pd.size = sizeof pd;
+    ph.size = sizeof ph;
+    if (hsa_amd_pointer_info(dptr, &pd, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS ||
+        hsa_amd_pointer_info(hptr, &ph, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || pd.type == HSA_EXT_POINTER_TYPE_UNKNOWN ||
+        ph.type == HSA_EXT_POINTER_TYPE_UNKNOWN)
+      return false;
+    gpu = pd.agentOwner;
+    cpu = ph.agentOwner;
+    uint32_t avail = 0, pref = 0;
+    if (hsa_amd_memory_copy_engine_status(cpu, gpu, &avail) != HSA_STATUS_SUCCESS || !avail) return false;
+    (void)hsa_amd_memory_get_preferred_copy_engine(cpu, gpu, &pref);
+    uint32_t pick = pref & avail ? pref & avail : avail & 0xFu ? avail & 0xFu : avail; // (engines beyond the first four serve the xGMI links: 6-13 GB/s to the host)
+    engine[0] = pick & (0u - pick);
+    pick &= ~engine[0];
+    engine[1] = pick ? pick & (0u - pick) : engine[0];
+    ok = true;
+    return true;
+  }
+  // -> a signal that reaches 0 when the copy has landed; handle 0: not issued (the caller copies the HIP way)
+  hsa_signal_t copy(void *dst, const void *src, size_t bytes, bool two_engines) {
+    hsa_signal_t none{0};
+    if (!ok) return none;
+    if (next >= sigs.size()) {
+      hsa_signal_t sg;
+      if (hsa_signal_create(1, 0, nullptr, &sg) != HSA_STATUS_SUCCESS) return none;
+      sigs.push_back(sg);
+    }
+    const hsa_signal_t sg = sigs[next];
+    hsa_signal_store_relaxed(sg, 1);
+    if (hsa_amd_memory_async_copy_on_engine(dst, cpu, src, gpu, bytes, 0, nullptr, sg, (hsa_amd_sdma_engine_id_t)engine[two_engines ? next & 1 : 0], false) != HSA_STATUS_SUCCESS)
+      return none;
+    ++next;
+    return sg;
+  }
+  static bool wait(hsa_signal_t sg, bool spin) {
+    while (hsa_signal_wait_scacquire(sg, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, spin ? HSA_WAIT_STATE_ACTIVE : HSA_WAIT_STATE_BLOCKED) >= 1) {
+    }
+    return true;
+  }
+  void quiesce() { // every copy issued so far has landed (before its buffers are reused or freed)
+    for (unsigned k = 0; k < next && k < sigs.size(); ++k) wait(sigs[k], false);
+    next = 0;
+  }
+  void destroy() {
+    quiesce();
+    for (auto &sg : sigs) hsa_signal_destroy(sg);
+    sigs.clear();
+    if (tried && ok) hsa_shut_down();
+    ok = false;
+  }
+};
+
 } // namespace
 
 struct fgmm_ctx {
   int device = 0;
+  HsaCopier hsa;
   std::mutex mu; // one call at a time per context
   Pool *pool = nullptr;
   char *d_ws = nullptr;
@@ -164,7 +238,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, tab_place = 0, tab_spin = kTabSpinLimit;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, tab_place = 0, tab_spin = kTabSpinLimit, copy_engine = 0;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -225,6 +299,7 @@ struct fgmm_ctx {
   }
   std::vector<int32_t> h_sym; // decode: int32 symbols of every bitstream of a call (grown, kept)
   void trim() {
+    hsa.quiesce();
     std::vector<int32_t>().swap(h_sym);
     if (d_ws) (void)hipFree(d_ws);
     if (h_ws) (void)hipHostFree(h_ws);
@@ -646,6 +721,7 @@ struct DecItem {
   int n_piece = 1;
   TabPiece piece[kMaxPieces] = {};
   hipEvent_t piece_ev[kMaxPieces] = {}; // recorded (this call) before the item's job is submitted
+  hsa_signal_t piece_sig[kMaxPieces] = {}; // ... or, for a piece copied by an SDMA engine (HsaCopier), the signal of its copy (handle 0: the event)
   char *h_out = nullptr;                // pinned: decoded symbols (host-written, read by the scatter kernel)
   int wide = 0; // h_out holds int32 symbols (some symbol outside int16), else int16
   int64_t narrowed = 0; // symbols already converted to int16 in h_out (piece by piece)
@@ -1068,7 +1144,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   // look-back states of every launch, right behind the counters: zeroed with them in one memset
   for (auto &u : units) {
     for (auto &p : u.parts) u.scan_total += p.blk_end - p.blk_begin;
-    u.placement = ctx->opt.tab_place == 0 ? 1 : 0;
+    u.placement = ctx->opt.tab_place == 1 ? 1 : 0;
     u.o_scan = ar.take(sizeof(unsigned long long) * (size_t)std::max<int64_t>(u.scan_total, 1), 8);
   }
   const size_t zero_bytes = ar.off - o_counters;
@@ -1079,6 +1155,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   int64_t lat_total = 0;
   for (auto &it : items) lat_total += it.n;
   const bool spin = ctx->opt.spin_lat < 0 ? false : lat_total <= ctx->opt.spin_lat;
+  ctx->hsa.quiesce(); // (an earlier call that returned early may have left engine copies in flight: before any buffer moves)
   if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(upload_bytes + kCounterBytes * (size_t)std::max(n_units, 1))) ||
       (rc = ctx->ensure_events((spin ? 3 : 2) * (size_t)std::max(n_units, 1) + 2, (size_t)n_units + 2)) || (rc = ctx->ensure_stage(stage_total)))
     return rc;
@@ -1229,6 +1306,11 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
     return 0;
   };
+  // waits until piece p of the item is in host memory: the event of its copy, or the signal of the SDMA engine that copies it
+  auto landed = [spin](const DecItem &it, int p) {
+    if (it.piece_sig[p].handle) return HsaCopier::wait(it.piece_sig[p], spin);
+    return hipEventSynchronize(it.piece_ev[p]) == hipSuccess;
+  };
   // before / after a piece is decoded (no lock held)
   auto prepare = [&](DecItem &it, int p) {
     if (p == 0) {
@@ -1237,7 +1319,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       if (it.status == FGMM_OK) it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
     }
     const double tw0 = tr.level > 1 ? tr.ms() : 0;
-    if (it.status == FGMM_OK && hipEventSynchronize(it.piece_ev[p]) != hipSuccess) it.status = FGMM_ERR_HIP;
+    if (it.status == FGMM_OK && !landed(it, p)) it.status = FGMM_ERR_HIP;
     const double tw1 = tr.level > 1 ? tr.ms() : 0;
     it.t_waited += tw1 - tw0;
     it.t_lastland = tw1;
@@ -1277,7 +1359,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     const double tw0 = tr.level > 1 ? tr.ms() : 0;
     bool ok = !it.ckpt_bad.load(std::memory_order_relaxed);
     for (int p = p0; p <= p1 && ok; ++p)
-      if (hipEventSynchronize(it.piece_ev[p]) != hipSuccess) ok = false;
+      if (!landed(it, p)) ok = false;
     const double tw1 = tr.level > 1 ? tr.ms() : 0;
     if (ok) {
       TabDecoder td;
@@ -1312,7 +1394,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     if (it.ckpt_bad.load()) { // sequential decode of the whole bitstream (every piece is queued: the last segment needed the last one)
       it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
       for (int p = 0; p < it.n_piece && it.status == FGMM_OK; ++p) {
-        if (hipEventSynchronize(it.piece_ev[p]) != hipSuccess) it.status = FGMM_ERR_HIP;
+        if (!landed(it, p)) it.status = FGMM_ERR_HIP;
         else it.status = it.dec.piece(p);
       }
       const int rf = it.dec.finish();
@@ -1497,9 +1579,16 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     char *h_range = nullptr;
     if ((rc = ctx->chunk_alloc(un.fixed + used + 256, &h_range))) return rc;
     memset(h_range + un.fixed + used, 0, 256); // slack: the host's SIMD search reads a little past a row
-    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_kernel[u], 0));
-    if (un.fixed + used) HIP_TRY(hipMemcpyAsync(h_range, un.d_range, un.fixed + used, hipMemcpyDeviceToHost, ctx->copy_stream));
-    HIP_TRY(hipEventRecord(ev_landed[u], ctx->copy_stream));
+    // the unit's kernel is complete (its counters are here): the copy depends on nothing.  Straight to an SDMA engine
+    // (option copy_engine), or the runtime's way
+    hsa_signal_t sig{0};
+    if (ctx->opt.copy_engine >= 1 && un.fixed + used && ctx->hsa.init(un.d_range, h_range))
+      sig = ctx->hsa.copy(h_range, un.d_range, un.fixed + used, ctx->opt.copy_engine == 2);
+    if (!sig.handle) {
+      HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev_kernel[u], 0));
+      if (un.fixed + used) HIP_TRY(hipMemcpyAsync(h_range, un.d_range, un.fixed + used, hipMemcpyDeviceToHost, ctx->copy_stream));
+      HIP_TRY(hipEventRecord(ev_landed[u], ctx->copy_stream));
+    }
     for (auto &p : un.parts) {
       DecItem &it = items[p.item];
       TabPiece &pc = it.piece[p.piece];
@@ -1509,6 +1598,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       pc.rows_len = used + 256;
       pc.end = std::min<int64_t>(p.blk_end * it.tl, it.n);
       it.piece_ev[p.piece] = ev_landed[u];
+      it.piece_sig[p.piece] = sig;
       const int64_t lat = pc.end - std::min<int64_t>(p.blk_begin * it.tl, it.n);
       it.table_bytes += (uint64_t)it.hdr_form * (uint64_t)lat + sizeof(uint32_t) * (uint64_t)(p.blk_end - p.blk_begin);
       mark_queued(p.item, p.piece + 1); // pieces reach an item in order: rounds are piece-major
@@ -1650,10 +1740,14 @@ const OptName kOpts[] = {
     {"ckpt_decode", &fgmm_ctx::Opts::ckpt_decode, 0, 2, "FGMM_CKPT_DECODE"},
     {"spin_lat", &fgmm_ctx::Opts::spin_lat, -1, 1ll << 40, "FGMM_SPIN_LAT"},
     {"gpu_decode", &fgmm_ctx::Opts::gpu_decode, 0, 2, "FGMM_GPU_DECODE"},
-    // tab_kernel's placement of a block's rows: 0 = decoupled look-back (launch order, no same-address atomics), 1 = one atomic
-    // add per block on a cursor (round 1-3; also what a launch is re-run with should a look-back ever give up)
+    // tab_kernel's placement of a block's rows: 0 = one atomic add per block on a cursor (arrival order), 1 = decoupled look-back
+    // (launch order: deterministic tables, no same-address atomics - and a third slower: every block waits for all of its
+    // predecessors to arrive, profiles/r04_tab_place_sweep.txt; a launch in which a look-back gives up is re-run with the cursor)
     {"tab_place", &fgmm_ctx::Opts::tab_place, 0, 1, "FGMM_TAB_PLACE"},
     {"tab_spin", &fgmm_ctx::Opts::tab_spin, 0, 1 << 30, nullptr}, // look-back polls before giving up (tests set 0: every wait gives up)
+    // decode tables device -> pinned host: 0 = hipMemcpyAsync (shader copies on this runtime), 1 = straight to ONE SDMA engine,
+    // 2 = two engines in turn (measured slower in situ than the shader copies: profiles/r04_copy_engine.md)
+    {"copy_engine", &fgmm_ctx::Opts::copy_engine, 0, 2, "FGMM_COPY_ENGINE"},
 };
 } // namespace
 
@@ -1777,6 +1871,7 @@ void fgmm_ctx_destroy(fgmm_ctx *ctx) {
       for (auto e : pr)
         if (e) (void)hipEventDestroy(e);
     ctx->trim();
+    ctx->hsa.destroy();
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   }
@@ -2280,7 +2375,7 @@ int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const f
   hd->scan_total = nblk;
   hd->spin_limit = (int32_t)ctx->opt.tab_spin;
   unsigned long long cn[kTabCounters] = {};
-  for (int placement = ctx->opt.tab_place == 0 ? 1 : 0; placement >= 0; --placement) { // look-back; the cursor should a look-back give up
+  for (int placement = ctx->opt.tab_place == 1 ? 1 : 0; placement >= 0; --placement) { // look-back; the cursor should a look-back give up
     hd->placement = placement;
     HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(ctx->d_ws + 1024, 0, o_scan - 1024 + sizeof(unsigned long long) * (size_t)std::max<int64_t>(nblk, 1), s));

@@ -65,8 +65,9 @@ struct DecDesc {
                                  // host (only when count_edges; spread over slots: same-address atomics serialise chip-wide)
   int32_t count_edges;
   // placement of a block's rows in the launch's row area: 0 = ONE returning atomic add per block on counters[0] (blocks land
-  // in arrival order; the chip does ~38 of those per microsecond, which bounds the kernel up to 64 latents per block);
-  // 1 = decoupled look-back over `scan` (blocks land in launch order: deterministic tables, no same-address atomics)
+  // in arrival order; the chip does ~70 of those per microsecond: the kernel's bound only below 48 latents per block);
+  // 1 = decoupled look-back over `scan` (blocks land in launch order: deterministic tables, no same-address atomics; a block
+  // waits until every block ahead of it has been evaluated, which costs a third of the kernel's throughput)
   int32_t placement;
   unsigned long long *scan;      // [scan_total] per block of the LAUNCH, in launch order (part-major): state << 62 | bytes; 0 = not there
                                  // yet, 1 = the block's own bytes, 2 = bytes of all blocks up to and including it; zeroed by the host

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     const unsigned long long vmask = (1ull << 62) - 1ull;
     for (int64_t pos = scan_idx - 1;; pos -= 64) {
       const int64_t q = pos - lane;
-      unsigned long long v = 2ull << 62; // before the launch's first block: nothing
+      unsigned long long v = q >= 0 ? 0ull : 2ull << 62; // (before the launch's first block: a sum of nothing)
       int spins = 0;
       unsigned long long incl, missing;
       for (;;) {

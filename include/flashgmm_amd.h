@@ -106,6 +106,13 @@ int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, con
  *                       loses: it trades parallel workers for ILP
  *   "tab_cap_e"   [12288] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2));
  *                       at the default a call with a half-width that only fits 16384 edges (383 < max_bs <= 511) gets that
+ *   "tab_place"   [0]   single-pass table kernel: how a block finds its place in the launch's row area.  0 = one returning
+ *                       atomic add per block on a cursor (blocks lie in arrival order; ~70 of those per microsecond chip-wide:
+ *                       the bound only below 48 latents per block); 1 = decoupled look-back (every block publishes its bytes,
+ *                       a wave sums its predecessors': blocks lie in LAUNCH order - the tables of a call are the same bytes
+ *                       on every run - and nothing serialises on one address; a third slower, since a block cannot be placed
+ *                       before every block ahead of it has been evaluated).  A launch in which a look-back gives up
+ *                       ("tab_spin" polls, default 2^21: never seen) is re-run with the cursor
  *   "stage_max_mb" [0]  decode: cap of the device staging area for rows in MiB (0: a quarter of the free device memory).
  *                       A launch whose rows do not fit is re-run with the exact size its cursor reports.
  *   "ef_rows"     [0]   decode: 0 = Elias-Fano rows when min(host workers, bitstreams of the call) >= 10 (PCIe is the

@@ -1,0 +1,158 @@
+// Dev aid: device -> pinned-host copies through hipMemcpyAsync (which this runtime executes as blit
+// KERNELS on the CUs) against the same copies issued straight to an SDMA engine with hsa_amd_memory_async_copy_on_engine -
+// alone and beside a VALU-bound kernel, which is how the decode-side tables cross PCIe in a decode call.
+//   hipcc -O2 --offload-arch=gfx950 scripts/proto/sdma_copy.cpp -o scripts/bin/sdma_copy -lhsa-runtime64
+#include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+#define HSACHK(x) do { hsa_status_t s_ = (x); if (s_ != HSA_STATUS_SUCCESS) { const char *m_ = nullptr; hsa_status_string(s_, &m_); fprintf(stderr, "%s:%d hsa %d %s\n", __FILE__, __LINE__, (int)s_, m_ ? m_ : ""); exit(1); } } while (0)
+
+__global__ void busy_kernel(float *out, int iters) { // VALU-bound, every CU: what tab_kernel is to the copies
+  float a = threadIdx.x * 1e-3f, b = 1.0001f, c = 0.5f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a = __builtin_fmaf(a, b, c);
+  }
+  if (a == 12345.678f) out[blockIdx.x] = a;
+}
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv) {
+  const size_t MB = (argc > 1 ? atoi(argv[1]) : 24) * (size_t)1 << 20; // one copy (a decode call's pieces are 4 - 40 MB)
+  const int reps = argc > 2 ? atoi(argv[2]) : 16;
+  HIPCHK(hipSetDevice(0));
+  char *d = nullptr, *h = nullptr;
+  HIPCHK(hipMalloc(&d, MB * reps));
+  HIPCHK(hipHostMalloc(&h, MB * reps, hipHostMallocDefault));
+  HIPCHK(hipMemset(d, 1, MB * reps));
+  memset(h, 0, MB * reps);
+  float *dout = nullptr;
+  HIPCHK(hipMalloc(&dout, 1 << 20));
+  hipStream_t s_copy, s_k;
+  HIPCHK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
+  hipEvent_t k0, k1;
+  HIPCHK(hipEventCreate(&k0));
+  HIPCHK(hipEventCreate(&k1));
+
+  // HSA: the agents that own the two buffers, the engines between them
+  HSACHK(hsa_init());
+  hsa_amd_pointer_info_t pi_d, pi_h;
+  pi_d.size = sizeof pi_d;
+  pi_h.size = sizeof pi_h;
+  HSACHK(hsa_amd_pointer_info(d, &pi_d, nullptr, nullptr, nullptr));
+  HSACHK(hsa_amd_pointer_info(h, &pi_h, nullptr, nullptr, nullptr));
+  const hsa_agent_t gpu = pi_d.agentOwner, cpu = pi_h.agentOwner;
+  uint32_t mask = 0, pref = 0;
+  hsa_status_t st = hsa_amd_memory_copy_engine_status(cpu, gpu, &mask);
+  hsa_amd_memory_get_preferred_copy_engine(cpu, gpu, &pref);
+  printf("buffers: device type %d, host type %d; SDMA engines gpu->cpu: status %d mask 0x%x preferred 0x%x\n", (int)pi_d.type, (int)pi_h.type, (int)st, mask, pref);
+  hsa_signal_t sig;
+  HSACHK(hsa_signal_create(1, 0, nullptr, &sig));
+
+  auto run_busy = [&](int iters) {
+    HIPCHK(hipEventRecord(k0, s_k));
+    hipLaunchKernelGGL(busy_kernel, dim3(256 * 8), dim3(256), 0, s_k, dout, iters);
+    HIPCHK(hipEventRecord(k1, s_k));
+  };
+  // calibrate the busy kernel to ~ the duration of the copies (MB * reps at ~55 GB/s)
+  int iters = 20000;
+  run_busy(iters);
+  HIPCHK(hipStreamSynchronize(s_k));
+  float kms = 0;
+  HIPCHK(hipEventElapsedTime(&kms, k0, k1));
+  const double want_ms = (double)MB * reps / 55e6;
+  iters = (int)(iters * want_ms / kms);
+  run_busy(iters);
+  HIPCHK(hipStreamSynchronize(s_k));
+  HIPCHK(hipEventElapsedTime(&kms, k0, k1));
+  printf("busy kernel alone: %.3f ms (%d iterations); copies: %d x %zu MB\n", kms, iters, reps, MB >> 20);
+
+  auto hip_copies = [&]() {
+    const double t0 = now_ms();
+    for (int r = 0; r < reps; ++r) HIPCHK(hipMemcpyAsync(h + r * MB, d + r * MB, MB, hipMemcpyDeviceToHost, s_copy));
+    HIPCHK(hipStreamSynchronize(s_copy));
+    return now_ms() - t0;
+  };
+  auto hsa_copies = [&](uint32_t engine, int in_flight) { // engine 0: hsa_amd_memory_async_copy (the runtime's choice)
+    std::vector<hsa_signal_t> sigs((size_t)reps);
+    for (auto &sg : sigs) HSACHK(hsa_signal_create(1, 0, nullptr, &sg));
+    const double t0 = now_ms();
+    for (int r = 0; r < reps; ++r) {
+      if (r >= in_flight) while (hsa_signal_wait_scacquire(sigs[(size_t)(r - in_flight)], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+      if (engine) HSACHK(hsa_amd_memory_async_copy_on_engine(h + r * MB, cpu, d + r * MB, gpu, MB, 0, nullptr, sigs[(size_t)r], (hsa_amd_sdma_engine_id_t)engine, false));
+      else HSACHK(hsa_amd_memory_async_copy(h + r * MB, cpu, d + r * MB, gpu, MB, 0, nullptr, sigs[(size_t)r]));
+    }
+    for (int r = 0; r < reps; ++r) while (hsa_signal_wait_scacquire(sigs[(size_t)r], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+    const double dt = now_ms() - t0;
+    for (auto &sg : sigs) hsa_signal_destroy(sg);
+    return dt;
+  };
+  auto check = [&]() {
+    for (size_t i = 0; i < MB * reps; i += 4097) if (h[i] != 1) { printf("  DATA MISMATCH at %zu\n", i); return; }
+    memset(h, 0, MB * reps);
+  };
+  auto report = [&](const char *name, double ms, float k_ms) {
+    printf("%-44s %8.3f ms = %6.1f GB/s", name, ms, (double)MB * reps / ms / 1e6);
+    if (k_ms > 0) printf("   busy kernel beside it %.3f ms (alone %.3f)", k_ms, kms);
+    printf("\n");
+  };
+  for (int beside = 0; beside < 2; ++beside) {
+    printf(beside ? "---- beside the busy kernel\n" : "---- alone\n");
+    auto with = [&](auto f) {
+      float k = 0;
+      if (beside) run_busy(iters);
+      const double ms = f();
+      if (beside) {
+        HIPCHK(hipStreamSynchronize(s_k));
+        HIPCHK(hipEventElapsedTime(&k, k0, k1));
+      }
+      check();
+      return std::make_pair(ms, k);
+    };
+    for (int rep = 0; rep < 2; ++rep) {
+      auto a = with([&] { return hip_copies(); });
+      report("hipMemcpyAsync D2H", a.first, a.second);
+    }
+    auto b = with([&] { return hsa_copies(0, reps); });
+    report("hsa_amd_memory_async_copy", b.first, b.second);
+    for (uint32_t e = 1; e && e <= mask; e <<= 1) {
+      if (!(mask & e)) continue;
+      char nm[64];
+      snprintf(nm, sizeof nm, "hsa ..._on_engine 0x%x, all queued", e);
+      auto c = with([&] { return hsa_copies(e, reps); });
+      report(nm, c.first, c.second);
+    }
+    if (pref) {
+      // two engines in turn
+      uint32_t e1 = pref & (0u - pref), rest = pref & ~e1, e2 = rest ? rest & (0u - rest) : e1;
+      auto two = [&]() {
+        std::vector<hsa_signal_t> sigs((size_t)reps);
+        for (auto &sg : sigs) HSACHK(hsa_signal_create(1, 0, nullptr, &sg));
+        const double t0 = now_ms();
+        for (int r = 0; r < reps; ++r)
+          HSACHK(hsa_amd_memory_async_copy_on_engine(h + r * MB, cpu, d + r * MB, gpu, MB, 0, nullptr, sigs[(size_t)r], (hsa_amd_sdma_engine_id_t)(r & 1 ? e2 : e1), false));
+        for (int r = 0; r < reps; ++r) while (hsa_signal_wait_scacquire(sigs[(size_t)r], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+        const double dt = now_ms() - t0;
+        for (auto &sg : sigs) hsa_signal_destroy(sg);
+        return dt;
+      };
+      auto c = with(two);
+      char nm[64];
+      snprintf(nm, sizeof nm, "hsa ..._on_engine 0x%x / 0x%x in turn", e1, e2);
+      report(nm, c.first, c.second);
+    }
+  }
+  hsa_signal_destroy(sig);
+  hsa_shut_down();
+  return 0;
+}

@@ -1349,3 +1349,49 @@ def test_bench_two_ranks_rehearsed_on_one_device():
     assert d["ms_per_step"] == max(rk["ms_per_step"]) and d["value"] > 0
     assert d["upper_bound"]["value"] > 0 and d["checkpointed"]["value"] > 0 and d["checkpointed"]["bitstreams_handed_back_last_call"] == 0
     assert "latency_ms" not in d and "modes" not in d  # (N = 1 legs)
+
+
+def test_table_kernel_placements_agree_and_look_back_is_deterministic(oracle, ctx_options):
+    """tab_kernel places a block's rows by one atomic add per block on a cursor (option tab_place 0, the default: arrival order),
+    or by decoupled look-back (1: launch order, no same-address atomics; a third slower) - and should a look-back ever give up,
+    the host re-runs the launch with the cursor (forced here: tab_spin 0 makes every wait give up).  All three give the
+    oracle's table; look-back gives the SAME bytes and block offsets on every run, with blocks in launch order; the batched
+    decoder decodes through each."""
+    y, sg, mu, pi = T.make_latent(35, M=64, h=16, w=12)
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    max_bs = abs_max + 1
+    want = oracle.cdftab("polya", s, m, w, max_bs)
+    stalls0 = _lib.ctx_stat(0, 6)
+    ctx_options(tab_place=1)
+    h0, bo0, rows0, u0, tl = gpu_tab("polya", s, m, w, max_bs)
+    assert np.array_equal(expand_trimmed(h0, rows0, max_bs, bo0, tl), want)
+    assert len(bo0) > 50 and np.all(np.diff(bo0.astype(np.int64)) > 0) and bo0[0] == 0  # launch order: offsets ascend
+    for _ in range(3):
+        h1, bo1, rows1, u1, _ = gpu_tab("polya", s, m, w, max_bs)
+        assert u1 == u0 and np.array_equal(bo1, bo0) and np.array_equal(rows1[:u0], rows0[:u0]) and np.array_equal(h1, h0)
+    assert _lib.ctx_stat(0, 6) == stalls0
+
+    def sizes(bo, used):  # bytes of every block, from the offsets of blocks placed in any order
+        o = np.sort(bo.astype(np.int64)) * 4
+        return np.sort(np.diff(np.append(o, used)))
+
+    ctx_options(tab_place=0)
+    hc, boc, rowsc, uc, _ = gpu_tab("polya", s, m, w, max_bs)
+    assert uc == u0 and np.array_equal(hc, h0) and np.array_equal(expand_trimmed(hc, rowsc, max_bs, boc, tl), want)
+    assert np.array_equal(sizes(boc, uc), sizes(bo0, u0))  # the same blocks, in arrival order
+    ctx_options(tab_place=1, tab_spin=0)
+    hs, bos, rowss, us, _ = gpu_tab("polya", s, m, w, max_bs)
+    assert us == u0 and np.array_equal(expand_trimmed(hs, rowss, max_bs, bos, tl), want)
+    stalled = _lib.ctx_stat(0, 6) - stalls0
+    # batched decode of a few bitstreams through each placement (tab_spin 0: launches whose look-backs give up are re-run)
+    lat = [T.make_latent(360 + i, M=M, h=h_, w=w_, zero_frac=0.1) for i, (M, h_, w_) in enumerate([(192, 32, 24), (48, 16, 8), (96, 32, 24)])]
+    dev = [[dv(a) for a in l] for l in lat]
+    ys, ss, ms, ws = ([d[k] for d in dev] for k in range(4))
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    res = gmc.compress_batch(ys, ss, ms, ws)
+    args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+    for place, spin in ((1, 0), (0, 1 << 21), (1, 1 << 21)):
+        ctx_options(tab_place=place, tab_spin=spin)
+        out = gmc.decompress_batch(*args)
+        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), (place, spin)
+    assert _lib.ctx_stat(0, 6) - stalls0 >= stalled  # (how many launches gave up is the hardware's business; the results are not)
