@@ -713,7 +713,7 @@ struct DecItem {
   int64_t n = 0;
   size_t o_list = 0, o_rank = 0;
   int hdr_form = 4;
-  uint32_t ef_min = kTabEfMin, d2_min = kTabNoD2;
+  uint32_t ef_min = kTabEfMin;
   int32_t tl = 0;     // latents per block of the single-pass kernel; 0: generic two-pass path
   int64_t nblk = 0;   // blocks of tl latents
   uint64_t table_bytes = 0; // headers + block offsets + rows that crossed PCIe
@@ -1315,7 +1315,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   auto prepare = [&](DecItem &it, int p) {
     if (p == 0) {
       it.t_taken = tr.ms();
-      it.view = TabView{it.ef_min, it.d2_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
+      it.view = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
       if (it.status == FGMM_OK) it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
     }
     const double tw0 = tr.level > 1 ? tr.ms() : 0;
@@ -1539,7 +1539,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   }
 
   for (auto &it : items)
-    if (it.n_seg) it.view = TabView{it.ef_min, it.d2_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
+    if (it.n_seg) it.view = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
   // (a single bitstream too: its decoder starts on piece 0 while this thread is still queuing the later pieces' copies)
   const int n_workers = (int)std::min<int64_t>(std::max(ctx->pool->size(), 1), streams_of_work);
   for (int j = 0; j < n_workers; ++j) ctx->pool->submit(worker);

@@ -289,19 +289,6 @@ struct Dec {
     if (xx < kRansL) xx = (xx << 32) | next_word();
     x = xx;
   }
-  // the same without a branch on the coder state (the renormalisation test is data: taken for one symbol in ten on Kodak-like
-  // latents, at no learnable rhythm): the next word is loaded whether it is needed or not - from a zero word when the stream
-  // has run out, which `underrun` remembers
-  inline void advance_nb(uint32_t start, uint32_t freq) {
-    const uint64_t xx = (uint64_t)freq * (x >> kPrec) + (x & 0xFFFFu) - start;
-    static const uint32_t zero_word = 0;
-    const bool have = ptr < end;
-    const uint32_t w = *(have ? ptr : &zero_word);
-    const bool need = xx < kRansL;
-    x = need ? (xx << 32) | w : xx;
-    underrun |= need & !have;
-    ptr += need & have;
-  }
   inline uint32_t get_bits() { // Rans64DecGetBits(4)
     const uint32_t val = (uint32_t)(x & kMaxBypassVal);
     uint64_t xx = x >> kBypassBits;
@@ -384,40 +371,6 @@ __attribute__((target("avx2"))) inline int32_t upper_bound_u16(const uint16_t *r
   }
   return cnt;
 }
-
-// Number of entries <= cf of a non-decreasing row of 1 .. 256 entries, with NO branch on cf: every 16-entry vector of the row
-// is compared (the trip count is the row's length, known from its header long before the coder state is), the entries
-// beyond the row are masked out.  The early-exit form above leaves the loop at a vector that depends on cf - the one value
-// the whole dependency chain of the decoder runs through - and mispredicts every other symbol on rows of 17 entries and
-// more.  Reads up to 30 bytes past the row.
-#ifndef FGMM_DEC_RAW
-#define FGMM_DEC_RAW 1 // A/B builds: 0 = the early-exit search (rounds 1-3), 1 = straight-line AVX2, 2 = straight-line AVX-512BW (build with -mavx512bw -mavx512vl)
-#endif
-#if FGMM_DEC_RAW == 2
-inline int32_t count_le_u16(const uint16_t *row, int32_t cnt, uint32_t cf) {
-  const __m512i key = _mm512_set1_epi16((short)cf);
-  uint32_t n_le = 0;
-  for (int32_t k = 0; k < cnt; k += 32) {
-    const int32_t left = cnt - k;
-    const __mmask32 valid = left >= 32 ? ~(__mmask32)0 : (__mmask32)_bzhi_u32(~0u, (uint32_t)left);
-    n_le += (uint32_t)_mm_popcnt_u32((uint32_t)_mm512_mask_cmple_epu16_mask(valid, _mm512_maskz_loadu_epi16(valid, row + k), key));
-  }
-  return (int32_t)n_le;
-}
-#else
-__attribute__((target("avx2,bmi2,popcnt"))) inline int32_t count_le_u16(const uint16_t *row, int32_t cnt, uint32_t cf) {
-  const __m256i bias = _mm256_set1_epi16((short)0x8000);
-  const __m256i key = _mm256_set1_epi16((short)(cf ^ 0x8000u));
-  uint32_t n_gt2 = 0; // twice the entries > cf
-  for (int32_t k = 0; k < cnt; k += 16) {
-    const __m256i v = _mm256_xor_si256(_mm256_loadu_si256((const __m256i *)(row + k)), bias);
-    const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi16(v, key));
-    const int32_t left = cnt - k;
-    n_gt2 += (uint32_t)_mm_popcnt_u32(_bzhi_u32(m, (uint32_t)(left < 16 ? 2 * left : 32))); // (bzhi takes its index modulo 256)
-  }
-  return cnt - (int32_t)(n_gt2 >> 1);
-}
-#endif
 
 // ---- Elias-Fano rows (format v5): one bit string: HB = cnt + (65536 >> l) bits of unary high parts (bit (E_j >> l) + j
 // set for entry j), then, from the next byte boundary LB on, the low l bits of every entry.  Bucket b (the entries whose
@@ -621,143 +574,6 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow 
   return 1;
 }
 
-// ---- second-difference rows (format v6, fgmm_internal.h) ------------------------------------------------------------
-// which expansion this host runs (FGMM_D2_ISA=sse forces the 128-bit one: A/B, tests)
-static const bool g_d2_avx512 = [] {
-  const char *e = getenv("FGMM_D2_ISA");
-  if (e && !strcmp(e, "sse")) return false;
-  return __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("bmi2");
-}();
-// bytes of a D2 row whose first byte is p (cnt entries); 0 when the row does not fit [p, end)
-inline size_t d2_row_bytes(const uint8_t *p, const uint8_t *end, uint32_t cnt) {
-  const uint32_t ng = tab_d2_groups(cnt);
-  size_t bytes = 4 + ((size_t)ng + 1) / 2;
-  if ((size_t)(end - p) < bytes) return 0;
-  const uint8_t *nib = p + 4;
-  for (uint32_t g = 0; g < ng; ++g) bytes += tab_d2_width((nib[g >> 1] >> (4 * (g & 1))) & 15u);
-  bytes = (bytes + 1) & ~(size_t)1;
-  return (size_t)(end - p) < bytes ? 0 : bytes;
-}
-// Expands a D2 row into uint16 entries out[0 .. cnt) (out holds cnt rounded up to 8, + 16 of slack for the search): per group of
-// 8 slots one pdep (two beyond 8 bits) spreads the w-bit fields into lanes, two prefix sums (second differences -> first
-// differences -> entries) run in 16-bit lanes modulo 2^16 - exact, every true entry is below 2^16.  Nothing here depends on the
-// coder state: the out-of-order core runs it ahead of the state's dependency chain.  Reads up to 16 bytes past the row
-// (inside the row area's slack).  -> bytes of the row, 0: malformed / does not fit [p, end).
-__attribute__((target("avx2,bmi2,sse4.1,ssse3"))) inline size_t d2_expand(const uint8_t *p, const uint8_t *end, uint32_t cnt, uint16_t *out) {
-  static const uint64_t kMask16[17] = {0, 0x0001000100010001ull, 0x0003000300030003ull, 0x0007000700070007ull, 0x000F000F000F000Full, 0x001F001F001F001Full,
-                                       0x003F003F003F003Full, 0x007F007F007F007Full, 0x00FF00FF00FF00FFull, 0x01FF01FF01FF01FFull, 0x03FF03FF03FF03FFull, 0x07FF07FF07FF07FFull, 0x0FFF0FFF0FFF0FFFull,
-                                       0x1FFF1FFF1FFF1FFFull, 0x3FFF3FFF3FFF3FFFull, 0x7FFF7FFF7FFF7FFFull, 0xFFFFFFFFFFFFFFFFull};
-  const uint32_t ng = tab_d2_groups(cnt);
-  const size_t fixed = 4 + ((size_t)ng + 1) / 2;
-  if ((size_t)(end - p) < fixed + 16) return 0;
-  uint16_t e0, s0;
-  memcpy(&e0, p, 2);
-  memcpy(&s0, p + 2, 2);
-  const uint8_t *nib = p + 4, *pay = p + fixed;
-  const __m128i last = _mm_set1_epi16(0x0F0E); // byte shuffle: lane 7 to every lane
-  const __m128i one = _mm_set1_epi16(1), zero = _mm_setzero_si128();
-  __m128i d1_prev = zero, e_prev = zero;
-  // slots 0 and 1 are empty: E[0] and E[1] - 2 E[0] there make the two sums yield E[0], E[1]
-  uint32_t seed = (uint32_t)e0 | ((uint32_t)(uint16_t)(s0 - e0) << 16);
-  for (uint32_t g = 0; g < ng; ++g) {
-    const uint32_t c = (nib[g >> 1] >> (4 * (g & 1))) & 15u, w = tab_d2_width(c);
-    if (__builtin_expect((size_t)(end - pay) < (size_t)w + 16, 0)) return 0;
-    // no branch on the width (it changes from group to group at no learnable rhythm): four w-bit fields per pdep, whatever w is
-    uint64_t q0, q1;
-    memcpy(&q0, pay, 8);
-    memcpy(&q1, pay + ((4 * w) >> 3), 8);
-    q1 >>= (4 * w) & 7u;
-    const uint64_t m16 = kMask16[w];
-    __m128i v = _mm_set_epi64x((long long)_pdep_u64(q1, m16), (long long)_pdep_u64(q0, m16));
-    // zigzag (z >> 1) ^ -(z & 1) - or, code 15, the field as it is
-    const __m128i zz = _mm_xor_si128(_mm_srli_epi16(v, 1), _mm_sub_epi16(zero, _mm_and_si128(v, one)));
-    v = _mm_blendv_epi8(zz, v, _mm_set1_epi16((short)(c == 15u ? -1 : 0)));
-    v = _mm_or_si128(v, _mm_cvtsi32_si128((int)seed));
-    seed = 0;
-    // second differences -> first differences -> entries: two inclusive prefix sums over 8 lanes + what the groups before left
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 2));
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 4));
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 8));
-    v = _mm_add_epi16(v, d1_prev);
-    d1_prev = _mm_shuffle_epi8(v, last);
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 2));
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 4));
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 8));
-    v = _mm_add_epi16(v, e_prev);
-    e_prev = _mm_shuffle_epi8(v, last);
-    _mm_storeu_si128((__m128i *)(out + 8 * g), v);
-    pay += w;
-  }
-  return ((size_t)(pay - p) + 1) & ~(size_t)1;
-}
-
-#define FGMM_T512 __attribute__((target("avx512f,avx512bw,avx512vl,avx512dq,bmi2")))
-// inclusive prefix sum over 32 uint16 lanes + carry (all of its lanes equal): in-lane shifts, then the totals of the four
-// 128-bit lanes carried across
-FGMM_T512 static inline __m512i d2_scan32(__m512i v, __m512i carry) {
-  const __m512i zero = _mm512_setzero_si512();
-  v = _mm512_add_epi16(v, _mm512_bslli_epi128(v, 2));
-  v = _mm512_add_epi16(v, _mm512_bslli_epi128(v, 4));
-  v = _mm512_add_epi16(v, _mm512_bslli_epi128(v, 8));
-  __m512i t = _mm512_shuffle_epi8(v, _mm512_set1_epi16(0x0F0E)); // every 128-bit lane: its total
-  t = _mm512_add_epi16(t, _mm512_alignr_epi64(t, zero, 6));       // + the lane below
-  t = _mm512_add_epi16(t, _mm512_alignr_epi64(t, zero, 4));       // + the two below that: inclusive over the four lanes
-  return _mm512_add_epi16(_mm512_add_epi16(v, _mm512_alignr_epi64(t, zero, 6)), carry); // + the lanes below, + what came before
-}
-FGMM_T512 static inline long long d2_half(const uint8_t *q, uint32_t w, int hi, uint64_t m16) { // four w-bit fields -> four uint16
-  uint64_t x;
-  memcpy(&x, q + (hi ? (4 * w) >> 3 : 0), 8);
-  if (hi) x >>= (4 * w) & 7u;
-  return (long long)_pdep_u64(x, m16);
-}
-// The same with AVX-512BW: 32 slots (four groups) per step - the two prefix sums run over 32 lanes (in-lane shifts, then the
-// totals of the four 128-bit lanes carried across), a third of the instructions per slot.
-FGMM_T512 size_t d2_expand_avx512(const uint8_t *p, const uint8_t *end, uint32_t cnt, uint16_t *out) {
-  static const uint64_t kMask16[17] = {0, 0x0001000100010001ull, 0x0003000300030003ull, 0x0007000700070007ull, 0x000F000F000F000Full, 0x001F001F001F001Full,
-                                       0x003F003F003F003Full, 0x007F007F007F007Full, 0x00FF00FF00FF00FFull, 0x01FF01FF01FF01FFull, 0x03FF03FF03FF03FFull,
-                                       0x07FF07FF07FF07FFull, 0x0FFF0FFF0FFF0FFFull, 0x1FFF1FFF1FFF1FFFull, 0x3FFF3FFF3FFF3FFFull, 0x7FFF7FFF7FFF7FFFull,
-                                       0xFFFFFFFFFFFFFFFFull};
-  const uint32_t ng = tab_d2_groups(cnt);
-  const size_t fixed = 4 + ((size_t)ng + 1) / 2;
-  if ((size_t)(end - p) < fixed + 16) return 0;
-  uint16_t e0, s0;
-  memcpy(&e0, p, 2);
-  memcpy(&s0, p + 2, 2);
-  const uint8_t *nib = p + 4, *pay = p + fixed;
-  const __m512i one = _mm512_set1_epi16(1), zero = _mm512_setzero_si512();
-  const __m512i last_of_all = _mm512_set1_epi16(31); // vpermw index: the last of the 32 lanes
-  __m512i d1_prev = zero, e_prev = zero;
-  __m512i seed = _mm512_zextsi128_si512(_mm_cvtsi32_si128((int)((uint32_t)e0 | ((uint32_t)(uint16_t)(s0 - e0) << 16))));
-  for (uint32_t g = 0; g < ng; g += 4) {
-    // the width codes of four groups: two bytes of nibbles (the byte after the last group's is inside the row or its slack)
-    uint32_t nb;
-    memcpy(&nb, nib + (g >> 1), 2);
-    nb &= 0xFFFFu;
-    if (g + 4 > ng) nb &= (1u << (4 * (ng - g))) - 1u; // groups beyond the row: width 0, nothing read
-    const uint32_t c0 = nb & 15u, c1 = (nb >> 4) & 15u, c2 = (nb >> 8) & 15u, c3 = nb >> 12;
-    const uint32_t w0 = tab_d2_width(c0), w1 = tab_d2_width(c1), w2 = tab_d2_width(c2), w3 = tab_d2_width(c3);
-    if (__builtin_expect((size_t)(end - pay) < (size_t)(w0 + w1 + w2 + w3) + 16, 0)) return 0;
-    const uint8_t *p0 = pay, *p1 = p0 + w0, *p2 = p1 + w1, *p3 = p2 + w2;
-    const uint64_t m0 = kMask16[w0], m1 = kMask16[w1], m2 = kMask16[w2], m3 = kMask16[w3];
-    const __m128i x0 = _mm_set_epi64x(d2_half(p0, w0, 1, m0), d2_half(p0, w0, 0, m0)), x1 = _mm_set_epi64x(d2_half(p1, w1, 1, m1), d2_half(p1, w1, 0, m1));
-    const __m128i x2 = _mm_set_epi64x(d2_half(p2, w2, 1, m2), d2_half(p2, w2, 0, m2)), x3 = _mm_set_epi64x(d2_half(p3, w3, 1, m3), d2_half(p3, w3, 0, m3));
-    __m512i v = _mm512_inserti64x4(_mm512_castsi256_si512(_mm256_set_m128i(x1, x0)), _mm256_set_m128i(x3, x2), 1);
-    // zigzag (z >> 1) ^ -(z & 1), except in groups of code 15 (the 16-bit field as it is): mask of their 8-lane groups
-    const __mmask32 raw = (__mmask32)((c0 == 15u ? 0xFFu : 0u) | (c1 == 15u ? 0xFF00u : 0u) | (c2 == 15u ? 0xFF0000u : 0u) | (c3 == 15u ? 0xFF000000u : 0u));
-    const __m512i zz = _mm512_xor_si512(_mm512_srli_epi16(v, 1), _mm512_sub_epi16(zero, _mm512_and_si512(v, one)));
-    v = _mm512_mask_mov_epi16(zz, raw, v);
-    v = _mm512_or_si512(v, seed);
-    seed = zero;
-    v = d2_scan32(v, d1_prev);
-    d1_prev = _mm512_permutexvar_epi16(last_of_all, v);
-    v = d2_scan32(v, e_prev);
-    e_prev = _mm512_permutexvar_epi16(last_of_all, v);
-    _mm512_storeu_si512((void *)(out + 8 * g), v);
-    pay = p3 + w3;
-  }
-  return ((size_t)(pay - p) + 1) & ~(size_t)1;
-}
-
 } // namespace
 
 // The decoder proper, resumable piece by piece (a host worker may follow several bitstreams as their tables land):
@@ -809,9 +625,8 @@ struct PieceRun {
   const uint8_t *rowp = nullptr, *rows_end = nullptr;
   int32_t max_bs = 0;
   int hdr_form = 4;
-  uint32_t ef_min = kTabEfMin, d2_min = kTabNoD2;
+  uint32_t ef_min = kTabEfMin;
   int rc = FGMM_OK;
-  alignas(64) uint16_t d2buf[kTabD2MaxCnt + 32 + 32]; // a second-difference row, expanded (+ what the search reads past it)
 
   // false: nothing to do (rc says whether that is an error)
   bool begin(TabDecoder &d, int k) {
@@ -834,7 +649,6 @@ struct PieceRun {
     W = 2 * (int64_t)max_bs + 2;
     hdr_form = d.tv->hdr_form;
     ef_min = d.tv->ef_min;
-    d2_min = d.tv->d2_min;
     // a search may read up to 32 bytes past its row: rows must end that far before the end of the area
     rows_end = pc->rows + (pc->rows_len >= 32 ? pc->rows_len - 32 : 0);
     rowp = pc->rows; // sequential placement: a running sum, never stored
@@ -865,7 +679,6 @@ struct PieceRun {
     W = 2 * (int64_t)max_bs + 2;
     hdr_form = d.tv->hdr_form;
     ef_min = d.tv->ef_min;
-    d2_min = d.tv->d2_min;
     rows_end = pc->rows + (pc->rows_len >= 32 ? pc->rows_len - 32 : 0);
     tl = d.tv->tl;
     blk = (d.i - i_beg) / tl;
@@ -901,15 +714,8 @@ struct PieceRun {
       cnt = (int64_t)((h >> 32) & 0x7FFFFFFFu);
       nonmono = (uint32_t)(h >> 63);
     }
-    if (cnt < 1) { rc = FGMM_ERR_INVALID; return; }
-    uint64_t rbytes;
-    if (tab_row_is_d2((uint32_t)cnt, nonmono, d2_min)) {
-      rbytes = d2_row_bytes(rowp, rows_end, (uint32_t)cnt);
-      if (!rbytes) { rc = FGMM_ERR_INVALID; return; }
-    } else {
-      rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
-    }
-    if ((uint64_t)(rows_end - rowp) < rbytes) { rc = FGMM_ERR_INVALID; return; }
+    const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
+    if (cnt < 1 || (uint64_t)(rows_end - rowp) < rbytes) { rc = FGMM_ERR_INVALID; return; }
     rowp += rbytes;
     ++i;
   }
@@ -979,21 +785,12 @@ struct PieceRun {
     }
     // a row covers indices [a + max_bs, a + max_bs + cnt) of the W-entry virtual table
     if (__builtin_expect(cnt < 1 || a < -(int64_t)max_bs || a + max_bs + cnt > W, 0)) { rc = FGMM_ERR_INVALID; return; }
-    const bool is_d2 = tab_row_is_d2((uint32_t)cnt, nonmono, d2_min);
-    const bool is_ef = !is_d2 && tab_row_is_ef((uint32_t)cnt, nonmono, ef_min);
+    const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono, ef_min);
+    const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
+    if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; return; }
     const bool zero_before = a > -(int64_t)max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
     const uint8_t *row_bytes = rowp;
-    if (is_d2) { // expanded here, before the coder state is looked at: the search below sees plain uint16 entries
-      if (__builtin_expect(rows_end - rowp < 6, 0)) { rc = FGMM_ERR_INVALID; return; }
-      const size_t used = g_d2_avx512 ? d2_expand_avx512(rowp, rows_end + 32, (uint32_t)cnt, d2buf) : d2_expand(rowp, rows_end + 32, (uint32_t)cnt, d2buf);
-      if (__builtin_expect(!used || (uint64_t)(rows_end - rowp) < used, 0)) { rc = FGMM_ERR_INVALID; return; }
-      rowp += used;
-      row_bytes = reinterpret_cast<const uint8_t *>(d2buf);
-    } else {
-      const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
-      if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; return; }
-      rowp += rbytes;
-    }
+    rowp += rbytes;
 
     const uint32_t cf = (uint32_t)(dec.x & 0xFFFFu); // Rans64DecGet
     int32_t value;
@@ -1005,30 +802,17 @@ struct PieceRun {
       if (!is_ef) {
         const uint16_t *row = reinterpret_cast<const uint16_t *>(row_bytes);
         if (__builtin_expect(!nonmono, 1)) {
-          if (__builtin_expect(FGMM_DEC_RAW != 0 && cnt <= 256, 1)) {
-            // straight-line from cf to (start, freq): count, then ONE load of the pair (row[j-1], row[j]) - for j = 0 the pair
-            // (row[0], row[1]) shifted up by an entry: the implied zero edge below the row
-            const int32_t j = count_le_u16(row, (int32_t)cnt, cf);
-            uint32_t pair;
-            memcpy(&pair, row + (j > 0 ? j - 1 : 0), 4);
-            pair = j > 0 ? pair : pair << 16;
-            start = pair & 0xFFFFu;
-            freq = ((pair >> 16) - start) & 0xFFFFu;
+          const int32_t j = upper_bound_u16(row, (int32_t)cnt, cf);
+          if (__builtin_expect(j >= 1 && j < cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
+            start = row[j - 1];
+            freq = (uint32_t)(row[j] - start) & 0xFFFFu;
             value = (int32_t)(a + j - 1);
-            done = (j >= 1 || zero_before) && j < cnt; // else: no entry pair brackets cf (never in a stream its encoder wrote)
-          } else {
-            const int32_t j = upper_bound_u16(row, (int32_t)cnt, cf);
-            if (__builtin_expect(j >= 1 && j < cnt, 1)) { // row[j-1] <= cf < row[j]: the unique bracket
-              start = row[j - 1];
-              freq = (uint32_t)(row[j] - start) & 0xFFFFu;
-              value = (int32_t)(a + j - 1);
-              done = true;
-            } else if (j == 0 && zero_before) { // 0 <= cf < row[0]: the symbol whose lower edge is the implied zero
-              start = 0;
-              freq = row[0];
-              value = (int32_t)(a - 1);
-              done = true;
-            }
+            done = true;
+          } else if (j == 0 && zero_before) { // 0 <= cf < row[0]: the symbol whose lower edge is the implied zero
+            start = 0;
+            freq = row[0];
+            value = (int32_t)(a - 1);
+            done = true;
           }
         }
         if (!done) value = bisect_reference(Row{row, (int32_t)a, (int32_t)cnt}, cf, max_bs, &start, &freq);
@@ -1048,7 +832,7 @@ struct PieceRun {
         }
       }
       if (__builtin_expect(freq == 0, 0)) { rc = FGMM_ERR_INVALID; return; } // cannot come out of a well-formed row
-      if (FGMM_DEC_RAW != 0) dec.advance_nb(start, freq); else dec.advance(start, freq);
+      dec.advance(start, freq);
     }
     td->out[i] = value;
     if (__builtin_expect(dec.underrun, 0)) { rc = FGMM_ERR_STREAM; return; }
@@ -1403,7 +1187,7 @@ int fgmm_rans_decode_tab_ckpt(const uint8_t *encoded, size_t encoded_len, const 
   if (hdr_form == 2 && !fgmm::tab_hdr_fits16(max_bs)) return FGMM_ERR_INVALID;
   if (hdr_form == 4 && max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_INVALID;
   const fgmm::TabPiece pc{hdr, blk_off, rows, (size_t)rows_len, n};
-  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, (flags & FGMM_TAB_D2_ROWS) ? fgmm::kTabD2Default : fgmm::kTabNoD2, hdr_form, tl, 1, &pc, nullptr, nullptr};
+  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, hdr_form, tl, 1, &pc, nullptr, nullptr};
   bool ok = true;
   int hard = FGMM_OK; // an error that is not the notes' fault
   // ONE decoder for all segments: begin() copies a misaligned bitstream whole, which must not happen once per segment
@@ -1466,8 +1250,7 @@ int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const ui
   if (n > 0 && (!hdr || !pool)) return FGMM_ERR_INVALID;
   if (max_bs < 0 || max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_UNSUPPORTED; // this entry point takes 4-byte headers
   const fgmm::TabPiece pc{hdr, nullptr, pool, (size_t)pool_len, n};
-  if (flags & FGMM_TAB_D2_ROWS) return FGMM_ERR_INVALID; // (second-difference rows are the single-pass kernel's)
-  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, fgmm::kTabNoD2, 4, 0, 1, &pc, nullptr, nullptr};
+  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, 4, 0, 1, &pc, nullptr, nullptr};
   return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
 }
 
@@ -1479,7 +1262,7 @@ int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void 
   if (hdr_form == 2 && !fgmm::tab_hdr_fits16(max_bs)) return FGMM_ERR_INVALID;
   if (hdr_form == 4 && max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_INVALID;
   const fgmm::TabPiece pc{hdr, blk_off, rows, (size_t)rows_len, n};
-  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, (flags & FGMM_TAB_D2_ROWS) ? fgmm::kTabD2Default : fgmm::kTabNoD2, hdr_form, tl, 1, &pc, nullptr, nullptr};
+  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, hdr_form, tl, 1, &pc, nullptr, nullptr};
   return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
 }
 
@@ -1496,7 +1279,7 @@ int fgmm_rans_decode_tab2(const fgmm_tab_ref *a, const fgmm_tab_ref *b) {
     if (r.max_bs < 0 || r.max_bs > FGMM_MAX_BS || (r.blk_off && r.tl < 1)) return FGMM_ERR_INVALID;
     if ((r.hdr_form == 2 && !fgmm::tab_hdr_fits16(r.max_bs)) || (r.hdr_form == 4 && r.max_bs > FGMM_MAX_BS_H4)) return FGMM_ERR_INVALID;
     pc[k] = fgmm::TabPiece{r.hdr, r.blk_off, r.rows, (size_t)r.rows_len, r.n};
-    tv[k] = fgmm::TabView{(r.flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, (r.flags & FGMM_TAB_D2_ROWS) ? fgmm::kTabD2Default : fgmm::kTabNoD2, r.hdr_form, r.tl, 1, &pc[k], nullptr, nullptr};
+    tv[k] = fgmm::TabView{(r.flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, r.hdr_form, r.tl, 1, &pc[k], nullptr, nullptr};
   }
   for (int k = 0; k < 2; ++k) rc[k] = td[k].begin(t[k]->encoded, t[k]->encoded_len, &tv[k], t[k]->n, t[k]->max_bs, t[k]->out_symbols);
   if (rc[0] == FGMM_OK && rc[1] == FGMM_OK) fgmm::rans_decode_pieces2(td[0], 0, td[1], 0, &rc[0], &rc[1]);

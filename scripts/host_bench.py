@@ -8,9 +8,8 @@ from flashgmm_amd import _lib, testing as T
 import helpers
 from helpers import trim_full_table, host_decode_cdftab, host_decode_tab, host_encode_symtab
 helpers.EF_MIN = int(os.environ.get("EF_MIN", str(helpers.EF_MIN)))  # must match the library's FGMM_EF_MIN
-helpers.D2_MIN = int(os.environ.get("D2_MIN", str(helpers.D2_MIN)))  # 16: second-difference rows (FGMM_TAB_D2_ROWS)
 
-cache = f"/tmp/host_bench_tables_v6_{helpers.EF_MIN}_{helpers.D2_MIN}.npz"
+cache = f"/tmp/host_bench_tables_v5_{helpers.EF_MIN}.npz"
 if os.path.exists(cache):
     z = np.load(cache); hdr, pool, sym, packed, max_bs = z["hdr"], z["pool"], z["sym"], z["packed"], int(z["max_bs"])
     enc = bytes(z["enc"])
@@ -21,10 +20,7 @@ else:
     enc = O.encode_gmm(0, sym, s, m, w)
     packed = O.symtab(0, sym, s, m, w)
     tab = O.cdftab(0, s, m, w, max_bs)
-    d2 = helpers.D2_MIN
-    helpers.D2_MIN = 1 << 30  # (the sequential 4-byte-header form is the generic kernels': no second-difference rows)
     hdr, pool, used = trim_full_table(tab, max_bs)
-    helpers.D2_MIN = d2
     h2, bo2, pool2, used2 = trim_full_table(tab, max_bs, form=2, tl=96, shuffle_seed=1)
     np.savez(cache, hdr=hdr, pool=pool, sym=sym, packed=packed, max_bs=max_bs, enc=np.frombuffer(enc, np.uint8), h2=h2, bo2=bo2, pool2=pool2)
     z = np.load(cache)
@@ -32,15 +28,12 @@ L = _lib.lib()
 n = len(sym)
 cnt = (hdr >> 16) & 0x7FFF
 h2, bo2, pool2 = z["h2"], z["bo2"], z["pool2"]
-print(f"n={n} rows: sequential form {len(pool)/n:.1f} B/latent, block form {len(pool2)/n:.1f} B/latent;  EF rows {((cnt>=helpers.EF_MIN) & (cnt<helpers.D2_MIN)).mean():.3f}  D2 rows {(cnt>=helpers.D2_MIN).mean():.3f}")
+print(f"n={n} rows: sequential form {len(pool)/n:.1f} B/latent, block form {len(pool2)/n:.1f} B/latent;  EF rows {(cnt>=helpers.EF_MIN).mean():.3f}")
 best = {}
 def note(k, v):
     best[k] = min(best.get(k, 1e9), v)
 for rep in range(int(os.environ.get("REPS", "7"))):
-    d2 = helpers.D2_MIN
-    helpers.D2_MIN = 1 << 30
     t0 = time.perf_counter(); rc, out = host_decode_cdftab(L, enc, hdr, pool, max_bs); t1 = time.perf_counter()
-    helpers.D2_MIN = d2
     assert rc == 0 and np.array_equal(out, sym)
     t2 = time.perf_counter(); b = host_encode_symtab(L, packed, None); t3 = time.perf_counter()
     assert b == enc
