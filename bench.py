@@ -30,7 +30,7 @@ One JSON line is printed by rank 0; besides the driver's contract it carries
   modes            BASELINE configs[2] in the same run (N = 1): the A&S and logistic approximations on the same batch, a few steps each,
                    the first four bitstreams checked against the reference's md5s (tests/golden/ka1.json: fixtures made from the
                    compiled reference)
-  elic4k           BASELINE configs[4] in the same run (N = 1): eight 4K images, fp16 parameter planes, a few steps
+  elic4k           BASELINE configs[4] in the same run (N = 1): sixteen 4K images in flight, fp16 parameter planes, a few steps
   checkpointed     the step on checkpointed bitstreams (segments decoded on the GPU), every rank, max over ranks
 """
 from __future__ import annotations
@@ -56,6 +56,7 @@ VALU_PEAK_LANE_SLOTS = 256 * 4 * 64 / 4 * 2.4e9
 TAB_SLOTS_PER_EDGE = {"polya": (134 + 107 * 1.16 + 4) / 2, "as": (150 + 140 * 1.16 + 4) / 2, "logistic": (230 + 110 * 1.16 + 4) / 2}
 
 ELIC_GROUPS = (16, 16, 32, 64, 192)  # elic_gmm.py:92-96
+ELIC_IMAGES = 16  # 4K images in flight per GPU (4.6 GB resident with fp16 parameter planes)
 
 
 def workload_shapes(workload: str):
@@ -685,7 +686,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kodak24", choices=["kodak24", "elic4k"])
-    ap.add_argument("--images", type=int, default=None, help="images per GPU (default 24 for kodak24, 8 for elic4k)")
+    ap.add_argument("--images", type=int, default=None, help="images per GPU (default 24 for kodak24, 16 for elic4k)")
     ap.add_argument("--param-dtype", default=None, choices=["f32", "f16"], help="default f32 (kodak24) / f16 (elic4k)")
     ap.add_argument("--mode", default="polya", choices=["polya", "as", "logistic"])
     ap.add_argument("--schedule", default="codec", choices=["codec", "all-at-once"],
@@ -749,9 +750,11 @@ def main(argv=None):
     from flashgmm_amd import GaussianMixtureConditional, _lib, container as Cn
 
     if a.images is None:
-        # elic4k: EIGHT 4K images in flight, decoded stage-major (stage s of every image in one call, as kodak24 does with
-        # its 24 images); one image alone is a chain of ten single-bitstream calls - that is the latency_ms leg
-        a.images = 24 if a.workload == "kodak24" else 8
+        # elic4k: SIXTEEN 4K images in flight, decoded stage-major (stage s of every image in one call, as kodak24 does with
+        # its 24 images): a call then has a bitstream for every host worker (with eight, half the workers idle: 458 against
+        # 612 Mpixels/s, profiles/r04_elic_images_ab.txt); one image alone is a chain of ten single-bitstream calls - that
+        # is the latency_ms leg
+        a.images = 24 if a.workload == "kodak24" else ELIC_IMAGES
     f16 = (a.param_dtype or ("f32" if a.workload == "kodak24" else "f16")) == "f16"
     _lib.ctx(local_rank, a.host_threads)
     _lib.set_profiling(local_rank, True)
@@ -880,13 +883,13 @@ def main(argv=None):
                         "reference_md5": ka1_check(lm, res_m)}
         extras["modes"] = modes
         try:
-            el = Leg(env, "elic4k", 8, "polya", True, keep_host_images=1)
+            el = Leg(env, "elic4k", ELIC_IMAGES, "polya", True, keep_host_images=1)
             el.step("codec")
             dt_e, st_e = el.timed("codec", 3, record=True)
             res_e = el.check_last()
             nc_e, sym_ms_e, ach_e = el.symtab_roofline(res_e)
             tb_e = float(np.mean(el.tab_bytes))
-            elic = {"config": {"workload": "elic4k", "images_per_gpu": 8, "param_dtype": "f16", "schedule": "codec", "decode_calls_per_step": el.spi,
+            elic = {"config": {"workload": "elic4k", "images_per_gpu": ELIC_IMAGES, "param_dtype": "f16", "schedule": "codec", "decode_calls_per_step": el.spi,
                                "coded_symbols_per_gpu": nc_e, "approx_mode": "polya"},
                     "value": round(el.mpix(3, dt_e), 2), "unit": "Mpixels/s", "steps": 3, "ms_per_step": round(dt_e / 3 * 1e3, 3), "step_ms": st_e["all"],
                     "symtab": {"launch_ms": round(sym_ms_e, 4), "achieved": round(ach_e, 1), "unit": "GB/s", "frac": round(ach_e / HBM_PEAK_GBS, 4),

@@ -940,7 +940,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     // Is the GPU the faster decoder for this call?  A segment's waves decode it at ~0.65 us per symbol however empty the chip is
     // (its widest rows included), and the chip as a whole at ~0.35 ns per symbol (Kodak-like latents); the host decodes at ~12 ns per symbol and worker and
     // is fed at 58 B per latent over PCIe.  Many segments (a batch, a 4K image's group): the GPU, by 2-4x; one Kodak half
-    // in a few hundred long segments: the host workers.  ("gpu_decode" = 1: always)
+    // in a few hundred long segments: the host workers.  ("gpu_decode" = 1: always)  The rates below are those of the boxes this
+    // was measured on (MI355X + EPYC 9575F, 16 workers, PCIe 5 x16): another host overrides the choice with the option.
     if (!gpu.empty() && ctx->opt.gpu_decode == 0) {
       double syms = 0, stride_max = 0, work = 0;
       for (int i : gpu) {

@@ -125,7 +125,10 @@ int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, con
  *                       with a segment the kernel does not settle itself (a non-monotone row, a note that does not verify)
  *                       goes through the table path.  0 = when the call has enough segments for the GPU to be the faster
  *                       decoder (a batch, a 4K image's channel group; one Kodak half in long segments decodes faster on the
- *                       host's workers), 1 = whenever a bitstream carries valid notes, 2 = never
+ *                       host's workers), 1 = whenever a bitstream carries valid notes, 2 = never.  The estimate behind 0 uses
+ *                       rates measured on ONE kind of box (MI355X + EPYC 9575F: 0.65 us per symbol of a segment's length and
+ *                       0.35 ns per symbol chip-wide on the GPU; 12 ns per symbol and worker, 58 B per latent at 55.7 GB/s
+ *                       for the table path): on another host set 1 or 2
  *   "ckpt_decode" [0]   decode, table path: checkpointed bitstreams are decoded in segments on all host workers: 0 = when the
  *                       call has fewer bitstreams than workers (else every worker has a bitstream anyway), 1 = always,
  *                       2 = never (the notes are ignored)
