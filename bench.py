@@ -70,6 +70,23 @@ def stream_seed(rank: int, image: int, stream: int, streams_per_image: int) -> i
     return 1000 * rank + image * streams_per_image + stream
 
 
+class _plain_children:
+    """Helper processes (workload generation, the CPU baselines) never touch the GPU - and must not be started with a profiler's
+    preloaded tool library: under `rocprofv3 --pmc` every process it is loaded into initialises the GPU, a pool of eight of them
+    beside the bench hung a profiling run (and exceeds what a box lets one command put on its card).  The variables are taken out
+    of the environment while a pool starts its workers, and put back."""
+
+    NAMES = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "HSA_TOOLS_LIB", "ROCP_TOOL_ATTACH")
+
+    def __enter__(self):
+        self.saved = {k: os.environ.pop(k) for k in list(os.environ) if k in self.NAMES or k.startswith("ROCPROF")}
+        return self
+
+    def __exit__(self, *exc):
+        os.environ.update(self.saved)
+        return False
+
+
 def _make_stream(args):
     seed, M, h, w, f16 = args
     from flashgmm_amd import testing as T
@@ -93,7 +110,9 @@ def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: b
     if procs > 1:
         import multiprocessing as mp
 
-        with mp.get_context("spawn").Pool(procs) as pool:
+        with _plain_children():
+            pool = mp.get_context("spawn").Pool(procs)
+        with pool:
             for k, st in enumerate(pool.imap(_make_stream, jobs, chunksize=1)):
                 host.append(st if k < keep_host_images * len(shapes) else None)  # (host copies feed the CPU baseline only)
                 devt.append([torch.from_numpy(a).to(dev) for a in st])
@@ -268,7 +287,9 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
         seeds = [stream_seed(rank, k // streams_per_image, k % streams_per_image, streams_per_image) for k in range(n_streams)]
         shp = [shapes[k % streams_per_image] for k in range(n_streams)]
         jobs = [(seeds[c::cores], shp[c::cores], f16, 6.0) for c in range(cores)]
-        with mp.get_context("spawn").Pool(cores) as pool:
+        with _plain_children():
+            pool = mp.get_context("spawn").Pool(cores)
+        with pool:
             res = pool.map(_all_cores_worker, jobs)
         streams_done = sum(r[0] for r in res)
         wall = max(r[2] for r in res) - min(r[1] for r in res)
@@ -285,7 +306,9 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
             n_sc = max(1, n_img // 4) * streams_per_image
             seeds = [stream_seed(rank, k // streams_per_image, k % streams_per_image, streams_per_image) for k in range(n_sc)]
             shp = [shapes[k % streams_per_image] for k in range(n_sc)]
-            with mp.get_context("spawn").Pool(1) as pool:
+            with _plain_children():
+                pool = mp.get_context("spawn").Pool(1)
+            with pool:
                 k2, sym2, best2, passes2 = pool.map(_scalar_worker, [(seeds, shp, f16, 8.0)])[0]
             out["scalar"] = {"value": round(n_sc / streams_per_image * pix_per_image / best2 / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
                              "kind": k2, "env": "USE_SIMD=0",
