@@ -113,7 +113,9 @@ def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: b
         with _plain_children():
             pool = mp.get_context("spawn").Pool(procs)
         with pool:
-            for k, st in enumerate(pool.imap(_make_stream, jobs, chunksize=1)):
+            it = pool.imap(_make_stream, jobs, chunksize=1)
+            for k in range(len(jobs)):
+                st = it.next(timeout=300)  # (a helper that never answers must not hang the run: TimeoutError ends this leg)
                 host.append(st if k < keep_host_images * len(shapes) else None)  # (host copies feed the CPU baseline only)
                 devt.append([torch.from_numpy(a).to(dev) for a in st])
     else:
