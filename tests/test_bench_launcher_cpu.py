@@ -140,3 +140,23 @@ def test_a_launcher_killed_outright_takes_its_ranks_with_it():
         time.sleep(0.2)
     for k in kids:
         assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z"
+
+
+def test_helper_processes_start_without_a_profilers_preload(monkeypatch):
+    """bench.py's pools (workload generation, CPU baselines) never touch the GPU and must not inherit a profiler's tool library:
+    the variables are out of the environment while a pool starts its workers, and back afterwards"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    monkeypatch.setenv("HSA_TOOLS_LIB", "libx.so")
+    monkeypatch.setenv("KEEP_ME", "1")
+    with bench._plain_children():
+        assert "LD_PRELOAD" not in os.environ and "ROCPROF_OUTPUT_PATH" not in os.environ and "HSA_TOOLS_LIB" not in os.environ
+        assert os.environ["KEEP_ME"] == "1"
+        seen = subprocess.run([sys.executable, "-c", "import os; print(int('LD_PRELOAD' in os.environ))"], capture_output=True, text=True).stdout.strip()
+        assert seen == "0"
+    assert os.environ["LD_PRELOAD"].endswith("tool.so") and os.environ["ROCPROF_OUTPUT_PATH"] == "/tmp/x" and os.environ["HSA_TOOLS_LIB"] == "libx.so"
