@@ -952,7 +952,8 @@ def main(argv=None):
         # worker (encode tables + decode tables), per second of stepping
         host_traffic = 2.0 * (enc_table_bytes + tbytes) / (ms_per_step * 1e-3) / 1e9
         note = (f"{host_threads} host rANS workers for this GPU = min(affinity {budget.get('affinity')}, cgroup quota "
-                f"{budget.get('quota')}) / {_lib.ranks_on_node()} rank(s) on the node, at most 16")
+                f"{budget.get('quota')}) / {_lib.ranks_on_node()} rank(s) on the node - x3 (up to the rank's share of the mask) where the quota, a limit on CPU time, "
+                f"is the smaller: the workers sleep most of a call - at most 48")
         if host_threads < 8:
             note += ("; FEWER THAN 8 WORKERS: the plain (table) path is host-bound by configuration here - its rate follows the "
                      "workers (one_host_thread x workers), the `checkpointed` leg does not need them")

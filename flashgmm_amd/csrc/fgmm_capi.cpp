@@ -1829,17 +1829,22 @@ int fgmm_host_cpu_budget(double *cpus_out, int *affinity_out, double *quota_out)
 }
 
 int fgmm_host_thread_budget(int ranks_sharing) {
-  double cpus = 4;
-  (void)fgmm_host_cpu_budget(&cpus, nullptr, nullptr);
-  if (ranks_sharing > 1) cpus /= ranks_sharing;
-  // One worker per CPU of the share, at most 16.  The workers SLEEP on the copies' events and are busy three quarters of a
-  // decode call, so a pool as large as the quota does not exhaust it: the cgroup's nr_throttled does not move inside bench.py's
-  // timed region (the bench line carries the counters), and leaving two CPUs to the calling thread and the runtime's threads
-  // measured slower on both boxes tried - 16 / 14 / 12 workers: 962 / 938 / 891 Mpixels/s (profiles/r03_host_threads.md)
-  const int t = (int)floor(cpus + 1e-9);
-  return std::max(1, std::min(t, 16));
+  double cpus = 4, quota = -1;
+  int aff = 4;
+  (void)fgmm_host_cpu_budget(&cpus, &aff, &quota);
+  double aff_share = aff;
+  if (ranks_sharing > 1) cpus /= ranks_sharing, aff_share /= ranks_sharing;
+  // The workers SLEEP on the copies' events and are busy three quarters of a decode call (less, the more of them there are), and a
+  // cgroup quota limits CPU TIME per period, not how many threads may run at once: where the affinity mask is wider than the quota
+  // (a GPU box: 128 CPUs of the GPU's node, a quota of 16) a pool of up to three workers per CPU of the share runs the bursts of a
+  // step - 48 bitstreams to encode, 24 to decode - on as many cores, stays inside the quota (a Kodak step uses 9-10 CPUs' worth of
+  // time; nr_throttled does not move, the bench line carries the counters) and is 3 % faster than 16 workers (48: step median
+  // 9.41-9.60 ms, 16: 9.73-9.80 on quiet boxes; checkpointed streams +6 %: profiles/r04_host_threads.txt).  Never more workers than
+  // the rank's share of the affinity mask; 16 / 14 / 12 workers: 962 / 938 / 891 Mpixels/s (profiles/r03_host_threads.md).
+  const int by_time = (int)floor(cpus + 1e-9), by_mask = (int)floor(aff_share + 1e-9);
+  const int t = quota > 0 && by_mask > by_time ? std::min(by_mask, 3 * by_time) : by_time;
+  return std::max(1, std::min(t, 48));
 }
-
 int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {
   if (!out) return fail(FGMM_ERR_INVALID, "out == NULL");
   *out = nullptr;

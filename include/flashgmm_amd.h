@@ -71,9 +71,11 @@ const char *fgmm_last_error(void); /* thread-local text of the last failure on t
  * cpu.max of cgroup v2 / cpu.cfs_quota_us of v1, ancestors included); *affinity_out / *quota_out the two terms (quota < 0:
  * none).  Any out-pointer may be NULL. */
 int fgmm_host_cpu_budget(double *cpus_out, int *affinity_out, double *quota_out);
-/* Host rANS workers a context gets by default when `ranks_sharing` processes (one per GPU) share that budget:
- * floor(budget / ranks_sharing), within [1, 16].  (The workers sleep on the copies' events and are busy three quarters of a
- * call: a pool as large as the share does not get the process throttled, and two workers fewer measured 2.5 % slower.) */
+/* Host rANS workers a context gets by default when `ranks_sharing` processes (one per GPU) share that budget: the share's CPUs,
+ * floor(budget / ranks_sharing) - or, where a cgroup quota (CPU TIME per period) is what limits the budget and the affinity mask is
+ * wider, up to three workers per CPU of the share (never more than the share of the mask): the workers sleep on the copies' events
+ * most of a call, so the bursts of a step run on as many cores while the quota is not exhausted (measured: 48 workers under a 16-CPU
+ * quota are 3 % faster than 16 and are not throttled).  Within [1, 48]. */
 int fgmm_host_thread_budget(int ranks_sharing);
 
 /* device < 0: current HIP device.  n_threads <= 0: fgmm_host_thread_budget(1) host rANS workers. */

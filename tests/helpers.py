@@ -220,3 +220,10 @@ def host_decode_tab2(lib, tabs):
                                  out.ctypes.data))
     rc = lib.fgmm_rans_decode_tab2(C.byref(refs[0]), C.byref(refs[1]))
     return rc, outs
+
+
+def expected_threads(budget: dict, ranks: int = 1) -> int:
+    """fgmm_host_thread_budget, restated: the share's CPUs; x3 (up to the share of the affinity mask) when a cgroup quota is the limit"""
+    by_time, by_mask = int(budget["cpus"] / ranks + 1e-9), int(budget["affinity"] / ranks + 1e-9)
+    t = min(by_mask, 3 * by_time) if budget.get("quota") and by_mask > by_time else by_time
+    return max(1, min(t, 48))

@@ -9,6 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(args, extra_env=None):
@@ -34,7 +35,8 @@ def test_self_launch_prints_one_line(n):
     assert d["ranks"]["backend"] == "gloo" and d["ranks"]["rccl_ranks"] == 0 and d["ranks"]["allgather_ms"] > 0
     threads = d["ranks"]["host_threads_per_gpu"]
     budget = d["ranks"]["host_cpu_budget"]
-    assert len(threads) == n and all(t == max(1, min(16, int(budget["cpus"] / n))) for t in threads)
+    from helpers import expected_threads
+    assert len(threads) == n and all(t == expected_threads(budget, n) for t in threads)
     for key in ("metric", "value", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "config"):
         assert key in d
 

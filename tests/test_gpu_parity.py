@@ -1344,7 +1344,8 @@ def test_bench_two_ranks_rehearsed_on_one_device():
     rk = d["ranks"]
     assert rk["backend"] == "gloo" and rk["rccl_ranks"] == 0 and len(rk["ms_per_step"]) == 2 and rk["result_checked_ranks"] == 2
     budget = d["config"]["host_cpu_budget"]
-    assert rk["host_threads_per_gpu"] == [max(1, min(16, int(budget["cpus"] / 2)))] * 2
+    from helpers import expected_threads
+    assert rk["host_threads_per_gpu"] == [expected_threads(budget, 2)] * 2
     assert rk["allgather_ms"] is not None and rk["allgather_ms"] > 0 and rk["allgather_payload_ms"] > 0
     assert d["ms_per_step"] == max(rk["ms_per_step"]) and d["value"] > 0
     assert d["upper_bound"]["value"] > 0 and d["checkpointed"]["value"] > 0 and d["checkpointed"]["bitstreams_handed_back_last_call"] == 0

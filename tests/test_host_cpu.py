@@ -558,10 +558,16 @@ def test_host_budget_reads_the_cgroup_v2_quota_of_the_group_and_its_ancestors(tm
     n_aff = len(os.sched_getaffinity(0))
     budget, threads = _budget_in_child(tmp_path)
     assert budget["affinity"] == n_aff and budget["quota"] == 16.0 and budget["cpus"] == min(n_aff, 16.0)
-    assert threads == max(1, min(16, int(budget["cpus"])))
+    from helpers import expected_threads
+    assert threads == expected_threads(budget)
     # eight ranks share the node: each gets an eighth, and at least one worker
     _, per_rank = _budget_in_child(tmp_path, ranks=8)
-    assert per_rank == max(1, int(budget["cpus"] / 8))
+    assert per_rank == expected_threads(budget, 8)
+    # a quota below the mask (a GPU box: 128 CPUs visible, 16 granted): three workers per granted CPU, never more than the mask
+    if n_aff >= 4:
+        _tree(tmp_path, {"/sys/fs/cgroup/pod/cpu.max": "200000 100000\n"})
+        b2, t2 = _budget_in_child(tmp_path)
+        assert b2["quota"] == 2.0 and t2 == min(n_aff, 6)
 
 
 def test_host_budget_reads_a_cgroup_v1_quota_and_the_affinity_mask(tmp_path):
@@ -571,7 +577,8 @@ def test_host_budget_reads_a_cgroup_v1_quota_and_the_affinity_mask(tmp_path):
                      "/sys/fs/cgroup/cpu,cpuacct/cpu.cfs_quota_us": "-1\n",
                      "/sys/fs/cgroup/cpu,cpuacct/cpu.cfs_period_us": "100000\n"})
     budget, threads = _budget_in_child(tmp_path)
-    assert budget["quota"] == 3.5 and budget["cpus"] == min(budget["affinity"], 3.5) and threads == max(1, int(budget["cpus"]))
+    from helpers import expected_threads
+    assert budget["quota"] == 3.5 and budget["cpus"] == min(budget["affinity"], 3.5) and threads == expected_threads(budget)
     one = sorted(os.sched_getaffinity(0))[:1]
     budget, threads = _budget_in_child(tmp_path, cpus=one)  # a one-CPU mask wins over the quota
     assert budget["affinity"] == 1 and budget["cpus"] == 1.0 and threads == 1
