@@ -24,10 +24,10 @@ note "rocprof kodak done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_elic" -- python3 bench.py --workload elic4k --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$out/bench_elic4k_under_rocprof.json" 2> "$out/prof_elic.err"
 f=$(ls $out/prof_elic/*/*kernel_stats.csv | head -1); cp "$f" "$out/kernel_stats_elic4k.csv"
 note "rocprof elic done"
-bash scripts/collect_pmc.sh "$out/pmc" polya kodak24 4 > "$out/pmc.log" 2>&1
+timeout -k 10 300 bash scripts/collect_pmc.sh "$out/pmc" polya kodak24 4 > "$out/pmc.log" 2>&1
 cp "$out/pmc/pmc_symtab.json" "$out/pmc_symtab.json"
 note "pmc kodak done"
-bash scripts/collect_pmc.sh "$out/pmc_elic" polya elic4k 2 > "$out/pmc_elic.log" 2>&1
+timeout -k 10 300 bash scripts/collect_pmc.sh "$out/pmc_elic" polya elic4k 2 > "$out/pmc_elic.log" 2>&1
 cp "$out/pmc_elic/pmc_symtab.json" "$out/pmc_symtab_elic4k.json"
 note "pmc elic done"
 rm -rf "$out/prof" "$out/prof_elic" "$out/pmc/pmc_fetch" "$out/pmc/pmc_write" "$out/pmc_elic/pmc_fetch" "$out/pmc_elic/pmc_write"
