@@ -104,6 +104,7 @@ SIGNATURES = {
     "fgmm_rans_decode_tab_ckpt": (_i, [_p, _sz, _p, _i, _p, _i32, _p, C.c_uint64, _i64, _i32, _i, _p, _i64, _i64, _p, C.POINTER(_i32)]),
     "fgmm_rans_encode_symtab2": (_i, [_p, _p, _i64, _p, _p, _i64, _pp, _psz, _pp, _psz]),
     "fgmm_rans_encode_symtab_n": (_i, [_i, _p, _p, _p, _p, _p]),
+    "fgmm_rans_encode_symtab_segs": (_i, [_p, _i, _i64, _p, _i64, _i64, _pp, _psz, _p]),
     "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, C.c_uint64, _i64, _i32, _i, _p]),
     "fgmm_rans_decode_tab": (_i, [_p, _sz, _p, _i, _p, _i32, _p, C.c_uint64, _i64, _i32, _i, _p]),
     "fgmm_rans_decode_tab2": (_i, [_p, _p]),

@@ -238,7 +238,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, tab_place = 0, tab_spin = kTabSpinLimit, copy_engine = 0;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, tab_place = 0, tab_spin = kTabSpinLimit, copy_engine = 0, enc_segs = 1;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -419,6 +419,9 @@ struct EncItem {
   int status = FGMM_OK;
   // workspace offsets
   size_t o_min = 0, o_max = 0, o_nz = 0, o_list = 0, o_meta = 0, o_packed = 0, meta_count = 0;
+  // the table in segments of compact channels (EncDesc::packed_seg): offsets, channels per segment, segments, copy group of each
+  size_t o_seg[kEncSegs] = {0, 0, 0, 0};
+  int32_t cps = 0, n_seg = 0, seg_group[kEncSegs] = {0, 0, 0, 0};
   // what the item's host job needs (set when its side information has been read)
   const int32_t *job_syms = nullptr;
   int64_t job_n = 0, job_bypass = 0;
@@ -452,10 +455,45 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   std::vector<int> order((size_t)count);
   for (int i = 0; i < count; ++i) order[(size_t)i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (int64_t)items[a].M * items[a].hw > (int64_t)items[b].M * items[b].hw; });
-  for (int i : order) items[i].o_packed = ar.take(sizeof(uint32_t) * (size_t)items[i].M * (size_t)items[i].hw + 64);
+  // A bitstream is encoded BACKWARDS (rANS), so its encoder needs the END of its table first - and with whole tables crossing
+  // PCIe one after another the call ends a whole job (0.3-0.45 ms for a Kodak half) after the last table has landed.  When every
+  // bitstream has a worker of its own, the tables are therefore laid out in up to four SEGMENTS of compact channels each, LAST
+  // SEGMENT FIRST across all bitstreams: the encoders start on the tails after an eighth of the transfer and follow the landing;
+  // what is left after the last byte is a quarter of a job (48 Kodak halves: 1.18 -> 0.9 ms per call).
+  const int enc_T = std::max(ctx->pool->size(), 1);
+  // automatic: pairs as soon as there are more bitstreams than workers (measured on the box, 48 bitstreams on 16 workers:
+  // pairs 1.78 ms per call, threes 2.28, workers pulling one or two as the tables land 1.95-2.04)
+  const int enc_ways = ctx->opt.enc_ways > 0 ? (int)ctx->opt.enc_ways : (count > enc_T ? 2 : 1);
+  bool segmented = ctx->opt.enc_segs != 0 && count >= 2 && enc_ways == 1;
+  {
+    size_t table_bytes = 0;
+    for (auto &it : items) {
+      table_bytes += sizeof(uint32_t) * (size_t)it.M * (size_t)it.hw;
+      segmented = segmented && it.y && !it.symbuf && it.M >= 2 * kEncSegs;
+    }
+    segmented = segmented && table_bytes >= ((size_t)4 << 20); // (smaller calls: the transfer is not what they wait for)
+  }
+  if (!segmented) {
+    for (int i : order) items[i].o_packed = ar.take(sizeof(uint32_t) * (size_t)items[i].M * (size_t)items[i].hw + 64);
+  } else {
+    for (auto &it : items) {
+      it.cps = (it.M + kEncSegs - 1) / kEncSegs;
+      it.n_seg = (it.M + it.cps - 1) / it.cps;
+    }
+    for (int sg = kEncSegs - 1; sg >= 0; --sg)
+      for (int i : order) {
+        EncItem &it = items[i];
+        if (sg >= it.n_seg) continue;
+        const int32_t ch = std::min(it.M, (sg + 1) * it.cps) - sg * it.cps;
+        it.o_seg[sg] = ar.take(sizeof(uint32_t) * (size_t)ch * (size_t)it.hw + 64);
+      }
+    for (auto &it : items) it.o_packed = it.o_seg[0];
+  }
+  const size_t o_tables_end = ar.off;
   const size_t total = ar.off;
   int rc;
-  if ((rc = ctx->ensure_device(total)) || (rc = ctx->ensure_host(total)) || (rc = ctx->ensure_events(count + 1))) return rc;
+  if ((rc = ctx->ensure_device(total)) || (rc = ctx->ensure_host(total)) || (rc = ctx->ensure_events((size_t)count + 17, 16))) return rc;
+  const size_t ev_meta = (size_t)count + 16; // (the copy groups of the tables use the events before it: at most count, or nine)
 
   // ---- descriptors ------------------------------------------------------------------------------
   EncDesc *hd = reinterpret_cast<EncDesc *>(ctx->h_ws + o_descs);
@@ -482,6 +520,15 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     d.chan_nz = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_nz) : nullptr;
     d.chan_list = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_list) : nullptr;
     d.packed = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_packed);
+    d.seg_b[0] = d.seg_b[1] = d.seg_b[2] = INT32_MAX;
+    d.packed_seg[0] = d.packed;
+    if (segmented) {
+      d.cps = it.cps;
+      for (int sg = 0; sg < it.n_seg; ++sg) {
+        d.packed_seg[sg] = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_seg[sg]);
+        if (sg + 1 < it.n_seg) d.seg_b[sg] = (sg + 1) * it.cps;
+      }
+    }
     d.meta = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_meta);
     vec4 = vec4 && enc_vec4_ok(d, it.prm.dtype == FGMM_F16);
     any_y = any_y || it.y;
@@ -508,11 +555,41 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   if ((rc = ctx->prof_end(0, stream))) return rc;
   // ---- tables back to the host: small region first, then one copy + event per item ----------------
   HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_small, ctx->d_ws + o_small, small_bytes, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipEventRecord(ctx->events[count], stream));
+  HIP_TRY(hipEventRecord(ctx->events[ev_meta], stream));
   // the per-item tables are contiguous in the workspace (in `order`): a handful of large copies instead of one per item
   std::vector<int> group_of(count);
   int n_groups = 0;
-  {
+  if (segmented) {
+    // the segments in the order they were laid out (tails of all bitstreams first), in about eight copies
+    struct Chunk {
+      int item, sg;
+      size_t beg, end;
+    };
+    std::vector<Chunk> chunks;
+    size_t bytes = 0;
+    for (int sg = kEncSegs - 1; sg >= 0; --sg)
+      for (int i : order) {
+        const EncItem &it = items[i];
+        if (sg >= it.n_seg) continue;
+        const int32_t ch = std::min(it.M, (sg + 1) * it.cps) - sg * it.cps;
+        chunks.push_back(Chunk{i, sg, it.o_seg[sg], it.o_seg[sg] + sizeof(uint32_t) * (size_t)ch * (size_t)it.hw});
+        bytes += chunks.back().end - chunks.back().beg;
+      }
+    const size_t per_group = bytes / 8 + 1;
+    for (size_t c0 = 0; c0 < chunks.size(); ++n_groups) {
+      size_t c1 = c0, got = 0;
+      do {
+        got += chunks[c1].end - chunks[c1].beg;
+        ++c1;
+      } while (c1 < chunks.size() && got < per_group);
+      const size_t beg = chunks[c0].beg, end = chunks[c1 - 1].end; // (laid out in this order: one contiguous range)
+      if (end > beg) HIP_TRY(hipMemcpyAsync(ctx->h_ws + beg, ctx->d_ws + beg, end - beg, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipEventRecord(ctx->sleep_events[n_groups], stream));
+      for (size_t c = c0; c < c1; ++c) items[chunks[c].item].seg_group[chunks[c].sg] = n_groups;
+      c0 = c1;
+    }
+    (void)o_tables_end;
+  } else {
     size_t table_bytes = 0;
     for (auto &it : items) table_bytes += sizeof(uint32_t) * (size_t)it.M * (size_t)it.hw;
     const size_t per_group = count >= 16 ? table_bytes / 6 + 1 : 0; // (fewer than 16 bitstreams: a copy each)
@@ -532,18 +609,25 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     }
   }
   tr.mark("enqueued");
-  HIP_TRY(hipEventSynchronize(ctx->events[count]));
+  HIP_TRY(hipEventSynchronize(ctx->events[ev_meta]));
   tr.mark("kernels + meta landed");
   ctx->stat[0] = 0;
   for (auto &it : items) ctx->stat[0] += sizeof(uint32_t) * (unsigned long long)it.M * (unsigned long long)it.hw;
 
   // ---- host side: per item side information, then one rANS job per item -----------------------------
   std::vector<std::vector<int32_t>> wide_syms(count); // only for bypass symbols beyond int16 (rare)
+  // segmented tables: an encoder asks for a segment before it enters it and SLEEPS on the event of the copy that carries it
+  // (hipEventBlockingSync, like the decode workers on their pieces: no thread of this process polls or hands events on)
+  struct SegWaitArg {
+    hipEvent_t *ev;       // the copy groups' events
+    const int32_t *group; // EncItem::seg_group
+  };
+  std::vector<SegWaitArg> seg_args((size_t)count);
   PoolDrain drain{ctx->pool};
-  const int enc_T = std::max(ctx->pool->size(), 1);
-  // automatic: pairs as soon as there are more bitstreams than workers (measured on the box, 48 bitstreams on 16 workers:
-  // pairs 1.78 ms per call, threes 2.28, workers pulling one or two as the tables land 1.95-2.04)
-  const int enc_ways = ctx->opt.enc_ways > 0 ? (int)ctx->opt.enc_ways : (count > enc_T ? 2 : 1);
+  auto seg_wait = +[](void *arg, int sg) -> int {
+    SegWaitArg *a = static_cast<SegWaitArg *>(arg);
+    return hipEventSynchronize(a->ev[a->group[sg]]) == hipSuccess ? FGMM_OK : FGMM_ERR_HIP;
+  };
   // jobs: runs of up to `enc_ways` bitstreams adjacent in `order` (similar sizes), coded in turn by one worker; a bitstream that
   // is a worker's fair share by itself (>= 1 / (2 * workers) of the call) is a job of its own - sixteen large pairs on eight
   // workers would leave the other eight idle
@@ -626,13 +710,42 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     const int g_begin = job_first[(size_t)pos], n_in = pos - g_begin + 1;
     int last_group = 0;
     for (int r = g_begin; r <= pos; ++r) last_group = std::max(last_group, group_of[order[(size_t)r]]);
-    HIP_TRY(hipEventSynchronize(ctx->events[last_group])); // copies complete in the order they were queued
+    if (!segmented) HIP_TRY(hipEventSynchronize(ctx->events[last_group])); // copies complete in the order they were queued
     const char *h_ws = ctx->h_ws;
+    if (segmented) seg_args[(size_t)i] = SegWaitArg{ctx->sleep_events.data(), it.seg_group};
+    SegWaitArg *const seg_arg = segmented ? &seg_args[(size_t)i] : nullptr;
     EncItem *const *first = &job_items[(size_t)g_begin];
     const double t_sub = tr.ms();
     for (int q = 0; q < n_in; ++q) first[q]->t_sub = t_sub;
-    auto job = [first, n_in, h_ws, &tr] {
+    auto job = [first, n_in, h_ws, &tr, seg_arg, seg_wait] {
       const double t_start = tr.ms();
+      if (seg_arg) { // (n_in == 1) the table lies in segments that land tail first: the encoder asks for each before it enters it
+        EncItem &e = *first[0];
+        e.t_start = t_start;
+        SegTable t;
+        t.n_seg = e.n_seg;
+        t.seg_len = (int64_t)e.cps * e.hw;
+        for (int sg = 0; sg < kEncSegs; ++sg) t.seg[sg] = sg < e.n_seg ? reinterpret_cast<const uint32_t *>(h_ws + e.o_seg[sg]) : nullptr;
+        t.wait = seg_wait;
+        t.arg = seg_arg;
+        const int64_t stride = e.ckpt_stride;
+        const int64_t n_ck = stride > 0 && e.job_n > 0 ? (e.job_n - 1) / stride : 0;
+        int rc = FGMM_OK;
+        if (n_ck > 0) {
+          e.ckpt = static_cast<fgmm_ckpt *>(malloc(sizeof(fgmm_ckpt) * (size_t)n_ck));
+          if (!e.ckpt) rc = FGMM_ERR_NOMEM;
+          e.n_ckpt = e.ckpt ? n_ck : 0;
+        }
+        if (rc == FGMM_OK) rc = rans_encode_symtab_segs(t, e.job_syms, e.job_n, e.job_bypass, &e.bytes, &e.bytes_len, n_ck > 0 ? stride : 0, e.ckpt);
+        if (rc != FGMM_OK) {
+          free(e.ckpt);
+          e.ckpt = nullptr;
+          e.n_ckpt = 0;
+        }
+        e.status = rc;
+        e.t_end = tr.ms();
+        return;
+      }
       if (n_in == 1 && first[0]->symbuf) {
         first[0]->t_start = t_start;
         first[0]->status = fgmm_symbuf_append_symtab(first[0]->symbuf, reinterpret_cast<const uint32_t *>(h_ws + first[0]->o_packed), first[0]->job_syms, first[0]->job_n);
@@ -678,7 +791,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     };
     if (count == 1) job(); else ctx->pool->submit(job);
   }
-  tr.mark("all tables landed, jobs out");
+  tr.mark(segmented ? "jobs out" : "all tables landed, jobs out");
   if (count > 1) ctx->pool->wait_all();
   tr.mark("host rANS done");
   if (tr.level > 1)
@@ -1749,6 +1862,9 @@ const OptName kOpts[] = {
     // decode tables device -> pinned host: 0 = hipMemcpyAsync (shader copies on this runtime), 1 = straight to ONE SDMA engine,
     // 2 = two engines in turn (measured slower in situ than the shader copies: profiles/r04_copy_engine.md)
     {"copy_engine", &fgmm_ctx::Opts::copy_engine, 0, 2, "FGMM_COPY_ENGINE"},
+    // encode: 1 = the tables of a call with a worker per bitstream cross PCIe TAIL FIRST in four segments per bitstream and the
+    // encoders (which walk a table backwards) follow the landing; 0 = whole tables, bitstream after bitstream
+    {"enc_segs", &fgmm_ctx::Opts::enc_segs, 0, 1, "FGMM_ENC_SEGS"},
 };
 } // namespace
 
@@ -2278,6 +2394,8 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
   hd->hw = n;
   hd->M = 1;
   hd->packed = packed;
+  hd->packed_seg[0] = packed;
+  hd->seg_b[0] = hd->seg_b[1] = hd->seg_b[2] = INT32_MAX; // the table in one piece
   hd->meta = reinterpret_cast<uint32_t *>(ctx->d_ws + 1024);
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, hd, sizeof *hd, hipMemcpyHostToDevice, s));

@@ -33,7 +33,14 @@ struct EncDesc {
   float *chan_max;       // [M]
   int32_t *chan_nz;      // [M]  any round(y) != 0
   int32_t *chan_list;    // [M+1] compact index -> channel; [M] = number of non-zero channels (null: identity)
-  uint32_t *packed;      // [n_nz*hw] start | range<<16, channels compacted
+  uint32_t *packed;      // [n_nz*hw] start | range<<16, channels compacted - when the table is ONE piece (seg_b[0] = INT32_MAX)
+  // The table in up to kEncSegs SEGMENTS of compact channels: segment s holds the compact channels [s * cps, (s + 1) * cps)
+  // contiguously at packed_seg[s]; seg_b[s] = (s + 1) * cps for the segments in use, INT32_MAX beyond.  The batched encoder
+  // lays the segments of a call out LAST SEGMENT FIRST across all items: a bitstream is encoded backwards, so the tables'
+  // tails cross PCIe first and the host encoders follow the landing instead of waiting for whole tables (fgmm_capi.cpp).
+  uint32_t *packed_seg[4];
+  int32_t seg_b[3];
+  int32_t cps;
   uint32_t *meta;        // [4 * blocks] bypass symbols seen by each wave (zeroed by the host, summed by the host:
                          // device-scope atomics on one counter serialise across the 8 XCDs, ~0.1 ms for a 6 M-symbol item)
 };
@@ -125,6 +132,7 @@ int launch_segzero(const SegDesc *d_descs, int count, int64_t max_dead, void *st
 //   placement: sequential in latent order (generic path, the building-block API), or per block of `tl` latents at
 //   rows + 4 * blk_off[block] (tab_kernel: blocks are placed by an atomic cursor, in no particular order)
 constexpr int kMaxPieces = 16; // FGMM_MAX_PIECES
+constexpr int kEncSegs = 4;    // EncDesc::packed_seg
 constexpr int kTabEdgeSlots = 64;               // DecDesc::counters
 constexpr int kTabCounters = 4 + kTabEdgeSlots;
 constexpr int kTabSpinLimit = 1 << 21;          // look-back polls (a microsecond or two each) before a block gives up
@@ -208,6 +216,18 @@ int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, i
 // ... noting a checkpoint (include/flashgmm_amd.h: fgmm_ckpt) every `stride` symbols (a power of two; 0: none):
 // ckpt[(n - 1) / stride] entries, entry k for symbol (k + 1) * stride
 int rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint, uint8_t **out,
+                            size_t *out_len, int64_t stride, fgmm_ckpt *ckpt);
+// ... from a table that lies in `n_seg` segments of `seg_len` entries (the last one may be shorter): seg[s] holds the entries
+// [s * seg_len, (s + 1) * seg_len).  The walk runs backwards, so the LAST segment is needed first; wait(arg, s) (may be null)
+// returns once segment s may be read (FGMM_OK) - the batched encoder's tables land tail first.
+struct SegTable {
+  const uint32_t *seg[kEncSegs];
+  int64_t seg_len;
+  int n_seg;
+  int (*wait)(void *arg, int s);
+  void *arg;
+};
+int rans_encode_symtab_segs(const SegTable &t, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint, uint8_t **out,
                             size_t *out_len, int64_t stride, fgmm_ckpt *ckpt);
 // two streams by one thread, interleaved (each output identical to rans_encode_symtab's)
 constexpr int kMaxEncWays = 4;

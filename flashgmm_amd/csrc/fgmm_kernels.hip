@@ -176,6 +176,9 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
     active = p0 < hw;
   }
   const int c = d.chan_list ? d.chan_list[rank] : rank;
+  // where the compact channel's entries go: the table is one piece, or up to four segments of compact channels (wave-uniform)
+  const int seg = (rank >= d.seg_b[0]) + (rank >= d.seg_b[1]) + (rank >= d.seg_b[2]);
+  uint32_t *const row_out = (seg ? d.packed_seg[seg] : d.packed) + (int64_t)(rank - seg * d.cps) * hw;
   int nbypass = 0;
   if (!active) {
   } else if constexpr (VEC > 1) {
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
       out[e] = sym_entry<MODE, CLAMPED>(vq[e], vi[e], mu, sg, pi, bp);
       nbypass += __popcll(__ballot(bp)); // the wave's count on the scalar unit: no lane-wise sum, no cross-lane reduction
     }
-    stg<uvec_t>(d.packed + (int64_t)rank * hw + p0, out);
+    stg<uvec_t>(row_out + p0, out);
   } else {
     const int64_t base = (int64_t)c * d.stride_c + p0 * d.stride_p;
     float vq;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
     }
     if (d.logits) softmax4(pi);
     int bp;
-    stg<uint32_t>(d.packed + (int64_t)rank * hw + p0, sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp));
+    stg<uint32_t>(row_out + p0, sym_entry<MODE, CLAMPED>(vq, vi, mu, sg, pi, bp));
     nbypass = __popcll(__ballot(bp));
   }
   // bypass census (the host sizes its output buffer from it): one plain store per wave that saw any, no atomics.  nbypass is

@@ -190,6 +190,45 @@ int rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols, int6
   return finish_stream(e, end, out, out_len);
 }
 
+// the same from a table in segments (SegTable): the walk is backwards, so it starts in the last segment and asks for each one
+// before it enters it - the batched encoder's tables cross PCIe tail first and the encoders follow the landing
+int rans_encode_symtab_segs(const SegTable &t, const int32_t *symbols, int64_t n, int64_t n_bypass_hint, uint8_t **out, size_t *out_len,
+                            int64_t stride, fgmm_ckpt *ckpt) {
+  std::call_once(g_rcp_once, init_rcp);
+  if (n < 0 || !out || !out_len || n_bypass_hint < 0 || stride < 0 || (stride & (stride - 1)) || (ckpt_count(n, stride) && !ckpt) ||
+      t.n_seg < 1 || t.n_seg > kEncSegs || t.seg_len < 1 || n > (int64_t)t.n_seg * t.seg_len)
+    return FGMM_ERR_INVALID;
+  const size_t nwords = encode_words(n, n_bypass_hint);
+  static thread_local std::vector<uint32_t> scratch;
+  try {
+    if (scratch.size() < nwords) scratch.resize(nwords);
+  } catch (const std::bad_alloc &) {
+    return FGMM_ERR_NOMEM;
+  }
+  uint32_t *const end = scratch.data() + nwords;
+  Enc e{kRansL, end}; // Rans64EncInit
+  CkRec ck{ckpt, stride, ckpt_count(n, stride)};
+  const uint64_t smask = ck.n_out ? (uint64_t)stride - 1 : ~0ull;
+  for (int64_t hi = n; hi > 0;) {
+    const int sg = (int)((hi - 1) / t.seg_len);
+    const int64_t lo = (int64_t)sg * t.seg_len;
+    if (!t.seg[sg]) return FGMM_ERR_INVALID;
+    if (t.wait) {
+      const int rc = t.wait(t.arg, sg);
+      if (rc != FGMM_OK) return rc;
+    }
+    const uint32_t *const p = t.seg[sg] - lo; // p[i] for lo <= i < hi
+    for (int64_t i = hi - 1; i >= lo; --i) {  // reversed _syms (rans_interface.cpp:569)
+      if ((i & 15) == 15 && i - 512 >= lo) __builtin_prefetch(p + i - 512); // the table was just DMA-written: not in any cache
+      encode_entry(e, p[i], symbols, i);
+      if (__builtin_expect(((uint64_t)i & smask) == 0 && i > 0, 0)) ck.note(e, end, i);
+    }
+    hi = lo;
+  }
+  ck.finish(e, end);
+  return finish_stream(e, end, out, out_len);
+}
+
 // Up to four independent bitstreams coded by one thread, symbol by symbol in turn.  A stream's state update is a chain
 // of ~11 dependent cycles per symbol; several chains fill the core's issue slots: 1.47 ns/symbol with two against 2.4 for
 // one stream alone (Zen 5, scripts/enc_ilp.cpp).  Each stream's output is exactly what rans_encode_symtab gives.
@@ -1215,6 +1254,23 @@ int fgmm_rans_decode_tab_ckpt(const uint8_t *encoded, size_t encoded_len, const 
   }
   if (hard != FGMM_OK) return hard;
   return fgmm_rans_decode_tab(encoded, encoded_len, hdr, hdr_form, blk_off, tl, rows, rows_len, n, max_bs, flags, out_symbols);
+}
+
+int fgmm_rans_encode_symtab_segs(const uint32_t *const *seg, int n_seg, int64_t seg_len, const int32_t *symbols_or_null, int64_t n,
+                                 int64_t stride, uint8_t **out, size_t *out_len, fgmm_ckpt *ckpt_out) {
+  if (!seg || n_seg < 1 || n_seg > fgmm::kEncSegs || seg_len < 1 || n < 0 || n > (int64_t)n_seg * seg_len || stride < 0 || (stride & (stride - 1)))
+    return FGMM_ERR_INVALID;
+  fgmm::SegTable t{};
+  t.seg_len = seg_len;
+  t.n_seg = n_seg;
+  int64_t nb = 0;
+  for (int s = 0; s < n_seg; ++s) {
+    t.seg[s] = seg[s];
+    const int64_t lo = (int64_t)s * seg_len, cnt = std::min(seg_len, n - lo);
+    if (cnt > 0 && !seg[s]) return FGMM_ERR_INVALID;
+    for (int64_t i = 0; i < cnt; ++i) nb += (seg[s][i] >> 16) == 0;
+  }
+  return fgmm::rans_encode_symtab_segs(t, symbols_or_null, n, nb, out, out_len, stride, ckpt_out);
 }
 
 int fgmm_rans_encode_symtab2(const uint32_t *packed0, const int32_t *symbols0_or_null, int64_t n0, const uint32_t *packed1,

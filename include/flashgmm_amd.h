@@ -101,6 +101,11 @@ int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, con
  *                       work per bitstream behind it, not one bitstream
  *   "enc_ways"    [0]   encode: consecutive bitstreams one worker codes symbol by symbol in turn (several dependency chains
  *                       share a core): 1..4; 0 = two when the call has more bitstreams than workers, else one
+ *   "enc_segs"    [1]   encode: a call in which every bitstream has a host worker of its own (and whose tables are 4 MB and more)
+ *                       lays every table out in four segments of compact channels, LAST SEGMENT FIRST across all bitstreams:
+ *                       rANS encodes backwards, so the encoders start on the tails after an eighth of the transfer and follow the
+ *                       landing; what is left after the last byte is a quarter of a bitstream's job instead of a whole one.
+ *                       0 = whole tables, bitstream after bitstream
  *   "dec_pair"    [0]   decode: a worker takes two ready tasks and decodes them latent by latent in turn
  *                       (fgmm_rans_decode_tab2: 8.9 -> 5.9 ns/symbol per thread with uint16 rows) unless that leaves a
  *                       sleeping worker without one.  0 = when the call has at least two bitstreams per worker and ships
@@ -346,6 +351,13 @@ int fgmm_rans_encode_symtab_n(int ways, const uint32_t *const *packed, const int
 int64_t fgmm_ckpt_count(int64_t n, int64_t stride); /* (n - 1) / stride, 0 for stride <= 0 */
 int fgmm_rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t stride, uint8_t **out,
                                  size_t *out_len, fgmm_ckpt *ckpt_out);
+
+/* The same from a table that lies in `n_seg` (1..4) SEGMENTS of `seg_len` entries (the last may be shorter): seg[s] holds the entries
+ * [s * seg_len, (s + 1) * seg_len).  What the batched encoder does with the tables of a large call: they cross PCIe in segments, LAST
+ * SEGMENT FIRST (rANS encodes backwards), and an encoder follows the landing.  The bitstream (and the checkpoints, stride > 0) are
+ * byte for byte those of the one-piece forms. */
+int fgmm_rans_encode_symtab_segs(const uint32_t *const *seg, int n_seg, int64_t seg_len, const int32_t *symbols_or_null, int64_t n,
+                                 int64_t stride, uint8_t **out, size_t *out_len, fgmm_ckpt *ckpt_out);
 
 /* Host, integer only: edge tables (4-byte headers, rows sequential in latent order, as fgmm_build_cdftab_hip lays them
  * out) -> symbols; the reference's bisection with every float evaluation replaced by a look-up in F_i.  pool_len bounds

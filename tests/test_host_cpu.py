@@ -587,7 +587,7 @@ def test_host_budget_reads_a_cgroup_v1_quota_and_the_affinity_mask(tmp_path):
 def test_host_budget_without_a_quota_is_the_affinity_mask(tmp_path):
     _tree(tmp_path, {"/proc/self/cgroup": "0::/\n", "/sys/fs/cgroup/cpu.max": "max 100000\n"})
     budget, threads = _budget_in_child(tmp_path)
-    assert budget["quota"] is None and budget["cpus"] == budget["affinity"] and threads == min(16, budget["affinity"])
+    assert budget["quota"] is None and budget["cpus"] == budget["affinity"] and threads == min(48, budget["affinity"])
 
 
 # ---- checkpoints: seekable streams without touching the bitstream (fgmm_ckpt) ---------------------------------
@@ -686,3 +686,43 @@ def test_checkpoints_are_verified_never_trusted(oracle):
     # a truncated stream is an error with or without notes
     rc, out, ok = _ckpt_decode(L, enc[:len(enc) // 2 & ~3], hdr, pool, max_bs, bo, 32, ck, n_ck, stride)
     assert rc == 5
+
+
+@pytest.mark.parametrize("stride", [0, 256])
+def test_encoder_follows_a_table_that_lies_in_segments(oracle, stride):
+    """fgmm_rans_encode_symtab_segs: the table in 1..4 segments (what the batched encoder's tables are when they cross PCIe tail
+    first): the bitstream and the checkpoints are byte for byte those of the one-piece encoder - for segment lengths that do
+    and do not divide the table, bypass-coded symbols on segment borders, a table shorter than its segments' capacity, n = 0"""
+    from flashgmm_amd._lib import fgmm_ckpt
+
+    L = _lib.lib()
+    y, sg, mu, pi = T.make_latent(77, M=12, h=16, w=8, zero_frac=0.2)
+    y = y.copy()
+    y.reshape(-1)[::37] *= 40  # bypass-coded symbols
+    sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
+    packed = np.ascontiguousarray(oracle.symtab("polya", sym, s, m, w), np.uint32)
+    n = len(packed)
+    assert (packed >> 16 == 0).sum() > 5
+    want, ck_want, n_ck = _ckpt_encode(L, packed, sym, stride) if stride else (host_encode_symtab(L, packed, sym), None, 0)
+    assert want == oracle.encode_gmm("polya", sym, s, m, w)
+    for n_seg, seg_len in ((1, n), (2, (n + 1) // 2), (3, n // 3 + 5), (4, (n + 3) // 4), (4, n // 2 + 1), (4, n)):
+        for n_used in (n, 0) if seg_len == (n + 3) // 4 else (n,):
+            parts = [np.ascontiguousarray(packed[k * seg_len:(k + 1) * seg_len]) for k in range(n_seg)]
+            ptrs = (C.c_void_p * n_seg)(*[p.ctypes.data if len(p) else None for p in parts])
+            ck = (fgmm_ckpt * max(L.fgmm_ckpt_count(n_used, stride), 1))()
+            out, ln = C.c_void_p(), C.c_size_t()
+            rc = L.fgmm_rans_encode_symtab_segs(ptrs, n_seg, seg_len, sym.ctypes.data_as(C.c_void_p), n_used, stride, C.byref(out), C.byref(ln),
+                                                C.cast(ck, C.c_void_p))
+            assert rc == 0, (n_seg, seg_len)
+            data = C.string_at(out, ln.value)
+            L.fgmm_free(out)
+            if n_used == 0:
+                assert data == bytes.fromhex("0000008000000000")
+                continue
+            assert data == want, (n_seg, seg_len)
+            if stride:
+                assert all(ck[k].x == ck_want[k].x and ck[k].pos == ck_want[k].pos for k in range(n_ck))
+    ptrs = (C.c_void_p * 2)(packed.ctypes.data, None)
+    out, ln = C.c_void_p(), C.c_size_t()
+    assert L.fgmm_rans_encode_symtab_segs(ptrs, 2, n // 2, None, n, 0, C.byref(out), C.byref(ln), None) == 1  # a segment is missing
+    assert L.fgmm_rans_encode_symtab_segs(ptrs, 5, n, None, n, 0, C.byref(out), C.byref(ln), None) == 1
