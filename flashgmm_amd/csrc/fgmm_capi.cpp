@@ -238,7 +238,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, tab_place = 0, tab_spin = kTabSpinLimit, copy_engine = 0, enc_segs = 1, d2_min = 0;
+    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, tab_place = 0, tab_spin = kTabSpinLimit, copy_engine = 0, enc_segs = 1;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -826,7 +826,7 @@ struct DecItem {
   int64_t n = 0;
   size_t o_list = 0, o_rank = 0;
   int hdr_form = 4;
-  uint32_t ef_min = kTabEfMin, d2_min = kTabNoD2;
+  uint32_t ef_min = kTabEfMin;
   int32_t tl = 0;     // latents per block of the single-pass kernel; 0: generic two-pass path
   int64_t nblk = 0;   // blocks of tl latents
   uint64_t table_bytes = 0; // headers + block offsets + rows that crossed PCIe
@@ -1137,8 +1137,6 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     it.hdr_form = tab_hdr_form(it.max_bs);
     it.ef_min = ef_min;
     it.tl = tab_tl(it.max_bs, cap_e);
-    // second-difference rows: long rows of a PCIe-bound call (the host pays 2.5 ns per group of 8 entries to expand one)
-    it.d2_min = it.tl && ef_min != kTabNoEf && ctx->opt.d2_min >= (int64_t)kTabD2Min ? (uint32_t)ctx->opt.d2_min : kTabNoD2;
     it.nblk = it.tl ? (it.n + it.tl - 1) / it.tl : 0;
     if (it.nblk > 0x7FFFFFFFll) it.tl = 0, it.nblk = 0;
     (it.tl ? fast : generic).push_back(i);
@@ -1231,8 +1229,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       p.o_blkoff = off;
       off += align_up(sizeof(uint32_t) * (size_t)(p.blk_end - p.blk_begin), 256);
       // worst case of a row: every edge of the window kept as a uint16, plus the 2-byte form's escape header
-      // (+ W / 8 + 8: a second-difference row whose every group takes the 16-bit form is that much larger than its entries)
-      u.rows_cap += (size_t)lat * (2 * (size_t)(2 * (int64_t)it.max_bs + 2) + 4 + (size_t)(2 * (int64_t)it.max_bs + 2) / 8 + 8) + 2 * (size_t)(p.blk_end - p.blk_begin);
+      u.rows_cap += (size_t)lat * (2 * (size_t)(2 * (int64_t)it.max_bs + 2) + 4) + 2 * (size_t)(p.blk_end - p.blk_begin);
     }
     u.fixed = off;
     u.rows_cap = align_up(u.rows_cap, 256);
@@ -1311,7 +1308,6 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     d.prune = 1;
     d.hdr_form = it.hdr_form;
     d.ef_min = ef_min;
-    d.d2_min = it.d2_min;
     d.tl = it.tl;
     d.count_edges = ctx->profiling ? 1 : 0; // measurement aid only (bench.py's roofline_decode)
     return d;
@@ -1433,7 +1429,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   auto prepare = [&](DecItem &it, int p) {
     if (p == 0) {
       it.t_taken = tr.ms();
-      it.view = TabView{it.ef_min, it.d2_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
+      it.view = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
       if (it.status == FGMM_OK) it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
     }
     const double tw0 = tr.level > 1 ? tr.ms() : 0;
@@ -1657,7 +1653,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   }
 
   for (auto &it : items)
-    if (it.n_seg) it.view = TabView{it.ef_min, it.d2_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
+    if (it.n_seg) it.view = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
   // (a single bitstream too: its decoder starts on piece 0 while this thread is still queuing the later pieces' copies)
   const int n_workers = (int)std::min<int64_t>(std::max(ctx->pool->size(), 1), streams_of_work);
   for (int j = 0; j < n_workers; ++j) ctx->pool->submit(worker);
@@ -1746,7 +1742,6 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     char *d_g = nullptr;
     if ((rc = temp.alloc(ga.off, &d_g))) return rc;
     DecDesc d = base_desc(it);
-    d.d2_min = kTabNoD2;
     d.hdr_form = it.hdr_form == 8 ? 8 : 4; // the generic kernels write 4- or 8-byte headers
     it.hdr_form = d.hdr_form;
     d.hdr = d_g + g_hdr;
@@ -1870,8 +1865,6 @@ const OptName kOpts[] = {
     // encode: 1 = the tables of a call with a worker per bitstream cross PCIe TAIL FIRST in four segments per bitstream and the
     // encoders (which walk a table backwards) follow the landing; 0 = whole tables, bitstream after bitstream
     {"enc_segs", &fgmm_ctx::Opts::enc_segs, 0, 1, "FGMM_ENC_SEGS"},
-    // decode: monotone rows of at least this many entries cross PCIe as second differences (format v6); 0 = none
-    {"d2_min", &fgmm_ctx::Opts::d2_min, 0, 1 << 20, "FGMM_D2_MIN"},
 };
 } // namespace
 
@@ -2492,7 +2485,6 @@ int fgmm_build_tab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const f
   hd->clamp = (flags & FGMM_TAB_CLAMP) ? 1 : 0;
   hd->hdr_form = tab_hdr_form(max_bs);
   hd->ef_min = (flags & FGMM_TAB_RAW_ROWS) ? kTabNoEf : kTabEfMin;
-  hd->d2_min = (flags & FGMM_TAB_D2_ROWS) ? kTabD2Default : kTabNoD2;
   hd->tl = tl;
   hd->blk_begin = 0;
   hd->blk_end = (int32_t)nblk;

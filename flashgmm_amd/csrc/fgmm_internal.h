@@ -58,8 +58,6 @@ struct DecDesc {
   int32_t prune;                 // 1: skip the saturated tails (exact, see tab_window); 0: evaluate all of F
   int32_t hdr_form;              // bytes per header as the host gets them: 2, 4 or 8 (format v5 below)
   uint32_t ef_min;               // rows with at least this many entries are Elias-Fano coded (kTabEfMin / kTabNoEf)
-  uint32_t d2_min;               // tab_kernel: monotone rows of d2_min .. kTabD2MaxCnt entries are second-difference coded (before ef_min is looked at); kTabNoD2: none
-  int32_t pad4_;
   int32_t tl;                    // tab_kernel: latents per block (rows of a block are contiguous, blocks are placed by a cursor)
   // ---- tab_kernel (single pass): the blocks [blk_begin, blk_end) of this item, into one launch's range
   int32_t blk_begin, blk_end;
@@ -168,33 +166,6 @@ FGMM_HD static inline unsigned long long tab_ef_bits(uint32_t cnt, uint32_t l) {
 FGMM_HD static inline unsigned long long tab_row_bytes(uint32_t cnt, uint32_t nonmono, uint32_t ef_min) {
   return tab_row_is_ef(cnt, nonmono, ef_min) ? 2ull * ((tab_ef_bits(cnt, tab_ef_l(cnt)) + 15ull) >> 4) : 2ull * (unsigned long long)cnt;
 }
-// ---- second-difference rows (format v6; tab_kernel only): a CDF is smooth, so E[k] - 2 E[k-1] + E[k-2] is small where the mixture
-// is wide - exactly where rows are long.  A monotone row of d2_min .. kTabD2MaxCnt entries is stored as
-//     uint16 E[0] ; uint16 E[1] - E[0]
-//     width codes: one nibble per group of 8 entries (group g = entries 8g .. 8g+7), group g in byte g >> 1, low nibble first
-//     payload: group after group, 8 slots of w bits each (= w bytes: every group starts on a byte boundary), slot s at bits
-//              [s w, (s + 1) w) of the group's little-endian bit string:
-//                code c <= 14: w = c, the slot of entry k holds zigzag(d2[k]), d2[k] = E[k] - 2 E[k-1] + E[k-2]  (2 <= k < cnt)
-//                code 15     : w = 16, the slot holds d2[k] mod 2^16
-//              slots of k < 2 and of k >= cnt hold zero
-//     padded to an even number of bytes
-// (43.6 B/latent on Kodak-like tables with d2_min 16, against 59.7 with Elias-Fano rows from 49 entries on and 72.6 raw; the host pays
-// 2.5 ns per group to expand a row, so the batched decoder applies the form to long rows only: option "d2_min".)
-// The host expands a row with two prefix sums per group (SIMD, independent of the coder state) and searches the expanded row.
-constexpr uint32_t kTabD2Min = 8;        // the format's floor for d2_min (a group of 8)
-constexpr uint32_t kTabD2Default = 64;   // FGMM_TAB_D2_ROWS of the building blocks; the batched decoder: option "d2_min"
-constexpr uint32_t kTabD2MaxCnt = 2048;  // longer rows stay as they were (the host expands into a fixed buffer)
-constexpr uint32_t kTabNoD2 = 0x7FFFFFFFu;
-FGMM_HD static inline bool tab_row_is_d2(uint32_t cnt, uint32_t nonmono, uint32_t d2_min) { return !nonmono && cnt >= d2_min && cnt <= kTabD2MaxCnt; }
-FGMM_HD static inline uint32_t tab_d2_groups(uint32_t cnt) { return (cnt + 7u) >> 3; }
-FGMM_HD static inline uint32_t tab_d2_width(uint32_t code) { return code == 15u ? 16u : code; }
-// width code of a group from the largest zigzag value of its slots (values of 15 bits and more: the raw 16-bit form)
-FGMM_HD static inline uint32_t tab_d2_code(uint32_t zmax) {
-  uint32_t b = 0;
-  while (b < 15u && (zmax >> b)) ++b;
-  return b; // 0 .. 14: bits of zmax; 15: more than 14
-}
-
 FGMM_HD static inline bool tab_hdr_fits16(int32_t max_bs) { return 2 * (int64_t)max_bs + 2 <= 254; }
 FGMM_HD static inline int tab_hdr_form(int32_t max_bs) { return tab_hdr_fits16(max_bs) ? 2 : (max_bs <= 16382 ? 4 : 8); }
 // tab_kernel: entries of evaluated edges one block may keep in LDS, and the latents per block that guarantees it
@@ -279,7 +250,6 @@ struct TabPiece {
 };
 struct TabView {
   uint32_t ef_min; // as the kernels were told (DecDesc::ef_min)
-  uint32_t d2_min; // ... (DecDesc::d2_min; kTabNoD2: no second-difference rows)
   int hdr_form; // 2, 4, 8
   int tl;       // latents per block (blk_off granularity); ignored when blk_off is null
   int npiece;

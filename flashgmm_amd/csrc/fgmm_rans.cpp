@@ -613,70 +613,6 @@ __attribute__((target("bmi2,popcnt,sse4.1"))) inline int ef_bracket(const EfRow 
   return 1;
 }
 
-// ---- second-difference rows (format v6, fgmm_internal.h) ------------------------------------------------------------
-// bytes of a D2 row whose first byte is p (cnt entries); 0 when the row does not fit [p, end)
-inline size_t d2_row_bytes(const uint8_t *p, const uint8_t *end, uint32_t cnt) {
-  const uint32_t ng = tab_d2_groups(cnt);
-  size_t bytes = 4 + ((size_t)ng + 1) / 2;
-  if ((size_t)(end - p) < bytes) return 0;
-  const uint8_t *nib = p + 4;
-  for (uint32_t g = 0; g < ng; ++g) bytes += tab_d2_width((nib[g >> 1] >> (4 * (g & 1))) & 15u);
-  bytes = (bytes + 1) & ~(size_t)1;
-  return (size_t)(end - p) < bytes ? 0 : bytes;
-}
-// Expands a D2 row into uint16 entries out[0 .. cnt) (out holds cnt rounded up to 8, + 16 of slack for the search): per group of
-// 8 slots one pdep (two beyond 8 bits) spreads the w-bit fields into lanes, two prefix sums (second differences -> first
-// differences -> entries) run in 16-bit lanes modulo 2^16 - exact, every true entry is below 2^16.  Nothing here depends on the
-// coder state: the out-of-order core runs it ahead of the state's dependency chain.  Reads up to 16 bytes past the row
-// (inside the row area's slack).  -> bytes of the row, 0: malformed / does not fit [p, end).
-__attribute__((target("avx2,bmi2,sse4.1,ssse3"))) inline size_t d2_expand(const uint8_t *p, const uint8_t *end, uint32_t cnt, uint16_t *out) {
-  static const uint64_t kMask16[17] = {0, 0x0001000100010001ull, 0x0003000300030003ull, 0x0007000700070007ull, 0x000F000F000F000Full, 0x001F001F001F001Full,
-                                       0x003F003F003F003Full, 0x007F007F007F007Full, 0x00FF00FF00FF00FFull, 0x01FF01FF01FF01FFull, 0x03FF03FF03FF03FFull, 0x07FF07FF07FF07FFull, 0x0FFF0FFF0FFF0FFFull,
-                                       0x1FFF1FFF1FFF1FFFull, 0x3FFF3FFF3FFF3FFFull, 0x7FFF7FFF7FFF7FFFull, 0xFFFFFFFFFFFFFFFFull};
-  const uint32_t ng = tab_d2_groups(cnt);
-  const size_t fixed = 4 + ((size_t)ng + 1) / 2;
-  if ((size_t)(end - p) < fixed + 16) return 0;
-  uint16_t e0, s0;
-  memcpy(&e0, p, 2);
-  memcpy(&s0, p + 2, 2);
-  const uint8_t *nib = p + 4, *pay = p + fixed;
-  const __m128i last = _mm_set1_epi16(0x0F0E); // byte shuffle: lane 7 to every lane
-  const __m128i one = _mm_set1_epi16(1), zero = _mm_setzero_si128();
-  __m128i d1_prev = zero, e_prev = zero;
-  // slots 0 and 1 are empty: E[0] and E[1] - 2 E[0] there make the two sums yield E[0], E[1]
-  uint32_t seed = (uint32_t)e0 | ((uint32_t)(uint16_t)(s0 - e0) << 16);
-  for (uint32_t g = 0; g < ng; ++g) {
-    const uint32_t c = (nib[g >> 1] >> (4 * (g & 1))) & 15u, w = tab_d2_width(c);
-    if (__builtin_expect((size_t)(end - pay) < (size_t)w + 16, 0)) return 0;
-    // no branch on the width (it changes from group to group at no learnable rhythm): four w-bit fields per pdep, whatever w is
-    uint64_t q0, q1;
-    memcpy(&q0, pay, 8);
-    memcpy(&q1, pay + ((4 * w) >> 3), 8);
-    q1 >>= (4 * w) & 7u;
-    const uint64_t m16 = kMask16[w];
-    __m128i v = _mm_set_epi64x((long long)_pdep_u64(q1, m16), (long long)_pdep_u64(q0, m16));
-    // zigzag (z >> 1) ^ -(z & 1) - or, code 15, the field as it is
-    const __m128i zz = _mm_xor_si128(_mm_srli_epi16(v, 1), _mm_sub_epi16(zero, _mm_and_si128(v, one)));
-    v = _mm_blendv_epi8(zz, v, _mm_set1_epi16((short)(c == 15u ? -1 : 0)));
-    v = _mm_or_si128(v, _mm_cvtsi32_si128((int)seed));
-    seed = 0;
-    // second differences -> first differences -> entries: two inclusive prefix sums over 8 lanes + what the groups before left
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 2));
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 4));
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 8));
-    v = _mm_add_epi16(v, d1_prev);
-    d1_prev = _mm_shuffle_epi8(v, last);
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 2));
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 4));
-    v = _mm_add_epi16(v, _mm_slli_si128(v, 8));
-    v = _mm_add_epi16(v, e_prev);
-    e_prev = _mm_shuffle_epi8(v, last);
-    _mm_storeu_si128((__m128i *)(out + 8 * g), v);
-    pay += w;
-  }
-  return ((size_t)(pay - p) + 1) & ~(size_t)1;
-}
-
 } // namespace
 
 // The decoder proper, resumable piece by piece (a host worker may follow several bitstreams as their tables land):
@@ -728,9 +664,8 @@ struct PieceRun {
   const uint8_t *rowp = nullptr, *rows_end = nullptr;
   int32_t max_bs = 0;
   int hdr_form = 4;
-  uint32_t ef_min = kTabEfMin, d2_min = kTabNoD2;
+  uint32_t ef_min = kTabEfMin;
   int rc = FGMM_OK;
-  alignas(32) uint16_t d2buf[kTabD2MaxCnt + 8 + 32]; // a second-difference row, expanded (+ what the search reads past it)
 
   // false: nothing to do (rc says whether that is an error)
   bool begin(TabDecoder &d, int k) {
@@ -753,7 +688,6 @@ struct PieceRun {
     W = 2 * (int64_t)max_bs + 2;
     hdr_form = d.tv->hdr_form;
     ef_min = d.tv->ef_min;
-    d2_min = d.tv->d2_min;
     // a search may read up to 32 bytes past its row: rows must end that far before the end of the area
     rows_end = pc->rows + (pc->rows_len >= 32 ? pc->rows_len - 32 : 0);
     rowp = pc->rows; // sequential placement: a running sum, never stored
@@ -784,7 +718,6 @@ struct PieceRun {
     W = 2 * (int64_t)max_bs + 2;
     hdr_form = d.tv->hdr_form;
     ef_min = d.tv->ef_min;
-    d2_min = d.tv->d2_min;
     rows_end = pc->rows + (pc->rows_len >= 32 ? pc->rows_len - 32 : 0);
     tl = d.tv->tl;
     blk = (d.i - i_beg) / tl;
@@ -820,15 +753,8 @@ struct PieceRun {
       cnt = (int64_t)((h >> 32) & 0x7FFFFFFFu);
       nonmono = (uint32_t)(h >> 63);
     }
-    if (cnt < 1) { rc = FGMM_ERR_INVALID; return; }
-    uint64_t rbytes;
-    if (tab_row_is_d2((uint32_t)cnt, nonmono, d2_min)) {
-      rbytes = d2_row_bytes(rowp, rows_end, (uint32_t)cnt);
-      if (!rbytes) { rc = FGMM_ERR_INVALID; return; }
-    } else {
-      rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
-    }
-    if ((uint64_t)(rows_end - rowp) < rbytes) { rc = FGMM_ERR_INVALID; return; }
+    const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
+    if (cnt < 1 || (uint64_t)(rows_end - rowp) < rbytes) { rc = FGMM_ERR_INVALID; return; }
     rowp += rbytes;
     ++i;
   }
@@ -898,21 +824,12 @@ struct PieceRun {
     }
     // a row covers indices [a + max_bs, a + max_bs + cnt) of the W-entry virtual table
     if (__builtin_expect(cnt < 1 || a < -(int64_t)max_bs || a + max_bs + cnt > W, 0)) { rc = FGMM_ERR_INVALID; return; }
-    const bool is_d2 = tab_row_is_d2((uint32_t)cnt, nonmono, d2_min);
-    const bool is_ef = !is_d2 && tab_row_is_ef((uint32_t)cnt, nonmono, ef_min);
+    const bool is_ef = tab_row_is_ef((uint32_t)cnt, nonmono, ef_min);
+    const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
+    if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; return; }
     const bool zero_before = a > -(int64_t)max_bs; // rows start at their first non-zero edge; F[v < a] = 0 (v >= -max_bs exists)
     const uint8_t *row_bytes = rowp;
-    if (is_d2) { // expanded here, before the coder state is looked at: the search below sees plain uint16 entries
-      if (__builtin_expect(rows_end - rowp < 6, 0)) { rc = FGMM_ERR_INVALID; return; }
-      const size_t used = d2_expand(rowp, rows_end + 32, (uint32_t)cnt, d2buf);
-      if (__builtin_expect(!used || (uint64_t)(rows_end - rowp) < used, 0)) { rc = FGMM_ERR_INVALID; return; }
-      rowp += used;
-      row_bytes = reinterpret_cast<const uint8_t *>(d2buf);
-    } else {
-      const uint64_t rbytes = tab_row_bytes((uint32_t)cnt, nonmono, ef_min);
-      if (__builtin_expect((uint64_t)(rows_end - rowp) < rbytes, 0)) { rc = FGMM_ERR_INVALID; return; }
-      rowp += rbytes;
-    }
+    rowp += rbytes;
 
     const uint32_t cf = (uint32_t)(dec.x & 0xFFFFu); // Rans64DecGet
     int32_t value;
@@ -1309,7 +1226,7 @@ int fgmm_rans_decode_tab_ckpt(const uint8_t *encoded, size_t encoded_len, const 
   if (hdr_form == 2 && !fgmm::tab_hdr_fits16(max_bs)) return FGMM_ERR_INVALID;
   if (hdr_form == 4 && max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_INVALID;
   const fgmm::TabPiece pc{hdr, blk_off, rows, (size_t)rows_len, n};
-  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, (flags & FGMM_TAB_D2_ROWS) ? fgmm::kTabD2Default : fgmm::kTabNoD2, hdr_form, tl, 1, &pc, nullptr, nullptr};
+  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, hdr_form, tl, 1, &pc, nullptr, nullptr};
   bool ok = true;
   int hard = FGMM_OK; // an error that is not the notes' fault
   // ONE decoder for all segments: begin() copies a misaligned bitstream whole, which must not happen once per segment
@@ -1389,8 +1306,7 @@ int fgmm_rans_decode_cdftab(const uint8_t *encoded, size_t encoded_len, const ui
   if (n > 0 && (!hdr || !pool)) return FGMM_ERR_INVALID;
   if (max_bs < 0 || max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_UNSUPPORTED; // this entry point takes 4-byte headers
   const fgmm::TabPiece pc{hdr, nullptr, pool, (size_t)pool_len, n};
-  if (flags & FGMM_TAB_D2_ROWS) return FGMM_ERR_INVALID; // (second-difference rows are the single-pass kernel's)
-  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, fgmm::kTabNoD2, 4, 0, 1, &pc, nullptr, nullptr};
+  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, 4, 0, 1, &pc, nullptr, nullptr};
   return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
 }
 
@@ -1402,7 +1318,7 @@ int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void 
   if (hdr_form == 2 && !fgmm::tab_hdr_fits16(max_bs)) return FGMM_ERR_INVALID;
   if (hdr_form == 4 && max_bs > FGMM_MAX_BS_H4) return FGMM_ERR_INVALID;
   const fgmm::TabPiece pc{hdr, blk_off, rows, (size_t)rows_len, n};
-  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, (flags & FGMM_TAB_D2_ROWS) ? fgmm::kTabD2Default : fgmm::kTabNoD2, hdr_form, tl, 1, &pc, nullptr, nullptr};
+  const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, hdr_form, tl, 1, &pc, nullptr, nullptr};
   return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
 }
 
@@ -1419,7 +1335,7 @@ int fgmm_rans_decode_tab2(const fgmm_tab_ref *a, const fgmm_tab_ref *b) {
     if (r.max_bs < 0 || r.max_bs > FGMM_MAX_BS || (r.blk_off && r.tl < 1)) return FGMM_ERR_INVALID;
     if ((r.hdr_form == 2 && !fgmm::tab_hdr_fits16(r.max_bs)) || (r.hdr_form == 4 && r.max_bs > FGMM_MAX_BS_H4)) return FGMM_ERR_INVALID;
     pc[k] = fgmm::TabPiece{r.hdr, r.blk_off, r.rows, (size_t)r.rows_len, r.n};
-    tv[k] = fgmm::TabView{(r.flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, (r.flags & FGMM_TAB_D2_ROWS) ? fgmm::kTabD2Default : fgmm::kTabNoD2, r.hdr_form, r.tl, 1, &pc[k], nullptr, nullptr};
+    tv[k] = fgmm::TabView{(r.flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, r.hdr_form, r.tl, 1, &pc[k], nullptr, nullptr};
   }
   for (int k = 0; k < 2; ++k) rc[k] = td[k].begin(t[k]->encoded, t[k]->encoded_len, &tv[k], t[k]->n, t[k]->max_bs, t[k]->out_symbols);
   if (rc[0] == FGMM_OK && rc[1] == FGMM_OK) fgmm::rans_decode_pieces2(td[0], 0, td[1], 0, &rc[0], &rc[1]);

@@ -315,11 +315,7 @@ struct TabSmem { // carve-up of the dynamic LDS of one block (every offset a mul
   uint32_t *scratch; // [16]
   uint32_t *efoff;   // [tl + 1] Elias-Fano rows before latent l: entries (low 16 bits) | words of unary high parts (high 16 bits)
   uint32_t *bitmap;  // [cap_e / 32 + 9 * tl] the unary high parts of the block's Elias-Fano rows
-  uint32_t *gofs;    // [tl + 1] second-difference rows: groups of 8 entries before latent l
-  uint8_t *gw;       // [cap_e / 8 + tl] per group: bits per slot (0 .. 14, 16)
-  uint32_t *d2head;  // [tl] second-difference rows: E[0] | (E[1] - E[0]) << 16 (their storage is overwritten by the packed payload)
-  uint32_t *E32;     // [cap_e / 2 + tl] evaluated edges, two uint16 per word: edge k of latent l's window is uint16 2 * (offP[l] + l) + k
-                     // (one spare pair per latent: the packed payload of a second-difference row's last group may need it)
+  uint32_t *E32;     // [cap_e / 2] evaluated edges, two uint16 per word: entry k of latent l is uint16 2 * offP[l] + k
   __device__ __forceinline__ TabSmem(unsigned char *base, int tl, int cap_e) {
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -337,16 +333,13 @@ struct TabSmem { // carve-up of the dynamic LDS of one block (every offset a mul
     scratch = reinterpret_cast<uint32_t *>(take(64));
     efoff = reinterpret_cast<uint32_t *>(take(4 * ((size_t)tl + 1)));
     bitmap = reinterpret_cast<uint32_t *>(take(4 * ((size_t)cap_e / 32 + 9 * (size_t)tl)));
-    gofs = reinterpret_cast<uint32_t *>(take(4 * ((size_t)tl + 1)));
-    gw = reinterpret_cast<uint8_t *>(take((size_t)cap_e / 8 + (size_t)tl));
-    d2head = reinterpret_cast<uint32_t *>(take(4 * (size_t)tl));
-    E32 = reinterpret_cast<uint32_t *>(take(2 * (size_t)cap_e + 4 * (size_t)tl));
+    E32 = reinterpret_cast<uint32_t *>(take(2 * (size_t)cap_e));
   }
 };
 static size_t tab_smem_bytes(int tl, int cap_e) {
   auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  return r(64 * (size_t)tl) + r(4 * ((size_t)tl + 1)) * 4 + r(4 * (size_t)tl) * 2 + r(2 * (size_t)tl) + r((size_t)tl) + 64 +
-         r(4 * ((size_t)cap_e / 32 + 9 * (size_t)tl)) + r((size_t)cap_e / 8 + (size_t)tl) + r(4 * (size_t)tl) + r(2 * (size_t)cap_e + 4 * (size_t)tl);
+  return r(64 * (size_t)tl) + r(4 * ((size_t)tl + 1)) * 3 + r(4 * (size_t)tl) * 2 + r(2 * (size_t)tl) + r((size_t)tl) + 64 +
+         r(4 * ((size_t)cap_e / 32 + 9 * (size_t)tl)) + r(2 * (size_t)cap_e);
 }
 
 // block-wide exclusive scan for up to kBlock values held by the first threads (others pass 0); total in *total
@@ -500,7 +493,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
         c0 = mix4_slow<MODE>(x0, mu[0], mu[1], mu[2], mu[3], s4[0], s4[1], s4[2], s4[3], pi[0], pi[1], pi[2], pi[3]);
         c1 = mix4_slow<MODE>(x1, mu[0], mu[1], mu[2], mu[3], s4[0], s4[1], s4[2], s4[3], pi[0], pi[1], pi[2], pi[3]);
       }
-      S.E32[t + (uint32_t)l] = quant16(c0) | (quant16(c1) << 16);
+      S.E32[t] = quant16(c0) | (quant16(c1) << 16);
     }
   }
   __syncthreads();
@@ -508,15 +501,15 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
 
   TAB_T(1); // phase 2
   // ---- phase 3: trim every row, header, row size ------------------------------------------------------------------
-  uint32_t bytes = 0, ng_mine = 0; // ng_mine: groups of 8 entries of this lane's row when it is second-difference coded
+  uint32_t bytes = 0;
   if (tid < nl) {
     const uint32_t w = S.win[tid];
     const int j_lo = (int)(w & 0xFFFFu), len = (int)(w >> 16), j_hi = j_lo + len;
-    const uint16_t *e = E16 + 2 * ((size_t)S.offP[tid] + (size_t)tid);
+    const uint16_t *e = E16 + 2 * (size_t)S.offP[tid];
     TrimState ts;
     ts.init(j_lo);
     // entries two at a time (one 32-bit LDS read), eight reads in flight: the loop is bound by LDS latency otherwise
-    const uint32_t *e32 = S.E32 + S.offP[tid] + tid;
+    const uint32_t *e32 = S.E32 + S.offP[tid];
     int k = 0;
 #pragma unroll 1
     for (; k + 16 <= len; k += 16) {
@@ -536,8 +529,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     const uint32_t nm = ts.nonmono ? 1u : 0u;
     S.meta[tid] = (uint32_t)a_idx | (cnt << 16);
     if (nm) S.flags[tid] |= 2;
-    bytes = tab_row_is_d2(cnt, nm, d.d2_min) ? 0u : (uint32_t)tab_row_bytes(cnt, nm, d.ef_min); // (second-difference rows: below)
-    ng_mine = tab_row_is_d2(cnt, nm, d.d2_min) ? tab_d2_groups(cnt) : 0u;
+    bytes = (uint32_t)tab_row_bytes(cnt, nm, d.ef_min);
     const int64_t li = (int64_t)(b - d.blk_begin) * tl + tid; // latent index within this launch's header array
     if (d.hdr_form == 2) {
       const uint32_t c8 = nm ? kHdr2Escape : cnt; // W <= 254 here, so cnt <= 254
@@ -549,106 +541,6 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       static_cast<unsigned long long *>(d.hdr_out)[li] = tab_hdr8_pack(a_idx - max_bs, cnt, nm);
     }
   }
-  // what a lane keeps of the row it is working on (reloaded from LDS only when it moves on to another latent)
-  struct RowRef {
-    const uint16_t *e; // first evaluated edge of the latent
-    int j_lo, j_hi, a_idx;
-    uint32_t cnt, nm, T_sat, aux; // aux: first entry / first word of the unary part of the row among the block's Elias-Fano rows
-    uint32_t efl, HB, LB, M;      // Elias-Fano row: low bits, bits of the unary part, first bit of the low parts, 2^20 / efl rounded up; efl = 0: raw row
-    bool d2;                      // second-difference row (then efl = 0)
-    uint32_t d2_g, d2_acc;        // ... the group the lane's walk through the row's payload stands in, payload bytes before it
-    uint32_t d2_base;             // ... byte offset (in the edge storage) of the row's first entry: group g's packed payload sits at + 16 g
-    __device__ __forceinline__ void load(const TabSmem &S, const uint16_t *E16, int l, uint32_t ef_min, uint32_t d2_min = kTabNoD2) {
-      const uint32_t w = S.win[l], mt = S.meta[l];
-      j_lo = (int)(w & 0xFFFFu);
-      j_hi = j_lo + (int)(w >> 16);
-      a_idx = (int)(mt & 0xFFFFu);
-      cnt = mt >> 16;
-      nm = (S.flags[l] >> 1) & 1u;
-      T_sat = S.tsat[l];
-      e = E16 + 2 * ((size_t)S.offP[l] + (size_t)l) - j_lo; // e[idx] for j_lo <= idx < j_hi
-      aux = S.efoff[l];
-      d2 = tab_row_is_d2(cnt, nm, d2_min);
-      d2_g = d2_acc = 0;
-      d2_base = 2u * (2u * (S.offP[l] + (uint32_t)l) + (uint32_t)(a_idx - j_lo));
-      efl = !d2 && tab_row_is_ef(cnt, nm, ef_min) ? tab_ef_l(cnt) : 0u;
-      HB = efl ? tab_ef_hb(cnt, efl) : 0u;
-      LB = (HB + 7u) & ~7u;
-      M = efl == 8u ? (1u << 20) / 8u + 1u : (efl == 12u ? (1u << 20) / 12u + 1u : (efl ? (1u << 20) / efl + 1u : 0u)); // no division for the two widths in use
-    }
-    // entry k of the row: F[a_idx + k] — an evaluated edge, or one of the two constants outside the evaluation window
-    __device__ __forceinline__ uint32_t entry(uint32_t k) const {
-      const int idx = a_idx + (int)k;
-      return idx < j_lo ? 0u : (idx >= j_hi ? T_sat : (uint32_t)e[idx]);
-    }
-  };
-
-  // ---- phase 3b-d: second-difference rows (format v6): a width per group of 8 entries, then the row's size ----------------
-  // 3b: groups before each latent
-  uint32_t GT;
-  const uint32_t exG = tab_scan(ng_mine, S.scratch, &GT);
-  if (tid < nl) S.gofs[tid] = exG;
-  if (tid == 0) S.gofs[nl] = GT;
-  __syncthreads();
-  // 3c: FLATTENED over (row, group), 256 groups at a time: the group's eight slots zigzag(E[k] - 2 E[k-1] + E[k-2]), the bits
-  // the widest needs, and the PACKED payload (8 slots x w bits = w <= 16 bytes) written over the group's own eight entries - what
-  // phase 5b copies out byte by byte.  A group reads the last two entries of the group before it: all reads of a round come
-  // before its writes, and the rounds run from the last groups to the first (a write never lands on entries still to be read).
-  for (int round = (int)((GT + kBlock - 1u) / kBlock) - 1; round >= 0; --round) {
-    const uint32_t t = (uint32_t)round * kBlock + (uint32_t)tid;
-    unsigned long long pk_lo = 0, pk_hi = 0; // the group's 128-bit payload
-    uint32_t w = 0, base = 0, n_u16 = 0;
-    if (t < GT) {
-      const int l = find_owner(S.gofs, nl, t);
-      const uint32_t g = t - S.gofs[l];
-      RowRef R;
-      R.load(S, E16, l, d.ef_min, d.d2_min);
-      const uint32_t k0 = 8u * g, m = min(8u, R.cnt - k0);
-      int e2 = k0 >= 2u ? (int)R.entry(k0 - 2u) : 0, e1 = k0 >= 1u ? (int)R.entry(k0 - 1u) : 0; // E[k-2], E[k-1]
-      uint32_t code[8], raw[8], zmax = 0;
-#pragma unroll
-      for (uint32_t sl = 0; sl < 8u; ++sl) {
-        const uint32_t k = k0 + sl;
-        int dd = 0;
-        if (sl < m) {
-          const int e0 = (int)R.entry(k);
-          if (k >= 2u) dd = e0 - 2 * e1 + e2;
-          if (g == 0u && sl == 1u) S.d2head[l] = (uint32_t)e1 | (((uint32_t)(e0 - e1) & 0xFFFFu) << 16); // E[0] | E[1] - E[0]
-          e2 = e1;
-          e1 = e0;
-        }
-        code[sl] = (uint32_t)(dd >= 0 ? 2 * dd : -2 * dd - 1);
-        raw[sl] = (uint32_t)dd & 0xFFFFu;
-        zmax = max(zmax, code[sl]);
-      }
-      w = tab_d2_width(tab_d2_code(zmax));
-      S.gw[t] = (uint8_t)w;
-#pragma unroll
-      for (uint32_t sl = 0; sl < 8u; ++sl) { // slot sl at bits [sl w, (sl + 1) w) of the group's 128-bit string
-        const unsigned long long v = w == 16u ? raw[sl] : code[sl];
-        const uint32_t bit = sl * w;
-        if (bit < 64u) {
-          pk_lo |= v << bit;
-          if (bit + w > 64u) pk_hi |= v >> (64u - bit);
-        } else {
-          pk_hi |= v << (bit - 64u);
-        }
-      }
-      base = R.d2_base / 2u + k0;          // uint16 index of the group's first entry in the edge storage
-      n_u16 = (m * w + 15u) >> 4;          // what of the payload is not zero anyway (slots of k >= cnt are)
-    }
-    __syncthreads();
-    uint16_t *Ew = reinterpret_cast<uint16_t *>(S.E32);
-    for (uint32_t q = 0; q < n_u16; ++q) Ew[base + q] = (uint16_t)((q < 4u ? pk_lo : pk_hi) >> (16u * (q & 3u)));
-    __syncthreads();
-  }
-  // 3d: lane = latent: where each group's payload starts, the row's bytes
-  if (tid < nl && ng_mine) {
-    const uint32_t g0 = S.gofs[tid];
-    uint32_t acc = 0;
-    for (uint32_t g = 0; g < ng_mine; ++g) acc += S.gw[g0 + g];
-    bytes = (4u + ((ng_mine + 1u) >> 1) + acc + 1u) & ~1u;
-  }
   TAB_T(2); // phase 3
   // ---- phase 4: place the block's rows; Elias-Fano rows: entries and upper words before each ------------------------
   uint32_t B, EFT;
@@ -657,7 +549,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   uint32_t ef_pack = 0;
   if (tid < nl) {
     const uint32_t cnt = S.meta[tid] >> 16, nm = (S.flags[tid] >> 1) & 1u;
-    if (!tab_row_is_d2(cnt, nm, d.d2_min) && tab_row_is_ef(cnt, nm, d.ef_min)) ef_pack = cnt | (((tab_ef_hb(cnt, tab_ef_l(cnt)) + 31u) >> 5) << 16); // both sums stay below 2^16 (cap_e <= 32768)
+    if (tab_row_is_ef(cnt, nm, d.ef_min)) ef_pack = cnt | (((tab_ef_hb(cnt, tab_ef_l(cnt)) + 31u) >> 5) << 16); // both sums stay below 2^16 (cap_e <= 32768)
   }
   const uint32_t exEF = tab_scan(ef_pack, S.scratch, &EFT);
   if (tid < nl) {
@@ -692,6 +584,34 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
   }
   if (!d.placement && !S.scratch[10]) return; // the launch's row area is too small: the host re-runs it with what the cursor asks for
 
+  // what a lane keeps of the row it is working on (reloaded from LDS only when it moves on to another latent)
+  struct RowRef {
+    const uint16_t *e; // first evaluated edge of the latent
+    int j_lo, j_hi, a_idx;
+    uint32_t cnt, nm, T_sat, aux; // aux: first entry / first word of the unary part of the row among the block's Elias-Fano rows
+    uint32_t efl, HB, LB, M;      // Elias-Fano row: low bits, bits of the unary part, first bit of the low parts, 2^20 / efl rounded up; efl = 0: raw row
+    __device__ __forceinline__ void load(const TabSmem &S, const uint16_t *E16, int l, uint32_t ef_min) {
+      const uint32_t w = S.win[l], mt = S.meta[l];
+      j_lo = (int)(w & 0xFFFFu);
+      j_hi = j_lo + (int)(w >> 16);
+      a_idx = (int)(mt & 0xFFFFu);
+      cnt = mt >> 16;
+      nm = (S.flags[l] >> 1) & 1u;
+      T_sat = S.tsat[l];
+      e = E16 + 2 * (size_t)S.offP[l] - j_lo; // e[idx] for j_lo <= idx < j_hi
+      aux = S.efoff[l];
+      efl = tab_row_is_ef(cnt, nm, ef_min) ? tab_ef_l(cnt) : 0u;
+      HB = efl ? tab_ef_hb(cnt, efl) : 0u;
+      LB = (HB + 7u) & ~7u;
+      M = efl == 8u ? (1u << 20) / 8u + 1u : (efl == 12u ? (1u << 20) / 12u + 1u : (efl ? (1u << 20) / efl + 1u : 0u)); // no division for the two widths in use
+    }
+    // entry k of the row: F[a_idx + k] — an evaluated edge, or one of the two constants outside the evaluation window
+    __device__ __forceinline__ uint32_t entry(uint32_t k) const {
+      const int idx = a_idx + (int)k;
+      return idx < j_lo ? 0u : (idx >= j_hi ? T_sat : (uint32_t)e[idx]);
+    }
+  };
+
   TAB_T(3); // phase 4
   // ---- phase 5a: unary high parts of the Elias-Fano rows, FLATTENED over their entries: bit ((E_j >> l) + j) ---------
   // Every lane takes a run of CONSECUTIVE entries (not every 64th): it stays inside one row for nearly all of them - the
@@ -710,7 +630,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       }
       int l = lo;
       RowRef R;
-      R.load(S, E16, l, d.ef_min, d.d2_min);
+      R.load(S, E16, l, d.ef_min);
       uint32_t l_beg = R.aux & 0xFFFFu, l_end = S.efoff[l + 1] & 0xFFFFu;
       uint32_t acc_w = ~0u, acc = 0; // bitmap word the gathered bits belong to | the bits
       for (; t < t_end; ++t) {
@@ -720,7 +640,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
             l_beg = l_end;
             l_end = S.efoff[l + 1] & 0xFFFFu;
           } while (t >= l_end);
-          R.load(S, E16, l, d.ef_min, d.d2_min);
+          R.load(S, E16, l, d.ef_min);
         }
         const uint32_t k = t - l_beg, pos = (R.entry(k) >> R.efl) + k;
         const uint32_t wi = (R.aux >> 16) + (pos >> 5);
@@ -805,33 +725,10 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       l = find_owner(S.rowoff, nl, 4 * q);
       r_beg = S.rowoff[l];
       r_end = S.rowoff[l + 1];
-      R.load(S, E16, l, d.ef_min, d.d2_min);
+      R.load(S, E16, l, d.ef_min);
     }
     // 16-bit unit h of the row R describes
-    // byte o (>= 4) of a second-difference row: a byte of width codes, or a byte of the payload phase 3c packed in place
-    auto d2_byte = [&](uint32_t o) -> uint32_t {
-      const uint32_t ng = tab_d2_groups(R.cnt), P0 = 4u + ((ng + 1u) >> 1), g0 = S.gofs[l];
-      if (o < P0) {
-        const uint32_t g = 2u * (o - 4u);
-        const uint32_t wa = S.gw[g0 + g], wb = g + 1u < ng ? (uint32_t)S.gw[g0 + g + 1u] : 0u;
-        return (wa == 16u ? 15u : wa) | ((wb == 16u ? 15u : wb) << 4);
-      }
-      // the group payload byte po lies in: a lane asks for the bytes of a row in ascending order, so the walk only moves forward
-      const uint32_t po = o - P0;
-      uint32_t w = S.gw[g0 + R.d2_g];
-      while (po >= R.d2_acc + w && R.d2_g + 1u < ng) {
-        R.d2_acc += w;
-        w = S.gw[g0 + ++R.d2_g];
-      }
-      const uint32_t g = R.d2_g, bsel = po - R.d2_acc, m = min(8u, R.cnt - 8u * g);
-      if (bsel >= ((m * w + 7u) >> 3)) return 0u; // slots beyond the row, the row's padding byte
-      return reinterpret_cast<const uint8_t *>(S.E32)[R.d2_base + 16u * g + bsel];
-    };
     auto unit = [&](uint32_t h) -> uint32_t {
-      if (R.d2) { // uint16 E[0]; uint16 E[1] - E[0]; width codes; payload
-        if (h < 2u) return (S.d2head[l] >> (16u * h)) & 0xFFFFu;
-        return d2_byte(2u * h) | (d2_byte(2u * h + 1u) << 8);
-      }
       const bool escaped = d.hdr_form == 2 && R.nm;
       if (escaped && h < 2) return (tab_hdr_pack(R.a_idx - max_bs, R.cnt, 1u) >> (16 * h)) & 0xFFFFu;
       if (!R.efl) return R.entry(escaped ? h - 2 : h);
@@ -861,7 +758,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
             r_beg = r_end;
             r_end = S.rowoff[l + 1];
           } while (4 * q >= r_end);
-          R.load(S, E16, l, d.ef_min, d.d2_min);
+          R.load(S, E16, l, d.ef_min);
         }
         const uint32_t h = (4 * q - r_beg) >> 1;
         val = unit(h);
@@ -871,7 +768,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
           ++l;
           r_beg = r_end;
           r_end = S.rowoff[l + 1];
-          R.load(S, E16, l, d.ef_min, d.d2_min);
+          R.load(S, E16, l, d.ef_min);
           val |= unit(0) << 16;
         }
       }

@@ -311,15 +311,6 @@ int fgmm_build_symtab_hip(fgmm_ctx *ctx, void *stream, const int32_t *symbols, c
 #define FGMM_TAB_CLAMP 2    /* flags: clamp sigma to [0.11, 256] first (the entropy-model path's kernel variant) */
 #define FGMM_TAB_RAW_ROWS 4 /* flags: no Elias-Fano rows, every row as uint16 entries (35 % more bytes, 2-3x faster to search:
                                what the batched decoder chooses for calls with fewer bitstreams than host workers) */
-#define FGMM_TAB_D2_ROWS 8  /* flags (fgmm_build_tab_hip and the decoders of its tables): monotone rows of 16 .. 2048 entries as SECOND
-                               DIFFERENCES (format v6): uint16 E[0]; uint16 E[1] - E[0]; one width nibble per group of 8 entries (group g
-                               in byte g >> 1, low nibble first); then per group 8 slots of w bits (w bytes; slot s at bits [s w, (s+1) w)
-                               of the group's little-endian bit string): code c <= 14: w = c, zigzag(E[k] - 2 E[k-1] + E[k-2]); c = 15:
-                               w = 16, that difference modulo 2^16; slots of k < 2 and k >= cnt are zero; padded to an even number of
-                               bytes.  A CDF is smooth where the mixture is wide - where rows are long: 43.6 B/latent on Kodak-like tables
-                               against 59.7 with Elias-Fano rows from 49 entries on.  The host expands a row with two prefix sums per group
-                               (SIMD, independent of the coder state) and searches it like a uint16 row.  Takes precedence over the
-                               Elias-Fano form for the rows it applies to */
 #define FGMM_HDR_FORM(max_bs) ((2 * (int64_t)(max_bs) + 2 <= 254) ? 2 : ((max_bs) <= FGMM_MAX_BS_H4 ? 4 : 8))
 int fgmm_build_cdftab_hip(fgmm_ctx *ctx, void *stream, const float *scales, const float *means,
                           const float *weights, int64_t n, int64_t stride_n, int64_t stride_k, int mode,

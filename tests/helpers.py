@@ -9,8 +9,6 @@ import numpy as np
 
 
 EF_MIN = 14
-D2_MIN = 1 << 30  # rows of at least this many entries are second-difference coded (format v6; 64 with FGMM_TAB_D2_ROWS)
-D2_MAX_CNT = 2048
 MAX_BS_H4 = 16382
 
 
@@ -18,61 +16,8 @@ def hdr_form(max_bs: int) -> int:
     return 2 if 2 * max_bs + 2 <= 254 else (4 if max_bs <= MAX_BS_H4 else 8)
 
 
-def row_is_d2(cnt: int, nonmono: int) -> bool:
-    return D2_MIN <= cnt <= D2_MAX_CNT and not nonmono
-
-
 def row_is_ef(cnt: int, nonmono: int) -> bool:
-    return cnt >= EF_MIN and not nonmono and not row_is_d2(cnt, nonmono)
-
-
-def d2_encode(row: np.ndarray) -> np.ndarray:
-    """a monotone row (int64 entries) -> its second-difference form (format v6, include/flashgmm_amd.h FGMM_TAB_D2_ROWS)"""
-    cnt = len(row)
-    ng = (cnt + 7) // 8
-    d2 = np.zeros(8 * ng, np.int64)
-    d2[2:cnt] = row[2:] - 2 * row[1:-1] + row[:-2]
-    zz = np.where(d2 >= 0, 2 * d2, -2 * d2 - 1)
-    out = [np.array([row[0], row[1] - row[0]], "<u2").view(np.uint8)]
-    nib = np.zeros((ng + 1) // 2, np.uint8)
-    pay = []
-    for g in range(ng):
-        zmax = int(zz[8 * g:8 * g + 8].max())
-        code = min(zmax.bit_length(), 15)
-        nib[g >> 1] |= code << (4 * (g & 1))
-        w = 16 if code == 15 else code
-        vals = (d2[8 * g:8 * g + 8] & 0xFFFF) if code == 15 else zz[8 * g:8 * g + 8]
-        bits = ((vals[:, None] >> np.arange(w)[None, :]) & 1).astype(np.uint8).reshape(-1)  # slot s at bits [s w, (s+1) w)
-        pay.append(np.packbits(bits, bitorder="little"))
-        assert len(pay[-1]) == w
-    body = np.concatenate(out + [nib] + pay)
-    return np.concatenate([body, np.zeros(len(body) & 1, np.uint8)])
-
-
-def d2_decode(buf: np.ndarray, cnt: int):
-    """-> (row int64[cnt], bytes of the row)"""
-    ng = (cnt + 7) // 8
-    e0, s0 = (int(v) for v in buf[:4].view("<u2"))
-    nib = buf[4:4 + (ng + 1) // 2]
-    off = 4 + (ng + 1) // 2
-    d2 = np.zeros(8 * ng, np.int64)
-    for g in range(ng):
-        code = (int(nib[g >> 1]) >> (4 * (g & 1))) & 15
-        w = 16 if code == 15 else code
-        bits = np.unpackbits(buf[off:off + w], bitorder="little").astype(np.int64).reshape(8, w) if w else np.zeros((8, 0), np.int64)
-        vals = (bits << np.arange(w)[None, :]).sum(1)
-        if code == 15:
-            vals = np.where(vals >= 32768, vals - 65536, vals)
-        else:
-            vals = np.where(vals & 1, -((vals + 1) >> 1), vals >> 1)
-        d2[8 * g:8 * g + 8] = vals
-        off += w
-    assert not d2[:2].any() and not d2[cnt:].any()  # the empty slots are zero
-    d1 = np.zeros(cnt, np.int64)
-    d1[1] = s0
-    d1[2:] = s0 + np.cumsum(d2[2:cnt])
-    row = (e0 + np.cumsum(d1)) & 0xFFFF
-    return row, (off + 1) & ~1
+    return cnt >= EF_MIN and not nonmono
 
 
 def ef_l(cnt: int) -> int:
@@ -102,8 +47,6 @@ def _trim_row(F: np.ndarray):
 
 def _row_payload(row: np.ndarray, nonmono: int):
     cnt = len(row)
-    if row_is_d2(cnt, nonmono):
-        return [d2_encode(row)]
     if row_is_ef(cnt, nonmono):
         l = ef_l(cnt)
         HB = cnt + (65536 >> l)
@@ -198,10 +141,7 @@ def expand_trimmed(hdr: np.ndarray, pool: np.ndarray, max_bs: int, blk_off=None,
             a = h & 0xFFFFFFFF
             a = a - (1 << 32) if a >= (1 << 31) else a
             cnt, nonmono = (h >> 32) & 0x7FFFFFFF, h >> 63
-        if row_is_d2(cnt, nonmono):
-            row, used = d2_decode(pool[off:], cnt)
-            off += used - row_bytes(cnt, nonmono)  # (the common advance below adds row_bytes)
-        elif row_is_ef(cnt, nonmono):
+        if row_is_ef(cnt, nonmono):
             l = ef_l(cnt)
             HB = cnt + (65536 >> l)
             bits = np.unpackbits(pool[off:off + row_bytes(cnt, nonmono)], bitorder="little").astype(np.int64)
@@ -235,8 +175,7 @@ def host_encode_symtab(lib, packed: np.ndarray, symbols) -> bytes:
 
 
 def _flags():
-    # FGMM_TAB_RAW_ROWS when the tables were built without Elias-Fano rows, FGMM_TAB_D2_ROWS with second-difference rows
-    return (4 if EF_MIN > 65536 else 0) | (8 if D2_MIN <= D2_MAX_CNT else 0)
+    return 4 if EF_MIN > 65536 else 0  # FGMM_TAB_RAW_ROWS when the tables were built without Elias-Fano rows
 
 
 def host_decode_cdftab(lib, enc: bytes, hdr: np.ndarray, pool: np.ndarray, max_bs: int, pool_len=None):

@@ -1396,60 +1396,3 @@ def test_table_kernel_placements_agree_and_look_back_is_deterministic(oracle, ct
         out = gmc.decompress_batch(*args)
         assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), (place, spin)
     assert _lib.ctx_stat(0, 6) - stalls0 >= stalled  # (how many launches gave up is the hardware's business; the results are not)
-
-
-@pytest.mark.parametrize("mode", MODES)
-def test_second_difference_rows_equal_the_oracle_table_and_decode(oracle, ctx_options, mode):
-    """Format v6: monotone rows of 64 entries and more (FGMM_TAB_D2_ROWS; the batched decoder: option d2_min) cross PCIe as second
-    differences - uint16 E[0], E[1] - E[0], a width nibble per group of 8 entries, zigzag(E[k] - 2 E[k-1] + E[k-2]) packed at that width.
-    The single-pass kernel's table expands (tests/helpers.py, the format restated in numpy) to the oracle's full table, is smaller than
-    the Elias-Fano form, and the host decoder - which expands a row with two prefix sums per group - decodes through it: wide rows,
-    rows that end in the saturated tail (a virtual last entry), 16-bit groups (a narrow component inside a wide one), thresholds
-    from one group up, every header form the kernel writes."""
-    import helpers
-
-    rng = np.random.default_rng(17)
-    saved = (helpers.D2_MIN, helpers.EF_MIN)
-    try:
-        for n, max_bs, scale in ((3000, 126, 30.0), (2000, 100, 8.0), (700, 300, 60.0), (257, 127, 200.0)):
-            sg = (np.exp(rng.uniform(-3, 0.5, (n, 4))) * scale).astype(np.float32)
-            sg[::7, 0] = np.float32(0.12)  # a needle inside a wide mixture: second differences of 15 bits and more
-            mu = (rng.standard_normal((n, 4)) * scale * 0.7).astype(np.float32)
-            pi = rng.dirichlet(np.ones(4), n).astype(np.float32)
-            pi[::11] = rng.uniform(-0.3, 1.1, (len(pi[::11]), 4)).astype(np.float32)  # some non-monotone rows (never second differences)
-            want = oracle.cdftab(mode, np.clip(sg, np.float32(0.11), np.float32(256)), mu, pi, max_bs)
-            helpers.D2_MIN, helpers.EF_MIN = 64, 14
-            h, bo, rows, used, tl = gpu_tab(mode, sg, mu, pi, max_bs, flags=2 | 8)
-            got = expand_trimmed(h, rows, max_bs, bo, tl)
-            assert np.array_equal(got, want), (n, max_bs)
-            helpers.D2_MIN = 1 << 30
-            h0, bo0, rows0, used0, _ = gpu_tab(mode, sg, mu, pi, max_bs, flags=2)
-            assert np.array_equal(expand_trimmed(h0, rows0, max_bs, bo0, tl), want) and used < 0.9 * used0, (used, used0)
-            # the host decoder through a second-difference table (proper weights: a stream the reference's coder round-trips)
-            helpers.D2_MIN = 64
-            pic = rng.dirichlet(np.ones(4), n).astype(np.float32)
-            sgc = np.clip(sg, np.float32(0.11), np.float32(256))
-            sym = np.clip(np.round(mu[:, 0] + rng.standard_normal(n) * np.minimum(sgc[:, 0], 40)), -max_bs + 1, max_bs - 1).astype(np.int32)
-            enc = oracle.encode_gmm(mode, sym, sgc, mu, pic)
-            assert np.array_equal(oracle.decode_gmm(mode, enc, sgc, mu, pic, max_bs), sym)
-            hc, boc, rowsc, usedc, tlc = gpu_tab(mode, sg, mu, pic, max_bs, flags=2 | 8)
-            assert ((hc >> 8 if hc.dtype == np.uint16 else (hc >> 16) & 0x7FFF) >= 64).mean() > 0.2  # (many rows take the form)
-            rc, out = helpers.host_decode_tab(_lib.lib(), enc, hc, rowsc, max_bs, boc, tlc)
-            assert rc == 0 and np.array_equal(out, sym), (n, max_bs)
-    finally:
-        helpers.D2_MIN, helpers.EF_MIN = saved
-    # the batched decoder: thresholds from one group of 8 up; results equal the plain tables', fewer bytes cross
-    lat = [T.make_latent(380 + i, M=M, h=h_, w=w_, zero_frac=0.1) for i, (M, h_, w_) in enumerate([(192, 32, 24)] * 12)]
-    ys, ss, ms, ws = (torch.cat([dv(l[k]) for l in lat]) for k in range(4))
-    gmc = GaussianMixtureConditional(K=4, mode=mode)
-    res = gmc.compress_batch(ys, ss, ms, ws)
-    args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
-    ctx_options(ef_rows=1)
-    out = gmc.decompress_batch(*args)
-    plain_bytes = _lib.ctx_stat(0, 1)
-    assert all(torch.equal(o, r[1]) for o, r in zip(out, res))
-    for d2 in (64, 16, 8, 200):
-        ctx_options(d2_min=d2)
-        out = gmc.decompress_batch(*args)
-        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), d2
-        assert _lib.ctx_stat(0, 1) <= plain_bytes * (0.95 if d2 <= 64 else 1.0), (d2, _lib.ctx_stat(0, 1), plain_bytes)
