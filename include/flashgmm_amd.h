@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FGMM_ABI_VERSION 3
+#define FGMM_ABI_VERSION 4 /* 4: + fgmm_rans_encode_symtab_segs, fgmm_ctx_stat index 6, options tab_place / tab_spin / copy_engine / enc_segs; nothing removed or changed */
 
 typedef enum {
   FGMM_OK = 0,

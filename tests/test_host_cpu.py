@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.fgmm_abi_version() == 3
+    assert L.fgmm_abi_version() == 4
 
 
 def test_header_is_plain_c_and_links():
