@@ -826,8 +826,13 @@ constexpr int kSegLds = kSegLdsBuf + 2 * kSegBufBytes; // 15.9 KB per segment: t
 // The CONSUMER (wave 0) walks the batch symbol by symbol on the scalar unit: lane = edge, one compare + popcount is the
 // reference's bisection in a monotone row, two v_readlane pick F[J] and F[J + 1], the 64-bit state advances in SGPRs.  While it
 // decodes batch n the producer evaluates batch n + 1 (on another SIMD of the CU): the sequential chain never waits for edges.
+#ifdef FGMM_SEG_WAVES // (experiments: cap the registers for this many waves per SIMD)
+#define FGMM_SEG_OCC __attribute__((amdgpu_waves_per_eu(FGMM_SEG_WAVES, FGMM_SEG_WAVES)))
+#else
+#define FGMM_SEG_OCC
+#endif
 template <int MODE, bool CLAMPED, typename PT>
-__global__ __launch_bounds__(192) void segdec_kernel(const SegDesc *__restrict__ descs, const SegRef *__restrict__ segs, int64_t n_segs) {
+__global__ __launch_bounds__(192) FGMM_SEG_OCC void segdec_kernel(const SegDesc *__restrict__ descs, const SegRef *__restrict__ segs, int64_t n_segs) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kSegLds];
   float4_t *const P = reinterpret_cast<float4_t *>(lds + kSegLdsP);         // [64][4]: mu, sigma (clamped), pi, refined 1/sigma
   uint32_t *const offP = reinterpret_cast<uint32_t *>(lds + kSegLdsOff);    // [65] pairs before latent l of the batch
@@ -856,6 +861,9 @@ __global__ __launch_bounds__(192) void segdec_kernel(const SegDesc *__restrict__
   unsigned long long seg_acc[6] = {};
 #endif
   SEG_T(t_begin);
+#ifdef FGMM_SEG_PROF
+  const unsigned long long w_begin = wall_clock64(); // (100 MHz, one counter for the chip: clock64 is per XCD)
+#endif
 
   // =============================== producer: batch [base, base + nk) -> B ===============================
   // (producers meet at LDS flags: a partial barrier does not exist, and the consumer must not wait for them inside a batch)
@@ -1258,7 +1266,7 @@ __global__ __launch_bounds__(192) void segdec_kernel(const SegDesc *__restrict__
     if (!producer) {
       atomicAdd(&g_segprof[6], (unsigned long long)(clock64() - t_begin));
       atomicAdd(&g_segprof[7], 1ull);
-      if (wid < 16384) g_segtimes[2 * wid] = t_begin, g_segtimes[2 * wid + 1] = clock64();
+      if (wid < 16384) g_segtimes[2 * wid] = w_begin, g_segtimes[2 * wid + 1] = wall_clock64();
     }
   }
 #endif

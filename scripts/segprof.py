@@ -35,9 +35,12 @@ if hasattr(L, "fgmm_debug_segtimes") and len(sys.argv) > 3:
     L.fgmm_debug_segtimes(tb)
     t = np.array(tb, dtype=np.float64).reshape(-1, 2)[: int(min(waves, 16384))]
     t0 = t[:, 0].min()
-    beg, end = (t[:, 0] - t0) / 2.4e6, (t[:, 1] - t0) / 2.4e6   # ms at 2.4 GHz ticks
+    beg, end = (t[:, 0] - t0) / 1e5, (t[:, 1] - t0) / 1e5   # ms: wall_clock64 counts at 100 MHz
     dur = end - beg
     print(f"segments: duration ms min {dur.min():.3f} p10 {np.percentile(dur, 10):.3f} median {np.median(dur):.3f} p90 {np.percentile(dur, 90):.3f} max {dur.max():.3f}; last start {beg.max():.3f}, last end {end.max():.3f}")
     order = np.argsort(beg)
     print("start time of every 500th segment in start order:", np.round(beg[order][::500], 3).tolist())
-    print("durations of segments 0..4095 by id, averaged over runs of 127 (one bitstream):", np.round(dur[: 127 * 32].reshape(32, 127).mean(1), 3).tolist())
+    print("end time of every 250th segment in launch order:", np.round(end[::250], 3).tolist())
+    print("start / duration of every 250th segment in launch order:", [(round(float(b), 3), round(float(x), 3)) for b, x in zip(beg[::250], dur[::250])])
+    busy = [(int(((beg <= x) & (end > x)).sum())) for x in np.arange(0, end.max(), 0.1)]
+    print("segments in flight every 0.1 ms:", busy)
