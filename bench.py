@@ -758,6 +758,8 @@ def main(argv=None):
     numa = P.bind_to_gpu_numa_node(local_rank) if os.environ.get("FGMM_BENCH_BIND", "1") != "0" else "not bound (FGMM_BENCH_BIND=0)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if os.environ.get("FGMM_BENCH_BIND", "1") != "0":
+        numa = P.confirm_numa_binding(local_rank, numa)  # the runtime's own address for the device: rebinds if sysfs said otherwise
     dist = None
     backend = None
     if world > 1:

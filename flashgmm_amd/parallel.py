@@ -8,13 +8,13 @@ on ROCm; "gloo" runs the same code on CPU tensors (tests/test_parallel_cpu.py, w
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 __all__ = ["shard_units", "owner_of", "all_gather_stream_lengths", "container_index", "gather_containers",
-           "bind_to_gpu_numa_node"]
+           "bind_to_gpu_numa_node", "confirm_numa_binding"]
 
 
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:
@@ -137,7 +137,26 @@ def gpu_pci_address(device_index: int) -> str:
     return gpus[order[device_index]]
 
 
-def bind_to_gpu_numa_node(device_index: int, all_threads: bool = True) -> str:
+def runtime_pci_address(device_index: int) -> str:
+    """PCI address of HIP device `device_index` as the RUNTIME reports it (initialises the device)."""
+    p = torch.cuda.get_device_properties(device_index)
+    return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+
+
+def confirm_numa_binding(device_index: int, description: str) -> str:
+    """After the runtime is up: is the GPU that ``bind_to_gpu_numa_node`` looked up in sysfs the one the runtime calls
+    `device_index`?  (UUID filters, a runtime that orders devices differently: the early lookup cannot know.)  If not, bind
+    again to the runtime's device and say so; returns the description to report."""
+    try:
+        seen = runtime_pci_address(device_index)
+        if f"({seen})" in description:
+            return description
+        return bind_to_gpu_numa_node(device_index, bdf=seen) + f"  [rebound: the early lookup said: {description}]"
+    except Exception as e:  # pragma: no cover
+        return description + f"  [not confirmed: {e}]"
+
+
+def bind_to_gpu_numa_node(device_index: int, all_threads: bool = True, bdf: Optional[str] = None) -> str:
     """Pin this process to the CPUs of the NUMA node the GPU hangs off: every thread it has NOW (``all_threads``: the HIP
     runtime's signal / interrupt handling threads exist from the first GPU call on, and ``sched_setaffinity(0, ...)`` alone
     moves the calling thread only) and, by inheritance, every thread created afterwards (the host rANS workers).
@@ -149,11 +168,11 @@ def bind_to_gpu_numa_node(device_index: int, all_threads: bool = True) -> str:
     import os
 
     try:
-        try:
-            bdf = gpu_pci_address(device_index)
-        except LookupError:
-            p = torch.cuda.get_device_properties(device_index)
-            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        if bdf is None:
+            try:
+                bdf = gpu_pci_address(device_index)
+            except LookupError:
+                bdf = runtime_pci_address(device_index)
         node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
         if node < 0:
             return f"gpu {device_index} ({bdf}): no NUMA affinity reported"

@@ -168,3 +168,18 @@ def test_visible_device_filters_compose_as_the_runtime_composes_them(monkeypatch
     monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "GPU-deadbeef")
     with pytest.raises(LookupError):
         P._visible_filter(4)
+
+
+def test_numa_binding_is_confirmed_against_the_runtimes_own_address(monkeypatch):
+    """Once the runtime is up its PCI address for the device is compared with the one the early sysfs lookup bound to: equal ->
+    the description stands; different -> bound again to the runtime's device, and the report says so"""
+    calls = []
+    monkeypatch.setattr(P, "runtime_pci_address", lambda i: "0000:5d:00.0")
+    monkeypatch.setattr(P, "bind_to_gpu_numa_node", lambda i, all_threads=True, bdf=None: calls.append(bdf) or f"gpu {i} ({bdf}) -> NUMA node 1")
+    early = "gpu 0 (0000:5d:00.0) -> NUMA node 0, 128 CPUs, 65 thread(s) bound"
+    assert P.confirm_numa_binding(0, early) == early and calls == []
+    wrong = "gpu 0 (0000:1a:00.0) -> NUMA node 0, 128 CPUs, 65 thread(s) bound"
+    out = P.confirm_numa_binding(0, wrong)
+    assert calls == ["0000:5d:00.0"] and out.startswith("gpu 0 (0000:5d:00.0)") and "rebound" in out and "0000:1a:00.0" in out
+    monkeypatch.setattr(P, "runtime_pci_address", lambda i: (_ for _ in ()).throw(RuntimeError("no device")))
+    assert "not confirmed" in P.confirm_numa_binding(0, early)
