@@ -1396,3 +1396,32 @@ def test_table_kernel_placements_agree_and_look_back_is_deterministic(oracle, ct
         out = gmc.decompress_batch(*args)
         assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), (place, spin)
     assert _lib.ctx_stat(0, 6) - stalls0 >= stalled  # (how many launches gave up is the hardware's business; the results are not)
+
+
+def test_scheduling_options_change_no_byte(oracle, ctx_options):
+    """How a call's tables cross PCIe is a matter of scheduling only: encode tables whole (enc_segs 0) or in four segments per bitstream,
+    tails first (1, the default: the encoders follow the landing); decode tables through hipMemcpyAsync (copy_engine 0, the default)
+    or straight to the SDMA engines through HSA (1: signals the workers sleep on; 2: one engine).  Every combination gives the
+    oracle's bytes and the encoder's reconstruction - on a batch large enough for the segmented layout (>= 4 MB of tables), with
+    an all-zero item and a channel count that is not a multiple of four among them."""
+    specs = [(192, 32, 24, 0.1)] * 6 + [(190, 32, 24, 0.3), (192, 32, 24, 1.0), (192, 32, 24, 0.0)]
+    lat = [T.make_latent(4400 + i, M=M, h=h, w=w, zero_frac=zf) for i, (M, h, w, zf) in enumerate(specs)]
+    dev = [[dv(a) for a in l] for l in lat]
+    ys, ss, ms, ws = ([d[k] for d in dev] for k in range(4))
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    want = []
+    for y, sg, mu, pi in lat[:3] + lat[6:]:
+        sym, s, m, wt, am, zbm, yq = T.to_coder_inputs(y, sg, mu, pi)
+        want.append(oracle.encode_gmm("polya", sym, s, m, wt))
+    results = {}
+    for segs in (0, 1):
+        ctx_options(enc_segs=segs)
+        res = gmc.compress_batch(ys, ss, ms, ws)
+        results[segs] = [bytes(r[0][0]) for r in res]
+        assert [results[segs][i] for i in (0, 1, 2, 6, 7, 8)] == want, segs
+    assert results[0] == results[1]
+    args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+    for engine in (1, 2, 0):
+        ctx_options(copy_engine=engine)
+        out = gmc.decompress_batch(*args)
+        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), engine
