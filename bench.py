@@ -577,14 +577,19 @@ class Leg:
         from flashgmm_amd import _lib
 
         lr = self.env.local_rank
-        outs = [None] * self.n_streams
+        spi = self.spi
+        outs = [None] * (spi if self.stacked else self.n_streams)
         tk = eg = tb = 0.0
-        for s in range(self.spi):
-            idx = self.stage_idx[s]
+        for s in range(spi):
             sp, mp_, wp = self.stage_params[s]
-            o = self.gmc.decompress_batch([res[i][0][0] for i in idx], [res[i][0][1] for i in idx], [res[i][0][2] for i in idx], sp, mp_, wp)
-            for i, t in zip(idx, o):
-                outs[i] = t
+            if self.stacked:  # the batch's results are held stacked (CompressedBatch): a stage is a stride over them, in and out
+                outs[s] = self.gmc.decompress_batch(res.strings[s::spi], res.abs_maxes[s::spi], res.zero_bitmaps[s::spi], sp, mp_, wp,
+                                                    stacked_output=True)
+            else:
+                idx = self.stage_idx[s]
+                o = self.gmc.decompress_batch([res[i][0][0] for i in idx], [res[i][0][1] for i in idx], [res[i][0][2] for i in idx], sp, mp_, wp)
+                for i, t in zip(idx, o):
+                    outs[i] = t
             if record:
                 tk += _lib.kernel_ms(lr, 1)
                 eg += _lib.ctx_stat(lr, 3)
@@ -597,7 +602,10 @@ class Leg:
         from flashgmm_amd import _lib
 
         lr = self.env.local_rank
-        outs = self.gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], self.ss, self.ms, self.ws)
+        if self.stacked:
+            outs = [self.gmc.decompress_batch(res.strings, res.abs_maxes, res.zero_bitmaps, self.ss, self.ms, self.ws, stacked_output=True)]
+        else:
+            outs = self.gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], self.ss, self.ms, self.ws)
         if record:
             self.k_tab.append(_lib.kernel_ms(lr, 1)), self.edges.append(_lib.ctx_stat(lr, 3)), self.tab_bytes.append(_lib.ctx_stat(lr, 1))
         return outs
@@ -612,7 +620,8 @@ class Leg:
             self.k_qs.append(_lib.kernel_ms(self.env.local_rank, 2))
         if self.env.world > 1:  # the path's one exchange: per-stream bitstream lengths, RCCL all-gather
             t0 = time.perf_counter()
-            P.all_gather_stream_lengths([len(r[0][0]) for r in res], len(res), device=self.env.coll_dev)
+            P.all_gather_stream_lengths([len(b) for b in res.strings] if self.stacked else [len(r[0][0]) for r in res], len(res),
+                                        device=self.env.coll_dev)
             if record:
                 self.t_gather.append(time.perf_counter() - t0)
         outs = self.decode_codec(res, record) if schedule == "codec" else self.decode_all(res, record)
@@ -641,9 +650,14 @@ class Leg:
     def check_last(self):
         """correctness of what was timed: decode(encode(y)) == round(y) for every stream of this rank"""
         res, outs = self.last["res"], self.last["outs"]
+        if self.stacked:  # outs: one [N', 1, M, h, w] tensor per decode call (stage s = every spi-th stream from s; or all of them)
+            assert torch.equal(res.y_q[:, 0], torch.round(self.ys)), "quantised latents mismatch"
+            step = len(outs)
+            for s, o in enumerate(outs):
+                assert o.shape[0] == len(range(s, self.n_streams, step)) and torch.equal(o, res.y_q[s::step]), f"decode call {s} mismatch"
+            return res
         for i in range(self.n_streams):
-            y_i = self.ys[i:i + 1] if self.stacked else self.ys[i]
-            assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(y_i)), f"stream {i} mismatch"
+            assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(self.ys[i])), f"stream {i} mismatch"
         return res
 
     def coded_symbols(self, res):

@@ -27,7 +27,7 @@ from torch import Tensor
 
 from . import _lib
 
-__all__ = ["GaussianMixtureConditional", "EntropyBottleneckCoder", "CheckpointedBytes"]
+__all__ = ["GaussianMixtureConditional", "EntropyBottleneckCoder", "CheckpointedBytes", "CompressedBatch"]
 
 CKPT_DTYPE = np.dtype([("x", "<u8"), ("pos", "<u8")])  # fgmm_ckpt
 
@@ -62,6 +62,28 @@ class CheckpointedBytes(bytes):
 
 
 _NO_CKPT = np.zeros(0, CKPT_DTYPE)
+
+
+class CompressedBatch(Sequence):
+    """What ``compress_batch`` returns for STACKED inputs: the N results held as the call produced them - ``strings`` (list of
+    N ``bytes``), ``abs_maxes`` (list of N ints), ``zero_bitmaps`` (one ``[N, M]`` int64 CPU tensor), ``y_q`` (one
+    ``[N, 1, M, h, w]`` tensor).  It IS the sequence of ``((bytes, abs_max, zero_bitmap), y_q)`` the list form returns -
+    ``len``, indexing, slicing and iteration give the per-item tuples (views, made when asked for) - and its fields go
+    straight back into ``decompress_batch`` (``strings[s::2]``, ``zero_bitmaps[s::2]`` ...) without 2 N tensor views
+    being built for a caller that never looks at them."""
+
+    __slots__ = ("strings", "abs_maxes", "zero_bitmaps", "y_q")
+
+    def __init__(self, strings: List[bytes], abs_maxes: List[int], zero_bitmaps: Tensor, y_q: Tensor):
+        self.strings, self.abs_maxes, self.zero_bitmaps, self.y_q = strings, abs_maxes, zero_bitmaps, y_q
+
+    def __len__(self) -> int:
+        return len(self.strings)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self.strings)))]
+        return (self.strings[i], self.abs_maxes[i], self.zero_bitmaps[i]), self.y_q[i]
 
 
 def _take_ckpts_many(device: int, ptrs, counts):
@@ -213,7 +235,7 @@ class GaussianMixtureConditional(nn.Module):
     def _compress_stacked(self, y: Tensor, scales: Tensor, means: Tensor, weights: Tensor, flags: int = 0):
         items, keep, N, M, h, w, dev = self._stacked_items(y, scales, means, weights, flags)
         if N == 0:
-            return []
+            return CompressedBatch([], [], torch.empty((0, M), dtype=torch.int64), torch.empty((0, 1, M, h, w), dtype=torch.float32, device=dev))
         yq = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
         zb = torch.empty((N, M), dtype=torch.int64)
         items["yq_out"] = np.uint64(yq.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * h * w * 4)
@@ -227,29 +249,28 @@ class GaussianMixtureConditional(nn.Module):
         ptrs, lens, amax = items["bytes"].tolist(), items["bytes_len"].tolist(), items["abs_max"].tolist()
         datas = _lib.take_bytes_many(dev.index if dev.index is not None else -1, ptrs, lens, CheckpointedBytes if self.checkpoint_stride else None)
         cks = _take_ckpts_many(dev.index if dev.index is not None else -1, items["ckpt"].tolist(), items["n_ckpt"].tolist()) if self.checkpoint_stride else None
-        out = []
-        for i, (q, b) in enumerate(zip(yq.unbind(0), zb.unbind(0))):
-            data = datas[i]
-            if cks is not None:
-                data = CheckpointedBytes._adopt(data, cks[i][0], self.checkpoint_stride, cks[i][1])
-            out.append(((data, amax[i], b), q))
-        return out
+        if cks is not None:
+            datas = [CheckpointedBytes._adopt(d, ck[0], self.checkpoint_stride, ck[1]) for d, ck in zip(datas, cks)]
+        return CompressedBatch(datas, amax, zb, yq)
 
     def _decompress_stacked(self, strings: Sequence[bytes], abs_maxes: Sequence[int], zero_bitmaps, scales: Tensor,
-                            means: Tensor, weights: Tensor, flags: int = 0) -> List[Tensor]:
+                            means: Tensor, weights: Tensor, flags: int = 0, stacked_output: bool = False):
         items, keep, N, M, h, w, dev = self._stacked_items(None, scales, means, weights, flags)
         if len(strings) != N or len(abs_maxes) != N or len(zero_bitmaps) != N:
             raise RuntimeError(f"{N} items in the parameter tensors, {len(strings)} bitstreams")
         if N == 0:
-            return []
+            return torch.empty((0, 1, M, h, w), dtype=torch.float32, device=dev) if stacked_output else []
         if isinstance(zero_bitmaps, Tensor):
             zb = zero_bitmaps
         else:
             zb = torch.stack([z.to("cpu", torch.int64) for z in zero_bitmaps])
-        if zb.device.type != "cpu" or zb.dtype != torch.int64 or not zb.is_contiguous():
-            zb = zb.to("cpu", torch.int64).contiguous()
+        if zb.device.type != "cpu" or zb.dtype != torch.int64:
+            zb = zb.to("cpu", torch.int64)
         if tuple(zb.shape) != (N, M):
             raise RuntimeError(f"zero bitmaps have shape {tuple(zb.shape)}, expected ({N}, {M})")
+        if M > 1 and zb.stride(1) != 1:
+            zb = zb.contiguous()
+        zb_row = zb.stride(0) if N > 1 else M  # rows may be a strided view of a larger batch (a codec stage: every second one)
         data = [s_ if isinstance(s_, bytes) else bytes(s_) for s_ in strings]
         bufs = (C.c_char_p * N)(*data)  # borrowed pointers into the bytes objects (kept alive by `data`)
         y_hat = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
@@ -260,17 +281,18 @@ class GaussianMixtureConditional(nn.Module):
             items["ckpt"], items["n_ckpt"], items["ckpt_stride"] = (np.array(c, dtype=np.uint64) for c in zip(*cks))
         items["abs_max"] = np.asarray(abs_maxes, dtype=np.int64)
         items["yq_out"] = np.uint64(y_hat.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * h * w * 4)
-        items["zero_bitmap"] = np.uint64(zb.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * 8)
+        items["zero_bitmap"] = np.uint64(zb.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(zb_row * 8)
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = _lib.lib().fgmm_gmc_decompress_batch(_lib.ctx(dev.index if dev.index is not None else -1), stream,
                                                   C.cast(items.ctypes.data, C.POINTER(_lib.fgmm_item)), N, self._mode(),
             int(self.clamp_scales))
         _lib.check(rc, "GaussianMixtureConditional.decompress")
-        return list(y_hat.unbind(0))
+        return y_hat if stacked_output else list(y_hat.unbind(0))
 
     def compress_batch(self, ys, scales, means, weights, *, weights_are_logits: bool = False):
         """N independent ``compress`` calls in one native call (kernels batched over items, one host rANS worker
-        per bitstream).  Returns a list of ``((bytes, abs_max, zero_bitmap_cpu), y_q)``.
+        per bitstream).  Returns a sequence of ``((bytes, abs_max, zero_bitmap_cpu), y_q)`` - a list, or for stacked inputs a
+        ``CompressedBatch`` (the same sequence, held stacked).
 
         The items are given either as sequences of ``[1, M, h, w]`` / ``[1, K*M, h, w]`` tensors (any mix of shapes)
         or, for items of one shape, stacked: ``y [N, M, h, w]``, parameters ``[N, K*M, h, w]`` — what a network
@@ -325,14 +347,18 @@ class GaussianMixtureConditional(nn.Module):
         return (data, abs_max, zb.to(y.device)), yq
 
     def decompress_batch(self, strings: Sequence[bytes], abs_maxes: Sequence[int], zero_bitmaps, scales, means,
-                         weights, *, weights_are_logits: bool = False) -> List[Tensor]:
+                         weights, *, weights_are_logits: bool = False, stacked_output: bool = False):
         """N independent ``decompress`` calls in one native call; parameters as sequences of ``[1, K*M, h, w]``
-        tensors or stacked ``[N, K*M, h, w]`` (see ``compress_batch``).  Returns N ``[1, M, h, w]`` tensors."""
+        tensors or stacked ``[N, K*M, h, w]`` (see ``compress_batch``; ``zero_bitmaps`` may then be one ``[N, M]`` tensor).
+        Returns N ``[1, M, h, w]`` tensors - with ``stacked_output`` (stacked parameters only) the one ``[N, 1, M, h, w]``
+        tensor they are views of."""
         if self.K != _lib.FGMM_K:
             raise RuntimeError(f"K = {self.K}: the coder is bound for K = 4 only (as the reference's)")
         flags = _lib.FGMM_PARAMS_LOGITS if weights_are_logits else 0
         if isinstance(scales, Tensor):
-            return self._decompress_stacked(strings, abs_maxes, zero_bitmaps, scales, means, weights, flags)
+            return self._decompress_stacked(strings, abs_maxes, zero_bitmaps, scales, means, weights, flags, stacked_output)
+        if stacked_output:
+            raise RuntimeError("stacked_output needs stacked parameters ([N, K*M, h, w] tensors)")
         n_items = len(strings)
         items = (_lib.fgmm_item * n_items)()
         keep: list = []

@@ -31,18 +31,15 @@ for it in range(40):
     t = tick("c.tolist", t)
     datas = _lib.take_bytes_many(0, ptrs, lens, None)
     t = tick("c.take_bytes_many", t)
-    qs, bs = yq.unbind(0), zb.unbind(0)
-    t = tick("c.unbind", t)
-    res = [((datas[i], amax[i], b), q) for i, (q, b) in enumerate(zip(qs, bs))]
-    t = tick("c.tuples", t)
+    res = EM.CompressedBatch(datas, amax, zb, yq)
+    t = tick("c.result", t)
     for s in range(2):
-        idx = range(s, 48, 2)
-        strings, ams, zbs = [res[i][0][0] for i in idx], [res[i][0][1] for i in idx], [res[i][0][2] for i in idx]
+        strings, ams, zbs = res.strings[s::2], res.abs_maxes[s::2], res.zero_bitmaps[s::2]
         sc, me, we = ss[s::2], ms[s::2], ws[s::2]
-        t = tick("d.caller lists+views", t)
+        t = tick("d.caller slices+views", t)
         items, keep, N, M, h, w, d = self._stacked_items(None, sc, me, we, 0)
         t = tick("d.stacked_items", t)
-        zb2 = torch.stack([z.to("cpu", torch.int64) for z in zbs])
+        zb2 = zbs.to("cpu", torch.int64).contiguous()
         t = tick("d.zero bitmaps", t)
         data = [s_ if isinstance(s_, bytes) else bytes(s_) for s_ in strings]
         bufs = (C.c_char_p * N)(*data)
@@ -56,8 +53,8 @@ for it in range(40):
         t = tick("d.pointers+fields", t)
         rc = L.fgmm_gmc_decompress_batch(_lib.ctx(0), stream, C.cast(items.ctypes.data, C.POINTER(_lib.fgmm_item)), N, self._mode(), int(self.clamp_scales))
         t = tick("d.NATIVE", t)
-        outs = list(y_hat.unbind(0))
-        t = tick("d.unbind", t)
+        outs = y_hat
+        t = tick("d.result", t)
     del outs, y_hat, res, datas, yq
     t = tick("free", t)
 tot = 0

@@ -1425,3 +1425,35 @@ def test_scheduling_options_change_no_byte(oracle, ctx_options):
         ctx_options(copy_engine=engine)
         out = gmc.decompress_batch(*args)
         assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), engine
+
+
+def test_stacked_results_are_the_list_forms_sequence(oracle):
+    """compress_batch on stacked inputs returns a CompressedBatch: the same sequence of ((bytes, abs_max, zero_bitmap), y_q) as the
+    list form - by index, slice and iteration - held stacked; its fields go back into decompress_batch as they are (a stage = a
+    stride), and stacked_output gives the one tensor the per-item outputs are views of."""
+    from flashgmm_amd import CompressedBatch
+
+    lat = [T.make_latent(5100 + i, M=24, h=8, w=12, zero_frac=0.25) for i in range(6)]
+    ys, ss, ms, ws = (torch.cat([dv(l[k]) for l in lat]) for k in range(4))
+    gmc = GaussianMixtureConditional(K=4, mode="as")
+    stacked = gmc.compress_batch(ys, ss, ms, ws)
+    listed = gmc.compress_batch([ys[i:i + 1] for i in range(6)], [ss[i:i + 1] for i in range(6)], [ms[i:i + 1] for i in range(6)],
+                                [ws[i:i + 1] for i in range(6)])
+    assert isinstance(stacked, CompressedBatch) and isinstance(listed, list) and len(stacked) == 6
+    for i, (((b, am, zb), q), ((b2, am2, zb2), q2)) in enumerate(zip(stacked, listed)):
+        sym, s, m, wt, am_o, zbm, yq = T.to_coder_inputs(*lat[i])
+        assert b == b2 == oracle.encode_gmm("as", sym, s, m, wt) and am == am2 == am_o and torch.equal(zb, zb2) and torch.equal(q, q2)
+    assert [x[0][0] for x in stacked[1:5:2]] == [stacked.strings[1], stacked.strings[3]] and stacked[-1][0][1] == stacked.abs_maxes[5]
+    with pytest.raises(IndexError):
+        stacked[6]
+    for s in range(2):  # a codec stage: every second bitstream, fields in, one tensor out
+        out = gmc.decompress_batch(stacked.strings[s::2], stacked.abs_maxes[s::2], stacked.zero_bitmaps[s::2], ss[s::2], ms[s::2], ws[s::2],
+                                   stacked_output=True)
+        assert out.shape == (3, 1, 24, 8, 12) and torch.equal(out, stacked.y_q[s::2])
+        views = gmc.decompress_batch(stacked.strings[s::2], stacked.abs_maxes[s::2], stacked.zero_bitmaps[s::2], ss[s::2], ms[s::2], ws[s::2])
+        assert isinstance(views, list) and all(torch.equal(v, o) for v, o in zip(views, out))
+    with pytest.raises(RuntimeError):
+        gmc.decompress_batch([stacked.strings[0]], [stacked.abs_maxes[0]], [stacked.zero_bitmaps[0]], [ss[:1]], [ms[:1]], [ws[:1]], stacked_output=True)
+    empty = gmc.compress_batch(ys[:0], ss[:0], ms[:0], ws[:0])
+    assert len(empty) == 0 and list(empty) == []
+    assert gmc.decompress_batch([], [], empty.zero_bitmaps, ss[:0], ms[:0], ws[:0], stacked_output=True).shape == (0, 1, 24, 8, 12)
