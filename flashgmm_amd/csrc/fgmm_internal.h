@@ -202,6 +202,20 @@ int launch_tab(const DecDesc *d_descs, int count, int blocks_max, int tl_max, in
 // host memory (read over PCIe)   (entropy_models.py:903-908)
 int launch_softmax_probe(const float *logits, float *pi, int64_t n, void *stream);
 int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y_hat, int M, int64_t hw, void *stream);
+// The decoded symbols of a call's items back into their latents ROUND BY ROUND (round = piece index of the table pipeline): the
+// items' symbols of pieces that every decoder has finished are scattered while the later pieces are still being decoded, so
+// that what is left after the last decoder is the last, smallest piece (decode_batch).
+struct ScatDesc {
+  const int16_t *sym;        // pinned host: the item's compact symbols, int16 (an item that turns out wide is redone whole)
+  const int32_t *chan_list;  // device [n_ch]: compact channel -> channel
+  const int32_t *rank;       // device [M]: channel -> compact channel, -1 = no coded symbol (zero in y_hat)
+  float *y_hat;              // device [M * hw]; null: the item takes no part
+  int64_t hw;
+  int32_t M, pad;
+  int64_t bound[kMaxPieces + 1]; // round r scatters the compact symbols [bound[r], bound[r + 1])
+};
+int launch_yhat_scatter_round(const ScatDesc *d_descs, int count, int round, int64_t max_range, void *stream);
+int launch_yhat_zero_dead(const ScatDesc *d_descs, int count, int M_max, int64_t hw_max, void *stream);
 // checkerboard split (embed = false: [planes,h,w] -> [2,planes,h,w/2]) / merge (embed = true); w even, elem_bytes 2 or 4
 int launch_ckbd(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int elem_bytes, int anchor_odd, bool embed,
                 void *stream);

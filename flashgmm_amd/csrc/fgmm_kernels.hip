@@ -293,6 +293,26 @@ __global__ __launch_bounds__(kBlock) void yhat_scatter_kernel(const ST *__restri
   y_hat[(int64_t)c * hw + p] = r < 0 ? 0.0f : (float)sym[(int64_t)r * hw + p];
 }
 
+// The same by ROUNDS over a batch of items (ScatDesc): round r = the compact symbols [bound[r], bound[r + 1]) of every item; the
+// channels without a coded symbol are zeroed once, by yhat_zero_dead_kernel.
+__global__ __launch_bounds__(kBlock) void yhat_scatter_round_kernel(const ScatDesc *__restrict__ descs, int round) {
+  const ScatDesc &d = descs[blockIdx.y];
+  if (!d.y_hat) return;
+  const int64_t lo = d.bound[round], hi = d.bound[round + 1], hw = d.hw;
+  const bool small = hi <= 0x7FFFFFFFll;
+  for (int64_t i = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < hi; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = small ? (int64_t)((uint32_t)i / (uint32_t)hw) : i / hw;
+    d.y_hat[(int64_t)d.chan_list[r] * hw + (i - r * hw)] = (float)d.sym[i];
+  }
+}
+__global__ __launch_bounds__(kBlock) void yhat_zero_dead_kernel(const ScatDesc *__restrict__ descs) {
+  const ScatDesc &d = descs[blockIdx.z];
+  const int c = blockIdx.y;
+  if (!d.y_hat || c >= d.M || d.rank[c] >= 0) return;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p < d.hw) d.y_hat[(int64_t)c * d.hw + p] = 0.0f;
+}
+
 // softmax_probe_kernel: the kernels' mixture-weight sequence on (n, 4) rows of logits (tests: against torch.softmax)
 __global__ __launch_bounds__(kBlock) void softmax_probe_kernel(const float *__restrict__ logits, float *__restrict__ pi, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -544,6 +564,21 @@ int launch_yhat_scatter(const void *sym, int wide, const int32_t *rank, float *y
   dim3 grid((unsigned)((hw + kBlock - 1) / kBlock), (unsigned)M);
   if (wide) hipLaunchKernelGGL(yhat_scatter_kernel<int32_t>, grid, dim3(kBlock), 0, (hipStream_t)stream, (const int32_t *)sym, rank, y_hat, hw);
   else hipLaunchKernelGGL(yhat_scatter_kernel<int16_t>, grid, dim3(kBlock), 0, (hipStream_t)stream, (const int16_t *)sym, rank, y_hat, hw);
+  return launch_err();
+}
+
+int launch_yhat_scatter_round(const ScatDesc *d_descs, int count, int round, int64_t max_range, void *stream) {
+  if (count <= 0 || max_range <= 0) return 0;
+  if (count > 65535 || round < 0 || round >= kMaxPieces) return (int)hipErrorInvalidValue;
+  const dim3 grid((unsigned)std::min<int64_t>((max_range + kBlock - 1) / kBlock, 1024), (unsigned)count);
+  hipLaunchKernelGGL(yhat_scatter_round_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, d_descs, round);
+  return launch_err();
+}
+int launch_yhat_zero_dead(const ScatDesc *d_descs, int count, int M_max, int64_t hw_max, void *stream) {
+  if (count <= 0 || M_max <= 0 || hw_max <= 0) return 0;
+  if (count > 65535 || M_max > 65535) return (int)hipErrorInvalidValue;
+  const dim3 grid((unsigned)((hw_max + kBlock - 1) / kBlock), (unsigned)M_max, (unsigned)count);
+  hipLaunchKernelGGL(yhat_zero_dead_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, d_descs);
   return launch_err();
 }
 

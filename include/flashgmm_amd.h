@@ -106,6 +106,10 @@ int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, con
  *                       rANS encodes backwards, so the encoders start on the tails after an eighth of the transfer and follow the
  *                       landing; what is left after the last byte is a quarter of a bitstream's job instead of a whole one.
  *                       0 = whole tables, bitstream after bitstream
+ *   "scatter_rounds" [1] decode: the decoded symbols of the bitstreams that decode piece by piece return to the GPU round by round
+ *                       (one launch per piece index, as soon as every such bitstream has decoded that piece) instead of one
+ *                       launch per bitstream when it has finished: what follows the last decoder is its last, smallest piece.
+ *                       0 = bitstream by bitstream
  *   "dec_pair"    [0]   decode: a worker takes two ready tasks and decodes them latent by latent in turn
  *                       (fgmm_rans_decode_tab2: 8.9 -> 5.9 ns/symbol per thread with uint16 rows) unless that leaves a
  *                       sleeping worker without one.  0 = when the call has at least two bitstreams per worker and ships

@@ -1421,10 +1421,37 @@ def test_scheduling_options_change_no_byte(oracle, ctx_options):
         assert [results[segs][i] for i in (0, 1, 2, 6, 7, 8)] == want, segs
     assert results[0] == results[1]
     args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
-    for engine in (1, 2, 0):
-        ctx_options(copy_engine=engine)
+    for engine, rounds in ((1, 1), (2, 0), (0, 0), (0, 1)):
+        ctx_options(copy_engine=engine, scatter_rounds=rounds)
         out = gmc.decompress_batch(*args)
-        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), engine
+        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), (engine, rounds)
+
+
+def test_round_scatter_redoes_an_item_with_symbols_beyond_int16(oracle, ctx_options):
+    """The decoded symbols return to the GPU round by round as int16 (option scatter_rounds).  A bypass-coded symbol beyond int16
+    can only reach that path when the caller's abs_max is smaller than the stream's symbols (a hostile or corrupt container: an
+    honest half-width of 32768 takes the generic kernels) - the bypass nibbles carry it whatever the half-width
+    (rans_interface.cpp:808-824).  Such an item is scattered once more, whole and wide, after the rounds have read: the result
+    is the oracle decoder's for that (stream, half-width), in a multi-piece batch beside ordinary items."""
+    lat = [T.make_latent(4700 + i, M=192, h=32, w=24, zero_frac=0.1) for i in range(3)]
+    y1 = lat[1][0].copy()
+    clean_max = T.to_coder_inputs(*lat[1])[4]  # the honest abs_max of the latent without its outliers
+    nzc = [c for c in range(192) if np.round(y1[0, c]).any()]  # coded channels: the outliers do not change the zero bitmap
+    y1[0, nzc[3], 5, 7], y1[0, nzc[40], 0, 0], y1[0, nzc[-1], 31, 23] = 70000.4, -40000.0, 32768.0
+    lat[1] = (y1,) + tuple(lat[1][1:])
+    dev = [[dv(a) for a in l] for l in lat]
+    ys, ss, ms, ws = ([d[k] for d in dev] for k in range(4))
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    res = gmc.compress_batch(ys, ss, ms, ws)
+    sym, s, m, wt, am, zbm, yq = T.to_coder_inputs(*lat[1])
+    assert res[1][0][1] == am > 70000 > 32767 > clean_max and res[1][0][0] == oracle.encode_gmm("polya", sym, s, m, wt)
+    assert np.array_equal(oracle.decode_gmm("polya", res[1][0][0], s, m, wt, clean_max + 1), sym)  # the small half-width decodes it too
+    abs_maxes = [res[0][0][1], clean_max, res[2][0][1]]
+    for rounds in (1, 0):
+        ctx_options(scatter_rounds=rounds)
+        out = gmc.decompress_batch([r[0][0] for r in res], abs_maxes, [r[0][2] for r in res], ss, ms, ws)
+        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), rounds
+        assert float(out[1].abs().max()) == 70000.0
 
 
 def test_stacked_results_are_the_list_forms_sequence(oracle):
