@@ -18,8 +18,9 @@
 #include <string.h>
 
 #include <algorithm>
-#include <chrono>
+#include <array>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -1693,6 +1694,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
 
   // ---- unit by unit: size known -> pinned range, ONE copy; the workers are told ----------------------------------------
   unsigned long long edges = 0;
+  std::vector<std::array<double, 3>> unit_trace; // trace level 2: [queued at, bytes, landed at] per unit
   for (int u = 0; u < n_units; ++u) {
     Unit &un = units[(size_t)u];
     HIP_TRY(hipEventSynchronize(ev_counters[u]));
@@ -1752,8 +1754,19 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
     // rows are shared by the unit's items: account them once
     if (!un.parts.empty()) items[un.parts[0].item].table_bytes += used;
+    if (tr.level > 1) unit_trace.push_back({tr.ms(), (double)(un.fixed + used), 0.0});
   }
   tr.mark("sizes known, copies queued");
+  if (tr.level > 1 && !ctx->opt.copy_engine) { // the copies' own timeline: this thread watches every unit land (delays the scatter rounds a little)
+    for (int u = 0; u < n_units; ++u) {
+      (void)hipEventSynchronize(ev_landed[u]);
+      unit_trace[(size_t)u][2] = tr.ms();
+    }
+    for (int u = 0; u < n_units; ++u)
+      fprintf(stderr, "[fgmm decode]   unit %2d  %2zu parts  %9.0f bytes  queued %7.3f  landed %7.3f  (%.1f GB/s since the unit before landed or this one was queued)\n", u,
+              units[(size_t)u].parts.size(), unit_trace[(size_t)u][1], unit_trace[(size_t)u][0], unit_trace[(size_t)u][2],
+              unit_trace[(size_t)u][1] / 1e6 / std::max(1e-6, unit_trace[(size_t)u][2] - std::max(unit_trace[(size_t)u][0], u ? unit_trace[(size_t)u - 1][2] : 0.0)));
+  }
 
   // ---- generic path: items too wide for the single-pass kernel, one at a time ------------------------------------------
   for (int i : generic) {
