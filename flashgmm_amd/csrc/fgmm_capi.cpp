@@ -1294,6 +1294,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       (rc = ctx->ensure_events((spin ? 3 : 2) * (size_t)std::max(n_units, 1) + 2, (size_t)n_units + 2)) || (rc = ctx->ensure_stage(stage_total)))
     return rc;
   ctx->chunks_reset();
+  tr.mark("planned, buffers ensured");
   // pinned output areas (decoded symbols) of all items
   {
     size_t out_total = 256;
@@ -1386,6 +1387,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     units[(size_t)u].d_range = ctx->d_stage + units[(size_t)u].o_stage;
     fill_unit_descs(u);
   }
+  tr.mark("descriptors built");
   HIP_TRY(hipMemcpyAsync(ctx->d_ws, ctx->h_ws, upload_bytes, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(ctx->d_ws + o_counters, 0, zero_bytes, stream));
   if (n_round && dead_round) LAUNCH_TRY(launch_yhat_zero_dead(d_scat, count, M_round, hw_round, stream)); // (channels without a coded symbol)
@@ -1401,17 +1403,29 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     return FGMM_OK;
   };
   unsigned long long *h_counters = reinterpret_cast<unsigned long long *>(ctx->h_ws + o_counters);
-  if ((rc = ctx->prof_begin(1, stream))) return rc;
-  for (int u = 0; u < n_units; ++u) {
-    if ((rc = launch_unit(u))) return rc;
+  // The launches are enqueued a few units AHEAD of the unit whose size this thread waits for, not all up front: a launch costs this
+  // thread ~11 us of API calls (kernel, two events, a stream wait, the counters' copy), eleven of them 0.12 ms - by which time the
+  // first unit's kernel had long finished and its copy, the first bytes on the bus, was 0.08 ms late.
+  constexpr int kLaunchAhead = 3;
+  int launched = 0;
+  auto launch_next = [&]() -> int {
+    const int u = launched;
+    int rc_ = launch_unit(u);
+    if (rc_) return rc_;
     HIP_TRY(hipEventRecord(ev_kernel[u], stream));
     HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_kernel[u], 0));
     HIP_TRY(hipMemcpyAsync(h_counters + kTabCounters * (size_t)u, ctx->d_ws + o_counters + kCounterBytes * (size_t)u, kCounterBytes, hipMemcpyDeviceToHost,
                            ctx->aux_stream));
     HIP_TRY(hipEventRecord(ev_counters[u], ctx->aux_stream));
-  }
-  if ((rc = ctx->prof_end(1, stream))) return rc; // brackets every table kernel of the call
-  tr.mark("enqueued");
+    ++launched;
+    if (launched == n_units) return ctx->prof_end(1, stream); // brackets every table kernel of the call
+    return FGMM_OK;
+  };
+  if ((rc = ctx->prof_begin(1, stream))) return rc;
+  if (n_units == 0 && (rc = ctx->prof_end(1, stream))) return rc;
+  while (launched < std::min(n_units, kLaunchAhead))
+    if ((rc = launch_next())) return rc;
+  tr.mark("first launches enqueued");
 
   // ---- the host side: (item, piece) tasks --------------------------------------------------------------------------------
   std::mutex mu; // guards the schedule state of the items, the ready heap, `abandon`, `unfinished`
@@ -1697,6 +1711,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   std::vector<std::array<double, 3>> unit_trace; // trace level 2: [queued at, bytes, landed at] per unit
   for (int u = 0; u < n_units; ++u) {
     Unit &un = units[(size_t)u];
+    while (launched < std::min(n_units, u + 1 + kLaunchAhead))
+      if ((rc = launch_next())) return rc;
     HIP_TRY(hipEventSynchronize(ev_counters[u]));
     unsigned long long *cn = h_counters + kTabCounters * (size_t)u;
     // Not placed as launched: a look-back gave up (bit 1; never seen outside the test that forces it) - once more with the
