@@ -622,12 +622,18 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   struct SegWaitArg {
     hipEvent_t *ev;       // the copy groups' events
     const int32_t *group; // EncItem::seg_group
+    Trace *tr;            // trace level 2: the time spent waiting, per job
+    double waited;
   };
   std::vector<SegWaitArg> seg_args((size_t)count);
   PoolDrain drain{ctx->pool};
   auto seg_wait = +[](void *arg, int sg) -> int {
     SegWaitArg *a = static_cast<SegWaitArg *>(arg);
-    return hipEventSynchronize(a->ev[a->group[sg]]) == hipSuccess ? FGMM_OK : FGMM_ERR_HIP;
+    if (a->tr->level < 2) return hipEventSynchronize(a->ev[a->group[sg]]) == hipSuccess ? FGMM_OK : FGMM_ERR_HIP;
+    const double t0 = a->tr->ms();
+    const bool ok = hipEventSynchronize(a->ev[a->group[sg]]) == hipSuccess;
+    a->waited += a->tr->ms() - t0;
+    return ok ? FGMM_OK : FGMM_ERR_HIP;
   };
   // jobs: runs of up to `enc_ways` bitstreams adjacent in `order` (similar sizes), coded in turn by one worker; a bitstream that
   // is a worker's fair share by itself (>= 1 / (2 * workers) of the call) is a job of its own - sixteen large pairs on eight
@@ -713,7 +719,7 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     for (int r = g_begin; r <= pos; ++r) last_group = std::max(last_group, group_of[order[(size_t)r]]);
     if (!segmented) HIP_TRY(hipEventSynchronize(ctx->events[last_group])); // copies complete in the order they were queued
     const char *h_ws = ctx->h_ws;
-    if (segmented) seg_args[(size_t)i] = SegWaitArg{ctx->sleep_events.data(), it.seg_group};
+    if (segmented) seg_args[(size_t)i] = SegWaitArg{ctx->sleep_events.data(), it.seg_group, &tr, 0.0};
     SegWaitArg *const seg_arg = segmented ? &seg_args[(size_t)i] : nullptr;
     EncItem *const *first = &job_items[(size_t)g_begin];
     const double t_sub = tr.ms();
@@ -797,8 +803,8 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   tr.mark("host rANS done");
   if (tr.level > 1)
     for (int i = 0; i < count; ++i)
-      fprintf(stderr, "[fgmm encode]   item %2d  submitted %7.3f  job %7.3f .. %7.3f  (%.3f ms)\n", i, items[i].t_sub,
-              items[i].t_start, items[i].t_end, items[i].t_end - items[i].t_start);
+      fprintf(stderr, "[fgmm encode]   item %2d  submitted %7.3f  job %7.3f .. %7.3f  (%.3f ms, %.3f of it waiting for its table's segments)\n", i,
+              items[i].t_sub, items[i].t_start, items[i].t_end, items[i].t_end - items[i].t_start, segmented ? seg_args[(size_t)i].waited : 0.0);
   for (auto &it : items)
     if (it.status) return fail(it.status, "host rANS encode failed (%d)", it.status);
   return FGMM_OK;
