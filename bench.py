@@ -48,6 +48,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0  # ... what a float4 copy kernel reaches on the chip (same guide): reported beside the spec fraction, never instead of it
 # VALU issue peak of the chip as scripts/valu_peak.hip measures it (profiles/r02_valu_peak.txt): a wave64 fp32 instruction
 # issues once per 4 cycles per SIMD: 256 CUs x 4 SIMDs x 64 lanes / 4 cycles x 2.4 GHz
 VALU_PEAK_LANE_SLOTS = 256 * 4 * 64 / 4 * 2.4e9
@@ -1005,7 +1006,8 @@ def main(argv=None):
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": "recorded PMC measurement of this workload (file in traffic_source), not collected in this run",
                          "launch_ms": round(sym_ms, 4), "bytes_per_launch": n_coded * leg.bytes_per_symbol,
-                         "bytes_per_symbol": leg.bytes_per_symbol},
+                         "bytes_per_symbol": leg.bytes_per_symbol,
+                         "frac_of_measured_copy_bandwidth": round(achieved / HBM_COPY_GBS, 4), "measured_copy_bandwidth": HBM_COPY_GBS},
             # the decode-side table kernel against BOTH of its rooflines: VALU issue and HBM
             "roofline_decode": {"kernel": "tab_kernel (decode-side edge tables, all launches of a step)", "bound": "valu",
                                 "ms_per_step": round(tab_ms, 4), "edges_evaluated": int(n_edges),
