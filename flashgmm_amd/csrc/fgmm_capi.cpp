@@ -239,7 +239,7 @@ struct fgmm_ctx {
   hipStream_t aux_stream = nullptr;  // the few bytes of per-launch counters
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
-    int64_t pieces = 8, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, tab_place = 0, tab_spin = kTabSpinLimit, copy_engine = 0, enc_segs = 1, scatter_rounds = 1;
+    int64_t pieces = 0, dec_group = 0, dec_first = 2, tab_cap_e = kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0, ef_min = kTabEfDefault, dec_pair = 0, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, tab_place = 0, tab_spin = kTabSpinLimit, copy_engine = 0, enc_segs = 1, scatter_rounds = 1;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies
   // are in flight (sizes are only known launch by launch)
@@ -1178,8 +1178,16 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   // early as possible), later rounds are one launch + one copy each.
   int np = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.pieces, 1), kMaxPieces);
   {
-    int64_t lat = 0;
-    for (int k = 0; k < n_fast; ++k) lat += items[fast[k]].n;
+    int64_t lat = 0, lat_max = 0;
+    for (int k = 0; k < n_fast; ++k) lat += items[fast[k]].n, lat_max = std::max(lat_max, items[fast[k]].n);
+    if (ctx->opt.pieces <= 0) {
+      // automatic: eight pieces leave a Kodak half's decoder at most 4 096 latents (1 / 36 of its bitstream, 40 us) behind the bus's last
+      // byte; a bitstream of an ELIC-4K stage is up to 24 times as long, and so were its first piece (the head of the call) and its last
+      // (the tail) - as many pieces as keep the last one at that size, at most 24 (ELIC-4K, 16 images: 231 -> 210 ms per step with 24,
+      // 32 no better; profiles/r04_elic_pieces_ab.txt)
+      np = 8;
+      while (np < kAutoPiecesMax && (int64_t)np * (np + 1) / 2 * 4096 < lat_max) ++np;
+    }
     if (lat < 65536) np = 1; // pieces only pay for rows that take a while to cross
     if (decoders == 1) np = std::min(np, 3); // one decoder: pieces only let it start early, and each costs a hand-over (20 us)
     // every round costs this thread ~60 us of launch / counter / copy round trips: no more rounds than the tables' time on the bus
@@ -1928,7 +1936,7 @@ struct OptName {
   const char *env; // read once at context creation (compatibility with round-1 scripts)
 };
 const OptName kOpts[] = {
-    {"pieces", &fgmm_ctx::Opts::pieces, 1, kMaxPieces, "FGMM_PIECES"},
+    {"pieces", &fgmm_ctx::Opts::pieces, 0, kMaxPieces, "FGMM_PIECES"},
     {"dec_group", &fgmm_ctx::Opts::dec_group, 0, 1 << 20, "FGMM_DEC_GROUP"},
     {"dec_first", &fgmm_ctx::Opts::dec_first, 1, 1 << 20, "FGMM_DEC_FIRST"},
     {"tab_cap_e", &fgmm_ctx::Opts::tab_cap_e, 256, 32768, "FGMM_TAB_CAP_E"},

@@ -131,7 +131,8 @@ int launch_segzero(const SegDesc *d_descs, int count, int64_t max_dead, void *st
 //                                         bits [LB + j * l, LB + (j + 1) * l), LB = HB rounded up to 8: the low l bits of E_j
 //   placement: sequential in latent order (generic path, the building-block API), or per block of `tl` latents at
 //   rows + 4 * blk_off[block] (tab_kernel: blocks are placed by an atomic cursor, in no particular order)
-constexpr int kMaxPieces = 16; // FGMM_MAX_PIECES
+constexpr int kMaxPieces = 32; // FGMM_MAX_PIECES
+constexpr int kAutoPiecesMax = 24; // what the automatic choice goes up to (option "pieces" 0)
 constexpr int kEncSegs = 4;    // EncDesc::packed_seg
 constexpr int kTabEdgeSlots = 64;               // DecDesc::counters
 constexpr int kTabCounters = 4 + kTabEdgeSlots;

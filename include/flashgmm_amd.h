@@ -94,7 +94,8 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
 int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, const size_t *len, int count);
 
 /* Tuning knobs of a context (defaults in brackets).  Unknown names return FGMM_ERR_INVALID.
- *   "pieces"      [8]   decode: the tables of every bitstream of a call reach the host in this many pieces (at most 16),
+ *   "pieces"      [0]   decode: the tables of every bitstream of a call reach the host in this many pieces (at most 32; 0 = by the
+ *                       call's longest bitstream: 8 up to 147 k latents, 24 from 1.1 M on - the last piece stays ~4 000 latents),
  *                       piece-major and shrinking (piece p of P carries P - p parts of P (P + 1) / 2); the host workers take
  *                       (bitstream, piece) tasks as they land - a bitstream decodes sequentially, but its coder state
  *                       moves from worker to worker between pieces: what lands last leaves one small piece of host
