@@ -576,7 +576,7 @@ def test_stacked_batch_equals_item_lists(dtype):
 
 
 @pytest.mark.parametrize("pieces,first,group,threads,pair", [(4, 2, 0, 0, 0), (1, 2, 0, 0, 1), (2, 1, 0, 3, 1), (3, 9, 2, 0, 0), (8, 2, 0, 2, 1),
-                                                              (7, 1, 4, 16, 0), (8, 2, 0, 1, 1), (16, 2, 0, 0, 0)])
+                                                              (7, 1, 4, 16, 0), (8, 2, 0, 1, 1), (16, 2, 0, 0, 0), (32, 2, 0, 0, 0), (0, 3, 0, 5, 0)])
 def test_decode_piece_schedule_settings(ctx_options, pieces, first, group, threads, pair):
     """The tables of a decode batch land on the host in pieces, piece-major, and each host worker follows its own bitstreams
     piece by piece (fgmm_capi.cpp, decode_batch), alone or two at a time in turn (dec_pair): every setting of the schedule,
