@@ -432,28 +432,347 @@ def launch_ranks(a, argv):
     sys.stdout.flush()
 
 
-def cpu_throttle_counters():
-    """(nr_periods, nr_throttled, throttled_usec) of this process's cgroup (v2 cpu.stat, v1 cpu/cpu.stat), or None.
-    A timed region during which nr_throttled grows ran with the CPU quota exhausted: the number is the host's, not the path's."""
-    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
-        try:
-            kv = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
-            if "nr_throttled" in kv:
-                t = kv.get("throttled_usec") or str(int(kv.get("throttled_time", "0")) // 1000)
-                return int(kv.get("nr_periods", 0)), int(kv["nr_throttled"]), int(t)
-        except (OSError, ValueError):
+def _cgroup_dirs():
+    """directories of this process's cgroup and its ancestors as far as they are visible: [(label, dir)] - cgroup v2 (unified)
+    and the v1 cpu controller"""
+    rel2 = rel1 = None
+    try:
+        for ln in open("/proc/self/cgroup"):
+            a = ln.rstrip("\n").split(":", 2)
+            if len(a) == 3:
+                if a[1] == "":
+                    rel2 = a[2]
+                elif "cpu" in a[1].split(","):
+                    rel1 = a[2]
+    except OSError:
+        pass
+    out = []
+    for tag, roots, rel in (("v2", ("/sys/fs/cgroup", "/sys/fs/cgroup/unified"), rel2), ("v1", ("/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"), rel1)):
+        if rel is None:
             continue
-    return None
+        for root in roots:
+            r, seen = rel.rstrip("/"), 0
+            while True:
+                d = root + r
+                if os.path.exists(os.path.join(d, "cpu.stat")):
+                    out.append((f"{tag}:{r or '/'}", d))
+                    seen += 1
+                if not r:
+                    break
+                r = r[: r.rfind("/")]
+            if seen:
+                break
+    return out
 
 
-def step_stats(step_s, before, after):
-    """per-step wall times of a timed region + what the cgroup's CPU controller did to the process meanwhile"""
+class HostProbe:
+    """What the HOST did to this process during a timed region, step by step: raw reads between steps (a clock, the process's CPU
+    time, a few pread()s of files kept open - parsed after the region), so that a slow step can be told apart: the cgroup's CPU
+    controller throttled it (cpu.stat of every visible level), its threads waited for a CPU (pressure files, per-thread run delay),
+    it spun (CPU time up), or it waited for the device / the bus with its CPUs idle (none of those moved).
+    full=False: cpu.stat + cpu.pressure of the cgroup levels (two or three pread()s, ~10 us per step: the headline's region);
+    full=True: + memory / io pressure, the host-wide /proc/pressure/*, /proc/stat, /proc/loadavg and every thread's schedstat
+    (a few hundred pread()s, ~0.5 ms per step: the diagnostic leg only)."""
+
+    def __init__(self, full: bool = False):
+        self.full, self.fds, self.samples = full, [], []
+        names = ("cpu.stat", "cpu.pressure") + (("memory.pressure", "io.pressure") if full else ())
+        for label, d in _cgroup_dirs():
+            for nm in names:
+                self._open(f"{label}:{nm}", os.path.join(d, nm))
+        if full:
+            for nm in ("cpu", "memory", "io"):
+                self._open(f"host:pressure.{nm}", f"/proc/pressure/{nm}")
+            self._open("host:stat", "/proc/stat")
+            self.comm = {}
+            self._open("host:loadavg", "/proc/loadavg")
+            self._open("host:vmstat", "/proc/vmstat")
+            self._open("self:stat", "/proc/self/stat")
+            try:
+                for tid in os.listdir("/proc/self/task"):
+                    self._open(f"task:{tid}", f"/proc/self/task/{tid}/schedstat")
+                    try:
+                        self.comm[tid] = open(f"/proc/self/task/{tid}/comm").read().strip()
+                    except OSError:
+                        pass
+            except OSError:
+                pass
+
+    def _open(self, key, path):
+        try:
+            fd = os.open(path, os.O_RDONLY)
+            os.pread(fd, 64, 0)
+            self.fds.append((key, fd))
+        except OSError:
+            pass
+
+    def sample(self):
+        raw = []
+        for k, fd in self.fds:
+            try:
+                raw.append(os.pread(fd, 16384 if k == "host:vmstat" else 4096, 0))
+            except OSError:  # (a thread that has exited)
+                raw.append(b"")
+        self.samples.append((time.perf_counter(), time.process_time(), raw))
+
+    def close(self):
+        for k, fd in self.fds:
+            try:
+                if fd >= 0:
+                    os.close(fd)
+            except OSError:
+                pass
+        self.fds = [(k, -1) for k, _ in self.fds]  # (the keys stay: per_step() parses after the region)
+
+    @staticmethod
+    def _parse(key, b):
+        """-> {counter: number} (monotone counters only, except loadavg's runnable count)"""
+        t = b.decode(errors="replace")
+        out = {}
+        if key.endswith("cpu.stat"):
+            for ln in t.splitlines():
+                a = ln.split()
+                if len(a) == 2 and a[0] in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec", "throttled_time", "nr_bursts", "burst_usec"):
+                    out["throttled_usec" if a[0] == "throttled_time" else a[0]] = int(a[1]) // (1000 if a[0] == "throttled_time" else 1)
+        elif "pressure" in key:
+            for ln in t.splitlines():
+                a = ln.split()
+                if a and a[0] in ("some", "full"):
+                    for f in a[1:]:
+                        if f.startswith("total="):
+                            out[a[0] + "_us"] = int(f[6:])
+        elif key == "host:stat":
+            a = t.split("\n", 1)[0].split()
+            if a and a[0] == "cpu":
+                v = [int(x) for x in a[1:]]
+                out["busy_jiffies"] = sum(v[:3]) + sum(v[5:8])  # user nice system + irq softirq steal
+                out["idle_jiffies"] = v[3] + v[4]
+        elif key == "host:vmstat":  # automatic NUMA balancing at work (host-wide counters): PTEs made inaccessible, hinting faults, pages moved
+            for ln in t.splitlines():
+                a = ln.split()
+                if len(a) == 2 and a[0] in ("numa_pte_updates", "numa_hint_faults", "numa_hint_faults_local", "numa_pages_migrated", "pgmigrate_success",
+                                            "pgfault", "thp_split_pmd", "nr_tlb_remote_flush", "nr_tlb_remote_flush_received"):
+                    out[a[0]] = int(a[1])
+        elif key == "self:stat":  # this process's own page faults (minor, major) and context: are the host's fault bursts ours?
+            a = t.rsplit(")", 1)[-1].split()
+            if len(a) > 10:
+                out["minflt"], out["majflt"] = int(a[7]), int(a[9])
+        elif key == "host:loadavg":
+            a = t.split()
+            if len(a) >= 4 and "/" in a[3]:
+                out["runnable_now"] = int(a[3].split("/")[0])
+        elif key.startswith("task:"):
+            a = t.split()
+            if len(a) >= 2:
+                out["exec_ns"], out["run_delay_ns"] = int(a[0]), int(a[1])
+        return out
+
+    def per_step(self):
+        """-> list (one per interval between consecutive samples) of {"ms", "cpu_ms", "<file>.<counter>": delta ...}; thread files
+        are summed into "threads.exec_ms" / "threads.run_delay_ms" """
+        parsed = [(t, c, [self._parse(k, b) for (k, _), b in zip(self.fds, raw)]) for t, c, raw in self.samples]
+        steps = []
+        for (t0, c0, p0), (t1, c1, p1) in zip(parsed, parsed[1:]):
+            d = {"ms": (t1 - t0) * 1e3, "cpu_ms": (c1 - c0) * 1e3}
+            ex = rd = 0
+            for (k, _), a, b in zip(self.fds, p0, p1):
+                for name in b:
+                    if name not in a:
+                        continue
+                    if k.startswith("task:"):
+                        ex, rd = ex + (b[name] - a[name] if name == "exec_ns" else 0), rd + (b[name] - a[name] if name == "run_delay_ns" else 0)
+                    elif name == "runnable_now":
+                        d[f"{k}.{name}"] = b[name]
+                    else:
+                        d[f"{k}.{name}"] = b[name] - a[name]
+            if self.full:
+                d["threads.exec_ms"], d["threads.run_delay_ms"] = ex / 1e6, rd / 1e6
+                per = [(k[5:], (b.get("run_delay_ns", 0) - a.get("run_delay_ns", 0)) / 1e6, (b.get("exec_ns", 0) - a.get("exec_ns", 0)) / 1e6)
+                       for (k, _), a, b in zip(self.fds, p0, p1) if k.startswith("task:") and "run_delay_ns" in a and "run_delay_ns" in b]
+                d["_threads"] = sorted(per, key=lambda x: -x[1])[:6]  # (tid, run delay ms, exec ms): who waited for a CPU
+            steps.append(d)
+        return steps
+
+
+def step_stats(step_s, probe: "HostProbe | None" = None):
+    """per-step wall times of a timed region + what the host did to the process meanwhile (HostProbe, sampled between steps):
+    cpu_ms = CPU time of all threads of the process per step; per cgroup level the CPU controller's throttling over the region and
+    the pressure-stall time (threads runnable but not running) per step"""
     ms = np.asarray(step_s) * 1e3
     out = {"min": round(float(ms.min()), 3), "median": round(float(np.median(ms)), 3), "p90": round(float(np.percentile(ms, 90)), 3),
            "max": round(float(ms.max()), 3), "all": [round(float(v), 2) for v in ms]}
-    if before and after:
-        out["cpu_throttled"] = {"periods": after[0] - before[0], "nr_throttled": after[1] - before[1],
-                                "throttled_ms": round((after[2] - before[2]) / 1e3, 1)}
+    if probe is not None and len(probe.samples) >= 2:
+        st = probe.per_step()
+        out["cpu_ms"] = [round(d["cpu_ms"], 1) for d in st]
+        levels = sorted({k.rsplit(":", 1)[0] for k in st[0] if ":cpu.stat." in k or ":cpu.pressure." in k})
+        thr = {}
+        for lv in levels:
+            key, e = lv + ":cpu.stat", {}
+            if key + ".nr_throttled" in st[0]:
+                e = {"periods": sum(d.get(key + ".nr_periods", 0) for d in st), "nr_throttled": sum(d.get(key + ".nr_throttled", 0) for d in st),
+                     "throttled_ms": round(sum(d.get(key + ".throttled_usec", 0) for d in st) / 1e3, 1)}
+            if key + ".usage_usec" in st[0]:
+                e["usage_ms"] = [round(d.get(key + ".usage_usec", 0) / 1e3, 1) for d in st]
+            psi = lv + ":cpu.pressure.some_us"
+            if psi in st[0]:
+                e["cpu_pressure_some_ms"] = [round(d.get(psi, 0) / 1e3, 2) for d in st]
+            thr[lv] = e
+        out["cpu_throttled"] = thr
+        out["nr_throttled"] = sum(v.get("nr_throttled", 0) for v in thr.values())
+    return out
+
+
+def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
+    """The self-diagnosing leg.  `configs` = [host workers, ...]; the configurations take
+    turns in blocks of `block` steps until each has run `steps` steps (boxes differ and drift: only interleaved blocks compare).
+    Every step is sampled with the full HostProbe and the library's call log (phase marks of the step's native calls); a helper
+    process (scripts/bin/host_watch) samples the host's count of runnable tasks and its own wake-up lateness every 0.5 ms.  For every
+    step slower than 1.3x its configuration's median the output says WHICH part stretched - the calling thread's glue, a call's
+    head (until its first table copy is queued), its bus phase (first copy queued -> last piece seen landed), its host tail (last
+    piece landed -> last coder done) - next to what the host did meanwhile: throttling at every cgroup level, pressure-stall time,
+    the run delay of this process's threads (runnable, not running) and which threads, CPU time, the host's runnable tasks."""
+    import subprocess
+
+    from flashgmm_amd import _lib
+
+    lr = leg.env.local_rank
+    before = _lib.lib().fgmm_ctx_threads(_lib.ctx(lr))
+    calls_per_step = 1 + (leg.spi if schedule == "codec" else 1)
+
+    def phases(calls):
+        ph = {}
+        for j, c in enumerate(calls):
+            m, nm = c["ms"], f"call{j}_{c['kind']}"
+            ph[nm + ".head"] = m[1]
+            ph[nm + ".bus"] = max(m[3] - m[1], 0.0)
+            ph[nm + ".host_tail"] = max(m[4] - max(m[3], m[1]), 0.0)
+            ph[nm + ".end"] = max(m[5] - m[4], 0.0)
+            ph[nm + ".worker_busy"] = c["worker_busy_ms"]
+            ph[nm + ".worker_wait"] = c["worker_wait_ms"]
+        return ph
+
+    rounds = max(1, (steps + block - 1) // block)
+    watch = None
+    exe = os.path.join(ROOT, "scripts", "bin", "host_watch")
+    if os.path.exists(exe):
+        try:
+            with _plain_children():
+                watch = subprocess.Popen([exe, str(60.0)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        except OSError:
+            watch = None
+    per = {c: {"st": [], "ph": [], "t": [], "comm": {}} for c in configs}
+    try:
+        for _ in range(rounds):
+            for cfg in configs:
+                _lib.set_threads(lr, cfg)
+                for _ in range(2):
+                    leg.step(schedule)
+                torch.cuda.synchronize()
+                probe = HostProbe(full=True)
+                logs = []
+                probe.sample()
+                for _ in range(block):
+                    leg.step(schedule)
+                    probe.sample()
+                    logs.append(_lib.call_log(lr, calls_per_step))
+                torch.cuda.synchronize()
+                probe.close()
+                st = probe.per_step()
+                ph = [phases(lg) for lg in logs]
+                for i in range(block):
+                    ph[i]["python_glue"] = st[i]["ms"] - sum(c["ms"][5] for c in logs[i])
+                e = per[cfg]
+                e["st"] += st
+                e["ph"] += ph
+                e["t"] += [(a[0] * 1e3, b[0] * 1e3) for a, b in zip(probe.samples, probe.samples[1:])]  # CLOCK_MONOTONIC ms, as host_watch's
+                e["comm"].update(probe.comm)
+    finally:
+        _lib.set_threads(lr, before)
+        wt = wr = wl = None
+        if watch is not None:
+            watch.terminate()
+            try:
+                raw = watch.communicate(timeout=10)[0].decode(errors="replace").split()
+                k = len(raw) // 3 * 3
+                wt, wr, wl = (np.asarray(raw[j:k:3], dtype=np.float64) for j in range(3))
+            except Exception:
+                wt = None
+    out = {"host_threads_tried": list(configs), "block": block, "host_watch": None}
+    if wt is not None and len(wt):
+        # the host's runnable tasks: how often do they surge (other tenants' threads, all runnable at once), and at which cadence?
+        r_med = float(np.median(wr))
+        thr = max(3.0 * r_med, r_med + 64.0)
+        up = np.flatnonzero((wr > thr) & (np.concatenate(([0.0], wr[:-1])) <= thr))  # rising edges
+        at = wt[up] - wt[0]
+        gaps = np.diff(at)
+        out["host_watch"] = {
+            "samples": int(len(wt)), "runnable_median": r_med, "runnable_p99": float(np.percentile(wr, 99)), "runnable_max": float(wr.max()),
+            "surge_threshold": thr, "surges": int(len(up)), "surges_per_s": round(len(up) / max((wt[-1] - wt[0]) / 1e3, 1e-9), 1),
+            "surge_gap_ms_median": round(float(np.median(gaps)), 1) if len(gaps) else None,
+            "surge_gaps_ms_first_20": [round(float(g), 1) for g in gaps[:20]],
+            "watcher_late_over_1ms": int((wl > 1.0).sum()), "watcher_late_max_ms": round(float(wl.max()), 2),
+            "note": "scripts/bin/host_watch: /proc/loadavg's runnable tasks of the whole host every 0.5 ms + the lateness of its own wake-ups"}
+    for cfg in configs:
+        e = per[cfg]
+        st, ph, n = e["st"], e["ph"], len(e["st"])
+        ms = np.asarray([d["ms"] for d in st])
+        med = float(np.median(ms))
+        slow = [i for i in range(n) if ms[i] > 1.3 * med]
+        normal = [i for i in range(n) if ms[i] <= 1.15 * med]
+        keys = sorted((set(st[0]) | set(ph[0])) - {"_threads"})
+        keys = [k for k in keys if not k.endswith((".nr_periods", ".usage_usec"))]
+
+        def val(i, k):
+            return ph[i][k] if k in ph[i] else st[i].get(k, 0)
+
+        def watched(i):
+            """the host's runnable tasks and the watcher's lateness while step i ran"""
+            if wt is None or not len(wt):
+                return None
+            m = (wt >= e["t"][i][0]) & (wt <= e["t"][i][1])
+            return (float(wr[m].max()), float(wl[m].max())) if m.any() else None
+
+        norm = {k: float(np.median([val(i, k) for i in normal])) for k in keys} if normal else {}
+        rows = []
+        for i in slow[:10]:
+            row = {"step": i, "ms": round(float(ms[i]), 2)}
+            moved = {}
+            for k in keys:
+                v, n0 = val(i, k), norm.get(k, 0.0)
+                if k.endswith(("_us", "_usec")):
+                    if v - n0 > 300:
+                        moved[k] = [round(v / 1e3, 2), round(n0 / 1e3, 2), "ms"]
+                elif k.endswith((".nr_throttled", ".nr_bursts", ".majflt")):
+                    if v > 0:
+                        moved[k] = [v, n0]
+                elif k.endswith(("jiffies", "runnable_now")) or k.startswith("host:vmstat"):
+                    continue
+                elif k.endswith(".minflt"):
+                    if v - n0 > 1000:
+                        moved[k] = [v, n0]
+                elif k != "ms" and v - n0 > 0.3:
+                    moved[k] = [round(v, 2), round(n0, 2)]
+            row["moved_[slow,normal]"] = moved
+            w = watched(i)
+            if w:
+                row["host_runnable_max"], row["watcher_late_max_ms"] = w[0], round(w[1], 2)
+            row["host_pgfault"] = st[i].get("host:vmstat.pgfault")
+            row["threads_that_waited_[name,run_delay_ms,exec_ms]"] = [[e["comm"].get(t, t), round(rd, 2), round(ex, 2)] for t, rd, ex in st[i].get("_threads", []) if rd > 0.2]
+            rows.append(row)
+        wn = [watched(i) for i in normal]
+        wn = [w for w in wn if w]
+        out[str(cfg)] = {
+            "host_threads": cfg, "steps": n, "median_ms": round(med, 3), "p90_ms": round(float(np.percentile(ms, 90)), 3),
+            "max_ms": round(float(ms.max()), 3), "mean_ms": round(float(ms.mean()), 3), "p90_over_median": round(float(np.percentile(ms, 90)) / med, 3),
+            "slow_steps": len(slow), "all_ms": [round(float(v), 2) for v in ms],
+            "run_delay_ms_per_step": {"normal_median": round(norm.get("threads.run_delay_ms", 0.0), 2),
+                                      "slow_median": round(float(np.median([st[i]["threads.run_delay_ms"] for i in slow])), 2) if slow else None},
+            "host_runnable_max_per_step": {"normal_median": float(np.median([w[0] for w in wn])) if wn else None,
+                                           "slow_median": float(np.median([w[0] for w in map(watched, slow) if w])) if slow and wt is not None and len(wt) else None},
+            "normal_medians": {k: round(v / 1e3, 3) if k.endswith(("_us", "_usec")) else round(v, 3) for k, v in norm.items()
+                               if not k.endswith(("jiffies",)) and not k.startswith("host:vmstat") and (abs(v) > 1e-9 or k.endswith("nr_throttled"))},
+            "slow": rows,
+        }
     return out
 
 
@@ -637,16 +956,18 @@ class Leg:
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
-        c0 = cpu_throttle_counters()
-        marks = [time.perf_counter()]
+        probe = HostProbe()
+        probe.sample()
         for _ in range(steps):
             self.last["res"], self.last["outs"] = self.step(schedule, record=record)
-            marks.append(time.perf_counter())
+            probe.sample()
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
         t1 = time.perf_counter()
-        return t1 - marks[0], step_stats(np.diff(marks), c0, cpu_throttle_counters())
+        probe.close()
+        marks = [sm[0] for sm in probe.samples]
+        return t1 - marks[0], step_stats(np.diff(marks), probe)
 
     def check_last(self):
         """correctness of what was timed: decode(encode(y)) == round(y) for every stream of this rank"""
@@ -743,6 +1064,11 @@ def main(argv=None):
     ap.add_argument("--checkpoint-stride", type=_stride, default=1024,
                     help="stride of the `checkpointed` extra legs: symbols between the out-of-band notes of the coder state (16 B each)")
     ap.add_argument("--host-threads", type=int, default=0, help="host rANS workers per GPU (0: this rank's share of the CPU budget)")
+    ap.add_argument("--diag-steps", type=int, default=40,
+                    help="steps per pool size of the self-diagnosing `step_diag` leg (0: skip): full host probes + the library's call log, "
+                         "slow steps explained phase by phase")
+    ap.add_argument("--diag-pools", default="", help="step_diag: comma-separated host-worker counts that take turns in blocks of 20 steps (default: the "
+                                                     "context's pool and - when that is a different number - as many workers as the quota has CPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip upper_bound / latency / per-thread legs (profiling runs)")
     ap.add_argument("--no-sublegs", action="store_true",
@@ -897,6 +1223,17 @@ def main(argv=None):
                 one_image(True)
                 extras["latency_ms"]["as_codec_checkpointed_stride_256"] = round(float(np.median([one_image(True) for _ in range(reps)])), 3)
                 extras["latency_ms"]["checkpoint_bytes_stride_256"] = int(sum(16 * len(x[0][0].ckpt) for x in r_256))
+            if a.diag_steps > 0:
+                threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
+                if a.diag_pools:
+                    cfgs = [int(x) for x in a.diag_pools.split(",") if x]
+                else:
+                    by_quota = max(1, int(_lib.host_cpu_budget()["cpus"] // _lib.ranks_on_node()))
+                    cfgs = [threads] + ([by_quota] if by_quota != threads else [])
+                try:
+                    extras["step_diag"] = step_diag(leg, a.schedule, a.diag_steps, cfgs)
+                except Exception as e:  # pragma: no cover - a diagnostic must not cost the run its line
+                    extras["step_diag"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             # one host thread instead of the pool: what the GPU path is worth per host core
             threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
             _lib.set_threads(local_rank, 1)
@@ -968,9 +1305,9 @@ def main(argv=None):
         # host memory traffic of the plain path per rank: every table byte is written once by the DMA and read once by a host
         # worker (encode tables + decode tables), per second of stepping
         host_traffic = 2.0 * (enc_table_bytes + tbytes) / (ms_per_step * 1e-3) / 1e9
-        note = (f"{host_threads} host rANS workers for this GPU = min(affinity {budget.get('affinity')}, cgroup quota "
-                f"{budget.get('quota')}) / {_lib.ranks_on_node()} rank(s) on the node - x3 (up to the rank's share of the mask) where the quota, a limit on CPU time, "
-                f"is the smaller: the workers sleep most of a call - at most 48")
+        note = (f"{host_threads} host rANS workers for this GPU: min(affinity {budget.get('affinity')}, cgroup quota "
+                f"{budget.get('quota')}) / {_lib.ranks_on_node()} rank(s) on the node, times FGMM_WORKERS_PER_CPU (default 3, up to the rank's share of "
+                f"the mask) where the quota, a limit on CPU time, is the smaller - the workers sleep most of a call; at most 48")
         if host_threads < 8:
             note += ("; FEWER THAN 8 WORKERS: the plain (table) path is host-bound by configuration here - its rate follows the "
                      "workers (one_host_thread x workers), the `checkpointed` leg does not need them")
@@ -1033,6 +1370,10 @@ def main(argv=None):
             "reference_md5": ka1,
         }
         out.update(extras)
+        out["host_throttled"] = bool(step_ms.get("nr_throttled", 0))
+        if out["host_throttled"]:
+            print(f"[bench] THE CGROUP'S CPU CONTROLLER THROTTLED THIS PROCESS DURING THE TIMED REGION ({step_ms.get('cpu_throttled')}): `value` "
+                  f"measures the quota, not the path - fewer host workers (--host-threads, FGMM_WORKERS_PER_CPU) or a larger quota", file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(leg.host, leg.shapes1, pix_per_image, spi, rank, f16)
             if "one_host_thread" in extras and cb.get("value"):
@@ -1040,7 +1381,10 @@ def main(argv=None):
             if cb.get("all_cores", {}).get("value"):
                 cb["speedup_vs_all_cores"] = round(value / cb["all_cores"]["value"], 1)
             if cb.get("value"):
-                cb["speedup"] = round(value / cb["value"], 1)  # whole GPU path (all host workers) over ONE reference thread
+                # THROUGHPUT: the whole GPU path (24 images in flight, all host workers) over ONE reference thread coding image after
+                # image.  north_star's >= 100x is worded on LATENCY: that ratio is latency_ms.speedup_plain (one image through the
+                # reference's interface) and its floor is the sequential rANS decoder, see latency_ms.note
+                cb["throughput_speedup"] = round(value / cb["value"], 1)
             if "latency_ms" in out:
                 lt = out["latency_ms"]
                 lt["reference_cpu"] = cb["ms_per_image"]
@@ -1050,6 +1394,11 @@ def main(argv=None):
                 ck_key = "as_codec_checkpointed_stride_256" if "as_codec_checkpointed_stride_256" in lt else "as_codec_checkpointed"
                 lt["speedup_checkpointed"] = round(cb["ms_per_image"] / lt[ck_key], 1)
                 lt["speedup_checkpointed_basis"] = ck_key
+                lt["note"] = ("north_star's >= 100x is stated on one-image latency: speedup_plain is that number through the reference's own "
+                              "interface (byte-identical single rANS streams), speedup_checkpointed needs out-of-band notes the reference's "
+                              "format does not have.  100x is out of reach with byte-identical streams: a 129 k-symbol stream encodes "
+                              "in 0.33 ms and decodes in 1.1-1.5 ms on one core (9-11 ns per symbol, a dependent chain), and the codec's two "
+                              "halves decode one after the other: 0.5 + 2 x 1.5 ms against the reference's 42 ms is 12x at best")
             out["cpu_baseline"] = cb
         emit(out)
     if dist:

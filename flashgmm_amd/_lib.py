@@ -43,6 +43,11 @@ class fgmm_ckpt(C.Structure):
     _fields_ = [("x", C.c_uint64), ("pos", C.c_uint64)]
 
 
+class fgmm_call_marks(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("count", C.c_int32), ("t_begin_ms", C.c_double), ("ms", C.c_double * 6),
+                ("worker_busy_ms", C.c_double), ("worker_wait_ms", C.c_double)]
+
+
 class fgmm_item(C.Structure):
     _fields_ = [("y", C.c_void_p), ("params", fgmm_params), ("M", C.c_int32), ("K", C.c_int32), ("hw", C.c_int64),
                 ("yq_out", C.c_void_p), ("zero_bitmap", C.c_void_p), ("abs_max", C.c_int32),
@@ -86,6 +91,7 @@ SIGNATURES = {
     "fgmm_ctx_set_profiling": (_i, [_p, _i]),
     "fgmm_ctx_kernel_ms": (_i, [_p, _i, C.POINTER(C.c_float)]),
     "fgmm_ctx_stat": (_i, [_p, _i, C.POINTER(C.c_uint64)]),
+    "fgmm_ctx_call_log": (_i, [_p, C.POINTER(fgmm_call_marks), _i, C.POINTER(_i)]),
     "fgmm_encode_with_indexes_gmm": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _i32, _pp, _psz]),
     "fgmm_decode_with_indexes_gmm": (_i, [_p, _p, _sz, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _i32, _p]),
     "fgmm_gmc_compress": (_i, [_p, _p, _p, C.POINTER(fgmm_params), _i, _i, _i64, _i, _i, _p, C.POINTER(_i32), _p, _pp, _psz]),
@@ -301,3 +307,15 @@ def ctx_stat(device: int, which: int) -> int:
     out = C.c_uint64()
     check(lib().fgmm_ctx_stat(ctx(device), which, C.byref(out)), "fgmm_ctx_stat")
     return int(out.value)
+
+
+CALL_KINDS = {0: "encode", 1: "decode", 2: "decode_gpu"}
+
+
+def call_log(device: int, last: int = 64) -> list:
+    """phase marks of the context's most recent batched calls, oldest first (include/flashgmm_amd.h: fgmm_ctx_call_log)"""
+    buf = (fgmm_call_marks * 64)()
+    n = C.c_int()
+    check(lib().fgmm_ctx_call_log(ctx(device), buf, min(int(last), 64), C.byref(n)), "fgmm_ctx_call_log")
+    return [{"kind": CALL_KINDS.get(m.kind, m.kind), "count": m.count, "t_begin_ms": m.t_begin_ms, "ms": list(m.ms),
+             "worker_busy_ms": m.worker_busy_ms, "worker_wait_ms": m.worker_wait_ms} for m in buf[:n.value]]

@@ -11,6 +11,7 @@
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <math.h>
+#include <pthread.h>
 #include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -66,9 +67,7 @@ struct Trace {
   int level;
   std::chrono::steady_clock::time_point t0, last;
   const char *what;
-  Trace(const char *w, int lvl) : on(lvl > 0), level(lvl), what(w) {
-    if (on) t0 = last = std::chrono::steady_clock::now();
-  }
+  Trace(const char *w, int lvl) : on(lvl > 0), level(lvl), what(w) { t0 = last = std::chrono::steady_clock::now(); }
   void mark(const char *phase) {
     if (!on) return;
     const auto now = std::chrono::steady_clock::now();
@@ -77,14 +76,20 @@ struct Trace {
             std::chrono::duration<double, std::milli>(now - t0).count());
     last = now;
   }
-  double ms() const { return on ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() : 0.0; }
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } // (always: the call log)
 };
 
 // ---- host worker pool ----------------------------------------------------------------------------------
 class Pool {
 public:
   explicit Pool(int n) {
-    for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+    for (int i = 0; i < n; ++i)
+      th_.emplace_back([this, i] {
+        char name[16];
+        snprintf(name, sizeof name, "fgmm-w%d", i); // (visible in /proc/<pid>/task/<tid>/comm: bench.py's step_diag names the threads that waited for a CPU)
+        pthread_setname_np(pthread_self(), name);
+        run();
+      });
   }
   ~Pool() {
     {
@@ -309,6 +314,21 @@ struct fgmm_ctx {
     chunks.clear();
     d_ws = h_ws = d_stage = nullptr;
     d_cap = h_cap = d_stage_cap = 0;
+  }
+  // the call log: phase marks of the most recent batched calls (fgmm_ctx_call_log), always kept - a few clock reads per call
+  const std::chrono::steady_clock::time_point born = std::chrono::steady_clock::now();
+  static constexpr int kLogCap = 64;
+  fgmm_call_marks log[kLogCap];
+  unsigned long long log_n = 0;
+  void log_call(int kind, int count, const Trace &tr, const double ms[5], double busy, double wait) {
+    fgmm_call_marks &m = log[log_n++ % kLogCap];
+    m.kind = kind;
+    m.count = count;
+    m.t_begin_ms = std::chrono::duration<double, std::milli>(tr.t0 - born).count();
+    for (int k = 0; k < 5; ++k) m.ms[k] = ms[k];
+    m.ms[5] = tr.ms();
+    m.worker_busy_ms = busy;
+    m.worker_wait_ms = wait;
   }
   bool profiling = false;
   unsigned long long stat[7] = {0, 0, 0, 0, 0, 0, 0}; // [6] table launches re-run with the cursor after a look-back gave up (since the context exists); [4] bitstreams the GPU's segment decoder decoded, [5] ... handed back to the table path;
@@ -610,8 +630,10 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     }
   }
   tr.mark("enqueued");
+  double marks[5] = {tr.ms(), 0, 0, 0, 0}; // the call log: enqueued | kernels + side information here | jobs out | last table (segment) seen landed | last job done
   HIP_TRY(hipEventSynchronize(ctx->events[ev_meta]));
   tr.mark("kernels + meta landed");
+  marks[1] = tr.ms();
   ctx->stat[0] = 0;
   for (auto &it : items) ctx->stat[0] += sizeof(uint32_t) * (unsigned long long)it.M * (unsigned long long)it.hw;
 
@@ -622,17 +644,17 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
   struct SegWaitArg {
     hipEvent_t *ev;       // the copy groups' events
     const int32_t *group; // EncItem::seg_group
-    Trace *tr;            // trace level 2: the time spent waiting, per job
-    double waited;
+    Trace *tr;
+    double waited, last; // the time spent waiting, per job; when the last wait returned
   };
   std::vector<SegWaitArg> seg_args((size_t)count);
   PoolDrain drain{ctx->pool};
   auto seg_wait = +[](void *arg, int sg) -> int {
     SegWaitArg *a = static_cast<SegWaitArg *>(arg);
-    if (a->tr->level < 2) return hipEventSynchronize(a->ev[a->group[sg]]) == hipSuccess ? FGMM_OK : FGMM_ERR_HIP;
     const double t0 = a->tr->ms();
     const bool ok = hipEventSynchronize(a->ev[a->group[sg]]) == hipSuccess;
-    a->waited += a->tr->ms() - t0;
+    a->last = a->tr->ms();
+    a->waited += a->last - t0;
     return ok ? FGMM_OK : FGMM_ERR_HIP;
   };
   // jobs: runs of up to `enc_ways` bitstreams adjacent in `order` (similar sizes), coded in turn by one worker; a bitstream that
@@ -717,9 +739,12 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     const int g_begin = job_first[(size_t)pos], n_in = pos - g_begin + 1;
     int last_group = 0;
     for (int r = g_begin; r <= pos; ++r) last_group = std::max(last_group, group_of[order[(size_t)r]]);
-    if (!segmented) HIP_TRY(hipEventSynchronize(ctx->events[last_group])); // copies complete in the order they were queued
+    if (!segmented) {
+      HIP_TRY(hipEventSynchronize(ctx->events[last_group])); // copies complete in the order they were queued
+      marks[3] = tr.ms();
+    }
     const char *h_ws = ctx->h_ws;
-    if (segmented) seg_args[(size_t)i] = SegWaitArg{ctx->sleep_events.data(), it.seg_group, &tr, 0.0};
+    if (segmented) seg_args[(size_t)i] = SegWaitArg{ctx->sleep_events.data(), it.seg_group, &tr, 0.0, 0.0};
     SegWaitArg *const seg_arg = segmented ? &seg_args[(size_t)i] : nullptr;
     EncItem *const *first = &job_items[(size_t)g_begin];
     const double t_sub = tr.ms();
@@ -799,8 +824,20 @@ int encode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<EncItem> &items,
     if (count == 1) job(); else ctx->pool->submit(job);
   }
   tr.mark(segmented ? "jobs out" : "all tables landed, jobs out");
+  marks[2] = tr.ms();
   if (count > 1) ctx->pool->wait_all();
   tr.mark("host rANS done");
+  {
+    double busy = 0, wait = 0;
+    for (int i = 0; i < count; ++i) {
+      const double w = segmented ? seg_args[(size_t)i].waited : 0.0;
+      if (segmented) marks[3] = std::max(marks[3], seg_args[(size_t)i].last);
+      marks[4] = std::max(marks[4], items[i].t_end);
+      busy += items[i].t_end - items[i].t_start - w;
+      wait += w;
+    }
+    ctx->log_call(0, count, tr, marks, busy, wait);
+  }
   if (tr.level > 1)
     for (int i = 0; i < count; ++i)
       fprintf(stderr, "[fgmm encode]   item %2d  submitted %7.3f  job %7.3f .. %7.3f  (%.3f ms, %.3f of it waiting for its table's segments)\n", i,
@@ -1020,8 +1057,13 @@ int decode_batch_gpu(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &it
   if ((rc = ctx->prof_end(3, stream))) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->h_ws + o_status, ctx->d_ws + o_status, sizeof(uint32_t) * (size_t)n_segs, hipMemcpyDeviceToHost, stream));
   tr.mark("enqueued");
+  const double t_enq = tr.ms();
   HIP_TRY(hipStreamSynchronize(stream));
   tr.mark("segments decoded");
+  {
+    const double t_done = tr.ms(), mk[5] = {t_enq, t_enq, t_enq, t_done, t_done};
+    ctx->log_call(2, count, tr, mk, 0.0, 0.0);
+  }
   for (int k = 0; k < count; ++k) {
     DecItem &it = items[which[k]];
     const uint32_t *st = reinterpret_cast<const uint32_t *>(ctx->h_ws + off[(size_t)k].status);
@@ -1309,6 +1351,7 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     return rc;
   ctx->chunks_reset();
   tr.mark("planned, buffers ensured");
+  double marks[5] = {tr.ms(), 0, 0, 0, 0}; // the call log: planned | first copy queued | last copy queued | last piece seen landed | last decoder done
   // pinned output areas (decoded symbols) of all items
   {
     size_t out_total = 256;
@@ -1505,9 +1548,9 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       it.view = TabView{it.ef_min, it.hdr_form, it.tl, it.n_piece, it.piece, nullptr, nullptr};
       if (it.status == FGMM_OK) it.status = it.dec.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
     }
-    const double tw0 = tr.level > 1 ? tr.ms() : 0;
+    const double tw0 = tr.ms();
     if (it.status == FGMM_OK && !landed(it, p)) it.status = FGMM_ERR_HIP;
-    const double tw1 = tr.level > 1 ? tr.ms() : 0;
+    const double tw1 = tr.ms();
     it.t_waited += tw1 - tw0;
     it.t_lastland = tw1;
     if (p == 0) it.t_start = tw1;
@@ -1544,11 +1587,11 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     int p0 = 0;
     while (p0 + 1 < it.n_piece && it.piece_end[p0] <= lo) ++p0;
     const int p1 = seg_last_piece(it, sg);
-    const double tw0 = tr.level > 1 ? tr.ms() : 0;
+    const double tw0 = tr.ms();
     bool ok = !it.ckpt_bad.load(std::memory_order_relaxed);
     for (int p = p0; p <= p1 && ok; ++p)
       if (!landed(it, p)) ok = false;
-    const double tw1 = tr.level > 1 ? tr.ms() : 0;
+    const double tw1 = tr.ms();
     if (ok) {
       TabDecoder td;
       int rc2 = td.begin(it.enc, it.enc_len, &it.view, it.n, it.max_bs, it.sym);
@@ -1571,10 +1614,11 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       }
       if (acc) it.wide_any.store(1);
     }
-    if (tr.level > 1) {
+    {
       std::lock_guard<std::mutex> l(mu);
       it.t_waited += tw1 - tw0;
       it.t_work += tr.ms() - tw1;
+      it.t_lastland = std::max(it.t_lastland, tw1);
       if (sg == 0) it.t_taken = it.t_start = tw0;
     }
     if (it.segs_left.fetch_sub(1) != 1) return false;
@@ -1660,24 +1704,24 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
       l.unlock();
       DecItem &a = items[i0];
       prepare(a, p0);
-      const double t0 = tr.level > 1 ? tr.ms() : 0;
+      const double t0 = tr.ms();
       if (i1 < 0) {
         if (a.status == FGMM_OK) a.status = a.dec.piece(p0);
-        if (tr.level > 1) a.t_work += tr.ms() - t0;
+        a.t_work += tr.ms() - t0;
         const bool fa = complete(a, p0);
         l.lock();
         give_back(i0, p0, fa);
       } else {
         DecItem &b = items[i1];
         prepare(b, p1);
-        const double t1 = tr.level > 1 ? tr.ms() : 0;
+        const double t1 = tr.ms();
         if (a.status == FGMM_OK && b.status == FGMM_OK) {
           rans_decode_pieces2(a.dec, p0, b.dec, p1, &a.status, &b.status);
         } else {
           if (a.status == FGMM_OK) a.status = a.dec.piece(p0);
           if (b.status == FGMM_OK) b.status = b.dec.piece(p1);
         }
-        if (tr.level > 1) {
+        {
           const double dt = tr.ms() - t1;
           a.t_work += dt / 2;
           b.t_work += dt / 2;
@@ -1784,6 +1828,8 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
     }
     // rows are shared by the unit's items: account them once
     if (!un.parts.empty()) items[un.parts[0].item].table_bytes += used;
+    marks[2] = tr.ms();
+    if (u == 0) marks[1] = marks[2];
     if (tr.level > 1) unit_trace.push_back({tr.ms(), (double)(un.fixed + used), 0.0});
   }
   tr.mark("sizes known, copies queued");
@@ -1901,6 +1947,16 @@ int decode_batch(fgmm_ctx *ctx, hipStream_t stream, std::vector<DecItem> &items,
   tr.mark("host rANS done");
   HIP_TRY(hipStreamSynchronize(stream));
   tr.mark("y_hat written");
+  {
+    double busy = 0, wait = 0;
+    for (auto &it : items) {
+      marks[3] = std::max(marks[3], it.t_lastland);
+      marks[4] = std::max(marks[4], it.t_end);
+      busy += it.t_work;
+      wait += it.t_waited;
+    }
+    ctx->log_call(1, count, tr, marks, busy, wait);
+  }
   if (tr.level > 1)
     for (int i = 0; i < count; ++i)
       fprintf(stderr, "[fgmm decode]   item %2d  pieces %d  taken %7.3f  job %7.3f .. %7.3f  (decoding %.3f ms, waiting for copies %.3f, last piece at %.3f)\n",
@@ -2055,8 +2111,11 @@ int fgmm_host_thread_budget(int ranks_sharing) {
   // time; nr_throttled does not move, the bench line carries the counters) and is 3 % faster than 16 workers (48: step median
   // 9.41-9.60 ms, 16: 9.73-9.80 on quiet boxes; checkpointed streams +6 %: profiles/r04_host_threads.txt).  Never more workers than
   // the rank's share of the affinity mask; 16 / 14 / 12 workers: 962 / 938 / 891 Mpixels/s (profiles/r03_host_threads.md).
+  // FGMM_WORKERS_PER_CPU (1..4, default 3): the multiplier, for hosts where other processes of the same cgroup need part of the quota
+  int per_cpu = 3;
+  if (const char *e = getenv("FGMM_WORKERS_PER_CPU")) per_cpu = std::min(std::max(atoi(e), 1), 4);
   const int by_time = (int)floor(cpus + 1e-9), by_mask = (int)floor(aff_share + 1e-9);
-  const int t = quota > 0 && by_mask > by_time ? std::min(by_mask, 3 * by_time) : by_time;
+  const int t = quota > 0 && by_mask > by_time ? std::min(by_mask, per_cpu * by_time) : by_time;
   return std::max(1, std::min(t, 48));
 }
 int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {
@@ -2156,6 +2215,15 @@ int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out) {
   if (!ctx || which < 0 || which > 6 || !out) return fail(FGMM_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lock(ctx->mu);
   *out = ctx->stat[which];
+  return FGMM_OK;
+}
+
+int fgmm_ctx_call_log(fgmm_ctx *ctx, fgmm_call_marks *out, int cap, int *n_out) {
+  if (!ctx || cap < 0 || (cap && !out) || !n_out) return fail(FGMM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const unsigned long long have = std::min<unsigned long long>(ctx->log_n, (unsigned long long)std::min(cap, (int)fgmm_ctx::kLogCap));
+  for (unsigned long long k = 0; k < have; ++k) out[k] = ctx->log[(ctx->log_n - have + k) % fgmm_ctx::kLogCap];
+  *n_out = (int)have;
   return FGMM_OK;
 }
 

@@ -196,3 +196,4 @@ def bind_to_gpu_numa_node(device_index: int, all_threads: bool = True, bdf: Opti
         return f"gpu {device_index} ({bdf}) -> NUMA node {node}, {len(cpus)} CPUs, {moved} thread(s) bound"
     except Exception as e:  # pragma: no cover - topology files differ between hosts
         return f"gpu {device_index}: not bound ({e})"
+

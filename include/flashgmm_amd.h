@@ -161,6 +161,23 @@ int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable);
  * was created) table-kernel launches that were re-run with cursor placement because a look-back gave up (expected: 0). */
 int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out);
 int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out);
+/* The call log: phase marks of the context's most recent batched calls (at most 64 are kept), always recorded - a handful of
+ * clock reads per call.  What a caller needs to tell WHICH part of a slow call was slow: the GPU and the bus (marks 1..3), the host
+ * workers (mark 4 against mark 3, busy / wait), or the calling thread.  Times in milliseconds.
+ *   kind 0 = batched encode: ms[0] kernels and table copies enqueued, [1] kernels done and side information on the host, [2] host
+ *            jobs handed out, [3] last table (segment) seen landed by an encoder, [4] last encoder done, [5] call end
+ *   kind 1 = batched decode, table path: ms[0] planned and buffers ensured, [1] first table copy queued, [2] last table copy queued,
+ *            [3] last table piece seen landed by a decoder, [4] last decoder done, [5] call end (y_hat complete)
+ *   kind 2 = batched decode on the GPU (checkpointed bitstreams): ms[0..2] enqueued, [3..4] segments decoded, [5] call end
+ *   worker_busy_ms / worker_wait_ms: summed over the host jobs of the call - coding, and waiting for a table copy to land */
+typedef struct {
+  int32_t kind, count;   /* count: bitstreams of the call */
+  double t_begin_ms;     /* steady clock, since the context was created */
+  double ms[6];          /* since t_begin_ms */
+  double worker_busy_ms, worker_wait_ms;
+} fgmm_call_marks;
+/* out[0 .. *n_out) = the most recent min(cap, 64, calls so far) calls, oldest first */
+int fgmm_ctx_call_log(fgmm_ctx *ctx, fgmm_call_marks *out, int cap, int *n_out);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 1. The reference's native boundary (compressai.ans), same argument meaning and order.
