@@ -132,7 +132,7 @@ def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: b
 # here only as the reported baseline
 # ---------------------------------------------------------------------------------------------------------------------
 def _cpu_coder():
-    """-> (kind, prepare(host stream) -> state, code(state) -> (decoded symbols, expected symbols))"""
+    """-> (kind, prepare(host stream) -> state, code(state) -> (decoded symbols, expected symbols, the encoder's bytes))"""
     from flashgmm_amd import testing as T
     from oracle import oracle as O
 
@@ -157,9 +157,9 @@ def _cpu_coder():
         sym, s, m, w, am, want = st
         if kind == "reference":
             b = ans.RansEncoder().encode_with_indexes_gmm(sym, s, m, w, am + 1)
-            return ans.RansDecoder().decode_with_indexes_gmm(b, s, m, w, am + 1).numpy(), want
+            return ans.RansDecoder().decode_with_indexes_gmm(b, s, m, w, am + 1).numpy(), want, b
         b = O.encode_gmm(0, sym, s, m, w)
-        return O.decode_gmm(0, b, s, m, w, am + 1), want
+        return O.decode_gmm(0, b, s, m, w, am + 1), want, b
 
     return kind, prepare, code
 
@@ -207,7 +207,7 @@ def _scalar_worker(args):
     while passes < 3 and (passes < 1 or time.perf_counter() - t_start < budget_s):
         t0 = time.perf_counter()
         for st in states:
-            got, want = code(st)
+            got, want, _ = code(st)
             assert np.array_equal(got, want)  # the scalar path round-trips its own streams (they are not the SIMD path's)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
@@ -215,10 +215,60 @@ def _scalar_worker(args):
     return kind, sum(len(st[-1]) for st in states), best, passes
 
 
-def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank: int, f16: bool, budget_s: float = 10.0):
+def _mode_md5_worker(args):
+    """the reference's ENCODER under another approximation mode (APPROX_MODE is latched once per process,
+    rans_interface.cpp:99-115: its own process) on streams regenerated from their seeds -> (kind, [md5 of each bitstream])"""
+    mode_id, seeds, shapes, f16 = args
+    os.environ["APPROX_MODE"] = str(mode_id)
+    import hashlib
+
+    from flashgmm_amd import testing as T
+    from oracle import oracle as O
+
+    torch.set_num_threads(1)
+    ans = O.ref_ans() if O.ref_available() else None
+    out = []
+    for seed, (M, h, w) in zip(seeds, shapes):
+        y, sg, mu, pi = T.make_latent(seed, M=M, h=h, w=w)
+        if f16:
+            sg, mu, pi = T.to_float16_planes(sg, mu, pi)
+        sym, s, m, wt, am, zb, yq = T.to_coder_inputs(y, *(a.astype(np.float32) for a in (sg, mu, pi)))
+        if ans is not None:
+            b = ans.RansEncoder().encode_with_indexes_gmm(torch.from_numpy(sym), *(torch.from_numpy(np.ascontiguousarray(a.T)).T for a in (s, m, wt)), am + 1)
+        else:
+            b = O.encode_gmm(mode_id, sym, s, m, wt)
+        out.append(hashlib.md5(b).hexdigest())
+    return ("reference" if ans is not None else "port"), out
+
+
+def reference_bytes_of_modes(modes: dict, rank: int, shapes, streams_per_image: int, f16: bool):
+    """{mode name: [bytes of every bitstream of the HIP path]} -> {mode name: reference_bytes_equal}: the reference's encoder run on
+    the same streams in one helper process per mode (in parallel), md5 against md5"""
+    import hashlib
+    import multiprocessing as mp
+
+    from flashgmm_amd import _lib
+
+    names = list(modes)
+    n = len(modes[names[0]])
+    seeds = [stream_seed(rank, k // streams_per_image, k % streams_per_image, streams_per_image) for k in range(n)]
+    shp = [shapes[k % streams_per_image] for k in range(n)]
+    with _plain_children():
+        pool = mp.get_context("spawn").Pool(len(names))
+    with pool:
+        res = pool.map(_mode_md5_worker, [(_lib.mode_id(nm), seeds, shp, f16) for nm in names])
+    out = {}
+    for nm, (kind, md5s) in zip(names, res):
+        eq = sum(hashlib.md5(bytes(b)).hexdigest() == h for b, h in zip(modes[nm], md5s))
+        out[nm] = {"streams": n, "equal": eq, "kind": kind}
+    return out
+
+
+def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank: int, f16: bool, budget_s: float = 10.0, hip_bytes=None):
     """Time the reference's own coder on this box: ONE core on the same images (bounded sample), then every core this
     process may use, one stream at a time per process (the reference is single-threaded and holds the GIL), then its
-    USE_SIMD=0 path on a smaller sample."""
+    USE_SIMD=0 path on a smaller sample.  `hip_bytes`: the HIP path's bitstreams of the same streams - the reference encoder's
+    bytes are compared with them, stream by stream (`reference_bytes_equal`: checker use of the baseline)."""
     kind, prepare, code = _cpu_coder()
     host = host[: next((k for k, st in enumerate(host) if st is None), len(host))]  # (legs that kept the first image(s) only)
     # a bounded sample of the same workload: whole images, up to about 8 M latents (all 24 Kodak images; one 4K image)
@@ -232,10 +282,13 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
     best = None
     passes = 0
     t_start = time.perf_counter()
+    ref_bytes = []
     while passes < 5 and (passes < 1 or time.perf_counter() - t_start < budget_s):
         t0 = time.perf_counter()
         for st in prepared:
-            got, want = code(st)
+            got, want, b = code(st)
+            if passes == 0:
+                ref_bytes.append(b)
         dt = time.perf_counter() - t0
         assert np.array_equal(got, want)
         best = dt if best is None else min(best, dt)
@@ -251,6 +304,11 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
                   f"{best * 1e3:.0f} ms/pass = {best / n_sym * 1e9:.0f} ns/symbol",
         "ms_per_image": round(best / n_img * 1e3, 2),
     }
+    if hip_bytes is not None:
+        eq = sum(bytes(h) == bytes(r) for h, r in zip(hip_bytes, ref_bytes))
+        out["reference_bytes_equal"] = {"streams": len(ref_bytes), "equal": eq, "kind": kind}
+        if eq != len(ref_bytes):
+            print(f"[bench] PARITY FAILURE: {len(ref_bytes) - eq} of {len(ref_bytes)} bitstreams differ from the {kind} encoder's bytes", file=sys.stderr)
     # how this repo's C restatement (what `kind: "port"` runs would time) compares with the reference extension on this host:
     # the first image, both coders, so that a line from a checkout without oracle/_ref stays comparable
     if kind == "reference":
@@ -1260,6 +1318,17 @@ def main(argv=None):
                         "symtab": {"launch_ms": round(sym_ms_m, 4), "achieved": round(ach_m, 1), "unit": "GB/s", "frac": round(ach_m / HBM_PEAK_GBS, 4)},
                         "tab_kernels_ms_per_step": round(float(np.mean(lm.k_tab)), 4),
                         "reference_md5": ka1_check(lm, res_m)}
+            modes[m]["_bytes"] = [bytes(r[0][0]) for r in res_m]
+        if not a.no_cpu_baseline:  # the reference's encoder under each mode on ALL 48 streams, bytes against bytes
+            try:
+                rb = reference_bytes_of_modes({m: modes[m]["_bytes"] for m in modes}, rank, leg.shapes1, spi, f16)
+                for m in modes:
+                    modes[m]["reference_bytes_equal"] = rb[m]
+            except Exception as e:  # pragma: no cover
+                for m in modes:
+                    modes[m]["reference_bytes_equal"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        for m in modes:
+            del modes[m]["_bytes"]
         extras["modes"] = modes
         try:
             el = Leg(env, "elic4k", ELIC_IMAGES, "polya", True, keep_host_images=1)
@@ -1279,10 +1348,15 @@ def main(argv=None):
                 kind, prepare, code = _cpu_coder()
                 prepared = [prepare(s) for s in el.host[:el.spi]]
                 t0 = time.perf_counter()
+                ref_b = []
                 for st in prepared:
-                    got, want = code(st)
+                    got, want, b = code(st)
+                    ref_b.append(b)
                     assert np.array_equal(got, want)
                 t_ref = time.perf_counter() - t0
+                eq = sum(bytes(res_e[k][0][0]) == bytes(rb_) for k, rb_ in enumerate(ref_b))
+                elic["reference_bytes_equal"] = {"streams": len(ref_b), "equal": eq, "kind": kind,
+                                                 "note": "image 0: five channel groups x two halves, the 64- and 192-channel groups included"}
                 elic["cpu_baseline"] = {"value": round(el.pix_per_image / t_ref / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
                                         "sample": f"1 image x {el.spi} streams ({sum(len(p[-1]) for p in prepared)} symbols), encode+decode, one pass, {t_ref * 1e3:.0f} ms"}
             del el
@@ -1375,7 +1449,7 @@ def main(argv=None):
             print(f"[bench] THE CGROUP'S CPU CONTROLLER THROTTLED THIS PROCESS DURING THE TIMED REGION ({step_ms.get('cpu_throttled')}): `value` "
                   f"measures the quota, not the path - fewer host workers (--host-threads, FGMM_WORKERS_PER_CPU) or a larger quota", file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(leg.host, leg.shapes1, pix_per_image, spi, rank, f16)
+            cb = cpu_baseline(leg.host, leg.shapes1, pix_per_image, spi, rank, f16, hip_bytes=[bytes(r[0][0]) for r in res])
             if "one_host_thread" in extras and cb.get("value"):
                 cb["per_thread_speedup"] = round(extras["one_host_thread"]["value"] / cb["value"], 1)
             if cb.get("all_cores", {}).get("value"):

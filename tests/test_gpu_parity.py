@@ -490,18 +490,20 @@ def test_buffered_encoder_concatenates(oracle):
 @pytest.mark.parametrize("mode", MODES)
 def test_batch_of_kodak_halves_full_size(mode):
     """BASELINE configs[1] shape: 24 images x 2 halves of [1,192,32,24], one native call each way.
-    Checked against the reference through its golden md5s (seeds 0..3 are in ka1.json) and, for the whole batch,
-    through the size-independent property decode(encode(y)) == round(y)."""
-    ka = json.load(open(os.path.join(GOLD, "ka1.json")))[mode]
+    EVERY one of the 48 bitstreams against the reference's own bytes (tests/golden/fullsize.json: length + md5 of what the compiled
+    reference's RansEncoder returns for these seeds, rans_interface.cpp:609-617), and the whole batch through
+    decode(encode(y)) == round(y)."""
+    ka = json.load(open(os.path.join(GOLD, "fullsize.json")))[mode]["kodak24"]
     gmc = GaussianMixtureConditional(K=4, mode=mode)
     ys, ss, ms, ws = [], [], [], []
     for seed in range(48):
         y, sg, mu, pi = T.make_latent(seed)
         ys.append(dv(y)); ss.append(dv(sg)); ms.append(dv(mu)); ws.append(dv(pi))
     res = gmc.compress_batch(ys, ss, ms, ws)
-    for seed in range(4):
+    for seed in range(48):
         (b, abs_max, zb), yq = res[seed]
-        assert (len(b), hashlib.md5(b).hexdigest(), abs_max) == (ka[str(seed)]["len"], ka[str(seed)]["md5"], ka[str(seed)]["abs_max"])
+        assert (len(b), hashlib.md5(b).hexdigest(), abs_max, int(zb.sum())) == (ka[str(seed)]["len"], ka[str(seed)]["md5"], ka[str(seed)]["abs_max"],
+                                                                                ka[str(seed)]["nz_channels"]), seed
     outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
     for seed in range(48):
         assert torch.equal(outs[seed], res[seed][1]), seed
@@ -677,22 +679,50 @@ def test_fp16_parameter_planes(oracle, mode):
 
 
 def test_elic_channel_group_shapes(oracle):
-    """BASELINE configs[4] geometry: ELIC groups of 16/16/32 channels of a 4K latent (h*w = 136*120 per half);
-    the 64- and 192-channel groups go through the same code and are covered by the round-trip property."""
+    """BASELINE configs[4] geometry: ELIC's five channel groups 16/16/32/64/192 of a 4K latent (h*w = 136*120 per half), one ragged
+    batch: every bitstream - the 2.1 M and 3.1 M symbol ones included - against the reference's own bytes
+    (tests/golden/fullsize.json "elic_groups") and against the oracle."""
     gmc = GaussianMixtureConditional(K=4, mode="polya")
+    gold = json.load(open(os.path.join(GOLD, "fullsize.json")))["polya"]["elic_groups"]
     ys, ss, ms, ws, host = [], [], [], [], []
     for seed, M in ((51, 16), (52, 16), (53, 32), (54, 64), (55, 192)):
         y, sg, mu, pi = T.make_latent(seed, M=M, h=136, w=120, clamp=False)
         host.append((y, sg, mu, pi))
         ys.append(dv(y)); ss.append(dv(sg)); ms.append(dv(mu)); ws.append(dv(pi))
     res = gmc.compress_batch(ys, ss, ms, ws)  # ragged batch: M differs per item
-    for i in range(3):
+    for i, seed in enumerate((51, 52, 53, 54, 55)):
         sym, s, m, wt, am, zbm, yqn = T.to_coder_inputs(*host[i])
         (b, abs_max, zb), yq = res[i]
+        assert (len(b), hashlib.md5(b).hexdigest(), abs_max) == (gold[str(seed)]["len"], gold[str(seed)]["md5"], gold[str(seed)]["abs_max"]), seed
         assert b == oracle.encode_gmm("polya", sym, s, m, wt) and abs_max == am and zb.tolist() == zbm.tolist()
     outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
     for i in range(len(res)):
         assert torch.equal(outs[i], res[i][1]) and torch.equal(res[i][1], torch.round(ys[i]))
+
+
+def test_elic4k_image_fp16_planes_equals_reference_bytes():
+    """BASELINE configs[4] as bench.py runs it: the ten bitstreams of a 4K image (groups 16/16/32/64/192 x two halves, seeds 0..9),
+    fp16 (mu, sigma, pi) planes, encoded in ONE call and decoded stage by stage - each stream's bytes against what the compiled
+    reference returns when fed the widened planes (tests/golden/fullsize.json "elic4k_image0")."""
+    gold = json.load(open(os.path.join(GOLD, "fullsize.json")))["polya"]["elic4k_image0"]
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    ys, ss, ms, ws = [], [], [], []
+    k = 0
+    for g in (16, 16, 32, 64, 192):
+        for _ in range(2):
+            y, sg, mu, pi = T.make_latent(k, M=g, h=136, w=120)
+            sg, mu, pi = T.to_float16_planes(sg, mu, pi)
+            ys.append(dv(y)); ss.append(dv(sg)); ms.append(dv(mu)); ws.append(dv(pi))
+            k += 1
+    assert ss[0].dtype == torch.float16
+    res = gmc.compress_batch(ys, ss, ms, ws)
+    for k in range(10):
+        (b, abs_max, zb), yq = res[k]
+        assert (len(b), hashlib.md5(b).hexdigest(), abs_max, int(zb.sum())) == (gold[str(k)]["len"], gold[str(k)]["md5"], gold[str(k)]["abs_max"],
+                                                                                gold[str(k)]["nz_channels"]), k
+    for k in range(10):  # the codec's decode schedule: one stage at a time
+        out = gmc.decompress_batch([res[k][0][0]], [res[k][0][1]], [res[k][0][2]], [ss[k]], [ms[k]], [ws[k]])
+        assert torch.equal(out[0], res[k][1]) and torch.equal(res[k][1], torch.round(ys[k])), k
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -755,7 +785,7 @@ def test_config4_elic_4k_fp16_through_the_group_codec(oracle):
     """BASELINE configs[4] as stated: ELIC on a 4K image — y [1, 320, 136, 240], channel groups 16/16/32/64/192, each a
     checkerboard codec over the GMM entropy model (models/elic_gmm.py:198-219) — with fp16 (mu, sigma, pi) planes and fp32
     CDF arithmetic, all five groups in their sequential flow through ChannelGroupsLatentCodec on exact networks.  Checked:
-    the ten bitstreams of the three small groups byte for byte against the oracle on the (widened) parameters each half was
+    all ten bitstreams byte for byte against the oracle on the (widened) parameters each half was
     coded with; every group through decode(encode(y)) == y_hat; encode in ONE batched call == the group-by-group schedule."""
     from flashgmm_amd.latent_codecs import ChannelGroupsLatentCodec, CheckerboardLatentCodec, GaussianMixtureConditionalLatentCodec
 
@@ -783,7 +813,7 @@ def test_config4_elic_4k_fp16_through_the_group_codec(oracle):
     enc = codec.compress(yd, sided)
     assert len(enc["strings"]) == 10 and len(seen) == 10 and [tuple(s_) for s_ in enc["shape"]] == [(g, h, w) for g in groups]
     assert all(p[1].dtype == torch.float16 and tuple(p[1].shape) == (1, 4 * g, h, w // 2) for p, g in zip(seen, [g for g in groups for _ in (0, 1)]))
-    for i in range(6):  # the three small groups, both halves: the reference path fed the widened planes
+    for i in range(10):  # all five groups, both halves (the 64- and 192-channel ones: 1 M / 3.1 M symbols each): the reference path fed the widened planes
         yc, sg, mu, pi = (t.cpu().numpy() for t in seen[i])
         sym, s_, m_, w_, am, zbm, yqn = T.to_coder_inputs(yc, *(a.astype(np.float32) for a in (sg, mu, pi)))
         b, abs_max, zb = enc["strings"][i]

@@ -61,6 +61,24 @@ def test_g3_small_streams_verbatim(oracle, mode):
         assert oracle.rans_decode_cdftab(b, tab, ent[mode]["max_bs"]).tolist() == ent[mode]["decoded"]
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_fullsize_fixture_sample(oracle, mode):
+    """tests/golden/fullsize.json (the reference's bytes of every full-size bitstream the GPU tests and bench.py code; its
+    generator already held the oracle to ALL of them): here a sample - every eighth Kodak half, and the first ELIC group."""
+    gold = json.load(open(os.path.join(GOLD, "fullsize.json")))[mode]
+    assert len(gold["kodak24"]) == 48 and all(e["roundtrip"] for st in gold.values() for e in st.values())
+    for seed in range(5, 48, 8):
+        sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(*T.make_latent(seed))
+        b = oracle.encode_gmm(mode, sym, s, m, w)
+        assert (len(b), hashlib.md5(b).hexdigest(), abs_max) == (gold["kodak24"][str(seed)]["len"], gold["kodak24"][str(seed)]["md5"],
+                                                                 gold["kodak24"][str(seed)]["abs_max"]), seed
+    if mode == "polya":
+        assert len(gold["elic_groups"]) == 5 and len(gold["elic4k_image0"]) == 10
+        sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(*T.make_latent(51, M=16, h=136, w=120, clamp=False))
+        b = oracle.encode_gmm(mode, sym, s, m, w)
+        assert (len(b), hashlib.md5(b).hexdigest()) == (gold["elic_groups"]["51"]["len"], gold["elic_groups"]["51"]["md5"])
+
+
 def test_empty_stream_is_8_bytes(oracle):
     sym, s, m, w = _g3_cases()["n0"]
     assert oracle.encode_gmm("polya", sym, s, m, w) == bytes.fromhex("0000008000000000")
