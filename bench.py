@@ -681,8 +681,8 @@ def step_stats(step_s, probe: "HostProbe | None" = None):
 
 
 def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
-    """The self-diagnosing leg.  `configs` = [host workers, ...]; the configurations take
-    turns in blocks of `block` steps until each has run `steps` steps (boxes differ and drift: only interleaved blocks compare).
+    """The self-diagnosing leg.  `configs` = ["48", "16", "48+hedge=0" ...]: host workers, optionally
+    "+option=value" settings of the library (an A/B inside one run); the configurations take turns in blocks of `block` steps until each has run `steps` steps (boxes differ and drift: only interleaved blocks compare).
     Every step is sampled with the full HostProbe and the library's call log (phase marks of the step's native calls); a helper
     process (scripts/bin/host_watch) samples the host's count of runnable tasks and its own wake-up lateness every 0.5 ms.  For every
     step slower than 1.3x its configuration's median the output says WHICH part stretched - the calling thread's glue, a call's
@@ -719,10 +719,15 @@ def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
         except OSError:
             watch = None
     per = {c: {"st": [], "ph": [], "t": [], "comm": {}} for c in configs}
+    saved_opts = {}
     try:
         for _ in range(rounds):
             for cfg in configs:
-                _lib.set_threads(lr, cfg)
+                pool_, *opts_ = str(cfg).split("+")
+                _lib.set_threads(lr, int(pool_))
+                for kv in opts_:
+                    saved_opts.setdefault(kv.split("=")[0], _lib.get_option(lr, kv.split("=")[0]))
+                    _lib.set_option(lr, kv.split("=")[0], int(kv.split("=")[1]))
                 for _ in range(2):
                     leg.step(schedule)
                 torch.cuda.synchronize()
@@ -744,8 +749,12 @@ def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
                 e["ph"] += ph
                 e["t"] += [(a[0] * 1e3, b[0] * 1e3) for a, b in zip(probe.samples, probe.samples[1:])]  # CLOCK_MONOTONIC ms, as host_watch's
                 e["comm"].update(probe.comm)
+                for k_, v_ in saved_opts.items():
+                    _lib.set_option(lr, k_, v_)
     finally:
         _lib.set_threads(lr, before)
+        for k_, v_ in saved_opts.items():
+            _lib.set_option(lr, k_, v_)
         wt = wr = wl = None
         if watch is not None:
             watch.terminate()
@@ -820,7 +829,7 @@ def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
         wn = [watched(i) for i in normal]
         wn = [w for w in wn if w]
         out[str(cfg)] = {
-            "host_threads": cfg, "steps": n, "median_ms": round(med, 3), "p90_ms": round(float(np.percentile(ms, 90)), 3),
+            "host_threads": int(str(cfg).split("+")[0]), "options": str(cfg).split("+")[1:], "steps": n, "median_ms": round(med, 3), "p90_ms": round(float(np.percentile(ms, 90)), 3),
             "max_ms": round(float(ms.max()), 3), "mean_ms": round(float(ms.mean()), 3), "p90_over_median": round(float(np.percentile(ms, 90)) / med, 3),
             "slow_steps": len(slow), "all_ms": [round(float(v), 2) for v in ms],
             "run_delay_ms_per_step": {"normal_median": round(norm.get("threads.run_delay_ms", 0.0), 2),
@@ -1284,10 +1293,10 @@ def main(argv=None):
             if a.diag_steps > 0:
                 threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
                 if a.diag_pools:
-                    cfgs = [int(x) for x in a.diag_pools.split(",") if x]
+                    cfgs = [x for x in a.diag_pools.split(",") if x]
                 else:
                     by_quota = max(1, int(_lib.host_cpu_budget()["cpus"] // _lib.ranks_on_node()))
-                    cfgs = [threads] + ([by_quota] if by_quota != threads else [])
+                    cfgs = [str(threads)] + ([str(by_quota)] if by_quota != threads else [])
                 try:
                     extras["step_diag"] = step_diag(leg, a.schedule, a.diag_steps, cfgs)
                 except Exception as e:  # pragma: no cover - a diagnostic must not cost the run its line

@@ -33,12 +33,6 @@ class fgmm_params(C.Structure):
                 ("stride_k", C.c_int64), ("stride_c", C.c_int64), ("dtype", C.c_int32), ("flags", C.c_int32)]
 
 
-class fgmm_tab_ref(C.Structure):
-    _fields_ = [("encoded", C.c_void_p), ("encoded_len", C.c_size_t), ("hdr", C.c_void_p), ("hdr_form", C.c_int32), ("tl", C.c_int32),
-                ("blk_off", C.c_void_p), ("rows", C.c_void_p), ("rows_len", C.c_uint64), ("n", C.c_int64), ("max_bs", C.c_int32),
-                ("flags", C.c_int32), ("out_symbols", C.c_void_p)]
-
-
 class fgmm_ckpt(C.Structure):
     _fields_ = [("x", C.c_uint64), ("pos", C.c_uint64)]
 
@@ -113,7 +107,6 @@ SIGNATURES = {
     "fgmm_rans_encode_symtab_segs": (_i, [_p, _i, _i64, _p, _i64, _i64, _pp, _psz, _p]),
     "fgmm_rans_decode_cdftab": (_i, [_p, _sz, _p, _p, C.c_uint64, _i64, _i32, _i, _p]),
     "fgmm_rans_decode_tab": (_i, [_p, _sz, _p, _i, _p, _i32, _p, C.c_uint64, _i64, _i32, _i, _p]),
-    "fgmm_rans_decode_tab2": (_i, [_p, _p]),
     "fgmm_build_tab_hip": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i32, _i, _p, _p, _p, C.c_uint64, _p, C.POINTER(_i32)]),
     "fgmm_ctx_set_option": (_i, [_p, C.c_char_p, _i64]),
     "fgmm_ctx_get_option": (_i, [_p, C.c_char_p, C.POINTER(_i64)]),

@@ -5,11 +5,15 @@
 #   -march=x86-64-v3                          : host rANS code may use AVX2/BMI2, stays portable across hosts
 #   -Xarch_device -fno-slp-vectorize          : packed fp32 ops (v_pk_fma_f32 ...) issue at half rate on gfx950 and cost
 #                                               pairing moves: measured 1-6 % (symtab) / 12 % (cdftab count) slower with them
+# Sources: the kernels (*.hip), the device layer over HIP (fgmm_device_hip.cpp), and the host side, which sees the device only
+# through fgmm_device.h (fgmm_capi / fgmm_encode / fgmm_decode / fgmm_decode_gpu / fgmm_rans: plain C++, also built without a GPU
+# toolchain against tests/fake/fake_device.cpp by scripts/tsan_host.sh).
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=${OUT:-../libflashgmm_amd.so}
 COMMON="-O3 -fPIC -std=c++17 -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math"
 $HIPCC $COMMON --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc -Xarch_device -fno-slp-vectorize \
-    -march=x86-64-v3 -shared -o $OUT fgmm_kernels.hip fgmm_tab.hip fgmm_rans.cpp fgmm_capi.cpp -lpthread -lhsa-runtime64 "$@"
+    -march=x86-64-v3 -shared -o $OUT fgmm_kernels.hip fgmm_tab.hip fgmm_device_hip.cpp fgmm_rans.cpp fgmm_capi.cpp fgmm_encode.cpp \
+    fgmm_decode.cpp fgmm_decode_gpu.cpp -lpthread "$@"
 echo "built $(realpath $OUT)"

@@ -65,22 +65,12 @@ struct DecDesc {
   uint32_t *blkoff_out;          // [blk_end - blk_begin] byte offset / 4 of each block's first row, from `rows`
   uint8_t *rows;                 // the launch's row area (device staging)
   unsigned long long rows_cap;   // bytes
-  unsigned long long *counters;  // shared by the launch (kTabCounters words): [0] bytes of rows placed (the cursor; with look-back
-                                 // placement: written once, by the launch's last block), [1] bit 0: overflow (a block did not
-                                 // fit), bit 1: a look-back gave up (the host re-runs the launch with the cursor), [2] unused,
-                                 // [3] blocks with a non-monotone row, [4 .. 4 + kTabEdgeSlots) edges evaluated, summed by the
-                                 // host (only when count_edges; spread over slots: same-address atomics serialise chip-wide)
-  int32_t count_edges;
-  // placement of a block's rows in the launch's row area: 0 = ONE returning atomic add per block on counters[0] (blocks land
-  // in arrival order; the chip does ~70 of those per microsecond: the kernel's bound only below 48 latents per block);
-  // 1 = decoupled look-back over `scan` (blocks land in launch order: deterministic tables, no same-address atomics; a block
-  // waits until every block ahead of it has been evaluated, which costs a third of the kernel's throughput)
-  int32_t placement;
-  unsigned long long *scan;      // [scan_total] per block of the LAUNCH, in launch order (part-major): state << 62 | bytes; 0 = not there
-                                 // yet, 1 = the block's own bytes, 2 = bytes of all blocks up to and including it; zeroed by the host
-  int64_t scan_base;             // index of this part's block blk_begin in `scan`
-  int64_t scan_total;            // blocks of the launch
-  int32_t spin_limit, pad3_;     // polls of one look-back step before it gives up (a stalled predecessor: never seen)
+  unsigned long long *counters;  // shared by the launch (kTabCounters words): [0] bytes of rows placed - the cursor: ONE returning
+                                 // atomic add per block (blocks lie in arrival order), [1] overflow (a block did not fit: the host
+                                 // re-runs the launch with [0] bytes), [2] unused, [3] blocks with a non-monotone row,
+                                 // [4 .. 4 + kTabEdgeSlots) edges evaluated, summed by the host (only when count_edges; spread over
+                                 // slots: same-address atomics serialise chip-wide)
+  int32_t count_edges, pad2_;
   // ---- generic two-pass path (cdftab_count / scan / fill): any half-width, rows sequential in latent order
   void *hdr;                     // [n] headers, 4-byte form (8-byte form when hdr_form == 8)
   int32_t tiles;                 // blocks per channel = ceil(hw / 256)
@@ -136,7 +126,6 @@ constexpr int kAutoPiecesMax = 24; // what the automatic choice goes up to (opti
 constexpr int kEncSegs = 4;    // EncDesc::packed_seg
 constexpr int kTabEdgeSlots = 64;               // DecDesc::counters
 constexpr int kTabCounters = 4 + kTabEdgeSlots;
-constexpr int kTabSpinLimit = 1 << 21;          // look-back polls (a microsecond or two each) before a block gives up
 #ifndef FGMM_EF_MIN
 #define FGMM_EF_MIN 14
 #endif
@@ -290,7 +279,5 @@ struct TabDecoder {
   int segment(int64_t lo, int64_t hi, uint64_t x0, uint64_t pos0, uint64_t *x1, uint64_t *pos1); // checkpointed streams
   int finish();
 };
-// two pieces of two decoders on one thread, latent by latent in turn (two dependency chains share the core)
-void rans_decode_pieces2(TabDecoder &a, int ka, TabDecoder &b, int kb, int *rc_a, int *rc_b);
 
 } // namespace fgmm

@@ -653,9 +653,7 @@ int TabDecoder::begin(const uint8_t *enc, size_t enc_len, const TabView *view, i
 #endif
 namespace {
 
-// One decoder's walk through one piece, a latent per step() - so that one thread can advance two bitstreams in turn
-// (rans_decode_pieces2): a bitstream's decode is one long dependency chain (state -> search -> state), two chains
-// share a core's issue slots.
+// One decoder's walk through one piece, a latent per step().
 struct PieceRun {
   TabDecoder *td = nullptr;
   const TabPiece *pc = nullptr;
@@ -937,28 +935,6 @@ int TabDecoder::segment(int64_t lo, int64_t hi, uint64_t x0, uint64_t pos0, uint
   *x1 = x;
   *pos1 = (uint64_t)(ptr - base_);
   return rc;
-}
-
-// piece ka of decoder a and piece kb of decoder b, decoded by the calling thread latent by latent in turn; each decoder
-// ends exactly where its own piece() would have left it.  rc_a / rc_b: the decoders' status.
-void rans_decode_pieces2(TabDecoder &a, int ka, TabDecoder &b, int kb, int *rc_a, int *rc_b) {
-  PieceRun ra, rb;
-  const bool ga = ra.begin(a, ka), gb = rb.begin(b, kb);
-  if (ga && gb)
-    while (ra.active() && rb.active()) {
-      ra.step();
-      rb.step();
-    }
-  if (ga) {
-    while (ra.active()) ra.step();
-    ra.finish();
-  }
-  if (gb) {
-    while (rb.active()) rb.step();
-    rb.finish();
-  }
-  *rc_a = ga ? a.rc : ra.rc;
-  *rc_b = gb ? b.rc : rb.rc;
 }
 
 // after the last piece: FGMM_OK only if every latent was decoded
@@ -1320,30 +1296,6 @@ int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void 
   const fgmm::TabPiece pc{hdr, blk_off, rows, (size_t)rows_len, n};
   const fgmm::TabView tv{(flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, hdr_form, tl, 1, &pc, nullptr, nullptr};
   return fgmm::rans_decode_tab(encoded, encoded_len, tv, n, max_bs, out_symbols);
-}
-
-int fgmm_rans_decode_tab2(const fgmm_tab_ref *a, const fgmm_tab_ref *b) {
-  if (!a || !b) return FGMM_ERR_INVALID;
-  const fgmm_tab_ref *t[2] = {a, b};
-  fgmm::TabPiece pc[2];
-  fgmm::TabView tv[2];
-  fgmm::TabDecoder td[2];
-  int rc[2];
-  for (int k = 0; k < 2; ++k) {
-    const fgmm_tab_ref &r = *t[k];
-    if (r.n > 0 && (!r.hdr || !r.rows)) return FGMM_ERR_INVALID;
-    if (r.max_bs < 0 || r.max_bs > FGMM_MAX_BS || (r.blk_off && r.tl < 1)) return FGMM_ERR_INVALID;
-    if ((r.hdr_form == 2 && !fgmm::tab_hdr_fits16(r.max_bs)) || (r.hdr_form == 4 && r.max_bs > FGMM_MAX_BS_H4)) return FGMM_ERR_INVALID;
-    pc[k] = fgmm::TabPiece{r.hdr, r.blk_off, r.rows, (size_t)r.rows_len, r.n};
-    tv[k] = fgmm::TabView{(r.flags & FGMM_TAB_RAW_ROWS) ? fgmm::kTabNoEf : fgmm::kTabEfMin, r.hdr_form, r.tl, 1, &pc[k], nullptr, nullptr};
-  }
-  for (int k = 0; k < 2; ++k) rc[k] = td[k].begin(t[k]->encoded, t[k]->encoded_len, &tv[k], t[k]->n, t[k]->max_bs, t[k]->out_symbols);
-  if (rc[0] == FGMM_OK && rc[1] == FGMM_OK) fgmm::rans_decode_pieces2(td[0], 0, td[1], 0, &rc[0], &rc[1]);
-  for (int k = 0; k < 2; ++k) {
-    const int rf = td[k].finish();
-    if (rc[k] == FGMM_OK) rc[k] = rf;
-  }
-  return rc[0] != FGMM_OK ? rc[0] : rc[1];
 }
 
 void fgmm_free(void *p) { free(p); }

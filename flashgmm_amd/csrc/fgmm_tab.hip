@@ -556,33 +556,28 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
     S.rowoff[tid] = exB;
     S.efoff[tid] = exEF;
   }
-  // The block's place in the launch's row area.  Cursor placement (d.placement == 0): ONE returning atomic add on the launch's
-  // cursor - the chip does ~38 of those per microsecond, which is the kernel's floor up to 64 latents per block.  Look-back
-  // placement: this block's bytes are published now, the sum over its predecessors is collected AFTER phase 5a (which needs no
-  // address), by which time most of them have arrived.
-  const int64_t scan_idx = d.scan_base + (b - d.blk_begin);
+  // The block's place in the launch's row area: ONE returning atomic add per block on the launch's cursor (blocks lie in arrival
+  // order; the chip does ~70 of those per microsecond: the kernel's bound only below 48 latents per block.  Round 4 built and
+  // measured decoupled look-back instead - tables that are the same bytes on every run, a third slower, since a block cannot be
+  // placed before every block ahead of it has been evaluated: profiles/r04_tab_place_sweep.txt, git history)
   if (tid == 0) {
     S.rowoff[nl] = B;
     S.efoff[nl] = EFT;
-    if (d.placement) {
-      __hip_atomic_store(&d.scan[scan_idx], (1ull << 62) | (unsigned long long)B4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)B4);
-      const bool fits = base + B4 <= d.rows_cap;
-      if (!fits) atomicOr(&d.counters[1], 1ull);
-      d.blkoff_out[b - d.blk_begin] = (uint32_t)(base >> 2);
-      S.scratch[8] = (uint32_t)base;
-      S.scratch[9] = (uint32_t)(base >> 32);
-      S.scratch[10] = fits ? 1u : 0u;
-    }
-    if (d.count_edges) atomicAdd(&d.counters[4 + (scan_idx & (kTabEdgeSlots - 1))], 2ull * NP);
+    const unsigned long long base = atomicAdd(&d.counters[0], (unsigned long long)B4);
+    const bool fits = base + B4 <= d.rows_cap;
+    if (!fits) atomicOr(&d.counters[1], 1ull);
+    d.blkoff_out[b - d.blk_begin] = (uint32_t)(base >> 2);
+    S.scratch[8] = (uint32_t)base;
+    S.scratch[9] = (uint32_t)(base >> 32);
+    S.scratch[10] = fits ? 1u : 0u;
+    if (d.count_edges) atomicAdd(&d.counters[4 + (b & (kTabEdgeSlots - 1))], 2ull * NP);
   }
   for (uint32_t q = tid; q < (EFT >> 16); q += kBlock) S.bitmap[q] = 0;
   {
     const int any_nm = __syncthreads_or(tid < nl && (S.flags[tid] & 2)); // also publishes rowoff / efoff / scratch / bitmap
     if (tid == 0 && any_nm) atomicAdd(&d.counters[3], 1ull);
   }
-  if (!d.placement && !S.scratch[10]) return; // the launch's row area is too small: the host re-runs it with what the cursor asks for
+  if (!S.scratch[10]) return; // the launch's row area is too small: the host re-runs it with what the cursor asks for
 
   // what a lane keeps of the row it is working on (reloaded from LDS only when it moves on to another latent)
   struct RowRef {
@@ -654,57 +649,7 @@ __global__ __launch_bounds__(kBlock, FGMM_TAB_WAVES) void tab_kernel(const DecDe
       if (acc) atomicOr(&S.bitmap[acc_w], acc);
     }
   }
-  // ---- look-back (d.placement): bytes of all blocks before this one in launch order = where its rows start ------------------
-  // Wave 0, lane k reads the state of block scan_idx - 1 - k (- 64 per round): the nearest predecessor that already knows its
-  // inclusive sum ends the walk, the blocks between contribute their own bytes.  Blocks are dispatched in launch order and wait
-  // for nothing once they have published, so the lowest unpublished block never waits: no deadlock.  A look-back that polls
-  // spin_limit times in vain (never seen) gives up: the block reports it in counters[1], publishes a sum so that its
-  // successors end too, and the host re-runs the launch with the cursor.
-  if (d.placement && wave == 0) {
-    unsigned long long excl = 0;
-    bool gave_up = false;
-    const unsigned long long vmask = (1ull << 62) - 1ull;
-    for (int64_t pos = scan_idx - 1;; pos -= 64) {
-      const int64_t q = pos - lane;
-      unsigned long long v = q >= 0 ? 0ull : 2ull << 62; // (before the launch's first block: a sum of nothing)
-      int spins = 0;
-      unsigned long long incl, missing;
-      for (;;) {
-        if (q >= 0 && (v >> 62) != 2) v = __hip_atomic_load(&d.scan[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        incl = __ballot((v >> 62) == 2);
-        missing = __ballot((v >> 62) == 0);
-        // needed: every lane below the first one that holds an inclusive sum (all 64 when none does)
-        const unsigned long long need = incl ? ((incl & (0ull - incl)) - 1ull) : ~0ull;
-        if (!(missing & need)) break;
-        if (++spins > d.spin_limit) {
-          gave_up = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-      if (gave_up) break;
-      const int first = incl ? (int)__builtin_ctzll(incl) : 64;
-      unsigned long long c = lane <= first ? (v & vmask) : 0ull;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-      excl += c;
-      if (incl) break;
-    }
-    if (lane == 0) {
-      if (gave_up) atomicOr(&d.counters[1], 2ull);
-      const unsigned long long incl_sum = excl + B4;
-      __hip_atomic_store(&d.scan[scan_idx], (2ull << 62) | (incl_sum & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool fits = !gave_up && incl_sum <= d.rows_cap;
-      if (!fits) atomicOr(&d.counters[1], 1ull);
-      if (scan_idx == d.scan_total - 1) d.counters[0] = incl_sum; // the launch's total, as the cursor would report it
-      d.blkoff_out[b - d.blk_begin] = (uint32_t)(excl >> 2);
-      S.scratch[8] = (uint32_t)excl;
-      S.scratch[9] = (uint32_t)(excl >> 32);
-      S.scratch[10] = fits ? 1u : 0u;
-    }
-  }
-  __syncthreads();
-  if (!S.scratch[10]) return; // (look-back placement: known only now)
+  __syncthreads(); // the unary parts are complete before phase 5b reads them
   uint8_t *__restrict__ out = d.rows + (((unsigned long long)S.scratch[9] << 32) | S.scratch[8]);
 
   TAB_T(4); // phase 5a

@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define FGMM_ABI_VERSION 4 /* 4: + fgmm_rans_encode_symtab_segs, fgmm_ctx_stat index 6, options tab_place / tab_spin / copy_engine / enc_segs; nothing removed or changed */
+#define FGMM_ABI_VERSION 5 /* 5: + fgmm_ctx_call_log, option hedge; REMOVED (measured, lost, pruned): options tab_place / tab_spin / copy_engine /
+                              dec_pair / dec_group, fgmm_rans_decode_tab2 + fgmm_tab_ref, fgmm_ctx_stat index 6 */
 
 typedef enum {
   FGMM_OK = 0,
@@ -73,9 +74,9 @@ const char *fgmm_last_error(void); /* thread-local text of the last failure on t
 int fgmm_host_cpu_budget(double *cpus_out, int *affinity_out, double *quota_out);
 /* Host rANS workers a context gets by default when `ranks_sharing` processes (one per GPU) share that budget: the share's CPUs,
  * floor(budget / ranks_sharing) - or, where a cgroup quota (CPU TIME per period) is what limits the budget and the affinity mask is
- * wider, up to three workers per CPU of the share (never more than the share of the mask): the workers sleep on the copies' events
- * most of a call, so the bursts of a step run on as many cores while the quota is not exhausted (measured: 48 workers under a 16-CPU
- * quota are 3 % faster than 16 and are not throttled).  Within [1, 48]. */
+ * wider, up to FGMM_WORKERS_PER_CPU (environment, 1..4, default 3) workers per CPU of the share (never more than the share of the mask):
+ * the workers sleep on the copies' events most of a call, so the bursts of a step run on as many cores while the quota is not exhausted
+ * (48 workers under a 16-CPU quota use 14-15 CPUs' worth and are 5 % faster than 16: profiles/r05_stall_diagnosis.md).  Within [1, 48]. */
 int fgmm_host_thread_budget(int ranks_sharing);
 
 /* device < 0: current HIP device.  n_threads <= 0: fgmm_host_thread_budget(1) host rANS workers. */
@@ -93,57 +94,35 @@ void fgmm_free(void *p); /* releases any buffer this library returned through an
  * single-threaded copies when its language wants to own the bytes (Python: 30 MB of bitstreams of eight 4K images, 3 ms). */
 int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, const size_t *len, int count);
 
-/* Tuning knobs of a context (defaults in brackets).  Unknown names return FGMM_ERR_INVALID.
- *   "pieces"      [0]   decode: the tables of every bitstream of a call reach the host in this many pieces (at most 32; 0 = by the
- *                       call's longest bitstream: 8 up to 147 k latents, 24 from 1.1 M on - the last piece stays ~4 000 latents),
- *                       piece-major and shrinking (piece p of P carries P - p parts of P (P + 1) / 2); the host workers take
- *                       (bitstream, piece) tasks as they land - a bitstream decodes sequentially, but its coder state
- *                       moves from worker to worker between pieces: what lands last leaves one small piece of host
- *                       work per bitstream behind it, not one bitstream
- *   "enc_ways"    [0]   encode: consecutive bitstreams one worker codes symbol by symbol in turn (several dependency chains
- *                       share a core): 1..4; 0 = two when the call has more bitstreams than workers, else one
- *   "enc_segs"    [1]   encode: a call in which every bitstream has a host worker of its own (and whose tables are 4 MB and more)
- *                       lays every table out in four segments of compact channels, LAST SEGMENT FIRST across all bitstreams:
- *                       rANS encodes backwards, so the encoders start on the tails after an eighth of the transfer and follow the
- *                       landing; what is left after the last byte is a quarter of a bitstream's job instead of a whole one.
- *                       0 = whole tables, bitstream after bitstream
- *   "scatter_rounds" [1] decode: the decoded symbols of the bitstreams that decode piece by piece return to the GPU round by round
- *                       (one launch per piece index, as soon as every such bitstream has decoded that piece) instead of one
- *                       launch per bitstream when it has finished: what follows the last decoder is its last, smallest piece.
- *                       0 = bitstream by bitstream
- *   "dec_pair"    [0]   decode: a worker takes two ready tasks and decodes them latent by latent in turn
- *                       (fgmm_rans_decode_tab2: 8.9 -> 5.9 ns/symbol per thread with uint16 rows) unless that leaves a
- *                       sleeping worker without one.  0 = when the call has at least two bitstreams per worker and ships
- *                       uint16 rows (hosts with few threads), 1 = always, 2 = never.  With 24 bitstreams on 16 workers it
- *                       loses: it trades parallel workers for ILP
- *   "tab_cap_e"   [12288] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2));
- *                       at the default a call with a half-width that only fits 16384 edges (383 < max_bs <= 511) gets that
- *   "tab_place"   [0]   single-pass table kernel: how a block finds its place in the launch's row area.  0 = one returning
- *                       atomic add per block on a cursor (blocks lie in arrival order; ~70 of those per microsecond chip-wide:
- *                       the bound only below 48 latents per block); 1 = decoupled look-back (every block publishes its bytes,
- *                       a wave sums its predecessors': blocks lie in LAUNCH order - the tables of a call are the same bytes
- *                       on every run - and nothing serialises on one address; a third slower, since a block cannot be placed
- *                       before every block ahead of it has been evaluated).  A launch in which a look-back gives up
- *                       ("tab_spin" polls, default 2^21: never seen) is re-run with the cursor
- *   "stage_max_mb" [0]  decode: cap of the device staging area for rows in MiB (0: a quarter of the free device memory).
- *                       A launch whose rows do not fit is re-run with the exact size its cursor reports.
- *   "ef_rows"     [0]   decode: 0 = Elias-Fano rows when min(host workers, bitstreams of the call) >= 10 (PCIe is the
- *                       bottleneck), uint16 rows otherwise (the sequential host decoders are); 1 = always, 2 = never
- *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor).
- *                       14 gives the fewest bytes (55.7 B/latent on Kodak-like tables against 57.6) but costs the host
- *                       decoders more than the PCIe time it saves when 16 threads serve one GPU
- *   "gpu_decode"  [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded ON THE GPU, a workgroup per segment, the edges of a
- *                       latent across the lanes (no decode-side tables, nothing but the bitstreams crosses PCIe); a bitstream
- *                       with a segment the kernel does not settle itself (a non-monotone row, a note that does not verify)
- *                       goes through the table path.  0 = when the call has enough segments for the GPU to be the faster
- *                       decoder (a batch, a 4K image's channel group; one Kodak half in long segments decodes faster on the
- *                       host's workers), 1 = whenever a bitstream carries valid notes, 2 = never.  The estimate behind 0 uses
- *                       rates measured on ONE kind of box (MI355X + EPYC 9575F: 0.65 us per symbol of a segment's length and
- *                       0.35 ns per symbol chip-wide on the GPU; 12 ns per symbol and worker, 58 B per latent at 55.7 GB/s
- *                       for the table path): on another host set 1 or 2
- *   "ckpt_decode" [0]   decode, table path: checkpointed bitstreams are decoded in segments on all host workers: 0 = when the
- *                       call has fewer bitstreams than workers (else every worker has a bitstream anyway), 1 = always,
- *                       2 = never (the notes are ignored)
+/* Tuning knobs of a context (defaults in brackets; what was measured behind each: DESIGN.md).  Unknown names return FGMM_ERR_INVALID.
+ *   "pieces"      [0]   decode: the tables of every bitstream of a call reach the host in this many pieces, piece-major and shrinking
+ *                       (at most 32; 0 = by the call's longest bitstream: 8 up to 147 k latents, 24 from 1.1 M on); the host workers take
+ *                       (bitstream, piece) tasks as they land, the coder state travels with the bitstream from worker to worker
+ *   "dec_first"   [2]   decode: bitstreams in the first launch of the first round of pieces (doubling from there: first tables early)
+ *   "hedge"       [1]   decode: 1 = a worker takes a (bitstream, piece) task only once its tables are known to have landed - a worker
+ *                       that is woken late then holds nothing up; 0 = it takes the task first and sleeps holding it (rounds 2-4)
+ *   "enc_ways"    [0]   encode: consecutive bitstreams one worker codes symbol by symbol in turn (several dependency chains share a
+ *                       core): 1..4; 0 = two when the call has more bitstreams than workers, else one
+ *   "enc_segs"    [1]   encode: a call in which every bitstream has a host worker of its own (and whose tables are 4 MB and more) lays
+ *                       every table out in four segments of compact channels, LAST SEGMENT FIRST across all bitstreams: rANS encodes
+ *                       backwards, so the encoders follow the landing.  0 = whole tables, bitstream after bitstream
+ *   "scatter_rounds" [1] decode: decoded symbols return to the GPU round by round (one launch per piece index) instead of one launch per
+ *                       bitstream when it has finished
+ *   "tab_cap_e"   [12288] single-pass table kernel: edges one block keeps in LDS (latents per block = cap / (2*max_bs+2)); at the
+ *                       default a call with a half-width that only fits 16384 edges (383 < max_bs <= 511) gets that
+ *   "stage_max_mb" [0]  decode: cap of the device staging area for rows in MiB (0: a quarter of the free device memory).  A launch
+ *                       whose rows do not fit is re-run with the exact size its cursor reports
+ *   "ef_rows"     [0]   decode: 0 = Elias-Fano rows when min(host workers, bitstreams of the call) >= 10 (PCIe is the bottleneck),
+ *                       uint16 rows otherwise (the sequential host decoders are); 1 = always, 2 = never
+ *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor)
+ *   "gpu_decode"  [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded ON THE GPU, a workgroup per segment (no decode-side
+ *                       tables at all); a bitstream with a segment the kernel does not settle goes through the table path.  0 = when
+ *                       the call has enough segments for the GPU to be the faster decoder (estimated with rates measured on MI355X +
+ *                       EPYC 9575F: on another host set 1 or 2), 1 = whenever a bitstream carries valid notes, 2 = never
+ *   "ckpt_decode" [0]   decode, table path: checkpointed bitstreams are decoded in segments on all host workers: 0 = when the call
+ *                       has fewer bitstreams than workers, 1 = always, 2 = never (the notes are ignored)
+ *   "spin_lat"    [400000] decode: calls of at most this many latents wait on polled events instead of sleeping ones (-1: never)
+ *   "enc_vec" / "enc_linear"  A/B switches of the encode-side kernel's load width and grid (0 / 1: the defaults)
  *   "trace"       [0]   1: phase timestamps of every batched call on stderr, 2: + per-bitstream job timeline */
 int fgmm_ctx_set_option(fgmm_ctx *ctx, const char *name, int64_t value);
 int fgmm_ctx_get_option(fgmm_ctx *ctx, const char *name, int64_t *value_out);
@@ -157,8 +136,7 @@ int fgmm_ctx_trim(fgmm_ctx *ctx);
 int fgmm_ctx_set_profiling(fgmm_ctx *ctx, int enable);
 /* Counters of the most recent batched call: which = 0 encode tables copied D2H (bytes), 1 decode headers + block offsets
  * + rows copied D2H (bytes), 2 latents those decode tables describe, 3 edges the decode-side kernels evaluated, 4 bitstreams
- * the GPU's segment decoder decoded (checkpointed ones), 5 bitstreams it handed back to the table path; 6 (since the context
- * was created) table-kernel launches that were re-run with cursor placement because a look-back gave up (expected: 0). */
+ * the GPU's segment decoder decoded (checkpointed ones), 5 bitstreams it handed back to the table path. */
 int fgmm_ctx_stat(fgmm_ctx *ctx, int which, uint64_t *out);
 int fgmm_ctx_kernel_ms(fgmm_ctx *ctx, int which, float *ms_out);
 /* The call log: phase marks of the context's most recent batched calls (at most 64 are kept), always recorded - a handful of
@@ -400,22 +378,6 @@ int fgmm_rans_decode_tab(const uint8_t *encoded, size_t encoded_len, const void 
 int fgmm_rans_decode_tab_ckpt(const uint8_t *encoded, size_t encoded_len, const void *hdr, int hdr_form, const uint32_t *blk_off,
                               int32_t tl, const uint8_t *rows, uint64_t rows_len, int64_t n, int32_t max_bs, int flags,
                               const fgmm_ckpt *ckpt, int64_t n_ckpt, int64_t stride, int32_t *out_symbols, int32_t *verified_out);
-/* Two tables -> two symbol arrays, decoded by the calling thread latent by latent in turn (the batched decoder does this
- * when there are more bitstreams than idle workers: a bitstream's decode is one dependency chain, two chains share a
- * core).  Each output is exactly what fgmm_rans_decode_tab gives for its table; returns the first error of the two. */
-typedef struct fgmm_tab_ref {
-  const uint8_t *encoded;
-  size_t encoded_len;
-  const void *hdr;
-  int32_t hdr_form, tl;   /* tl: latents per block when blk_off != NULL */
-  const uint32_t *blk_off;
-  const uint8_t *rows;
-  uint64_t rows_len;
-  int64_t n;
-  int32_t max_bs, flags;
-  int32_t *out_symbols;
-} fgmm_tab_ref;
-int fgmm_rans_decode_tab2(const fgmm_tab_ref *a, const fgmm_tab_ref *b);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 4. Table path — the `z` hyper-latent coder: CompressAI's original table rANS, the other

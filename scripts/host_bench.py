@@ -39,8 +39,6 @@ for rep in range(int(os.environ.get("REPS", "7"))):
     assert b == enc
     t4 = time.perf_counter(); rc, out = host_decode_tab(L, enc, h2, pool2, max_bs, bo2, 96); t5 = time.perf_counter()
     assert rc == 0 and np.array_equal(out, sym)
-    t6 = time.perf_counter(); rc2, outs = helpers.host_decode_tab2(L, [(enc, h2, pool2, max_bs, bo2, 96), (enc, h2, pool2, max_bs, bo2, 96)]); t7 = time.perf_counter()
-    assert rc2 == 0 and np.array_equal(outs[0], sym) and np.array_equal(outs[1], sym)
-    note("two streams in turn on one thread", 1e9*(t7-t6)/(2*n)); note("decode (4-byte headers, sequential)", 1e9*(t1-t0)/n)
+    note("decode (4-byte headers, sequential)", 1e9*(t1-t0)/n)
     note("decode (2-byte headers, blocks of 96)", 1e9*(t5-t4)/n); note("encode", 1e9*(t3-t2)/n)
 print("   ".join(f"{k} {v:.1f} ns/sym" for k, v in best.items()), f"  (best of {rep + 1})")

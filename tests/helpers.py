@@ -203,25 +203,6 @@ def host_decode_tab(lib, enc: bytes, hdr: np.ndarray, pool: np.ndarray, max_bs: 
     return rc, out
 
 
-def host_decode_tab2(lib, tabs):
-    """fgmm_rans_decode_tab2: two (enc, hdr, pool, max_bs, blk_off, tl) tables decoded in turn by one thread"""
-    from flashgmm_amd._lib import fgmm_tab_ref
-    refs, keep, outs = [], [], []
-    for enc, hdr, pool, max_bs, blk_off, tl in tabs:
-        hdr = np.ascontiguousarray(hdr)
-        pool = np.ascontiguousarray(np.asarray(pool).view(np.uint8))
-        out = np.empty(len(hdr), np.int32)
-        bo = np.ascontiguousarray(blk_off, np.uint32) if blk_off is not None else None
-        buf = C.create_string_buffer(enc, len(enc))
-        keep += [hdr, pool, bo, buf]
-        outs.append(out)
-        refs.append(fgmm_tab_ref(C.cast(buf, C.c_void_p).value, len(enc), hdr.ctypes.data, hdr.dtype.itemsize, tl,
-                                 bo.ctypes.data if bo is not None else None, pool.ctypes.data, len(pool), len(hdr), max_bs, _flags(),
-                                 out.ctypes.data))
-    rc = lib.fgmm_rans_decode_tab2(C.byref(refs[0]), C.byref(refs[1]))
-    return rc, outs
-
-
 def expected_threads(budget: dict, ranks: int = 1) -> int:
     """fgmm_host_thread_budget, restated: the share's CPUs; x3 (up to the share of the affinity mask) when a cgroup quota is the limit"""
     by_time, by_mask = int(budget["cpus"] / ranks + 1e-9), int(budget["affinity"] / ranks + 1e-9)

@@ -577,17 +577,17 @@ def test_stacked_batch_equals_item_lists(dtype):
         gmc.decompress_batch([r[0][0] for r in a][:-1], [r[0][1] for r in a], [r[0][2] for r in a], sg, mu, pi)
 
 
-@pytest.mark.parametrize("pieces,first,group,threads,pair", [(4, 2, 0, 0, 0), (1, 2, 0, 0, 1), (2, 1, 0, 3, 1), (3, 9, 2, 0, 0), (8, 2, 0, 2, 1),
-                                                              (7, 1, 4, 16, 0), (8, 2, 0, 1, 1), (16, 2, 0, 0, 0), (32, 2, 0, 0, 0), (0, 3, 0, 5, 0)])
-def test_decode_piece_schedule_settings(ctx_options, pieces, first, group, threads, pair):
-    """The tables of a decode batch land on the host in pieces, piece-major, and each host worker follows its own bitstreams
-    piece by piece (fgmm_capi.cpp, decode_batch), alone or two at a time in turn (dec_pair): every setting of the schedule,
-    and any number of workers, must give the same symbols; the encoder side codes ceil(9 / workers) bitstreams in turn per
-    worker (enc_ways), up to four."""
+@pytest.mark.parametrize("pieces,first,threads,hedge", [(4, 2, 0, 1), (1, 2, 0, 0), (2, 1, 3, 1), (3, 9, 0, 0), (8, 2, 2, 1),
+                                                        (7, 1, 16, 0), (8, 2, 1, 1), (16, 2, 0, 1), (32, 2, 0, 0), (0, 3, 5, 1)])
+def test_decode_piece_schedule_settings(ctx_options, pieces, first, threads, hedge):
+    """The tables of a decode batch land on the host in pieces, piece-major, and the host workers take (bitstream, piece) tasks as
+    they land (fgmm_decode.cpp) - after the landing (hedge 1, the default) or holding the task while its tables are on the bus
+    (0): every setting of the schedule, and any number of workers, must give the same symbols; the encoder side codes
+    ceil(9 / workers) bitstreams in turn per worker (enc_ways), up to four."""
     if threads:
         _lib.set_threads(0, threads)  # a fresh context: before the options
     try:
-        ctx_options(pieces=pieces, dec_first=first, dec_group=group, dec_pair=2 - pair, ef_min=14 + 35 * (pieces & 1), ef_rows=(pieces >> 1) & 1)
+        ctx_options(pieces=pieces, dec_first=first, hedge=hedge, ef_min=14 + 35 * (pieces & 1), ef_rows=(pieces >> 1) & 1)
         _piece_schedule_case()
     finally:
         if threads:
@@ -1382,56 +1382,27 @@ def test_bench_two_ranks_rehearsed_on_one_device():
     assert "latency_ms" not in d and "modes" not in d  # (N = 1 legs)
 
 
-def test_table_kernel_placements_agree_and_look_back_is_deterministic(oracle, ctx_options):
-    """tab_kernel places a block's rows by one atomic add per block on a cursor (option tab_place 0, the default: arrival order),
-    or by decoupled look-back (1: launch order, no same-address atomics; a third slower) - and should a look-back ever give up,
-    the host re-runs the launch with the cursor (forced here: tab_spin 0 makes every wait give up).  All three give the
-    oracle's table; look-back gives the SAME bytes and block offsets on every run, with blocks in launch order; the batched
-    decoder decodes through each."""
+def test_table_kernel_blocks_are_placed_by_a_cursor(oracle):
+    """tab_kernel places a block's rows by ONE atomic add per block on the launch's cursor: blocks lie in arrival order - any
+    order -, the offsets are a permutation of the running sums of the block sizes, and the table is the oracle's whatever the
+    order.  (Round 4's decoupled look-back placement - launch order, a third slower - is in the git history.)"""
     y, sg, mu, pi = T.make_latent(35, M=64, h=16, w=12)
     sym, s, m, w, abs_max, zb, yq = T.to_coder_inputs(y, sg, mu, pi)
     max_bs = abs_max + 1
     want = oracle.cdftab("polya", s, m, w, max_bs)
-    stalls0 = _lib.ctx_stat(0, 6)
-    ctx_options(tab_place=1)
     h0, bo0, rows0, u0, tl = gpu_tab("polya", s, m, w, max_bs)
     assert np.array_equal(expand_trimmed(h0, rows0, max_bs, bo0, tl), want)
-    assert len(bo0) > 50 and np.all(np.diff(bo0.astype(np.int64)) > 0) and bo0[0] == 0  # launch order: offsets ascend
-    for _ in range(3):
-        h1, bo1, rows1, u1, _ = gpu_tab("polya", s, m, w, max_bs)
-        assert u1 == u0 and np.array_equal(bo1, bo0) and np.array_equal(rows1[:u0], rows0[:u0]) and np.array_equal(h1, h0)
-    assert _lib.ctx_stat(0, 6) == stalls0
-
-    def sizes(bo, used):  # bytes of every block, from the offsets of blocks placed in any order
-        o = np.sort(bo.astype(np.int64)) * 4
-        return np.sort(np.diff(np.append(o, used)))
-
-    ctx_options(tab_place=0)
-    hc, boc, rowsc, uc, _ = gpu_tab("polya", s, m, w, max_bs)
-    assert uc == u0 and np.array_equal(hc, h0) and np.array_equal(expand_trimmed(hc, rowsc, max_bs, boc, tl), want)
-    assert np.array_equal(sizes(boc, uc), sizes(bo0, u0))  # the same blocks, in arrival order
-    ctx_options(tab_place=1, tab_spin=0)
-    hs, bos, rowss, us, _ = gpu_tab("polya", s, m, w, max_bs)
-    assert us == u0 and np.array_equal(expand_trimmed(hs, rowss, max_bs, bos, tl), want)
-    stalled = _lib.ctx_stat(0, 6) - stalls0
-    # batched decode of a few bitstreams through each placement (tab_spin 0: launches whose look-backs give up are re-run)
-    lat = [T.make_latent(360 + i, M=M, h=h_, w=w_, zero_frac=0.1) for i, (M, h_, w_) in enumerate([(192, 32, 24), (48, 16, 8), (96, 32, 24)])]
-    dev = [[dv(a) for a in l] for l in lat]
-    ys, ss, ms, ws = ([d[k] for d in dev] for k in range(4))
-    gmc = GaussianMixtureConditional(K=4, mode="polya")
-    res = gmc.compress_batch(ys, ss, ms, ws)
-    args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
-    for place, spin in ((1, 0), (0, 1 << 21), (1, 1 << 21)):
-        ctx_options(tab_place=place, tab_spin=spin)
-        out = gmc.decompress_batch(*args)
-        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), (place, spin)
-    assert _lib.ctx_stat(0, 6) - stalls0 >= stalled  # (how many launches gave up is the hardware's business; the results are not)
+    o = np.sort(bo0.astype(np.int64)) * 4
+    assert len(bo0) > 50 and o[0] == 0 and len(np.unique(o)) == len(o) and o[-1] < u0  # every block has a place of its own
+    h1, bo1, rows1, u1, _ = gpu_tab("polya", s, m, w, max_bs)
+    assert u1 == u0 and np.array_equal(h1, h0) and np.array_equal(expand_trimmed(h1, rows1, max_bs, bo1, tl), want)
+    assert np.array_equal(np.sort(np.diff(np.append(o, u0))), np.sort(np.diff(np.append(np.sort(bo1.astype(np.int64)) * 4, u1))))  # the same blocks
 
 
 def test_scheduling_options_change_no_byte(oracle, ctx_options):
     """How a call's tables cross PCIe is a matter of scheduling only: encode tables whole (enc_segs 0) or in four segments per bitstream,
-    tails first (1, the default: the encoders follow the landing); decode tables through hipMemcpyAsync (copy_engine 0, the default)
-    or straight to the SDMA engines through HSA (1: signals the workers sleep on; 2: one engine).  Every combination gives the
+    tails first (1, the default: the encoders follow the landing); decode tasks taken after their tables have landed (hedge 1, the
+    default) or before, symbols back to the GPU round by round or bitstream by bitstream.  Every combination gives the
     oracle's bytes and the encoder's reconstruction - on a batch large enough for the segmented layout (>= 4 MB of tables), with
     an all-zero item and a channel count that is not a multiple of four among them."""
     specs = [(192, 32, 24, 0.1)] * 6 + [(190, 32, 24, 0.3), (192, 32, 24, 1.0), (192, 32, 24, 0.0)]
@@ -1451,10 +1422,10 @@ def test_scheduling_options_change_no_byte(oracle, ctx_options):
         assert [results[segs][i] for i in (0, 1, 2, 6, 7, 8)] == want, segs
     assert results[0] == results[1]
     args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
-    for engine, rounds in ((1, 1), (2, 0), (0, 0), (0, 1)):
-        ctx_options(copy_engine=engine, scatter_rounds=rounds)
+    for hedge, rounds in ((1, 1), (1, 0), (0, 0), (0, 1)):
+        ctx_options(hedge=hedge, scatter_rounds=rounds)
         out = gmc.decompress_batch(*args)
-        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), (engine, rounds)
+        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), (hedge, rounds)
 
 
 def test_round_scatter_redoes_an_item_with_symbols_beyond_int16(oracle, ctx_options):

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.fgmm_abi_version() == 4
+    assert L.fgmm_abi_version() == 5
 
 
 def test_header_is_plain_c_and_links():
@@ -381,37 +381,6 @@ def test_host_decoder_header_forms_and_block_placement(oracle, max_bs, tl):
     hdr_s, pool_s, _ = trim_full_table(tab, max_bs, form=form)  # the same form, rows sequential
     rc, out = host_decode_tab(L, enc, hdr_s, pool_s, max_bs)
     assert rc == 0 and np.array_equal(out, want)
-
-
-def test_host_pair_decoder_equals_single(oracle):
-    """fgmm_rans_decode_tab2 (two bitstreams decoded in turn by one thread): each output == the single-stream decoder's;
-    unequal lengths, different header forms / placements, an empty table, a truncated stream in either slot"""
-    L = _lib.lib()
-    rng = np.random.default_rng(21)
-    tabs = []
-    for n, max_bs, tl in ((700, 99, 0), (1500, 20, 32), (0, 9, 0), (300, 200, 16)):
-        W = 2 * max_bs + 2
-        tab = np.sort(rng.integers(0, 65536, (n, W)), axis=1).astype(np.uint16)
-        tab[::4, : W // 3] = 0
-        tab[1::4, W // 2:] = tab[1::4, W // 2 - 1: W // 2]
-        enc = rng.integers(0, 256, 4 * (n + 64), dtype=np.uint8).tobytes()
-        form = helpers.hdr_form(max_bs)
-        if tl:
-            hdr, bo, pool, _ = trim_full_table(tab, max_bs, form=form, tl=tl, shuffle_seed=3)
-        else:
-            hdr, pool, _ = trim_full_table(tab, max_bs, form=form)
-            bo = None
-        rc, want = host_decode_tab(L, enc, hdr, pool, max_bs, bo, tl)
-        assert rc == 0 and np.array_equal(want, oracle.rans_decode_cdftab(enc, tab, max_bs))
-        tabs.append(((enc, hdr, pool, max_bs, bo, tl), want))
-    for ia in range(len(tabs)):
-        for ib in range(len(tabs)):
-            rc, outs = helpers.host_decode_tab2(L, [tabs[ia][0], tabs[ib][0]])
-            assert rc == 0 and np.array_equal(outs[0], tabs[ia][1]) and np.array_equal(outs[1], tabs[ib][1]), (ia, ib)
-    short = (tabs[1][0][0][:40],) + tabs[1][0][1:]
-    assert helpers.host_decode_tab2(L, [tabs[0][0], short])[0] == 5  # FGMM_ERR_STREAM
-    rc, outs = helpers.host_decode_tab2(L, [short, tabs[0][0]])
-    assert rc == 5 and np.array_equal(outs[1], tabs[0][1])  # the other stream still decodes to the end
 
 
 def test_host_decoder_raw_rows_only(oracle, monkeypatch):
