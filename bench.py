@@ -681,7 +681,7 @@ def step_stats(step_s, probe: "HostProbe | None" = None):
 
 
 def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
-    """The self-diagnosing leg.  `configs` = ["48", "16", "48+hedge=0" ...]: host workers, optionally
+    """The self-diagnosing leg.  `configs` = ["48", "16", "48+pieces=4" ...]: host workers, optionally
     "+option=value" settings of the library (an A/B inside one run); the configurations take turns in blocks of `block` steps until each has run `steps` steps (boxes differ and drift: only interleaved blocks compare).
     Every step is sampled with the full HostProbe and the library's call log (phase marks of the step's native calls); a helper
     process (scripts/bin/host_watch) samples the host's count of runnable tasks and its own wake-up lateness every 0.5 ms.  For every

@@ -176,9 +176,8 @@ const OptName kOpts[] = {
     {"ckpt_decode", &fgmm_ctx::Opts::ckpt_decode, 0, 2, "FGMM_CKPT_DECODE"},
     {"spin_lat", &fgmm_ctx::Opts::spin_lat, -1, 1ll << 40, "FGMM_SPIN_LAT"},
     {"gpu_decode", &fgmm_ctx::Opts::gpu_decode, 0, 2, "FGMM_GPU_DECODE"},
-    {"enc_segs", &fgmm_ctx::Opts::enc_segs, 0, 1, "FGMM_ENC_SEGS"},
+    {"enc_segs", &fgmm_ctx::Opts::enc_segs, 0, 2, "FGMM_ENC_SEGS"}, // (2: segments whatever the tables' size - tests)
     {"scatter_rounds", &fgmm_ctx::Opts::scatter_rounds, 0, 1, nullptr},
-    {"hedge", &fgmm_ctx::Opts::hedge, 0, 1, "FGMM_HEDGE"},
 };
 } // namespace
 

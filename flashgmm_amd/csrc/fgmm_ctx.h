@@ -177,7 +177,7 @@ struct fgmm_ctx {
   // tuning knobs (fgmm_ctx_set_option); the FGMM_* environment variables of the same meaning are read once, at creation
   struct Opts {
     int64_t pieces = 0, dec_first = 2, tab_cap_e = fgmm::kTabCapE, stage_max_mb = 0, trace = 0, enc_vec = 0, enc_linear = 1, ef_rows = 0,
-            ef_min = fgmm::kTabEfDefault, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, enc_segs = 1, scatter_rounds = 1, hedge = 1;
+            ef_min = fgmm::kTabEfDefault, enc_ways = 0, ckpt_decode = 0, spin_lat = 400000, gpu_decode = 0, enc_segs = 1, scatter_rounds = 1;
   } opt;
   // pinned receive area of the decode tables: a list of chunks, bump-allocated per call, never moved while copies are in
   // flight (sizes are only known launch by launch)

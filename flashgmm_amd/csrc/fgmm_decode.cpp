@@ -16,6 +16,8 @@
 // after the final copy is 1/36 of each bitstream.  Why a task is taken only AFTER its tables have landed (round 5): a worker
 // that is woken late - on a shared host a woken thread can stand on a run queue for one or two scheduler ticks, 4-8 ms,
 // profiles/r05_stall_diagnosis.md - then holds nothing; whoever is awake decodes the piece, and the late one finds it done.
+// (Measured against taking the task first and sleeping on it, rounds 2-4's way: the same step times on quiet and on noisy
+// boxes - the slow steps of a noisy box are mostly the CALLING thread's lost time slices, profiles/r05_hedge_ab_*.json.)
 // Items whose half-width does not fit the single-pass kernel (tab_tl() == 0) take the generic two-pass kernels, one item at a
 // time, synchronously (8-byte headers past max_bs 16382).
 //
@@ -60,7 +62,7 @@ struct DecodeCall {
   Trace tr;
   // ---- configuration of the call
   int cap_e = kTabCapE, np = 1, decoders = 1;
-  bool clamped = false, f16 = false, spin = false, hedge = true;
+  bool clamped = false, f16 = false, spin = false;
   uint32_t ef_min = kTabNoEf;
   int64_t streams_of_work = 0;
   // ---- plan
@@ -106,7 +108,6 @@ struct DecodeCall {
         }
     clamped = items[0].clamp != 0;
     f16 = items[0].prm.dtype == FGMM_F16;
-    hedge = ctx->opt.hedge != 0;
     // Segments pay when a call has fewer bitstreams than workers (one image, ELIC's stages of a few images); a call with a bitstream
     // per worker or more keeps them all busy piece by piece and would only pay the segments' bookkeeping: the notes are ignored there
     const bool use_ckpt = ctx->opt.ckpt_decode == 1 || (ctx->opt.ckpt_decode == 0 && count < std::max(ctx->pool->size(), 1));
@@ -148,13 +149,12 @@ struct DecodeCall {
     np = (int)std::min<int64_t>(std::max<int64_t>(ctx->opt.pieces, 1), kMaxPieces);
     int64_t lat = 0, lat_max = 0;
     for (int i : fast) lat += items[i].n, lat_max = std::max(lat_max, items[i].n);
-    if (ctx->opt.pieces <= 0) {
-      // automatic: eight pieces leave a Kodak half's decoder at most 4 096 latents (1 / 36 of its bitstream, 40 us) behind the bus's
-      // last byte; a bitstream of an ELIC-4K stage is up to 24 times as long - as many pieces as keep the last one at that size, at
-      // most 24 (ELIC-4K, 16 images: 231 -> 210 ms per step with 24, 32 no better; profiles/r04_elic_pieces_ab.txt)
-      np = 8;
-      while (np < kAutoPiecesMax && (int64_t)np * (np + 1) / 2 * 4096 < lat_max) ++np;
-    }
+    if (ctx->opt.pieces > 0) return; // (an explicit number is taken as it is)
+    // automatic: eight pieces leave a Kodak half's decoder at most 4 096 latents (1 / 36 of its bitstream, 40 us) behind the bus's last
+    // byte; a bitstream of an ELIC-4K stage is up to 24 times as long - as many pieces as keep the last one at that size, at most 24
+    // (ELIC-4K, 16 images: 231 -> 210 ms per step with 24, 32 no better; profiles/r04_elic_pieces_ab.txt)
+    np = 8;
+    while (np < kAutoPiecesMax && (int64_t)np * (np + 1) / 2 * 4096 < lat_max) ++np;
     if (lat < 65536) np = 1;                 // pieces only pay for rows that take a while to cross
     if (decoders == 1) np = std::min(np, 3); // one decoder: pieces only let it start early, and each costs a hand-over (20 us)
     // every round costs this thread ~60 us of launch / counter / copy round trips: no more rounds than the tables' time on the bus
@@ -671,7 +671,7 @@ struct DecodeCall {
       }
       const Key k = ready.top();
       const bool here = k.unit < 0 || unit_landed[(size_t)k.unit];
-      if (!here && hedge) {
+      if (!here) {
         // The tables of the earliest task are not known to be on the host yet: sleep on that unit's copy WITHOUT taking the task.
         // Whoever is awake when it lands takes it; a worker that wakes late finds it gone and holds nothing up.
         if (abandon) return;
@@ -681,7 +681,6 @@ struct DecodeCall {
       ready.pop();
       DecItem &it = items[k.item];
       if (k.seg >= 0) { // a segment of a checkpointed bitstream: independent of every other task
-        if (!here) await_unit(l, k.unit);
         if (copy_failed) it.ckpt_bad.store(1), it.status = FGMM_ERR_HIP;
         l.unlock();
         const bool fin = run_segment(it, k.seg);
@@ -692,7 +691,6 @@ struct DecodeCall {
       it.in_ready = false;
       it.busy = true;
       const int p = it.next_piece;
-      if (!here) await_unit(l, k.unit); // (hedge off: the task is held while its tables are on the bus, as until round 4)
       if (copy_failed && it.status == FGMM_OK) it.status = FGMM_ERR_HIP;
       l.unlock();
       const bool fin = run_piece(it, p);
@@ -793,6 +791,23 @@ struct DecodeCall {
         c->work_cv.notify_all();
       }
     };
+    // Any return, last of all (after the workers have gone): nothing of this call may still be in flight on the device - a bitstream
+    // that fails early (truncated input) finishes its item while the copies of its later pieces are still queued, and the NEXT call
+    // would hand the same staging area to its kernels and the same pinned ranges to its copies (found by ThreadSanitizer on the fake
+    // device, round 5).  Free on the normal path: the last unit is known to have landed, the caller's stream has been synchronised.
+    struct Quiesce {
+      DecodeCall *c;
+      bool clean = false;
+      ~Quiesce() {
+        bool landed_all;
+        {
+          std::lock_guard<std::mutex> l(c->mu);
+          landed_all = c->n_units == 0 || c->unit_landed[(size_t)c->n_units - 1];
+        }
+        if (!clean) (void)dev::stream_sync(c->stream), (void)dev::stream_sync(c->ctx->aux_stream);
+        if (!clean || !landed_all || c->launched < c->n_units) (void)dev::stream_sync(c->ctx->copy_stream);
+      }
+    } quiesce{this};
     PoolDrain drain{ctx->pool}; // on any return: wait for every job before the objects they use go away
     Abandon abandon_on_exit{this};
     if ((rc = upload_and_prime())) return rc;
@@ -807,6 +822,7 @@ struct DecodeCall {
       if ((rc = run_generic(i))) return rc;
     rc = scatter_and_finish();
     account();
+    quiesce.clean = rc == FGMM_OK;
     return rc;
   }
 };

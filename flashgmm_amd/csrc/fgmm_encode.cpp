@@ -100,7 +100,7 @@ struct EncodeCall {
       tables += table_bytes(it);
       segmented = segmented && it.y && !it.symbuf && it.M >= 2 * kEncSegs;
     }
-    segmented = segmented && tables >= ((size_t)4 << 20); // (smaller calls: the transfer is not what they wait for)
+    segmented = segmented && (tables >= ((size_t)4 << 20) || ctx->opt.enc_segs == 2); // (smaller calls: the transfer is not what they wait for; 2: tests)
     if (!segmented) {
       for (int i : order) items[i].o_packed = ar.take(table_bytes(items[i]) + 64);
     } else {
@@ -475,7 +475,9 @@ struct EncodeCall {
 int encode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<EncItem> &items, int mode) {
   if (items.empty()) return FGMM_OK;
   EncodeCall call(ctx, stream, items, mode);
-  return call.run();
+  const int rc = call.run();
+  if (rc != FGMM_OK) (void)dev::stream_sync(stream); // (an early return: nothing of this call may still be writing the workspace the next one reuses)
+  return rc;
 }
 
 } // namespace fgmm

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FGMM_ABI_VERSION 5 /* 5: + fgmm_ctx_call_log, option hedge; REMOVED (measured, lost, pruned): options tab_place / tab_spin / copy_engine /
+#define FGMM_ABI_VERSION 5 /* 5: + fgmm_ctx_call_log; REMOVED (measured, lost, pruned): options tab_place / tab_spin / copy_engine /
                               dec_pair / dec_group, fgmm_rans_decode_tab2 + fgmm_tab_ref, fgmm_ctx_stat index 6 */
 
 typedef enum {
@@ -97,10 +97,9 @@ int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, con
 /* Tuning knobs of a context (defaults in brackets; what was measured behind each: DESIGN.md).  Unknown names return FGMM_ERR_INVALID.
  *   "pieces"      [0]   decode: the tables of every bitstream of a call reach the host in this many pieces, piece-major and shrinking
  *                       (at most 32; 0 = by the call's longest bitstream: 8 up to 147 k latents, 24 from 1.1 M on); the host workers take
- *                       (bitstream, piece) tasks as they land, the coder state travels with the bitstream from worker to worker
+ *                       (bitstream, piece) tasks once their tables have landed, the coder state travels with the bitstream from
+ *                       worker to worker
  *   "dec_first"   [2]   decode: bitstreams in the first launch of the first round of pieces (doubling from there: first tables early)
- *   "hedge"       [1]   decode: 1 = a worker takes a (bitstream, piece) task only once its tables are known to have landed - a worker
- *                       that is woken late then holds nothing up; 0 = it takes the task first and sleeps holding it (rounds 2-4)
  *   "enc_ways"    [0]   encode: consecutive bitstreams one worker codes symbol by symbol in turn (several dependency chains share a
  *                       core): 1..4; 0 = two when the call has more bitstreams than workers, else one
  *   "enc_segs"    [1]   encode: a call in which every bitstream has a host worker of its own (and whose tables are 4 MB and more) lays

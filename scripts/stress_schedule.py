@@ -21,7 +21,7 @@ rounds = errors_expected = 0
 while time.time() < t_end:
     threads = int(rng.choice([1, 2, 3, 8, 16, 48]))
     _lib.set_threads(0, threads)
-    opts = dict(pieces=int(rng.integers(0, 33)), dec_first=int(rng.integers(1, 10)), hedge=int(rng.integers(0, 2)),
+    opts = dict(pieces=int(rng.integers(0, 33)), dec_first=int(rng.integers(1, 10)),
                 ef_min=int(rng.choice([14, 33, 49, 200])), ef_rows=int(rng.integers(0, 3)),
                 enc_ways=int(rng.integers(0, 5)), ckpt_decode=int(rng.integers(0, 3)), gpu_decode=int(rng.choice([0, 2])),
                 enc_segs=int(rng.integers(0, 2)), scatter_rounds=int(rng.integers(0, 2)))

@@ -1,0 +1,174 @@
+// stress_main.cpp — TEST INFRASTRUCTURE: randomized batches through the product's C ABI (include/flashgmm_amd.h) on the FAKE device
+// (fake_device.cpp), meant to run under ThreadSanitizer / AddressSanitizer + UBSan (scripts/tsan_host.sh).  Every batch:
+//   fgmm_gmc_compress_batch   -> each bitstream == the oracle's encoder on the same symbols and parameters (fgo_encode_gmm), bit for bit
+//   fgmm_gmc_decompress_batch -> y_hat == round(y) for every item
+// under random pipeline options (pieces, first launch, Elias-Fano threshold, encoder ways, whole / segmented encode
+// tables, scatter rounds, checkpointed streams decoded in host segments / handed to the "GPU" and partly handed back, a tiny staging
+// budget that forces overflow re-runs, an LDS budget that sends items to the generic kernels) and random worker counts; now and then a
+// truncated bitstream, which must be refused.   stress_main [seconds] [seed]
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <vector>
+
+#include "../../include/flashgmm_amd.h"
+
+extern "C" int fgo_encode_gmm(int mode, int64_t n, const int32_t *symbols, const float *scales, const float *means, const float *weights, int64_t sn, int64_t sk,
+                              uint8_t **out, size_t *out_len, int64_t *n_bypass_out);
+extern "C" void fgo_free(void *p);
+
+static uint64_t rng_state = 88172645463325252ull;
+static uint64_t rnd() {
+  rng_state ^= rng_state << 13, rng_state ^= rng_state >> 7, rng_state ^= rng_state << 17;
+  return rng_state;
+}
+static double uni() { return (double)(rnd() >> 11) / 9007199254740992.0; }
+static double gauss() { return sqrt(-2.0 * log(uni() + 1e-300)) * cos(6.283185307179586 * uni()); }
+static int64_t pick(int64_t lo, int64_t hi) { return lo + (int64_t)(rnd() % (uint64_t)(hi - lo + 1)); }
+
+#define CHECK(cond, ...)                                     \
+  do {                                                       \
+    if (!(cond)) {                                           \
+      fprintf(stderr, "STRESS FAILURE %s:%d: ", __FILE__, __LINE__); \
+      fprintf(stderr, __VA_ARGS__);                          \
+      fprintf(stderr, "  [%s]\n", fgmm_last_error());        \
+      exit(1);                                               \
+    }                                                        \
+  } while (0)
+
+struct Item {
+  int M;
+  int64_t hw;
+  std::vector<float> y, sg, mu, pi, yq, yhat; // planes [K, M, hw]
+  std::vector<int64_t> zb;
+};
+
+static void make_item(Item &it, int M, int64_t hw, double zero_frac) {
+  it.M = M, it.hw = hw;
+  const size_t n = (size_t)M * (size_t)hw;
+  it.y.resize(n), it.yq.assign(n, -7.f), it.yhat.assign(n, -9.f), it.zb.assign((size_t)M, -1);
+  it.sg.resize(4 * n), it.mu.resize(4 * n), it.pi.resize(4 * n);
+  for (int c = 0; c < M; ++c) {
+    const double e = exp(-3.0 + 4.5 * uni());
+    const bool dead = uni() < zero_frac;
+    for (int64_t p = 0; p < hw; ++p) {
+      const size_t i = (size_t)c * hw + p;
+      it.y[i] = dead ? (float)(0.4 * (uni() - 0.5)) : (float)(gauss() * 1.5 * e);
+      double w[4], ws = 0;
+      for (int k = 0; k < 4; ++k) w[k] = exp(gauss()), ws += w[k];
+      for (int k = 0; k < 4; ++k) {
+        it.mu[(size_t)k * n + i] = (float)(gauss() * e);
+        it.sg[(size_t)k * n + i] = (float)((uni() * 2 + 0.05) * e); // un-clamped: the path clamps to [0.11, 256]
+        it.pi[(size_t)k * n + i] = (float)(w[k] / ws * 0.999);      // (sum <= 1 after rounding)
+      }
+    }
+  }
+}
+
+static void set_opt(fgmm_ctx *ctx, const char *name, int64_t v) { CHECK(fgmm_ctx_set_option(ctx, name, v) == FGMM_OK, "option %s=%lld", name, (long long)v); }
+
+int main(int argc, char **argv) {
+  const double budget = argc > 1 ? atof(argv[1]) : 20.0;
+  if (argc > 2) rng_state ^= (uint64_t)atoll(argv[2]) * 0x9E3779B97F4A7C15ull;
+  fgmm_ctx *ctx = nullptr;
+  CHECK(fgmm_ctx_create(0, 4, &ctx) == FGMM_OK, "ctx");
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(budget);
+  long rounds = 0, refused = 0, streams = 0, symbols = 0;
+  static const int kThreads[] = {1, 2, 3, 5, 8, 16};
+  while (std::chrono::steady_clock::now() < t_end) {
+    CHECK(fgmm_ctx_set_threads(ctx, kThreads[rnd() % 6]) == FGMM_OK, "threads");
+    set_opt(ctx, "pieces", rnd() % 3 ? pick(1, 12) : 0);
+    set_opt(ctx, "dec_first", pick(1, 6));
+    set_opt(ctx, "ef_rows", pick(0, 2));
+    set_opt(ctx, "ef_min", rnd() % 2 ? 14 : 49);
+    set_opt(ctx, "enc_ways", pick(0, 4));
+    set_opt(ctx, "enc_segs", pick(0, 2));
+    set_opt(ctx, "scatter_rounds", rnd() % 2);
+    set_opt(ctx, "ckpt_decode", pick(0, 2));
+    set_opt(ctx, "gpu_decode", pick(0, 2));
+    set_opt(ctx, "stage_max_mb", rnd() % 4 == 0 ? 1 : 0); // a tiny staging budget: launches overflow and are re-run
+    set_opt(ctx, "tab_cap_e", rnd() % 5 == 0 ? 256 : 12288); // a tiny LDS budget: items take the generic two-pass kernels
+    set_opt(ctx, "spin_lat", rnd() % 3 == 0 ? -1 : 400000);
+    const int mode = (int)(rnd() % 3), clamp = 1;
+    const int32_t stride = rnd() % 2 ? (int32_t)(256 << (rnd() % 3)) : 0; // checkpointed streams
+    const int count = (int)pick(1, 12);
+    std::vector<Item> its((size_t)count);
+    std::vector<fgmm_item> fi((size_t)count);
+    for (int i = 0; i < count; ++i) {
+      static const int Ms[] = {1, 3, 8, 9, 17, 24};
+      static const int64_t HWs[] = {1, 7, 64, 96, 192, 384};
+      make_item(its[(size_t)i], Ms[rnd() % 6], HWs[rnd() % 6], rnd() % 5 == 0 ? 1.0 : 0.15);
+      Item &it = its[(size_t)i];
+      fgmm_item &f = fi[(size_t)i];
+      memset(&f, 0, sizeof f);
+      f.y = it.y.data();
+      f.params.scales = it.sg.data(), f.params.means = it.mu.data(), f.params.weights = it.pi.data();
+      f.params.stride_k = (int64_t)it.M * it.hw, f.params.stride_c = it.hw, f.params.dtype = FGMM_F32;
+      f.M = it.M, f.K = 4, f.hw = it.hw;
+      f.yq_out = it.yq.data();
+      f.zero_bitmap = it.zb.data();
+      f.ckpt_stride = stride;
+    }
+    CHECK(fgmm_gmc_compress_batch(ctx, nullptr, fi.data(), count, mode, clamp) == FGMM_OK, "compress_batch (count %d)", count);
+    // ---- every bitstream against the oracle's encoder
+    for (int i = 0; i < count; ++i) {
+      Item &it = its[(size_t)i];
+      const size_t n_all = (size_t)it.M * it.hw;
+      std::vector<int32_t> sym;
+      std::vector<float> s, m, w;
+      for (int c = 0; c < it.M; ++c) {
+        bool nz = false;
+        for (int64_t p = 0; p < it.hw; ++p) {
+          const float q = nearbyintf(it.y[(size_t)c * it.hw + p]);
+          CHECK(it.yq[(size_t)c * it.hw + p] == q, "y_q item %d", i);
+          nz |= q != 0.0f;
+        }
+        CHECK(it.zb[(size_t)c] == (nz ? 1 : 0), "zero bitmap item %d channel %d", i, c);
+        if (!nz) continue;
+        for (int64_t p = 0; p < it.hw; ++p) {
+          const size_t at = (size_t)c * it.hw + p;
+          sym.push_back((int32_t)nearbyintf(it.y[at]));
+          for (int k = 0; k < 4; ++k) {
+            s.push_back(fminf(fmaxf(it.sg[(size_t)k * n_all + at], 0.11f), 256.0f));
+            m.push_back(it.mu[(size_t)k * n_all + at]);
+            w.push_back(it.pi[(size_t)k * n_all + at]);
+          }
+        }
+      }
+      uint8_t *want = nullptr;
+      size_t want_len = 0;
+      CHECK(fgo_encode_gmm(mode, (int64_t)sym.size(), sym.data(), s.data(), m.data(), w.data(), 4, 1, &want, &want_len, nullptr) == 0, "oracle");
+      CHECK(fi[(size_t)i].bytes_len == want_len && !memcmp(fi[(size_t)i].bytes, want, want_len), "bitstream %d of %d differs from the oracle's (%zu / %zu bytes)", i,
+            count, fi[(size_t)i].bytes_len, want_len);
+      fgo_free(want);
+      streams += 1, symbols += (long)sym.size();
+    }
+    // ---- decode: y_hat == y_q
+    for (int i = 0; i < count; ++i) fi[(size_t)i].yq_out = its[(size_t)i].yhat.data();
+    CHECK(fgmm_gmc_decompress_batch(ctx, nullptr, fi.data(), count, mode, clamp) == FGMM_OK, "decompress_batch (count %d)", count);
+    for (int i = 0; i < count; ++i) CHECK(its[(size_t)i].yhat == its[(size_t)i].yq, "y_hat != y_q, item %d of %d", i, count);
+    // ---- a truncated bitstream must be refused (and must not take the call down with it)
+    if (rnd() % 3 == 0) {
+      int victim = -1;
+      for (int i = 0; i < count; ++i)
+        if (fi[(size_t)i].bytes_len > 64) victim = i;
+      if (victim >= 0) {
+        const fgmm_item keep = fi[(size_t)victim];
+        fi[(size_t)victim].bytes_len = 16;
+        if (rnd() % 2) fi[(size_t)victim].ckpt = nullptr, fi[(size_t)victim].n_ckpt = 0; // (with and without its notes)
+        CHECK(fgmm_gmc_decompress_batch(ctx, nullptr, fi.data(), count, mode, clamp) != FGMM_OK, "a truncated bitstream decoded");
+        fi[(size_t)victim] = keep;
+        ++refused;
+      }
+    }
+    for (auto &f : fi) fgmm_free(f.bytes), fgmm_free(f.ckpt);
+    ++rounds;
+  }
+  fgmm_ctx_destroy(ctx);
+  printf("stress on the fake device: %ld batches, %ld bitstreams == oracle, %ld symbols, %ld truncated batches refused\n", rounds, streams, symbols, refused);
+  return 0;
+}

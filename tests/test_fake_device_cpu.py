@@ -1,0 +1,38 @@
+"""The product's host pipeline on the FAKE device (tests/fake/fake_device.cpp: device memory = host memory, every stream an in-order
+queue on its own thread, the kernels restated from the oracle): randomized batches through the C ABI, every bitstream against the
+oracle's encoder, every decode against round(y), truncated bitstreams refused - the same driver scripts/tsan_host.sh runs under
+ThreadSanitizer and AddressSanitizer + UBSan.  Here: an un-instrumented build, a few seconds, so that the CPU suite covers the
+concurrent pipeline (planner, staging, task queue, event waits, overflow re-runs, GPU-segment hand-back) without a GPU."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = ["flashgmm_amd/csrc/fgmm_capi.cpp", "flashgmm_amd/csrc/fgmm_encode.cpp", "flashgmm_amd/csrc/fgmm_decode.cpp", "flashgmm_amd/csrc/fgmm_decode_gpu.cpp",
+       "flashgmm_amd/csrc/fgmm_rans.cpp", "tests/fake/fake_device.cpp", "tests/fake/stress_main.cpp"]
+
+
+@pytest.fixture(scope="module")
+def stress_binary():
+    out = os.path.join(ROOT, "scripts", "bin", "stress_plain")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    newest = max(os.path.getmtime(os.path.join(ROOT, f)) for f in SRC + ["oracle/fgmm_oracle.c", "flashgmm_amd/csrc/fgmm_ctx.h", "flashgmm_amd/csrc/fgmm_internal.h"])
+    if not os.path.exists(out) or os.path.getmtime(out) < newest:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-march=x86-64-v3", "-ffp-contract=off", "-fno-fast-math"] + SRC +
+                              ["-x", "c", "oracle/fgmm_oracle.c", "-x", "none", "-lpthread", "-lm", "-o", out], cwd=ROOT)
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_host_pipeline_on_the_fake_device(stress_binary, seed):
+    r = subprocess.run([stress_binary, "4", str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "bitstreams == oracle" in r.stdout and " 0 batches" not in r.stdout, r.stdout
+
+
+def test_host_sources_do_not_include_the_gpu_runtime():
+    """the host side reaches the device through fgmm_device.h only: that is what lets it build against the fake"""
+    for f in SRC[:5] + ["flashgmm_amd/csrc/fgmm_ctx.h", "flashgmm_amd/csrc/fgmm_internal.h", "flashgmm_amd/csrc/fgmm_device.h"]:
+        text = open(os.path.join(ROOT, f)).read()
+        assert "hip/hip_runtime" not in text and "#include <hsa" not in text, f

@@ -577,17 +577,15 @@ def test_stacked_batch_equals_item_lists(dtype):
         gmc.decompress_batch([r[0][0] for r in a][:-1], [r[0][1] for r in a], [r[0][2] for r in a], sg, mu, pi)
 
 
-@pytest.mark.parametrize("pieces,first,threads,hedge", [(4, 2, 0, 1), (1, 2, 0, 0), (2, 1, 3, 1), (3, 9, 0, 0), (8, 2, 2, 1),
-                                                        (7, 1, 16, 0), (8, 2, 1, 1), (16, 2, 0, 1), (32, 2, 0, 0), (0, 3, 5, 1)])
-def test_decode_piece_schedule_settings(ctx_options, pieces, first, threads, hedge):
+@pytest.mark.parametrize("pieces,first,threads", [(4, 2, 0), (1, 2, 0), (2, 1, 3), (3, 9, 0), (8, 2, 2), (7, 1, 16), (8, 2, 1), (16, 2, 0), (32, 2, 0), (0, 3, 5)])
+def test_decode_piece_schedule_settings(ctx_options, pieces, first, threads):
     """The tables of a decode batch land on the host in pieces, piece-major, and the host workers take (bitstream, piece) tasks as
-    they land (fgmm_decode.cpp) - after the landing (hedge 1, the default) or holding the task while its tables are on the bus
-    (0): every setting of the schedule, and any number of workers, must give the same symbols; the encoder side codes
+    they land (fgmm_decode.cpp): every setting of the schedule, and any number of workers, must give the same symbols; the encoder side codes
     ceil(9 / workers) bitstreams in turn per worker (enc_ways), up to four."""
     if threads:
         _lib.set_threads(0, threads)  # a fresh context: before the options
     try:
-        ctx_options(pieces=pieces, dec_first=first, hedge=hedge, ef_min=14 + 35 * (pieces & 1), ef_rows=(pieces >> 1) & 1)
+        ctx_options(pieces=pieces, dec_first=first, ef_min=14 + 35 * (pieces & 1), ef_rows=(pieces >> 1) & 1)
         _piece_schedule_case()
     finally:
         if threads:
@@ -1401,8 +1399,8 @@ def test_table_kernel_blocks_are_placed_by_a_cursor(oracle):
 
 def test_scheduling_options_change_no_byte(oracle, ctx_options):
     """How a call's tables cross PCIe is a matter of scheduling only: encode tables whole (enc_segs 0) or in four segments per bitstream,
-    tails first (1, the default: the encoders follow the landing); decode tasks taken after their tables have landed (hedge 1, the
-    default) or before, symbols back to the GPU round by round or bitstream by bitstream.  Every combination gives the
+    tails first (1, the default: the encoders follow the landing); symbols back to the GPU round by round or bitstream by bitstream.
+    Every combination gives the
     oracle's bytes and the encoder's reconstruction - on a batch large enough for the segmented layout (>= 4 MB of tables), with
     an all-zero item and a channel count that is not a multiple of four among them."""
     specs = [(192, 32, 24, 0.1)] * 6 + [(190, 32, 24, 0.3), (192, 32, 24, 1.0), (192, 32, 24, 0.0)]
@@ -1422,10 +1420,10 @@ def test_scheduling_options_change_no_byte(oracle, ctx_options):
         assert [results[segs][i] for i in (0, 1, 2, 6, 7, 8)] == want, segs
     assert results[0] == results[1]
     args = ([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
-    for hedge, rounds in ((1, 1), (1, 0), (0, 0), (0, 1)):
-        ctx_options(hedge=hedge, scatter_rounds=rounds)
+    for rounds in (1, 0):
+        ctx_options(scatter_rounds=rounds)
         out = gmc.decompress_batch(*args)
-        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), (hedge, rounds)
+        assert all(torch.equal(o, r[1]) for o, r in zip(out, res)), rounds
 
 
 def test_round_scatter_redoes_an_item_with_symbols_beyond_int16(oracle, ctx_options):
