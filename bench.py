@@ -870,10 +870,15 @@ def dryrun(a, world, rank):
     threads = _lib.lib().fgmm_host_thread_budget(_lib.ranks_on_node())  # what this rank's context would get
     t_gather = []
 
+    ex = P.LengthExchange(n_streams) if world > 1 else None
+
     def step():
         lens = [1000 + 7 * rank + i for i in range(n_streams)]  # stand-in for the coder's output lengths
         t0 = time.perf_counter()
-        g = P.all_gather_stream_lengths(lens, n_streams) if world > 1 else None
+        g = None
+        if ex is not None:
+            ex.start(lens)  # (in flight while the decode calls would run)
+            g = ex.wait()
         t_gather.append(time.perf_counter() - t0)
         return g
 
@@ -953,6 +958,11 @@ class Leg:
         self.bytes_per_symbol = 32 if f16 else 56
         self.gmc = GaussianMixtureConditional(K=4, mode=mode)
         self.k_sym, self.k_tab, self.k_qs, self.t_gather, self.edges, self.tab_bytes = [], [], [], [], [], []
+        # the path's one exchange: per-stream bitstream lengths, ONE preallocated all_gather_into_tensor, issued
+        # asynchronously after the encode call and waited for at the end of the step (the lengths only feed the container index)
+        from flashgmm_amd import parallel as P_
+
+        self.ex = P_.LengthExchange(self.n_streams, device=env.coll_dev) if env.dist else None
         self.last = {}
 
     def with_mode(self, mode: str):
@@ -999,19 +1009,18 @@ class Leg:
 
     def step(self, schedule, record=False):
         from flashgmm_amd import _lib
-        from flashgmm_amd import parallel as P
 
         res = self.gmc.compress_batch(self.ys, self.ss, self.ms, self.ws)
         if record:
             self.k_sym.append(_lib.kernel_ms(self.env.local_rank, 0))
             self.k_qs.append(_lib.kernel_ms(self.env.local_rank, 2))
-        if self.env.world > 1:  # the path's one exchange: per-stream bitstream lengths, RCCL all-gather
-            t0 = time.perf_counter()
-            P.all_gather_stream_lengths([len(b) for b in res.strings] if self.stacked else [len(r[0][0]) for r in res], len(res),
-                                        device=self.env.coll_dev)
-            if record:
-                self.t_gather.append(time.perf_counter() - t0)
+        if self.ex is not None:  # issued now, in flight during the decode calls
+            self.ex.start([len(b) for b in res.strings] if self.stacked else [len(r[0][0]) for r in res])
         outs = self.decode_codec(res, record) if schedule == "codec" else self.decode_all(res, record)
+        if self.ex is not None:
+            self.last["lengths"] = self.ex.wait(to_host=False)  # (read on the host when the containers are assembled: check_last)
+            if record:
+                self.t_gather.append((self.ex.issue_ms, self.ex.exposed_ms, self.ex.total_ms))
         return res, outs
 
     def timed(self, schedule, steps, record=False):
@@ -1039,6 +1048,9 @@ class Leg:
     def check_last(self):
         """correctness of what was timed: decode(encode(y)) == round(y) for every stream of this rank"""
         res, outs = self.last["res"], self.last["outs"]
+        if self.ex is not None:  # what the exchange delivered for this rank's row: the last step's bitstream lengths
+            mine = self.last["lengths"][self.env.rank].cpu().tolist()
+            assert mine[: self.n_streams] == ([len(b) for b in res.strings] if self.stacked else [len(r[0][0]) for r in res]), "gathered stream lengths mismatch"
         if self.stacked:  # outs: one [N', 1, M, h, w] tensor per decode call (stage s = every spi-th stream from s; or all of them)
             assert torch.equal(res.y_q[:, 0], torch.round(self.ys)), "quantised latents mismatch"
             step = len(outs)
@@ -1170,15 +1182,32 @@ def main(argv=None):
         numa = P.confirm_numa_binding(local_rank, numa)  # the runtime's own address for the device: rebinds if sysfs said otherwise
     dist = None
     backend = None
-    if world > 1:
+    pg_note = None
+    if world > 1 or "WORLD_SIZE" in os.environ or os.environ.get("FGMM_BENCH_PG", "0") != "0":
+        # N = 1 goes through the same collective when a process group exists - a launcher started this rank (WORLD_SIZE=1), or
+        # FGMM_BENCH_PG=1 asks for one: a group of one rank over RCCL (`ranks.rccl_ranks` 1).  The plain `python bench.py` of a
+        # one-GPU run makes none: at N = 1 the exchange is pure overhead (measured: 0.3 ms of c10d / Python per step + RCCL's
+        # threads beside the host workers: step median 9.34 -> 10.03 ms, profiles/r05_n1_process_group.txt)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_device:  # RCCL refuses two ranks on one GPU: rehearse with gloo
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        backend = dist.get_backend()
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        try:
+            if one_device:  # RCCL refuses two ranks on one GPU: rehearse with gloo
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            backend = dist.get_backend()
+        except Exception as e:
+            if world > 1:
+                raise
+            pg_note = f"no process group at N = 1 ({type(e).__name__}: {str(e)[:120]})"
+            dist = None
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     env = Env(rank, world, local_rank, dev, dist, coll_dev, backend)
 
@@ -1448,7 +1477,12 @@ def main(argv=None):
             "ranks": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                       "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
                       "host_threads_per_gpu": per_rank_threads, "result_checked_ranks": checked,
-                      "allgather_ms": round(float(np.mean(leg.t_gather)) * 1e3, 4) if leg.t_gather else None,
+                      # the lengths' all-gather per step: issued after the encode call, waited for at the end of the step -
+                      # `exposed` is what the step pays, `total` how long the collective was in flight (hidden behind the decode)
+                      "allgather_ms": ({"issue": round(float(np.mean([t[0] for t in leg.t_gather])), 4), "exposed": round(float(np.mean([t[1] for t in leg.t_gather])), 4),
+                                        "total_in_flight": round(float(np.mean([t[2] for t in leg.t_gather])), 3),
+                                        "form": "one preallocated all_gather_into_tensor, async_op"} if leg.t_gather else None),
+                      "process_group_note": pg_note,
                       "allgather_payload_ms": round(payload_ms, 4) if payload_ms is not None else None},
             "reference_md5": ka1,
         }

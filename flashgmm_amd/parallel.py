@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_units", "owner_of", "all_gather_stream_lengths", "container_index", "gather_containers",
+__all__ = ["shard_units", "owner_of", "all_gather_stream_lengths", "LengthExchange", "container_index", "gather_containers",
            "bind_to_gpu_numa_node", "confirm_numa_binding"]
 
 
@@ -38,6 +38,66 @@ def all_gather_stream_lengths(local_lengths: Sequence[int], streams_per_rank: in
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf, group=group)
     return torch.stack(out)
+
+
+class LengthExchange:
+    """The path's one exchange, made to overlap: ONE ``all_gather_into_tensor`` of the per-stream byte lengths on PREALLOCATED
+    buffers, issued asynchronously right after the encode call (``start``) and waited for where the lengths are needed - when the
+    containers are assembled, after the decode calls (``wait``).  The lengths only feed ``container_index``; nothing of the
+    coding path depends on them, so the collective's latency (tens of microseconds over xGMI, more on a busy host) hides behind
+    the decode.  With a process group of ONE rank the same call still goes through the backend (RCCL at N = 1); without a
+    process group ``wait`` returns the local row.  Timing of the most recent exchange: ``issue_ms`` (the ``start`` call),
+    ``exposed_ms`` (the time ``wait`` blocked), ``total_ms`` (``start`` to the end of ``wait``)."""
+
+    def __init__(self, streams_per_rank: int, device=None, group=None):
+        import time
+
+        self._time = time.perf_counter
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.n = int(streams_per_rank)
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        cuda = self.device.type == "cuda"
+        self.host_in = torch.full((self.n,), -1, dtype=torch.int64, pin_memory=cuda)
+        self.inp = torch.full((self.n,), -1, dtype=torch.int64, device=self.device)
+        self.out = torch.full((self.world, self.n), -1, dtype=torch.int64, device=self.device)
+        self.work = None
+        self.issue_ms = self.exposed_ms = self.total_ms = 0.0
+        self._t0 = 0.0
+
+    def start(self, local_lengths: Sequence[int]) -> None:
+        t0 = self._time()
+        k = len(local_lengths)
+        if k > self.n:
+            raise ValueError(f"{k} lengths for {self.n} streams per rank")
+        h = self.host_in.numpy()  # (a view: two numpy stores instead of tensor construction + indexing)
+        h[k:] = -1
+        h[:k] = local_lengths
+        self.inp.copy_(self.host_in, non_blocking=True)
+        if self.active:
+            self.work = dist.all_gather_into_tensor(self.out.view(-1), self.inp, group=self.group, async_op=True)
+        else:
+            self.out[0].copy_(self.inp)
+        self._t0 = t0
+        self.issue_ms = (self._time() - t0) * 1e3
+
+    def wait(self, to_host: bool = True) -> torch.Tensor:
+        """-> int64 [world, streams_per_rank]; ranks with fewer streams are padded with -1.  ``to_host`` (default): a host copy,
+        complete on return; False: the collective's own buffer, ordered after the collective on the current stream (valid until
+        the next ``start``) - for a caller that reads the lengths later, or never on the host"""
+        t0 = self._time()
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if not to_host:
+            g = self.out
+        else:
+            g = self.out.cpu() if self.device.type == "cuda" else self.out.clone()  # (a device tensor: the copy waits for the collective)
+        t1 = self._time()
+        self.exposed_ms = (t1 - t0) * 1e3
+        self.total_ms = (t1 - self._t0) * 1e3
+        return g
 
 
 def container_index(lengths: torch.Tensor, n_units: int, streams_per_unit: int) -> List[Tuple[int, int, int, int]]:

@@ -17,6 +17,12 @@ dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 g = P.all_gather_stream_lengths([11, 22, 33], 4, device=dev)
 assert g.device.type == "cuda" and g.tolist() == [[11, 22, 33, -1]], g
+# the overlapped form bench.py uses: one preallocated all_gather_into_tensor, asynchronous, reused
+ex = P.LengthExchange(4, device=dev)
+for rep in range(3):
+    ex.start([11 + rep, 22, 33])
+    assert ex.work is not None
+    assert ex.wait().tolist() == [[11 + rep, 22, 33, -1]]
 # a real 2-rank-style all_gather call on the GPU (world size 1 still goes through RCCL)
 buf = torch.arange(6, dtype=torch.int64, device=dev)
 out = [torch.empty_like(buf)]

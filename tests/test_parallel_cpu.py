@@ -1,5 +1,6 @@
 """CPU: the N > 1 path (sharding + the one collective) with gloo, world_size 2."""
 import os
+import time
 import socket
 
 import pytest
@@ -26,6 +27,18 @@ def _worker(rank, world, port, n_units, q):
     per_rank = 2 * ((n_units + world - 1) // world)
     g = P.all_gather_stream_lengths(lens, per_rank)
     idx = P.container_index(g, n_units, 2)
+    # the overlapped form bench.py uses: one preallocated all_gather_into_tensor, issued asynchronously, waited for later - twice on
+    # the same buffers, with other work (here: a second collective and a sleep) between start and wait
+    ex = P.LengthExchange(per_rank)
+    for rep in range(2):
+        ex.start([ln + rep for ln in lens])
+        assert ex.work is not None  # in flight: nothing has been waited for
+        dist.barrier()
+        time.sleep(0.01)
+        g2 = ex.wait()
+        assert ex.work is None and g2.tolist() == [[v + rep if v >= 0 else v for v in row] for row in g.tolist()], (rank, rep)
+        assert ex.total_ms >= 10.0 and ex.exposed_ms < ex.total_ms
+    assert P.container_index(g2, n_units, 2) == [(u, s_, o + 2 * u + s_, ln + 1) for (u, s_, o, ln) in idx]
     q.put((rank, mine, g.tolist(), idx))
     dist.barrier()
     dist.destroy_process_group()
@@ -58,6 +71,9 @@ def test_single_process_degenerates():
     assert g.tolist() == [[5, 6, 7, 8]]
     assert P.container_index(g, 2, 2) == [(0, 0, 0, 5), (0, 1, 5, 6), (1, 0, 11, 7), (1, 1, 18, 8)]
     assert P.owner_of(9, 8) == 1
+    ex = P.LengthExchange(4)  # no process group: the local row
+    ex.start([5, 6, 7])
+    assert ex.wait().tolist() == [[5, 6, 7, -1]]
 
 
 # ---- container byte layout (flashgmm_amd/container.py) and its gather across ranks -------------------------------
