@@ -127,6 +127,39 @@ def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: b
     return host, devt, pix
 
 
+def load_latents_dir(path: str, dev, f16: bool, images=None):
+    """--latents-dir: REAL latents instead of the synthetic ones - what it takes to repeat the reference's own measurement
+    (eval_ckbd.py:113-143: real images through a trained checkpoint) when someone supplies both: every `*.pt` file of the directory
+    is one image, a list of its bitstreams in coding order, each a dict {"y": [1, M, h, w], "scales" / "means" / "weights":
+    [1, 4 M, h, w]} (float tensors as the latent codec hands them to GaussianMixtureConditional.compress,
+    latent_codecs/gaussian_mixture_conditional.py:134; INTEGRATION.md shows the three lines that save them), optionally
+    {"pixels": H * W} as a last element.  -> (host arrays per stream, device tensors per stream, pixels per image, streams per image)"""
+    files = sorted(f for f in os.listdir(path) if f.endswith(".pt"))
+    if images:
+        files = files[:images]
+    if not files:
+        raise SystemExit(f"--latents-dir {path}: no *.pt files")
+    host, devt, pix, spi = [], [], None, None
+    for f in files:
+        img = torch.load(os.path.join(path, f), map_location="cpu")
+        streams = [e for e in img if isinstance(e, dict) and "y" in e]
+        meta = [e for e in img if isinstance(e, dict) and "pixels" in e]
+        if spi is None:
+            spi = len(streams)
+        if len(streams) != spi:
+            raise SystemExit(f"{f}: {len(streams)} bitstreams, the first image had {spi}")
+        if meta:
+            pix = int(meta[0]["pixels"])
+        for e in streams:
+            y = e["y"].float().contiguous()
+            prm = [e[k].to(torch.float16 if f16 else torch.float32).contiguous() for k in ("scales", "means", "weights")]
+            if y.dim() != 4 or y.shape[0] != 1 or any(p.shape != (1, 4 * y.shape[1], y.shape[2], y.shape[3]) for p in prm):
+                raise SystemExit(f"{f}: expected y [1, M, h, w] and parameters [1, 4 M, h, w]")
+            host.append((y.numpy(), *(p.numpy() for p in prm)))
+            devt.append([y.to(dev), *(p.to(dev) for p in prm)])
+    return host, devt, pix, spi
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the reference's own coder (or the C restatement) on host cores of this box — test infrastructure, used
 # here only as the reported baseline
@@ -264,7 +297,8 @@ def reference_bytes_of_modes(modes: dict, rank: int, shapes, streams_per_image: 
     return out
 
 
-def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank: int, f16: bool, budget_s: float = 10.0, hip_bytes=None):
+def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank: int, f16: bool, budget_s: float = 10.0, hip_bytes=None,
+                 from_seeds: bool = True):
     """Time the reference's own coder on this box: ONE core on the same images (bounded sample), then every core this
     process may use, one stream at a time per process (the reference is single-threaded and holds the GIL), then its
     USE_SIMD=0 path on a smaller sample.  `hip_bytes`: the HIP path's bitstreams of the same streams - the reference encoder's
@@ -339,6 +373,8 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
                                           "note": "oracle/fgmm_oracle.c (scalar C restatement, what kind=port times) over the reference extension's SIMD path, first image, best of 2"}
         except Exception as e:  # pragma: no cover
             out["port_over_reference"] = {"time_ratio": None, "error": str(e)[:200]}
+    if not from_seeds:  # (real latents: the helper processes of the two legs below regenerate synthetic streams from their seeds)
+        return out
     # all cores: processes, not threads; each regenerates its share of the streams from their seeds
     try:
         import multiprocessing as mp
@@ -395,6 +431,30 @@ def pmc_traffic(workload: str, mode: str, f16: bool, images: int):
         except Exception:
             pass
     return best, src
+
+
+def symtab_valu_roof(workload: str, mode: str, f16: bool, n_coded: int, launch_ms: float):
+    """The encode-side kernel against its OTHER roof, VALU issue: wave-level VALU instructions per coded symbol as the SQ counters
+    give them (recorded: profiles/r*_pmc_valu_symtab.json, scripts/pmc_valu.sh) x coded symbols x the measured average issue cost of
+    this kernel's instruction mix (cycles per wave64 instruction: plain 4.5, packed fp32 5.2, rcp / rsq 9 - scripts/valu_peak.hip)
+    / (1024 SIMDs x 2.4 GHz) / the launch duration measured in THIS run.  -> dict, or None when no count is recorded for the
+    configuration."""
+    best = src = None
+    for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_valu_symtab.json"))):
+        try:
+            d = json.load(open(f))
+            e = d.get(workload)
+            if e and e.get("mode") == mode and e.get("param_dtype") == ("f16" if f16 else "f32"):
+                best, src = (e["valu_wave_insts_per_symbol"], d["cycles_per_wave_instruction"]["average"]), os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+    if best is None or launch_ms <= 0:
+        return None
+    per_sym, cyc = best
+    issue_ms = per_sym * n_coded * cyc / (256 * 4 * 2.4e9) * 1e3
+    return {"valu_frac": round(issue_ms / launch_ms, 4), "valu_issue_ms_at_peak": round(issue_ms, 4), "valu_wave_insts_per_symbol": per_sym,
+            "cycles_per_wave_instruction": cyc, "counts_source": src,
+            "note": "instruction counts recorded (PMC passes of their own), launch time measured in this run"}
 
 
 def _die_with_parent():
@@ -933,13 +993,30 @@ class Leg:
     """One workload resident in HBM and the schedules that are timed over it.  Streams in coding order: image-major,
     stage-minor; stage s of the decode schedule = stream s of every image."""
 
-    def __init__(self, env: Env, workload: str, images: int, mode: str, f16: bool, keep_host_images: int = 1 << 30, share=None):
+    def __init__(self, env: Env, workload: str, images: int, mode: str, f16: bool, keep_host_images: int = 1 << 30, share=None, latents_dir=None,
+                 pixels_per_image=None):
         from flashgmm_amd import GaussianMixtureConditional
 
         self.env, self.workload, self.images, self.mode, self.f16 = env, workload, images, mode, f16
         self.shapes1, _ = workload_shapes(workload)
         self.spi = len(self.shapes1)  # streams per image = stages of the codec's decode schedule
-        if share is None:
+        self.real = False
+        if share is None and latents_dir:
+            self.host, devt, pix, self.spi = load_latents_dir(latents_dir, env.dev, f16, images)
+            self.images = images = len(devt) // self.spi
+            self.pix_per_image = pix or pixels_per_image or workload_shapes(workload)[1]
+            self.shapes1 = [tuple(t[0].shape[1:]) for t in devt[: self.spi]]
+            self.real = True
+        if share is None and self.real:
+            self.n_streams = len(devt)
+            self.hw_of = [t[0].shape[2] * t[0].shape[3] for t in devt]
+            self.shapes = sorted({tuple(t[0].shape) for t in devt})
+            self.stacked = len(self.shapes) == 1
+            if self.stacked:
+                self.ys, self.ss, self.ms, self.ws = (torch.cat([t[k] for t in devt]) for k in range(4))
+            else:
+                self.ys, self.ss, self.ms, self.ws = ([t[k] for t in devt] for k in range(4))
+        elif share is None:
             self.host, devt, self.pix_per_image = make_workload(env.rank, images, env.dev, workload, f16, keep_host_images)
             self.n_streams = len(devt)
             self.hw_of = [t[0].shape[2] * t[0].shape[3] for t in devt]
@@ -950,7 +1027,7 @@ class Leg:
             else:
                 self.ys, self.ss, self.ms, self.ws = ([t[k] for t in devt] for k in range(4))
         else:  # the same tensors under another approximation mode
-            for k in ("host", "pix_per_image", "n_streams", "hw_of", "shapes", "stacked", "ys", "ss", "ms", "ws"):
+            for k in ("host", "pix_per_image", "n_streams", "hw_of", "shapes", "stacked", "ys", "ss", "ms", "ws", "real", "spi", "shapes1", "images"):
                 setattr(self, k, getattr(share, k))
         spi, n = self.spi, self.n_streams
         self.stage_params = [(self.ss[s::spi], self.ms[s::spi], self.ws[s::spi]) for s in range(spi)]  # strided batch views / sub-lists
@@ -1148,6 +1225,11 @@ def main(argv=None):
                          "slow steps explained phase by phase")
     ap.add_argument("--diag-pools", default="", help="step_diag: comma-separated host-worker counts that take turns in blocks of 20 steps (default: the "
                                                      "context's pool and - when that is a different number - as many workers as the quota has CPUs)")
+    ap.add_argument("--latents-dir", default=None,
+                    help="REAL latents instead of synthetic ones: a directory of *.pt files, one per image (see load_latents_dir; the line then "
+                         "says data: real-latents).  The reference's own measurement (eval_ckbd.py:113-143) needs a trained checkpoint and the "
+                         "Kodak PNGs, neither of which exists offline: this is the hook for whoever has them")
+    ap.add_argument("--pixels-per-image", type=int, default=None, help="with --latents-dir, when the files carry no {'pixels': H*W} entry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip upper_bound / latency / per-thread legs (profiling runs)")
     ap.add_argument("--no-sublegs", action="store_true",
@@ -1222,7 +1304,8 @@ def main(argv=None):
     f16 = (a.param_dtype or ("f32" if a.workload == "kodak24" else "f16")) == "f16"
     _lib.ctx(local_rank, a.host_threads)
     _lib.set_profiling(local_rank, True)
-    leg = Leg(env, a.workload, a.images, a.mode, f16)
+    leg = Leg(env, a.workload, a.images, a.mode, f16, latents_dir=a.latents_dir, pixels_per_image=a.pixels_per_image)
+    a.images = leg.images
     spi, n_streams, pix_per_image = leg.spi, leg.n_streams, leg.pix_per_image
     ys, ss, ms, ws = leg.ys, leg.ss, leg.ms, leg.ws
 
@@ -1341,7 +1424,7 @@ def main(argv=None):
             _lib.set_threads(local_rank, threads)
 
     # ---- BASELINE configs[2] and configs[4] in the default line (N = 1): a few steps each, so that the driver's own run witnesses them
-    sublegs = world == 1 and a.workload == "kodak24" and a.mode == "polya" and not f16 and not a.no_sublegs and not a.no_extras
+    sublegs = world == 1 and a.workload == "kodak24" and a.mode == "polya" and not f16 and not a.no_sublegs and not a.no_extras and not leg.real
     if sublegs:
         t_sub = time.perf_counter()
         modes = {}
@@ -1379,7 +1462,8 @@ def main(argv=None):
                                "coded_symbols_per_gpu": nc_e, "approx_mode": "polya"},
                     "value": round(el.mpix(3, dt_e), 2), "unit": "Mpixels/s", "steps": 3, "ms_per_step": round(dt_e / 3 * 1e3, 3), "step_ms": st_e["all"],
                     "symtab": {"launch_ms": round(sym_ms_e, 4), "achieved": round(ach_e, 1), "unit": "GB/s", "frac": round(ach_e / HBM_PEAK_GBS, 4),
-                               "bytes_per_symbol": el.bytes_per_symbol},
+                               "bytes_per_symbol": el.bytes_per_symbol, "loads": "16 B per lane and plane (8 positions per lane)",
+                               "valu": symtab_valu_roof("elic4k", "polya", True, nc_e, sym_ms_e)},
                     "decode_table_bytes_per_latent": round(tb_e / max(1, nc_e), 2),
                     "checkpointed": el.checkpointed("codec", a.checkpoint_stride, 3, sum(len(r[0][0]) for r in res_e))}
             if not a.no_cpu_baseline:  # the reference's own coder on ONE of these images, one pass
@@ -1439,7 +1523,7 @@ def main(argv=None):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",  # the CDF arithmetic; parameter planes: config.param_dtype
-            "data": "synthetic",
+            "data": "real-latents" if leg.real else "synthetic",
             "config": {"workload": a.workload, "schedule": a.schedule,
                        "decode_calls_per_step": spi if a.schedule == "codec" else 1, "images_per_gpu": a.images,
                        "streams_per_gpu": n_streams, "stream_shapes": leg.shapes, "stacked_input": leg.stacked, "K": 4, "approx_mode": a.mode,
@@ -1456,7 +1540,9 @@ def main(argv=None):
                          "traffic_note": "recorded PMC measurement of this workload (file in traffic_source), not collected in this run",
                          "launch_ms": round(sym_ms, 4), "bytes_per_launch": n_coded * leg.bytes_per_symbol,
                          "bytes_per_symbol": leg.bytes_per_symbol,
-                         "frac_of_measured_copy_bandwidth": round(achieved / HBM_COPY_GBS, 4), "measured_copy_bandwidth": HBM_COPY_GBS},
+                         "frac_of_measured_copy_bandwidth": round(achieved / HBM_COPY_GBS, 4), "measured_copy_bandwidth": HBM_COPY_GBS,
+                         # the same launch against the kernel's other roof (VALU issue): it is balanced between the two at fp32 planes
+                         "valu": symtab_valu_roof(a.workload, a.mode, f16, n_coded, sym_ms)},
             # the decode-side table kernel against BOTH of its rooflines: VALU issue and HBM
             "roofline_decode": {"kernel": "tab_kernel (decode-side edge tables, all launches of a step)", "bound": "valu",
                                 "ms_per_step": round(tab_ms, 4), "edges_evaluated": int(n_edges),
@@ -1492,7 +1578,7 @@ def main(argv=None):
             print(f"[bench] THE CGROUP'S CPU CONTROLLER THROTTLED THIS PROCESS DURING THE TIMED REGION ({step_ms.get('cpu_throttled')}): `value` "
                   f"measures the quota, not the path - fewer host workers (--host-threads, FGMM_WORKERS_PER_CPU) or a larger quota", file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(leg.host, leg.shapes1, pix_per_image, spi, rank, f16, hip_bytes=[bytes(r[0][0]) for r in res])
+            cb = cpu_baseline(leg.host, leg.shapes1, pix_per_image, spi, rank, f16, hip_bytes=[bytes(r[0][0]) for r in res], from_seeds=not leg.real)
             if "one_host_thread" in extras and cb.get("value"):
                 cb["per_thread_speedup"] = round(extras["one_host_thread"]["value"] / cb["value"], 1)
             if cb.get("all_cores", {}).get("value"):

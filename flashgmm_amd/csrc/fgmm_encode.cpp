@@ -159,10 +159,15 @@ struct EncodeCall {
   // ---- descriptors, kernels -------------------------------------------------------------------------------------------------------
   int enqueue_kernels() {
     EncDesc *hd = reinterpret_cast<EncDesc *>(ctx->h_ws + o_descs);
-    bool vec4 = true, any_y = false;
+    bool vec4 = true, vec8 = ctx->opt.enc_vec == 0 || ctx->opt.enc_vec == 8, any_y = false;
     for (int i = 0; i < count; ++i) {
       fill_desc(i, hd[i]);
-      vec4 = vec4 && enc_vec4_ok(hd[i], items[i].prm.dtype == FGMM_F16);
+      const EncDesc &d = hd[i];
+      vec4 = vec4 && enc_vec4_ok(d, items[i].prm.dtype == FGMM_F16);
+      // 8 positions per lane for fp16 planes (one 16-byte load per plane: +4-5 % over 8-byte loads on ELIC-4K batches,
+      // profiles/r05_symtab_fp16_vec8_ab.txt): everything 16-byte aligned, rows of 8
+      vec8 = vec8 && items[i].prm.dtype == FGMM_F16 && (d.hw & 7) == 0 && (d.stride_c & 7) == 0 && (d.stride_k & 7) == 0 && aligned16(d.scales) &&
+             aligned16(d.means) && aligned16(d.weights);
       any_y = any_y || items[i].y;
     }
     DEV_TRY(dev::copy_async(ctx->d_ws + o_descs, hd, sizeof(EncDesc) * (size_t)count, dev::kH2D, stream));
@@ -176,7 +181,7 @@ struct EncodeCall {
       if ((rc = ctx->prof_end(2, stream))) return rc;
     }
     if ((rc = ctx->prof_begin(0, stream))) return rc;
-    const int vec = vec4 ? (ctx->opt.enc_vec == 1 ? 1 : ctx->opt.enc_vec == 2 ? 2 : 4) : 1; // option "enc_vec" = 1, 2: A/B narrower loads
+    const int vec = vec4 ? (ctx->opt.enc_vec == 1 ? 1 : ctx->opt.enc_vec == 2 ? 2 : vec8 ? 8 : 4) : 1; // option "enc_vec" = 1, 2, 4: A/B narrower loads
     int64_t n_max = 0;
     bool linear = ctx->opt.enc_linear != 0; // option "enc_linear" = 0: A/B the per-channel grid
     for (auto &it : items) {

@@ -146,7 +146,7 @@ __device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu
 #define FGMM_SYMTAB_WAVES 5 // min waves per SIMD the register allocator must leave room for (<= 96 VGPRs)
 #endif
 template <int MODE, int VEC, bool CLAMPED, typename PT, bool LINEAR>
-__global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const EncDesc *__restrict__ descs) {
+__global__ __launch_bounds__(kBlock, VEC == 8 ? 4 : FGMM_SYMTAB_WAVES) void symtab_kernel(const EncDesc *__restrict__ descs) { // (VEC = 8: 128 VGPRs, else it spills)
   const EncDesc &d = descs[blockIdx.z];
   const int64_t hw = d.hw;
   const int n_nz = d.chan_list ? d.chan_list[d.M] : d.M; // wave-uniform scalar load
@@ -181,6 +181,58 @@ __global__ __launch_bounds__(kBlock, FGMM_SYMTAB_WAVES) void symtab_kernel(const
   uint32_t *const row_out = (seg ? d.packed_seg[seg] : d.packed) + (int64_t)(rank - seg * d.cps) * hw;
   int nbypass = 0;
   if (!active) {
+  } else if constexpr (VEC == 8) {
+    // fp16 planes, 8 positions per lane: every plane read is ONE 16-byte load (the VEC = 4 form reads 8 bytes per lane and plane);
+    // the halves stay packed in registers (48 VGPRs for the twelve planes) and are widened as each position is evaluated.
+    // Measured against VEC = 4 on ELIC-4K batches (profiles/r05_symtab_fp16_vec8_ab.txt): 127.6 / 133.1 against 123.0 / 126.8 G
+    // symbols per second (2 / 4 images) - the kernel is bound by VALU issue (0.86 of the issue roof, bench.py's valu_frac) and
+    // this form issues fewer load and address instructions.  The default for aligned fp16 planes; option "enc_vec" = 4 is the A/B.
+    typedef PT pvec_t __attribute__((ext_vector_type(8)));
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    const int64_t base = (int64_t)c * d.stride_c + p0;
+    float vq[8];
+    int vi[8];
+    if (d.sym) {
+      const i4_t t0 = ldg<i4_t>(d.sym + (int64_t)c * hw + p0), t1 = ldg<i4_t>(d.sym + (int64_t)c * hw + p0 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        vi[e] = e < 4 ? t0[e & 3] : t1[e & 3];
+        vq[e] = (float)vi[e];
+      }
+    } else {
+      const f4_t t0 = ldg<f4_t>(d.y + (int64_t)c * hw + p0), t1 = ldg<f4_t>(d.y + (int64_t)c * hw + p0 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        vq[e] = __builtin_rintf(e < 4 ? t0[e & 3] : t1[e & 3]);
+        vi[e] = (int)vq[e];
+      }
+    }
+    pvec_t rS[4], rM[4], rP[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      rS[k] = ldg<pvec_t>(static_cast<const PT *>(d.scales) + base + k * d.stride_k);
+      rM[k] = ldg<pvec_t>(static_cast<const PT *>(d.means) + base + k * d.stride_k);
+      rP[k] = ldg<pvec_t>(static_cast<const PT *>(d.weights) + base + k * d.stride_k);
+    }
+    u4_t out[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float mu[4], sg[4], pi[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sg[k] = (float)rS[k][e];
+        mu[k] = (float)rM[k][e];
+        pi[k] = (float)rP[k][e];
+      }
+      if (d.logits) softmax4(pi);
+      int bp;
+      out[e >> 2][e & 3] = sym_entry<MODE, CLAMPED>(vq[e], vi[e], mu, sg, pi, bp);
+      nbypass += __popcll(__ballot(bp));
+    }
+    stg<u4_t>(row_out + p0, out[0]);
+    stg<u4_t>(row_out + p0 + 4, out[1]);
   } else if constexpr (VEC > 1) {
     // planar, aligned (checked by the host): one VEC-wide load per plane per lane (16 B fp32 / 8 B fp16 at VEC = 4)
     typedef float fvec_t __attribute__((ext_vector_type(VEC)));
@@ -520,7 +572,10 @@ static int launch_symtab_v(const EncDesc *d, int count, int M_max, int64_t hw_ma
 template <typename PT, bool LINEAR>
 static int launch_symtab_t(const EncDesc *d, int count, int M_max, int64_t hw_max, int64_t n_max, int mode, int vec, bool clamped,
                            hipStream_t s) {
-  if (vec == 4) return clamped ? launch_symtab_v<4, true, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s)
+  if constexpr (sizeof(PT) == 2) // (fp16 planes only: 16-byte loads per plane)
+    if (vec == 8) return clamped ? launch_symtab_v<8, true, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s)
+                                 : launch_symtab_v<8, false, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s);
+  if (vec >= 4) return clamped ? launch_symtab_v<4, true, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s)
                                : launch_symtab_v<4, false, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s);
   if (vec == 2) return clamped ? launch_symtab_v<2, true, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s)
                                : launch_symtab_v<2, false, PT, LINEAR>(d, count, M_max, hw_max, n_max, mode, s);

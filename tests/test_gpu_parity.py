@@ -1398,6 +1398,29 @@ def test_table_kernel_blocks_are_placed_by_a_cursor(oracle):
     assert np.array_equal(np.sort(np.diff(np.append(o, u0))), np.sort(np.diff(np.append(np.sort(bo1.astype(np.int64)) * 4, u1))))  # the same blocks
 
 
+def test_bench_latents_dir_hook(tmp_path):
+    """bench.py --latents-dir: saved (y, scales, means, weights) tensors of real images instead of the synthetic batch - the hook for
+    repeating the reference's own measurement (eval_ckbd.py:113-143) when a checkpoint and images are supplied.  Here: two small
+    "images" of two bitstreams each, the line must say so and its results must have been checked (decode == round(y))."""
+    import subprocess
+    import sys
+
+    for i in range(2):
+        img = []
+        for j in range(2):
+            y, sg, mu, pi = T.make_latent(900 + 10 * i + j, M=48, h=16, w=12)
+            img.append({"y": torch.from_numpy(y), "scales": torch.from_numpy(sg), "means": torch.from_numpy(mu), "weights": torch.from_numpy(pi)})
+        img.append({"pixels": 128 * 192})
+        torch.save(img, tmp_path / f"image_{i:02d}.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--latents-dir", str(tmp_path), "--steps", "2", "--warmup", "1", "--no-extras",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["data"] == "real-latents" and d["config"]["images_per_gpu"] == 2 and d["config"]["streams_per_gpu"] == 4 and d["value"] > 0
+    assert d["config"]["coded_symbols_per_gpu"] > 0 and d["ranks"]["result_checked_ranks"] == 1
+
+
 def test_a_failed_call_leaves_nothing_in_flight(ctx_options):
     """A bitstream that fails early (truncated input) finishes its item while the copies of its LATER table pieces are still queued;
     the call must not return before they have drained - the next call hands the same staging area to its kernels and the same pinned
