@@ -1265,11 +1265,11 @@ def main(argv=None):
     dist = None
     backend = None
     pg_note = None
-    if world > 1 or "WORLD_SIZE" in os.environ or os.environ.get("FGMM_BENCH_PG", "0") != "0":
-        # N = 1 goes through the same collective when a process group exists - a launcher started this rank (WORLD_SIZE=1), or
-        # FGMM_BENCH_PG=1 asks for one: a group of one rank over RCCL (`ranks.rccl_ranks` 1).  The plain `python bench.py` of a
-        # one-GPU run makes none: at N = 1 the exchange is pure overhead (measured: 0.3 ms of c10d / Python per step + RCCL's
-        # threads beside the host workers: step median 9.34 -> 10.03 ms, profiles/r05_n1_process_group.txt)
+    if world > 1 or os.environ.get("FGMM_BENCH_PG", "1") != "0":
+        # N = 1 goes through the same collective: a process group of one rank over RCCL (`ranks.rccl_ranks` 1), so that the line of a
+        # one-GPU run has made, on hardware, the exchange it will make at N > 1.  What it costs the step: 0.08 ms to issue + 0.02 ms
+        # exposed (profiles/r05_n1_process_group.txt; the first build, which copied the lengths to the host on every step, cost
+        # 0.7 ms).  FGMM_BENCH_PG=0 runs without a process group; if RCCL cannot be initialised the run goes on without (and says so).
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

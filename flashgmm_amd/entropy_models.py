@@ -85,6 +85,14 @@ class CompressedBatch(Sequence):
             return [self[j] for j in range(*i.indices(len(self.strings)))]
         return (self.strings[i], self.abs_maxes[i], self.zero_bitmaps[i]), self.y_q[i]
 
+    # list semantics where they are cheap (callers written against the list a sequence-input call returns): concatenation
+    # gives a plain list of the per-item tuples
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
 
 def _take_ckpts_many(device: int, ptrs, counts):
     """the library-allocated fgmm_ckpt arrays of a batch -> [(ndarray view, its address)], the arrays released: ONE array for the

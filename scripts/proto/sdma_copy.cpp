@@ -26,6 +26,24 @@ __global__ void busy_kernel(float *out, int iters) { // VALU-bound, every CU: wh
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// waits for an engine copy's signal: BOUNDED (two seconds), and a negative value - how HSA reports a failed copy - is a failure, not
+// "landed" (round 4's library code waited with UINT64_MAX and took any value < 1 for success: ADVICE r04)
+static bool wait_done(hsa_signal_t sg) {
+  const double t_end = now_ms() + 2000.0;
+  for (;;) {
+    const hsa_signal_value_t v = hsa_signal_wait_scacquire(sg, HSA_SIGNAL_CONDITION_LT, 1, 100000000ull /* 0.1 s of the signal's clock at most */, HSA_WAIT_STATE_BLOCKED);
+    if (v == 0) return true;
+    if (v < 0) {
+      fprintf(stderr, "engine copy failed (signal %lld)\n", (long long)v);
+      return false;
+    }
+    if (now_ms() > t_end) {
+      fprintf(stderr, "engine copy did not complete within 2 s\n");
+      return false;
+    }
+  }
+}
+
 int main(int argc, char **argv) {
   const size_t MB = (argc > 1 ? atoi(argv[1]) : 24) * (size_t)1 << 20; // one copy (a decode call's pieces are 4 - 40 MB)
   const int reps = argc > 2 ? atoi(argv[2]) : 16;
@@ -88,11 +106,12 @@ int main(int argc, char **argv) {
     for (auto &sg : sigs) HSACHK(hsa_signal_create(1, 0, nullptr, &sg));
     const double t0 = now_ms();
     for (int r = 0; r < reps; ++r) {
-      if (r >= in_flight) while (hsa_signal_wait_scacquire(sigs[(size_t)(r - in_flight)], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+      if (r >= in_flight && !wait_done(sigs[(size_t)(r - in_flight)])) exit(2);
       if (engine) HSACHK(hsa_amd_memory_async_copy_on_engine(h + r * MB, cpu, d + r * MB, gpu, MB, 0, nullptr, sigs[(size_t)r], (hsa_amd_sdma_engine_id_t)engine, false));
       else HSACHK(hsa_amd_memory_async_copy(h + r * MB, cpu, d + r * MB, gpu, MB, 0, nullptr, sigs[(size_t)r]));
     }
-    for (int r = 0; r < reps; ++r) while (hsa_signal_wait_scacquire(sigs[(size_t)r], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+    for (int r = 0; r < reps; ++r)
+      if (!wait_done(sigs[(size_t)r])) exit(2);
     const double dt = now_ms() - t0;
     for (auto &sg : sigs) hsa_signal_destroy(sg);
     return dt;
@@ -141,7 +160,8 @@ int main(int argc, char **argv) {
         const double t0 = now_ms();
         for (int r = 0; r < reps; ++r)
           HSACHK(hsa_amd_memory_async_copy_on_engine(h + r * MB, cpu, d + r * MB, gpu, MB, 0, nullptr, sigs[(size_t)r], (hsa_amd_sdma_engine_id_t)(r & 1 ? e2 : e1), false));
-        for (int r = 0; r < reps; ++r) while (hsa_signal_wait_scacquire(sigs[(size_t)r], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+        for (int r = 0; r < reps; ++r)
+      if (!wait_done(sigs[(size_t)r])) exit(2);
         const double dt = now_ms() - t0;
         for (auto &sg : sigs) hsa_signal_destroy(sg);
         return dt;
@@ -153,6 +173,7 @@ int main(int argc, char **argv) {
     }
   }
   hsa_signal_destroy(sig);
-  hsa_shut_down();
+  // (no hsa_shut_down(): HIP sits on the same runtime and hsa_init() above only took a reference - tearing the runtime down under
+  // HIP, or under a profiler's tool library, is what hung this prototype under rocprofv3 in round 4; the process's exit releases it)
   return 0;
 }
