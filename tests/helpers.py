@@ -206,5 +206,7 @@ def host_decode_tab(lib, enc: bytes, hdr: np.ndarray, pool: np.ndarray, max_bs: 
 def expected_threads(budget: dict, ranks: int = 1) -> int:
     """fgmm_host_thread_budget, restated: the share's CPUs; x3 (up to the share of the affinity mask) when a cgroup quota is the limit"""
     by_time, by_mask = int(budget["cpus"] / ranks + 1e-9), int(budget["affinity"] / ranks + 1e-9)
-    t = min(by_mask, 3 * by_time) if budget.get("quota") and by_mask > by_time else by_time
+    import os
+    per_cpu = min(max(int(os.environ.get("FGMM_WORKERS_PER_CPU", "3")), 1), 4)
+    t = min(by_mask, per_cpu * by_time) if budget.get("quota") and by_mask > by_time else by_time
     return max(1, min(t, 48))

@@ -1365,9 +1365,6 @@ def test_bench_two_ranks_rehearsed_on_one_device():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    out_dir = os.path.join(root, "gpurun_out")
-    if os.path.isdir(out_dir):
-        open(os.path.join(out_dir, "n2_one_device.json"), "w").write(lines[0] + "\n")
     assert d["n_gpus"] == 2 and d["config"]["one_device_rehearsal"] is True and d["config"]["images_per_gpu"] == 4
     rk = d["ranks"]
     assert rk["backend"] == "gloo" and rk["rccl_ranks"] == 0 and len(rk["ms_per_step"]) == 2 and rk["result_checked_ranks"] == 2

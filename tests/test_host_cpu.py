@@ -537,6 +537,13 @@ def test_host_budget_reads_the_cgroup_v2_quota_of_the_group_and_its_ancestors(tm
         _tree(tmp_path, {"/sys/fs/cgroup/pod/cpu.max": "200000 100000\n"})
         b2, t2 = _budget_in_child(tmp_path)
         assert b2["quota"] == 2.0 and t2 == min(n_aff, 6)
+        # FGMM_WORKERS_PER_CPU: the multiplier (1..4; default 3) - a host where the cgroup's other processes need part of the quota
+        for per_cpu, want in (("1", 2), ("2", min(n_aff, 4)), ("9", min(n_aff, 8))):
+            os.environ["FGMM_WORKERS_PER_CPU"] = per_cpu
+            try:
+                assert _budget_in_child(tmp_path)[1] == want, per_cpu
+            finally:
+                del os.environ["FGMM_WORKERS_PER_CPU"]
 
 
 def test_host_budget_reads_a_cgroup_v1_quota_and_the_affinity_mask(tmp_path):
