@@ -1105,7 +1105,8 @@ class Leg:
         own stream synchronisation (decompress returns with y_hat complete): they add nothing to the region.
         (main() keeps the interpreter's generational GC off for the whole run: a pass takes tens of ms with torch loaded and
         is not part of the path.)"""
-        dist = self.env.dist
+        dist = self.env.dist if self.env.world > 1 else None  # (a barrier over one rank orders nothing - and an RCCL barrier right before
+        #                                                       the timed steps idles the GPU long enough to cost the first two of them 1-3 ms)
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
