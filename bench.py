@@ -886,9 +886,18 @@ def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
             row["host_pgfault"] = st[i].get("host:vmstat.pgfault")
             row["threads_that_waited_[name,run_delay_ms,exec_ms]"] = [[e["comm"].get(t, t), round(rd, 2), round(ex, 2)] for t, rd, ex in st[i].get("_threads", []) if rd > 0.2]
             rows.append(row)
-        wn = [watched(i) for i in normal]
-        wn = [w for w in wn if w]
+        wn = [w for w in map(watched, normal) if w]
+        thr_total = sum(int(d.get(k, 0)) for d in st for k in d if k.endswith(".nr_throttled"))
+        rd_slow = float(np.median([st[i]["threads.run_delay_ms"] for i in slow])) if slow else None
+        ws = [w for w in map(watched, slow) if w]
+        finding = (f"{len(slow)} of {n} steps slower than 1.3x the median ({med:.2f} ms)" +
+                   (f": in those the process's threads stood runnable-but-not-running for {rd_slow:.1f} ms per step "
+                    f"({norm.get('threads.run_delay_ms', 0.0):.2f} in a normal step)" if slow else "") +
+                   (f" while the HOST's runnable tasks peaked at {np.median([w[0] for w in ws]):.0f} "
+                    f"({np.median([w[0] for w in wn]):.0f} in a normal step)" if ws and wn else "") +
+                   f"; the cgroup's CPU controller throttled the process {thr_total} times (every visible level summed)")
         out[str(cfg)] = {
+            "finding": finding,
             "host_threads": int(str(cfg).split("+")[0]), "options": str(cfg).split("+")[1:], "steps": n, "median_ms": round(med, 3), "p90_ms": round(float(np.percentile(ms, 90)), 3),
             "max_ms": round(float(ms.max()), 3), "mean_ms": round(float(ms.mean()), 3), "p90_over_median": round(float(np.percentile(ms, 90)) / med, 3),
             "slow_steps": len(slow), "all_ms": [round(float(v), 2) for v in ms],

@@ -456,6 +456,11 @@ struct EncodeCall {
       tr.mark(segmented ? "jobs out" : "all tables landed, jobs out");
       marks[2] = tr.ms();
     }
+    // Segmented tables: an encoder waits only for the segments it enters - a bitstream without a coded symbol enters none - so the last
+    // copy group may still be in flight here, and the next call writes the pinned workspace it lands in (found on the fake device under
+    // AddressSanitizer, round 5: descriptors of the following decode call overwritten by a stale table copy).  Copies complete in the
+    // order they were queued: the last group's event covers them all; normally it has long fired.
+    if (segmented && n_groups > 0) DEV_TRY(dev::event_sync(ctx->sleep_events[(size_t)n_groups - 1]));
     tr.mark("host rANS done");
     double busy = 0, wait = 0;
     for (auto &it : items) {

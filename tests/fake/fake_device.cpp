@@ -13,6 +13,7 @@
 //             and the table format of fgmm_internal.h; float32 planes only, no fused softmax (the stress does not use them)
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -390,6 +391,9 @@ std::mutex g_cursor_mu; // the launch's cursor is ONE atomic on the device; here
 void k_tab(const DecDesc *descs, int count, int mode, bool clamped, uint64_t shuffle) {
   for (int q = 0; q < count; ++q) {
     const DecDesc &d = descs[q];
+    if (getenv("FGMM_FAKE_VERBOSE"))
+      fprintf(stderr, "   [k_tab] part %d/%d: n %lld hw %lld n_ch %d tl %d blocks [%d, %d) max_bs %d hdr_form %d stride k %lld c %lld p %lld\n", q, count, (long long)d.n,
+              (long long)d.hw, d.n_ch, d.tl, d.blk_begin, d.blk_end, d.max_bs, d.hdr_form, (long long)d.stride_k, (long long)d.stride_c, (long long)d.stride_p);
     std::vector<int32_t> order;
     for (int32_t b = d.blk_begin; b < d.blk_end; ++b) order.push_back(b);
     for (size_t k = order.size(); k > 1; --k) {

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -69,6 +70,46 @@ static void make_item(Item &it, int M, int64_t hw, double zero_frac) {
   }
 }
 
+// one coded channel of an item through the raw (n, 4) boundary, host memory, the reference's view strides (1, n)
+static void raw_boundary(fgmm_ctx *ctx, const Item &it, int mode) {
+  const int64_t n = it.hw;
+  const size_t n_all = (size_t)it.M * it.hw;
+  const int c = (int)(rnd() % (uint64_t)it.M);
+  std::vector<int32_t> sym((size_t)n);
+  std::vector<float> s(4 * (size_t)n), m(4 * (size_t)n), w(4 * (size_t)n); // [k * n + i]: stride_n 1, stride_k n
+  int32_t amax = 0;
+  for (int64_t p = 0; p < n; ++p) {
+    sym[(size_t)p] = (int32_t)nearbyintf(it.y[(size_t)c * it.hw + p]);
+    amax = std::max(amax, std::abs(sym[(size_t)p]));
+    for (int k = 0; k < 4; ++k) {
+      s[(size_t)k * n + p] = fminf(fmaxf(it.sg[(size_t)k * n_all + (size_t)c * it.hw + p], 0.11f), 256.0f);
+      m[(size_t)k * n + p] = it.mu[(size_t)k * n_all + (size_t)c * it.hw + p];
+      w[(size_t)k * n + p] = it.pi[(size_t)k * n_all + (size_t)c * it.hw + p];
+    }
+  }
+  uint8_t *want = nullptr, *got = nullptr;
+  size_t want_len = 0, got_len = 0;
+  CHECK(fgo_encode_gmm(mode, n, sym.data(), s.data(), m.data(), w.data(), 1, n, &want, &want_len, nullptr) == 0, "oracle");
+  CHECK(fgmm_encode_with_indexes_gmm(ctx, sym.data(), s.data(), m.data(), w.data(), n, 1, n, 4, mode, FGMM_HOST, amax + 1, &got, &got_len) == FGMM_OK, "encode_with_indexes_gmm");
+  CHECK(got_len == want_len && !memcmp(got, want, want_len), "raw boundary: bytes differ from the oracle's (%zu / %zu)", got_len, want_len);
+  std::vector<int32_t> dec((size_t)n, 12345);
+  CHECK(fgmm_decode_with_indexes_gmm(ctx, got, got_len, s.data(), m.data(), w.data(), n, 1, n, 4, mode, FGMM_HOST, amax + 1, dec.data()) == FGMM_OK, "decode_with_indexes_gmm");
+  CHECK(dec == sym, "raw boundary: decoded symbols differ");
+  fgmm_free(got);
+  // BufferedRansEncoder: the channel in two appends, one flush
+  fgmm_symbuf *b = nullptr;
+  CHECK(fgmm_symbuf_create(&b) == FGMM_OK, "symbuf");
+  const int64_t cut = n / 3;
+  // (an append takes a contiguous run of rows: with stride (1, n) the second part starts `cut` elements into every plane)
+  CHECK(fgmm_symbuf_append_gmm(ctx, b, sym.data(), s.data(), m.data(), w.data(), cut, 1, n, 4, mode, FGMM_HOST) == FGMM_OK, "symbuf append 1");
+  CHECK(fgmm_symbuf_append_gmm(ctx, b, sym.data() + cut, s.data() + cut, m.data() + cut, w.data() + cut, n - cut, 1, n, 4, mode, FGMM_HOST) == FGMM_OK, "symbuf append 2");
+  CHECK(fgmm_symbuf_flush(b, &got, &got_len) == FGMM_OK, "symbuf flush");
+  CHECK(got_len == want_len && !memcmp(got, want, want_len), "buffered encoder: bytes differ from the oracle's");
+  fgmm_free(got);
+  fgmm_symbuf_destroy(b);
+  fgo_free(want);
+}
+
 static void set_opt(fgmm_ctx *ctx, const char *name, int64_t v) { CHECK(fgmm_ctx_set_option(ctx, name, v) == FGMM_OK, "option %s=%lld", name, (long long)v); }
 
 int main(int argc, char **argv) {
@@ -113,6 +154,16 @@ int main(int argc, char **argv) {
       f.zero_bitmap = it.zb.data();
       f.ckpt_stride = stride;
     }
+    if (getenv("FGMM_STRESS_VERBOSE")) {
+      fprintf(stderr, "[round %ld] threads %d mode %d stride %d count %d:", rounds, fgmm_ctx_threads(ctx), mode, stride, count);
+      for (int i = 0; i < count; ++i) fprintf(stderr, " %dx%lld", its[(size_t)i].M, (long long)its[(size_t)i].hw);
+      for (const char *nm : {"pieces", "dec_first", "ef_rows", "ef_min", "enc_ways", "enc_segs", "scatter_rounds", "ckpt_decode", "gpu_decode", "stage_max_mb", "tab_cap_e", "spin_lat"}) {
+        int64_t v = 0;
+        fgmm_ctx_get_option(ctx, nm, &v);
+        fprintf(stderr, " %s=%lld", nm, (long long)v);
+      }
+      fprintf(stderr, "\n");
+    }
     CHECK(fgmm_gmc_compress_batch(ctx, nullptr, fi.data(), count, mode, clamp) == FGMM_OK, "compress_batch (count %d)", count);
     // ---- every bitstream against the oracle's encoder
     for (int i = 0; i < count; ++i) {
@@ -153,6 +204,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < count; ++i) CHECK(its[(size_t)i].yhat == its[(size_t)i].yq, "y_hat != y_q, item %d of %d", i, count);
     // ---- a truncated bitstream must be refused (and must not take the call down with it)
     if (rnd() % 3 == 0) {
+      if (getenv("FGMM_STRESS_VERBOSE")) fprintf(stderr, "   truncated victim\n");
       int victim = -1;
       for (int i = 0; i < count; ++i)
         if (fi[(size_t)i].bytes_len > 64) victim = i;
@@ -164,6 +216,33 @@ int main(int argc, char **argv) {
         fi[(size_t)victim] = keep;
         ++refused;
       }
+    }
+    // ---- the reference's native boundary on one of the items' channels: (n, 4) rows in HOST memory, strided as the reference's views
+    // (stride (1, n)), staged through the device by the library: RansEncoder / RansDecoder.*_with_indexes_gmm, and the buffered
+    // form (BufferedRansEncoder: two appends, one flush == the concatenation's stream)
+    if (getenv("FGMM_STRESS_VERBOSE")) fprintf(stderr, "   batch ok\n");
+    if (rnd() % 2 == 0) raw_boundary(ctx, its[(size_t)(rnd() % (uint64_t)count)], mode);
+    // ---- buffers handed over in one native call (a binding that wants to own the bytes), the call log, trimming the context
+    if (rnd() % 4 == 0) {
+      std::vector<std::vector<uint8_t>> own((size_t)count);
+      std::vector<void *> dst((size_t)count), src((size_t)count);
+      std::vector<size_t> len((size_t)count);
+      for (int i = 0; i < count; ++i) {
+        own[(size_t)i].resize(fi[(size_t)i].bytes_len + 1);
+        dst[(size_t)i] = own[(size_t)i].data(), src[(size_t)i] = fi[(size_t)i].bytes, len[(size_t)i] = fi[(size_t)i].bytes_len;
+      }
+      std::vector<std::vector<uint8_t>> want((size_t)count);
+      for (int i = 0; i < count; ++i) want[(size_t)i].assign(fi[(size_t)i].bytes, fi[(size_t)i].bytes + fi[(size_t)i].bytes_len);
+      CHECK(fgmm_ctx_take_buffers(ctx, dst.data(), src.data(), len.data(), count) == FGMM_OK, "take_buffers");
+      for (int i = 0; i < count; ++i) {
+        CHECK(!memcmp(own[(size_t)i].data(), want[(size_t)i].data(), want[(size_t)i].size()), "take_buffers item %d", i);
+        fi[(size_t)i].bytes = nullptr; // (released by the library)
+      }
+      fgmm_call_marks log[8];
+      int n_log = 0;
+      CHECK(fgmm_ctx_call_log(ctx, log, 8, &n_log) == FGMM_OK && n_log >= 2, "call log");
+      for (int k = 0; k < n_log; ++k) CHECK(log[k].count >= 1 && log[k].ms[5] >= log[k].ms[0] && log[k].ms[0] >= 0, "call log entry %d", k);
+      if (rnd() % 2) CHECK(fgmm_ctx_trim(ctx) == FGMM_OK, "trim");
     }
     for (auto &f : fi) fgmm_free(f.bytes), fgmm_free(f.ckpt);
     ++rounds;

@@ -1439,6 +1439,26 @@ def test_a_failed_call_leaves_nothing_in_flight(ctx_options):
     assert torch.equal(gmc.decompress(b, abs_max, zb, *t[1:]), yq)
 
 
+def test_an_encode_call_drains_its_segment_copies(ctx_options):
+    """Segmented encode tables (tails first): an encoder waits only for the segments it enters, and a bitstream without a coded symbol
+    enters none - the call must still not return before its last table copy has landed, or that copy writes into the pinned workspace
+    the NEXT call is filling (found under AddressSanitizer on the fake device, round 5: the descriptors of a following decode call
+    overwritten).  Here: segmentation forced (enc_segs 2) on batches whose items are all dead, each straight into a decode call."""
+    ctx_options(enc_segs=2, pieces=10)
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    dead = [[dv(a) for a in T.make_latent(7300 + i, M=M, h=h, w=w, zero_frac=1.0)] for i, (M, h, w) in enumerate([(9, 16, 24), (17, 1, 1), (24, 8, 8)])]
+    live = [[dv(a) for a in T.make_latent(7310 + i, M=48, h=16, w=12)] for i in range(4)]
+    res_live = gmc.compress_batch(*[[o[k] for o in live] for k in range(4)])
+    good = ([r[0][0] for r in res_live], [r[0][1] for r in res_live], [r[0][2] for r in res_live], *[[o[k] for o in live] for k in (1, 2, 3)])
+    for rep in range(10):
+        res = gmc.compress_batch(*[[o[k] for o in dead] for k in range(4)])
+        assert all(bytes(r[0][0]) == bytes.fromhex("0000008000000000") and int(r[0][2].sum()) == 0 for r in res), rep
+        out = gmc.decompress_batch(*good)
+        assert all(torch.equal(o, r[1]) for o, r in zip(out, res_live)), rep
+        out = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], *[[o[k] for o in dead] for k in (1, 2, 3)])
+        assert all(torch.equal(o, r[1]) and not o.any() for o, r in zip(out, res)), rep
+
+
 def test_scheduling_options_change_no_byte(oracle, ctx_options):
     """How a call's tables cross PCIe is a matter of scheduling only: encode tables whole (enc_segs 0) or in four segments per bitstream,
     tails first (1, the default: the encoders follow the landing); symbols back to the GPU round by round or bitstream by bitstream.
