@@ -445,6 +445,7 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
       return fail(FGMM_ERR_INVALID, "item %d: parameter dtype must be FGMM_F32 or FGMM_F16 and the same for a whole batch", i);
     if (s.params.flags & ~FGMM_PARAMS_LOGITS) return fail(FGMM_ERR_INVALID, "item %d: unknown fgmm_params.flags %d", i, s.params.flags);
     EncItem &e = v[i];
+    e.latent = true;
     e.y = s.y;
     e.prm = s.params;
     e.M = s.M;
@@ -498,8 +499,8 @@ int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int
   for (int i = 0; i < count; ++i) {
     const fgmm_item &s = items[i];
     if (s.K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", s.K);
-    if (s.M < 0 || s.hw < 0 || !s.bytes || !s.zero_bitmap || !s.yq_out ||
-        (s.M * s.hw && (!s.params.scales || !s.params.means || !s.params.weights)))
+    if (s.M < 0 || s.hw < 0 || !s.bytes || (s.M && !s.zero_bitmap) ||
+        (s.M * s.hw && (!s.yq_out || !s.params.scales || !s.params.means || !s.params.weights)))
       return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
     if (s.params.dtype != items[0].params.dtype || (s.params.dtype != FGMM_F32 && s.params.dtype != FGMM_F16))
       return fail(FGMM_ERR_INVALID, "item %d: parameter dtype must be FGMM_F32 or FGMM_F16 and the same for a whole batch", i);

@@ -225,6 +225,7 @@ namespace fgmm {
 // ---- one bitstream of a batched encode --------------------------------------------------------------------------------------
 struct EncItem {
   // inputs
+  bool latent = false;               // latent-codec layout (y [M, hw], per-channel statistics, channel compaction) - also when M * hw == 0 and y is null
   const float *y = nullptr;          // device
   const int32_t *sym_dev = nullptr;  // device (raw boundary)
   const int32_t *sym_host = nullptr; // host copy of the raw symbols when the caller has one

@@ -98,7 +98,7 @@ struct EncodeCall {
     size_t tables = 0;
     for (auto &it : items) {
       tables += table_bytes(it);
-      segmented = segmented && it.y && !it.symbuf && it.M >= 2 * kEncSegs;
+      segmented = segmented && it.latent && !it.symbuf && it.M >= 2 * kEncSegs && it.hw > 0;
     }
     segmented = segmented && (tables >= ((size_t)4 << 20) || ctx->opt.enc_segs == 2); // (smaller calls: the transfer is not what they wait for; 2: tests)
     if (!segmented) {
@@ -141,8 +141,8 @@ struct EncodeCall {
     d.yq = it.yq;
     d.chan_min = reinterpret_cast<float *>(ctx->d_ws + it.o_min);
     d.chan_max = reinterpret_cast<float *>(ctx->d_ws + it.o_max);
-    d.chan_nz = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_nz) : nullptr;
-    d.chan_list = it.y ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_list) : nullptr;
+    d.chan_nz = it.latent ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_nz) : nullptr;
+    d.chan_list = it.latent ? reinterpret_cast<int32_t *>(ctx->d_ws + it.o_list) : nullptr;
     d.packed = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_packed);
     d.seg_b[0] = d.seg_b[1] = d.seg_b[2] = INT32_MAX;
     d.packed_seg[0] = d.packed;
@@ -168,7 +168,7 @@ struct EncodeCall {
       // profiles/r05_symtab_fp16_vec8_ab.txt): everything 16-byte aligned, rows of 8
       vec8 = vec8 && items[i].prm.dtype == FGMM_F16 && (d.hw & 7) == 0 && (d.stride_c & 7) == 0 && (d.stride_k & 7) == 0 && aligned16(d.scales) &&
              aligned16(d.means) && aligned16(d.weights);
-      any_y = any_y || items[i].y;
+      any_y = any_y || items[i].latent;
     }
     DEV_TRY(dev::copy_async(ctx->d_ws + o_descs, hd, sizeof(EncDesc) * (size_t)count, dev::kH2D, stream));
     DEV_TRY(dev::memset_async(ctx->d_ws + o_small, 0, small_bytes, stream));
@@ -255,7 +255,7 @@ struct EncodeCall {
     unsigned long long n_bypass = 0;
     for (size_t k = 0; k < it.meta_count; ++k) n_bypass += reinterpret_cast<const uint32_t *>(ctx->h_ws + it.o_meta)[k];
     const int32_t *syms_for_bypass = it.sym_host;
-    if (it.y) {
+    if (it.latent) {
       const float *mn = reinterpret_cast<const float *>(ctx->h_ws + it.o_min);
       const float *mx = reinterpret_cast<const float *>(ctx->h_ws + it.o_max);
       const int32_t *nz = reinterpret_cast<const int32_t *>(ctx->h_ws + it.o_nz);

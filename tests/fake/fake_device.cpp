@@ -254,7 +254,7 @@ struct Rows {
 void k_quant_stats(const EncDesc *descs, int count) {
   for (int i = 0; i < count; ++i) {
     const EncDesc &d = descs[i];
-    if (!d.y) continue;
+    if (!d.chan_nz) continue; // (a raw-boundary item; a latent-layout item with M * hw == 0 may have a null y)
     int n_nz = 0;
     for (int c = 0; c < d.M; ++c) {
       float mn = INFINITY, mx = -INFINITY;

@@ -142,7 +142,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < count; ++i) {
       static const int Ms[] = {1, 3, 8, 9, 17, 24};
       static const int64_t HWs[] = {1, 7, 64, 96, 192, 384};
-      make_item(its[(size_t)i], Ms[rnd() % 6], HWs[rnd() % 6], rnd() % 5 == 0 ? 1.0 : 0.15);
+      make_item(its[(size_t)i], Ms[rnd() % 6], rnd() % 40 == 0 ? 0 : HWs[rnd() % 6], rnd() % 5 == 0 ? 1.0 : 0.15); // (now and then an EMPTY item: hw = 0)
       Item &it = its[(size_t)i];
       fgmm_item &f = fi[(size_t)i];
       memset(&f, 0, sizeof f);
@@ -221,7 +221,10 @@ int main(int argc, char **argv) {
     // (stride (1, n)), staged through the device by the library: RansEncoder / RansDecoder.*_with_indexes_gmm, and the buffered
     // form (BufferedRansEncoder: two appends, one flush == the concatenation's stream)
     if (getenv("FGMM_STRESS_VERBOSE")) fprintf(stderr, "   batch ok\n");
-    if (rnd() % 2 == 0) raw_boundary(ctx, its[(size_t)(rnd() % (uint64_t)count)], mode);
+    if (rnd() % 2 == 0) {
+      const Item &pick_ = its[(size_t)(rnd() % (uint64_t)count)];
+      if (pick_.hw > 0) raw_boundary(ctx, pick_, mode);
+    }
     // ---- buffers handed over in one native call (a binding that wants to own the bytes), the call log, trimming the context
     if (rnd() % 4 == 0) {
       std::vector<std::vector<uint8_t>> own((size_t)count);

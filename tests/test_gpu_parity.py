@@ -548,6 +548,28 @@ def test_batch_of_ragged_empty_and_tiny_items(oracle, ctx_options, pieces):
         assert outs[i].shape == ys[i].shape and torch.equal(outs[i], res[i][1]), specs[i]
 
 
+def test_items_without_positions_in_a_batch(oracle, ctx_options):
+    """An item with h * w == 0 (tensors without elements: null device pointers) beside ordinary ones - outside what the reference
+    can be handed (`y.max()` of an empty tensor raises, entropy_models.py:834) but inside what a C caller can pass: the empty stream,
+    an all-zero bitmap, abs_max 1; the neighbours untouched; also with the segmented table layout asked for (found on the fake
+    device, round 5: such an item had no statistics arrays and the segmented encoder refused a zero-length segment)."""
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    lat = [T.make_latent(7400 + i, M=24, h=8, w=12, zero_frac=0.1) for i in range(3)]
+    ys, ss, ms, ws = ([dv(l[k]) for l in lat] for k in range(4))
+    for k, t in enumerate((ys, ss, ms, ws)):
+        t.insert(1, torch.zeros((1, 6 if k == 0 else 24, 0, 12), dtype=torch.float32, device=DEV))
+    for segs in (1, 2):
+        ctx_options(enc_segs=segs)
+        res = gmc.compress_batch(ys, ss, ms, ws)
+        (b, abs_max, zb), yq = res[1]
+        assert bytes(b) == bytes.fromhex("0000008000000000") and abs_max == 1 and zb.tolist() == [0] * 6 and tuple(yq.shape) == (1, 6, 0, 12)
+        for i, l in zip((0, 2, 3), lat):
+            sym, s_, m_, w_, am, zbm, yqn = T.to_coder_inputs(*l)
+            assert res[i][0][0] == oracle.encode_gmm("polya", sym, s_, m_, w_) and res[i][0][1] == am, (segs, i)
+        outs = gmc.decompress_batch([r[0][0] for r in res], [r[0][1] for r in res], [r[0][2] for r in res], ss, ms, ws)
+        assert tuple(outs[1].shape) == (1, 6, 0, 12) and all(torch.equal(outs[i], res[i][1]) for i in (0, 2, 3)), segs
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_stacked_batch_equals_item_lists(dtype):
     """Items of one shape given as ONE tensor each ([N, M, h, w] / [N, K*M, h, w], batch-strided views included)
