@@ -144,6 +144,10 @@ int main(int argc, char **argv) {
       static const int64_t HWs[] = {1, 7, 64, 96, 192, 384};
       make_item(its[(size_t)i], Ms[rnd() % 6], rnd() % 40 == 0 ? 0 : HWs[rnd() % 6], rnd() % 5 == 0 ? 1.0 : 0.15); // (now and then an EMPTY item: hw = 0)
       Item &it = its[(size_t)i];
+      // now and then an OUTLIER in a small item: a symbol far outside every component (bypass-coded, beyond int16: the wide symbol
+      // paths), a half-width that needs 4- or 8-byte headers and the generic two-pass kernels
+      if (it.hw > 0 && (size_t)it.M * it.hw <= 200 && rnd() % 6 == 0)
+        it.y[rnd() % it.y.size()] = (float)((rnd() % 2 ? 1.0 : -1.0) * (double)pick(300, rnd() % 3 ? 3000 : 70000));
       fgmm_item &f = fi[(size_t)i];
       memset(&f, 0, sizeof f);
       f.y = it.y.data();
