@@ -5,7 +5,8 @@
 // under random pipeline options (pieces, first launch, Elias-Fano threshold, encoder ways, whole / segmented encode
 // tables, scatter rounds, checkpointed streams decoded in host segments / handed to the "GPU" and partly handed back, a tiny staging
 // budget that forces overflow re-runs, an LDS budget that sends items to the generic kernels) and random worker counts; now and then a
-// truncated bitstream, which must be refused.   stress_main [seconds] [seed]
+// truncated bitstream, which must be refused, and a corrupted one, which must decode to what the oracle's decoder makes of it.
+//   stress_main [seconds] [seed]
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -20,6 +21,8 @@
 
 extern "C" int fgo_encode_gmm(int mode, int64_t n, const int32_t *symbols, const float *scales, const float *means, const float *weights, int64_t sn, int64_t sk,
                               uint8_t **out, size_t *out_len, int64_t *n_bypass_out);
+extern "C" int fgo_decode_gmm(int mode, const uint8_t *enc, size_t enc_len, int64_t n, const float *scales, const float *means, const float *weights, int64_t sn, int64_t sk,
+                              int32_t max_bs, int32_t *out);
 extern "C" void fgo_free(void *p);
 
 static uint64_t rng_state = 88172645463325252ull;
@@ -110,6 +113,25 @@ static void raw_boundary(fgmm_ctx *ctx, const Item &it, int mode) {
   fgo_free(want);
 }
 
+// the rows an item's bitstream codes, in coding order: (non-zero channel, position); parameters as (n, 4) rows, sigma clamped
+static void coded_rows(const Item &it, std::vector<int32_t> &sym, std::vector<float> &s, std::vector<float> &m, std::vector<float> &w) {
+  const size_t n_all = (size_t)it.M * it.hw;
+  for (int c = 0; c < it.M; ++c) {
+    bool nz = false;
+    for (int64_t p = 0; p < it.hw; ++p) nz |= nearbyintf(it.y[(size_t)c * it.hw + p]) != 0.0f;
+    if (!nz) continue;
+    for (int64_t p = 0; p < it.hw; ++p) {
+      const size_t at = (size_t)c * it.hw + p;
+      sym.push_back((int32_t)nearbyintf(it.y[at]));
+      for (int k = 0; k < 4; ++k) {
+        s.push_back(fminf(fmaxf(it.sg[(size_t)k * n_all + at], 0.11f), 256.0f));
+        m.push_back(it.mu[(size_t)k * n_all + at]);
+        w.push_back(it.pi[(size_t)k * n_all + at]);
+      }
+    }
+  }
+}
+
 static void set_opt(fgmm_ctx *ctx, const char *name, int64_t v) { CHECK(fgmm_ctx_set_option(ctx, name, v) == FGMM_OK, "option %s=%lld", name, (long long)v); }
 
 int main(int argc, char **argv) {
@@ -118,7 +140,7 @@ int main(int argc, char **argv) {
   fgmm_ctx *ctx = nullptr;
   CHECK(fgmm_ctx_create(0, 4, &ctx) == FGMM_OK, "ctx");
   const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(budget);
-  long rounds = 0, refused = 0, streams = 0, symbols = 0;
+  long rounds = 0, refused = 0, streams = 0, symbols = 0, corrupted_same = 0, corrupted_refused = 0;
   static const int kThreads[] = {1, 2, 3, 5, 8, 16};
   while (std::chrono::steady_clock::now() < t_end) {
     CHECK(fgmm_ctx_set_threads(ctx, kThreads[rnd() % 6]) == FGMM_OK, "threads");
@@ -183,17 +205,8 @@ int main(int argc, char **argv) {
           nz |= q != 0.0f;
         }
         CHECK(it.zb[(size_t)c] == (nz ? 1 : 0), "zero bitmap item %d channel %d", i, c);
-        if (!nz) continue;
-        for (int64_t p = 0; p < it.hw; ++p) {
-          const size_t at = (size_t)c * it.hw + p;
-          sym.push_back((int32_t)nearbyintf(it.y[at]));
-          for (int k = 0; k < 4; ++k) {
-            s.push_back(fminf(fmaxf(it.sg[(size_t)k * n_all + at], 0.11f), 256.0f));
-            m.push_back(it.mu[(size_t)k * n_all + at]);
-            w.push_back(it.pi[(size_t)k * n_all + at]);
-          }
-        }
       }
+      coded_rows(it, sym, s, m, w);
       uint8_t *want = nullptr;
       size_t want_len = 0;
       CHECK(fgo_encode_gmm(mode, (int64_t)sym.size(), sym.data(), s.data(), m.data(), w.data(), 4, 1, &want, &want_len, nullptr) == 0, "oracle");
@@ -219,6 +232,48 @@ int main(int argc, char **argv) {
         CHECK(fgmm_gmc_decompress_batch(ctx, nullptr, fi.data(), count, mode, clamp) != FGMM_OK, "a truncated bitstream decoded");
         fi[(size_t)victim] = keep;
         ++refused;
+      }
+    }
+    // ---- a CORRUPTED bitstream (same length, bytes overwritten from somewhere on): no notes -> whatever the sequential decoder of the
+    // reference makes of it (the oracle's float bisection on the same bytes), or the call refuses it when the desynchronised
+    // decoder runs off the stream's end; with the good stream's notes -> the same: notes are verified, never trusted
+    if (rnd() % 3 == 0) {
+      int victim = -1;
+      for (int i = 0; i < count; ++i)
+        if (fi[(size_t)i].bytes_len > 64) victim = i;
+      if (victim >= 0) {
+        if (getenv("FGMM_STRESS_VERBOSE")) fprintf(stderr, "   corrupted victim %d\n", victim);
+        Item &it = its[(size_t)victim];
+        const fgmm_item keep = fi[(size_t)victim];
+        std::vector<uint32_t> bad((keep.bytes_len + 3) / 4);
+        memcpy(bad.data(), keep.bytes, keep.bytes_len);
+        uint8_t *b8 = reinterpret_cast<uint8_t *>(bad.data());
+        for (size_t k = (size_t)pick(0, (int64_t)keep.bytes_len - 1); k < keep.bytes_len; k += (size_t)pick(1, 9)) b8[k] = (uint8_t)rnd();
+        fi[(size_t)victim].bytes = b8;
+        if (rnd() % 2) fi[(size_t)victim].ckpt = nullptr, fi[(size_t)victim].n_ckpt = 0;
+        std::fill(it.yhat.begin(), it.yhat.end(), -9.f);
+        const int rc = fgmm_gmc_decompress_batch(ctx, nullptr, fi.data(), count, mode, clamp);
+        if (rc == FGMM_OK) {
+          std::vector<int32_t> sym, dec;
+          std::vector<float> s, m, w;
+          coded_rows(it, sym, s, m, w);
+          dec.assign(sym.size(), 0);
+          CHECK(fgo_decode_gmm(mode, b8, keep.bytes_len, (int64_t)sym.size(), s.data(), m.data(), w.data(), 4, 1, keep.abs_max + 1, dec.data()) == 0, "oracle decoder");
+          size_t at = 0;
+          for (int c = 0; c < it.M; ++c)
+            for (int64_t p = 0; p < it.hw; ++p) {
+              const float want = it.zb[(size_t)c] ? (float)dec[at++] : 0.0f;
+              CHECK(it.yhat[(size_t)c * it.hw + p] == want, "corrupted bitstream: item %d channel %d position %lld decodes to %g, the oracle's decoder to %g", victim, c,
+                    (long long)p, (double)it.yhat[(size_t)c * it.hw + p], (double)want);
+            }
+          ++corrupted_same;
+        } else {
+          CHECK(rc == FGMM_ERR_STREAM, "a corrupted bitstream: status %d", rc);
+          ++corrupted_refused;
+        }
+        for (int i = 0; i < count; ++i)
+          if (i != victim) CHECK(its[(size_t)i].yhat == its[(size_t)i].yq, "a corrupted neighbour changed item %d", i);
+        fi[(size_t)victim] = keep;
       }
     }
     // ---- the reference's native boundary on one of the items' channels: (n, 4) rows in HOST memory, strided as the reference's views
@@ -255,6 +310,7 @@ int main(int argc, char **argv) {
     ++rounds;
   }
   fgmm_ctx_destroy(ctx);
-  printf("stress on the fake device: %ld batches, %ld bitstreams == oracle, %ld symbols, %ld truncated batches refused\n", rounds, streams, symbols, refused);
+  printf("stress on the fake device: %ld batches, %ld bitstreams == oracle, %ld symbols, %ld truncated batches refused, %ld corrupted bitstreams == oracle's decoder (%ld ran off the end: refused)\n", rounds, streams, symbols, refused,
+         corrupted_same, corrupted_refused);
   return 0;
 }
