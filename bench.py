@@ -740,6 +740,42 @@ def step_stats(step_s, probe: "HostProbe | None" = None):
     return out
 
 
+def call_phases(calls):
+    """the library's phase marks of one step's native calls (fgmm_ctx_call_log) as named durations: a call's head (until its first
+    table copy is queued), bus phase (first copy queued -> last piece seen landed), host tail (-> last coder done), end"""
+    ph = {}
+    for j, c in enumerate(calls):
+        m, nm = c["ms"], f"call{j}_{c['kind']}"
+        ph[nm + ".head"] = m[1]
+        ph[nm + ".bus"] = max(m[3] - m[1], 0.0)
+        ph[nm + ".host_tail"] = max(m[4] - max(m[3], m[1]), 0.0)
+        ph[nm + ".end"] = max(m[5] - m[4], 0.0)
+        ph[nm + ".worker_busy"] = c["worker_busy_ms"]
+        ph[nm + ".worker_wait"] = c["worker_wait_ms"]
+    return ph
+
+
+def region_phases(device: int, calls_per_step: int, step_ms):
+    """Where a timed region's steps spent their time, from the library's own call log (a ring of 64 calls the library keeps anyway:
+    read AFTER the region, it costs the steps nothing): medians over the region's last steps of every call's phases and of the time
+    between the calls (the calling thread's Python).  None when the log does not hold whole steps of the expected shape."""
+    from flashgmm_amd import _lib
+
+    m = min(len(step_ms), 64 // max(calls_per_step, 1))
+    log = _lib.call_log(device, m * calls_per_step)
+    if m < 1 or len(log) != m * calls_per_step:
+        return None
+    steps = [log[i * calls_per_step:(i + 1) * calls_per_step] for i in range(m)]
+    if any(st[0]["kind"] != "encode" or any(c["kind"] == "encode" for c in st[1:]) for st in steps):
+        return None
+    ph = [call_phases(st) for st in steps]
+    for i, st in enumerate(steps):
+        ph[i]["between_calls"] = step_ms[len(step_ms) - m + i] - sum(c["ms"][5] for c in st)
+    if any(set(p_) != set(ph[0]) for p_ in ph):
+        return None
+    return {"steps": m, **{k: round(float(np.median([p_[k] for p_ in ph])), 3) for k in sorted(ph[0])}}
+
+
 def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
     """The self-diagnosing leg.  `configs` = ["48", "16", "48+pieces=4" ...]: host workers, optionally
     "+option=value" settings of the library (an A/B inside one run); the configurations take turns in blocks of `block` steps until each has run `steps` steps (boxes differ and drift: only interleaved blocks compare).
@@ -757,17 +793,7 @@ def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
     before = _lib.lib().fgmm_ctx_threads(_lib.ctx(lr))
     calls_per_step = 1 + (leg.spi if schedule == "codec" else 1)
 
-    def phases(calls):
-        ph = {}
-        for j, c in enumerate(calls):
-            m, nm = c["ms"], f"call{j}_{c['kind']}"
-            ph[nm + ".head"] = m[1]
-            ph[nm + ".bus"] = max(m[3] - m[1], 0.0)
-            ph[nm + ".host_tail"] = max(m[4] - max(m[3], m[1]), 0.0)
-            ph[nm + ".end"] = max(m[5] - m[4], 0.0)
-            ph[nm + ".worker_busy"] = c["worker_busy_ms"]
-            ph[nm + ".worker_wait"] = c["worker_wait_ms"]
-        return ph
+    phases = call_phases
 
     rounds = max(1, (steps + block - 1) // block)
     watch = None
@@ -1130,7 +1156,9 @@ class Leg:
         t1 = time.perf_counter()
         probe.close()
         marks = [sm[0] for sm in probe.samples]
-        return t1 - marks[0], step_stats(np.diff(marks), probe)
+        stats = step_stats(np.diff(marks), probe)
+        stats["phases_ms"] = region_phases(self.env.local_rank, 1 + (self.spi if schedule == "codec" else 1), [x * 1e3 for x in np.diff(marks)])
+        return t1 - marks[0], stats
 
     def check_last(self):
         """correctness of what was timed: decode(encode(y)) == round(y) for every stream of this rank"""
