@@ -747,6 +747,10 @@ def call_phases(calls):
     for j, c in enumerate(calls):
         m, nm = c["ms"], f"call{j}_{c['kind']}"
         ph[nm + ".head"] = m[1]
+        if c["kind"] == "decode" and c.get("head_ms") and c["head_ms"][2] > 0:  # the head in detail: the calling thread's own work until
+            h = c["head_ms"]                                                      # the workers are started | waiting for the first launch's size
+            ph[nm + ".head_host"] = h[1]
+            ph[nm + ".head_first_launch"] = max(h[2] - h[1], 0.0)
         ph[nm + ".bus"] = max(m[3] - m[1], 0.0)
         ph[nm + ".host_tail"] = max(m[4] - max(m[3], m[1]), 0.0)
         ph[nm + ".end"] = max(m[5] - m[4], 0.0)

@@ -39,7 +39,7 @@ class fgmm_ckpt(C.Structure):
 
 class fgmm_call_marks(C.Structure):
     _fields_ = [("kind", C.c_int32), ("count", C.c_int32), ("t_begin_ms", C.c_double), ("ms", C.c_double * 6),
-                ("worker_busy_ms", C.c_double), ("worker_wait_ms", C.c_double)]
+                ("worker_busy_ms", C.c_double), ("worker_wait_ms", C.c_double), ("head_ms", C.c_double * 3)]
 
 
 class fgmm_item(C.Structure):
@@ -311,4 +311,4 @@ def call_log(device: int, last: int = 64) -> list:
     n = C.c_int()
     check(lib().fgmm_ctx_call_log(ctx(device), buf, min(int(last), 64), C.byref(n)), "fgmm_ctx_call_log")
     return [{"kind": CALL_KINDS.get(m.kind, m.kind), "count": m.count, "t_begin_ms": m.t_begin_ms, "ms": list(m.ms),
-             "worker_busy_ms": m.worker_busy_ms, "worker_wait_ms": m.worker_wait_ms} for m in buf[:n.value]]
+             "worker_busy_ms": m.worker_busy_ms, "worker_wait_ms": m.worker_wait_ms, "head_ms": list(m.head_ms)} for m in buf[:n.value]]

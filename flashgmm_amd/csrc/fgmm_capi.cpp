@@ -108,7 +108,7 @@ void fgmm_ctx::trim() {
   d_ws = h_ws = d_stage = nullptr;
   d_cap = h_cap = d_stage_cap = 0;
 }
-void fgmm_ctx::log_call(int kind, int count, const Trace &tr, const double ms[5], double busy, double wait) {
+void fgmm_ctx::log_call(int kind, int count, const Trace &tr, const double ms[5], double busy, double wait, const double *head) {
   fgmm_call_marks &m = log[log_n++ % kLogCap];
   m.kind = kind;
   m.count = count;
@@ -117,6 +117,7 @@ void fgmm_ctx::log_call(int kind, int count, const Trace &tr, const double ms[5]
   m.ms[5] = tr.ms();
   m.worker_busy_ms = busy;
   m.worker_wait_ms = wait;
+  for (int k = 0; k < 3; ++k) m.head_ms[k] = head ? head[k] : 0.0;
 }
 int fgmm_ctx::prof_begin(int which, dev::Stream s) {
   if (!profiling) return FGMM_OK;

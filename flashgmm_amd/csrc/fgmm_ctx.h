@@ -208,7 +208,7 @@ struct fgmm_ctx {
   static constexpr int kLogCap = 64;
   fgmm_call_marks log[kLogCap];
   unsigned long long log_n = 0;
-  void log_call(int kind, int count, const fgmm::Trace &tr, const double ms[5], double busy, double wait);
+  void log_call(int kind, int count, const fgmm::Trace &tr, const double ms[5], double busy, double wait, const double *head = nullptr);
   // measurement aid (fgmm_ctx_set_profiling): timing events around the kernels
   bool profiling = false;
   fgmm::dev::Event prof[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};

@@ -81,6 +81,7 @@ struct DecodeCall {
   int launched = 0;
   unsigned long long edges = 0;
   std::vector<std::array<double, 3>> unit_trace; // trace level 2: [queued at, bytes, landed at] per unit
+  double head[3] = {0, 0, 0};                    // ... and the time before marks[1] in detail (fgmm_call_marks.head_ms)
   double marks[5] = {0, 0, 0, 0, 0};             // the call log: planned | first copy queued | last copy queued | last unit seen landed | last decoder done
   // ---- the task queue (everything below is guarded by `mu`)
   std::mutex mu;
@@ -443,6 +444,7 @@ struct DecodeCall {
     while (launched < std::min(n_units, u + 1 + kLaunchAhead))
       if ((rc = launch_next())) return rc;
     DEV_TRY(dev::event_sync(ev_counters[u]));
+    if (u == 0) head[2] = tr.ms();
     unsigned long long *cn = reinterpret_cast<unsigned long long *>(ctx->h_ws + o_counters) + kTabCounters * (size_t)u;
     if (cn[1] && (rc = rerun_unit(u, cn))) return rc;
     const size_t used = (size_t)cn[0];
@@ -764,7 +766,7 @@ struct DecodeCall {
     if (ctx->stat[1] >= (8u << 20) && marks[3] > marks[1])
       fgmm_ctx::Rates::blend(ctx->rates.bus_bytes_per_us, (double)ctx->stat[1] / ((marks[3] - marks[1]) * 1e3), 7000.0, 450000.0);
     std::lock_guard<std::mutex> l(mu);
-    ctx->log_call(1, count, tr, marks, busy, wait_ms);
+    ctx->log_call(1, count, tr, marks, busy, wait_ms, head);
     if (tr.level > 1) {
       for (size_t u = 0; u < unit_trace.size(); ++u)
         fprintf(stderr, "[fgmm decode]   unit %2zu  %2zu parts  %9.0f bytes  queued %7.3f  first seen landed %7.3f\n", u, units[u].parts.size(), unit_trace[u][1],
@@ -785,6 +787,7 @@ struct DecodeCall {
     marks[0] = tr.ms();
     fill_host_side();
     tr.mark("descriptors built");
+    head[0] = tr.ms();
     struct Abandon { // any return: release workers that wait for work (before PoolDrain waits for the workers)
       DecodeCall *c;
       ~Abandon() {
@@ -819,6 +822,7 @@ struct DecodeCall {
     // (a single bitstream too: its decoder starts on piece 0 while this thread is still queuing the later pieces' copies)
     const int n_workers = (int)std::min<int64_t>(std::max(ctx->pool->size(), 1), streams_of_work);
     for (int j = 0; j < n_workers; ++j) ctx->pool->submit([this] { worker(); });
+    head[1] = tr.ms();
     for (int u = 0; u < n_units; ++u)
       if ((rc = collect_unit(u))) return rc;
     tr.mark("sizes known, copies queued");

@@ -153,6 +153,8 @@ typedef struct {
   double t_begin_ms;     /* steady clock, since the context was created */
   double ms[6];          /* since t_begin_ms */
   double worker_busy_ms, worker_wait_ms;
+  double head_ms[3];     /* kind 1, the time before ms[1] in detail: [0] descriptors built, [1] first launches enqueued and the host
+                            workers started, [2] the first launch's size seen on the host (its copy is queued next); else 0 */
 } fgmm_call_marks;
 /* out[0 .. *n_out) = the most recent min(cap, 64, calls so far) calls, oldest first */
 int fgmm_ctx_call_log(fgmm_ctx *ctx, fgmm_call_marks *out, int cap, int *n_out);
