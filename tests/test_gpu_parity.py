@@ -1438,6 +1438,12 @@ def test_bench_latents_dir_hook(tmp_path):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["data"] == "real-latents" and d["config"]["images_per_gpu"] == 2 and d["config"]["streams_per_gpu"] == 4 and d["value"] > 0
     assert d["config"]["coded_symbols_per_gpu"] > 0 and d["ranks"]["result_checked_ranks"] == 1
+    # the region's time by phase, from the library's call log: one encode call and two decode calls (two bitstreams per image) per step,
+    # and the phases account for the steps (what is left is the Python between the calls)
+    ph = d["step_ms"]["phases_ms"]
+    assert ph["steps"] == 2 and {"call0_encode.bus", "call1_decode.head", "call2_decode.host_tail", "between_calls"} <= set(ph)
+    in_calls = sum(v for k, v in ph.items() if k.endswith((".head", ".bus", ".host_tail", ".end")))
+    assert 0 <= ph["between_calls"] and in_calls < d["step_ms"]["max"] * 1.05
 
 
 def test_a_failed_call_leaves_nothing_in_flight(ctx_options):
