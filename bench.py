@@ -740,6 +740,132 @@ def step_stats(step_s, probe: "HostProbe | None" = None):
     return out
 
 
+def _cpulist(text: str) -> set:
+    out = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def _as_cpulist(cpus) -> str:
+    c = sorted(cpus)
+    runs, i = [], 0
+    while i < len(c):
+        j = i
+        while j + 1 < len(c) and c[j + 1] == c[j] + 1:
+            j += 1
+        runs.append(f"{c[i]}-{c[j]}" if j > i else f"{c[i]}")
+        i = j + 1
+    return ",".join(runs)
+
+
+def plan_l3(local_rank: int, ranks_on_node: int):
+    """Which CPUs this rank's calling thread keeps to itself and which its host workers get - decided BEFORE the library creates the
+    workers, and the same way on every rank of the node.
+
+    The workers stream the decode-side tables (358 MB per Kodak step) through the L3 of whatever core complex they run on, and an
+    interpreter that shares that L3 runs the code between the native calls from DRAM: `between_calls` 0.9 - 1.5 ms per step instead
+    of 0.5, per process, by the luck of the scheduler's placement (profiles/r05_l3_ab.txt: 969 / 979 / 989 / 977 / 923 Mpixels/s
+    against 1 024 / 1 034 / 1 031 / 1 029 / 1 021, taking turns on one box).  The library by itself keeps its workers off the L3 its
+    creating thread sits on (fgmm_ctx_worker_cpus); with several ranks on a node that is not enough - rank A's workers would stream
+    through rank B's reserved L3 - so here the L3 domains of the process's (NUMA-bound) CPUs are numbered, domain 0 is left alone
+    (housekeeping lands there), each rank of the NUMA node takes one of the next ones for its calling thread and FGMM_WORKER_CPUS gives
+    the workers of EVERY rank the CPUs outside all of those.  timed() keeps the calling thread on its domain for the timed region.
+    -> (the calling thread's CPUs or None, description).  FGMM_BENCH_L3=0: nothing of this (FGMM_WORKER_CPUS=inherit)."""
+    if os.environ.get("FGMM_BENCH_L3", "1") == "0":
+        os.environ.setdefault("FGMM_WORKER_CPUS", "inherit")
+        return None, "off (FGMM_BENCH_L3=0): workers and calling thread wherever the scheduler puts them"
+    if os.environ.get("FGMM_WORKER_CPUS"):
+        return None, "FGMM_WORKER_CPUS is set by the caller: left alone"
+    try:
+        mask = os.sched_getaffinity(0)
+        domains, seen = [], set()
+        for c in sorted(mask):
+            if c in seen:
+                continue
+            d = _cpulist(open(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list").read()) & mask
+            seen |= d | {c}
+            domains.append(d)
+        numa_nodes = max(1, len([n for n in os.listdir("/sys/devices/system/node") if n.startswith("node") and n[4:].isdigit()]))
+        per_node = -(-max(ranks_on_node, 1) // numa_nodes)  # ranks that share this NUMA node's CPUs (GPUs are spread evenly over the nodes)
+        reserved = domains[1:1 + per_node]
+        workers = mask - set().union(*reserved) if reserved else mask
+        if len(reserved) < per_node or len(workers) < 32:
+            return None, f"not done: {len(domains)} L3 domains in {len(mask)} CPUs, {per_node} rank(s) on the NUMA node (the library's own rule applies)"
+        mine = reserved[local_rank % per_node]
+        os.environ["FGMM_WORKER_CPUS"] = _as_cpulist(workers)
+        return mine, (f"calling thread on CPUs {_as_cpulist(mine)} during timed regions (L3 domain {1 + local_rank % per_node} of {len(domains)}); host workers on the "
+                      f"{len(workers)} CPUs outside the {per_node} reserved domain(s)")
+    except (OSError, ValueError) as e:
+        return None, f"not done ({e}): the library's own rule applies"
+
+
+def _interpreter_work():
+    """a fixed piece of interpreter work (list / dict / ctypes traffic like the wrappers'): ~30 us on an undisturbed Zen 5 core"""
+    import ctypes as C_
+
+    a_ = [i * 3 for i in range(600)]
+    d_ = {i: str(i) for i in range(300)}
+    arr = (C_.c_uint64 * 96)(*range(96))
+    s_ = 0
+    for i in range(96):
+        s_ += arr[i] + len(d_[i]) + a_[i]
+    return s_
+
+
+def settle_calling_thread(max_probe: int = 24):
+    """Moves the calling thread to a CPU whose SMT sibling is idle, before a timed region (FGMM_BENCH_SETTLE=0: off).
+
+    Why: the Python between the native calls (`phases_ms.between_calls`) takes 0.46 ms per step in one process and 1.1 ms in the next on
+    the same box while every native phase is the same (profiles/r05_stall_diagnosis.md 7).  On these shared hosts a few CPUs at any
+    moment run interpreter work at HALF speed - their sibling hyperthread is busy with another tenant (scripts/py_speed_probe.py:
+    0.030 ms on most CPUs, 0.048 - 0.058 on some, different ones a minute later) - and the calling thread, which polls and never
+    sleeps, is never re-placed by the scheduler once it sits on one.  So: time a fixed piece of interpreter work here and on a sample
+    of the allowed CPUs, go to the fastest, and open the affinity mask again (the thread stays where it is until the scheduler has a
+    reason).  ~5 ms, outside the timed region; the worker threads are the scheduler's business as before."""
+    import ctypes as C_
+
+    if os.environ.get("FGMM_BENCH_SETTLE", "1") == "0":
+        return None
+    try:
+        libc = C_.CDLL(None)
+        mask = os.sched_getaffinity(0)
+
+        def speed():
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                _interpreter_work()
+                best = min(best, time.perf_counter() - t0)
+            return best * 1e3
+
+        speed()
+        here = int(libc.sched_getcpu())
+        t_here = speed()
+        cpus = sorted(mask - {here})
+        stride = max(1, len(cpus) // max_probe)
+        off = (os.getpid() + here) % stride  # (not the same sample every time)
+        best_c, best_t, probed = here, t_here, 0
+        try:
+            for c in cpus[off::stride][:max_probe]:
+                os.sched_setaffinity(0, {c})
+                speed()
+                t = speed()
+                probed += 1
+                if t < 0.93 * best_t:
+                    best_c, best_t = c, t
+            os.sched_setaffinity(0, {best_c})
+            t_now = speed()
+        finally:
+            os.sched_setaffinity(0, mask)
+        return {"cpu_before": here, "cpu": best_c, "work_ms_before": round(t_here, 4), "work_ms": round(t_now, 4), "cpus_probed": probed,
+                "note": "a fixed piece of interpreter work timed on a sample of the allowed CPUs; the calling thread moved to the fastest (an idle SMT sibling)"}
+    except (OSError, AttributeError) as e:  # pragma: no cover
+        return {"error": str(e)}
+
+
 def call_phases(calls):
     """the library's phase marks of one step's native calls (fgmm_ctx_call_log) as named durations: a call's head (until its first
     table copy is queued), bus phase (first copy queued -> last piece seen landed), host tail (-> last coder done), end"""
@@ -1017,8 +1143,9 @@ def dryrun(a, world, rank):
 class Env:
     """what every leg of a run shares: the rank's place in the job, its device, the process group"""
 
-    def __init__(self, rank, world, local_rank, dev, dist, coll_dev, backend):
+    def __init__(self, rank, world, local_rank, dev, dist, coll_dev, backend, l3_cpus=None):
         self.rank, self.world, self.local_rank, self.dev, self.dist, self.coll_dev, self.backend = rank, world, local_rank, dev, dist, coll_dev, backend
+        self.l3_cpus = l3_cpus  # own_l3_for_calling_thread(): where timed() keeps the calling thread (the workers are elsewhere)
 
     def max_over_ranks(self, v: float) -> float:
         if not self.dist:
@@ -1146,6 +1273,13 @@ class Leg:
         is not part of the path.)"""
         dist = self.env.dist if self.env.world > 1 else None  # (a barrier over one rank orders nothing - and an RCCL barrier right before
         #                                                       the timed steps idles the GPU long enough to cost the first two of them 1-3 ms)
+        wide = None
+        if self.env.l3_cpus:  # the calling thread on its own L3 for the region (own_l3_for_calling_thread); the mask is opened again below
+            wide = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, self.env.l3_cpus)
+        settled = settle_calling_thread()
+        if settled is not None or wide is not None:
+            self.step(schedule)  # (one more untimed step: the 5 ms of probing / a migration must not be the idle gap before the region)
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -1158,9 +1292,12 @@ class Leg:
         if dist:
             dist.barrier()
         t1 = time.perf_counter()
+        if wide is not None:
+            os.sched_setaffinity(0, wide)
         probe.close()
         marks = [sm[0] for sm in probe.samples]
         stats = step_stats(np.diff(marks), probe)
+        stats["calling_thread"] = settled
         stats["phases_ms"] = region_phases(self.env.local_rank, 1 + (self.spi if schedule == "codec" else 1), [x * 1e3 for x in np.diff(marks)])
         return t1 - marks[0], stats
 
@@ -1344,7 +1481,9 @@ def main(argv=None):
         # is the latency_ms leg
         a.images = 24 if a.workload == "kodak24" else ELIC_IMAGES
     f16 = (a.param_dtype or ("f32" if a.workload == "kodak24" else "f16")) == "f16"
+    env.l3_cpus, l3_note = plan_l3(local_rank, _lib.ranks_on_node())  # (before the library creates its workers)
     _lib.ctx(local_rank, a.host_threads)
+    l3_note += f"; fgmm_ctx_worker_cpus: '{_lib.worker_cpus(local_rank)}'"
     _lib.set_profiling(local_rank, True)
     leg = Leg(env, a.workload, a.images, a.mode, f16, latents_dir=a.latents_dir, pixels_per_image=a.pixels_per_image)
     a.images = leg.images
@@ -1572,7 +1711,7 @@ def main(argv=None):
                        "param_dtype": "f16" if f16 else "f32",
                        "coded_symbols_per_gpu": n_coded, "bitstream_bytes_per_gpu": total_bytes,
                        "host_threads_per_gpu": host_threads, "host_cpu_budget": budget,
-                       "ranks_on_node": _lib.ranks_on_node(), "numa": numa,
+                       "ranks_on_node": _lib.ranks_on_node(), "numa": numa, "l3": l3_note,
                        "host_mem_traffic_GBps_per_rank": round(host_traffic, 1), "cpu_budget_note": note,
                        "one_device_rehearsal": one_device,
                        "parallelism": f"images sharded over {world} GPU(s)"},

@@ -80,6 +80,7 @@ SIGNATURES = {
     "fgmm_ctx_device": (_i, [_p]),
     "fgmm_ctx_threads": (_i, [_p]),
     "fgmm_ctx_set_threads": (_i, [_p, _i]),
+    "fgmm_ctx_worker_cpus": (_i, [_p, C.c_char_p, _sz]),
     "fgmm_free": (None, [_p]),
     "fgmm_ctx_take_buffers": (_i, [_p, _p, _p, _p, _i]),
     "fgmm_ctx_set_profiling": (_i, [_p, _i]),
@@ -303,6 +304,13 @@ def ctx_stat(device: int, which: int) -> int:
 
 
 CALL_KINDS = {0: "encode", 1: "decode", 2: "decode_gpu"}
+
+
+def worker_cpus(device: int) -> str:
+    """cpulist of the CPUs the context's host workers may run on ("" = the creating thread's mask): fgmm_ctx_worker_cpus"""
+    buf = C.create_string_buffer(4096)
+    check(lib().fgmm_ctx_worker_cpus(ctx(device), buf, len(buf)), "fgmm_ctx_worker_cpus")
+    return buf.value.decode()
 
 
 def call_log(device: int, last: int = 64) -> list:

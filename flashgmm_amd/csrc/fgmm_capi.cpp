@@ -292,7 +292,8 @@ int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {
   fgmm_ctx *c = new (std::nothrow) fgmm_ctx;
   if (!c) return fail(FGMM_ERR_NOMEM, "ctx");
   c->device = device;
-  c->pool = new Pool(n_threads);
+  c->worker_cpus = WorkerCpus::choose(n_threads);
+  c->pool = new Pool(n_threads, c->worker_cpus);
   for (const OptName &o : kOpts)
     if (o.env && getenv(o.env)) c->opt.*(o.field) = std::min(std::max<int64_t>(atoll(getenv(o.env)), o.lo), o.hi);
   *out = c;
@@ -392,10 +393,18 @@ int fgmm_ctx_set_threads(fgmm_ctx *ctx, int n_threads) {
   if (n_threads <= 0) n_threads = fgmm_host_thread_budget(1);
   if (n_threads > 256) return fail(FGMM_ERR_INVALID, "n_threads %d", n_threads);
   if (ctx->pool && ctx->pool->size() == n_threads) return FGMM_OK;
-  Pool *fresh = new (std::nothrow) Pool(n_threads);
+  Pool *fresh = new (std::nothrow) Pool(n_threads, ctx->worker_cpus);
   if (!fresh) return fail(FGMM_ERR_NOMEM, "worker pool");
   delete ctx->pool;
   ctx->pool = fresh;
+  return FGMM_OK;
+}
+
+int fgmm_ctx_worker_cpus(fgmm_ctx *ctx, char *out, size_t cap) {
+  if (!ctx || !out || cap == 0) return fail(FGMM_ERR_INVALID, "bad argument");
+  const std::string s = ctx->worker_cpus.cpulist();
+  if (s.size() + 1 > cap) return fail(FGMM_ERR_INVALID, "cpulist of %zu characters, room for %zu", s.size(), cap - 1);
+  memcpy(out, s.c_str(), s.size() + 1);
   return FGMM_OK;
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,6 +17,7 @@
 #include <functional>
 #include <mutex>
 #include <queue>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -54,15 +56,88 @@ struct Trace {
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// Where a context's host workers may run.  They stream the decode-side tables (358 MB per Kodak step) through the L3 of whatever core
+// complex they run on, and a calling thread that shares that L3 - a Python interpreter above all - runs the code between the calls
+// from DRAM: 0.9 - 1.5 ms of glue per Kodak step instead of 0.5, by the luck of the scheduler's placement (profiles/r05_l3_ab.txt).
+//   FGMM_WORKER_CPUS unset     the creating thread's mask MINUS the CPUs that share an L3 with the CPU it is on, when that leaves the
+//                              workers enough room (at least 32 CPUs and two per worker); else the creating thread's mask
+//   FGMM_WORKER_CPUS=inherit   the creating thread's mask, untouched
+//   FGMM_WORKER_CPUS=<cpulist> exactly these ("0-7,16-23"), e.g. from a deployment that pins its calling thread somewhere else
+// The library never touches the calling thread's own affinity.
+struct WorkerCpus {
+  cpu_set_t set;
+  bool restricted = false; // false: the workers inherit the creating thread's mask
+  static bool parse(const char *text, cpu_set_t *out) {
+    CPU_ZERO(out);
+    int n = 0;
+    for (const char *p = text; *p && *p != '\n';) {
+      char *end = nullptr;
+      const long lo = strtol(p, &end, 10);
+      if (end == p || lo < 0) return false;
+      long hi = lo;
+      if (*end == '-') {
+        const char *q = end + 1;
+        hi = strtol(q, &end, 10);
+        if (end == q || hi < lo) return false;
+      }
+      for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) CPU_SET((int)c, out), ++n;
+      if (*end == ',') ++end;
+      else if (*end && *end != '\n') return false;
+      p = end;
+    }
+    return n > 0;
+  }
+  static WorkerCpus choose(int n_threads) {
+    WorkerCpus w;
+    CPU_ZERO(&w.set);
+    const char *e = getenv("FGMM_WORKER_CPUS");
+    if (e && !strcmp(e, "inherit")) return w;
+    if (e && *e) {
+      w.restricted = parse(e, &w.set);
+      return w;
+    }
+    cpu_set_t have, l3;
+    const int cpu = sched_getcpu();
+    if (cpu < 0 || sched_getaffinity(0, sizeof have, &have) != 0) return w;
+    char path[96], text[512];
+    snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    FILE *f = fopen(path, "r");
+    if (!f) return w;
+    const bool got = fgets(text, sizeof text, f) != nullptr;
+    fclose(f);
+    if (!got || !parse(text, &l3)) return w;
+    int left = 0;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &have) && !CPU_ISSET(c, &l3)) CPU_SET(c, &w.set), ++left;
+    w.restricted = left >= std::max(32, 2 * n_threads);
+    return w;
+  }
+  std::string cpulist() const { // "" when the workers inherit
+    std::string out;
+    if (!restricted) return out;
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+      if (!CPU_ISSET(c, &set)) continue;
+      int hi = c;
+      while (hi + 1 < CPU_SETSIZE && CPU_ISSET(hi + 1, &set)) ++hi;
+      if (!out.empty()) out += ',';
+      out += std::to_string(c);
+      if (hi > c) out += '-' + std::to_string(hi);
+      c = hi;
+    }
+    return out;
+  }
+};
+
 // ---- host worker pool ----------------------------------------------------------------------------------
 class Pool {
 public:
-  explicit Pool(int n) {
+  Pool(int n, const WorkerCpus &where) {
     for (int i = 0; i < n; ++i)
-      th_.emplace_back([this, i] {
+      th_.emplace_back([this, i, where] {
         char name[16];
         snprintf(name, sizeof name, "fgmm-w%d", i); // (/proc/<pid>/task/<tid>/comm: bench.py's step_diag names the threads that waited for a CPU)
         pthread_setname_np(pthread_self(), name);
+        if (where.restricted) (void)sched_setaffinity(0, sizeof where.set, &where.set); // (refused by the kernel: the inherited mask)
         run();
       });
   }
@@ -164,6 +239,7 @@ struct fgmm_ctx {
   int device = 0;
   std::mutex mu; // one call at a time per context
   fgmm::Pool *pool = nullptr;
+  fgmm::WorkerCpus worker_cpus; // decided once, when the context is created (fgmm_ctx_set_threads keeps it)
   char *d_ws = nullptr; // device workspace (descriptors, counters, encode tables): grown on demand, reused
   size_t d_cap = 0;
   char *h_ws = nullptr; // its pinned mirror

@@ -87,6 +87,16 @@ int fgmm_ctx_threads(const fgmm_ctx *ctx);
 /* Resizes the context's pool of host rANS workers in place (n_threads <= 0: the default); options, profiling state and
  * buffers are kept.  Must not race with a call on the same context (it takes the context's lock like every call). */
 int fgmm_ctx_set_threads(fgmm_ctx *ctx, int n_threads);
+/* Where the context's host workers may run, as a Linux cpulist ("" = wherever the thread that created the context may).  The workers
+ * stream the decode-side tables through the L3 of the core complex they run on; a calling thread that shares that L3 - a Python
+ * interpreter above all - pays for it between the calls (0.9 - 1.5 ms of glue per Kodak step instead of 0.5).  Decided when the context
+ * is created, from the environment variable FGMM_WORKER_CPUS:
+ *   unset      the creating thread's CPUs minus those that share an L3 with the CPU it is on (if >= 32 CPUs and two per worker remain)
+ *   "inherit"  the creating thread's CPUs
+ *   a cpulist  exactly these, e.g. "16-127"
+ * The library never changes the calling thread's own affinity; a caller that wants the full benefit keeps its thread on the CPUs
+ * that are NOT in this list (bench.py does, for its timed regions). */
+int fgmm_ctx_worker_cpus(fgmm_ctx *ctx, char *cpulist_out, size_t cap);
 
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */
 /* Moves `count` buffers this library returned (src[i], len[i] bytes: bitstreams of a batched compress) into the caller's own

@@ -1,0 +1,16 @@
+#!/usr/bin/env bash
+# Dev aid (GPU box): bench.py's headline with the calling thread on an L3 of its own (workers on the other CPUs: FGMM_WORKER_CPUS) and
+# without, taking turns in one box.   scripts/l3_ab.sh [rounds]
+cd "$(dirname "$0")/.."
+for rep in $(seq 1 ${1:-5}); do
+  for s in 0 1; do
+    FGMM_BENCH_L3=$s python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > gpurun_out/l3_${s}_${rep}.json 2> /dev/null || exit 1
+    python3 - "$s" gpurun_out/l3_${s}_${rep}.json <<'P'
+import json, sys
+d = json.load(open(sys.argv[2])); p = d["step_ms"]["phases_ms"]; c = d["step_ms"].get("calling_thread")
+print(f"own L3 {sys.argv[1]}: {d['value']:7.1f} Mpixels/s  step median {d['step_ms']['median']:.3f} p90 {d['step_ms']['p90']:.3f}  between_calls {p['between_calls']:.3f}  "
+      f"bus {p['call1_decode.bus']:.3f} {p['call2_decode.bus']:.3f}  tails {p['call1_decode.host_tail']:.3f} {p['call2_decode.host_tail']:.3f}  busy {p['call1_decode.worker_busy']:.1f} {p['call2_decode.worker_busy']:.1f}  "
+      + (f"cpu {c['cpu_before']} -> {c['cpu']}" if c else "") + "  | " + str(d["config"].get("l3"))[:70])
+P
+  done
+done

@@ -12,6 +12,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dirent.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -139,6 +141,39 @@ int main(int argc, char **argv) {
   if (argc > 2) rng_state ^= (uint64_t)atoll(argv[2]) * 0x9E3779B97F4A7C15ull;
   fgmm_ctx *ctx = nullptr;
   CHECK(fgmm_ctx_create(0, 4, &ctx) == FGMM_OK, "ctx");
+  if (const char *want = getenv("FGMM_STRESS_EXPECT_WORKER_CPUS")) { // (tests/test_fake_device_cpu.py: FGMM_WORKER_CPUS is honoured)
+    char got[4096];
+    CHECK(fgmm_ctx_worker_cpus(ctx, got, sizeof got) == FGMM_OK && !strcmp(got, want), "worker CPUs '%s', expected '%s'", got, want);
+    CHECK(fgmm_ctx_set_threads(ctx, 6) == FGMM_OK, "threads"); // (a resized pool keeps the context's decision)
+    int seen = 0;
+    DIR *tasks = *want ? opendir("/proc/self/task") : nullptr;
+    for (struct dirent *de; tasks && (de = readdir(tasks));) {
+      const int tid = atoi(de->d_name);
+      if (tid <= 0) continue;
+      char path[64], line[256];
+      snprintf(path, sizeof path, "/proc/self/task/%d/comm", tid);
+      FILE *f = fopen(path, "r");
+      if (!f) continue;
+      const bool worker = fgets(line, sizeof line, f) && !strncmp(line, "fgmm-w", 6);
+      fclose(f);
+      if (!worker) continue;
+      snprintf(path, sizeof path, "/proc/self/task/%d/status", tid);
+      f = fopen(path, "r");
+      CHECK(f != nullptr, "status of thread %d", tid);
+      while (fgets(line, sizeof line, f))
+        if (!strncmp(line, "Cpus_allowed_list:", 18)) {
+          char *v = line + 18;
+          while (*v == ' ' || *v == '\t') ++v;
+          v[strcspn(v, "\n")] = 0;
+          CHECK(!strcmp(v, want), "worker thread %d may run on '%s', expected '%s'", tid, v, want);
+          ++seen;
+        }
+      fclose(f);
+    }
+    if (tasks) closedir(tasks);
+    CHECK(!*want || seen == 6, "%d worker threads found, expected 6", seen);
+    printf("worker CPUs: '%s' (%d threads checked)\n", got, seen);
+  }
   const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(budget);
   long rounds = 0, refused = 0, streams = 0, symbols = 0, corrupted_same = 0, corrupted_refused = 0;
   static const int kThreads[] = {1, 2, 3, 5, 8, 16};

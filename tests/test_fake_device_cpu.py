@@ -36,3 +36,18 @@ def test_host_sources_do_not_include_the_gpu_runtime():
     for f in SRC[:5] + ["flashgmm_amd/csrc/fgmm_ctx.h", "flashgmm_amd/csrc/fgmm_internal.h", "flashgmm_amd/csrc/fgmm_device.h"]:
         text = open(os.path.join(ROOT, f)).read()
         assert "hip/hip_runtime" not in text and "#include <hsa" not in text, f
+
+
+def test_worker_cpus_follow_the_environment(stress_binary):
+    """FGMM_WORKER_CPUS: a cpulist = exactly these CPUs for every host worker (a resized pool included), "inherit" = the creating
+    thread's mask; unset on a host too small to set an L3 aside (this one: < 32 CPUs would remain) = the creating thread's mask too.
+    (What it is for: the workers stream the decode tables through their L3 - profiles/r05_l3_ab.txt.)"""
+    cpus = sorted(os.sched_getaffinity(0))
+    one = str(cpus[-1])
+    for env, want in (({"FGMM_WORKER_CPUS": one}, one), ({"FGMM_WORKER_CPUS": "inherit"}, "")) + ((({}, ""),) if len(cpus) < 48 else ()):
+        e = {k: v for k, v in os.environ.items() if k != "FGMM_WORKER_CPUS"}
+        e.update(env)
+        e["FGMM_STRESS_EXPECT_WORKER_CPUS"] = want
+        r = subprocess.run([stress_binary, "1", "3"], capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        assert f"worker CPUs: '{want}'" in r.stdout and "bitstreams == oracle" in r.stdout, r.stdout
