@@ -740,66 +740,16 @@ def step_stats(step_s, probe: "HostProbe | None" = None):
     return out
 
 
-def _cpulist(text: str) -> set:
-    out = set()
-    for part in text.strip().split(","):
-        if part:
-            lo, _, hi = part.partition("-")
-            out.update(range(int(lo), int(hi or lo) + 1))
-    return out
-
-
-def _as_cpulist(cpus) -> str:
-    c = sorted(cpus)
-    runs, i = [], 0
-    while i < len(c):
-        j = i
-        while j + 1 < len(c) and c[j + 1] == c[j] + 1:
-            j += 1
-        runs.append(f"{c[i]}-{c[j]}" if j > i else f"{c[i]}")
-        i = j + 1
-    return ",".join(runs)
-
-
 def plan_l3(local_rank: int, ranks_on_node: int):
-    """Which CPUs this rank's calling thread keeps to itself and which its host workers get - decided BEFORE the library creates the
-    workers, and the same way on every rank of the node.
+    """flashgmm_amd.parallel.plan_l3 (an L3 domain of its own for the calling thread, the host workers of every rank elsewhere) with the
+    bench's switch: FGMM_BENCH_L3=0 leaves workers and calling thread wherever the scheduler puts them (FGMM_WORKER_CPUS=inherit).
+    timed() keeps the calling thread on its domain for the timed region only (helper processes must inherit the wide mask)."""
+    from flashgmm_amd import parallel as P_
 
-    The workers stream the decode-side tables (358 MB per Kodak step) through the L3 of whatever core complex they run on, and an
-    interpreter that shares that L3 runs the code between the native calls from DRAM: `between_calls` 0.9 - 1.5 ms per step instead
-    of 0.5, per process, by the luck of the scheduler's placement (profiles/r05_l3_ab.txt: 969 / 979 / 989 / 977 / 923 Mpixels/s
-    against 1 024 / 1 034 / 1 031 / 1 029 / 1 021, taking turns on one box).  The library by itself keeps its workers off the L3 its
-    creating thread sits on (fgmm_ctx_worker_cpus); with several ranks on a node that is not enough - rank A's workers would stream
-    through rank B's reserved L3 - so here the L3 domains of the process's (NUMA-bound) CPUs are numbered, domain 0 is left alone
-    (housekeeping lands there), each rank of the NUMA node takes one of the next ones for its calling thread and FGMM_WORKER_CPUS gives
-    the workers of EVERY rank the CPUs outside all of those.  timed() keeps the calling thread on its domain for the timed region.
-    -> (the calling thread's CPUs or None, description).  FGMM_BENCH_L3=0: nothing of this (FGMM_WORKER_CPUS=inherit)."""
     if os.environ.get("FGMM_BENCH_L3", "1") == "0":
         os.environ.setdefault("FGMM_WORKER_CPUS", "inherit")
         return None, "off (FGMM_BENCH_L3=0): workers and calling thread wherever the scheduler puts them"
-    if os.environ.get("FGMM_WORKER_CPUS"):
-        return None, "FGMM_WORKER_CPUS is set by the caller: left alone"
-    try:
-        mask = os.sched_getaffinity(0)
-        domains, seen = [], set()
-        for c in sorted(mask):
-            if c in seen:
-                continue
-            d = _cpulist(open(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list").read()) & mask
-            seen |= d | {c}
-            domains.append(d)
-        numa_nodes = max(1, len([n for n in os.listdir("/sys/devices/system/node") if n.startswith("node") and n[4:].isdigit()]))
-        per_node = -(-max(ranks_on_node, 1) // numa_nodes)  # ranks that share this NUMA node's CPUs (GPUs are spread evenly over the nodes)
-        reserved = domains[1:1 + per_node]
-        workers = mask - set().union(*reserved) if reserved else mask
-        if len(reserved) < per_node or len(workers) < 32:
-            return None, f"not done: {len(domains)} L3 domains in {len(mask)} CPUs, {per_node} rank(s) on the NUMA node (the library's own rule applies)"
-        mine = reserved[local_rank % per_node]
-        os.environ["FGMM_WORKER_CPUS"] = _as_cpulist(workers)
-        return mine, (f"calling thread on CPUs {_as_cpulist(mine)} during timed regions (L3 domain {1 + local_rank % per_node} of {len(domains)}); host workers on the "
-                      f"{len(workers)} CPUs outside the {per_node} reserved domain(s)")
-    except (OSError, ValueError) as e:
-        return None, f"not done ({e}): the library's own rule applies"
+    return P_.plan_l3(local_rank, ranks_on_node)
 
 
 def _interpreter_work():

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["shard_units", "owner_of", "all_gather_stream_lengths", "LengthExchange", "container_index", "gather_containers",
-           "bind_to_gpu_numa_node", "confirm_numa_binding"]
+           "bind_to_gpu_numa_node", "confirm_numa_binding", "plan_l3"]
 
 
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:
@@ -173,6 +173,71 @@ def _visible_filter(n_gpus: int) -> List[int]:
             raise LookupError(f"{name}={v!r}")
         idx = [idx[i] for i in pick if 0 <= i < len(idx)]
     return idx
+
+
+def cpulist_to_set(text: str) -> set:
+    """Linux cpulist ("0-7,16-23") -> set of CPU numbers"""
+    out = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def set_to_cpulist(cpus) -> str:
+    c = sorted(cpus)
+    runs, i = [], 0
+    while i < len(c):
+        j = i
+        while j + 1 < len(c) and c[j + 1] == c[j] + 1:
+            j += 1
+        runs.append(f"{c[i]}-{c[j]}" if j > i else f"{c[i]}")
+        i = j + 1
+    return ",".join(runs)
+
+
+def plan_l3(local_rank: int, ranks_on_node: int):
+    """Which CPUs this rank's CALLING thread keeps to itself and which its host workers get - to be decided BEFORE the library creates
+    the workers (the first ``_lib.ctx`` of the process), and the same way on every rank of the node.
+
+    The workers stream the decode-side tables (358 MB per Kodak step) through the L3 of whatever core complex they run on, and an
+    interpreter that shares that L3 runs the code between the native calls from DRAM: 0.9 - 1.5 ms of Python per Kodak step instead
+    of 0.5, per process, by the luck of the scheduler's placement (profiles/r05_l3_ab.txt: 969 / 979 / 989 / 977 / 923 Mpixels/s
+    against 1 024 / 1 034 / 1 031 / 1 029 / 1 021, taking turns on one box).  The library by itself keeps its workers off the L3 its
+    creating thread sits on (``fgmm_ctx_worker_cpus``); with several ranks on a node that is not enough - rank A's workers would stream
+    through rank B's reserved L3 - so here the L3 domains of the process's (NUMA-bound) CPUs are numbered, domain 0 is left alone
+    (housekeeping lands there), each rank of the NUMA node takes one of the next ones for its calling thread, and the environment
+    variable FGMM_WORKER_CPUS gives the workers of EVERY rank the CPUs outside all of those.  The caller then keeps its thread on the
+    returned CPUs while it drives the codec (``os.sched_setaffinity(0, cpus)``: the calling thread only - restore the wider mask
+    before starting helper processes, they inherit it).
+    -> (the calling thread's CPUs or None, description).  Nothing is done (the library's own rule applies) when FGMM_WORKER_CPUS is
+    already set, when the topology is unreadable or when the workers would be left fewer than 32 CPUs."""
+    import os
+
+    if os.environ.get("FGMM_WORKER_CPUS"):
+        return None, "FGMM_WORKER_CPUS is set by the caller: left alone"
+    try:
+        mask = os.sched_getaffinity(0)
+        domains, seen = [], set()
+        for c in sorted(mask):
+            if c in seen:
+                continue
+            d = cpulist_to_set(open(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list").read()) & mask
+            seen |= d | {c}
+            domains.append(d)
+        numa_nodes = max(1, len([n for n in os.listdir("/sys/devices/system/node") if n.startswith("node") and n[4:].isdigit()]))
+        per_node = -(-max(ranks_on_node, 1) // numa_nodes)  # ranks that share this NUMA node's CPUs (GPUs are spread evenly over the nodes)
+        reserved = domains[1:1 + per_node]
+        workers = mask - set().union(*reserved) if reserved else mask
+        if len(reserved) < per_node or len(workers) < 32:
+            return None, f"not done: {len(domains)} L3 domains in {len(mask)} CPUs, {per_node} rank(s) on the NUMA node (the library's own rule applies)"
+        mine = reserved[local_rank % per_node]
+        os.environ["FGMM_WORKER_CPUS"] = set_to_cpulist(workers)
+        return mine, (f"calling thread on CPUs {set_to_cpulist(mine)} (L3 domain {1 + local_rank % per_node} of {len(domains)}); host workers on the "
+                      f"{len(workers)} CPUs outside the {per_node} reserved domain(s)")
+    except (OSError, ValueError) as e:
+        return None, f"not done ({e}): the library's own rule applies"
 
 
 def gpu_pci_address(device_index: int) -> str:

@@ -165,7 +165,7 @@ def test_helper_processes_start_without_a_profilers_preload(monkeypatch):
 
 
 def test_l3_plan_partitions_the_cpus(monkeypatch, tmp_path):
-    """bench.plan_l3: every rank of a NUMA node takes one L3 domain (not domain 0) for its calling thread, FGMM_WORKER_CPUS gives the
+    """parallel.plan_l3 (through bench.plan_l3): every rank of a NUMA node takes one L3 domain (not domain 0) for its calling thread, FGMM_WORKER_CPUS gives the
     workers of every rank the CPUs outside all reserved domains - on a made-up host of 2 NUMA nodes x 4 L3 domains x 16 CPUs, this
     process bound to node 0 (64 CPUs), one rank and four ranks per node; too small a host: nothing is done."""
     import builtins
@@ -173,6 +173,7 @@ def test_l3_plan_partitions_the_cpus(monkeypatch, tmp_path):
 
     sys.path.insert(0, ROOT)
     import bench
+    from flashgmm_amd import parallel as P
 
     l3 = {c: f"{c // 8 * 8}-{c // 8 * 8 + 7},{128 + c // 8 * 8}-{128 + c // 8 * 8 + 7}" for c in range(32)}  # domain d: CPUs 8d..8d+7 and their siblings 128+
     l3.update({128 + c: l3[c] for c in range(32)})
@@ -192,7 +193,7 @@ def test_l3_plan_partitions_the_cpus(monkeypatch, tmp_path):
     monkeypatch.delenv("FGMM_BENCH_L3", raising=False)
     mine, note = bench.plan_l3(0, 1)
     assert mine == set(range(8, 16)) | set(range(136, 144)), note
-    assert bench._cpulist(os.environ["FGMM_WORKER_CPUS"]) == mask - mine
+    assert P.cpulist_to_set(os.environ["FGMM_WORKER_CPUS"]) == mask - mine
     taken = []
     for r in range(8):  # eight ranks on the node, four per NUMA node: ranks 0-3 (and 4-7 on the other node's CPUs) take domains 1-3 ... too few here
         monkeypatch.delenv("FGMM_WORKER_CPUS", raising=False)
@@ -204,7 +205,7 @@ def test_l3_plan_partitions_the_cpus(monkeypatch, tmp_path):
         mine, note = bench.plan_l3(r, 4)
         d = 1 + r % 2
         assert mine == set(range(8 * d, 8 * d + 8)) | set(range(128 + 8 * d, 128 + 8 * d + 8)), (r, note)
-        assert bench._cpulist(os.environ["FGMM_WORKER_CPUS"]) == set(range(0, 8)) | set(range(24, 32)) | set(range(128, 136)) | set(range(152, 160))
+        assert P.cpulist_to_set(os.environ["FGMM_WORKER_CPUS"]) == set(range(0, 8)) | set(range(24, 32)) | set(range(128, 136)) | set(range(152, 160))
     monkeypatch.setenv("FGMM_BENCH_L3", "0")
     monkeypatch.delenv("FGMM_WORKER_CPUS", raising=False)
     assert bench.plan_l3(0, 1)[0] is None and os.environ["FGMM_WORKER_CPUS"] == "inherit"
