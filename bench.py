@@ -1224,9 +1224,12 @@ class Leg:
         dist = self.env.dist if self.env.world > 1 else None  # (a barrier over one rank orders nothing - and an RCCL barrier right before
         #                                                       the timed steps idles the GPU long enough to cost the first two of them 1-3 ms)
         wide = None
-        if self.env.l3_cpus:  # the calling thread on its own L3 for the region (own_l3_for_calling_thread); the mask is opened again below
-            wide = os.sched_getaffinity(0)
-            os.sched_setaffinity(0, self.env.l3_cpus)
+        if self.env.l3_cpus:  # the calling thread on its own L3 domain for the region (plan_l3); the mask is opened again below
+            try:
+                wide = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, self.env.l3_cpus)
+            except OSError:  # (the allowed CPUs have changed under us: go on without)
+                wide, self.env.l3_cpus = None, None
         settled = settle_calling_thread()
         if settled is not None or wide is not None:
             self.step(schedule)  # (one more untimed step: the 5 ms of probing / a migration must not be the idle gap before the region)
