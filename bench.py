@@ -886,6 +886,13 @@ def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
             watch = None
     per = {c: {"st": [], "ph": [], "t": [], "comm": {}} for c in configs}
     saved_opts = {}
+    wide = None
+    if leg.env.l3_cpus:  # as in timed(): the calling thread on its own L3 domain (helper processes have been started by now)
+        try:
+            wide = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, leg.env.l3_cpus)
+        except OSError:
+            wide = None
     try:
         for _ in range(rounds):
             for cfg in configs:
@@ -918,6 +925,8 @@ def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
                 for k_, v_ in saved_opts.items():
                     _lib.set_option(lr, k_, v_)
     finally:
+        if wide is not None:
+            os.sched_setaffinity(0, wide)
         _lib.set_threads(lr, before)
         for k_, v_ in saved_opts.items():
             _lib.set_option(lr, k_, v_)
