@@ -294,16 +294,6 @@ struct fgmm_ctx {
   // counters (fgmm_ctx_stat): last batched call: [0] encode table bytes D2H, [1] decode table bytes D2H, [2] decode latents,
   // [3] edges the decode-side kernels evaluated, [4] bitstreams the GPU's segment decoder decoded, [5] ... handed back to the table path
   unsigned long long stat[6] = {0, 0, 0, 0, 0, 0};
-  // what option gpu_decode = 0 prices its two decoders with (fgmm_decode.cpp: gpu_is_faster).  The starting values were measured on
-  // MI355X + EPYC 9575F; from then on they follow THIS context's own calls on this host and device (moving averages over calls
-  // large enough to measure a rate, held inside a factor of ~8 of the starting values so that one odd call cannot park the rule)
-  struct Rates {
-    double host_us_per_symbol = 0.012;      // a host worker's table search + rANS step
-    double bus_bytes_per_us = 55700.0;      // decode-side tables, device -> pinned host (first copy queued .. last seen landed)
-    double gpu_us_per_stride_symbol = 0.65; // segdec_kernel when its longest segment (one lane's sequential work) bounds it
-    double gpu_us_per_symbol = 0.00035;     // ... when the grid's throughput does
-    static void blend(double &r, double sample, double lo, double hi) { r += 0.25 * (std::min(std::max(sample, lo), hi) - r); }
-  } rates;
 };
 
 namespace fgmm {
@@ -395,7 +385,6 @@ struct DecItem {
 };
 int decode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<DecItem> &items, int mode);
 // checkpointed bitstreams decoded ON THE GPU (segdec_kernel); `redo`: items whose segments did not all verify
-constexpr double kGpuDecodeFixedUs = 100.0; // a GPU decode call's upload + launch + status copy, in the automatic choice's estimate
 int decode_batch_gpu(fgmm_ctx *ctx, dev::Stream stream, std::vector<DecItem> &items, const std::vector<int> &which, int mode, std::vector<int> &redo);
 bool gpu_decodable(const DecItem &it, int64_t n);
 

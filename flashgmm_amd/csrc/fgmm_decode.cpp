@@ -761,10 +761,6 @@ struct DecodeCall {
       marks[4] = std::max(marks[4], it.t_end);
       busy += it.t_work;
     }
-    // the rates the automatic choice of a decoder is priced with (fgmm_ctx::Rates), from calls large enough to show them
-    if (ctx->stat[2] >= 200000 && busy > 0) fgmm_ctx::Rates::blend(ctx->rates.host_us_per_symbol, busy * 1e3 / (double)ctx->stat[2], 0.0015, 0.1);
-    if (ctx->stat[1] >= (8u << 20) && marks[3] > marks[1])
-      fgmm_ctx::Rates::blend(ctx->rates.bus_bytes_per_us, (double)ctx->stat[1] / ((marks[3] - marks[1]) * 1e3), 7000.0, 450000.0);
     std::lock_guard<std::mutex> l(mu);
     ctx->log_call(1, count, tr, marks, busy, wait_ms, head);
     if (tr.level > 1) {
@@ -847,10 +843,12 @@ bool gpu_is_faster(const fgmm_ctx *ctx, const std::vector<DecItem> &items, const
     stride_max = std::max(stride_max, (double)std::min<int64_t>(items[i].ckpt_stride, items[i].n));
     work += (double)(items[i].n_ckpt + 1);
   }
-  const fgmm_ctx::Rates &r = ctx->rates; // (this context's own measurements: fgmm_ctx.h)
-  const double t_gpu = std::max(stride_max * r.gpu_us_per_stride_symbol, syms * r.gpu_us_per_symbol) + kGpuDecodeFixedUs;
+  // (rates measured on MI355X + EPYC 9575F.  A version that re-fitted them from the context's own calls was built and dropped in round 5:
+  // small or unusual calls - the fixed costs of a 200 k-symbol GPU call read as throughput - walked the estimate far enough to flip
+  // the choice for a Kodak batch, a 3x margin; on another platform the caller sets the option to 1 or 2)
+  const double t_gpu = std::max(stride_max * 0.65, syms * 0.00035) + 100.0;
   const double workers = std::min<double>(std::max(ctx->pool->size(), 1), work);
-  const double t_host = std::max(syms * r.host_us_per_symbol / workers, syms * 58.0 / r.bus_bytes_per_us) + 450.0 + 3.0 * work / workers; // + a segment's set-up
+  const double t_host = std::max(syms * 0.012 / workers, syms * 58.0 / 55700.0) + 450.0 + 3.0 * work / workers; // + a segment's set-up
   return t_gpu < t_host;
 }
 

@@ -132,18 +132,6 @@ int decode_batch_gpu(fgmm_ctx *ctx, dev::Stream stream, std::vector<DecItem> &it
   {
     const double t_done = tr.ms(), mk[5] = {t_enq, t_enq, t_enq, t_done, t_done};
     ctx->log_call(2, count, tr, mk, 0.0, 0.0);
-    // the segment decoder's two rates, as the automatic choice prices them (fgmm_ctx::Rates): whichever term bounded this call
-    double syms = 0, stride_max = 0;
-    for (int k = 0; k < count; ++k) {
-      const DecItem &it = items[which[k]];
-      syms += (double)it.n, stride_max = std::max(stride_max, (double)std::min<int64_t>(it.ckpt_stride, it.n));
-    }
-    const double us = (t_done - t_enq) * 1e3 - kGpuDecodeFixedUs;
-    fgmm_ctx::Rates &r = ctx->rates;
-    if (us > 50.0 && syms >= 200000) {
-      if (stride_max * r.gpu_us_per_stride_symbol >= syms * r.gpu_us_per_symbol) fgmm_ctx::Rates::blend(r.gpu_us_per_stride_symbol, us / stride_max, 0.08, 5.0);
-      else fgmm_ctx::Rates::blend(r.gpu_us_per_symbol, us / syms, 0.00005, 0.003);
-    }
   }
   for (int k = 0; k < count; ++k) {
     DecItem &it = items[which[k]];

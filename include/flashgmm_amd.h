@@ -126,9 +126,8 @@ int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, con
  *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor)
  *   "gpu_decode"  [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded ON THE GPU, a workgroup per segment (no decode-side
  *                       tables at all); a bitstream with a segment the kernel does not settle goes through the table path.  0 = when
- *                       the call has enough segments for the GPU to be the faster decoder (estimated with rates that start from
- *                       MI355X + EPYC 9575F measurements and then follow this context's own calls), 1 = whenever a bitstream carries
- *                       valid notes, 2 = never
+ *                       the call has enough segments for the GPU to be the faster decoder (estimated with rates measured on MI355X +
+ *                       EPYC 9575F: on another host set 1 or 2), 1 = whenever a bitstream carries valid notes, 2 = never
  *   "ckpt_decode" [0]   decode, table path: checkpointed bitstreams are decoded in segments on all host workers: 0 = when the call
  *                       has fewer bitstreams than workers, 1 = always, 2 = never (the notes are ignored)
  *   "spin_lat"    [400000] decode: calls of at most this many latents wait on polled events instead of sleeping ones (-1: never)

@@ -1573,3 +1573,39 @@ def test_stacked_results_are_the_list_forms_sequence(oracle):
     empty = gmc.compress_batch(ys[:0], ss[:0], ms[:0], ws[:0])
     assert len(empty) == 0 and list(empty) == []
     assert gmc.decompress_batch([], [], empty.zero_bitmaps, ss[:0], ms[:0], ws[:0], stacked_output=True).shape == (0, 1, 24, 8, 12)
+
+
+def test_workers_are_kept_off_the_creating_threads_l3():
+    """The host workers stream the decode-side tables through the L3 of the core complex they run on; the library keeps them off the
+    L3 of the thread that created the context (include/flashgmm_amd.h: fgmm_ctx_worker_cpus; profiles/r05_l3_ab.txt) when that leaves
+    them at least 32 CPUs and two per worker.  The reported cpulist must be the process's CPUs minus exactly one L3 domain, and every
+    worker thread must be confined to it."""
+    from flashgmm_amd import parallel as P
+
+    if os.environ.get("FGMM_WORKER_CPUS"):
+        pytest.skip("FGMM_WORKER_CPUS is set")
+    _lib.ctx(0)
+    wc = _lib.worker_cpus(0)
+    mask = os.sched_getaffinity(0)
+    n_workers = _lib.lib().fgmm_ctx_threads(_lib.ctx(0))
+    if not wc:
+        assert len(mask) - 16 < max(32, 2 * n_workers), f"{len(mask)} CPUs, {n_workers} workers: an L3 could have been set aside"
+        return
+    workers = P.cpulist_to_set(wc)
+    free = mask - workers
+    assert workers <= mask and free and len(workers) >= max(32, 2 * n_workers)
+    l3 = P.cpulist_to_set(open(f"/sys/devices/system/cpu/cpu{min(free)}/cache/index3/shared_cpu_list").read()) & mask
+    assert free == l3, (sorted(free), sorted(l3))
+    seen = 0
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            if not open(f"/proc/self/task/{tid}/comm").read().startswith("fgmm-w"):
+                continue
+            allowed = [ln.split(":", 1)[1].strip() for ln in open(f"/proc/self/task/{tid}/status") if ln.startswith("Cpus_allowed_list")][0]
+        except OSError:
+            continue
+        # (a process may hold several contexts - device 0 and "the current device" - each with its own decision)
+        off = mask - P.cpulist_to_set(allowed)
+        assert off and off == P.cpulist_to_set(open(f"/sys/devices/system/cpu/cpu{min(off)}/cache/index3/shared_cpu_list").read()) & mask, (tid, allowed)
+        seen += P.cpulist_to_set(allowed) == workers
+    assert seen >= n_workers
