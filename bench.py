@@ -1104,7 +1104,7 @@ class Env:
 
     def __init__(self, rank, world, local_rank, dev, dist, coll_dev, backend, l3_cpus=None):
         self.rank, self.world, self.local_rank, self.dev, self.dist, self.coll_dev, self.backend = rank, world, local_rank, dev, dist, coll_dev, backend
-        self.l3_cpus = l3_cpus  # own_l3_for_calling_thread(): where timed() keeps the calling thread (the workers are elsewhere)
+        self.l3_cpus = l3_cpus  # plan_l3(): where timed() keeps the calling thread (the workers are elsewhere)
 
     def max_over_ranks(self, v: float) -> float:
         if not self.dist:
