@@ -131,14 +131,14 @@ struct WorkerCpus {
 // ---- host worker pool ----------------------------------------------------------------------------------
 class Pool {
 public:
-  Pool(int n, const WorkerCpus &where) {
+  Pool(int n, const WorkerCpus &where) : slot_((size_t)n), lifo_(getenv("FGMM_POOL_FIFO") == nullptr) {
     for (int i = 0; i < n; ++i)
       th_.emplace_back([this, i, where] {
         char name[16];
         snprintf(name, sizeof name, "fgmm-w%d", i); // (/proc/<pid>/task/<tid>/comm: bench.py's step_diag names the threads that waited for a CPU)
         pthread_setname_np(pthread_self(), name);
         if (where.restricted) (void)sched_setaffinity(0, sizeof where.set, &where.set); // (refused by the kernel: the inherited mask)
-        run();
+        run(i);
       });
   }
   ~Pool() {
@@ -146,17 +146,27 @@ public:
       std::lock_guard<std::mutex> l(m_);
       stop_ = true;
     }
-    cv_.notify_all();
+    for (auto &s : slot_) s.cv.notify_one();
     for (auto &t : th_) t.join();
   }
   int size() const { return (int)th_.size(); }
+  // A job wakes the worker that went idle LAST (a stack of idle workers, each with a condition variable of its own): a decode call
+  // of 24 bitstreams after one of 24 runs on the same 24 workers - their stacks and the decoder's code warm, on the cores the
+  // scheduler had settled them on - where one shared condition variable wakes the workers that have slept longest.
   void submit(std::function<void()> f) {
+    Slot *wake = nullptr;
     {
       std::lock_guard<std::mutex> l(m_);
       q_.push(std::move(f));
       ++pending_;
+      if (!idle_.empty()) {
+        const size_t at = lifo_ ? idle_.size() - 1 : 0;
+        wake = &slot_[(size_t)idle_[at]];
+        idle_.erase(idle_.begin() + (std::ptrdiff_t)at);
+        wake->signalled = true;
+      }
     }
-    cv_.notify_one();
+    if (wake) wake->cv.notify_one();
   }
   void wait_all() {
     std::unique_lock<std::mutex> l(m_);
@@ -164,13 +174,23 @@ public:
   }
 
 private:
-  void run() {
+  struct Slot {
+    std::condition_variable cv;
+    bool signalled = false;
+  };
+  void run(int id) {
+    Slot &me = slot_[(size_t)id];
     for (;;) {
       std::function<void()> f;
       {
         std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [this] { return stop_ || !q_.empty(); });
-        if (stop_ && q_.empty()) return;
+        while (!stop_ && q_.empty()) { // nothing to do: onto the stack of idle workers until a job names this one (or the pool ends)
+          idle_.push_back(id);
+          me.signalled = false;
+          me.cv.wait(l, [&] { return me.signalled || stop_; });
+          if (!me.signalled) idle_.erase(std::find(idle_.begin(), idle_.end(), id)); // (woken by the pool's end: still on the stack)
+        }
+        if (q_.empty()) return; // (stop_, and every job taken)
         f = std::move(q_.front());
         q_.pop();
       }
@@ -182,8 +202,11 @@ private:
     }
   }
   std::vector<std::thread> th_;
+  std::vector<Slot> slot_;
+  std::vector<int> idle_; // ids of the workers that wait for a job, the one that went idle last at the back
+  const bool lifo_;       // (FGMM_POOL_FIFO in the environment: the longest-idle worker first, as a shared condition variable does - A/B)
   std::mutex m_;
-  std::condition_variable cv_, done_cv_;
+  std::condition_variable done_cv_;
   std::queue<std::function<void()>> q_;
   int pending_ = 0;
   bool stop_ = false;
