@@ -2,11 +2,16 @@
 # Dev aid (GPU box): does the NUMA node a bench.py process STARTS on decide how fast its Python runs after bench.py has bound it to the
 # GPU's node?  (The interpreter's heap and every imported module are first-touched where the process starts; binding moves the
 # threads, not the pages.)  The same command started on the GPU's node and on the other one, twice each, taking turns.
+# (Measured in round 5: it does not - two runs started AND kept on the far node: between_calls 1.44 and 0.53 ms; what decides is
+# whether the host workers share the calling thread's L3: profiles/r05_stall_diagnosis.md 7.)
 cd "$(dirname "$0")/.."
 bdf=$(python3 - <<'P'
 import sys; sys.path.insert(0, ".")
 from flashgmm_amd import parallel as P
-print(P.gpu_pci_address(0))
+try:
+    print(P.gpu_pci_address(0))
+except LookupError:  # (the KFD topology is not readable on every box: ask the runtime, in this helper process)
+    print(P.runtime_pci_address(0))
 P
 )
 gnode=$(cat /sys/bus/pci/devices/$bdf/numa_node)
