@@ -853,7 +853,19 @@ def region_phases(device: int, calls_per_step: int, step_ms):
         ph[i]["between_calls"] = step_ms[len(step_ms) - m + i] - sum(c["ms"][5] for c in st)
     if any(set(p_) != set(ph[0]) for p_ in ph):
         return None
-    return {"steps": m, **{k: round(float(np.median([p_[k] for p_ in ph])), 3) for k in sorted(ph[0])}}
+    med = {k: float(np.median([p_[k] for p_ in ph])) for k in sorted(ph[0])}
+    out = {"steps": m, **{k: round(v, 3) for k, v in med.items()}}
+    # a step slower than 1.3x the region's median: which of its phases stretched (more than 0.3 ms over that phase's median)
+    last = step_ms[len(step_ms) - m:]
+    step_med = float(np.median(last))
+    slow = []
+    for i, p_ in enumerate(ph):
+        if last[i] > 1.3 * step_med:
+            moved = {k: [round(p_[k], 2), round(med[k], 2)] for k in med if not k.endswith((".worker_busy", ".worker_wait")) and p_[k] > med[k] + 0.3}
+            slow.append({"step": len(step_ms) - m + i, "ms": round(float(last[i]), 2), "moved_[this,median]": moved})
+    if slow:
+        out["slow_steps"] = slow
+    return out
 
 
 def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):

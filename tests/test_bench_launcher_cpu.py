@@ -209,3 +209,25 @@ def test_l3_plan_partitions_the_cpus(monkeypatch, tmp_path):
     monkeypatch.setenv("FGMM_BENCH_L3", "0")
     monkeypatch.delenv("FGMM_WORKER_CPUS", raising=False)
     assert bench.plan_l3(0, 1)[0] is None and os.environ["FGMM_WORKER_CPUS"] == "inherit"
+
+
+def test_region_phases_names_what_stretched_in_a_slow_step(monkeypatch):
+    """bench.region_phases: the headline region's time by phase from the library's call log, and for a step slower than 1.3x the median
+    the phases that stretched - here a made-up log of three steps whose last one has 5 ms in the head of its first decode call"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from flashgmm_amd import _lib
+
+    def call(kind, ms):
+        return {"kind": kind, "count": 24, "t_begin_ms": 0.0, "ms": ms, "worker_busy_ms": 1.0, "worker_wait_ms": 1.0, "head_ms": [0.05, 0.1, 0.13]}
+
+    log = []
+    for st in range(3):
+        late = 5.0 if st == 2 else 0.0
+        log += [call("encode", [0.1, 0.14, 0.2, 0.8, 0.93, 0.94]), call("decode", [0.05, 0.15 + late, 3.0, 3.6 + late, 3.75 + late, 3.8 + late]),
+                call("decode", [0.05, 0.15, 3.0, 3.6, 3.75, 3.8])]
+    monkeypatch.setattr(_lib, "call_log", lambda dev, last=64: log[-last:])
+    ph = bench.region_phases(0, 3, [9.1, 9.0, 14.2])
+    assert ph["steps"] == 3 and abs(ph["call1_decode.bus"] - 3.45) < 1e-9 and abs(ph["between_calls"] - 0.56) < 0.01
+    assert ph["slow_steps"] == [{"step": 2, "ms": 14.2, "moved_[this,median]": {"call1_decode.head": [5.15, 0.15]}}]
+    assert bench.region_phases(0, 3, [9.1, 9.0]) is not None and bench.region_phases(0, 4, [9.1, 9.0, 9.2]) is None  # (a log of another shape: nothing)
