@@ -65,6 +65,7 @@ struct DecodeCall {
   bool clamped = false, f16 = false, spin = false;
   uint32_t ef_min = kTabNoEf;
   int64_t streams_of_work = 0;
+  bool lead_small = false; // plan_pieces: two pieces, an eighth and the rest (a call with one decoder)
   // ---- plan
   std::vector<int> fast, generic;
   std::vector<Unit> units;
@@ -157,12 +158,17 @@ struct DecodeCall {
     np = 8;
     while (np < kAutoPiecesMax && (int64_t)np * (np + 1) / 2 * 4096 < lat_max) ++np;
     if (lat < 65536) np = 1;                 // pieces only pay for rows that take a while to cross
-    if (decoders == 1) np = std::min(np, 3); // one decoder: pieces only let it start early, and each costs a hand-over (20 us)
+    // one decoder (one image's half, the latency case): it is the bottleneck (1.2 ms for a Kodak half against 0.14 ms of tables on the
+    // bus), so pieces only let it START early - a small first piece (an eighth: it lands 0.09 ms sooner than the half that
+    // "3, 2, 1" made it, and its 0.15 ms of decoding cover the arrival of the rest), then everything else in one
+    if (decoders == 1) np = std::min(np, 2);
     // every round costs this thread ~60 us of launch / counter / copy round trips: no more rounds than the tables' time on the bus
     // is worth (a lone Kodak half: 7.7 MB = 0.14 ms -> 2 pieces; measured 0.45 ms per call against 0.72 with 8)
     np = (int)std::min<int64_t>(np, std::max<int64_t>(1, lat * 58 / 55700 / 60)); // lat * 58 B / 55.7 GB/s in units of 60 us
+    lead_small = decoders == 1 && np == 2;
   }
   int64_t piece_bound(int64_t nblk, int p) const { // first block of piece p: weights np, np-1 ... 1
+    if (lead_small) return p <= 0 ? 0 : p == 1 ? nblk / 8 : nblk;
     const int64_t tot = (int64_t)np * (np + 1) / 2, cum = (int64_t)p * (2 * np - p + 1) / 2;
     return (int64_t)((__int128)nblk * cum / tot);
   }
