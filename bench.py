@@ -47,6 +47,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from scripts import bench_diag as D  # noqa: E402  (host-side forensics: off the default run's path except two counter reads)
+from scripts.bench_diag import _plain_children  # noqa: E402  (helper processes start without a profiler's preload)
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0  # ... what a float4 copy kernel reaches on the chip (same guide): reported beside the spec fraction, never instead of it
 # VALU issue peak of the chip as scripts/valu_peak.hip measures it (profiles/r02_valu_peak.txt): a wave64 fp32 instruction
@@ -58,6 +61,7 @@ TAB_SLOTS_PER_EDGE = {"polya": (134 + 107 * 1.16 + 4) / 2, "as": (150 + 140 * 1.
 
 ELIC_GROUPS = (16, 16, 32, 64, 192)  # elic_gmm.py:92-96
 ELIC_IMAGES = 16  # 4K images in flight per GPU (4.6 GB resident with fp16 parameter planes)
+ELIC_DISTINCT = 4  # ... of the default line's ELIC sub-leg: four generated from their seeds, each resident four times (seven seconds of numpy per image)
 
 
 def workload_shapes(workload: str):
@@ -71,23 +75,6 @@ def stream_seed(rank: int, image: int, stream: int, streams_per_image: int) -> i
     return 1000 * rank + image * streams_per_image + stream
 
 
-class _plain_children:
-    """Helper processes (workload generation, the CPU baselines) never touch the GPU - and must not be started with a profiler's
-    preloaded tool library: under `rocprofv3 --pmc` every process it is loaded into initialises the GPU, a pool of eight of them
-    beside the bench hung a profiling run (and exceeds what a box lets one command put on its card).  The variables are taken out
-    of the environment while a pool starts its workers, and put back."""
-
-    NAMES = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "HSA_TOOLS_LIB", "ROCP_TOOL_ATTACH")
-
-    def __enter__(self):
-        self.saved = {k: os.environ.pop(k) for k in list(os.environ) if k in self.NAMES or k.startswith("ROCPROF")}
-        return self
-
-    def __exit__(self, *exc):
-        os.environ.update(self.saved)
-        return False
-
-
 def _make_stream(args):
     seed, M, h, w, f16 = args
     from flashgmm_amd import testing as T
@@ -98,14 +85,17 @@ def _make_stream(args):
     return y, sg, mu, pi
 
 
-def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: bool = False, keep_host_images: int = 1 << 30):
+def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: bool = False, keep_host_images: int = 1 << 30, distinct=None):
     """-> (host arrays per stream, device tensors per stream, pixels per image).
     kodak24: 2 streams per image, [1,192,32,24]; elic4k: 10 streams per image (5 channel groups x 2 halves of a
     3840x2160 image padded to 2176 rows -> y [1,320,136,240], SURVEY.md §8 sizes).  Large workloads (ELIC: seven seconds of
-    numpy per image) are generated by a pool of processes, stream by stream from their seeds - the same arrays either way."""
+    numpy per image) are generated by a pool of processes, stream by stream from their seeds - the same arrays either way.
+    `distinct` < images: only the first `distinct` images are generated; image i >= distinct is a device-side COPY (its own HBM) of
+    image i mod distinct - the same work per image for every kernel, copy and host decoder, a quarter of the numpy (the ELIC sub-leg)."""
     host, devt = [], []
     shapes, pix = workload_shapes(workload)
-    jobs = [(stream_seed(rank, i, j, len(shapes)), M, h, w, f16) for i in range(images) for j, (M, h, w) in enumerate(shapes)]
+    n_gen = images if not distinct else min(images, distinct)
+    jobs = [(stream_seed(rank, i, j, len(shapes)), M, h, w, f16) for i in range(n_gen) for j, (M, h, w) in enumerate(shapes)]
     n_elem = sum(M * h * w for _, M, h, w, _ in jobs)
     procs = min(len(os.sched_getaffinity(0)), 8, len(jobs)) if n_elem > 8_000_000 else 1
     if procs > 1:
@@ -124,6 +114,10 @@ def make_workload(rank: int, images: int, dev, workload: str = "kodak24", f16: b
             st = _make_stream(jb)
             host.append(st if k < keep_host_images * len(shapes) else None)
             devt.append([torch.from_numpy(a).to(dev) for a in st])
+    for i in range(n_gen, images):
+        for j in range(len(shapes)):
+            host.append(None)
+            devt.append([t.clone() for t in devt[(i % n_gen) * len(shapes) + j]])
     return host, devt, pix
 
 
@@ -297,11 +291,11 @@ def reference_bytes_of_modes(modes: dict, rank: int, shapes, streams_per_image: 
     return out
 
 
-def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank: int, f16: bool, budget_s: float = 10.0, hip_bytes=None,
-                 from_seeds: bool = True):
+def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank: int, f16: bool, budget_s: float = 3.5, hip_bytes=None,
+                 from_seeds: bool = True, extras: bool = False):
     """Time the reference's own coder on this box: ONE core on the same images (bounded sample), then every core this
     process may use, one stream at a time per process (the reference is single-threaded and holds the GIL), then its
-    USE_SIMD=0 path on a smaller sample.  `hip_bytes`: the HIP path's bitstreams of the same streams - the reference encoder's
+    USE_SIMD=0 path on a smaller sample (those two and the C restatement's own time only with `extras`: --baseline-extras).  `hip_bytes`: the HIP path's bitstreams of the same streams - the reference encoder's
     bytes are compared with them, stream by stream (`reference_bytes_equal`: checker use of the baseline)."""
     kind, prepare, code = _cpu_coder()
     host = host[: next((k for k, st in enumerate(host) if st is None), len(host))]  # (legs that kept the first image(s) only)
@@ -317,7 +311,7 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
     passes = 0
     t_start = time.perf_counter()
     ref_bytes = []
-    while passes < 5 and (passes < 1 or time.perf_counter() - t_start < budget_s):
+    while passes < 5 and (passes < 2 or time.perf_counter() - t_start < budget_s):  # (whole passes: 1.0 s each on kodak24)
         t0 = time.perf_counter()
         for st in prepared:
             got, want, b = code(st)
@@ -343,6 +337,8 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
         out["reference_bytes_equal"] = {"streams": len(ref_bytes), "equal": eq, "kind": kind}
         if eq != len(ref_bytes):
             print(f"[bench] PARITY FAILURE: {len(ref_bytes) - eq} of {len(ref_bytes)} bitstreams differ from the {kind} encoder's bytes", file=sys.stderr)
+    if not extras:
+        return out
     # how this repo's C restatement (what `kind: "port"` runs would time) compares with the reference extension on this host:
     # the first image, both coders, so that a line from a checkout without oracle/_ref stays comparable
     if kind == "reference":
@@ -550,196 +546,6 @@ def launch_ranks(a, argv):
     sys.stdout.flush()
 
 
-def _cgroup_dirs():
-    """directories of this process's cgroup and its ancestors as far as they are visible: [(label, dir)] - cgroup v2 (unified)
-    and the v1 cpu controller"""
-    rel2 = rel1 = None
-    try:
-        for ln in open("/proc/self/cgroup"):
-            a = ln.rstrip("\n").split(":", 2)
-            if len(a) == 3:
-                if a[1] == "":
-                    rel2 = a[2]
-                elif "cpu" in a[1].split(","):
-                    rel1 = a[2]
-    except OSError:
-        pass
-    out = []
-    for tag, roots, rel in (("v2", ("/sys/fs/cgroup", "/sys/fs/cgroup/unified"), rel2), ("v1", ("/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"), rel1)):
-        if rel is None:
-            continue
-        for root in roots:
-            r, seen = rel.rstrip("/"), 0
-            while True:
-                d = root + r
-                if os.path.exists(os.path.join(d, "cpu.stat")):
-                    out.append((f"{tag}:{r or '/'}", d))
-                    seen += 1
-                if not r:
-                    break
-                r = r[: r.rfind("/")]
-            if seen:
-                break
-    return out
-
-
-class HostProbe:
-    """What the HOST did to this process during a timed region, step by step: raw reads between steps (a clock, the process's CPU
-    time, a few pread()s of files kept open - parsed after the region), so that a slow step can be told apart: the cgroup's CPU
-    controller throttled it (cpu.stat of every visible level), its threads waited for a CPU (pressure files, per-thread run delay),
-    it spun (CPU time up), or it waited for the device / the bus with its CPUs idle (none of those moved).
-    full=False: cpu.stat + cpu.pressure of the cgroup levels (two or three pread()s, ~10 us per step: the headline's region);
-    full=True: + memory / io pressure, the host-wide /proc/pressure/*, /proc/stat, /proc/loadavg and every thread's schedstat
-    (a few hundred pread()s, ~0.5 ms per step: the diagnostic leg only)."""
-
-    def __init__(self, full: bool = False):
-        self.full, self.fds, self.samples = full, [], []
-        names = ("cpu.stat", "cpu.pressure") + (("memory.pressure", "io.pressure") if full else ())
-        for label, d in _cgroup_dirs():
-            for nm in names:
-                self._open(f"{label}:{nm}", os.path.join(d, nm))
-        if full:
-            for nm in ("cpu", "memory", "io"):
-                self._open(f"host:pressure.{nm}", f"/proc/pressure/{nm}")
-            self._open("host:stat", "/proc/stat")
-            self.comm = {}
-            self._open("host:loadavg", "/proc/loadavg")
-            self._open("host:vmstat", "/proc/vmstat")
-            self._open("self:stat", "/proc/self/stat")
-            try:
-                for tid in os.listdir("/proc/self/task"):
-                    self._open(f"task:{tid}", f"/proc/self/task/{tid}/schedstat")
-                    try:
-                        self.comm[tid] = open(f"/proc/self/task/{tid}/comm").read().strip()
-                    except OSError:
-                        pass
-            except OSError:
-                pass
-
-    def _open(self, key, path):
-        try:
-            fd = os.open(path, os.O_RDONLY)
-            os.pread(fd, 64, 0)
-            self.fds.append((key, fd))
-        except OSError:
-            pass
-
-    def sample(self):
-        raw = []
-        for k, fd in self.fds:
-            try:
-                raw.append(os.pread(fd, 16384 if k == "host:vmstat" else 4096, 0))
-            except OSError:  # (a thread that has exited)
-                raw.append(b"")
-        self.samples.append((time.perf_counter(), time.process_time(), raw))
-
-    def close(self):
-        for k, fd in self.fds:
-            try:
-                if fd >= 0:
-                    os.close(fd)
-            except OSError:
-                pass
-        self.fds = [(k, -1) for k, _ in self.fds]  # (the keys stay: per_step() parses after the region)
-
-    @staticmethod
-    def _parse(key, b):
-        """-> {counter: number} (monotone counters only, except loadavg's runnable count)"""
-        t = b.decode(errors="replace")
-        out = {}
-        if key.endswith("cpu.stat"):
-            for ln in t.splitlines():
-                a = ln.split()
-                if len(a) == 2 and a[0] in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec", "throttled_time", "nr_bursts", "burst_usec"):
-                    out["throttled_usec" if a[0] == "throttled_time" else a[0]] = int(a[1]) // (1000 if a[0] == "throttled_time" else 1)
-        elif "pressure" in key:
-            for ln in t.splitlines():
-                a = ln.split()
-                if a and a[0] in ("some", "full"):
-                    for f in a[1:]:
-                        if f.startswith("total="):
-                            out[a[0] + "_us"] = int(f[6:])
-        elif key == "host:stat":
-            a = t.split("\n", 1)[0].split()
-            if a and a[0] == "cpu":
-                v = [int(x) for x in a[1:]]
-                out["busy_jiffies"] = sum(v[:3]) + sum(v[5:8])  # user nice system + irq softirq steal
-                out["idle_jiffies"] = v[3] + v[4]
-        elif key == "host:vmstat":  # automatic NUMA balancing at work (host-wide counters): PTEs made inaccessible, hinting faults, pages moved
-            for ln in t.splitlines():
-                a = ln.split()
-                if len(a) == 2 and a[0] in ("numa_pte_updates", "numa_hint_faults", "numa_hint_faults_local", "numa_pages_migrated", "pgmigrate_success",
-                                            "pgfault", "thp_split_pmd", "nr_tlb_remote_flush", "nr_tlb_remote_flush_received"):
-                    out[a[0]] = int(a[1])
-        elif key == "self:stat":  # this process's own page faults (minor, major) and context: are the host's fault bursts ours?
-            a = t.rsplit(")", 1)[-1].split()
-            if len(a) > 10:
-                out["minflt"], out["majflt"] = int(a[7]), int(a[9])
-        elif key == "host:loadavg":
-            a = t.split()
-            if len(a) >= 4 and "/" in a[3]:
-                out["runnable_now"] = int(a[3].split("/")[0])
-        elif key.startswith("task:"):
-            a = t.split()
-            if len(a) >= 2:
-                out["exec_ns"], out["run_delay_ns"] = int(a[0]), int(a[1])
-        return out
-
-    def per_step(self):
-        """-> list (one per interval between consecutive samples) of {"ms", "cpu_ms", "<file>.<counter>": delta ...}; thread files
-        are summed into "threads.exec_ms" / "threads.run_delay_ms" """
-        parsed = [(t, c, [self._parse(k, b) for (k, _), b in zip(self.fds, raw)]) for t, c, raw in self.samples]
-        steps = []
-        for (t0, c0, p0), (t1, c1, p1) in zip(parsed, parsed[1:]):
-            d = {"ms": (t1 - t0) * 1e3, "cpu_ms": (c1 - c0) * 1e3}
-            ex = rd = 0
-            for (k, _), a, b in zip(self.fds, p0, p1):
-                for name in b:
-                    if name not in a:
-                        continue
-                    if k.startswith("task:"):
-                        ex, rd = ex + (b[name] - a[name] if name == "exec_ns" else 0), rd + (b[name] - a[name] if name == "run_delay_ns" else 0)
-                    elif name == "runnable_now":
-                        d[f"{k}.{name}"] = b[name]
-                    else:
-                        d[f"{k}.{name}"] = b[name] - a[name]
-            if self.full:
-                d["threads.exec_ms"], d["threads.run_delay_ms"] = ex / 1e6, rd / 1e6
-                per = [(k[5:], (b.get("run_delay_ns", 0) - a.get("run_delay_ns", 0)) / 1e6, (b.get("exec_ns", 0) - a.get("exec_ns", 0)) / 1e6)
-                       for (k, _), a, b in zip(self.fds, p0, p1) if k.startswith("task:") and "run_delay_ns" in a and "run_delay_ns" in b]
-                d["_threads"] = sorted(per, key=lambda x: -x[1])[:6]  # (tid, run delay ms, exec ms): who waited for a CPU
-            steps.append(d)
-        return steps
-
-
-def step_stats(step_s, probe: "HostProbe | None" = None):
-    """per-step wall times of a timed region + what the host did to the process meanwhile (HostProbe, sampled between steps):
-    cpu_ms = CPU time of all threads of the process per step; per cgroup level the CPU controller's throttling over the region and
-    the pressure-stall time (threads runnable but not running) per step"""
-    ms = np.asarray(step_s) * 1e3
-    out = {"min": round(float(ms.min()), 3), "median": round(float(np.median(ms)), 3), "p90": round(float(np.percentile(ms, 90)), 3),
-           "max": round(float(ms.max()), 3), "all": [round(float(v), 2) for v in ms]}
-    if probe is not None and len(probe.samples) >= 2:
-        st = probe.per_step()
-        out["cpu_ms"] = [round(d["cpu_ms"], 1) for d in st]
-        levels = sorted({k.rsplit(":", 1)[0] for k in st[0] if ":cpu.stat." in k or ":cpu.pressure." in k})
-        thr = {}
-        for lv in levels:
-            key, e = lv + ":cpu.stat", {}
-            if key + ".nr_throttled" in st[0]:
-                e = {"periods": sum(d.get(key + ".nr_periods", 0) for d in st), "nr_throttled": sum(d.get(key + ".nr_throttled", 0) for d in st),
-                     "throttled_ms": round(sum(d.get(key + ".throttled_usec", 0) for d in st) / 1e3, 1)}
-            if key + ".usage_usec" in st[0]:
-                e["usage_ms"] = [round(d.get(key + ".usage_usec", 0) / 1e3, 1) for d in st]
-            psi = lv + ":cpu.pressure.some_us"
-            if psi in st[0]:
-                e["cpu_pressure_some_ms"] = [round(d.get(psi, 0) / 1e3, 2) for d in st]
-            thr[lv] = e
-        out["cpu_throttled"] = thr
-        out["nr_throttled"] = sum(v.get("nr_throttled", 0) for v in thr.values())
-    return out
-
-
 def plan_l3(local_rank: int, ranks_on_node: int):
     """flashgmm_amd.parallel.plan_l3 (an L3 domain of its own for the calling thread, the host workers of every rank elsewhere) with the
     bench's switch: FGMM_BENCH_L3=0 leaves workers and calling thread wherever the scheduler puts them (FGMM_WORKER_CPUS=inherit).
@@ -752,299 +558,117 @@ def plan_l3(local_rank: int, ranks_on_node: int):
     return P_.plan_l3(local_rank, ranks_on_node)
 
 
-def _interpreter_work():
-    """a fixed piece of interpreter work (list / dict / ctypes traffic like the wrappers'): ~30 us on an undisturbed Zen 5 core"""
-    import ctypes as C_
-
-    a_ = [i * 3 for i in range(600)]
-    d_ = {i: str(i) for i in range(300)}
-    arr = (C_.c_uint64 * 96)(*range(96))
-    s_ = 0
-    for i in range(96):
-        s_ += arr[i] + len(d_[i]) + a_[i]
-    return s_
-
-
-def settle_calling_thread(max_probe: int = 24):
-    """Moves the calling thread to a CPU whose SMT sibling is idle, before a timed region (FGMM_BENCH_SETTLE=0: off).
-
-    Why: the Python between the native calls (`phases_ms.between_calls`) takes 0.46 ms per step in one process and 1.1 ms in the next on
-    the same box while every native phase is the same (profiles/r05_stall_diagnosis.md 7).  On these shared hosts a few CPUs at any
-    moment run interpreter work at HALF speed - their sibling hyperthread is busy with another tenant (scripts/py_speed_probe.py:
-    0.030 ms on most CPUs, 0.048 - 0.058 on some, different ones a minute later) - and the calling thread, which polls and never
-    sleeps, is never re-placed by the scheduler once it sits on one.  So: time a fixed piece of interpreter work here and on a sample
-    of the allowed CPUs, go to the fastest, and open the affinity mask again (the thread stays where it is until the scheduler has a
-    reason).  ~5 ms, outside the timed region; the worker threads are the scheduler's business as before."""
-    import ctypes as C_
-
-    if os.environ.get("FGMM_BENCH_SETTLE", "1") == "0":
-        return None
-    try:
-        libc = C_.CDLL(None)
-        mask = os.sched_getaffinity(0)
-
-        def speed():
-            best = 1e9
-            for _ in range(5):
-                t0 = time.perf_counter()
-                _interpreter_work()
-                best = min(best, time.perf_counter() - t0)
-            return best * 1e3
-
-        speed()
-        here = int(libc.sched_getcpu())
-        t_here = speed()
-        cpus = sorted(mask - {here})
-        stride = max(1, len(cpus) // max_probe)
-        off = (os.getpid() + here) % stride  # (not the same sample every time)
-        best_c, best_t, probed = here, t_here, 0
-        try:
-            for c in cpus[off::stride][:max_probe]:
-                os.sched_setaffinity(0, {c})
-                speed()
-                t = speed()
-                probed += 1
-                if t < 0.93 * best_t:
-                    best_c, best_t = c, t
-            os.sched_setaffinity(0, {best_c})
-            t_now = speed()
-        finally:
-            os.sched_setaffinity(0, mask)
-        return {"cpu_before": here, "cpu": best_c, "work_ms_before": round(t_here, 4), "work_ms": round(t_now, 4), "cpus_probed": probed,
-                "note": "a fixed piece of interpreter work timed on a sample of the allowed CPUs; the calling thread moved to the fastest (an idle SMT sibling)"}
-    except (OSError, AttributeError) as e:  # pragma: no cover
-        return {"error": str(e)}
-
-
-def call_phases(calls):
-    """the library's phase marks of one step's native calls (fgmm_ctx_call_log) as named durations: a call's head (until its first
-    table copy is queued), bus phase (first copy queued -> last piece seen landed), host tail (-> last coder done), end"""
-    ph = {}
-    for j, c in enumerate(calls):
-        m, nm = c["ms"], f"call{j}_{c['kind']}"
-        ph[nm + ".head"] = m[1]
-        if c["kind"] == "decode" and c.get("head_ms") and c["head_ms"][2] > 0:  # the head in detail: the calling thread's own work until
-            h = c["head_ms"]                                                      # the workers are started | waiting for the first launch's size
-            ph[nm + ".head_host"] = h[1]
-            ph[nm + ".head_first_launch"] = max(h[2] - h[1], 0.0)
-        ph[nm + ".bus"] = max(m[3] - m[1], 0.0)
-        ph[nm + ".host_tail"] = max(m[4] - max(m[3], m[1]), 0.0)
-        ph[nm + ".end"] = max(m[5] - m[4], 0.0)
-        ph[nm + ".worker_busy"] = c["worker_busy_ms"]
-        ph[nm + ".worker_wait"] = c["worker_wait_ms"]
-    return ph
-
-
-def region_phases(device: int, calls_per_step: int, step_ms):
-    """Where a timed region's steps spent their time, from the library's own call log (a ring of 64 calls the library keeps anyway:
-    read AFTER the region, it costs the steps nothing): medians over the region's last steps of every call's phases and of the time
-    between the calls (the calling thread's Python).  None when the log does not hold whole steps of the expected shape."""
-    from flashgmm_amd import _lib
-
-    m = min(len(step_ms), 64 // max(calls_per_step, 1))
-    log = _lib.call_log(device, m * calls_per_step)
-    if m < 1 or len(log) != m * calls_per_step:
-        return None
-    steps = [log[i * calls_per_step:(i + 1) * calls_per_step] for i in range(m)]
-    if any(st[0]["kind"] != "encode" or any(c["kind"] == "encode" for c in st[1:]) for st in steps):
-        return None
-    ph = [call_phases(st) for st in steps]
-    for i, st in enumerate(steps):
-        ph[i]["between_calls"] = step_ms[len(step_ms) - m + i] - sum(c["ms"][5] for c in st)
-    if any(set(p_) != set(ph[0]) for p_ in ph):
-        return None
-    med = {k: float(np.median([p_[k] for p_ in ph])) for k in sorted(ph[0])}
-    out = {"steps": m, **{k: round(v, 3) for k, v in med.items()}}
-    # a step slower than 1.3x the region's median: which of its phases stretched (more than 0.3 ms over that phase's median)
-    last = step_ms[len(step_ms) - m:]
-    step_med = float(np.median(last))
-    slow = []
-    for i, p_ in enumerate(ph):
-        if last[i] > 1.3 * step_med:
-            moved = {k: [round(p_[k], 2), round(med[k], 2)] for k in med if not k.endswith((".worker_busy", ".worker_wait")) and p_[k] > med[k] + 0.3}
-            slow.append({"step": len(step_ms) - m + i, "ms": round(float(last[i]), 2), "moved_[this,median]": moved})
-    if slow:
-        out["slow_steps"] = slow
-    return out
-
-
-def step_diag(leg, schedule: str, steps: int, configs, block: int = 20):
-    """The self-diagnosing leg.  `configs` = ["48", "16", "48+pieces=4" ...]: host workers, optionally
-    "+option=value" settings of the library (an A/B inside one run); the configurations take turns in blocks of `block` steps until each has run `steps` steps (boxes differ and drift: only interleaved blocks compare).
-    Every step is sampled with the full HostProbe and the library's call log (phase marks of the step's native calls); a helper
-    process (scripts/bin/host_watch) samples the host's count of runnable tasks and its own wake-up lateness every 0.5 ms.  For every
-    step slower than 1.3x its configuration's median the output says WHICH part stretched - the calling thread's glue, a call's
-    head (until its first table copy is queued), its bus phase (first copy queued -> last piece seen landed), its host tail (last
-    piece landed -> last coder done) - next to what the host did meanwhile: throttling at every cgroup level, pressure-stall time,
-    the run delay of this process's threads (runnable, not running) and which threads, CPU time, the host's runnable tasks."""
-    import subprocess
-
-    from flashgmm_amd import _lib
-
-    lr = leg.env.local_rank
-    before = _lib.lib().fgmm_ctx_threads(_lib.ctx(lr))
-    calls_per_step = 1 + (leg.spi if schedule == "codec" else 1)
-
-    phases = call_phases
-
-    rounds = max(1, (steps + block - 1) // block)
-    watch = None
-    exe = os.path.join(ROOT, "scripts", "bin", "host_watch")
-    if os.path.exists(exe):
-        try:
-            with _plain_children():
-                watch = subprocess.Popen([exe, str(60.0)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-        except OSError:
-            watch = None
-    per = {c: {"st": [], "ph": [], "t": [], "comm": {}} for c in configs}
-    saved_opts = {}
-    wide = None
-    if leg.env.l3_cpus:  # as in timed(): the calling thread on its own L3 domain (helper processes have been started by now)
-        try:
-            wide = os.sched_getaffinity(0)
-            os.sched_setaffinity(0, leg.env.l3_cpus)
-        except OSError:
-            wide = None
-    try:
-        for _ in range(rounds):
-            for cfg in configs:
-                pool_, *opts_ = str(cfg).split("+")
-                _lib.set_threads(lr, int(pool_))
-                for kv in opts_:
-                    saved_opts.setdefault(kv.split("=")[0], _lib.get_option(lr, kv.split("=")[0]))
-                    _lib.set_option(lr, kv.split("=")[0], int(kv.split("=")[1]))
-                for _ in range(2):
-                    leg.step(schedule)
-                torch.cuda.synchronize()
-                probe = HostProbe(full=True)
-                logs = []
-                probe.sample()
-                for _ in range(block):
-                    leg.step(schedule)
-                    probe.sample()
-                    logs.append(_lib.call_log(lr, calls_per_step))
-                torch.cuda.synchronize()
-                probe.close()
-                st = probe.per_step()
-                ph = [phases(lg) for lg in logs]
-                for i in range(block):
-                    ph[i]["python_glue"] = st[i]["ms"] - sum(c["ms"][5] for c in logs[i])
-                e = per[cfg]
-                e["st"] += st
-                e["ph"] += ph
-                e["t"] += [(a[0] * 1e3, b[0] * 1e3) for a, b in zip(probe.samples, probe.samples[1:])]  # CLOCK_MONOTONIC ms, as host_watch's
-                e["comm"].update(probe.comm)
-                for k_, v_ in saved_opts.items():
-                    _lib.set_option(lr, k_, v_)
-    finally:
-        if wide is not None:
-            os.sched_setaffinity(0, wide)
-        _lib.set_threads(lr, before)
-        for k_, v_ in saved_opts.items():
-            _lib.set_option(lr, k_, v_)
-        wt = wr = wl = None
-        if watch is not None:
-            watch.terminate()
-            try:
-                raw = watch.communicate(timeout=10)[0].decode(errors="replace").split()
-                k = len(raw) // 3 * 3
-                wt, wr, wl = (np.asarray(raw[j:k:3], dtype=np.float64) for j in range(3))
-            except Exception:
-                wt = None
-    out = {"host_threads_tried": list(configs), "block": block, "host_watch": None}
-    if wt is not None and len(wt):
-        # the host's runnable tasks: how often do they surge (other tenants' threads, all runnable at once), and at which cadence?
-        r_med = float(np.median(wr))
-        thr = max(3.0 * r_med, r_med + 64.0)
-        up = np.flatnonzero((wr > thr) & (np.concatenate(([0.0], wr[:-1])) <= thr))  # rising edges
-        at = wt[up] - wt[0]
-        gaps = np.diff(at)
-        out["host_watch"] = {
-            "samples": int(len(wt)), "runnable_median": r_med, "runnable_p99": float(np.percentile(wr, 99)), "runnable_max": float(wr.max()),
-            "surge_threshold": thr, "surges": int(len(up)), "surges_per_s": round(len(up) / max((wt[-1] - wt[0]) / 1e3, 1e-9), 1),
-            "surge_gap_ms_median": round(float(np.median(gaps)), 1) if len(gaps) else None,
-            "surge_gaps_ms_first_20": [round(float(g), 1) for g in gaps[:20]],
-            "watcher_late_over_1ms": int((wl > 1.0).sum()), "watcher_late_max_ms": round(float(wl.max()), 2),
-            "note": "scripts/bin/host_watch: /proc/loadavg's runnable tasks of the whole host every 0.5 ms + the lateness of its own wake-ups"}
-    for cfg in configs:
-        e = per[cfg]
-        st, ph, n = e["st"], e["ph"], len(e["st"])
-        ms = np.asarray([d["ms"] for d in st])
-        med = float(np.median(ms))
-        slow = [i for i in range(n) if ms[i] > 1.3 * med]
-        normal = [i for i in range(n) if ms[i] <= 1.15 * med]
-        keys = sorted((set(st[0]) | set(ph[0])) - {"_threads"})
-        keys = [k for k in keys if not k.endswith((".nr_periods", ".usage_usec"))]
-
-        def val(i, k):
-            return ph[i][k] if k in ph[i] else st[i].get(k, 0)
-
-        def watched(i):
-            """the host's runnable tasks and the watcher's lateness while step i ran"""
-            if wt is None or not len(wt):
-                return None
-            m = (wt >= e["t"][i][0]) & (wt <= e["t"][i][1])
-            return (float(wr[m].max()), float(wl[m].max())) if m.any() else None
-
-        norm = {k: float(np.median([val(i, k) for i in normal])) for k in keys} if normal else {}
-        rows = []
-        for i in slow[:10]:
-            row = {"step": i, "ms": round(float(ms[i]), 2)}
-            moved = {}
-            for k in keys:
-                v, n0 = val(i, k), norm.get(k, 0.0)
-                if k.endswith(("_us", "_usec")):
-                    if v - n0 > 300:
-                        moved[k] = [round(v / 1e3, 2), round(n0 / 1e3, 2), "ms"]
-                elif k.endswith((".nr_throttled", ".nr_bursts", ".majflt")):
-                    if v > 0:
-                        moved[k] = [v, n0]
-                elif k.endswith(("jiffies", "runnable_now")) or k.startswith("host:vmstat"):
-                    continue
-                elif k.endswith(".minflt"):
-                    if v - n0 > 1000:
-                        moved[k] = [v, n0]
-                elif k != "ms" and v - n0 > 0.3:
-                    moved[k] = [round(v, 2), round(n0, 2)]
-            row["moved_[slow,normal]"] = moved
-            w = watched(i)
-            if w:
-                row["host_runnable_max"], row["watcher_late_max_ms"] = w[0], round(w[1], 2)
-            row["host_pgfault"] = st[i].get("host:vmstat.pgfault")
-            row["threads_that_waited_[name,run_delay_ms,exec_ms]"] = [[e["comm"].get(t, t), round(rd, 2), round(ex, 2)] for t, rd, ex in st[i].get("_threads", []) if rd > 0.2]
-            rows.append(row)
-        wn = [w for w in map(watched, normal) if w]
-        thr_total = sum(int(d.get(k, 0)) for d in st for k in d if k.endswith(".nr_throttled"))
-        rd_slow = float(np.median([st[i]["threads.run_delay_ms"] for i in slow])) if slow else None
-        ws = [w for w in map(watched, slow) if w]
-        finding = (f"{len(slow)} of {n} steps slower than 1.3x the median ({med:.2f} ms)" +
-                   (f": in those the process's threads stood runnable-but-not-running for {rd_slow:.1f} ms per step "
-                    f"({norm.get('threads.run_delay_ms', 0.0):.2f} in a normal step)" if slow else "") +
-                   (f" while the HOST's runnable tasks peaked at {np.median([w[0] for w in ws]):.0f} "
-                    f"({np.median([w[0] for w in wn]):.0f} in a normal step)" if ws and wn else "") +
-                   f"; the cgroup's CPU controller throttled the process {thr_total} times (every visible level summed)")
-        out[str(cfg)] = {
-            "finding": finding,
-            "host_threads": int(str(cfg).split("+")[0]), "options": str(cfg).split("+")[1:], "steps": n, "median_ms": round(med, 3), "p90_ms": round(float(np.percentile(ms, 90)), 3),
-            "max_ms": round(float(ms.max()), 3), "mean_ms": round(float(ms.mean()), 3), "p90_over_median": round(float(np.percentile(ms, 90)) / med, 3),
-            "slow_steps": len(slow), "all_ms": [round(float(v), 2) for v in ms],
-            "run_delay_ms_per_step": {"normal_median": round(norm.get("threads.run_delay_ms", 0.0), 2),
-                                      "slow_median": round(float(np.median([st[i]["threads.run_delay_ms"] for i in slow])), 2) if slow else None},
-            "host_runnable_max_per_step": {"normal_median": float(np.median([w[0] for w in wn])) if wn else None,
-                                           "slow_median": float(np.median([w[0] for w in map(watched, slow) if w])) if slow and wt is not None and len(wt) else None},
-            "normal_medians": {k: round(v / 1e3, 3) if k.endswith(("_us", "_usec")) else round(v, 3) for k, v in norm.items()
-                               if not k.endswith(("jiffies",)) and not k.startswith("host:vmstat") and (abs(v) > 1e-9 or k.endswith("nr_throttled"))},
-            "slow": rows,
-        }
-    return out
-
-
 _REAL_STDOUT = None
+LINE_LIMIT = 4096  # the driver keeps ~8 KB of stdout: the ONE line it parses stays under half of that, asserted (BENCH_r05 was 22 KB: unparsed)
 
 
-def emit(line: dict) -> None:
+def step_stats(step_s, cpu_s=None, throttled=None):
+    """per-step wall times of a timed region; cpu_ms = CPU time of all threads of the process per step (time.process_time between
+    steps); nr_throttled = the cgroup CPU controller's throttling count over the region, every visible level summed (two reads)"""
+    ms = np.asarray(step_s) * 1e3
+    out = {"min": round(float(ms.min()), 3), "median": round(float(np.median(ms)), 3), "p90": round(float(np.percentile(ms, 90)), 3),
+           "max": round(float(ms.max()), 3), "all": [round(float(v), 2) for v in ms]}
+    if cpu_s is not None:
+        out["cpu_ms"] = [round(float(v) * 1e3, 1) for v in cpu_s]
+    if throttled is not None:
+        out["nr_throttled"] = int(throttled)
+    return out
+
+
+def _pick(d, *keys):
+    """the named keys of a dict that has them (None / absent ones dropped)"""
+    return {k: d[k] for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+def _eq(d):
+    """reference_bytes_equal without its notes"""
+    return _pick(d, "streams", "equal", "kind", "error") if isinstance(d, dict) else None
+
+
+def summary_line(full: dict, detail_path=None) -> dict:
+    """The ONE line of stdout: the driver's contract + `roofline` + `cpu_baseline` + one number per extra leg.  Everything else
+    (per-step arrays, phases, notes, the diagnostic legs) is `full`, which goes to bench_detail.json and stderr."""
+    g = full.get
+    out = {k: g(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                             "dtype", "data")}
+    sm = g("step_ms") or {}
+    out["step_ms"] = _pick(sm, "min", "median", "p90", "max")
+    if sm.get("cpu_ms"):
+        out["step_ms"]["cpu_ms_median"] = round(float(np.median(sm["cpu_ms"])), 1)
+    if sm.get("nr_throttled") is not None:
+        out["step_ms"]["nr_throttled"] = sm["nr_throttled"]
+    if isinstance(sm.get("phases_ms"), dict) and "between_calls" in sm["phases_ms"]:
+        out["step_ms"]["between_calls"] = sm["phases_ms"]["between_calls"]
+    out["config"] = _pick(g("config") or {}, "workload", "schedule", "images_per_gpu", "K", "approx_mode", "param_dtype", "coded_symbols_per_gpu",
+                          "host_threads_per_gpu", "binding", "checkpoint_stride", "streams_per_gpu", "one_device_rehearsal")
+    rf = g("roofline")
+    if isinstance(rf, dict):
+        out["roofline"] = _pick(rf, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic_source", "launch_ms", "bytes_per_launch")
+        out["roofline"]["traffic"] = rf.get("traffic")  # (null when no PMC measurement of this configuration is on file)
+        if isinstance(rf.get("valu"), dict):
+            out["roofline"]["valu"] = _pick(rf["valu"], "valu_frac")
+    rd = g("roofline_decode")
+    if isinstance(rd, dict):
+        out["roofline_decode"] = _pick(rd, "kernel", "bound", "ms_per_step", "valu_frac", "hbm_frac", "alone")
+    cb = g("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "sample", "ms_per_image", "throughput_speedup")
+        out["cpu_baseline"]["reference_bytes_equal"] = _eq(cb.get("reference_bytes_equal"))
+    lt = g("latency_ms")
+    if isinstance(lt, dict):
+        out["latency_ms"] = _pick(lt, "as_codec", "reference_cpu", "speedup_plain", "speedup_checkpointed")
+    for k in ("checkpointed", "upper_bound", "as_codec", "one_host_thread"):
+        if isinstance(g(k), dict):
+            out[k] = _pick(g(k), "value")
+    if isinstance(g("modes"), dict):
+        out["modes"] = {m: {"value": e.get("value"), "symtab": _pick(e.get("symtab") or {}, "frac"), "reference_bytes_equal": _eq(e.get("reference_bytes_equal"))}
+                        for m, e in g("modes").items()}
+    el = g("elic4k")
+    if isinstance(el, dict):
+        out["elic4k"] = {"value": el.get("value"), "symtab": _pick(el.get("symtab") or {}, "frac"),
+                         "reference_bytes_equal": _eq(el.get("reference_bytes_equal")),
+                         "cpu_baseline": _pick(el.get("cpu_baseline") or {}, "value"), **_pick(el, "error")}
+        if isinstance(el.get("checkpointed"), dict):
+            out["elic4k"]["checkpointed"] = _pick(el["checkpointed"], "value")
+    if isinstance(g("head_fused"), dict):
+        out["head_fused"] = _pick(g("head_fused"), "value", "mfma_frac", "head_ms", "unfused_ms", "bytes_equal_unfused")
+    rk = g("ranks") or {}
+    out["ranks"] = _pick(rk, "backend", "rccl_ranks", "ms_per_step", "host_threads_per_gpu", "result_checked_ranks")
+    if isinstance(rk.get("allgather_ms"), dict):
+        out["ranks"]["allgather_ms"] = _pick(rk["allgather_ms"], "issue", "exposed")
+    elif rk.get("allgather_ms") is not None:
+        out["ranks"]["allgather_ms"] = rk["allgather_ms"]
+    if "host_cpu_budget" in rk:
+        out["ranks"]["host_cpu_budget"] = rk["host_cpu_budget"]
+    if isinstance(g("reference_md5"), dict):
+        out["reference_md5_equal"] = g("reference_md5").get("md5_equal_reference")
+    if g("host_throttled"):
+        out["host_throttled"] = True
+    if g("bench_s") is not None:
+        out["bench_s"] = g("bench_s")
+    if detail_path:
+        out["detail"] = detail_path
+    return out
+
+
+def emit(full: dict, detail: bool = True) -> None:
+    """Rank 0's output: the whole result to bench_detail.json (FGMM_BENCH_DETAIL names another path; "" = none) and to stderr, the
+    summary - ONE line under LINE_LIMIT bytes - to stdout."""
+    detail_path = os.environ.get("FGMM_BENCH_DETAIL", "bench_detail.json") if detail else None
+    blob = json.dumps(full)
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                f.write(blob + "\n")
+        except OSError as e:
+            print(f"[bench] could not write {detail_path}: {e}", file=sys.stderr)
+            detail_path = None
+    if detail:
+        print("[bench detail] " + blob, file=sys.stderr)
+    line = json.dumps(summary_line(full, detail_path))
+    assert len(line) < LINE_LIMIT, f"bench.py's stdout line is {len(line)} bytes: the driver's window is ~8 KB, the limit here {LINE_LIMIT}"
     out = _REAL_STDOUT or sys.stdout
-    out.write(json.dumps(line) + "\n")
+    out.write(line + "\n")
     out.flush()
 
 
@@ -1106,7 +730,7 @@ def dryrun(a, world, rank):
               "ranks": {"backend": "gloo" if world > 1 else None, "rccl_ranks": 0,
                         "ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank],
                         "host_threads_per_gpu": per_rank_threads, "host_cpu_budget": _lib.host_cpu_budget(),
-                        "allgather_ms": round(float(np.mean(t_gather[-a.steps:])) * 1e3, 4)}})
+                        "allgather_ms": round(float(np.mean(t_gather[-a.steps:])) * 1e3, 4)}}, detail=False)
     if world > 1:
         dist.destroy_process_group()
 
@@ -1117,6 +741,7 @@ class Env:
     def __init__(self, rank, world, local_rank, dev, dist, coll_dev, backend, l3_cpus=None):
         self.rank, self.world, self.local_rank, self.dev, self.dist, self.coll_dev, self.backend = rank, world, local_rank, dev, dist, coll_dev, backend
         self.l3_cpus = l3_cpus  # plan_l3(): where timed() keeps the calling thread (the workers are elsewhere)
+        self.diag = False  # --diag
 
     def max_over_ranks(self, v: float) -> float:
         if not self.dist:
@@ -1131,7 +756,7 @@ class Leg:
     stage-minor; stage s of the decode schedule = stream s of every image."""
 
     def __init__(self, env: Env, workload: str, images: int, mode: str, f16: bool, keep_host_images: int = 1 << 30, share=None, latents_dir=None,
-                 pixels_per_image=None):
+                 pixels_per_image=None, distinct=None):
         from flashgmm_amd import GaussianMixtureConditional
 
         self.env, self.workload, self.images, self.mode, self.f16 = env, workload, images, mode, f16
@@ -1154,7 +779,7 @@ class Leg:
             else:
                 self.ys, self.ss, self.ms, self.ws = ([t[k] for t in devt] for k in range(4))
         elif share is None:
-            self.host, devt, self.pix_per_image = make_workload(env.rank, images, env.dev, workload, f16, keep_host_images)
+            self.host, devt, self.pix_per_image = make_workload(env.rank, images, env.dev, workload, f16, keep_host_images, distinct)
             self.n_streams = len(devt)
             self.hw_of = [t[0].shape[2] * t[0].shape[3] for t in devt]
             self.shapes = sorted({tuple(t[0].shape) for t in devt})
@@ -1251,29 +876,35 @@ class Leg:
                 os.sched_setaffinity(0, self.env.l3_cpus)
             except OSError:  # (the allowed CPUs have changed under us: go on without)
                 wide, self.env.l3_cpus = None, None
-        settled = settle_calling_thread()
+        settled = D.settle_calling_thread()
         if settled is not None or wide is not None:
             self.step(schedule)  # (one more untimed step: the 5 ms of probing / a migration must not be the idle gap before the region)
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
-        probe = HostProbe()
-        probe.sample()
+        probe = D.HostProbe() if self.env.diag else None  # (--diag: cgroup / pressure files between steps; default: two clocks)
+        thr0 = D.throttle_count()
+        marks = [(time.perf_counter(), time.process_time())]
         for _ in range(steps):
             self.last["res"], self.last["outs"] = self.step(schedule, record=record)
-            probe.sample()
+            marks.append((time.perf_counter(), time.process_time()))
+            if probe is not None:
+                probe.sample()
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
         t1 = time.perf_counter()
+        thr1 = D.throttle_count()
         if wide is not None:
             os.sched_setaffinity(0, wide)
-        probe.close()
-        marks = [sm[0] for sm in probe.samples]
-        stats = step_stats(np.diff(marks), probe)
+        wall, cpu = np.diff([m[0] for m in marks]), np.diff([m[1] for m in marks])
+        stats = step_stats(wall, cpu, None if thr0 is None or thr1 is None else thr1 - thr0)
         stats["calling_thread"] = settled
-        stats["phases_ms"] = region_phases(self.env.local_rank, 1 + (self.spi if schedule == "codec" else 1), [x * 1e3 for x in np.diff(marks)])
-        return t1 - marks[0], stats
+        stats["phases_ms"] = D.region_phases(self.env.local_rank, 1 + (self.spi if schedule == "codec" else 1), [x * 1e3 for x in wall])
+        if probe is not None:
+            probe.close()
+            stats["host_probe"] = D.probe_stats(probe)
+        return t1 - marks[0][0], stats
 
     def check_last(self):
         """correctness of what was timed: decode(encode(y)) == round(y) for every stream of this rank"""
@@ -1350,6 +981,7 @@ def ka1_check(leg: Leg, res):
 
 
 def main(argv=None):
+    t_bench0 = time.perf_counter()
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1373,9 +1005,10 @@ def main(argv=None):
     ap.add_argument("--checkpoint-stride", type=_stride, default=1024,
                     help="stride of the `checkpointed` extra legs: symbols between the out-of-band notes of the coder state (16 B each)")
     ap.add_argument("--host-threads", type=int, default=0, help="host rANS workers per GPU (0: this rank's share of the CPU budget)")
-    ap.add_argument("--diag-steps", type=int, default=40,
-                    help="steps per pool size of the self-diagnosing `step_diag` leg (0: skip): full host probes + the library's call log, "
-                         "slow steps explained phase by phase")
+    ap.add_argument("--diag", action="store_true",
+                    help="host-side forensics (scripts/bench_diag.py), off by default: cgroup / pressure probes between the steps of every timed "
+                         "region and the self-diagnosing `step_diag` leg - to bench_detail.json and stderr, never to the stdout line")
+    ap.add_argument("--diag-steps", type=int, default=40, help="--diag: steps per pool size of the `step_diag` leg")
     ap.add_argument("--diag-pools", default="", help="step_diag: comma-separated host-worker counts that take turns in blocks of 20 steps (default: the "
                                                      "context's pool and - when that is a different number - as many workers as the quota has CPUs)")
     ap.add_argument("--latents-dir", default=None,
@@ -1384,6 +1017,9 @@ def main(argv=None):
                          "Kodak PNGs, neither of which exists offline: this is the hook for whoever has them")
     ap.add_argument("--pixels-per-image", type=int, default=None, help="with --latents-dir, when the files carry no {'pixels': H*W} entry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--baseline-extras", action="store_true",
+                    help="cpu_baseline also times the reference on every core (one stream per process), its USE_SIMD=0 path and this repo's C "
+                         "restatement beside it: ~20 s more; the default line carries the one-core number north_star names")
     ap.add_argument("--no-extras", action="store_true", help="skip upper_bound / latency / per-thread legs (profiling runs)")
     ap.add_argument("--no-sublegs", action="store_true",
                     help="skip the `modes` (configs[2]) and `elic4k` (configs[4]) legs of the default kodak24 line")
@@ -1445,6 +1081,7 @@ def main(argv=None):
             dist = None
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     env = Env(rank, world, local_rank, dev, dist, coll_dev, backend)
+    env.diag = a.diag
 
     from flashgmm_amd import GaussianMixtureConditional, _lib, container as Cn
 
@@ -1557,7 +1194,7 @@ def main(argv=None):
                 one_image(True)
                 extras["latency_ms"]["as_codec_checkpointed_stride_256"] = round(float(np.median([one_image(True) for _ in range(reps)])), 3)
                 extras["latency_ms"]["checkpoint_bytes_stride_256"] = int(sum(16 * len(x[0][0].ckpt) for x in r_256))
-            if a.diag_steps > 0:
+            if a.diag and a.diag_steps > 0:
                 threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
                 if a.diag_pools:
                     cfgs = [x for x in a.diag_pools.split(",") if x]
@@ -1565,7 +1202,7 @@ def main(argv=None):
                     by_quota = max(1, int(_lib.host_cpu_budget()["cpus"] // _lib.ranks_on_node()))
                     cfgs = [str(threads)] + ([str(by_quota)] if by_quota != threads else [])
                 try:
-                    extras["step_diag"] = step_diag(leg, a.schedule, a.diag_steps, cfgs)
+                    extras["step_diag"] = D.step_diag(leg, a.schedule, a.diag_steps, cfgs)
                 except Exception as e:  # pragma: no cover - a diagnostic must not cost the run its line
                     extras["step_diag"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             # one host thread instead of the pool: what the GPU path is worth per host core
@@ -1607,14 +1244,14 @@ def main(argv=None):
             del modes[m]["_bytes"]
         extras["modes"] = modes
         try:
-            el = Leg(env, "elic4k", ELIC_IMAGES, "polya", True, keep_host_images=1)
+            el = Leg(env, "elic4k", ELIC_IMAGES, "polya", True, keep_host_images=1, distinct=ELIC_DISTINCT)
             for _ in range(2):  # (the first steps grow the pinned receive area to this workload's 2.8 GB per stage)
                 el.step("codec")
             dt_e, st_e = el.timed("codec", 3, record=True)
             res_e = el.check_last()
             nc_e, sym_ms_e, ach_e = el.symtab_roofline(res_e)
             tb_e = float(np.mean(el.tab_bytes))
-            elic = {"config": {"workload": "elic4k", "images_per_gpu": ELIC_IMAGES, "param_dtype": "f16", "schedule": "codec", "decode_calls_per_step": el.spi,
+            elic = {"config": {"workload": "elic4k", "images_per_gpu": ELIC_IMAGES, "distinct_images": ELIC_DISTINCT, "param_dtype": "f16", "schedule": "codec", "decode_calls_per_step": el.spi,
                                "coded_symbols_per_gpu": nc_e, "approx_mode": "polya"},
                     "value": round(el.mpix(3, dt_e), 2), "unit": "Mpixels/s", "steps": 3, "ms_per_step": round(dt_e / 3 * 1e3, 3), "step_ms": st_e["all"],
                     "symtab": {"launch_ms": round(sym_ms_e, 4), "achieved": round(ach_e, 1), "unit": "GB/s", "frac": round(ach_e / HBM_PEAK_GBS, 4),
@@ -1734,7 +1371,8 @@ def main(argv=None):
             print(f"[bench] THE CGROUP'S CPU CONTROLLER THROTTLED THIS PROCESS DURING THE TIMED REGION ({step_ms.get('cpu_throttled')}): `value` "
                   f"measures the quota, not the path - fewer host workers (--host-threads, FGMM_WORKERS_PER_CPU) or a larger quota", file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(leg.host, leg.shapes1, pix_per_image, spi, rank, f16, hip_bytes=[bytes(r[0][0]) for r in res], from_seeds=not leg.real)
+            cb = cpu_baseline(leg.host, leg.shapes1, pix_per_image, spi, rank, f16, hip_bytes=[bytes(r[0][0]) for r in res], from_seeds=not leg.real,
+                              extras=a.baseline_extras)
             if "one_host_thread" in extras and cb.get("value"):
                 cb["per_thread_speedup"] = round(extras["one_host_thread"]["value"] / cb["value"], 1)
             if cb.get("all_cores", {}).get("value"):
@@ -1759,6 +1397,7 @@ def main(argv=None):
                               "in 0.33 ms and decodes in 1.1-1.5 ms on one core (9-11 ns per symbol, a dependent chain), and the codec's two "
                               "halves decode one after the other: 0.5 + 2 x 1.5 ms against the reference's 42 ms is 12x at best")
             out["cpu_baseline"] = cb
+        out["bench_s"] = round(time.perf_counter() - t_bench0, 1)  # this process, argument parsing to here (imports excluded)
         emit(out)
     if dist:
         dist.destroy_process_group()

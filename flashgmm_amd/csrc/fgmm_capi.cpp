@@ -293,6 +293,11 @@ int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {
   if (!c) return fail(FGMM_ERR_NOMEM, "ctx");
   c->device = device;
   c->worker_cpus = WorkerCpus::choose(n_threads);
+  if (!c->worker_cpus.error.empty()) {
+    const std::string why = c->worker_cpus.error;
+    delete c;
+    return fail(FGMM_ERR_INVALID, "%s", why.c_str());
+  }
   c->pool = new Pool(n_threads, c->worker_cpus);
   for (const OptName &o : kOpts)
     if (o.env && getenv(o.env)) c->opt.*(o.field) = std::min(std::max<int64_t>(atoll(getenv(o.env)), o.lo), o.hi);
@@ -393,6 +398,7 @@ int fgmm_ctx_set_threads(fgmm_ctx *ctx, int n_threads) {
   if (n_threads <= 0) n_threads = fgmm_host_thread_budget(1);
   if (n_threads > 256) return fail(FGMM_ERR_INVALID, "n_threads %d", n_threads);
   if (ctx->pool && ctx->pool->size() == n_threads) return FGMM_OK;
+  ctx->worker_cpus.resize(n_threads);
   Pool *fresh = new (std::nothrow) Pool(n_threads, ctx->worker_cpus);
   if (!fresh) return fail(FGMM_ERR_NOMEM, "worker pool");
   delete ctx->pool;

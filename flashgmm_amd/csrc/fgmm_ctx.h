@@ -67,6 +67,14 @@ struct Trace {
 struct WorkerCpus {
   cpu_set_t set;
   bool restricted = false; // false: the workers inherit the creating thread's mask
+  bool automatic = false;  // `set` = the creating thread's mask minus its L3 (room() decides per pool size whether it is used)
+  int cpus = 0;            // CPUs in `set`
+  std::string error;       // FGMM_WORKER_CPUS could not be honoured: fgmm_ctx_create fails with this text
+  // the automatic rule: the workers leave the creating thread's L3 alone when that leaves them at least 32 CPUs and two per worker
+  bool room(int n_threads) const { return cpus >= std::max(32, 2 * n_threads); }
+  void resize(int n_threads) { // fgmm_ctx_set_threads: the room rule is re-evaluated for the new pool (an explicit list stays)
+    if (automatic) restricted = room(n_threads);
+  }
   static bool parse(const char *text, cpu_set_t *out) {
     CPU_ZERO(out);
     int n = 0;
@@ -92,13 +100,26 @@ struct WorkerCpus {
     CPU_ZERO(&w.set);
     const char *e = getenv("FGMM_WORKER_CPUS");
     if (e && !strcmp(e, "inherit")) return w;
+    cpu_set_t have, l3;
+    const bool have_mask = sched_getaffinity(0, sizeof have, &have) == 0;
     if (e && *e) {
-      w.restricted = parse(e, &w.set);
+      // an explicit list is honoured exactly or not at all: a typo must not silently put 48 workers on the caller's L3
+      cpu_set_t asked;
+      if (!parse(e, &asked)) {
+        w.error = std::string("FGMM_WORKER_CPUS='") + e + "' is neither \"inherit\" nor a cpulist like \"16-63,80-127\"";
+        return w;
+      }
+      for (int c = 0; c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &asked) && (!have_mask || CPU_ISSET(c, &have))) CPU_SET(c, &w.set), ++w.cpus; // (the EFFECTIVE set: what
+      if (w.cpus == 0) {                                           //  sched_setaffinity would grant; fgmm_ctx_worker_cpus reports it)
+        w.error = std::string("FGMM_WORKER_CPUS='") + e + "' names no CPU this process may run on";
+        return w;
+      }
+      w.restricted = true;
       return w;
     }
-    cpu_set_t have, l3;
     const int cpu = sched_getcpu();
-    if (cpu < 0 || sched_getaffinity(0, sizeof have, &have) != 0) return w;
+    if (cpu < 0 || !have_mask) return w;
     char path[96], text[512];
     snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
     FILE *f = fopen(path, "r");
@@ -106,10 +127,10 @@ struct WorkerCpus {
     const bool got = fgets(text, sizeof text, f) != nullptr;
     fclose(f);
     if (!got || !parse(text, &l3)) return w;
-    int left = 0;
     for (int c = 0; c < CPU_SETSIZE; ++c)
-      if (CPU_ISSET(c, &have) && !CPU_ISSET(c, &l3)) CPU_SET(c, &w.set), ++left;
-    w.restricted = left >= std::max(32, 2 * n_threads);
+      if (CPU_ISSET(c, &have) && !CPU_ISSET(c, &l3)) CPU_SET(c, &w.set), ++w.cpus;
+    w.automatic = true;
+    w.restricted = w.room(n_threads);
     return w;
   }
   std::string cpulist() const { // "" when the workers inherit
@@ -262,7 +283,7 @@ struct fgmm_ctx {
   int device = 0;
   std::mutex mu; // one call at a time per context
   fgmm::Pool *pool = nullptr;
-  fgmm::WorkerCpus worker_cpus; // decided once, when the context is created (fgmm_ctx_set_threads keeps it)
+  fgmm::WorkerCpus worker_cpus; // decided when the context is created; fgmm_ctx_set_threads re-applies the automatic rule's room test
   char *d_ws = nullptr; // device workspace (descriptors, counters, encode tables): grown on demand, reused
   size_t d_cap = 0;
   char *h_ws = nullptr; // its pinned mirror

@@ -831,7 +831,9 @@ struct DecodeCall {
     for (int i : generic)
       if ((rc = run_generic(i))) return rc;
     rc = scatter_and_finish();
-    account();
+    // (only a call that finished: on an early error return the workers are still decoding - Abandon and PoolDrain run when this
+    // scope is left - and would be writing the fields account() reads; a failed call is not in the call log)
+    if (rc == FGMM_OK) account();
     quiesce.clean = rc == FGMM_OK;
     return rc;
   }

@@ -59,33 +59,62 @@ class LengthExchange:
         self.n = int(streams_per_rank)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         cuda = self.device.type == "cuda"
-        self.host_in = torch.full((self.n,), -1, dtype=torch.int64, pin_memory=cuda)
-        self.inp = torch.full((self.n,), -1, dtype=torch.int64, device=self.device)
-        self.out = torch.full((self.world, self.n), -1, dtype=torch.int64, device=self.device)
+        # TWO sets of buffers, used in turn: start() of exchange i + 1 must not rewrite the pinned source of exchange i's
+        # non-blocking upload, nor the buffers its collective may still be reading or writing (wait(to_host=False) orders
+        # streams, it does not block the host).  Each set remembers the event recorded after its last upload.
+        self._slots = [{"host_in": torch.full((self.n,), -1, dtype=torch.int64, pin_memory=cuda),
+                        "inp": torch.full((self.n,), -1, dtype=torch.int64, device=self.device),
+                        "out": torch.full((self.world, self.n), -1, dtype=torch.int64, device=self.device),
+                        "uploaded": None} for _ in range(2)]
+        self._cur = 0
         self.work = None
         self.issue_ms = self.exposed_ms = self.total_ms = 0.0
         self._t0 = 0.0
+
+    # the current exchange's buffers (what wait() returns a view of)
+    @property
+    def host_in(self):
+        return self._slots[self._cur]["host_in"]
+
+    @property
+    def inp(self):
+        return self._slots[self._cur]["inp"]
+
+    @property
+    def out(self):
+        return self._slots[self._cur]["out"]
 
     def start(self, local_lengths: Sequence[int]) -> None:
         t0 = self._time()
         k = len(local_lengths)
         if k > self.n:
             raise ValueError(f"{k} lengths for {self.n} streams per rank")
-        h = self.host_in.numpy()  # (a view: two numpy stores instead of tensor construction + indexing)
+        if self.work is not None:  # an exchange nobody waited for: it must have finished before another is issued on the group
+            self.work.wait()
+            self.work = None
+        self._cur ^= 1
+        sl = self._slots[self._cur]
+        if sl["uploaded"] is not None:  # this set's previous upload (two exchanges ago): long done, but not by construction
+            sl["uploaded"].synchronize()
+        h = sl["host_in"].numpy()  # (a view: two numpy stores instead of tensor construction + indexing)
         h[k:] = -1
         h[:k] = local_lengths
-        self.inp.copy_(self.host_in, non_blocking=True)
+        sl["inp"].copy_(sl["host_in"], non_blocking=True)
+        if self.device.type == "cuda":
+            if sl["uploaded"] is None:
+                sl["uploaded"] = torch.cuda.Event()
+            sl["uploaded"].record(torch.cuda.current_stream(self.device))
         if self.active:
-            self.work = dist.all_gather_into_tensor(self.out.view(-1), self.inp, group=self.group, async_op=True)
+            self.work = dist.all_gather_into_tensor(sl["out"].view(-1), sl["inp"], group=self.group, async_op=True)
         else:
-            self.out[0].copy_(self.inp)
+            sl["out"][0].copy_(sl["inp"])
         self._t0 = t0
         self.issue_ms = (self._time() - t0) * 1e3
 
     def wait(self, to_host: bool = True) -> torch.Tensor:
         """-> int64 [world, streams_per_rank]; ranks with fewer streams are padded with -1.  ``to_host`` (default): a host copy,
         complete on return; False: the collective's own buffer, ordered after the collective on the current stream (valid until
-        the next ``start``) - for a caller that reads the lengths later, or never on the host"""
+        the ``start`` after next: the buffers are used in turn) - for a caller that reads the lengths later, or never on the host"""
         t0 = self._time()
         if self.work is not None:
             self.work.wait()
@@ -226,15 +255,24 @@ def plan_l3(local_rank: int, ranks_on_node: int):
             d = cpulist_to_set(open(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list").read()) & mask
             seen |= d | {c}
             domains.append(d)
-        numa_nodes = max(1, len([n for n in os.listdir("/sys/devices/system/node") if n.startswith("node") and n[4:].isdigit()]))
-        per_node = -(-max(ranks_on_node, 1) // numa_nodes)  # ranks that share this NUMA node's CPUs (GPUs are spread evenly over the nodes)
+        # the ranks that share this rank's (NUMA-bound) CPUs, and this rank's place among them: from the GPUs' own NUMA nodes where
+        # sysfs gives them (the GPUs of a node need not be a contiguous block of local ranks), else assuming the GPUs are spread evenly
+        # over the nodes in blocks
+        nodes_of = [gpu_numa_node(r) for r in range(max(ranks_on_node, 1))]
+        if 0 <= local_rank < len(nodes_of) and all(n is not None for n in nodes_of):
+            peers = [r for r, n in enumerate(nodes_of) if n == nodes_of[local_rank]]
+            per_node, slot = len(peers), peers.index(local_rank)
+        else:
+            numa_nodes = max(1, len([n for n in os.listdir("/sys/devices/system/node") if n.startswith("node") and n[4:].isdigit()]))
+            per_node = -(-max(ranks_on_node, 1) // numa_nodes)
+            slot = local_rank % per_node
         reserved = domains[1:1 + per_node]
         workers = mask - set().union(*reserved) if reserved else mask
         if len(reserved) < per_node or len(workers) < 32:
             return None, f"not done: {len(domains)} L3 domains in {len(mask)} CPUs, {per_node} rank(s) on the NUMA node (the library's own rule applies)"
-        mine = reserved[local_rank % per_node]
+        mine = reserved[slot]
         os.environ["FGMM_WORKER_CPUS"] = set_to_cpulist(workers)
-        return mine, (f"calling thread on CPUs {set_to_cpulist(mine)} (L3 domain {1 + local_rank % per_node} of {len(domains)}); host workers on the "
+        return mine, (f"calling thread on CPUs {set_to_cpulist(mine)} (L3 domain {1 + slot} of {len(domains)}); host workers on the "
                       f"{len(workers)} CPUs outside the {per_node} reserved domain(s)")
     except (OSError, ValueError) as e:
         return None, f"not done ({e}): the library's own rule applies"
@@ -260,6 +298,15 @@ def gpu_pci_address(device_index: int) -> str:
     if not 0 <= device_index < len(order):
         raise LookupError(f"device {device_index} of {len(order)} visible GPUs")
     return gpus[order[device_index]]
+
+
+def gpu_numa_node(device_index: int) -> Optional[int]:
+    """NUMA node of HIP device `device_index` from sysfs alone (no GPU call); None when the topology does not say"""
+    try:
+        node = int(open(f"/sys/bus/pci/devices/{gpu_pci_address(device_index)}/numa_node").read())
+        return node if node >= 0 else None
+    except (LookupError, OSError, ValueError):
+        return None
 
 
 def runtime_pci_address(device_index: int) -> str:

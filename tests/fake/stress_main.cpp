@@ -178,8 +178,13 @@ int main(int argc, char **argv) {
   long rounds = 0, refused = 0, streams = 0, symbols = 0, corrupted_same = 0, corrupted_refused = 0;
   static const int kThreads[] = {1, 2, 3, 5, 8, 16};
   while (std::chrono::steady_clock::now() < t_end) {
-    CHECK(fgmm_ctx_set_threads(ctx, kThreads[rnd() % 6]) == FGMM_OK, "threads");
-    set_opt(ctx, "pieces", rnd() % 3 ? pick(1, 12) : 0);
+    // The first three rounds of every run are LARGE bitstreams under the AUTOMATIC piece plan (pieces = 0), which the random
+    // items below - all under 65 536 latents, one piece - never reach: one bitstream of 131 072 latents on a pool of one worker and
+    // on a pool of eight (one decoder: two pieces, an eighth first - plan_pieces' lead_small), then two such bitstreams (the
+    // general multi-piece plan, shrinking pieces).
+    const bool big = rounds < 3;
+    CHECK(fgmm_ctx_set_threads(ctx, big ? (rounds == 0 ? 1 : 8) : kThreads[rnd() % 6]) == FGMM_OK, "threads");
+    set_opt(ctx, "pieces", big ? 0 : rnd() % 3 ? pick(1, 12) : 0);
     set_opt(ctx, "dec_first", pick(1, 6));
     set_opt(ctx, "ef_rows", pick(0, 2));
     set_opt(ctx, "ef_min", rnd() % 2 ? 14 : 49);
@@ -188,18 +193,19 @@ int main(int argc, char **argv) {
     set_opt(ctx, "scatter_rounds", rnd() % 2);
     set_opt(ctx, "ckpt_decode", pick(0, 2));
     set_opt(ctx, "gpu_decode", pick(0, 2));
-    set_opt(ctx, "stage_max_mb", rnd() % 4 == 0 ? 1 : 0); // a tiny staging budget: launches overflow and are re-run
-    set_opt(ctx, "tab_cap_e", rnd() % 5 == 0 ? 256 : 12288); // a tiny LDS budget: items take the generic two-pass kernels
+    set_opt(ctx, "stage_max_mb", !big && rnd() % 4 == 0 ? 1 : 0); // a tiny staging budget: launches overflow and are re-run
+    set_opt(ctx, "tab_cap_e", !big && rnd() % 5 == 0 ? 256 : 12288); // a tiny LDS budget: items take the generic two-pass kernels
     set_opt(ctx, "spin_lat", rnd() % 3 == 0 ? -1 : 400000);
     const int mode = (int)(rnd() % 3), clamp = 1;
-    const int32_t stride = rnd() % 2 ? (int32_t)(256 << (rnd() % 3)) : 0; // checkpointed streams
-    const int count = (int)pick(1, 12);
+    const int32_t stride = !big && rnd() % 2 ? (int32_t)(256 << (rnd() % 3)) : 0; // checkpointed streams
+    const int count = big ? (rounds == 2 ? 2 : 1) : (int)pick(1, 12);
     std::vector<Item> its((size_t)count);
     std::vector<fgmm_item> fi((size_t)count);
     for (int i = 0; i < count; ++i) {
       static const int Ms[] = {1, 3, 8, 9, 17, 24};
       static const int64_t HWs[] = {1, 7, 64, 96, 192, 384};
-      make_item(its[(size_t)i], Ms[rnd() % 6], rnd() % 40 == 0 ? 0 : HWs[rnd() % 6], rnd() % 5 == 0 ? 1.0 : 0.15); // (now and then an EMPTY item: hw = 0)
+      if (big) make_item(its[(size_t)i], 64, 2048, 0.0);
+      else make_item(its[(size_t)i], Ms[rnd() % 6], rnd() % 40 == 0 ? 0 : HWs[rnd() % 6], rnd() % 5 == 0 ? 1.0 : 0.15); // (now and then an EMPTY item: hw = 0)
       Item &it = its[(size_t)i];
       // now and then an OUTLIER in a small item: a symbol far outside every component (bypass-coded, beyond int16: the wide symbol
       // paths), a half-width that needs 4- or 8-byte headers and the generic two-pass kernels

@@ -206,13 +206,22 @@ def test_l3_plan_partitions_the_cpus(monkeypatch, tmp_path):
         d = 1 + r % 2
         assert mine == set(range(8 * d, 8 * d + 8)) | set(range(128 + 8 * d, 128 + 8 * d + 8)), (r, note)
         assert P.cpulist_to_set(os.environ["FGMM_WORKER_CPUS"]) == set(range(0, 8)) | set(range(24, 32)) | set(range(128, 136)) | set(range(152, 160))
+    # GPUs of a NUMA node that are NOT a contiguous block of local ranks (even GPUs on node 0, odd ones on node 1): a rank's domain is
+    # its place among the ranks of ITS node - ranks 0 and 2 (both on this node's CPUs) must not collide on one domain
+    monkeypatch.setattr(P, "gpu_numa_node", lambda r: r % 2)
+    got = {}
+    for r in (0, 2):
+        monkeypatch.delenv("FGMM_WORKER_CPUS", raising=False)
+        got[r], note = bench.plan_l3(r, 4)
+    assert got[0] == set(range(8, 16)) | set(range(136, 144)) and got[2] == set(range(16, 24)) | set(range(144, 152)), note
+    monkeypatch.setattr(P, "gpu_numa_node", lambda r: None)
     monkeypatch.setenv("FGMM_BENCH_L3", "0")
     monkeypatch.delenv("FGMM_WORKER_CPUS", raising=False)
     assert bench.plan_l3(0, 1)[0] is None and os.environ["FGMM_WORKER_CPUS"] == "inherit"
 
 
 def test_region_phases_names_what_stretched_in_a_slow_step(monkeypatch):
-    """bench.region_phases: the headline region's time by phase from the library's call log, and for a step slower than 1.3x the median
+    """scripts/bench_diag.region_phases: the headline region's time by phase from the library's call log, and for a step slower than 1.3x the median
     the phases that stretched - here a made-up log of three steps whose last one has 5 ms in the head of its first decode call"""
     sys.path.insert(0, ROOT)
     import bench
@@ -227,7 +236,58 @@ def test_region_phases_names_what_stretched_in_a_slow_step(monkeypatch):
         log += [call("encode", [0.1, 0.14, 0.2, 0.8, 0.93, 0.94]), call("decode", [0.05, 0.15 + late, 3.0, 3.6 + late, 3.75 + late, 3.8 + late]),
                 call("decode", [0.05, 0.15, 3.0, 3.6, 3.75, 3.8])]
     monkeypatch.setattr(_lib, "call_log", lambda dev, last=64: log[-last:])
-    ph = bench.region_phases(0, 3, [9.1, 9.0, 14.2])
+    ph = bench.D.region_phases(0, 3, [9.1, 9.0, 14.2])
     assert ph["steps"] == 3 and abs(ph["call1_decode.bus"] - 3.45) < 1e-9 and abs(ph["between_calls"] - 0.56) < 0.01
     assert ph["slow_steps"] == [{"step": 2, "ms": 14.2, "moved_[this,median]": {"call1_decode.head": [5.15, 0.15]}}]
-    assert bench.region_phases(0, 3, [9.1, 9.0]) is not None and bench.region_phases(0, 4, [9.1, 9.0, 9.2]) is None  # (a log of another shape: nothing)
+    assert bench.D.region_phases(0, 3, [9.1, 9.0]) is not None and bench.D.region_phases(0, 4, [9.1, 9.0, 9.2]) is None  # (a log of another shape: nothing)
+
+
+def _load_bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("recorded", ["r05_bench_last.json", "r05_bench_elic4k.json", "r05_n2_one_device.json", "r04_bench_last.json"])
+def test_the_stdout_line_fits_the_drivers_window(recorded, tmp_path, capfd, monkeypatch):
+    """BENCH_r05.json was `parsed: null`: the line had grown to 22 KB and the driver keeps ~8 KB of stdout.  The line is now a
+    summary of the full result (which goes to bench_detail.json and stderr), under 4 KB, asserted in emit(): built here from
+    recorded full results of earlier rounds - the largest the bench has ever produced."""
+    bench = _load_bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", recorded)))
+    assert len(json.dumps(full)) > 4096  # (the recorded result itself would not fit)
+    # the worst case the driver can produce: eight ranks' per-rank entries
+    full.setdefault("ranks", {})["ms_per_step"] = [9.446] * 8
+    full["ranks"]["host_threads_per_gpu"] = [48] * 8
+    detail = tmp_path / "detail.json"
+    monkeypatch.setenv("FGMM_BENCH_DETAIL", str(detail))
+    bench.emit(full)
+    out, err = capfd.readouterr()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_LIMIT <= 4096
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d and d[key] == full[key] or key == "config"
+    assert d["config"]["workload"] == full["config"]["workload"] and "model" not in d["config"]
+    assert set(d["step_ms"]) >= {"min", "median", "p90", "max"}
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    if "cpu_baseline" in full:
+        cb = d["cpu_baseline"]
+        assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["unit"] == "Mpixels/s" and "sample" in cb and cb["value"] > 0
+        assert cb["reference_bytes_equal"] is None or cb["reference_bytes_equal"]["equal"] == cb["reference_bytes_equal"]["streams"]
+    # nothing was lost: the whole result is beside the line and on stderr
+    assert json.load(open(detail)) == full and d["detail"] == str(detail)
+    assert "[bench detail] " in err
+
+
+def test_a_line_that_would_not_fit_is_refused(monkeypatch, tmp_path):
+    bench = _load_bench()
+    monkeypatch.setenv("FGMM_BENCH_DETAIL", str(tmp_path / "d.json"))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_last.json")))
+    full["cpu_baseline"]["sample"] = "x" * 5000
+    with pytest.raises(AssertionError, match="driver's window"):
+        bench.emit(full)

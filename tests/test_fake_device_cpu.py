@@ -51,3 +51,21 @@ def test_worker_cpus_follow_the_environment(stress_binary):
         r = subprocess.run([stress_binary, "1", "3"], capture_output=True, text=True, timeout=300, env=e)
         assert r.returncode == 0, (env, r.stderr[-2000:])
         assert f"worker CPUs: '{want}'" in r.stdout and "bitstreams == oracle" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("bad", ["abc", "5-", "3-1", "9999999"])
+def test_an_unusable_worker_cpulist_fails_the_context(stress_binary, bad):
+    """FGMM_WORKER_CPUS that is not a cpulist, or names no CPU the process may run on, is an ERROR at fgmm_ctx_create (through
+    fgmm_last_error) - never a silent fall back to the creating thread's mask, which would put the workers' table stream on the very
+    L3 the variable was set to protect."""
+    e = dict(os.environ, FGMM_WORKER_CPUS=bad)
+    r = subprocess.run([stress_binary, "1", "3"], capture_output=True, text=True, timeout=60, env=e)
+    assert r.returncode != 0 and "FGMM_WORKER_CPUS" in r.stderr, r.stderr[-1000:]
+
+
+def test_the_reported_worker_cpus_are_the_effective_ones(stress_binary):
+    """a list wider than the process's mask: the workers get (and fgmm_ctx_worker_cpus reports) its intersection with the mask"""
+    cpus = sorted(os.sched_getaffinity(0))
+    e = dict(os.environ, FGMM_WORKER_CPUS=f"{cpus[0]},4000-4003", FGMM_STRESS_EXPECT_WORKER_CPUS=str(cpus[0]))
+    r = subprocess.run([stress_binary, "1", "3"], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0 and f"worker CPUs: '{cpus[0]}'" in r.stdout, r.stderr[-1000:]

@@ -510,6 +510,25 @@ def test_batch_of_kodak_halves_full_size(mode):
         assert torch.equal(res[seed][1], torch.round(ys[seed]))
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_one_kodak_half_alone_with_default_options(mode):
+    """The latency case: ONE bitstream per call with the context's default options - the automatic piece plan gives a lone decoder
+    two pieces, an eighth first (fgmm_decode.cpp plan_pieces / piece_bound, `lead_small`), a branch no batch reaches.  Two halves
+    (seeds 0 and 1), each compressed and decompressed alone, against the reference's bytes and round(y)."""
+    ka = json.load(open(os.path.join(GOLD, "fullsize.json")))[mode]["kodak24"]
+    gmc = GaussianMixtureConditional(K=4, mode=mode)
+    assert _lib.get_option(0, "pieces") == 0
+    for seed in (0, 1):
+        t = [dv(a) for a in T.make_latent(seed)]
+        (b, abs_max, zb), yq = gmc.compress(*t)
+        assert (len(b), hashlib.md5(b).hexdigest(), abs_max) == (ka[str(seed)]["len"], ka[str(seed)]["md5"], ka[str(seed)]["abs_max"]), seed
+        for _ in range(3):  # (the same buffers reused call after call)
+            y_hat = gmc.decompress(b, abs_max, zb, *t[1:])
+            assert torch.equal(y_hat, yq) and torch.equal(yq, torch.round(t[0])), seed
+        log = _lib.call_log(0, 1)[0]
+        assert log["kind"] == "decode" and log["count"] == 1
+
+
 @pytest.fixture
 def ctx_options():
     """set options of the process-wide context for one test and restore them afterwards"""
@@ -1368,7 +1387,18 @@ def test_gpu_segment_decoder_on_a_corrupt_last_segment_equals_the_sequential_dec
                 assert (want is None and got is None) or (want is not None and got is not None and np.array_equal(got, want)), (seed, trial)
 
 
-def test_bench_two_ranks_rehearsed_on_one_device():
+def _bench_line_and_detail(r, detail_path):
+    """bench.py's stdout is ONE summary line under 4 KB (what the driver parses); the whole result lies in the detail file"""
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, r.stdout[-2000:]
+    line, full = json.loads(lines[0]), json.load(open(detail_path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "data"):
+        assert line[k] == full[k]
+    assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["detail"] == str(detail_path)
+    return line, full
+
+
+def test_bench_two_ranks_rehearsed_on_one_device(tmp_path):
     """BASELINE configs[3]'s code path in the one form a 1-GPU box allows (FGMM_BENCH_ONE_DEVICE): `bench.py --gpus 2` starts two
     fresh rank processes before anything touches the GPU (never a re-exec), both code on GPU 0, the process group is gloo, the
     per-step all-gather of bitstream lengths and one gather of the containers run, every rank checks its results, and rank 0
@@ -1377,16 +1407,15 @@ def test_bench_two_ranks_rehearsed_on_one_device():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FGMM_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, FGMM_BENCH_ONE_DEVICE="1", FGMM_BENCH_DETAIL=str(tmp_path / "detail.json"))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FGMM_BENCH_DRYRUN"):
         env.pop(k, None)
     torch.cuda.synchronize()
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--images", "4", "--steps", "3", "--warmup", "1",
                         "--no-cpu-baseline", "--launch-timeout", "400"], env=env, capture_output=True, text=True, timeout=480)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    line, d = _bench_line_and_detail(r, tmp_path / "detail.json")
+    assert line["n_gpus"] == 2 and line["ranks"]["backend"] == "gloo" and len(line["ranks"]["ms_per_step"]) == 2 and line["checkpointed"]["value"] > 0
     assert d["n_gpus"] == 2 and d["config"]["one_device_rehearsal"] is True and d["config"]["images_per_gpu"] == 4
     rk = d["ranks"]
     assert rk["backend"] == "gloo" and rk["rccl_ranks"] == 0 and len(rk["ms_per_step"]) == 2 and rk["result_checked_ranks"] == 2
@@ -1433,9 +1462,10 @@ def test_bench_latents_dir_hook(tmp_path):
         torch.save(img, tmp_path / f"image_{i:02d}.pt")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--latents-dir", str(tmp_path), "--steps", "2", "--warmup", "1", "--no-extras",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=dict(os.environ, FGMM_BENCH_DETAIL=str(tmp_path / "detail.json")))
     assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    line, d = _bench_line_and_detail(r, tmp_path / "detail.json")
+    assert line["data"] == "real-latents" and line["step_ms"]["between_calls"] >= 0
     assert d["data"] == "real-latents" and d["config"]["images_per_gpu"] == 2 and d["config"]["streams_per_gpu"] == 4 and d["value"] > 0
     assert d["config"]["coded_symbols_per_gpu"] > 0 and d["ranks"]["result_checked_ranks"] == 1
     # the region's time by phase, from the library's call log: one encode call and two decode calls (two bitstreams per image) per step,
