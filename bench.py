@@ -77,7 +77,7 @@ def stream_seed(rank: int, image: int, stream: int, streams_per_image: int) -> i
 
 def _make_stream(args):
     seed, M, h, w, f16 = args
-    from flashgmm_amd import testing as T
+    from tests import synth as T
 
     y, sg, mu, pi = T.make_latent(seed, M=M, h=h, w=w)  # sigma pre-clamped as KA-1
     if f16:
@@ -160,7 +160,7 @@ def load_latents_dir(path: str, dev, f16: bool, images=None):
 # ---------------------------------------------------------------------------------------------------------------------
 def _cpu_coder():
     """-> (kind, prepare(host stream) -> state, code(state) -> (decoded symbols, expected symbols, the encoder's bytes))"""
-    from flashgmm_amd import testing as T
+    from tests import synth as T
     from oracle import oracle as O
 
     kind = "port"
@@ -195,7 +195,7 @@ def _all_cores_worker(args):
     """one process of the all-cores baseline: its share of the streams, regenerated from their seeds; passes until the
     budget is spent -> (streams coded, wall clock start, wall clock end)"""
     seeds, shapes, f16, budget_s = args
-    from flashgmm_amd import testing as T
+    from tests import synth as T
 
     torch.set_num_threads(1)
     kind, prepare, code = _cpu_coder()
@@ -220,7 +220,7 @@ def _scalar_worker(args):
     -> (kind, symbols coded per pass, best seconds per pass, passes)"""
     seeds, shapes, f16, budget_s = args
     os.environ["USE_SIMD"] = "0"
-    from flashgmm_amd import testing as T
+    from tests import synth as T
 
     torch.set_num_threads(1)
     kind, prepare, code = _cpu_coder()
@@ -249,7 +249,7 @@ def _mode_md5_worker(args):
     os.environ["APPROX_MODE"] = str(mode_id)
     import hashlib
 
-    from flashgmm_amd import testing as T
+    from tests import synth as T
     from oracle import oracle as O
 
     torch.set_num_threads(1)
@@ -343,7 +343,7 @@ def cpu_baseline(host, shapes, pix_per_image: int, streams_per_image: int, rank:
     # the first image, both coders, so that a line from a checkout without oracle/_ref stays comparable
     if kind == "reference":
         try:
-            from flashgmm_amd import testing as T
+            from tests import synth as T
             from oracle import oracle as O
 
             t_port = t_ref = None

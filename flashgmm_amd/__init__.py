@@ -4,7 +4,7 @@
     flashgmm_amd.ans               RansEncoder / BufferedRansEncoder / RansDecoder   (mirror of compressai.ans)
     flashgmm_amd.entropy_models    GaussianMixtureConditional                        (mirror of the Python boundary)
     flashgmm_amd._lib              ctypes binding of libflashgmm_amd.so (include/flashgmm_amd.h)
-    flashgmm_amd.testing           seeded synthetic latents (tests / bench only)
+
 
 All floating-point work runs in hand-written HIP kernels (flashgmm_amd/csrc); there is no CPU fallback.
 """

@@ -85,7 +85,7 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
 
     def _planes(self, scales: Tensor, means: Tensor, weights: Tensor):
         """the planes as the entropy model gets them: float32 as they are, or float16 copies — weights rounded TOWARD ZERO,
-        because the algorithm needs sum_k pi_k <= 1 after widening (flashgmm_amd.testing.to_float16_planes)"""
+        because the algorithm needs sum_k pi_k <= 1 after widening (tests/synth.py to_float16_planes does it for the synthetic workloads)"""
         if self.param_dtype == torch.float32:
             return scales, means, weights
         w16 = weights.to(torch.float16)

@@ -55,7 +55,8 @@ print("nproc(os.cpu_count)", os.cpu_count(), " affinity", len(os.sched_getaffini
 print("cgroup", cgroup_cpu())
 print("nodes", read("/sys/devices/system/node/online"), {n: read(f"/sys/devices/system/node/{n}/cpulist") for n in sorted(os.listdir("/sys/devices/system/node")) if re.fullmatch(r"node\d+", n)})
 import numpy as np, torch
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T, parallel as P
+from flashgmm_amd import GaussianMixtureConditional, _lib, parallel as P
+from tests import synth as T
 if a.bind == "early":
     print("bind early:", P.bind_to_gpu_numa_node(0))
 p = torch.cuda.get_device_properties(0)

@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from oracle import oracle as O
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib
+from tests import synth as T
 MODES = ["polya", "as", "logistic"]
 dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40

@@ -3,7 +3,8 @@ streams), timed in place.   CKPT=1024 python scripts/glue_sections.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, ctypes as C
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T, entropy_models as EM
+from flashgmm_amd import GaussianMixtureConditional, _lib, entropy_models as EM
+from tests import synth as T
 dev = torch.device("cuda:0")
 lat = [T.make_latent(i) for i in range(48)]
 ys, ss, ms, ws = (torch.cat([torch.from_numpy(l[k]) for l in lat]).to(dev) for k in range(4))

@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import oracle as O
-from flashgmm_amd import _lib, testing as T
+from flashgmm_amd import _lib
+from tests import synth as T
 import helpers
 from helpers import trim_full_table, host_decode_cdftab, host_decode_tab, host_encode_symtab
 helpers.EF_MIN = int(os.environ.get("EF_MIN", str(helpers.EF_MIN)))  # must match the library's FGMM_EF_MIN

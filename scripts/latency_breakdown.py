@@ -3,7 +3,8 @@ call: Python total, native call, Python glue; then the native phases of one call
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib
+from tests import synth as T
 dev = torch.device("cuda:0")
 ck_stride = 0
 for kv in sys.argv[1:]:

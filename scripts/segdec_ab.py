@@ -3,7 +3,8 @@ codec call of Kodak halves, for the library FGMM_LIB names.    python scripts/se
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib
+from tests import synth as T
 stride = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 counts = [int(a) for a in sys.argv[2:]] or [24, 48, 2]
 dev = torch.device("cuda:0")

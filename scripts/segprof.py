@@ -4,7 +4,8 @@
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib
+from tests import synth as T
 stride = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nimg = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 dev = torch.device("cuda:0")

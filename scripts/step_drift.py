@@ -3,7 +3,8 @@ region: do the first timed steps pay for the pause?).  python scripts/step_drift
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib
+from tests import synth as T
 dev = torch.device("cuda:0")
 pause = float(sys.argv[1]) / 1e3 if len(sys.argv) > 1 else 0.15
 lat = [T.make_latent(i) for i in range(48)]

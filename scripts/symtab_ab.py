@@ -10,7 +10,8 @@ if len(sys.argv) > 1 and sys.argv[1] != "--child":
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib
+from tests import synth as T
 dev = torch.device("cuda:0")
 _lib.set_profiling(0, True)
 res_txt = []

@@ -4,7 +4,8 @@ python scripts/symtab_vec8_ab.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib
+from tests import synth as T
 dev = torch.device("cuda:0")
 _lib.set_profiling(0, True)
 ELIC = [(g, 136, 120) for g in (16, 16, 32, 64, 192) for _ in range(2)]

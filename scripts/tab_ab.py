@@ -11,7 +11,8 @@ if len(sys.argv) > 1 and sys.argv[1] != "--child":
 sys.path.insert(0, ROOT)
 import ctypes as C
 import numpy as np, torch
-from flashgmm_amd import _lib, testing as T
+from flashgmm_amd import _lib
+from tests import synth as T
 dev = torch.device("cuda:0")
 L, ctx = _lib.lib(), _lib.ctx(0)
 S, M_, W_, mb = [], [], [], 0

@@ -3,7 +3,8 @@ that took much longer than the median - where does a stalled call lose its time?
 import os, sys, io, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib
+from tests import synth as T
 dev = torch.device("cuda:0")
 lat = [T.make_latent(i) for i in range(48)]
 ys, ss, ms, ws = (torch.cat([torch.from_numpy(l[k]) for l in lat]).to(dev) for k in range(4))

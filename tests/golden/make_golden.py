@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import oracle as O  # noqa: E402
-from flashgmm_amd import testing as T  # noqa: E402
+from tests import synth as T  # noqa: E402
 
 MODE_NAMES = ["polya", "as", "logistic"]
 

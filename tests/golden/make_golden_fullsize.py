@@ -5,7 +5,7 @@
 
 Writes tests/golden/fullsize.json - length + md5 of what the reference's `RansEncoder.encode_with_indexes_gmm`
 (compressai/cpp_exts/rans/rans_interface.cpp:609-617) returns for EVERY bitstream of the BASELINE configurations the GPU
-tests and bench.py run at full size (inputs regenerated from their seeds by flashgmm_amd.testing.make_latent):
+tests and bench.py run at full size (inputs regenerated from their seeds by tests/synth.py: make_latent):
 
   kodak24        the 48 checkerboard halves [1,192,32,24] of bench.py's Kodak batch (rank 0: seeds 0..47), modes polya / as /
                  logistic - configs[1], configs[2]
@@ -27,7 +27,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-from flashgmm_amd import testing as T  # noqa: E402
+from tests import synth as T  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 MODE_NAMES = ["polya", "as", "logistic"]

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from flashgmm_amd import GaussianMixtureConditional, _lib, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib
+from tests import synth as T
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

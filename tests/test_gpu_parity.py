@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 import torch
 
-from flashgmm_amd import GaussianMixtureConditional, _lib, ans, testing as T
+from flashgmm_amd import GaussianMixtureConditional, _lib, ans
+from tests import synth as T
 from helpers import expand_trimmed, hdr_form
 
 pytestmark = pytest.mark.gpu
@@ -1243,7 +1244,7 @@ def test_checkerboard_split_merge_equals_reference_slicing(parity, dtype):
 @pytest.mark.parametrize("mode", MODES)
 def test_g7_codecs_equal_the_reference_classes(mode):
     """CheckerboardLatentCodec / ChannelGroupsLatentCodec (checkerboard.py:275-330, channel_groups.py:111-158): the
-    reference's own classes were run on device-independent networks (flashgmm_amd.testing.exact_modules) when
+    reference's own classes were run on device-independent networks (tests/synth.py: exact_modules) when
     tests/golden/g7_codecs.json was made; the mirrors must give the same strings, side information and tensors —
     including the reference's -0.0 in y_hat and its encoder/decoder mismatch for quantizer="weighted_mean_ste"
     (compress() feeds the un-recentred residual to the non-anchor context, decompress() the re-centred value)."""

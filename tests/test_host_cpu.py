@@ -14,7 +14,8 @@ import re
 import numpy as np
 import pytest
 
-from flashgmm_amd import _lib, testing as T
+from flashgmm_amd import _lib
+from tests import synth as T
 import helpers
 from helpers import expand_trimmed, host_decode_cdftab, host_decode_tab, host_encode_symtab, trim_full_table
 

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from flashgmm_amd import testing as T
+from tests import synth as T
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 MODES = ["polya", "as", "logistic"]

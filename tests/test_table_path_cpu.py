@@ -128,7 +128,7 @@ def test_g8_hyper_latent_z_stream_equals_the_reference_classes():
     import hashlib
 
     import torch
-    from flashgmm_amd import testing as T
+    from tests import synth as T
     from flashgmm_amd.latent_codecs import HyperLatentCodec
     from golden.make_golden import G8_HASHED, G8_HYPER, bytes_to_json
 
