@@ -9,7 +9,7 @@
 All floating-point work runs in hand-written HIP kernels (flashgmm_amd/csrc); there is no CPU fallback.
 """
 from . import _lib  # noqa: F401
-from .entropy_models import CheckpointedBytes, CompressedBatch, EntropyBottleneckCoder, GaussianMixtureConditional  # noqa: F401
+from .entropy_models import CheckpointedBytes, CompressedBatch, EntropyBottleneckCoder, GaussianMixtureConditional, ParameterHead  # noqa: F401
 from . import ans  # noqa: F401
 
 __version__ = "0.1.0"

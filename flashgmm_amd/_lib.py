@@ -93,6 +93,10 @@ SIGNATURES = {
     "fgmm_gmc_decompress": (_i, [_p, _p, _p, _sz, _i32, _p, C.POINTER(fgmm_params), _i, _i, _i64, _i, _i, _p]),
     "fgmm_gmc_compress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
     "fgmm_gmc_decompress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
+    "fgmm_head_create": (_i, [_p, _p, _p, _p, _i, _i, _i, _pp]),
+    "fgmm_head_destroy": (None, [_p]),
+    "fgmm_head_params_batch": (_i, [_p, _p, _p, _p, _p, _p, _i]),
+    "fgmm_gmc_compress_head_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _p, _i, _p, _i, _i]),
     "fgmm_gmm_cdf_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p, _p]),
     "fgmm_softmax4_hip": (_i, [_p, _p, _p, _p, _i64]),
     "fgmm_build_symtab_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),

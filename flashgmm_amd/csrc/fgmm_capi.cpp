@@ -446,8 +446,17 @@ int fgmm_ctx_threads(const fgmm_ctx *ctx) { return ctx && ctx->pool ? ctx->pool-
 
 // ---- section 2: entropy-model level ---------------------------------------------------------------------
 
-int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales) {
+// the packed weights of a parameter head (fgmm_head.hip), owned by the caller through fgmm_head_create / _destroy
+struct fgmm_head {
+  int device = 0;
+  float *packed = nullptr; // [wp | bp]
+  fgmm::HeadW w{};
+};
+
+static int compress_batch_impl(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales, const fgmm_head *head,
+                               const float *const *x) {
   if (!ctx || count < 0 || (count && !items) || !mode_ok(mode)) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (head && (head->device != ctx->device || (count && !x))) return fail(FGMM_ERR_INVALID, "head: made for device %d, context on %d (or x == NULL)", head->device, ctx->device);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
@@ -455,15 +464,25 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
   for (int i = 0; i < count; ++i) {
     const fgmm_item &s = items[i];
     if (s.K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", s.K);
-    if (s.M < 0 || s.hw < 0 || (s.M * s.hw && (!s.y || !s.params.scales || !s.params.means || !s.params.weights)))
-      return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
-    if (s.params.dtype != items[0].params.dtype || (s.params.dtype != FGMM_F32 && s.params.dtype != FGMM_F16))
-      return fail(FGMM_ERR_INVALID, "item %d: parameter dtype must be FGMM_F32 or FGMM_F16 and the same for a whole batch", i);
-    if (s.params.flags & ~FGMM_PARAMS_LOGITS) return fail(FGMM_ERR_INVALID, "item %d: unknown fgmm_params.flags %d", i, s.params.flags);
     EncItem &e = v[i];
+    if (head) {
+      // the parameters come out of the head's matrix product: the item names its features instead of parameter planes
+      if (s.M != head->w.M) return fail(FGMM_ERR_INVALID, "item %d: M = %d, the head was made for M = %d", i, s.M, head->w.M);
+      if (s.hw < 0 || (s.M * s.hw && (!s.y || !x[i]))) return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
+      e.x = x[i];
+      e.prm = fgmm_params{};
+      e.prm.dtype = FGMM_F32;
+      e.prm.flags = FGMM_PARAMS_LOGITS;
+    } else {
+      if (s.M < 0 || s.hw < 0 || (s.M * s.hw && (!s.y || !s.params.scales || !s.params.means || !s.params.weights)))
+        return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
+      if (s.params.dtype != items[0].params.dtype || (s.params.dtype != FGMM_F32 && s.params.dtype != FGMM_F16))
+        return fail(FGMM_ERR_INVALID, "item %d: parameter dtype must be FGMM_F32 or FGMM_F16 and the same for a whole batch", i);
+      if (s.params.flags & ~FGMM_PARAMS_LOGITS) return fail(FGMM_ERR_INVALID, "item %d: unknown fgmm_params.flags %d", i, s.params.flags);
+      e.prm = s.params;
+    }
     e.latent = true;
     e.y = s.y;
-    e.prm = s.params;
     e.M = s.M;
     e.hw = s.hw;
     e.clamp = clamp_scales;
@@ -473,7 +492,7 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
       return fail(FGMM_ERR_INVALID, "item %d: ckpt_stride must be 0 or a power of two >= 256, the same for a whole batch", i);
     e.ckpt_stride = s.ckpt_stride;
   }
-  const int rc = encode_batch(ctx, (dev::Stream)stream, v, mode);
+  const int rc = encode_batch(ctx, (dev::Stream)stream, v, mode, head ? &head->w : nullptr);
   for (int i = 0; i < count; ++i) {
     items[i].abs_max = v[i].abs_max;
     items[i].bytes = v[i].bytes;
@@ -483,6 +502,81 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
     items[i].n_ckpt = v[i].n_ckpt;
   }
   return rc;
+}
+
+int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales) {
+  return compress_batch_impl(ctx, stream, items, count, mode, clamp_scales, nullptr, nullptr);
+}
+
+// ---- the parameter head ---------------------------------------------------------------------------------------
+int fgmm_head_create(fgmm_ctx *ctx, void *stream, const float *weight, const float *bias, int M, int K, int c_in, fgmm_head **out) {
+  if (!out) return fail(FGMM_ERR_INVALID, "out == NULL");
+  *out = nullptr;
+  if (!ctx || !weight || M <= 0 || c_in <= 0 || M > (1 << 20) || c_in > (1 << 20)) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", K);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  fgmm_head *h = new (std::nothrow) fgmm_head;
+  if (!h) return fail(FGMM_ERR_NOMEM, "head");
+  h->device = ctx->device;
+  h->w.M = M, h->w.c_in = c_in;
+  h->w.n_cg = (M + kHeadCG - 1) / kHeadCG, h->w.n_kt = (c_in + kHeadBK - 1) / kHeadBK;
+  const size_t floats = head_packed_floats(M, c_in), bias_floats = (size_t)h->w.n_cg * 12 * kHeadCG;
+  void *p = nullptr;
+  if (dev::malloc_device(&p, floats * sizeof(float)) != 0) {
+    delete h;
+    return fail(FGMM_ERR_NOMEM, "%zu bytes of device memory for the packed weights", floats * sizeof(float));
+  }
+  h->packed = static_cast<float *>(p);
+  h->w.wp = h->packed, h->w.bp = h->packed + (floats - bias_floats);
+  int e = launch_head_pack(weight, bias, M, c_in, h->packed, h->packed + (floats - bias_floats), stream);
+  if (!e) e = dev::stream_sync((dev::Stream)stream); // (the caller may free or overwrite its weights on return)
+  if (e) {
+    (void)dev::free_device(p);
+    delete h;
+    return fail(FGMM_ERR_HIP, "packing the head's weights: %s", dev::error_string(e));
+  }
+  *out = h;
+  return FGMM_OK;
+}
+
+void fgmm_head_destroy(fgmm_head *h) {
+  if (!h) return;
+  {
+    DeviceGuard g(h->device);
+    (void)dev::free_device(h->packed);
+  }
+  delete h;
+}
+
+int fgmm_head_params_batch(fgmm_ctx *ctx, void *stream, const fgmm_head *head, const float *const *x, float *const *out, const int64_t *hw, int count) {
+  if (!ctx || !head || count < 0 || (count && (!x || !out || !hw))) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (head->device != ctx->device) return fail(FGMM_ERR_INVALID, "head: made for device %d, context on %d", head->device, ctx->device);
+  if (count == 0) return FGMM_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  int rc;
+  const size_t bytes = sizeof(HeadDesc) * (size_t)count;
+  if ((rc = ctx->ensure_device(bytes)) || (rc = ctx->ensure_host(bytes))) return rc;
+  HeadDesc *hd = reinterpret_cast<HeadDesc *>(ctx->h_ws);
+  int64_t hw_max = 0;
+  for (int i = 0; i < count; ++i) {
+    if (hw[i] < 0 || (hw[i] && (!x[i] || !out[i]))) return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
+    hd[i] = HeadDesc{x[i], out[i], hw[i]};
+    hw_max = std::max(hw_max, hw[i]);
+  }
+  DEV_TRY(dev::copy_async(ctx->d_ws, hd, bytes, dev::kH2D, (dev::Stream)stream));
+  LAUNCH_TRY(launch_head_params(reinterpret_cast<const HeadDesc *>(ctx->d_ws), head->w, count, hw_max, stream));
+  DEV_TRY(dev::stream_sync((dev::Stream)stream)); // (the descriptors' staging area belongs to the next call)
+  return FGMM_OK;
+}
+
+int fgmm_gmc_compress_head_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, const float *const *x, int count, const fgmm_head *head, int mode,
+                                 int clamp_scales) {
+  if (!head) return fail(FGMM_ERR_INVALID, "head == NULL");
+  return compress_batch_impl(ctx, stream, items, count, mode, clamp_scales, head, x);
 }
 
 int fgmm_gmc_compress(fgmm_ctx *ctx, void *stream, const float *y, const fgmm_params *params, int M, int K,

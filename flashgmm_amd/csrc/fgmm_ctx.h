@@ -347,6 +347,7 @@ struct EncItem {
   // inputs
   bool latent = false;               // latent-codec layout (y [M, hw], per-channel statistics, channel compaction) - also when M * hw == 0 and y is null
   const float *y = nullptr;          // device
+  const float *x = nullptr;          // device: the parameter head's input features [c_in, hw] (fused head: encode_batch's `head`)
   const int32_t *sym_dev = nullptr;  // device (raw boundary)
   const int32_t *sym_host = nullptr; // host copy of the raw symbols when the caller has one
   fgmm_params prm{};
@@ -375,7 +376,7 @@ struct EncItem {
   int64_t job_n = 0, job_bypass = 0;
   double t_sub = 0, t_start = 0, t_end = 0, t_waited = 0, t_lastland = 0; // job timeline (the call log; trace level 2)
 };
-int encode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<EncItem> &items, int mode);
+int encode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<EncItem> &items, int mode, const HeadW *head = nullptr);
 
 // ---- one bitstream of a batched decode --------------------------------------------------------------------------------------
 struct DecItem {

@@ -41,6 +41,7 @@ struct EncodeCall {
   dev::Stream stream;
   std::vector<EncItem> &items;
   int mode, count;
+  const HeadW *head; // the parameters come out of the head's matrix product (fgmm_head.hip) instead of planes
   Trace tr;
   // plan
   Arena ar;
@@ -61,8 +62,8 @@ struct EncodeCall {
   std::vector<EncItem *> job_items;
   double marks[5] = {0, 0, 0, 0, 0}; // the call log: enqueued | kernels + side information here | jobs out | last table (segment) seen landed | last job done
 
-  EncodeCall(fgmm_ctx *c, dev::Stream s, std::vector<EncItem> &it, int m)
-      : ctx(c), stream(s), items(it), mode(m), count((int)it.size()), tr("encode", (int)c->opt.trace) {}
+  EncodeCall(fgmm_ctx *c, dev::Stream s, std::vector<EncItem> &it, int m, const HeadW *h)
+      : ctx(c), stream(s), items(it), mode(m), count((int)it.size()), head(h), tr("encode", (int)c->opt.trace) {}
 
   size_t table_bytes(const EncItem &it) const { return sizeof(uint32_t) * (size_t)it.M * (size_t)it.hw; }
 
@@ -138,6 +139,8 @@ struct EncodeCall {
     d.M = it.M;
     d.clamp = it.clamp;
     d.logits = (it.prm.flags & FGMM_PARAMS_LOGITS) ? 1 : 0;
+    d.x = it.x;
+    d.meta_slots = (uint32_t)it.meta_count;
     d.yq = it.yq;
     d.chan_min = reinterpret_cast<float *>(ctx->d_ws + it.o_min);
     d.chan_max = reinterpret_cast<float *>(ctx->d_ws + it.o_max);
@@ -181,6 +184,10 @@ struct EncodeCall {
       if ((rc = ctx->prof_end(2, stream))) return rc;
     }
     if ((rc = ctx->prof_begin(0, stream))) return rc;
+    if (head) { // the fused head: matrix product + table entries in one kernel, no parameter planes
+      LAUNCH_TRY(launch_head_symtab(dd, *head, count, M_max, hw_max, mode, items[0].clamp != 0, stream));
+      return ctx->prof_end(0, stream);
+    }
     const int vec = vec4 ? (ctx->opt.enc_vec == 1 ? 1 : ctx->opt.enc_vec == 2 ? 2 : vec8 ? 8 : 4) : 1; // option "enc_vec" = 1, 2, 4: A/B narrower loads
     int64_t n_max = 0;
     bool linear = ctx->opt.enc_linear != 0; // option "enc_linear" = 0: A/B the per-channel grid
@@ -482,9 +489,9 @@ struct EncodeCall {
 
 } // namespace
 
-int encode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<EncItem> &items, int mode) {
+int encode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<EncItem> &items, int mode, const HeadW *head) {
   if (items.empty()) return FGMM_OK;
-  EncodeCall call(ctx, stream, items, mode);
+  EncodeCall call(ctx, stream, items, mode, head);
   const int rc = call.run();
   if (rc != FGMM_OK) (void)dev::stream_sync(stream); // (an early return: nothing of this call may still be writing the workspace the next one reuses)
   return rc;

@@ -26,7 +26,8 @@ struct EncDesc {
   int32_t M;
   int32_t clamp;
   int32_t logits;        // the weights planes hold LOGITS: pi = softmax4 over K in the kernel (fgmm_math.h)
-  int32_t pad_;
+  uint32_t meta_slots;   // entries of `meta`
+  const float *x;        // fused parameter head (fgmm_head.hip): the head's input features [c_in, hw]; the planes above are unused
   // outputs (device)
   float *yq;             // [M*hw] round(y), or null
   float *chan_min;       // [M]  min over the channel of y
@@ -81,6 +82,27 @@ struct DecDesc {
   uint32_t *blk_sums;            // [n_ch*tiles] row bytes per block
   unsigned long long *blk_off;   // [n_ch*tiles] byte offset of each block's first row
 };
+
+// ---- the parameter head's last layer on the matrix cores (fgmm_head.hip) ----------------------------------------
+constexpr int kHeadCG = 16; // latent channels per block: the packed weights are laid out in groups of this many
+constexpr int kHeadBK = 32; // input channels per LDS tile
+struct HeadW {              // the PACKED weights of a head (device): see head_pack_kernel
+  const float *wp;          // [n_cg][n_kt][12 * kHeadCG][kHeadBK]
+  const float *bp;          // [n_cg][12 * kHeadCG]
+  int32_t M, c_in, n_cg, n_kt;
+};
+struct HeadDesc { // one item of the un-fused form
+  const float *x; // device [c_in, hw]
+  float *out;     // device [3 * 4 * M, hw]: scales | means | logits planes, channel k * M + c
+  int64_t hw;
+};
+static inline size_t head_packed_floats(int M, int c_in) {
+  const size_t n_cg = ((size_t)M + kHeadCG - 1) / kHeadCG, n_kt = ((size_t)c_in + kHeadBK - 1) / kHeadBK;
+  return n_cg * n_kt * 12 * kHeadCG * kHeadBK + n_cg * 12 * kHeadCG;
+}
+int launch_head_pack(const float *w, const float *bias_or_null, int M, int c_in, float *wp, float *bp, void *stream);
+int launch_head_params(const HeadDesc *d_descs, const HeadW &w, int count, int64_t hw_max, void *stream);
+int launch_head_symtab(const EncDesc *d_descs, const HeadW &w, int count, int M_max, int64_t hw_max, int mode, bool clamped, void *stream);
 
 // ---- GPU-side decode of CHECKPOINTED bitstreams (segdec_kernel): one wave per segment ---------------------------
 struct SegDesc {

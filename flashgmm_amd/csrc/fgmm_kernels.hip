@@ -114,34 +114,6 @@ __global__ __launch_bounds__(kBlock) void chan_compact_kernel(const EncDesc *__r
 // row j of the table; blocks with j >= count leave after one scalar load.
 // VEC = 4: each lane owns 4 consecutive positions, every plane read is one 16-B load (1 KiB per wave-instr).
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE, bool CLAMPED>
-__device__ __forceinline__ uint32_t sym_entry(float vq, int vi, const float (&mu)[4], const float (&sg)[4], const float (&pi)[4],
-                                              int &bypass) {
-  const float x1 = vq - 0.5f;          // static_cast<float>(value) - offset             (:499)
-  const float x2 = vq - 0.5f + 1.0f;   // static_cast<float>(value) - offset + 1.0f
-  uint32_t lo, hi;
-  if constexpr (CLAMPED) {
-    Sigma4 S;
-    S.set(sg[0], sg[1], sg[2], sg[3]); // clamp + refined reciprocals, shared by both edges
-    bool ok = S.tame;
-    const f2 cc = mix4_clamped2<MODE>((f2){x1, x2}, mu, S, pi, ok); // both edges share every parameter: packed fp32
-    float c1 = cc.x, c2 = cc.y;
-    if (__builtin_expect(!ok, 0)) { // far-off / non-finite mean, NaN sigma: one rare out-of-line IEEE evaluation
-      const float s0 = clamp_scale(sg[0]), s1 = clamp_scale(sg[1]), s2 = clamp_scale(sg[2]), s3 = clamp_scale(sg[3]);
-      c1 = mix4_slow<MODE>(x1, mu[0], mu[1], mu[2], mu[3], s0, s1, s2, s3, pi[0], pi[1], pi[2], pi[3]);
-      c2 = mix4_slow<MODE>(x2, mu[0], mu[1], mu[2], mu[3], s0, s1, s2, s3, pi[0], pi[1], pi[2], pi[3]);
-    }
-    lo = quant16(c1);
-    hi = quant16(c2);
-  } else {
-    lo = quant16(mix4<MODE>(x1, mu, sg, pi));
-    hi = quant16(mix4<MODE>(x2, mu, sg, pi));
-  }
-  const uint32_t pmf = (hi - lo) & 0xFFFFu; // uint16_t pmf = next - value                (:512)
-  bypass = (pmf == 0);
-  return pmf ? (lo | (pmf << 16)) : ((uint32_t)vi & 0xFFFFu); // bypass: low 16 bits of the int32 symbol
-}
-
 #ifndef FGMM_SYMTAB_WAVES
 #define FGMM_SYMTAB_WAVES 5 // min waves per SIMD the register allocator must leave room for (<= 96 VGPRs)
 #endif

@@ -27,7 +27,7 @@ from torch import Tensor
 
 from . import _lib
 
-__all__ = ["GaussianMixtureConditional", "EntropyBottleneckCoder", "CheckpointedBytes", "CompressedBatch"]
+__all__ = ["GaussianMixtureConditional", "EntropyBottleneckCoder", "CheckpointedBytes", "CompressedBatch", "ParameterHead"]
 
 CKPT_DTYPE = np.dtype([("x", "<u8"), ("pos", "<u8")])  # fgmm_ckpt
 
@@ -132,6 +132,63 @@ def _plane_view(t: Tensor, K: int) -> Tuple[Tensor, int, int]:
 
 
 _PARAM_DTYPES = (torch.float32, torch.float16)
+
+
+class ParameterHead:
+    """The last layer of the reference's ``entropy_parameters`` - ``nn.Conv2d(c_in, 3*K*M, 1)`` (compressai/models/ckbd_gmm.py:115-121) -
+    with the ``chunk(3, 1)`` / softmax-over-K that follows it (latent_codecs/gaussian_mixture_conditional.py:183-202), on the matrix
+    cores in ONE fixed summation order (include/flashgmm_amd.h section 2b: bit for bit an ``fmaf`` chain over the input channels):
+
+        head = ParameterHead(entropy_parameters[-1])                       # any nn.Conv2d(c_in, 3*K*M, 1) on the GPU
+        scales, means, logits = head.params(x)                             # x [N, c_in, h, w] -> three [N, K*M, h, w] views
+        res = gmc.compress_head_batch(y, x, head)                          # the same parameters, never written to HBM
+        y_hat = gmc.decompress_batch(res.strings, res.abs_maxes, res.zero_bitmaps, scales, means, logits, weights_are_logits=True)
+
+    Encoder and decoder then derive identical parameters from identical weights whatever BLAS / MIOpen version either side
+    runs - the reference relies on that silently.  The weights are packed once, here."""
+
+    def __init__(self, conv, K: int = 4):
+        w = conv.weight.detach()
+        if w.dim() != 4 or w.shape[2:] != (1, 1) or w.shape[0] % (3 * K) or not w.is_cuda:
+            raise RuntimeError("expected the weights of a 1x1 nn.Conv2d(c_in, 3*K*M) on a HIP device")
+        self.K, self.M, self.c_in = int(K), int(w.shape[0] // (3 * K)), int(w.shape[1])
+        self.device = w.device
+        self._dev = w.device.index if w.device.index is not None else -1
+        w2 = w.reshape(w.shape[0], w.shape[1]).to(torch.float32).contiguous()
+        b = None if conv.bias is None else conv.bias.detach().to(torch.float32).contiguous()
+        out = C.c_void_p()
+        stream = torch.cuda.current_stream(w.device).cuda_stream
+        _lib.check(_lib.lib().fgmm_head_create(_lib.ctx(self._dev), stream, w2.data_ptr(), b.data_ptr() if b is not None else None, self.M, self.K,
+                                               self.c_in, C.byref(out)), "ParameterHead")
+        self._h = out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().fgmm_head_destroy(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+
+    def _features(self, x: Tensor) -> Tensor:
+        if x.dim() != 4 or x.shape[1] != self.c_in or x.device != self.device:
+            raise RuntimeError(f"features must be [N, {self.c_in}, h, w] on {self.device}; got {tuple(x.shape)} on {x.device}")
+        return x.to(torch.float32).contiguous()
+
+    def params(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        """-> (scales, means, logits): views ``[N, K*M, h, w]`` of one ``[N, 3*K*M, h, w]`` tensor - what ``entropy_parameters[-1](x)
+        .chunk(3, 1)`` gives, in the library's summation order.  ``logits``: pass ``weights_are_logits=True`` to the coder."""
+        x = self._features(x)
+        N, _, h, w = x.shape
+        out = torch.empty((N, 3 * self.K * self.M, h, w), dtype=torch.float32, device=x.device)
+        if N and h * w:
+            per_x, per_o = self.c_in * h * w * 4, 3 * self.K * self.M * h * w * 4
+            xs = (C.c_void_p * N)(*[x.data_ptr() + i * per_x for i in range(N)])
+            os_ = (C.c_void_p * N)(*[out.data_ptr() + i * per_o for i in range(N)])
+            hws = (C.c_int64 * N)(*([h * w] * N))
+            _lib.check(_lib.lib().fgmm_head_params_batch(_lib.ctx(self._dev), torch.cuda.current_stream(x.device).cuda_stream, self._h, xs, os_, hws, N),
+                       "ParameterHead.params")
+        return tuple(out.chunk(3, 1))
 
 
 class GaussianMixtureConditional(nn.Module):
@@ -348,6 +405,42 @@ class GaussianMixtureConditional(nn.Module):
                 data = CheckpointedBytes._adopt(data, cks[i][0], self.checkpoint_stride, cks[i][1])
             res.append(((data, int(items[i].abs_max), bitmaps[i]), outs[i].view_as(ys[i])))
         return res
+
+    def compress_head_batch(self, y: Tensor, x: Tensor, head: "ParameterHead") -> CompressedBatch:
+        """``compress_batch`` with the parameter head FUSED into the encode-side CDF kernel: ``y [N, M, h, w]`` latents, ``x [N, c_in, h, w]``
+        the features the head's last convolution reads.  The 3*K parameters of a latent go from the matrix cores' accumulators into
+        its table entry; the parameter tensors are never written.  The bitstreams are those of
+        ``compress_batch(y, *head.params(x), weights_are_logits=True)``, byte for byte."""
+        if self.K != _lib.FGMM_K or head.K != self.K:
+            raise RuntimeError(f"K = {self.K}: the coder is bound for K = 4 only (as the reference's)")
+        x = head._features(x)
+        N, _, h, w = x.shape
+        M = head.M
+        if y.dim() != 4 or tuple(y.shape) != (N, M, h, w) or y.dtype != torch.float32 or y.device != x.device:
+            raise RuntimeError(f"y must be float32 [{N}, {M}, {h}, {w}] on the features' device; got {tuple(y.shape)}")
+        dev = x.device
+        if N == 0:
+            return CompressedBatch([], [], torch.empty((0, M), dtype=torch.int64), torch.empty((0, 1, M, h, w), dtype=torch.float32, device=dev))
+        y = y.contiguous()
+        items = np.zeros(N, _lib.ITEM_DTYPE)
+        rng = np.arange(N, dtype=np.uint64)
+        items["y"] = np.uint64(y.data_ptr()) + rng * np.uint64(M * h * w * 4)
+        items["M"], items["K"], items["hw"] = M, self.K, h * w
+        yq = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
+        zb = torch.empty((N, M), dtype=torch.int64)
+        items["yq_out"] = np.uint64(yq.data_ptr()) + rng * np.uint64(M * h * w * 4)
+        items["zero_bitmap"] = np.uint64(zb.data_ptr()) + rng * np.uint64(M * 8)
+        items["ckpt_stride"] = self.checkpoint_stride
+        xs = (C.c_void_p * N)(*[x.data_ptr() + i * head.c_in * h * w * 4 for i in range(N)])
+        di = dev.index if dev.index is not None else -1
+        rc = _lib.lib().fgmm_gmc_compress_head_batch(_lib.ctx(di), torch.cuda.current_stream(dev).cuda_stream,
+                                                     C.cast(items.ctypes.data, C.POINTER(_lib.fgmm_item)), xs, N, head._h, self._mode(), int(self.clamp_scales))
+        _lib.check(rc, "GaussianMixtureConditional.compress_head_batch")
+        datas = _lib.take_bytes_many(di, items["bytes"].tolist(), items["bytes_len"].tolist(), CheckpointedBytes if self.checkpoint_stride else None)
+        if self.checkpoint_stride:
+            cks = _take_ckpts_many(di, items["ckpt"].tolist(), items["n_ckpt"].tolist())
+            datas = [CheckpointedBytes._adopt(d, ck[0], self.checkpoint_stride, ck[1]) for d, ck in zip(datas, cks)]
+        return CompressedBatch(datas, items["abs_max"].tolist(), zb, yq)
 
     def compress(self, y: Tensor, scales: Tensor, means: Tensor, weights: Tensor, *, weights_are_logits: bool = False):
         """-> ((bytes, abs_max, zero_bitmap), y_quantized)     (entropy_models.py:833-867)"""

@@ -38,8 +38,9 @@
 extern "C" {
 #endif
 
-#define FGMM_ABI_VERSION 5 /* 5: + fgmm_ctx_call_log; REMOVED (measured, lost, pruned): options tab_place / tab_spin / copy_engine /
-                              dec_pair / dec_group, fgmm_rans_decode_tab2 + fgmm_tab_ref, fgmm_ctx_stat index 6 */
+#define FGMM_ABI_VERSION 6 /* 6: + the parameter head (fgmm_head_*, fgmm_gmc_compress_head_batch); FGMM_WORKER_CPUS that cannot be honoured
+                              fails fgmm_ctx_create.  5: + fgmm_ctx_call_log; REMOVED (measured, lost, pruned): options tab_place /
+                              tab_spin / copy_engine / dec_pair / dec_group, fgmm_rans_decode_tab2 + fgmm_tab_ref, fgmm_ctx_stat index 6 */
 
 typedef enum {
   FGMM_OK = 0,
@@ -266,6 +267,35 @@ typedef struct {
 
 int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
 int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 2b. The parameter head's last layer, on the matrix cores.
+ *    Replaces: the final 1x1 convolution of `entropy_parameters`, nn.Conv2d(c_in, 3*K*M, 1) (compressai/models/ckbd_gmm.py:115-121;
+ *    c_in = 640, M = 192 there), the chunk(3, 1) into scales | means | weights and the softmax over K
+ *    (compressai/latent_codecs/gaussian_mixture_conditional.py:183-202).
+ *    out[o][p] = bias[o] + sum_k weight[o][k] * x[k][p], o = t * K*M + k * M + c (t: scales, means, logits), computed on
+ *    v_mfma_f32_32x32x2_f32 in ONE fixed order - bit for bit  acc = bias[o]; for k ascending: acc = fmaf(weight[o][k], x[k][p], acc)  -
+ *    so that encoder and decoder derive identical parameters from identical weights on any ROCm / torch / MIOpen version (a
+ *    BLAS's or MIOpen's summation order is not part of any contract; the reference silently relies on it being the same on both
+ *    sides).  Streams coded from these parameters decode from these parameters.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct fgmm_head fgmm_head; /* a head's weights, packed for the kernel, on the context's device */
+/* weight: device float32 [3*K*M, c_in] row-major (Conv2d.weight [3*K*M, c_in, 1, 1]); bias: device float32 [3*K*M] or NULL.
+ * The weights are copied (packed) before the call returns. */
+int fgmm_head_create(fgmm_ctx *ctx, void *stream, const float *weight, const float *bias, int M, int K, int c_in, fgmm_head **out);
+void fgmm_head_destroy(fgmm_head *head);
+/* The parameters as tensors, for the decoder (and for anyone who wants them): item i reads x[i] = device float32 [c_in, hw[i]] and
+ * writes out[i] = device float32 [3*K*M, hw[i]] - scales | means | LOGITS, each [K*M, hw] with channel k*M + c: three fgmm_params
+ * planes with stride_k = M*hw, stride_c = hw, flags FGMM_PARAMS_LOGITS (the softmax over K and the sigma clamp run in the table
+ * kernels).  Returns with the outputs complete. */
+int fgmm_head_params_batch(fgmm_ctx *ctx, void *stream, const fgmm_head *head, const float *const *x, float *const *out,
+                           const int64_t *hw, int count);
+/* fgmm_gmc_compress_batch with the head FUSED into the encode-side CDF kernel: items[i].params is ignored, the twelve parameters of
+ * a latent go from the MFMA accumulators into the table entry and never exist in HBM.  x[i]: device float32 [c_in, items[i].hw];
+ * items[i].M must be the head's M.  The bitstreams are those of fgmm_gmc_compress_batch fed fgmm_head_params_batch's planes with
+ * FGMM_PARAMS_LOGITS (same arithmetic, same bytes). */
+int fgmm_gmc_compress_head_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, const float *const *x, int count,
+                                 const fgmm_head *head, int mode, int clamp_scales);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 3. Building blocks ("same tables => same bytes" surfaces; also what the parity tests probe).

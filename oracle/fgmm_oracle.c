@@ -658,3 +658,20 @@ int fgo_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *c
   }
   return 0;
 }
+
+/* ---- the parameter head's last layer --------------------------------------------------------------------
+ * The final 1x1 convolution of `entropy_parameters` (compressai/models/ckbd_gmm.py:115-121: nn.Conv2d(N*10//3, 3*K*N, 1)) as the
+ * product library defines its arithmetic (include/flashgmm_amd.h section 2b): per output channel o and position p ONE chain of
+ * binary32 fused multiply-adds, k ascending, starting from the bias -
+ *     acc = bias[o];  for k = 0 .. c_in-1:  acc = fmaf(w[o][k], x[k][p], acc)
+ * which is what v_mfma_f32_32x32x2_f32 computes.  A convolution is a sum and torch / MIOpen fix no order for it, so this is pinned
+ * two ways: bit for bit against this chain, and within 1e-5 (relative to sum |w x|) of torch.nn.functional.conv2d in fp32.
+ * w [n_out, c_in] row-major, bias [n_out] or NULL, x [c_in, hw], out [n_out, hw]. */
+void fgo_head_params(int n_out, int c_in, int64_t hw, const float *w, const float *bias, const float *x, float *out) {
+  for (int o = 0; o < n_out; ++o)
+    for (int64_t p = 0; p < hw; ++p) {
+      float acc = bias ? bias[o] : 0.0f;
+      for (int k = 0; k < c_in; ++k) acc = fmaf(w[(int64_t)o * c_in + k], x[(int64_t)k * hw + p], acc);
+      out[(int64_t)o * hw + p] = acc;
+    }
+}

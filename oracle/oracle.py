@@ -63,6 +63,8 @@ def lib() -> C.CDLL:
         L.fgo_decode_table.restype = C.c_int
         L.fgo_pmf_to_quantized_cdf.argtypes = [p, C.c_int, C.c_int, p]
         L.fgo_pmf_to_quantized_cdf.restype = C.c_int
+        L.fgo_head_params.argtypes = [C.c_int, C.c_int, i64, p, p, p, p]
+        L.fgo_head_params.restype = None
         _lib = L
     return _lib
 
@@ -228,6 +230,19 @@ def pmf_to_quantized_cdf(pmf, precision: int = 16):
 # prebuilt files travelled to (the GPU box).  APPROX_MODE is latched once per process by the reference
 # (rans_interface.cpp:100), so callers choose the mode through the environment BEFORE first use.
 # ---------------------------------------------------------------------------------------------------
+
+def head_params(weight, bias, x) -> np.ndarray:
+    """the parameter head's last layer as the product defines its arithmetic (one fmaf chain per output, k ascending, from the bias):
+    weight [n_out, c_in], bias [n_out] or None, x [c_in, hw] -> [n_out, hw] float32"""
+    w = np.ascontiguousarray(weight, dtype=np.float32)
+    xx = np.ascontiguousarray(x, dtype=np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    n_out, c_in = w.shape
+    assert xx.shape[0] == c_in and (b is None or b.shape == (n_out,))
+    out = np.empty((n_out, xx.shape[1]), np.float32)
+    lib().fgo_head_params(n_out, c_in, xx.shape[1], _ptr(w), _ptr(b) if b is not None else None, _ptr(xx), _ptr(out))
+    return out
+
 
 def ref_available(flavour: str = "") -> bool:
     d = os.path.join(REF_DIR, flavour)

@@ -1,0 +1,132 @@
+"""GPU: the parameter head's last layer on the matrix cores, fused with the encode-side CDF kernel (SURVEY.md section 8 f2;
+flashgmm_amd/csrc/fgmm_head.hip).  Replaces compressai/models/ckbd_gmm.py:115-121 (the final nn.Conv2d(640, 3*K*N, 1) of
+`entropy_parameters`) + latent_codecs/gaussian_mixture_conditional.py:183-202 (chunk, softmax over K).
+
+Bars: the parameters are BIT FOR BIT the oracle's fmaf chain (one rounding per product, k ascending, from the bias - the order the
+library fixes) and within 1e-5 (relative to sum |w x|) of torch.nn.functional.conv2d in fp32; the fused kernel's bitstreams are byte
+for byte those of the un-fused path fed the head kernel's own parameter planes; decode(encode(y)) == round(y)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from flashgmm_amd import GaussianMixtureConditional, ParameterHead, _lib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+MODES = ["polya", "as", "logistic"]
+
+
+def make_head(seed, M, c_in, h, w, N, dead=0, dev="cuda:0"):
+    """a random 1x1 conv of the head's shape whose outputs look like entropy parameters (sigma of order e_c, means of order e_c,
+    logits of order one) for latents of per-channel energy e_c, and features / latents to go with it"""
+    rng = np.random.default_rng(seed)
+    e_c = np.exp(rng.uniform(-2.5, 2.0, M)).astype(np.float32)
+    W = (rng.standard_normal((3, 4, M, c_in)) / np.sqrt(c_in)).astype(np.float32)
+    b = np.zeros((3, 4, M), np.float32)
+    W[0] *= 0.3 * e_c[None, :, None]
+    b[0] = (0.6 + 0.5 * rng.uniform(0, 1, (4, M))) * e_c[None, :]  # sigma: mostly positive, sometimes under the clamp
+    W[1] *= e_c[None, :, None]
+    conv = torch.nn.Conv2d(c_in, 12 * M, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(W.reshape(12 * M, c_in, 1, 1)))
+        conv.bias.copy_(torch.from_numpy(b.reshape(-1)))
+    x = rng.standard_normal((N, c_in, h, w)).astype(np.float32)
+    x = np.where(x > 0, x, 0.01 * x)  # (the layer before is a LeakyReLU)
+    y = (rng.standard_normal((N, M, h, w)) * 1.5 * e_c[None, :, None, None]).astype(np.float32)
+    if dead:
+        y[:, rng.choice(M, dead, replace=False)] *= 0.0
+    return conv.to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+
+
+@pytest.mark.parametrize("M,c_in,h,w", [(192, 640, 32, 24), (16, 32, 4, 8), (24, 40, 5, 7), (8, 33, 3, 3), (40, 64, 16, 20)])
+def test_head_parameters_equal_the_fmaf_chain_bit_for_bit(oracle, M, c_in, h, w):
+    """v_mfma_f32_32x32x2_f32 == fmaf chain, k ascending, from the bias: every one of the 3*K*M*h*w outputs, ragged sizes included
+    (channels not a multiple of 16, input channels not a multiple of 32, positions not a multiple of 4 or 256)"""
+    conv, x, _ = make_head(11, M, c_in, h, w, N=2)
+    head = ParameterHead(conv)
+    got = torch.cat(head.params(x), 1).cpu().numpy()
+    Wn, bn = conv.weight.detach().cpu().numpy().reshape(12 * M, c_in), conv.bias.detach().cpu().numpy()
+    for i in range(x.shape[0]):
+        want = oracle.head_params(Wn, bn, x[i].cpu().numpy().reshape(c_in, h * w)).reshape(12 * M, h, w)
+        assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), (i, np.abs(got[i] - want).max())
+
+
+def test_head_parameters_within_1e5_of_torch_conv2d():
+    """... and they are the convolution: within 1e-5 of sum |w x| + |b| of torch's fp32 conv2d (which fixes no summation order)"""
+    M, c_in = 192, 640
+    conv, x, _ = make_head(12, M, c_in, 32, 24, N=3)
+    head = ParameterHead(conv)
+    got = torch.cat(head.params(x), 1)
+    with torch.no_grad():
+        want = torch.nn.functional.conv2d(x, conv.weight, conv.bias)
+        scale = torch.nn.functional.conv2d(x.abs(), conv.weight.abs(), conv.bias.abs())
+    rel = ((got - want).abs() / scale).max().item()
+    assert rel < 1e-5, rel
+    # the three chunks are what the latent codec's chunk(3, 1) gives (gaussian_mixture_conditional.py:193-195)
+    s, m, lg = head.params(x)
+    assert s.shape == (3, 4 * M, 32, 24) and torch.equal(torch.cat([s, m, lg], 1), got)
+
+
+def test_head_without_bias():
+    conv, x, _ = make_head(13, 16, 64, 8, 8, N=1)
+    conv.bias = None
+    got = torch.cat(ParameterHead(conv).params(x), 1)
+    with torch.no_grad():
+        want = torch.nn.functional.conv2d(x, conv.weight)
+    assert torch.allclose(got, want, rtol=0, atol=2e-5 * want.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("shape", [(192, 640, 32, 24, 4, 20), (24, 40, 5, 7, 3, 5), (32, 64, 16, 16, 2, 0)])
+def test_fused_head_bytes_equal_the_unfused_path(mode, shape):
+    """one kernel (matrix product + table entries) against two (head_params planes -> symtab_kernel with FGMM_PARAMS_LOGITS): the same
+    bytes, abs_max, zero bitmap and y_q for every item; and the streams decode from the head's planes to round(y)"""
+    M, c_in, h, w, N, dead = shape
+    conv, x, y = make_head(21, M, c_in, h, w, N, dead)
+    head = ParameterHead(conv)
+    gmc = GaussianMixtureConditional(K=4, mode=mode)
+    fused = gmc.compress_head_batch(y, x, head)
+    s, m, lg = head.params(x)
+    plain = gmc.compress_batch(y, s, m, lg, weights_are_logits=True)
+    assert len(fused) == N
+    for i in range(N):
+        (bf, af, zf), qf = fused[i]
+        (bp, ap, zp), qp = plain[i]
+        assert bytes(bf) == bytes(bp) and af == ap and torch.equal(zf, zp) and torch.equal(qf, qp), i
+        assert int(zf.sum()) == M - dead and len(bf) > 8
+    out = gmc.decompress_batch(fused.strings, fused.abs_maxes, fused.zero_bitmaps, s, m, lg, weights_are_logits=True, stacked_output=True)
+    assert torch.equal(out, fused.y_q) and torch.equal(fused.y_q[:, 0], torch.round(y))
+
+
+def test_fused_head_with_checkpoints_and_segmented_tables():
+    """the fused kernel writes the SAME table layout the host encoders expect: segmented tables (a worker per bitstream, tail first)
+    and checkpointed streams"""
+    M, c_in, h, w, N = 192, 640, 32, 24, 6
+    conv, x, y = make_head(22, M, c_in, h, w, N, dead=7)
+    head = ParameterHead(conv)
+    saved = _lib.get_option(0, "enc_segs")
+    try:
+        ref = GaussianMixtureConditional(K=4, mode="polya").compress_head_batch(y, x, head)
+        _lib.set_option(0, "enc_segs", 2)  # (forced: segmented whatever the size)
+        seg = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=256).compress_head_batch(y, x, head)
+    finally:
+        _lib.set_option(0, "enc_segs", saved)
+    for i in range(N):
+        assert bytes(seg.strings[i]) == bytes(ref.strings[i]) and len(seg.strings[i].ckpt) > 0
+
+
+def test_head_refuses_what_it_cannot_do():
+    conv, x, y = make_head(23, 16, 32, 4, 8, N=1)
+    head = ParameterHead(conv)
+    gmc = GaussianMixtureConditional(K=4)
+    with pytest.raises(RuntimeError):
+        gmc.compress_head_batch(y[:, :8], x, head)  # M mismatch
+    with pytest.raises(RuntimeError):
+        head.params(x[:, :16])  # c_in mismatch
+    with pytest.raises(RuntimeError):
+        ParameterHead(torch.nn.Conv2d(32, 12 * 16, 3).to("cuda:0"))  # not 1x1
