@@ -562,13 +562,15 @@ int fgmm_head_params_batch(fgmm_ctx *ctx, void *stream, const fgmm_head *head, c
   if ((rc = ctx->ensure_device(bytes)) || (rc = ctx->ensure_host(bytes))) return rc;
   HeadDesc *hd = reinterpret_cast<HeadDesc *>(ctx->h_ws);
   int64_t hw_max = 0;
+  bool vec = true;
   for (int i = 0; i < count; ++i) {
     if (hw[i] < 0 || (hw[i] && (!x[i] || !out[i]))) return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
     hd[i] = HeadDesc{x[i], out[i], hw[i]};
     hw_max = std::max(hw_max, hw[i]);
+    vec = vec && (hw[i] & 3) == 0 && (reinterpret_cast<uintptr_t>(x[i]) & 15) == 0;
   }
   DEV_TRY(dev::copy_async(ctx->d_ws, hd, bytes, dev::kH2D, (dev::Stream)stream));
-  LAUNCH_TRY(launch_head_params(reinterpret_cast<const HeadDesc *>(ctx->d_ws), head->w, count, hw_max, stream));
+  LAUNCH_TRY(launch_head_params(reinterpret_cast<const HeadDesc *>(ctx->d_ws), head->w, count, hw_max, vec, stream));
   DEV_TRY(dev::stream_sync((dev::Stream)stream)); // (the descriptors' staging area belongs to the next call)
   return FGMM_OK;
 }

@@ -16,8 +16,10 @@
 // Tiling (wave64, 256 threads = 4 waves, one block per CU - the kernel holds 192 accumulator registers per lane):
 //   block  = 16 latent channels (their 3*K = 12 parameters each: 192 rows of W) x 256 positions
 //   wave   = all 192 rows x 64 positions = 6 row tiles x 2 position tiles of 32x32 accumulators
-//   K loop = tiles of 32 input channels staged through LDS (W tile 192 x 32 from a PRE-PACKED copy of the weights: one contiguous 24 KB
-//            read per block and tile; x tile 32 x 256), global loads of tile i + 1 in flight while tile i is multiplied
+//   K loop = tiles of 32 input channels staged through LDS, two buffers (W tile 192 x 32 from a PRE-PACKED copy of the weights: one
+//            contiguous 24 KB read per block and tile; x tile 32 x 256): the global loads of tile i + 1 are in flight and its LDS writes
+//            issue while tile i is multiplied, one barrier per tile; the operand fragments are read from LDS one group of four k-pairs
+//            ahead of the products that use them
 //   rows   : row tile (g, t), g = which 8 of the 16 channels, t = scales | means | logits; row 4 * cl + k within it = parameter
 //            (t, k) of channel 8 g + cl.  The 32x32 accumulator map (row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), column = lane & 31)
 //            then gives every lane, for ITS position, registers 4 j + k = parameter (t, k) of channel 8 g + 2 j + (lane >> 5): a lane
@@ -64,11 +66,14 @@ __global__ __launch_bounds__(256) void head_pack_kernel(const float *__restrict_
 
 // FUSED: the epilogue evaluates the table entry (EncDesc: y, channel census of quant_stats_kernel, the table's place); else it writes the
 // three parameter tensors as planes [3 * 4 * M, hw] (scales | means | logits, channel k * M + c).
-template <int MODE, bool CLAMPED, bool FUSED>
+// VEC: every item's positions are a multiple of 4 and its features 16-byte aligned (checked by the host): the x tile is staged with
+// 16-byte loads; else element by element (any shape, slowly).
+constexpr int kStage = kRows * kALd + kBK * kBLd;                   // floats of one staged (W tile, x tile) pair
+constexpr size_t kHeadLds = 2 * sizeof(float) * (size_t)kStage;     // two of them: 129 024 bytes of the CU's 160 KB
+template <int MODE, bool CLAMPED, bool FUSED, bool VEC>
 __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict__ edescs, const HeadDesc *__restrict__ hdescs, HeadW hw_, int pt_max,
                                                        int cg_max, int total) {
-  __shared__ __attribute__((aligned(16))) float sA[kRows * kALd];
-  __shared__ __attribute__((aligned(16))) float sB[kBK * kBLd];
+  extern __shared__ __attribute__((aligned(16))) float s_stage[];
   __shared__ int s_rank[kCG];
   // ---- which (item, position tile, channel group): consecutive logical slots on one XCD (blocks are dealt to the 8 XCDs round robin)
   const int per_xcd = (int)gridDim.x >> 3;
@@ -122,9 +127,14 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
   // ---- K loop
   const int n_kt = hw_.n_kt, c_in = hw_.c_in;
   const float *wp = hw_.wp + (int64_t)cg * n_kt * (kRows * kBK);
-  const bool vec_ok = (hw & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  // Staging, branch-free (the K loop is ONE basic block, so that the instruction order below is the order issued): a load that would
+  // fall outside the features (input channels past c_in in the last tile, positions past hw in the last position tile) reads a valid
+  // address instead and is replaced by zero; the packed weights are zero there as well.
   float4_t ra[6], rb[8];
+  unsigned rb_ok = 0; // bit 4 j + e: element e of rb[j] lies inside the features (applied when the tile is WRITTEN: a select right after
+                      // the load would wait for it, and the loads are there to be in flight under a tile's products)
   auto load_tile = [&](int kt) {
+    rb_ok = 0;
     const float4_t *src = reinterpret_cast<const float4_t *>(wp + (int64_t)kt * (kRows * kBK));
 #pragma unroll
     for (int j = 0; j < 6; ++j) ra[j] = src[tid + 256 * j];
@@ -133,21 +143,23 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
       const int f = tid + 256 * j, kk = f >> 6, p4 = f & 63;
       const int kin = kt * kBK + kk;
       const int64_t p = P0 + 4 * p4;
-      float4_t v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (kin < c_in) {
-        const float *g = x + (int64_t)kin * hw + p;
-        if (vec_ok && p + 3 < hw) {
-          v = ldg<float4_t>(g);
-        } else {
+      const bool k_ok = kin < c_in;
+      const float *g = x + (int64_t)(k_ok ? kin : c_in - 1) * hw;
+      float4_t v;
+      if constexpr (VEC) {
+        v = ldg<float4_t>(g + (p < hw ? p : 0));
+        rb_ok |= (k_ok && p < hw ? 0xFu : 0u) << (4 * j); // (hw is a multiple of 4: the four positions are inside or outside together)
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (p + e < hw) v[e] = g[e];
+        for (int e = 0; e < 4; ++e) {
+          v[e] = g[p + e < hw ? p + e : 0];
+          rb_ok |= (k_ok && p + e < hw ? 1u : 0u) << (4 * j + e);
         }
       }
       rb[j] = v;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](float *sA, float *sB) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int f = tid + 256 * j;
@@ -156,38 +168,74 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int f = tid + 256 * j;
-      *reinterpret_cast<float4_t *>(&sB[(f >> 6) * kBLd + (f & 63) * 4]) = rb[j];
+      float4_t v = rb[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (rb_ok >> (4 * j + e)) & 1u ? v[e] : 0.0f;
+      *reinterpret_cast<float4_t *>(&sB[(f >> 6) * kBLd + (f & 63) * 4]) = v;
     }
   };
-  load_tile(0);
-  store_tile();
-  __syncthreads();
-  for (int kt = 0; kt < n_kt; ++kt) {
-    if (kt + 1 < n_kt) load_tile(kt + 1); // in flight while this tile is multiplied
-    const float *a_base = &sA[col * kALd + h * 16];
-    const float *b_base = &sB[h * kBLd + wave * 64 + col];
+  // the fragments of four k-pairs (one 16-byte read per row tile, the two position tiles' values of a k-pair in one ds_read2): read
+  // one group AHEAD of the products that use them, so that the matrix pipe never waits for the LDS (one wave per SIMD: nobody else
+  // would fill the gap)
+  struct Frag {
+    float4_t a[kTiles];
+    float b[4][2];
+  };
+  auto read_frag = [&](Frag &f, const float *sA, const float *sB, int s4) {
+    const float *a_base = sA + col * kALd + h * 16 + s4 * 4;
+    const float *b_base = sB + h * kBLd + wave * 64 + col + 8 * s4 * kBLd;
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      float4_t a[kTiles];
+    for (int tl = 0; tl < kTiles; ++tl) f.a[tl] = *reinterpret_cast<const float4_t *>(a_base + tl * 32 * kALd);
 #pragma unroll
-      for (int tl = 0; tl < kTiles; ++tl) a[tl] = *reinterpret_cast<const float4_t *>(a_base + tl * 32 * kALd + s4 * 4);
+    for (int e = 0; e < 4; ++e) f.b[e][0] = b_base[2 * e * kBLd], f.b[e][1] = b_base[2 * e * kBLd + 32];
+  };
+  auto multiply = [&](const Frag &f) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int s = s4 * 4 + e;
-        const float b0 = b_base[2 * s * kBLd], b1 = b_base[2 * s * kBLd + 32];
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int tl = 0; tl < kTiles; ++tl) {
-          acc[tl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tl][e], b0, acc[tl][0], 0, 0, 0);
-          acc[tl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tl][e], b1, acc[tl][1], 0, 0, 0);
-        }
+      for (int tl = 0; tl < kTiles; ++tl) {
+        acc[tl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tl][e], f.b[e][0], acc[tl][0], 0, 0, 0);
+        acc[tl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tl][e], f.b[e][1], acc[tl][1], 0, 0, 0);
       }
-    }
-    __syncthreads(); // every wave has read the tile
-    if (kt + 1 < n_kt) {
-      store_tile();
-      __syncthreads();
-    }
+  };
+  // __builtin_amdgcn_sched_barrier(0): nothing is scheduled across it.  Left to itself the scheduler sinks every LDS read to just before
+  // its first use and the global loads to just before the LDS writes - each then waited for with the matrix pipe idle (measured: 0.62
+  // of the MFMA roof; the bursts below cost a few issue slots per 48 products instead).
+#define FGMM_FENCE() __builtin_amdgcn_sched_barrier(0)
+  load_tile(0);
+  store_tile(s_stage, s_stage + kRows * kALd);
+  __syncthreads();
+  Frag f0, f1;
+  read_frag(f0, s_stage, s_stage + kRows * kALd, 0);
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const float *sA = s_stage + (kt & 1) * kStage, *sB = sA + kRows * kALd;
+    float *nA = s_stage + ((kt + 1) & 1) * kStage, *nB = nA + kRows * kALd;
+    // 192 products per wave and tile in four groups of 48; before each group, what a LATER step needs is issued:
+    //   group 0: the global loads of the next tile (the last tile loads itself again: harmless) and the fragments of group 1
+    //   group 1, 2: the fragments of groups 2, 3
+    //   group 3: the next tile's LDS writes - into the OTHER buffer, which was last read a tile ago, a barrier behind us
+    FGMM_FENCE();
+    load_tile(kt + 1 < n_kt ? kt + 1 : kt);
+    read_frag(f1, sA, sB, 1);
+    FGMM_FENCE();
+    multiply(f0);
+    FGMM_FENCE();
+    read_frag(f0, sA, sB, 2);
+    FGMM_FENCE();
+    multiply(f1);
+    FGMM_FENCE();
+    read_frag(f1, sA, sB, 3);
+    FGMM_FENCE();
+    multiply(f0);
+    FGMM_FENCE();
+    store_tile(nA, nB);
+    FGMM_FENCE();
+    multiply(f1);
+    FGMM_FENCE();
+    __syncthreads();
+    read_frag(f0, nA, nB, 0); // (after the last tile: a read of the other buffer that nobody uses)
   }
+#undef FGMM_FENCE
   // ---- epilogue: the lane's 16 latents (2 channel halves x 4 channels x 2 position tiles), all twelve parameters in registers
   if constexpr (FUSED) {
     const EncDesc &d = edescs[item];
@@ -246,14 +294,21 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
   }
 }
 
-template <int MODE, bool CLAMPED>
+template <typename K>
+int head_lds(K kernel) { // (more than the 64 KB a kernel gets without asking)
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHeadLds);
+}
+
+template <int MODE, bool CLAMPED, bool VEC>
 int launch_fused(const EncDesc *descs, const HeadW &w, int count, int M_max, int64_t hw_max, hipStream_t st) {
   const int pt_max = (int)((hw_max + kPB - 1) / kPB), cg_max = (M_max + kCG - 1) / kCG;
   const int64_t total = (int64_t)count * pt_max * cg_max;
   if (total <= 0) return 0;
   if (total > (1ll << 30)) return (int)hipErrorInvalidValue;
   const unsigned grid = (unsigned)((total + 7) / 8 * 8);
-  hipLaunchKernelGGL((head_kernel<MODE, CLAMPED, true>), dim3(grid), dim3(256), 0, st, descs, (const HeadDesc *)nullptr, w, pt_max, cg_max, (int)total);
+  auto kernel = head_kernel<MODE, CLAMPED, true, VEC>;
+  if (int e = head_lds(kernel)) return e;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), kHeadLds, st, descs, (const HeadDesc *)nullptr, w, pt_max, cg_max, (int)total);
   return (int)hipGetLastError();
 }
 
@@ -267,26 +322,33 @@ int launch_head_pack(const float *w, const float *bias, int M, int c_in, float *
   return (int)hipGetLastError();
 }
 
-int launch_head_params(const HeadDesc *d_descs, const HeadW &w, int count, int64_t hw_max, void *stream) {
+int launch_head_params(const HeadDesc *d_descs, const HeadW &w, int count, int64_t hw_max, bool vec, void *stream) {
   const int pt_max = (int)((hw_max + kPB - 1) / kPB), cg_max = w.n_cg;
   const int64_t total = (int64_t)count * pt_max * cg_max;
   if (total <= 0) return 0;
   if (total > (1ll << 30)) return (int)hipErrorInvalidValue;
   const unsigned grid = (unsigned)((total + 7) / 8 * 8);
-  hipLaunchKernelGGL((head_kernel<0, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const EncDesc *)nullptr, d_descs, w, pt_max, cg_max,
-                     (int)total);
+  auto kernel = vec ? head_kernel<0, true, false, true> : head_kernel<0, true, false, false>;
+  if (int e = head_lds(kernel)) return e;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), kHeadLds, (hipStream_t)stream, (const EncDesc *)nullptr, d_descs, w, pt_max, cg_max, (int)total);
   return (int)hipGetLastError();
 }
 
-int launch_head_symtab(const EncDesc *d_descs, const HeadW &w, int count, int M_max, int64_t hw_max, int mode, bool clamped, void *stream) {
+int launch_head_symtab(const EncDesc *d_descs, const HeadW &w, int count, int M_max, int64_t hw_max, int mode, bool clamped, bool vec, void *stream) {
   hipStream_t st = (hipStream_t)stream;
-  switch (mode * 2 + (clamped ? 1 : 0)) {
-  case 0: return launch_fused<0, false>(d_descs, w, count, M_max, hw_max, st);
-  case 1: return launch_fused<0, true>(d_descs, w, count, M_max, hw_max, st);
-  case 2: return launch_fused<1, false>(d_descs, w, count, M_max, hw_max, st);
-  case 3: return launch_fused<1, true>(d_descs, w, count, M_max, hw_max, st);
-  case 4: return launch_fused<2, false>(d_descs, w, count, M_max, hw_max, st);
-  case 5: return launch_fused<2, true>(d_descs, w, count, M_max, hw_max, st);
+  switch ((mode * 2 + (clamped ? 1 : 0)) * 2 + (vec ? 1 : 0)) {
+  case 0: return launch_fused<0, false, false>(d_descs, w, count, M_max, hw_max, st);
+  case 1: return launch_fused<0, false, true>(d_descs, w, count, M_max, hw_max, st);
+  case 2: return launch_fused<0, true, false>(d_descs, w, count, M_max, hw_max, st);
+  case 3: return launch_fused<0, true, true>(d_descs, w, count, M_max, hw_max, st);
+  case 4: return launch_fused<1, false, false>(d_descs, w, count, M_max, hw_max, st);
+  case 5: return launch_fused<1, false, true>(d_descs, w, count, M_max, hw_max, st);
+  case 6: return launch_fused<1, true, false>(d_descs, w, count, M_max, hw_max, st);
+  case 7: return launch_fused<1, true, true>(d_descs, w, count, M_max, hw_max, st);
+  case 8: return launch_fused<2, false, false>(d_descs, w, count, M_max, hw_max, st);
+  case 9: return launch_fused<2, false, true>(d_descs, w, count, M_max, hw_max, st);
+  case 10: return launch_fused<2, true, false>(d_descs, w, count, M_max, hw_max, st);
+  case 11: return launch_fused<2, true, true>(d_descs, w, count, M_max, hw_max, st);
   }
   return (int)hipErrorInvalidValue;
 }

@@ -101,8 +101,8 @@ static inline size_t head_packed_floats(int M, int c_in) {
   return n_cg * n_kt * 12 * kHeadCG * kHeadBK + n_cg * 12 * kHeadCG;
 }
 int launch_head_pack(const float *w, const float *bias_or_null, int M, int c_in, float *wp, float *bp, void *stream);
-int launch_head_params(const HeadDesc *d_descs, const HeadW &w, int count, int64_t hw_max, void *stream);
-int launch_head_symtab(const EncDesc *d_descs, const HeadW &w, int count, int M_max, int64_t hw_max, int mode, bool clamped, void *stream);
+int launch_head_params(const HeadDesc *d_descs, const HeadW &w, int count, int64_t hw_max, bool vec, void *stream); // vec: every hw % 4 == 0, x 16-byte aligned
+int launch_head_symtab(const EncDesc *d_descs, const HeadW &w, int count, int M_max, int64_t hw_max, int mode, bool clamped, bool vec, void *stream);
 
 // ---- GPU-side decode of CHECKPOINTED bitstreams (segdec_kernel): one wave per segment ---------------------------
 struct SegDesc {
