@@ -13,13 +13,14 @@
 // which the reference silently relies on.  oracle/fgmm_oracle.c restates the chain with fmaf (fgo_head_params): the GPU tests compare
 // bit for bit.
 //
-// Tiling (wave64, 256 threads = 4 waves, one block per CU - the kernel holds 192 accumulator registers per lane):
-//   block  = 16 latent channels (their 3*K = 12 parameters each: 192 rows of W) x 256 positions
-//   wave   = all 192 rows x 64 positions = 6 row tiles x 2 position tiles of 32x32 accumulators
-//   K loop = tiles of 32 input channels staged through LDS, two buffers (W tile 192 x 32 from a PRE-PACKED copy of the weights: one
-//            contiguous 24 KB read per block and tile; x tile 32 x 256): the global loads of tile i + 1 are in flight and its LDS writes
-//            issue while tile i is multiplied, one barrier per tile; the operand fragments are read from LDS one group of four k-pairs
-//            ahead of the products that use them
+// Tiling (wave64, 256 threads = 4 waves, TWO blocks per CU - a wave holds 96 accumulator registers and at most 256 in all):
+//   block  = 16 latent channels (their 3*K = 12 parameters each: 192 rows of W) x 128 positions
+//   wave   = all 192 rows x 32 positions = 6 row tiles of 32x32 accumulators
+//   K loop = tiles of 32 input channels staged through LDS (W tile 192 x 32 from a PRE-PACKED copy of the weights: one contiguous 24 KB
+//            read per block and tile; x tile 32 x 128): the global loads of tile i + 1 are in flight while tile i is multiplied, the
+//            operand fragments are read from LDS one group of four k-pairs ahead of the products that use them.  One LDS buffer,
+//            two barriers per tile: the CU's OTHER block multiplies meanwhile (two blocks drift out of phase by themselves - a block's
+//            prologue, barriers and epilogue fall under the other's products; one block per CU with twice the tile: 0.67 of the roof)
 //   rows   : row tile (g, t), g = which 8 of the 16 channels, t = scales | means | logits; row 4 * cl + k within it = parameter
 //            (t, k) of channel 8 g + cl.  The 32x32 accumulator map (row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), column = lane & 31)
 //            then gives every lane, for ITS position, registers 4 j + k = parameter (t, k) of channel 8 g + 2 j + (lane >> 5): a lane
@@ -27,13 +28,17 @@
 //   blocks that share an x tile (the channel groups of one position tile) get consecutive slots on ONE XCD: its L2 holds the tile.
 #include "fgmm_dev.h"
 
+#ifndef FGMM_HEAD_EXP
+#define FGMM_HEAD_EXP 0 // experiments (wrong results): bit 0 = no global loads in the K loop, bit 1 = no LDS writes, bit 2 = no barrier
+#endif
+
 namespace fgmm {
 namespace {
 
 constexpr int kCG = kHeadCG;          // latent channels per block
 constexpr int kRows = 12 * kCG;       // rows of W per block (192)
 constexpr int kBK = kHeadBK;          // input channels per LDS tile
-constexpr int kPB = 256;              // positions per block
+constexpr int kPB = 128;              // positions per block (4 waves x 32)
 constexpr int kALd = kBK + 4;         // LDS row pitch of the W tile (floats): 16-byte reads of 64 lanes hit 64 different banks
 constexpr int kBLd = kPB + 32;        // ... of the x tile: the two lane halves read rows k, k + 1 -> banks 32 apart
 constexpr int kTiles = kRows / 32;    // 6 row tiles
@@ -68,12 +73,11 @@ __global__ __launch_bounds__(256) void head_pack_kernel(const float *__restrict_
 // three parameter tensors as planes [3 * 4 * M, hw] (scales | means | logits, channel k * M + c).
 // VEC: every item's positions are a multiple of 4 and its features 16-byte aligned (checked by the host): the x tile is staged with
 // 16-byte loads; else element by element (any shape, slowly).
-constexpr int kStage = kRows * kALd + kBK * kBLd;                   // floats of one staged (W tile, x tile) pair
-constexpr size_t kHeadLds = 2 * sizeof(float) * (size_t)kStage;     // two of them: 129 024 bytes of the CU's 160 KB
 template <int MODE, bool CLAMPED, bool FUSED, bool VEC>
-__global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict__ edescs, const HeadDesc *__restrict__ hdescs, HeadW hw_, int pt_max,
+__global__ __launch_bounds__(256, 2) void head_kernel(const EncDesc *__restrict__ edescs, const HeadDesc *__restrict__ hdescs, HeadW hw_, int pt_max,
                                                        int cg_max, int total) {
-  extern __shared__ __attribute__((aligned(16))) float s_stage[];
+  __shared__ __attribute__((aligned(16))) float sA[kRows * kALd];
+  __shared__ __attribute__((aligned(16))) float sB[kBK * kBLd];
   __shared__ int s_rank[kCG];
   // ---- which (item, position tile, channel group): consecutive logical slots on one XCD (blocks are dealt to the 8 XCDs round robin)
   const int per_xcd = (int)gridDim.x >> 3;
@@ -96,12 +100,29 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
   if constexpr (FUSED) {
     // compact (coded) channel of each of the block's 16 channels, -1 = no coded symbol: a prefix sum over quant_stats' census
     const EncDesc &d = edescs[item];
+    // (every thread takes channels tid, tid + 256 ...: one ballot per wave and chunk, the sixteen ranks are popcounts below a channel)
+    __shared__ unsigned long long s_nzmask[4];
+    int below = 0; // coded channels in the chunks before the one that holds this block's channels
+    const int c_first = cg * kCG;
+    for (int base = 0; base <= c_first; base += 256) {
+      const int c = base + tid;
+      const unsigned long long m = __ballot(c < M && d.chan_nz[c] != 0);
+      if (base + 256 <= c_first) {
+        below += __popcll(m); // (per wave; summed over the waves below)
+        continue;
+      }
+      if (lane == 0) s_nzmask[wave] = m;
+    }
+    __shared__ int s_below[4];
+    if (lane == 0) s_below[wave] = below;
+    __syncthreads();
     if (tid < kCG) {
-      const int c = cg * kCG + tid;
+      const int c = c_first + tid, off = c & 255; // (the block's channels lie in one chunk: 256 is a multiple of 16)
       int r = -1;
-      if (c < M && d.chan_nz[c]) {
-        r = 0;
-        for (int cc = 0; cc < c; ++cc) r += d.chan_nz[cc] != 0;
+      if (c < M && ((s_nzmask[off >> 6] >> (off & 63)) & 1ull)) {
+        r = s_below[0] + s_below[1] + s_below[2] + s_below[3];
+        for (int wv = 0; wv < (off >> 6); ++wv) r += __popcll(s_nzmask[wv]);
+        r += __popcll(s_nzmask[off >> 6] & ((1ull << (off & 63)) - 1ull));
       }
       s_rank[tid] = r;
     }
@@ -111,18 +132,25 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
     for (int i = 0; i < kCG; ++i) any = any || s_rank[i] >= 0;
     if (!any) return; // sixteen channels that round to zero everywhere: nothing to code, nothing to multiply
   }
+  // the lane's eight latents, fetched now: their latency lies under the K loop instead of in front of the epilogue
+  float yv[8];
+  if constexpr (FUSED) {
+    const EncDesc &d = edescs[item];
+    const int64_t p = P0 + wave * 32 + col;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = cg * kCG + (q >> 2) * 8 + 2 * (q & 3) + h;
+      yv[q] = (s_rank[(q >> 2) * 8 + 2 * (q & 3) + h] >= 0 && p < hw) ? ldg<float>(d.y + (int64_t)c * hw + p) : 0.0f;
+    }
+  }
   // ---- accumulators start at the bias
-  f16_t acc[kTiles][2];
+  f16_t acc[kTiles];
   {
     const float *bp = hw_.bp + (int64_t)cg * kRows;
 #pragma unroll
     for (int tl = 0; tl < kTiles; ++tl)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float b = bp[tl * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-        acc[tl][0][r] = b;
-        acc[tl][1][r] = b;
-      }
+      for (int r = 0; r < 16; ++r) acc[tl][r] = bp[tl * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
   }
   // ---- K loop
   const int n_kt = hw_.n_kt, c_in = hw_.c_in;
@@ -130,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
   // Staging, branch-free (the K loop is ONE basic block, so that the instruction order below is the order issued): a load that would
   // fall outside the features (input channels past c_in in the last tile, positions past hw in the last position tile) reads a valid
   // address instead and is replaced by zero; the packed weights are zero there as well.
-  float4_t ra[6], rb[8];
+  float4_t ra[6], rb[4];
   unsigned rb_ok = 0; // bit 4 j + e: element e of rb[j] lies inside the features (applied when the tile is WRITTEN: a select right after
                       // the load would wait for it, and the loads are there to be in flight under a tile's products)
   auto load_tile = [&](int kt) {
@@ -139,8 +167,8 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
 #pragma unroll
     for (int j = 0; j < 6; ++j) ra[j] = src[tid + 256 * j];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int f = tid + 256 * j, kk = f >> 6, p4 = f & 63;
+    for (int j = 0; j < 4; ++j) {
+      const int f = tid + 256 * j, kk = f >> 5, p4 = f & 31;
       const int kin = kt * kBK + kk;
       const int64_t p = P0 + 4 * p4;
       const bool k_ok = kin < c_in;
@@ -159,84 +187,82 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
       rb[j] = v;
     }
   };
-  auto store_tile = [&](float *sA, float *sB) {
+  auto store_tile = [&]() {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int f = tid + 256 * j;
       *reinterpret_cast<float4_t *>(&sA[(f >> 3) * kALd + (f & 7) * 4]) = ra[j];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const int f = tid + 256 * j;
       float4_t v = rb[j];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (rb_ok >> (4 * j + e)) & 1u ? v[e] : 0.0f;
-      *reinterpret_cast<float4_t *>(&sB[(f >> 6) * kBLd + (f & 63) * 4]) = v;
+      *reinterpret_cast<float4_t *>(&sB[(f >> 5) * kBLd + (f & 31) * 4]) = v;
     }
   };
-  // the fragments of four k-pairs (one 16-byte read per row tile, the two position tiles' values of a k-pair in one ds_read2): read
-  // one group AHEAD of the products that use them, so that the matrix pipe never waits for the LDS (one wave per SIMD: nobody else
-  // would fill the gap)
+  // the fragments of four k-pairs (one 16-byte read per row tile, one 4-byte read per k-pair): read one group AHEAD of the products
+  // that use them
   struct Frag {
     float4_t a[kTiles];
-    float b[4][2];
+    float b[4];
   };
-  auto read_frag = [&](Frag &f, const float *sA, const float *sB, int s4) {
+  auto read_frag = [&](Frag &f, int s4) {
     const float *a_base = sA + col * kALd + h * 16 + s4 * 4;
-    const float *b_base = sB + h * kBLd + wave * 64 + col + 8 * s4 * kBLd;
+    const float *b_base = sB + h * kBLd + wave * 32 + col + 8 * s4 * kBLd;
 #pragma unroll
     for (int tl = 0; tl < kTiles; ++tl) f.a[tl] = *reinterpret_cast<const float4_t *>(a_base + tl * 32 * kALd);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) f.b[e][0] = b_base[2 * e * kBLd], f.b[e][1] = b_base[2 * e * kBLd + 32];
+    for (int e = 0; e < 4; ++e) f.b[e] = b_base[2 * e * kBLd];
   };
   auto multiply = [&](const Frag &f) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int tl = 0; tl < kTiles; ++tl) {
-        acc[tl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tl][e], f.b[e][0], acc[tl][0], 0, 0, 0);
-        acc[tl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tl][e], f.b[e][1], acc[tl][1], 0, 0, 0);
-      }
+      for (int tl = 0; tl < kTiles; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tl][e], f.b[e], acc[tl], 0, 0, 0);
   };
   // __builtin_amdgcn_sched_barrier(0): nothing is scheduled across it.  Left to itself the scheduler sinks every LDS read to just before
-  // its first use and the global loads to just before the LDS writes - each then waited for with the matrix pipe idle (measured: 0.62
-  // of the MFMA roof; the bursts below cost a few issue slots per 48 products instead).
+  // its first use and the global loads to just before the LDS writes - each then waited for with the matrix pipe idle.
 #define FGMM_FENCE() __builtin_amdgcn_sched_barrier(0)
   load_tile(0);
-  store_tile(s_stage, s_stage + kRows * kALd);
+  store_tile();
   __syncthreads();
   Frag f0, f1;
-  read_frag(f0, s_stage, s_stage + kRows * kALd, 0);
+  read_frag(f0, 0);
   for (int kt = 0; kt < n_kt; ++kt) {
-    const float *sA = s_stage + (kt & 1) * kStage, *sB = sA + kRows * kALd;
-    float *nA = s_stage + ((kt + 1) & 1) * kStage, *nB = nA + kRows * kALd;
-    // 192 products per wave and tile in four groups of 48; before each group, what a LATER step needs is issued:
-    //   group 0: the global loads of the next tile (the last tile loads itself again: harmless) and the fragments of group 1
-    //   group 1, 2: the fragments of groups 2, 3
-    //   group 3: the next tile's LDS writes - into the OTHER buffer, which was last read a tile ago, a barrier behind us
+    // 96 products per wave and tile in four groups of 24; before a group, what a LATER step needs is issued: the global loads of the
+    // next tile (the last tile loads itself again: harmless) and the fragments of the next group
     FGMM_FENCE();
+#if !(FGMM_HEAD_EXP & 1)
     load_tile(kt + 1 < n_kt ? kt + 1 : kt);
-    read_frag(f1, sA, sB, 1);
+#endif
+    read_frag(f1, 1);
     FGMM_FENCE();
     multiply(f0);
     FGMM_FENCE();
-    read_frag(f0, sA, sB, 2);
+    read_frag(f0, 2);
     FGMM_FENCE();
     multiply(f1);
     FGMM_FENCE();
-    read_frag(f1, sA, sB, 3);
+    read_frag(f1, 3);
     FGMM_FENCE();
     multiply(f0);
-    FGMM_FENCE();
-    store_tile(nA, nB);
-    FGMM_FENCE();
     multiply(f1);
     FGMM_FENCE();
+#if !(FGMM_HEAD_EXP & 4)
+    __syncthreads(); // every wave has read the tile
+#endif
+#if !(FGMM_HEAD_EXP & 2)
+    store_tile();
+#endif
+#if !(FGMM_HEAD_EXP & 4)
     __syncthreads();
-    read_frag(f0, nA, nB, 0); // (after the last tile: a read of the other buffer that nobody uses)
+#endif
+    read_frag(f0, 0); // (after the last tile: a read that nobody uses)
   }
 #undef FGMM_FENCE
-  // ---- epilogue: the lane's 16 latents (2 channel halves x 4 channels x 2 position tiles), all twelve parameters in registers
+  // ---- epilogue: the lane's 8 latents (2 channel halves x 4 channels at its position), all twelve parameters in registers
   if constexpr (FUSED) {
     const EncDesc &d = edescs[item];
     int nbypass = 0;
@@ -246,30 +272,26 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
       for (int j = 0; j < 4; ++j) {
         const int cl = g * 8 + 2 * j + h;
         const int rank = s_rank[cl];
-        const int c = cg * kCG + cl;
         uint32_t *row_out = nullptr;
         if (rank >= 0) {
           const int seg = (rank >= d.seg_b[0]) + (rank >= d.seg_b[1]) + (rank >= d.seg_b[2]);
           row_out = (seg ? d.packed_seg[seg] : d.packed) + (int64_t)(rank - seg * d.cps) * hw;
         }
+        const int64_t p = P0 + wave * 32 + col;
+        int bp = 0;
+        if (rank >= 0 && p < hw) {
+          float sg[4], mu[4], pi[4];
 #pragma unroll
-        for (int np = 0; np < 2; ++np) {
-          const int64_t p = P0 + wave * 64 + np * 32 + col;
-          int bp = 0;
-          if (rank >= 0 && p < hw) {
-            float sg[4], mu[4], pi[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              sg[k] = acc[g * 3 + 0][np][4 * j + k];
-              mu[k] = acc[g * 3 + 1][np][4 * j + k];
-              pi[k] = acc[g * 3 + 2][np][4 * j + k];
-            }
-            softmax4(pi);
-            const float vq = __builtin_rintf(ldg<float>(d.y + (int64_t)c * hw + p));
-            stg<uint32_t>(row_out + p, sym_entry<MODE, CLAMPED>(vq, (int)vq, mu, sg, pi, bp));
+          for (int k = 0; k < 4; ++k) {
+            sg[k] = acc[g * 3 + 0][4 * j + k];
+            mu[k] = acc[g * 3 + 1][4 * j + k];
+            pi[k] = acc[g * 3 + 2][4 * j + k];
           }
-          nbypass += __popcll(__ballot(bp));
+          softmax4(pi);
+          const float vq = __builtin_rintf(yv[g * 4 + j]);
+          stg<uint32_t>(row_out + p, sym_entry<MODE, CLAMPED>(vq, (int)vq, mu, sg, pi, bp));
         }
+        nbypass += __popcll(__ballot(bp));
       }
     // bypass census: the host sums the item's slots; one atomic per wave that saw any (rare: 0.2 % of the symbols)
     if (lane == 0 && nbypass) atomicAdd(d.meta + ((L * 4 + wave) % (int)d.meta_slots), (uint32_t)nbypass);
@@ -280,23 +302,15 @@ __global__ __launch_bounds__(256, 1) void head_kernel(const EncDesc *__restrict_
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = cg * kCG + g * 8 + 2 * j + h;
+        const int64_t p = P0 + wave * 32 + col;
+        if (c < M && p < hw) {
 #pragma unroll
-        for (int np = 0; np < 2; ++np) {
-          const int64_t p = P0 + wave * 64 + np * 32 + col;
-          if (c < M && p < hw) {
+          for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-              for (int k = 0; k < 4; ++k) out[((int64_t)t * 4 * M + (int64_t)k * M + c) * hw + p] = acc[g * 3 + t][np][4 * j + k];
-          }
+            for (int k = 0; k < 4; ++k) out[((int64_t)t * 4 * M + (int64_t)k * M + c) * hw + p] = acc[g * 3 + t][4 * j + k];
         }
       }
   }
-}
-
-template <typename K>
-int head_lds(K kernel) { // (more than the 64 KB a kernel gets without asking)
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHeadLds);
 }
 
 template <int MODE, bool CLAMPED, bool VEC>
@@ -307,8 +321,7 @@ int launch_fused(const EncDesc *descs, const HeadW &w, int count, int M_max, int
   if (total > (1ll << 30)) return (int)hipErrorInvalidValue;
   const unsigned grid = (unsigned)((total + 7) / 8 * 8);
   auto kernel = head_kernel<MODE, CLAMPED, true, VEC>;
-  if (int e = head_lds(kernel)) return e;
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), kHeadLds, st, descs, (const HeadDesc *)nullptr, w, pt_max, cg_max, (int)total);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, descs, (const HeadDesc *)nullptr, w, pt_max, cg_max, (int)total);
   return (int)hipGetLastError();
 }
 
@@ -329,8 +342,7 @@ int launch_head_params(const HeadDesc *d_descs, const HeadW &w, int count, int64
   if (total > (1ll << 30)) return (int)hipErrorInvalidValue;
   const unsigned grid = (unsigned)((total + 7) / 8 * 8);
   auto kernel = vec ? head_kernel<0, true, false, true> : head_kernel<0, true, false, false>;
-  if (int e = head_lds(kernel)) return e;
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), kHeadLds, (hipStream_t)stream, (const EncDesc *)nullptr, d_descs, w, pt_max, cg_max, (int)total);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const EncDesc *)nullptr, d_descs, w, pt_max, cg_max, (int)total);
   return (int)hipGetLastError();
 }
 

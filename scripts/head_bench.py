@@ -3,7 +3,7 @@
   unfused  ParameterHead.params (MFMA kernel, planes written) -> compress_batch                     library-owned order, planes in HBM
   fused    compress_head_batch (MFMA kernel with the table entries as its epilogue)                 no parameter planes at all
 GPU time of each stage by HIP/CUDA events on the current stream (the library's own events for its kernels), whole-call wall time,
-MFMA fraction of the 157.3 TF f32 roof.  usage: python scripts/head_bench.py [images=24] [reps=20]"""
+MFMA fraction of the 157.3 TF f32 roof.  usage: python scripts/head_bench.py [images=24] [reps=20] [c_in=640]"""
 import json
 import os
 import sys
@@ -20,7 +20,8 @@ from test_gpu_head import make_head  # noqa: E402
 
 images = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-N, M, c_in, h, w = 2 * images, 192, 640, 32, 24
+c_in = int(sys.argv[3]) if len(sys.argv) > 3 else 640
+N, M, h, w = 2 * images, 192, 32, 24
 conv, x, y = make_head(5, M, c_in, h, w, N)
 head = ParameterHead(conv)
 gmc = GaussianMixtureConditional(K=4, mode="polya")

@@ -1,6 +1,6 @@
 // mfma_f32_rate.hip — what v_mfma_f32_32x32x2_f32 sustains in the SHAPE the parameter-head kernel uses it (256 threads = one wave per SIMD,
 // twelve 32x32 accumulators per wave, 192 products per K tile), with nothing else in the loop, and with the head kernel's LDS reads.
-//   hipcc -O3 --offload-arch=gfx950 scripts/proto/mfma_f32_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate
+//   hipcc -O3 --offload-arch=gfx950 scripts/mfma_f32_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f16_t __attribute__((ext_vector_type(16)));
