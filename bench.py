@@ -801,7 +801,7 @@ class Leg:
         # asynchronously after the encode call and waited for at the end of the step (the lengths only feed the container index)
         from flashgmm_amd import parallel as P_
 
-        self.ex = P_.LengthExchange(self.n_streams, device=env.coll_dev) if env.dist else None
+        self.ex = P_.LengthExchange(self.n_streams, device=env.coll_dev, threaded=os.environ.get("FGMM_BENCH_EX_THREAD", "1") != "0") if env.dist else None
         self.last = {}
 
     def with_mode(self, mode: str):

@@ -137,6 +137,30 @@ SIGNATURES = {
 _lib = None
 _lock = threading.Lock()
 _ctxs = {}
+_native = None  # flashgmm_amd._native (csrc/fgmm_pybind.cpp), False when it cannot be used
+
+
+def native():
+    """The compiled boundary (``flashgmm_amd._native``, pybind11 over the same C ABI: items built in C++, the GIL released across
+    the call) or None - then the ctypes path of this module does the same work.  Not used with FGMM_LIB (an A/B build of the
+    library: the module is linked against the in-tree one) or FGMM_NATIVE=0."""
+    global _native
+    if _native is None:
+        _native = False
+        if not os.environ.get("FGMM_LIB") and os.environ.get("FGMM_NATIVE", "1") != "0":
+            try:
+                lib()  # (the library first, by its path: the module's own dependency then resolves to the same mapping)
+                from . import _native as mod
+
+                if mod.abi_version == lib().fgmm_abi_version():
+                    _native = mod
+            except ImportError:
+                pass
+    return _native or None
+
+
+def ctx_addr(device: int = -1) -> int:
+    return ctx(device).value
 
 
 def lib() -> C.CDLL:

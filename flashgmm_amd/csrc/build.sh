@@ -17,3 +17,13 @@ $HIPCC $COMMON --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -f
     -march=x86-64-v3 -shared -o $OUT fgmm_kernels.hip fgmm_tab.hip fgmm_head.hip fgmm_device_hip.cpp fgmm_rans.cpp fgmm_capi.cpp fgmm_encode.cpp \
     fgmm_decode.cpp fgmm_decode_gpu.cpp -lpthread "$@"
 echo "built $(realpath $OUT)"
+# The compiled Python boundary over the C ABI (fgmm_pybind.cpp -> flashgmm_amd/_native.*.so): plain C++ against the Python and pybind11
+# headers, linked to the library above through an $ORIGIN rpath.  Skipped (the ctypes binding, flashgmm_amd/_lib.py, binds the same
+# ABI) when OUT names another library (A/B builds) or the headers are not there.
+if [ "$OUT" = "../libflashgmm_amd.so" ] && PYINC=$(python3-config --includes 2>/dev/null) && PB=$(python3 -c 'import pybind11; print(pybind11.get_include())' 2>/dev/null); then
+  EXT=$(python3-config --extension-suffix)
+  ${CXX:-g++} -O2 -fPIC -shared -std=c++17 -Wall -fvisibility=hidden $PYINC -I"$PB" fgmm_pybind.cpp -o ../_native$EXT -L.. -lflashgmm_amd -Wl,-rpath,'$ORIGIN'
+  echo "built $(realpath ../_native$EXT)"
+else
+  echo "(flashgmm_amd/_native not built: pybind11 / Python headers missing or OUT set - the ctypes binding is used)"
+fi

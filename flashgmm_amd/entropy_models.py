@@ -114,6 +114,17 @@ def _take_ckpts_many(device: int, ptrs, counts):
     return out
 
 
+def _adopt_ckpts(strings, blob: bytes, counts, stride: int):
+    """the compiled boundary's checkpoint blob (every bitstream's notes back to back) -> CheckpointedBytes with views into it"""
+    pool = np.frombuffer(blob, dtype=CKPT_DTYPE) if len(blob) else _NO_CKPT
+    base = pool.ctypes.data if len(pool) else 0
+    out, at = [], 0
+    for d, n in zip(strings, counts):
+        out.append(CheckpointedBytes._adopt(d, pool[at:at + n] if n else _NO_CKPT, stride, base + 16 * at if n else 0))
+        at += n
+    return out
+
+
 def _plane_view(t: Tensor, K: int) -> Tuple[Tensor, int, int]:
     """-> (tensor kept alive, stride_k, stride_c) for a [1, K*M, h, w] parameter tensor whose (h, w) planes are
     dense; anything else is made contiguous first.  chunk(3, 1) views of the parameter head qualify as they are."""
@@ -297,7 +308,45 @@ class GaussianMixtureConditional(nn.Module):
             keep.append(y)
         return items, keep, N, M, h, w, scales.device
 
+    def _stacked_view(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor):
+        """validation of stacked inputs for the compiled boundary -> (y, scales, means, weights, N, M, h, w, item stride, stride_c)"""
+        if not scales.is_cuda:
+            raise RuntimeError(
+                "flashgmm_amd runs the GMM entropy-coding path on the GPU only: tensors must be on a HIP device "
+                "(there is deliberately no CPU fallback)")
+        if scales.dim() != 4 or means.shape != scales.shape or weights.shape != scales.shape:
+            raise RuntimeError("stacked entropy parameters must be three [N, K*M, h, w] tensors of one shape")
+        if not (scales.dtype == means.dtype == weights.dtype) or scales.dtype not in _PARAM_DTYPES:
+            raise RuntimeError("scales, means and weights must share one dtype, float32 or float16")
+        N, KM, h, w = scales.shape
+        st = scales.stride()
+        if (h * w > 1 and not (st[3] == 1 and st[2] == w)) or means.stride() != st or weights.stride() != st:
+            scales, means, weights = scales.contiguous(), means.contiguous(), weights.contiguous()
+            st = scales.stride()
+        M = KM // self.K
+        if y is not None:
+            if y.dim() != 4 or tuple(y.shape) != (N, M, h, w):
+                raise RuntimeError(f"y must be [{N}, {M}, {h}, {w}] matching the parameters; got {tuple(y.shape)}")
+            if y.dtype != torch.float32 or y.device != scales.device:
+                raise RuntimeError("y must be float32 on the parameters' device")
+            y = y.contiguous()
+        return y, scales, means, weights, N, M, h, w, st[0], (st[1] if KM > 1 else h * w)
+
     def _compress_stacked(self, y: Tensor, scales: Tensor, means: Tensor, weights: Tensor, flags: int = 0):
+        nat = _lib.native()
+        if nat is not None and scales.dim() == 4 and scales.shape[0] > 0:
+            y, scales, means, weights, N, M, h, w, s_item, sc = self._stacked_view(y, scales, means, weights)
+            dev = scales.device
+            di = dev.index if dev.index is not None else -1
+            yq = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
+            zb = torch.empty((N, M), dtype=torch.int64)
+            strings, amax, blob, counts = nat.compress_stacked(
+                _lib.ctx_addr(di), torch.cuda.current_stream(dev).cuda_stream, y.data_ptr(), scales.data_ptr(), means.data_ptr(), weights.data_ptr(),
+                N, M, h * w, s_item, M * sc, sc, _lib.FGMM_F16 if scales.dtype == torch.float16 else _lib.FGMM_F32, flags, self._mode(),
+                int(self.clamp_scales), self.checkpoint_stride, yq.data_ptr(), zb.data_ptr(), CheckpointedBytes if self.checkpoint_stride else None)
+            if self.checkpoint_stride:
+                strings = _adopt_ckpts(strings, blob, counts, self.checkpoint_stride)
+            return CompressedBatch(strings, amax, zb, yq)
         items, keep, N, M, h, w, dev = self._stacked_items(y, scales, means, weights, flags)
         if N == 0:
             return CompressedBatch([], [], torch.empty((0, M), dtype=torch.int64), torch.empty((0, 1, M, h, w), dtype=torch.float32, device=dev))
@@ -320,6 +369,30 @@ class GaussianMixtureConditional(nn.Module):
 
     def _decompress_stacked(self, strings: Sequence[bytes], abs_maxes: Sequence[int], zero_bitmaps, scales: Tensor,
                             means: Tensor, weights: Tensor, flags: int = 0, stacked_output: bool = False):
+        nat = _lib.native()
+        if nat is not None and scales.dim() == 4 and scales.shape[0] > 0 and isinstance(zero_bitmaps, Tensor):
+            _, scales, means, weights, N, M, h, w, s_item, sc = self._stacked_view(None, scales, means, weights)
+            zb = zero_bitmaps
+            if len(strings) != N or len(abs_maxes) != N or len(zb) != N:
+                raise RuntimeError(f"{N} items in the parameter tensors, {len(strings)} bitstreams")
+            if zb.device.type != "cpu" or zb.dtype != torch.int64:
+                zb = zb.to("cpu", torch.int64)
+            if tuple(zb.shape) != (N, M):
+                raise RuntimeError(f"zero bitmaps have shape {tuple(zb.shape)}, expected ({N}, {M})")
+            if M > 1 and zb.stride(1) != 1:
+                zb = zb.contiguous()
+            dev = scales.device
+            if not isinstance(strings, list) or not all(type(s_) is bytes or isinstance(s_, bytes) for s_ in strings):
+                strings = [s_ if isinstance(s_, bytes) else bytes(s_) for s_ in strings]
+            ck = None
+            if any(isinstance(d, CheckpointedBytes) for d in strings):
+                ck = [(d._ckpt_addr, len(d.ckpt), d.ckpt_stride) if isinstance(d, CheckpointedBytes) else (0, 0, 0) for d in strings]
+            y_hat = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
+            nat.decompress_stacked(_lib.ctx_addr(dev.index if dev.index is not None else -1), torch.cuda.current_stream(dev).cuda_stream, strings, abs_maxes,
+                                   zb.data_ptr(), zb.stride(0) if N > 1 else M, scales.data_ptr(), means.data_ptr(), weights.data_ptr(), N, M, h * w, s_item,
+                                   M * sc, sc, _lib.FGMM_F16 if scales.dtype == torch.float16 else _lib.FGMM_F32, flags, self._mode(), int(self.clamp_scales),
+                                   y_hat.data_ptr(), ck)
+            return y_hat if stacked_output else list(y_hat.unbind(0))
         items, keep, N, M, h, w, dev = self._stacked_items(None, scales, means, weights, flags)
         if len(strings) != N or len(abs_maxes) != N or len(zero_bitmaps) != N:
             raise RuntimeError(f"{N} items in the parameter tensors, {len(strings)} bitstreams")
@@ -422,6 +495,17 @@ class GaussianMixtureConditional(nn.Module):
         if N == 0:
             return CompressedBatch([], [], torch.empty((0, M), dtype=torch.int64), torch.empty((0, 1, M, h, w), dtype=torch.float32, device=dev))
         y = y.contiguous()
+        nat = _lib.native()
+        if nat is not None:
+            yq = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
+            zb = torch.empty((N, M), dtype=torch.int64)
+            strings, amax, blob, counts = nat.compress_head_stacked(
+                _lib.ctx_addr(dev.index if dev.index is not None else -1), torch.cuda.current_stream(dev).cuda_stream, y.data_ptr(), x.data_ptr(), head._h.value,
+                N, M, head.c_in, h * w, self._mode(), int(self.clamp_scales), self.checkpoint_stride, yq.data_ptr(), zb.data_ptr(),
+                CheckpointedBytes if self.checkpoint_stride else None)
+            if self.checkpoint_stride:
+                strings = _adopt_ckpts(strings, blob, counts, self.checkpoint_stride)
+            return CompressedBatch(strings, amax, zb, yq)
         items = np.zeros(N, _lib.ITEM_DTYPE)
         rng = np.arange(N, dtype=np.uint64)
         items["y"] = np.uint64(y.data_ptr()) + rng * np.uint64(M * h * w * 4)

@@ -49,9 +49,23 @@ class LengthExchange:
     process group ``wait`` returns the local row.  Timing of the most recent exchange: ``issue_ms`` (the ``start`` call),
     ``exposed_ms`` (the time ``wait`` blocked), ``total_ms`` (``start`` to the end of ``wait``)."""
 
-    def __init__(self, streams_per_rank: int, device=None, group=None):
+    def __init__(self, streams_per_rank: int, device=None, group=None, threaded: bool = False):
         import time
 
+        # threaded: ``start`` hands the exchange to a helper thread of this object and returns at once - the tensor and collective calls
+        # (0.1 - 0.2 ms of interpreter and dispatcher work at any world size) then run while the caller is inside its next native call,
+        # which releases the GIL; ``wait`` joins the helper first.  One exchange in flight at a time, as without the thread.
+        self._thread = None
+        self._jobs = None
+        self._done = None
+        if threaded:
+            import queue
+            import threading
+
+            self._jobs = queue.SimpleQueue()
+            self._done = threading.Event()
+            self._done.set()
+            self._err = None
         self._time = time.perf_counter
         self.group = group
         self.active = dist.is_available() and dist.is_initialized()
@@ -70,6 +84,11 @@ class LengthExchange:
         self.work = None
         self.issue_ms = self.exposed_ms = self.total_ms = 0.0
         self._t0 = 0.0
+        if threaded:  # (last: the helper sees a complete object)
+            import threading
+
+            self._thread = threading.Thread(target=self._serve, name="fgmm-lengths", daemon=True)
+            self._thread.start()
 
     # the current exchange's buffers (what wait() returns a view of)
     @property
@@ -84,7 +103,34 @@ class LengthExchange:
     def out(self):
         return self._slots[self._cur]["out"]
 
+    def _serve(self):
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            try:
+                self._start(job)
+            except BaseException as e:  # handed to the caller by wait()
+                self._err = e
+            self._done.set()
+
+    def close(self) -> None:
+        if self._thread is not None:
+            self._jobs.put(None)
+            self._thread.join(timeout=5.0)
+            self._thread = None
+
     def start(self, local_lengths: Sequence[int]) -> None:
+        if self._thread is None:
+            return self._start(local_lengths)
+        self._done.wait()  # (an exchange nobody waited for)
+        self._done.clear()
+        self._t0 = self._time()
+        self._jobs.put(list(local_lengths))
+
+    def _start(self, local_lengths: Sequence[int]) -> None:
         t0 = self._time()
         k = len(local_lengths)
         if k > self.n:
@@ -108,7 +154,8 @@ class LengthExchange:
             self.work = dist.all_gather_into_tensor(sl["out"].view(-1), sl["inp"], group=self.group, async_op=True)
         else:
             sl["out"][0].copy_(sl["inp"])
-        self._t0 = t0
+        if self._thread is None:
+            self._t0 = t0
         self.issue_ms = (self._time() - t0) * 1e3
 
     def wait(self, to_host: bool = True) -> torch.Tensor:
@@ -116,6 +163,11 @@ class LengthExchange:
         complete on return; False: the collective's own buffer, ordered after the collective on the current stream (valid until
         the ``start`` after next: the buffers are used in turn) - for a caller that reads the lengths later, or never on the host"""
         t0 = self._time()
+        if self._thread is not None:
+            self._done.wait()
+            if self._err is not None:
+                e, self._err = self._err, None
+                raise e
         if self.work is not None:
             self.work.wait()
             self.work = None

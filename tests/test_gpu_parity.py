@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from flashgmm_amd import GaussianMixtureConditional, _lib, ans
+from flashgmm_amd import CheckpointedBytes, GaussianMixtureConditional, _lib, ans
 from tests import synth as T
 from helpers import expand_trimmed, hdr_form
 
@@ -528,6 +528,31 @@ def test_one_kodak_half_alone_with_default_options(mode):
             assert torch.equal(y_hat, yq) and torch.equal(yq, torch.round(t[0])), seed
         log = _lib.call_log(0, 1)[0]
         assert log["kind"] == "decode" and log["count"] == 1
+
+
+@pytest.mark.parametrize("stride", [0, 512])
+def test_compiled_and_ctypes_bindings_agree(monkeypatch, stride):
+    """flashgmm_amd._native (pybind11, csrc/fgmm_pybind.cpp: the mirror of the reference's module definition, rans_interface.cpp:961-1036)
+    and the ctypes binding (flashgmm_amd/_lib.py, the documented fallback) drive the same C ABI: the same bytes, side information,
+    checkpoints and decoded latents from either - stacked inputs, strided stage views, plain and checkpointed streams."""
+    assert _lib.native() is not None, "flashgmm_amd/_native*.so is missing: flashgmm_amd/csrc/build.sh builds it"
+    gmc = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=stride)
+    lat = [T.make_latent(4200 + i, M=48, h=16, w=12, clamp=False, zero_frac=0.2) for i in range(6)]
+    ys, ss, ms, ws = (torch.stack([torch.from_numpy(l[k][0]) for l in lat]).to("cuda:0") for k in range(4))
+    nat = gmc.compress_batch(ys, ss, ms, ws)
+    out_nat = [gmc.decompress_batch(nat.strings[s::2], nat.abs_maxes[s::2], nat.zero_bitmaps[s::2], ss[s::2], ms[s::2], ws[s::2], stacked_output=True) for s in range(2)]
+    monkeypatch.setattr(_lib, "_native", False)
+    assert _lib.native() is None
+    cty = gmc.compress_batch(ys, ss, ms, ws)
+    out_cty = [gmc.decompress_batch(nat.strings[s::2], nat.abs_maxes[s::2], nat.zero_bitmaps[s::2], ss[s::2], ms[s::2], ws[s::2], stacked_output=True) for s in range(2)]
+    assert type(nat.strings[0]) is (CheckpointedBytes if stride else bytes) and type(cty.strings[0]) is type(nat.strings[0])
+    for i in range(6):
+        assert bytes(nat.strings[i]) == bytes(cty.strings[i]) and nat.abs_maxes[i] == cty.abs_maxes[i]
+        if stride:
+            assert nat.strings[i].ckpt_stride == stride and np.array_equal(nat.strings[i].ckpt, cty.strings[i].ckpt) and len(nat.strings[i].ckpt) == (int(nat.zero_bitmaps[i].sum()) * 192 - 1) // stride
+    assert torch.equal(nat.zero_bitmaps, cty.zero_bitmaps) and torch.equal(nat.y_q, cty.y_q) and torch.equal(nat.y_q[:, 0], torch.round(ys))
+    for s in range(2):
+        assert torch.equal(out_nat[s], nat.y_q[s::2]) and torch.equal(out_cty[s], nat.y_q[s::2])
 
 
 @pytest.fixture

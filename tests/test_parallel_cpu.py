@@ -1,4 +1,4 @@
-"""CPU: the N > 1 path (sharding + the one collective) with gloo, world_size 2."""
+"""CPU: the N > 1 path (sharding + the one collective) with gloo, world sizes 2, 4 and 8."""
 import os
 import time
 import socket
@@ -17,52 +17,61 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_units, q):
+def _worker(rank, world, port, n_units, q, spu=2, threaded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mine = P.shard_units(n_units, rank, world)
     # stand-in for the coder: stream lengths are a pure function of (unit, stream)
-    lens = [1000 + 17 * u + s for u in mine for s in range(2)]
-    per_rank = 2 * ((n_units + world - 1) // world)
+    lens = [1000 + 17 * u + s for u in mine for s in range(spu)]
+    per_rank = spu * ((n_units + world - 1) // world)
     g = P.all_gather_stream_lengths(lens, per_rank)
-    idx = P.container_index(g, n_units, 2)
+    idx = P.container_index(g, n_units, spu)
     # the overlapped form bench.py uses: one preallocated all_gather_into_tensor, issued asynchronously, waited for later - twice on
     # the same buffers, with other work (here: a second collective and a sleep) between start and wait
-    ex = P.LengthExchange(per_rank)
-    for rep in range(2):
+    # (threaded: the helper thread of the exchange issues the collective while this thread goes on - here straight into the sleep
+    # that stands for the decode calls; no other collective may be issued before wait(), every rank keeps that order)
+    ex = P.LengthExchange(per_rank, threaded=threaded)
+    for rep in range(3):
         ex.start([ln + rep for ln in lens])
-        assert ex.work is not None  # in flight: nothing has been waited for
-        dist.barrier()
+        if not threaded:
+            assert ex.work is not None  # in flight: nothing has been waited for
+            dist.barrier()
         time.sleep(0.01)
         g2 = ex.wait()
         assert ex.work is None and g2.tolist() == [[v + rep if v >= 0 else v for v in row] for row in g.tolist()], (rank, rep)
         assert ex.total_ms >= 10.0 and ex.exposed_ms < ex.total_ms
-    assert P.container_index(g2, n_units, 2) == [(u, s_, o + 2 * u + s_, ln + 1) for (u, s_, o, ln) in idx]
+    ex.close()
+    assert P.container_index(g2, n_units, spu) == [(u, s_, o + 2 * (spu * u + s_), ln + 2) for (u, s_, o, ln) in idx]
     q.put((rank, mine, g.tolist(), idx))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_units", [24, 5])
-def test_shard_and_gather_world2(n_units):
-    world, port = 2, _free_port()
+# (world, units, bitstreams per unit, threaded exchange): BASELINE configs[3] - 24 Kodak images of 2 bitstreams on 2 / 4 / 8 ranks (3 per
+# rank at 8) -, configs[4] - ELIC images of 10 bitstreams, one per rank -, and ragged splits whose last ranks own fewer units (or none)
+@pytest.mark.parametrize("world,n_units,spu,threaded", [(2, 24, 2, False), (2, 5, 2, True), (4, 24, 2, True), (8, 24, 2, True), (8, 8, 10, False),
+                                                          (8, 11, 10, True), (4, 3, 2, False)])
+def test_shard_and_gather(world, n_units, spu, threaded):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_units, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_units, q, spu, threaded)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
+    got = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     got.sort()
-    (r0, mine0, g0, idx0), (r1, mine1, g1, idx1) = got
-    assert sorted(mine0 + mine1) == list(range(n_units)) and not set(mine0) & set(mine1)
-    assert g0 == g1 and idx0 == idx1  # every rank derives the same container layout
+    owned = [m for _, m, _, _ in got]
+    assert sorted(u for m in owned for u in m) == list(range(n_units))  # every unit has exactly one owner
+    assert all(m == list(range(r, n_units, world)) for r, m in enumerate(owned))  # unit i -> rank i mod world
+    assert all(g == got[0][2] and idx == got[0][3] for _, _, g, idx in got)  # every rank derives the same container layout
     off = 0
-    for k, (u, s, o, ln) in enumerate(idx0):
-        assert (u, s) == (k // 2, k % 2) and o == off and ln == 1000 + 17 * u + s
+    for k, (u, s, o, ln) in enumerate(got[0][3]):
+        assert (u, s) == (k // spu, k % spu) and o == off and ln == 1000 + 17 * u + s
         off += ln
 
 
@@ -140,6 +149,7 @@ def _gather_worker(rank, world, port, n_units, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     local = [Cn.pack(*_fake_strings(u)) for u in P.shard_units(n_units, rank, world)]
     allc = P.gather_containers(local, n_units)
@@ -148,11 +158,13 @@ def _gather_worker(rank, world, port, n_units, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_units", [6, 5, 1])
-def test_gather_containers_world2(n_units):
+@pytest.mark.parametrize("world,n_units", [(2, 6), (2, 5), (2, 1), (4, 24), (8, 24), (8, 5)])
+def test_gather_containers(world, n_units):
+    """every rank ends with every unit's container in UNIT order, whatever the world size - 24 units on 4 and 8 ranks (BASELINE
+    configs[3]: 3 images per rank at 8), fewer units than ranks (ranks that own nothing contribute an empty payload)"""
     from flashgmm_amd import container as Cn
 
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_gather_worker, args=(r, world, port, n_units, q)) for r in range(world)]
@@ -163,7 +175,7 @@ def test_gather_containers_world2(n_units):
         p.join(60)
         assert p.exitcode == 0
     want = [Cn.pack(*_fake_strings(u)) for u in range(n_units)]
-    assert got[0] == want and got[1] == want  # every rank holds every unit's container, in unit order
+    assert all(got[r] == want for r in range(world))  # every rank holds every unit's container, in unit order
     assert P.gather_containers(want[:1], 1) == want[:1]  # world size 1 degenerates to the identity
 
 
