@@ -1092,6 +1092,7 @@ def main(argv=None):
         # is the latency_ms leg
         a.images = 24 if a.workload == "kodak24" else ELIC_IMAGES
     f16 = (a.param_dtype or ("f32" if a.workload == "kodak24" else "f16")) == "f16"
+    perf = D.PerfCounters() if a.diag else None  # (before the library creates its workers: the counters are inherited by new threads)
     env.l3_cpus, l3_note = plan_l3(local_rank, _lib.ranks_on_node())  # (before the library creates its workers)
     _lib.ctx(local_rank, a.host_threads)
     l3_note += f"; fgmm_ctx_worker_cpus: '{_lib.worker_cpus(local_rank)}'"
@@ -1129,6 +1130,23 @@ def main(argv=None):
     ka1 = ka1_check(leg, res)
 
     extras = {}
+    if perf is not None and perf.ok and rank == 0:
+        # --diag: where the host's cycles go, per coded symbol (user space, every thread of the process): the encode call alone, the
+        # decode calls alone, 10 passes each over the last step's data
+        def counted(fn, passes=10):
+            fn()
+            torch.cuda.synchronize()
+            c0, t0 = perf.read(), time.perf_counter()
+            for _ in range(passes):
+                fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            return D.PerfCounters.per_symbol(c0, perf.read(), n_coded * passes, dt) | {"ms_per_pass": round(dt / passes * 1e3, 3)}
+
+        extras["perf"] = {"encode_only": counted(lambda: leg.gmc.compress_batch(ys, ss, ms, ws)),
+                          "decode_only": counted(lambda: leg.decode_codec(res) if a.schedule == "codec" else leg.decode_all(res)),
+                          "note": "perf_event_open, user space, all threads of the process (host workers, calling thread, the runtime's own), per coded "
+                                  "symbol of the batch; cycles / instructions / last-level-cache references and misses"}
     payload_ms = None
     if world > 1:
         # the containers themselves, once per run (the timed step exchanges the LENGTHS; a deployment that assembles every

@@ -278,6 +278,16 @@ int fgmm_host_thread_budget(int ranks_sharing) {
   const int t = quota > 0 && by_mask > by_time ? std::min(by_mask, per_cpu * by_time) : by_time;
   return std::max(1, std::min(t, 48));
 }
+// the decode calls' pool (fgmm_ctx.h: one hardware thread per core), or none when that is the encode pool's own set
+static void make_decode_pool(fgmm_ctx *c, int n_threads) {
+  delete c->dec_pool;
+  c->dec_pool = nullptr;
+  const char *e = getenv("FGMM_DECODE_SMT");
+  if (e && *e == '1') return; // (A/B: both hardware threads of a core, as the encode pool)
+  const WorkerCpus one = c->worker_cpus.one_per_core(n_threads);
+  if (one.restricted && one.cpus != (c->worker_cpus.restricted ? c->worker_cpus.cpus : -1)) c->dec_pool = new (std::nothrow) Pool(n_threads, one);
+}
+
 int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {
   if (!out) return fail(FGMM_ERR_INVALID, "out == NULL");
   *out = nullptr;
@@ -299,6 +309,7 @@ int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {
     return fail(FGMM_ERR_INVALID, "%s", why.c_str());
   }
   c->pool = new Pool(n_threads, c->worker_cpus);
+  make_decode_pool(c, n_threads);
   for (const OptName &o : kOpts)
     if (o.env && getenv(o.env)) c->opt.*(o.field) = std::min(std::max<int64_t>(atoll(getenv(o.env)), o.lo), o.hi);
   *out = c;
@@ -310,6 +321,7 @@ void fgmm_ctx_destroy(fgmm_ctx *ctx) {
   {
     DeviceGuard g(ctx->device);
     delete ctx->pool;
+    delete ctx->dec_pool;
     for (auto e : ctx->events) (void)dev::event_destroy(e);
     for (auto e : ctx->sleep_events) (void)dev::event_destroy(e);
     for (auto &pr : ctx->prof)
@@ -403,6 +415,7 @@ int fgmm_ctx_set_threads(fgmm_ctx *ctx, int n_threads) {
   if (!fresh) return fail(FGMM_ERR_NOMEM, "worker pool");
   delete ctx->pool;
   ctx->pool = fresh;
+  make_decode_pool(ctx, n_threads);
   return FGMM_OK;
 }
 

@@ -133,6 +133,36 @@ struct WorkerCpus {
     w.restricted = w.room(n_threads);
     return w;
   }
+  // The same set with ONE hardware thread per core (the lowest-numbered sibling that is in the set): where the DECODE jobs run.  A host
+  // decoder is a dependent chain that misses the cache on rows the DMA engine has just written; two of them on one core's two
+  // hardware threads take 14 % more CPU time between them than on two cores (decode call 2 of a Kodak step: 48.6 -> 41.7 ms busy,
+  // profiles/r05_smt_ab.txt) - while the encode call, 48 bitstreams at once, wants every hardware thread (it lost 10 % when the
+  // whole pool was confined this way: hence two pools).  Unrestricted / unreadable topology / fewer than n_threads cores: *this.
+  WorkerCpus one_per_core(int n_threads) const {
+    cpu_set_t base;
+    if (restricted) base = set;
+    else if (sched_getaffinity(0, sizeof base, &base) != 0) return *this;
+    WorkerCpus w;
+    CPU_ZERO(&w.set);
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+      if (!CPU_ISSET(c, &base)) continue;
+      char path[96], text[256];
+      snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+      FILE *f = fopen(path, "r");
+      if (!f) return *this;
+      const bool got = fgets(text, sizeof text, f) != nullptr;
+      fclose(f);
+      cpu_set_t sib;
+      if (!got || !parse(text, &sib)) return *this;
+      bool first = true;
+      for (int q = 0; q < c; ++q)
+        if (CPU_ISSET(q, &sib) && CPU_ISSET(q, &base)) first = false;
+      if (first) CPU_SET(c, &w.set), ++w.cpus;
+    }
+    if (w.cpus < n_threads || w.cpus == (restricted ? cpus : CPU_COUNT(&base))) return *this; // too few cores / no SMT here
+    w.restricted = true;
+    return w;
+  }
   std::string cpulist() const { // "" when the workers inherit
     std::string out;
     if (!restricted) return out;
@@ -284,6 +314,9 @@ struct fgmm_ctx {
   std::mutex mu; // one call at a time per context
   fgmm::Pool *pool = nullptr;
   fgmm::WorkerCpus worker_cpus; // decided when the context is created; fgmm_ctx_set_threads re-applies the automatic rule's room test
+  fgmm::Pool *dec_pool = nullptr; // the decode calls' workers: as many, on one hardware thread per core (WorkerCpus::one_per_core);
+                                  // == pool when the host has no second hardware threads, too few cores, or FGMM_DECODE_SMT=1 says so
+  fgmm::Pool *decoders() const { return dec_pool ? dec_pool : pool; }
   char *d_ws = nullptr; // device workspace (descriptors, counters, encode tables): grown on demand, reused
   size_t d_cap = 0;
   char *h_ws = nullptr; // its pinned mirror

@@ -112,12 +112,12 @@ struct DecodeCall {
     f16 = items[0].prm.dtype == FGMM_F16;
     // Segments pay when a call has fewer bitstreams than workers (one image, ELIC's stages of a few images); a call with a bitstream
     // per worker or more keeps them all busy piece by piece and would only pay the segments' bookkeeping: the notes are ignored there
-    const bool use_ckpt = ctx->opt.ckpt_decode == 1 || (ctx->opt.ckpt_decode == 0 && count < std::max(ctx->pool->size(), 1));
+    const bool use_ckpt = ctx->opt.ckpt_decode == 1 || (ctx->opt.ckpt_decode == 0 && count < std::max(ctx->decoders()->size(), 1));
     for (auto &it : items) {
       if (!use_ckpt) it.ckpt = nullptr, it.n_ckpt = 0;
       streams_of_work += it.ckpt && it.n_ckpt > 0 ? it.n_ckpt + 1 : 1;
     }
-    decoders = (int)std::min<int64_t>(std::max(ctx->pool->size(), 1), streams_of_work);
+    decoders = (int)std::min<int64_t>(std::max(ctx->decoders()->size(), 1), streams_of_work);
     // Elias-Fano rows (long rows: ef_min) are 18 % fewer bytes than uint16 rows and 40 % more nanoseconds to search (57.6 B and 12 ns
     // per latent against 70 B and 8.7 ns on the Kodak workload): with P decoders at work a latent costs max(bytes / 55.7 GB/s,
     // ns / P) - Elias-Fano rows pay when 12 / P < 70 B / 55.7 GB/s = 1.26 ns, P >= 10
@@ -817,13 +817,13 @@ struct DecodeCall {
         if (!clean || !landed_all || c->launched < c->n_units) (void)dev::stream_sync(c->ctx->copy_stream);
       }
     } quiesce{this};
-    PoolDrain drain{ctx->pool}; // on any return: wait for every job before the objects they use go away
+    PoolDrain drain{ctx->decoders()}; // on any return: wait for every job before the objects they use go away
     Abandon abandon_on_exit{this};
     if ((rc = upload_and_prime())) return rc;
     tr.mark("first launches enqueued");
     // (a single bitstream too: its decoder starts on piece 0 while this thread is still queuing the later pieces' copies)
-    const int n_workers = (int)std::min<int64_t>(std::max(ctx->pool->size(), 1), streams_of_work);
-    for (int j = 0; j < n_workers; ++j) ctx->pool->submit([this] { worker(); });
+    const int n_workers = (int)std::min<int64_t>(std::max(ctx->decoders()->size(), 1), streams_of_work);
+    for (int j = 0; j < n_workers; ++j) ctx->decoders()->submit([this] { worker(); });
     head[1] = tr.ms();
     for (int u = 0; u < n_units; ++u)
       if ((rc = collect_unit(u))) return rc;
@@ -855,7 +855,7 @@ bool gpu_is_faster(const fgmm_ctx *ctx, const std::vector<DecItem> &items, const
   // small or unusual calls - the fixed costs of a 200 k-symbol GPU call read as throughput - walked the estimate far enough to flip
   // the choice for a Kodak batch, a 3x margin; on another platform the caller sets the option to 1 or 2)
   const double t_gpu = std::max(stride_max * 0.65, syms * 0.00035) + 100.0;
-  const double workers = std::min<double>(std::max(ctx->pool->size(), 1), work);
+  const double workers = std::min<double>(std::max(ctx->decoders()->size(), 1), work);
   const double t_host = std::max(syms * 0.012 / workers, syms * 58.0 / 55700.0) + 450.0 + 3.0 * work / workers; // + a segment's set-up
   return t_gpu < t_host;
 }

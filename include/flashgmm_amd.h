@@ -96,7 +96,10 @@ int fgmm_ctx_set_threads(fgmm_ctx *ctx, int n_threads);
  *   "inherit"  the creating thread's CPUs
  *   a cpulist  exactly these, e.g. "16-127"
  * The library never changes the calling thread's own affinity; a caller that wants the full benefit keeps its thread on the CPUs
- * that are NOT in this list (bench.py does, for its timed regions). */
+ * that are NOT in this list (bench.py does, for its timed regions).
+ * The DECODE calls run on a second pool of as many workers confined to ONE hardware thread per core of that list (two sequential
+ * decoders on one core's two hardware threads cost 14 % more CPU time than on two cores; the encode call wants every hardware thread):
+ * FGMM_DECODE_SMT=1 in the environment keeps the decoders on the list as it is. */
 int fgmm_ctx_worker_cpus(fgmm_ctx *ctx, char *cpulist_out, size_t cap);
 
 void fgmm_free(void *p); /* releases any buffer this library returned through an out-pointer */

@@ -216,6 +216,56 @@ def probe_stats(probe: "HostProbe"):
     return {"cpu_throttled": thr, "nr_throttled": sum(v.get("nr_throttled", 0) for v in thr.values())}
 
 
+class PerfCounters:
+    """A perf-stat-style reading of THIS process, every thread it creates after this object included (perf_event_open with inherit:
+    open it before the library starts its workers): user-space cycles, instructions, last-level-cache references and misses.
+    `read()` -> dict of running totals; differences around a region are the region's.  Unavailable (a kernel that forbids it, a VM
+    without a PMU): `ok` is False and read() returns {}."""
+
+    EVENTS = {"cycles": 0, "instructions": 1, "cache_references": 2, "cache_misses": 3}
+
+    def __init__(self):
+        import ctypes
+        import struct
+
+        self.fds, self.ok = {}, False
+        try:
+            libc = ctypes.CDLL(None, use_errno=True)
+            for name, config in self.EVENTS.items():
+                attr = bytearray(128)
+                struct.pack_into("IIQQQQ", attr, 0, 0, 128, config, 0, 0, 0)  # PERF_TYPE_HARDWARE, size, config, period, sample_type, read_format
+                struct.pack_into("Q", attr, 40, (1 << 1) | (1 << 5) | (1 << 6))  # inherit | exclude_kernel | exclude_hv (enabled at once)
+                fd = libc.syscall(298, (ctypes.c_char * 128).from_buffer(attr), 0, -1, -1, 0)
+                if fd >= 0:
+                    self.fds[name] = fd
+            self.ok = len(self.fds) == len(self.EVENTS)
+        except Exception:
+            pass
+
+    def read(self):
+        import struct
+
+        out = {}
+        for name, fd in self.fds.items():
+            try:
+                out[name] = struct.unpack("Q", os.read(fd, 8))[0]
+            except OSError:
+                pass
+        return out
+
+    @staticmethod
+    def per_symbol(before, after, symbols, seconds=None):
+        if not before or not after or symbols <= 0:
+            return None
+        d = {k: after[k] - before[k] for k in after if k in before}
+        out = {k + "_per_symbol": round(v / symbols, 3) for k, v in d.items()}
+        if d.get("cycles"):
+            out["ipc"] = round(d.get("instructions", 0) / d["cycles"], 3)
+            if seconds:
+                out["cpus_busy"] = round(d["cycles"] / seconds / 1e9, 2)  # (GHz-seconds: divide by the clock for CPUs)
+        return out
+
+
 _THROTTLE_FILES = None
 
 
@@ -336,9 +386,15 @@ def region_phases(device: int, calls_per_step: int, step_ms):
     ph = [call_phases(st) for st in steps]
     for i, st in enumerate(steps):
         ph[i]["between_calls"] = step_ms[len(step_ms) - m + i] - sum(c["ms"][5] for c in st)
-    if any(set(p_) != set(ph[0]) for p_ in ph):
+        # ... and where: the gap after every call of the step (the interpreter's work until the next native call begins; after the
+        # last call: until the next step's first call, not known for the region's last step)
+        for j, c in enumerate(st):
+            nxt = st[j + 1] if j + 1 < len(st) else (steps[i + 1][0] if i + 1 < len(steps) else None)
+            if nxt is not None:
+                ph[i][f"gap_after_call{j}"] = nxt["t_begin_ms"] - (c["t_begin_ms"] + c["ms"][5])
+    if any(set(p_) - set(ph[0]) for p_ in ph):
         return None
-    med = {k: float(np.median([p_[k] for p_ in ph])) for k in sorted(ph[0])}
+    med = {k: float(np.median([p_[k] for p_ in ph if k in p_])) for k in sorted(ph[0])}
     out = {"steps": m, **{k: round(v, 3) for k, v in med.items()}}
     # a step slower than 1.3x the region's median: which of its phases stretched (more than 0.3 ms over that phase's median)
     last = step_ms[len(step_ms) - m:]
@@ -346,7 +402,7 @@ def region_phases(device: int, calls_per_step: int, step_ms):
     slow = []
     for i, p_ in enumerate(ph):
         if last[i] > 1.3 * step_med:
-            moved = {k: [round(p_[k], 2), round(med[k], 2)] for k in med if not k.endswith((".worker_busy", ".worker_wait")) and p_[k] > med[k] + 0.3}
+            moved = {k: [round(p_[k], 2), round(med[k], 2)] for k in med if k in p_ and not k.endswith((".worker_busy", ".worker_wait")) and p_[k] > med[k] + 0.3}
             slow.append({"step": len(step_ms) - m + i, "ms": round(float(last[i]), 2), "moved_[this,median]": moved})
     if slow:
         out["slow_steps"] = slow
