@@ -429,6 +429,22 @@ def pmc_traffic(workload: str, mode: str, f16: bool, images: int):
     return best, src
 
 
+def tab_kernel_alone():
+    """roofline_decode.alone: the decode-side table kernel measured ALONE under rocprofv3 (scripts/profile_tab_alone.sh: one Kodak
+    stage in one launch, kernel-trace statistics + the SQ instruction counters in a pass of their own) - the latest committed
+    profiles/r*_tab_kernel_alone.json, a recorded measurement like roofline.traffic: in a bench step the launches share the GPU
+    with the table copies, and under --kernel-trace the step's 22 small launches are inflated 2.5x."""
+    for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_tab_kernel_alone.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            return {"launch_ms": d["valu"]["launch_ms"], "latents_per_launch": d["latents_per_launch"], "edges_per_latent": d["edges_per_latent"],
+                    "valu_frac": d["valu"]["valu_frac"], "valu_wave_insts_per_latent": d["valu"]["valu_wave_insts_per_latent"],
+                    "source": os.path.relpath(f, ROOT), "stats": os.path.relpath(f, ROOT).replace(".json", "_stats.csv")}
+        except Exception:
+            pass
+    return None
+
+
 def symtab_valu_roof(workload: str, mode: str, f16: bool, n_coded: int, launch_ms: float):
     """The encode-side kernel against its OTHER roof, VALU issue: wave-level VALU instructions per coded symbol as the SQ counters
     give them (recorded: profiles/r*_pmc_valu_symtab.json, scripts/pmc_valu.sh) x coded symbols x the measured average issue cost of
@@ -609,7 +625,9 @@ def summary_line(full: dict, detail_path=None) -> dict:
             out["roofline"]["valu"] = _pick(rf["valu"], "valu_frac")
     rd = g("roofline_decode")
     if isinstance(rd, dict):
-        out["roofline_decode"] = _pick(rd, "kernel", "bound", "ms_per_step", "valu_frac", "hbm_frac", "alone")
+        out["roofline_decode"] = _pick(rd, "kernel", "bound", "ms_per_step", "valu_frac", "hbm_frac")
+        if isinstance(rd.get("alone"), dict):
+            out["roofline_decode"]["alone"] = _pick(rd["alone"], "launch_ms", "valu_frac", "source")
     cb = g("cpu_baseline")
     if isinstance(cb, dict):
         out["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "sample", "ms_per_image", "throughput_speedup")
@@ -1365,7 +1383,9 @@ def main(argv=None):
                                 "hbm_bytes_algorithmic": int(tab_alg_bytes),
                                 "hbm_achieved": round(tab_alg_bytes / (tab_ms * 1e-3) / 1e9, 1),
                                 "hbm_frac": round(tab_alg_bytes / (tab_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "note": "in situ: the launches share the GPU with the table copies"},
+                                "note": "in situ: the launches share the GPU with the table copies; valu_frac counts the issue slots of the edge "
+                                        "evaluation alone (what the reference's arithmetic needs) - `alone` counts every VALU instruction the kernel issues",
+                                "alone": tab_kernel_alone() if a.workload == "kodak24" and a.mode == "polya" and not f16 else None},
             "kernels_ms": {"symtab": round(sym_ms, 4), "tab_kernels_all_launches": round(tab_ms, 4),
                            "quant_stats": round(float(np.mean(leg.k_qs)), 4)},
             # what crosses PCIe per step and rank (the decode-side tables are the longest leg of a step)
