@@ -980,6 +980,58 @@ class Leg:
                         "(segdec_kernel), every segment verified against the next checkpoint"}
 
 
+def head_leg(leg: Leg, device: int, reps: int = 8):
+    """SURVEY.md section 8 f2 in the default line: the parameter head's last layer - Conv2d(640, 3*K*192, 1), ckbd_gmm.py:115-121 - FUSED
+    with the encode-side CDF kernel (fgmm_head.hip: v_mfma_f32_32x32x2_f32, the table entry as the epilogue) on this batch's latents with
+    a random head of that shape, against what a caller does today (torch's fp32 conv2d, three parameter tensors through HBM,
+    symtab_kernel).  GPU milliseconds by events on the stream; `value` = matrix-product TFLOP/s of the fused kernel, table epilogue
+    included; the bitstreams of the fused kernel against those of the un-fused path fed the head kernel's own parameter planes."""
+    from flashgmm_amd import ParameterHead, _lib
+    from tests.synth import make_head
+
+    y = leg.ys
+    N, M, h, w = y.shape
+    conv, x, _ = make_head(5, M, 640, h, w, N, dev=y.device)
+    head = ParameterHead(conv)
+    gmc = leg.gmc
+    flop = 2.0 * 12 * M * 640 * N * h * w
+
+    def gpu_ms(fn):
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a_.record()
+        r = fn()
+        b_.record()
+        torch.cuda.synchronize()
+        return a_.elapsed_time(b_), r
+
+    def torch_params():
+        with torch.no_grad():
+            return torch.nn.functional.conv2d(x, conv.weight, conv.bias).chunk(3, 1)
+
+    t_conv, t_sym, t_fused = [], [], []
+    for i in range(reps + 2):
+        ms, prm = gpu_ms(torch_params)
+        gmc.compress_batch(y, *prm, weights_are_logits=True)
+        if i >= 2:
+            t_conv.append(ms), t_sym.append(_lib.kernel_ms(device, 0))
+    for i in range(reps + 2):
+        fused = gmc.compress_head_batch(y, x, head)
+        if i >= 2:
+            t_fused.append(_lib.kernel_ms(device, 0))
+    planes = head.params(x)
+    plain = gmc.compress_batch(y, *planes, weights_are_logits=True)
+    out = gmc.decompress_batch(fused.strings, fused.abs_maxes, fused.zero_bitmaps, *planes, weights_are_logits=True, stacked_output=True)
+    k = float(np.median(t_fused))
+    return {"value": round(flop / k / 1e9, 1), "unit": "TFLOP/s (f32 MFMA, table epilogue included)", "mfma_frac": round(flop / k / 1e9 / 157.3, 4),
+            "mfma_peak_tflops": 157.3, "head_ms": round(k, 4), "unfused_ms": round(float(np.median(t_conv) + np.median(t_sym)), 4),
+            "torch_conv_ms": round(float(np.median(t_conv)), 4), "symtab_ms": round(float(np.median(t_sym)), 4), "gemm_gflop": round(flop / 1e9, 1),
+            "bytes_equal_unfused": [bytes(b) for b in fused.strings] == [bytes(b) for b in plain.strings],
+            "decode_equals_round_y": bool(torch.equal(out, fused.y_q)),
+            "head": f"Conv2d(640, {12 * M}, 1), random weights; {N} bitstreams of [{M}, {h}, {w}]",
+            "detail": "profiles/r06_head_kernel.md"}
+
+
 def ka1_check(leg: Leg, res):
     """The first four bitstreams of rank 0 are SURVEY.md §8c's known-answer streams (seeds 0..3 = images 0 and 1 of the Kodak
     batch): their md5s against tests/golden/ka1.json — fixtures made from the reference compiled in the build container
@@ -1279,6 +1331,10 @@ def main(argv=None):
         for m in modes:
             del modes[m]["_bytes"]
         extras["modes"] = modes
+        try:
+            extras["head_fused"] = head_leg(leg, local_rank)
+        except Exception as e:  # pragma: no cover - the headline must not die of a sub-leg
+            extras["head_fused"] = {"value": None, "error": f"{type(e).__name__}: {str(e)[:300]}"}
         try:
             el = Leg(env, "elic4k", ELIC_IMAGES, "polya", True, keep_host_images=1, distinct=ELIC_DISTINCT)
             for _ in range(2):  # (the first steps grow the pinned receive area to this workload's 2.8 GB per stage)

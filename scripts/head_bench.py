@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from flashgmm_amd import GaussianMixtureConditional, ParameterHead, _lib  # noqa: E402
-from test_gpu_head import make_head  # noqa: E402
+from tests.synth import make_head  # noqa: E402
 
 images = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20

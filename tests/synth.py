@@ -179,3 +179,28 @@ def exact_codec_inputs(seed: int, c: int, c_side: int, h: int, w: int, dead: int
         y[:, :dead] = rng.uniform(-0.4, 0.4, (1, dead, h, w)).astype(np.float32)
     side = (rng.integers(-12, 13, (1, c_side, h, w)) / 4.0).astype(np.float32)
     return y, side
+
+
+def make_head(seed, M, c_in, h, w, N, dead=0, dev="cuda:0"):
+    """-> (conv, x [N, c_in, h, w], y [N, M, h, w]): a random 1x1 convolution of the parameter head's shape (nn.Conv2d(c_in, 3*K*M, 1),
+    compressai/models/ckbd_gmm.py:115-121) whose outputs look like entropy parameters - sigma and means of the order of a per-channel
+    energy e_c, logits of order one - and features / latents to go with it (tests/test_gpu_head.py, bench.py's head_fused leg)"""
+    import torch
+
+    rng = np.random.default_rng(seed)
+    e_c = np.exp(rng.uniform(-2.5, 2.0, M)).astype(np.float32)
+    W = (rng.standard_normal((3, 4, M, c_in)) / np.sqrt(c_in)).astype(np.float32)
+    b = np.zeros((3, 4, M), np.float32)
+    W[0] *= 0.3 * e_c[None, :, None]
+    b[0] = (0.6 + 0.5 * rng.uniform(0, 1, (4, M))) * e_c[None, :]  # sigma: mostly positive, sometimes under the clamp
+    W[1] *= e_c[None, :, None]
+    conv = torch.nn.Conv2d(c_in, 12 * M, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(W.reshape(12 * M, c_in, 1, 1)))
+        conv.bias.copy_(torch.from_numpy(b.reshape(-1)))
+    x = rng.standard_normal((N, c_in, h, w)).astype(np.float32)
+    x = np.where(x > 0, x, 0.01 * x)  # (the layer before is a LeakyReLU)
+    y = (rng.standard_normal((N, M, h, w)) * 1.5 * e_c[None, :, None, None]).astype(np.float32)
+    if dead:
+        y[:, rng.choice(M, dead, replace=False)] *= 0.0
+    return conv.to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)

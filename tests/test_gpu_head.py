@@ -16,31 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from flashgmm_amd import GaussianMixtureConditional, ParameterHead, _lib  # noqa: E402
+from tests.synth import make_head  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 MODES = ["polya", "as", "logistic"]
-
-
-def make_head(seed, M, c_in, h, w, N, dead=0, dev="cuda:0"):
-    """a random 1x1 conv of the head's shape whose outputs look like entropy parameters (sigma of order e_c, means of order e_c,
-    logits of order one) for latents of per-channel energy e_c, and features / latents to go with it"""
-    rng = np.random.default_rng(seed)
-    e_c = np.exp(rng.uniform(-2.5, 2.0, M)).astype(np.float32)
-    W = (rng.standard_normal((3, 4, M, c_in)) / np.sqrt(c_in)).astype(np.float32)
-    b = np.zeros((3, 4, M), np.float32)
-    W[0] *= 0.3 * e_c[None, :, None]
-    b[0] = (0.6 + 0.5 * rng.uniform(0, 1, (4, M))) * e_c[None, :]  # sigma: mostly positive, sometimes under the clamp
-    W[1] *= e_c[None, :, None]
-    conv = torch.nn.Conv2d(c_in, 12 * M, 1)
-    with torch.no_grad():
-        conv.weight.copy_(torch.from_numpy(W.reshape(12 * M, c_in, 1, 1)))
-        conv.bias.copy_(torch.from_numpy(b.reshape(-1)))
-    x = rng.standard_normal((N, c_in, h, w)).astype(np.float32)
-    x = np.where(x > 0, x, 0.01 * x)  # (the layer before is a LeakyReLU)
-    y = (rng.standard_normal((N, M, h, w)) * 1.5 * e_c[None, :, None, None]).astype(np.float32)
-    if dead:
-        y[:, rng.choice(M, dead, replace=False)] *= 0.0
-    return conv.to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
 
 
 @pytest.mark.parametrize("M,c_in,h,w", [(192, 640, 32, 24), (16, 32, 4, 8), (24, 40, 5, 7), (8, 33, 3, 3), (40, 64, 16, 20)])
