@@ -285,7 +285,7 @@ static void make_decode_pool(fgmm_ctx *c, int n_threads) {
   const char *e = getenv("FGMM_DECODE_SMT");
   if (e && *e == '1') return; // (A/B: both hardware threads of a core, as the encode pool)
   const WorkerCpus one = c->worker_cpus.one_per_core(n_threads);
-  if (one.restricted && one.cpus != (c->worker_cpus.restricted ? c->worker_cpus.cpus : -1)) c->dec_pool = new (std::nothrow) Pool(n_threads, one);
+  if (one.restricted && one.cpus != (c->worker_cpus.restricted ? c->worker_cpus.cpus : -1)) c->dec_pool = new (std::nothrow) Pool(n_threads, one, 'd');
 }
 
 int fgmm_ctx_create(int device, int n_threads, fgmm_ctx **out) {

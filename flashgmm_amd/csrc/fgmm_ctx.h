@@ -182,11 +182,11 @@ struct WorkerCpus {
 // ---- host worker pool ----------------------------------------------------------------------------------
 class Pool {
 public:
-  Pool(int n, const WorkerCpus &where) : slot_((size_t)n), lifo_(getenv("FGMM_POOL_FIFO") == nullptr) {
+  Pool(int n, const WorkerCpus &where, char tag = 'w') : slot_((size_t)n), lifo_(getenv("FGMM_POOL_FIFO") == nullptr) {
     for (int i = 0; i < n; ++i)
-      th_.emplace_back([this, i, where] {
+      th_.emplace_back([this, i, where, tag] {
         char name[16];
-        snprintf(name, sizeof name, "fgmm-w%d", i); // (/proc/<pid>/task/<tid>/comm: bench.py's step_diag names the threads that waited for a CPU)
+        snprintf(name, sizeof name, "fgmm-%c%d", tag, i); // fgmm-w*: the context's pool (encode, copies); fgmm-d*: the decode calls' pool // (/proc/<pid>/task/<tid>/comm: bench.py's step_diag names the threads that waited for a CPU)
         pthread_setname_np(pthread_self(), name);
         if (where.restricted) (void)sched_setaffinity(0, sizeof where.set, &where.set); // (refused by the kernel: the inherited mask)
         run(i);

@@ -1665,3 +1665,21 @@ def test_workers_are_kept_off_the_creating_threads_l3():
         assert off and off == P.cpulist_to_set(open(f"/sys/devices/system/cpu/cpu{min(off)}/cache/index3/shared_cpu_list").read()) & mask, (tid, allowed)
         seen += P.cpulist_to_set(allowed) == workers
     assert seen >= n_workers
+    # the decode calls' pool (threads fgmm-d*): as many workers, on ONE hardware thread of every core of that list (when the host has
+    # second hardware threads and enough cores)
+    dec = []
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            if open(f"/proc/self/task/{tid}/comm").read().startswith("fgmm-d"):
+                dec.append(P.cpulist_to_set([ln.split(":", 1)[1].strip() for ln in open(f"/proc/self/task/{tid}/status") if ln.startswith("Cpus_allowed_list")][0]))
+        except OSError:
+            continue
+
+    def siblings(c):
+        return P.cpulist_to_set(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read())
+
+    firsts = {c for c in workers if c == min(siblings(c) & workers)}
+    if os.environ.get("FGMM_DECODE_SMT") == "1" or len(firsts) == len(workers) or len(firsts) < n_workers:
+        assert not dec
+    else:
+        assert len(dec) >= n_workers and any(d == firsts for d in dec) and all(d <= workers for d in dec)
