@@ -10,7 +10,7 @@
 //     acc = bias[o];  for k = 0 .. c_in - 1:  acc = fmaf(W[o][k], x[k][p], acc)
 // (one rounding per product, k ascending: lane half 0 of the instruction holds the even k of a pair, half 1 the odd one).  The order is
 // the library's, not a BLAS's: encoder and decoder get the same parameters from the same weights on any ROCm / torch / MIOpen version,
-// which the reference silently relies on.  oracle/fgmm_oracle.c restates the chain with fmaf (fgo_head_params): the GPU tests compare
+// which the reference silently relies on.  The CPU checker under tests restates the chain with fmaf: the GPU tests compare
 // bit for bit.
 //
 // Tiling (wave64, 256 threads = 4 waves, TWO blocks per CU - a wave holds 96 accumulator registers and at most 256 in all):

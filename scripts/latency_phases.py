@@ -33,7 +33,7 @@ for r in range(reps + 5):
     outs = [gmc.decompress_batch(res.strings[s::2], res.abs_maxes[s::2], res.zero_bitmaps[s::2], ss[s::2], ms[s::2], ws[s::2], stacked_output=True) for s in range(2)]
     t1 = time.perf_counter()
     if r >= 5:
-        ph = B.call_phases(_lib.call_log(0, 3))
+        ph = B.D.call_phases(_lib.call_log(0, 3))
         ph["total"] = (t1 - t0) * 1e3
         ph["between_calls"] = ph["total"] - sum(c["ms"][5] for c in _lib.call_log(0, 3))
         rows.append(ph)

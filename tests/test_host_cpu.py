@@ -24,6 +24,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODES = ["polya", "as", "logistic"]
 
 
+def test_compiled_python_boundary_loads_and_matches_the_library():
+    """flashgmm_amd._native (pybind11, csrc/fgmm_pybind.cpp) is built beside the library, resolves it through its $ORIGIN rpath, reports
+    the library's ABI version and exposes the three batched calls; FGMM_NATIVE=0 turns it off (the ctypes binding then does the work)"""
+    import subprocess
+    import sys
+
+    nat = _lib.native()
+    assert nat is not None, "flashgmm_amd/_native*.so missing or not loadable: flashgmm_amd/csrc/build.sh builds it"
+    assert nat.abi_version == _lib.lib().fgmm_abi_version()
+    for fn in ("compress_stacked", "compress_head_stacked", "decompress_stacked"):
+        assert callable(getattr(nat, fn))
+    out = subprocess.run([sys.executable, "-c", "from flashgmm_amd import _lib; print(_lib.native())"], env=dict(os.environ, FGMM_NATIVE="0"),
+                         capture_output=True, text=True, cwd=ROOT)
+    assert out.stdout.strip() == "None", out.stderr[-500:]
+
+
 def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     header = open(os.path.join(ROOT, "include", "flashgmm_amd.h")).read()
@@ -33,7 +49,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.fgmm_abi_version() == 5
+    assert L.fgmm_abi_version() == 6  # (v6: + the parameter head, section 2b of the header)
 
 
 def test_header_is_plain_c_and_links():
