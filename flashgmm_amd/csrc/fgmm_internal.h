@@ -152,7 +152,9 @@ constexpr int kTabCounters = 4 + kTabEdgeSlots;
 #define FGMM_EF_MIN 14
 #endif
 constexpr uint32_t kTabEfMin = FGMM_EF_MIN; // rows with at least this many entries MAY be Elias-Fano coded (smaller than raw from here on)
-constexpr uint32_t kTabEfDefault = 49;     // ... and are, by default, in the batched decoder ("ef_min" option): see DESIGN.md section 5
+constexpr uint32_t kTabEfDefault = 33;     // ... and are, by default, in the batched decoder ("ef_min" option): see DESIGN.md section 5 (49 until
+                                           // round 6: with the decoders on a pool of their own, one hardware thread per core, the rows of 33-48 entries
+                                           // pay as Elias-Fano too - 57.6 -> 56.6 B/latent, step median 8.83 -> 8.72 ms, CPU per step +2 %)
 constexpr uint32_t kHdr2Escape = 255;
 FGMM_HD static inline uint32_t tab_hdr_pack(int32_t a, uint32_t cnt, uint32_t nonmono) {
   return (uint32_t)(uint16_t)(int16_t)a | ((cnt & 0x7FFFu) << 16) | (nonmono << 31);

@@ -127,7 +127,7 @@ int fgmm_ctx_take_buffers(fgmm_ctx *ctx, void *const *dst, void *const *src, con
  *                       whose rows do not fit is re-run with the exact size its cursor reports
  *   "ef_rows"     [0]   decode: 0 = Elias-Fano rows when min(host workers, bitstreams of the call) >= 10 (PCIe is the bottleneck),
  *                       uint16 rows otherwise (the sequential host decoders are); 1 = always, 2 = never
- *   "ef_min"      [49]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor)
+ *   "ef_min"      [33]  decode: rows with at least this many entries are Elias-Fano coded (>= 14, the format's floor)
  *   "gpu_decode"  [0]   decode: checkpointed bitstreams (fgmm_ckpt) are decoded ON THE GPU, a workgroup per segment (no decode-side
  *                       tables at all); a bitstream with a segment the kernel does not settle goes through the table path.  0 = when
  *                       the call has enough segments for the GPU to be the faster decoder (estimated with rates measured on MI355X +

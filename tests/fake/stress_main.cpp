@@ -187,7 +187,7 @@ int main(int argc, char **argv) {
     set_opt(ctx, "pieces", big ? 0 : rnd() % 3 ? pick(1, 12) : 0);
     set_opt(ctx, "dec_first", pick(1, 6));
     set_opt(ctx, "ef_rows", pick(0, 2));
-    set_opt(ctx, "ef_min", rnd() % 2 ? 14 : 49);
+    set_opt(ctx, "ef_min", rnd() % 3 == 0 ? 14 : rnd() % 2 ? 33 : 49);
     set_opt(ctx, "enc_ways", pick(0, 4));
     set_opt(ctx, "enc_segs", pick(0, 2));
     set_opt(ctx, "scatter_rounds", rnd() % 2);
