@@ -109,9 +109,17 @@ struct WorkerCpus {
         w.error = std::string("FGMM_WORKER_CPUS='") + e + "' is neither \"inherit\" nor a cpulist like \"16-63,80-127\"";
         return w;
       }
-      for (int c = 0; c < CPU_SETSIZE; ++c)
-        if (CPU_ISSET(c, &asked) && (!have_mask || CPU_ISSET(c, &have))) CPU_SET(c, &w.set), ++w.cpus; // (the EFFECTIVE set: what
-      if (w.cpus == 0) {                                           //  sched_setaffinity would grant; fgmm_ctx_worker_cpus reports it)
+      // the EFFECTIVE set - what the kernel grants a thread of this process that asks for the list (the process's cpuset decides, not
+      // the creating thread's own mask, which a caller may have narrowed to the CPUs it keeps for itself): asked for by a short-lived
+      // thread and read back; fgmm_ctx_worker_cpus reports it
+      bool granted = false;
+      std::thread probe([&] {
+        granted = sched_setaffinity(0, sizeof asked, &asked) == 0 && sched_getaffinity(0, sizeof w.set, &w.set) == 0;
+      });
+      probe.join();
+      w.cpus = granted ? CPU_COUNT(&w.set) : 0;
+      if (w.cpus == 0) {
+        CPU_ZERO(&w.set);
         w.error = std::string("FGMM_WORKER_CPUS='") + e + "' names no CPU this process may run on";
         return w;
       }

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <dirent.h>
+#include <sched.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -140,6 +141,17 @@ int main(int argc, char **argv) {
   const double budget = argc > 1 ? atof(argv[1]) : 20.0;
   if (argc > 2) rng_state ^= (uint64_t)atoll(argv[2]) * 0x9E3779B97F4A7C15ull;
   fgmm_ctx *ctx = nullptr;
+  if (getenv("FGMM_STRESS_NARROW_CALLER")) { // the creating thread keeps ONE CPU for itself before the context exists (a caller that has
+    cpu_set_t have, one;                     // already moved to the CPUs it reserves: the workers' list is still the kernel's to grant)
+    CHECK(sched_getaffinity(0, sizeof have, &have) == 0, "getaffinity");
+    CPU_ZERO(&one);
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &have)) {
+        CPU_SET(c, &one);
+        break;
+      }
+    CHECK(sched_setaffinity(0, sizeof one, &one) == 0, "setaffinity");
+  }
   CHECK(fgmm_ctx_create(0, 4, &ctx) == FGMM_OK, "ctx");
   if (const char *want = getenv("FGMM_STRESS_EXPECT_WORKER_CPUS")) { // (tests/test_fake_device_cpu.py: FGMM_WORKER_CPUS is honoured)
     char got[4096];

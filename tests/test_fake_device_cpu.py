@@ -69,3 +69,15 @@ def test_the_reported_worker_cpus_are_the_effective_ones(stress_binary):
     e = dict(os.environ, FGMM_WORKER_CPUS=f"{cpus[0]},4000-4003", FGMM_STRESS_EXPECT_WORKER_CPUS=str(cpus[0]))
     r = subprocess.run([stress_binary, "1", "3"], capture_output=True, text=True, timeout=300, env=e)
     assert r.returncode == 0 and f"worker CPUs: '{cpus[0]}'" in r.stdout, r.stderr[-1000:]
+
+
+def test_worker_cpulist_is_granted_by_the_kernel_not_by_the_callers_mask(stress_binary):
+    """a caller that narrows ITS OWN affinity to the CPUs it keeps for itself before the first context exists (plan_l3's recipe, in
+    that order) must still get the workers it named with FGMM_WORKER_CPUS: the process's cpuset decides what a thread may ask for, not
+    the creating thread's current mask (round 6: the loud check had intersected with that mask and refused a valid list)"""
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 2:
+        pytest.skip("one CPU")
+    e = dict(os.environ, FGMM_WORKER_CPUS=str(cpus[-1]), FGMM_STRESS_EXPECT_WORKER_CPUS=str(cpus[-1]), FGMM_STRESS_NARROW_CALLER="1")
+    r = subprocess.run([stress_binary, "1", "3"], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0 and f"worker CPUs: '{cpus[-1]}'" in r.stdout, r.stderr[-1000:]
