@@ -1311,10 +1311,11 @@ def main(argv=None):
         for m in ("as", "logistic"):
             lm = leg.with_mode(m)
             lm.step(a.schedule)
-            dt_m, st_m = lm.timed(a.schedule, 3, record=True)
+            n_m = 8  # (80 ms per mode: three steps were too few to stand a co-tenant's surge)
+            dt_m, st_m = lm.timed(a.schedule, n_m, record=True)
             res_m = lm.check_last()
             nc_m, sym_ms_m, ach_m = lm.symtab_roofline(res_m)
-            modes[m] = {"value": round(lm.mpix(3, dt_m), 2), "unit": "Mpixels/s", "steps": 3, "ms_per_step": round(dt_m / 3 * 1e3, 3),
+            modes[m] = {"value": round(lm.mpix(n_m, dt_m), 2), "unit": "Mpixels/s", "steps": n_m, "ms_per_step": round(dt_m / n_m * 1e3, 3),
                         "step_ms": st_m["all"], "bitstream_bytes": sum(len(r[0][0]) for r in res_m),
                         "symtab": {"launch_ms": round(sym_ms_m, 4), "achieved": round(ach_m, 1), "unit": "GB/s", "frac": round(ach_m / HBM_PEAK_GBS, 4)},
                         "tab_kernels_ms_per_step": round(float(np.mean(lm.k_tab)), 4),

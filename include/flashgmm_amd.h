@@ -94,7 +94,9 @@ int fgmm_ctx_set_threads(fgmm_ctx *ctx, int n_threads);
  * is created, from the environment variable FGMM_WORKER_CPUS:
  *   unset      the creating thread's CPUs minus those that share an L3 with the CPU it is on (if >= 32 CPUs and two per worker remain)
  *   "inherit"  the creating thread's CPUs
- *   a cpulist  exactly these, e.g. "16-127"
+ *   a cpulist  exactly these, e.g. "16-127" (what the kernel grants of them to a thread of this process: the list within the process's
+ *              cpuset; fgmm_ctx_worker_cpus reports that).  A value that is not a cpulist, or of which no CPU is granted, makes
+ *              fgmm_ctx_create fail with FGMM_ERR_INVALID - never a silent fall back onto the creating thread's L3
  * The library never changes the calling thread's own affinity; a caller that wants the full benefit keeps its thread on the CPUs
  * that are NOT in this list (bench.py does, for its timed regions).
  * The DECODE calls run on a second pool of as many workers confined to ONE hardware thread per core of that list (two sequential

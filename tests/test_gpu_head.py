@@ -109,3 +109,61 @@ def test_head_refuses_what_it_cannot_do():
         head.params(x[:, :16])  # c_in mismatch
     with pytest.raises(RuntimeError):
         ParameterHead(torch.nn.Conv2d(32, 12 * 16, 3).to("cuda:0"))  # not 1x1
+
+
+def test_fused_head_with_non_finite_features_equals_the_unfused_path():
+    """features with NaN / +-inf at a few positions give NaN / inf parameters there: the fused epilogue and symtab_kernel share one
+    sym_entry (its out-of-line IEEE evaluation included), so the bytes stay equal - and input channels past c_in (a last K tile that
+    is only partly real: c_in = 40) are masked, not multiplied"""
+    M, c_in, h, w, N = 24, 40, 8, 12, 2
+    conv, x, y = make_head(31, M, c_in, h, w, N)
+    x[0, 3, 2, 5] = float("nan")
+    x[0, 39, 0, 0] = float("inf")
+    x[1, 0, 7, 11] = float("-inf")
+    head = ParameterHead(conv)
+    for mode in MODES:
+        gmc = GaussianMixtureConditional(K=4, mode=mode)
+        fused = gmc.compress_head_batch(y, x, head)
+        s, m, lg = head.params(x)
+        assert not torch.isfinite(s).all()
+        plain = gmc.compress_batch(y, s, m, lg, weights_are_logits=True)
+        assert [bytes(b) for b in fused.strings] == [bytes(b) for b in plain.strings] and fused.abs_maxes == plain.abs_maxes
+        out = gmc.decompress_batch(fused.strings, fused.abs_maxes, fused.zero_bitmaps, s, m, lg, weights_are_logits=True, stacked_output=True)
+        assert torch.equal(out, fused.y_q)
+
+
+def test_head_c_abi_with_items_of_different_sizes():
+    """fgmm_gmc_compress_head_batch / fgmm_head_params_batch straight through the C ABI (ctypes) with RAGGED items - 96, 300 and 0
+    positions in one call (the stacked Python form has one size): every item equals its own single-item call"""
+    import ctypes as C
+
+    M, c_in = 16, 64
+    conv, _, _ = make_head(41, M, c_in, 2, 2, 1)
+    head = ParameterHead(conv)
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    rng = np.random.default_rng(5)
+    sizes = [(8, 12), (15, 20), (0, 7)]
+    xs = [torch.from_numpy(rng.standard_normal((1, c_in, hh, ww)).astype(np.float32)).cuda() for hh, ww in sizes]
+    ys = [torch.from_numpy((rng.standard_normal((1, M, hh, ww)) * 3).astype(np.float32)).cuda() for hh, ww in sizes]
+    n = len(sizes)
+    items = (_lib.fgmm_item * n)()
+    yq = [torch.empty_like(t) for t in ys]
+    zb = [torch.empty(M, dtype=torch.int64) for _ in sizes]
+    for i, (hh, ww) in enumerate(sizes):
+        items[i].y, items[i].M, items[i].K, items[i].hw = ys[i].data_ptr(), M, 4, hh * ww
+        items[i].yq_out, items[i].zero_bitmap = yq[i].data_ptr(), zb[i].data_ptr()
+    xp = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
+    _lib.check(L.fgmm_gmc_compress_head_batch(ctx, None, items, xp, n, head._h, 0, 1), "fgmm_gmc_compress_head_batch")
+    outs = [torch.empty((1, 12 * M, hh, ww), dtype=torch.float32, device="cuda") for hh, ww in sizes]
+    op = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+    hw = (C.c_int64 * n)(*[hh * ww for hh, ww in sizes])
+    _lib.check(L.fgmm_head_params_batch(ctx, None, head._h, xp, op, hw, n), "fgmm_head_params_batch")
+    for i, (hh, ww) in enumerate(sizes):
+        got = _lib.take_bytes(items[i].bytes, items[i].bytes_len)
+        if hh * ww == 0:
+            assert got == bytes.fromhex("0000008000000000")  # the flushed state of an empty stream
+            continue
+        one = gmc.compress_head_batch(ys[i], xs[i], head)
+        assert got == bytes(one.strings[0]) and items[i].abs_max == one.abs_maxes[0] and torch.equal(yq[i], one.y_q[0])
+        assert torch.equal(outs[i], torch.cat(head.params(xs[i]), 1))
