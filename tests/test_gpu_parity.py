@@ -1682,4 +1682,7 @@ def test_workers_are_kept_off_the_creating_threads_l3():
     if os.environ.get("FGMM_DECODE_SMT") == "1" or len(firsts) == len(workers) or len(firsts) < n_workers:
         assert not dec
     else:
-        assert len(dec) >= n_workers and any(d == firsts for d in dec) and all(d <= workers for d in dec)
+        # (a process may hold several contexts, each with its own list: this context's decoders are on `firsts`, every decoder of the
+        # process is on one hardware thread per core of the process's CPUs)
+        assert len(dec) >= n_workers and any(d == firsts for d in dec)
+        assert all(d <= mask and all(len(siblings(c) & d) == 1 for c in d) for d in dec)
