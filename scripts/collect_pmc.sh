@@ -10,8 +10,8 @@ workload=${3:-kodak24}
 steps=${4:-4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out/pmc_fetch" "$out/pmc_write"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps $steps --warmup 1 --mode "$mode" --workload "$workload" --no-cpu-baseline --no-extras --schedule all-at-once > "$out/pmc_fetch/bench.json" 2> "$out/pmc_fetch/err.txt"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps $steps --warmup 1 --mode "$mode" --workload "$workload" --no-cpu-baseline --no-extras --schedule all-at-once > "$out/pmc_write/bench.json" 2> "$out/pmc_write/err.txt"
+FGMM_BENCH_DETAIL="$out/pmc_fetch/detail.json" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps $steps --warmup 1 --mode "$mode" --workload "$workload" --no-cpu-baseline --no-extras --schedule all-at-once > "$out/pmc_fetch/bench.json" 2> "$out/pmc_fetch/err.txt"
+FGMM_BENCH_DETAIL="$out/pmc_write/detail.json" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps $steps --warmup 1 --mode "$mode" --workload "$workload" --no-cpu-baseline --no-extras --schedule all-at-once > "$out/pmc_write/bench.json" 2> "$out/pmc_write/err.txt"
 python3 - "$out" "$mode" "$workload" "$steps" <<'PY'
 import csv, glob, json, sys
 out, mode, workload, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
@@ -19,7 +19,7 @@ def mean_counter(d, name, kernel):
     f = glob.glob(f"{out}/{d}/*/*_counter_collection.csv")[0]
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name and kernel in r["Kernel_Name"]]
     return sum(v) / len(v), len(v)
-b0 = json.load(open(f"{out}/pmc_write/bench.json"))
+b0 = json.load(open(f"{out}/pmc_write/detail.json"))  # (the whole result: bench.py's stdout is a summary since round 6)
 res = {"workload": workload, "mode": mode, "param_dtype": b0["config"]["param_dtype"], "images_per_gpu": b0["config"]["images_per_gpu"],
        "kernel": "symtab_kernel", "algorithmic_bytes_per_launch": b0["roofline"]["bytes_per_launch"]}
 def sum_counter(d, name, kernel, steps):
@@ -36,7 +36,7 @@ res["symtab"]["traffic_over_algorithmic"] = round(res["symtab"]["hbm_bytes_corre
 try:
     fk, nf = sum_counter("pmc_fetch", "FETCH_SIZE", "tab_kernel", steps + 1)
     wk, nw = sum_counter("pmc_write", "WRITE_SIZE", "tab_kernel", steps + 1)
-    b = json.load(open(f"{out}/pmc_write/bench.json"))
+    b = json.load(open(f"{out}/pmc_write/detail.json"))
     alg = b["roofline_decode"]["hbm_bytes_algorithmic"]
     # parameters are read 4 bytes per lane (FETCH_SIZE uncalibrated for that width: reported raw and doubled), rows are written
     # 4 bytes per lane
