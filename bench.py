@@ -649,7 +649,7 @@ def summary_line(full: dict, detail_path=None) -> dict:
         if isinstance(el.get("checkpointed"), dict):
             out["elic4k"]["checkpointed"] = _pick(el["checkpointed"], "value")
     if isinstance(g("head_fused"), dict):
-        out["head_fused"] = _pick(g("head_fused"), "value", "mfma_frac", "head_ms", "unfused_ms", "bytes_equal_unfused")
+        out["head_fused"] = _pick(g("head_fused"), "value", "mfma_frac", "mfma_frac_back_to_back", "head_ms", "unfused_ms", "bytes_equal_unfused", "error")
     rk = g("ranks") or {}
     out["ranks"] = _pick(rk, "backend", "rccl_ranks", "ms_per_step", "host_threads_per_gpu", "result_checked_ranks")
     if isinstance(rk.get("allgather_ms"), dict):
@@ -1019,6 +1019,12 @@ def head_leg(leg: Leg, device: int, reps: int = 8):
         fused = gmc.compress_head_batch(y, x, head)
         if i >= 2:
             t_fused.append(_lib.kernel_ms(device, 0))
+    # the matrix product alone, launched back to back (six launches in one bracket): what the kernel takes when the GPU does not come
+    # out of an idle gap - 0.12-0.14 ms of a lone launch is the chip waking up (profiles/r06_head_kernel.md)
+    warm = []
+    for _ in range(3):
+        ms, _r = gpu_ms(lambda: [head.params(x) for _ in range(6)])
+        warm.append(ms / 6)
     planes = head.params(x)
     plain = gmc.compress_batch(y, *planes, weights_are_logits=True)
     out = gmc.decompress_batch(fused.strings, fused.abs_maxes, fused.zero_bitmaps, *planes, weights_are_logits=True, stacked_output=True)
@@ -1026,6 +1032,7 @@ def head_leg(leg: Leg, device: int, reps: int = 8):
     return {"value": round(flop / k / 1e9, 1), "unit": "TFLOP/s (f32 MFMA, table epilogue included)", "mfma_frac": round(flop / k / 1e9 / 157.3, 4),
             "mfma_peak_tflops": 157.3, "head_ms": round(k, 4), "unfused_ms": round(float(np.median(t_conv) + np.median(t_sym)), 4),
             "torch_conv_ms": round(float(np.median(t_conv)), 4), "symtab_ms": round(float(np.median(t_sym)), 4), "gemm_gflop": round(flop / 1e9, 1),
+            "head_params_ms_back_to_back": round(float(np.median(warm)), 4), "mfma_frac_back_to_back": round(flop / float(np.median(warm)) / 1e9 / 157.3, 4),
             "bytes_equal_unfused": [bytes(b) for b in fused.strings] == [bytes(b) for b in plain.strings],
             "decode_equals_round_y": bool(torch.equal(out, fused.y_q)),
             "head": f"Conv2d(640, {12 * M}, 1), random weights; {N} bitstreams of [{M}, {h}, {w}]",
