@@ -506,6 +506,11 @@ static int compress_batch_impl(fgmm_ctx *ctx, void *stream, fgmm_item *items, in
     e.ckpt_stride = s.ckpt_stride;
   }
   const int rc = encode_batch(ctx, (dev::Stream)stream, v, mode, head ? &head->w : nullptr);
+  if (rc != FGMM_OK) // a failed call returns no buffer: what the bitstreams that had finished hold is released here, not leaked by a
+    for (auto &e : v) { // binding that raises on the status
+      free(e.bytes), free(e.ckpt);
+      e.bytes = nullptr, e.ckpt = nullptr, e.bytes_len = 0, e.n_ckpt = 0;
+    }
   for (int i = 0; i < count; ++i) {
     items[i].abs_max = v[i].abs_max;
     items[i].bytes = v[i].bytes;

@@ -270,6 +270,8 @@ typedef struct {
   int64_t n_ckpt;          /* compress out / decompress in */
 } fgmm_item;
 
+/* A compress call that returns an error returns NO buffer (items[i].bytes / .ckpt are NULL, whatever items[i].status says): a binding
+ * may raise on the status without releasing anything. */
 int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
 int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
 
