@@ -114,11 +114,26 @@ py::tuple take_ckpts(fgmm_ctx *ctx, std::vector<fgmm_item> &it) {
     const int rc = fgmm_ctx_take_buffers(ctx, dst.data(), src.data(), len.data(), (int)dst.size());
     if (rc) raise("fgmm_ctx_take_buffers", rc);
   }
+  for (auto &f : it) f.ckpt = nullptr; // (copied and released by the library)
   return py::make_tuple(keep, counts);
 }
 
+// what a finished compress call returned in library-owned buffers, released if this binding does not get to hand it over (an allocation
+// that fails half way, a copy that is refused): fgmm_ctx_take_buffers releases what it copies
+struct Owned {
+  std::vector<fgmm_item> &it;
+  ~Owned() {
+    for (auto &f : it) {
+      fgmm_free(f.bytes), fgmm_free(f.ckpt);
+      f.bytes = nullptr, f.ckpt = nullptr;
+    }
+  }
+};
+
 py::tuple finish_compress(fgmm_ctx *ctx, std::vector<fgmm_item> &it, int ckpt_stride, py::handle cls) {
+  Owned owned{it};
   py::list strings = take_bytes(ctx, it, cls);
+  for (auto &f : it) f.bytes = nullptr; // (copied and released by the library)
   py::list abs_max(it.size());
   for (size_t i = 0; i < it.size(); ++i) PyList_SET_ITEM(abs_max.ptr(), (Py_ssize_t)i, PyLong_FromLong(it[i].abs_max));
   if (ckpt_stride) {
