@@ -30,7 +30,7 @@ from torch import Tensor
 
 from itertools import accumulate
 
-from .entropy_models import EntropyBottleneckCoder, GaussianMixtureConditional
+from .entropy_models import EntropyBottleneckCoder, GaussianMixtureConditional, ParameterHead
 from .ops import ckbd_embed, ckbd_unembed
 
 __all__ = ["GaussianMixtureConditionalLatentCodec", "CheckerboardLatentCodec", "ChannelGroupsLatentCodec", "HyperLatentCodec",
@@ -138,6 +138,32 @@ class GaussianMixtureConditionalLatentCodec(nn.Module):
         assert tuple(y_hat.shape[2:4]) == tuple(shape)
         return {"y_hat": y_hat}
 
+    # ---- the parameter head fused: `feat` = the input of entropy_parameters' LAST layer, `head` = a ParameterHead
+    # of that layer.  The codec owning the parameter network (CheckerboardLatentCodec(fuse_head=True)) calls these.
+    def _check_head(self):
+        if self.quantizer != "noise" or self.param_dtype != torch.float32:
+            raise RuntimeError("the fused parameter head needs quantizer='noise' and float32 parameters (as fuse_softmax)")
+
+    def compress_many_head(self, items: List[Tuple[Tensor, Tensor]], head: ParameterHead) -> List[Dict[str, Any]]:
+        """``compress`` of several ``(y [1, M, h, w], feat [1, c_in, h, w])`` of one shape in ONE native call, the parameters computed
+        by the head inside the encode-side kernel (never written to HBM)"""
+        self._check_head()
+        ys, feats = zip(*items)
+        res = self.gaussian_mixture_conditional.compress_head_batch(torch.cat(list(ys)), torch.cat(list(feats)), head)
+        return [{"strings": [(b, a, zb.to(y.device))], "shape": y.shape[2:4], "y_hat": yq} for ((b, a, zb), yq), y in zip(res, ys)]
+
+    def decompress_many_head(self, strings: List[List[Any]], shape: Tuple[int, int], feats: List[Tensor], head: ParameterHead) -> List[Dict[str, Any]]:
+        """the decoder's side: the SAME arithmetic gives the parameter tensors (``head.params``), the table kernels take the logits"""
+        self._check_head()
+        scales, means, logits = head.params(torch.cat(list(feats)))
+        items = [st[0] for st in strings]
+        outs = self.gaussian_mixture_conditional.decompress_batch([it[0] for it in items], [it[1] for it in items],
+                                                                  torch.stack([it[2].to("cpu", torch.int64) for it in items]), scales, means, logits,
+                                                                  weights_are_logits=True)
+        for y_hat in outs:
+            assert tuple(y_hat.shape[2:4]) == tuple(shape)
+        return [{"y_hat": y_hat} for y_hat in outs]
+
     def decompress_many(self, strings: List[List[Any]], shape: Tuple[int, int], ctx_params: List[Tensor]) -> List[Dict[str, Any]]:
         """``decompress`` of N independent items (the same stage of N images) in ONE batched native call: N host decoders
         side by side instead of N calls with one decoder each."""
@@ -175,10 +201,21 @@ class CheckerboardLatentCodec(nn.Module):
 
     def __init__(self, latent_codec: Optional[Dict[str, nn.Module]] = None, entropy_parameters: Optional[nn.Module] = None,
                  context_prediction: Optional[nn.Module] = None, anchor_parity: str = "even", forward_method: str = "twopass",
-                 **kwargs: Any):
+                 fuse_head: bool = False, **kwargs: Any):
         super().__init__()
         if anchor_parity not in ("even", "odd"):
             raise ValueError(f"anchor_parity {anchor_parity!r}")
+        # fuse_head: the LAST layer of entropy_parameters - nn.Conv2d(c_in, 3*K*M, 1), models/ckbd_gmm.py:115-121 - runs inside the
+        # library (flashgmm_amd.ParameterHead: matrix cores, one fixed summation order, fused with the encode-side CDF kernel; the
+        # softmax over K and the sigma clamp with it): encoder and decoder must agree on this switch like on the Phi approximation -
+        # the parameters differ from torch's convolution in their last bits
+        self.fuse_head = bool(fuse_head)
+        self._head: Optional[ParameterHead] = None
+        self._head_key = None
+        if self.fuse_head:
+            last = entropy_parameters[-1] if isinstance(entropy_parameters, nn.Sequential) and len(entropy_parameters) else entropy_parameters
+            if not isinstance(last, nn.Conv2d) or last.kernel_size != (1, 1) or last.stride != (1, 1) or last.groups != 1:
+                raise ValueError("fuse_head needs entropy_parameters to end in a plain 1x1 nn.Conv2d (models/ckbd_gmm.py:115-121)")
         self.anchor_parity = anchor_parity
         self.non_anchor_parity = {"odd": "even", "even": "odd"}[anchor_parity]
         self.forward_method = forward_method
@@ -200,6 +237,16 @@ class CheckerboardLatentCodec(nn.Module):
     def merge(self, *args: Tensor) -> Tensor:
         return torch.cat(args, dim=1)
 
+    def _head_parts(self):
+        """-> (everything of entropy_parameters before its last layer, the ParameterHead of that layer): packed once, again when the
+        layer's weights have changed (a checkpoint loaded, a device move)"""
+        ep = self.entropy_parameters
+        body, last = (ep[:-1], ep[-1]) if isinstance(ep, nn.Sequential) else (nn.Identity(), ep)
+        key = (last.weight.data_ptr(), last.weight._version, None if last.bias is None else (last.bias.data_ptr(), last.bias._version))
+        if self._head is None or self._head_key != key:
+            self._head, self._head_key = ParameterHead(last, K=self.latent_codec["y"].K), key
+        return body, self._head
+
     def _ctx(self, y_hat_: Tensor, i: int) -> Tensor:
         """context of half i from the halves reconstructed so far (:281-284, :310-313)"""
         y_ctx_i = self.unembed(self.context_prediction(self.embed(y_hat_)))[i]
@@ -217,9 +264,13 @@ class CheckerboardLatentCodec(nn.Module):
         side_params_ = self.unembed(side_params)
         y_ = self.unembed(y)
         prepared = []
+        body = self._head_parts()[0] if self.fuse_head else None
         for i in range(2):
-            params_i = self.entropy_parameters(self.merge(self._ctx(y_hat_, i), side_params_[i]))
-            prepared.append(codec.coder_inputs(y_[i], params_i))
+            if self.fuse_head:  # (y, the features the head's last layer reads): the parameters are the encode kernel's business
+                prepared.append((y_[i], body(self.merge(self._ctx(y_hat_, i), side_params_[i]))))
+            else:
+                params_i = self.entropy_parameters(self.merge(self._ctx(y_hat_, i), side_params_[i]))
+                prepared.append(codec.coder_inputs(y_[i], params_i))
             y_hat_[i] = torch.round(prepared[i][0])  # what compress() of this half returns as y_hat
         return prepared, self.embed(y_hat_)
 
@@ -229,6 +280,8 @@ class CheckerboardLatentCodec(nn.Module):
 
     def compress(self, y: Tensor, side_params: Tensor) -> Dict[str, Any]:
         prepared, y_hat = self.prepare(y, side_params)
+        if self.fuse_head:
+            return self.finish(self.latent_codec["y"].compress_many_head(prepared, self._head_parts()[1]), y_hat)
         return self.finish(self.latent_codec["y"].compress_many(prepared), y_hat)
 
     def decompress(self, strings: List[Any], shape: Tuple[int, ...], side_params: Tensor, **kwargs: Any) -> Dict[str, Any]:
@@ -238,6 +291,11 @@ class CheckerboardLatentCodec(nn.Module):
         y_hat_ = side_params.new_zeros((2, n, c, h, w // 2))
         side_params_ = self.unembed(side_params)
         for i in range(2):  # sequential by construction: the non-anchor parameters need the decoded anchors
+            if self.fuse_head:
+                body, head = self._head_parts()
+                feat_i = body(self.merge(self._ctx(y_hat_, i), side_params_[i]))
+                y_hat_[i] = codec.decompress_many_head([[strings[i]]], (h, w // 2), [feat_i], head)[0]["y_hat"]
+                continue
             params_i = self.entropy_parameters(self.merge(self._ctx(y_hat_, i), side_params_[i]))
             y_hat_[i] = codec.decompress([strings[i]], (h, w // 2), params_i)["y_hat"]
         return {"y_hat": self.embed(y_hat_)}
@@ -251,8 +309,13 @@ class CheckerboardLatentCodec(nn.Module):
         y_hat_ = [sp.new_zeros((2, 1, c, h, w // 2)) for sp in side_params]
         side_ = [self.unembed(sp) for sp in side_params]
         for i in range(2):
-            params = [self.entropy_parameters(self.merge(self._ctx(yh, i), sd[i])) for yh, sd in zip(y_hat_, side_)]
-            outs = codec.decompress_many([[st[i]] for st in strings], (h, w // 2), params)
+            if self.fuse_head:
+                body, head = self._head_parts()
+                feats = [body(self.merge(self._ctx(yh, i), sd[i])) for yh, sd in zip(y_hat_, side_)]
+                outs = codec.decompress_many_head([[st[i]] for st in strings], (h, w // 2), feats, head)
+            else:
+                params = [self.entropy_parameters(self.merge(self._ctx(yh, i), sd[i])) for yh, sd in zip(y_hat_, side_)]
+                outs = codec.decompress_many([[st[i]] for st in strings], (h, w // 2), params)
             for yh, o in zip(y_hat_, outs):
                 yh[i] = o["y_hat"]
         return [{"y_hat": self.embed(yh)} for yh in y_hat_]
@@ -304,6 +367,8 @@ class ChannelGroupsLatentCodec(nn.Module):
     def _one_call(codecs) -> bool:
         """can all groups be coded in one batched call?  (group codecs that can prepare, one Phi approximation, one clamp
         setting and one parameter dtype: what a batch of the entropy model must share)"""
+        if any(getattr(c, "fuse_head", False) for c in codecs):  # (every group has a head of its own: group by group)
+            return False
         try:
             keys = {(c.latent_codec["y"].gaussian_mixture_conditional._mode(), c.latent_codec["y"].gaussian_mixture_conditional.clamp_scales,
                      c.latent_codec["y"].param_dtype, c.latent_codec["y"].fuse_softmax) for c in codecs if hasattr(c, "prepare") and hasattr(c, "finish")}

@@ -167,3 +167,73 @@ def test_head_c_abi_with_items_of_different_sizes():
         one = gmc.compress_head_batch(ys[i], xs[i], head)
         assert got == bytes(one.strings[0]) and items[i].abs_max == one.abs_maxes[0] and torch.equal(yq[i], one.y_q[0])
         assert torch.equal(outs[i], torch.cat(head.params(xs[i]), 1))
+
+
+def _ckbd_codecs(M, seed, mode="polya"):
+    """two CheckerboardLatentCodecs over the same networks: one with fuse_head, one whose last layer is a module that calls the head's
+    un-fused kernel (the same arithmetic, parameter tensors through HBM, fuse_softmax in the GMM codec)"""
+    from flashgmm_amd.latent_codecs import CheckerboardLatentCodec, GaussianMixtureConditionalLatentCodec
+
+    torch.manual_seed(seed)
+    dev = "cuda:0"
+    ctx_net = torch.nn.Conv2d(M, 2 * M, 5, padding=2).to(dev)
+    body = [torch.nn.Conv2d(4 * M, 96, 1), torch.nn.LeakyReLU()]
+    last = torch.nn.Conv2d(96, 12 * M, 1)
+    with torch.no_grad():
+        last.bias[: 4 * M] += 1.0  # sigma mostly positive
+    ep = torch.nn.Sequential(*body, last).to(dev)
+
+    class HeadModule(torch.nn.Module):
+        def __init__(self, head):
+            super().__init__()
+            self.head = head
+
+        def forward(self, x):
+            return torch.cat(self.head.params(x), 1)
+
+    fused = CheckerboardLatentCodec(latent_codec={"y": GaussianMixtureConditionalLatentCodec(K=4, mode=mode)}, entropy_parameters=ep,
+                                    context_prediction=ctx_net, fuse_head=True)
+    plain = CheckerboardLatentCodec(latent_codec={"y": GaussianMixtureConditionalLatentCodec(K=4, mode=mode, fuse_softmax=True)},
+                                    entropy_parameters=torch.nn.Sequential(*ep[:-1], HeadModule(ParameterHead(ep[-1]))), context_prediction=ctx_net)
+    return fused, plain
+
+
+@pytest.mark.parametrize("mode", ["polya", "logistic"])
+def test_checkerboard_codec_with_the_fused_head(mode):
+    """CheckerboardLatentCodec(fuse_head=True) - the mirror of compressai/latent_codecs/checkerboard.py:275-330 with the last layer of its
+    entropy_parameters inside the library: the same strings, shape and y_hat as the codec that runs the head's un-fused kernel as its
+    last layer, both halves in one encode call; decompress (stage by stage) gives y_hat back, image by image and stage-major"""
+    M, h, w = 32, 16, 24
+    fused, plain = _ckbd_codecs(M, 3, mode)
+    rng = np.random.default_rng(9)
+    with torch.no_grad():
+        outs = []
+        for img in range(2):
+            y = torch.from_numpy((rng.standard_normal((1, M, h, w)) * 4).astype(np.float32)).cuda()
+            side = torch.from_numpy(rng.standard_normal((1, 2 * M, h, w)).astype(np.float32)).cuda()
+            a, b = fused.compress(y, side), plain.compress(y, side)
+            assert len(a["strings"]) == 2 and a["shape"] == b["shape"] and torch.equal(a["y_hat"], b["y_hat"]) and torch.equal(a["y_hat"], torch.round(y))
+            for (sa, ama, za), (sb, amb, zb_) in zip(a["strings"], b["strings"]):
+                assert bytes(sa) == bytes(sb) and ama == amb and torch.equal(za.cpu(), zb_.cpu())
+            assert torch.equal(fused.decompress(a["strings"], a["shape"], side)["y_hat"], a["y_hat"])
+            assert torch.equal(plain.decompress(a["strings"], a["shape"], side)["y_hat"], a["y_hat"])
+            outs.append((a, side))
+        many = fused.decompress_many([o[0]["strings"] for o in outs], outs[0][0]["shape"], [o[1] for o in outs])
+        for m_, (a, _) in zip(many, outs):
+            assert torch.equal(m_["y_hat"], a["y_hat"])
+        # new weights in the last layer: the head is packed again (not the stale one)
+        fused.entropy_parameters[-1].weight.mul_(1.25)
+        c = fused.compress(y, side)
+        assert any(bytes(x[0]) != bytes(z[0]) for x, z in zip(c["strings"], a["strings"]))
+        assert torch.equal(fused.decompress(c["strings"], c["shape"], side)["y_hat"], c["y_hat"])
+
+
+def test_fuse_head_is_refused_where_it_cannot_apply():
+    from flashgmm_amd.latent_codecs import CheckerboardLatentCodec, GaussianMixtureConditionalLatentCodec
+
+    with pytest.raises(ValueError):
+        CheckerboardLatentCodec(latent_codec={"y": GaussianMixtureConditionalLatentCodec(K=4)}, entropy_parameters=torch.nn.Conv2d(8, 96, 3), fuse_head=True)
+    codec = CheckerboardLatentCodec(latent_codec={"y": GaussianMixtureConditionalLatentCodec(K=4, quantizer="weighted_mean_ste")},
+                                    entropy_parameters=torch.nn.Conv2d(64, 12 * 8, 1).cuda(), context_prediction=torch.nn.Conv2d(8, 48, 1).cuda(), fuse_head=True)
+    with pytest.raises(RuntimeError):
+        codec.compress(torch.zeros((1, 8, 4, 8), device="cuda"), torch.zeros((1, 16, 4, 8), device="cuda"))
