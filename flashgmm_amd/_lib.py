@@ -17,6 +17,7 @@ FGMM_OK = 0
 FGMM_HOST, FGMM_DEVICE = 0, 1
 FGMM_K = 4
 FGMM_F32, FGMM_F16 = 0, 1
+FGMM_HEAD_BF16X6 = 1  # fgmm_head_create_ex flags
 FGMM_PARAMS_LOGITS = 1  # fgmm_params.flags: the weights planes hold logits, softmax over K runs in the kernels
 MODES = {"polya": 0, "as": 1, "logistic": 2}  # numbering of the reference CODE (rans_interface.cpp:224-232)
 
@@ -94,6 +95,7 @@ SIGNATURES = {
     "fgmm_gmc_compress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
     "fgmm_gmc_decompress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
     "fgmm_head_create": (_i, [_p, _p, _p, _p, _i, _i, _i, _pp]),
+    "fgmm_head_create_ex": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _pp]),
     "fgmm_head_destroy": (None, [_p]),
     "fgmm_head_params_batch": (_i, [_p, _p, _p, _p, _p, _p, _i]),
     "fgmm_gmc_compress_head_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _p, _i, _p, _i, _i]),

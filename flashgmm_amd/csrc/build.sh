@@ -14,7 +14,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=${OUT:-../libflashgmm_amd.so}
 COMMON="-O3 -fPIC -std=c++17 -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math"
 $HIPCC $COMMON --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc -Xarch_device -fno-slp-vectorize \
-    -march=x86-64-v3 -shared -o $OUT fgmm_kernels.hip fgmm_tab.hip fgmm_head.hip fgmm_device_hip.cpp fgmm_rans.cpp fgmm_capi.cpp fgmm_encode.cpp \
+    -march=x86-64-v3 -shared -o $OUT fgmm_kernels.hip fgmm_tab.hip fgmm_head.hip fgmm_head16.hip fgmm_device_hip.cpp fgmm_rans.cpp fgmm_capi.cpp fgmm_encode.cpp \
     fgmm_decode.cpp fgmm_decode_gpu.cpp -lpthread "$@"
 echo "built $(realpath $OUT)"
 # The compiled Python boundary over the C ABI (fgmm_pybind.cpp -> flashgmm_amd/_native.*.so): plain C++ against the Python and pybind11

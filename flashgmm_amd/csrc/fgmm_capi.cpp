@@ -528,9 +528,13 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
 
 // ---- the parameter head ---------------------------------------------------------------------------------------
 int fgmm_head_create(fgmm_ctx *ctx, void *stream, const float *weight, const float *bias, int M, int K, int c_in, fgmm_head **out) {
+  return fgmm_head_create_ex(ctx, stream, weight, bias, M, K, c_in, 0, out);
+}
+
+int fgmm_head_create_ex(fgmm_ctx *ctx, void *stream, const float *weight, const float *bias, int M, int K, int c_in, int flags, fgmm_head **out) {
   if (!out) return fail(FGMM_ERR_INVALID, "out == NULL");
   *out = nullptr;
-  if (!ctx || !weight || M <= 0 || c_in <= 0 || M > (1 << 20) || c_in > (1 << 20)) return fail(FGMM_ERR_INVALID, "bad argument");
+  if (!ctx || !weight || M <= 0 || c_in <= 0 || M > (1 << 20) || c_in > (1 << 20) || (flags & ~FGMM_HEAD_BF16X6)) return fail(FGMM_ERR_INVALID, "bad argument");
   if (K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", K);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
@@ -541,14 +545,18 @@ int fgmm_head_create(fgmm_ctx *ctx, void *stream, const float *weight, const flo
   h->w.M = M, h->w.c_in = c_in;
   h->w.n_cg = (M + kHeadCG - 1) / kHeadCG, h->w.n_kt = (c_in + kHeadBK - 1) / kHeadBK;
   const size_t floats = head_packed_floats(M, c_in), bias_floats = (size_t)h->w.n_cg * 12 * kHeadCG;
+  const bool b16 = (flags & FGMM_HEAD_BF16X6) != 0;
+  const size_t bytes = b16 ? head16_packed_bytes(M, c_in) : floats * sizeof(float);
   void *p = nullptr;
-  if (dev::malloc_device(&p, floats * sizeof(float)) != 0) {
+  if (dev::malloc_device(&p, bytes) != 0) {
     delete h;
-    return fail(FGMM_ERR_NOMEM, "%zu bytes of device memory for the packed weights", floats * sizeof(float));
+    return fail(FGMM_ERR_NOMEM, "%zu bytes of device memory for the packed weights", bytes);
   }
   h->packed = static_cast<float *>(p);
-  h->w.wp = h->packed, h->w.bp = h->packed + (floats - bias_floats);
-  int e = launch_head_pack(weight, bias, M, c_in, h->packed, h->packed + (floats - bias_floats), stream);
+  h->w.arith = b16 ? FGMM_HEAD_BF16X6 : 0;
+  h->w.wp = p;
+  h->w.bp = b16 ? reinterpret_cast<const float *>(static_cast<const char *>(p) + (bytes - bias_floats * sizeof(float))) : h->packed + (floats - bias_floats);
+  int e = b16 ? launch_head16_pack(weight, bias, M, c_in, p, stream) : launch_head_pack(weight, bias, M, c_in, h->packed, h->packed + (floats - bias_floats), stream);
   if (!e) e = dev::stream_sync((dev::Stream)stream); // (the caller may free or overwrite its weights on return)
   if (e) {
     (void)dev::free_device(p);
@@ -588,7 +596,8 @@ int fgmm_head_params_batch(fgmm_ctx *ctx, void *stream, const fgmm_head *head, c
     vec = vec && (hw[i] & 3) == 0 && (reinterpret_cast<uintptr_t>(x[i]) & 15) == 0;
   }
   DEV_TRY(dev::copy_async(ctx->d_ws, hd, bytes, dev::kH2D, (dev::Stream)stream));
-  LAUNCH_TRY(launch_head_params(reinterpret_cast<const HeadDesc *>(ctx->d_ws), head->w, count, hw_max, vec, stream));
+  if (head->w.arith == FGMM_HEAD_BF16X6) LAUNCH_TRY(launch_head16_params(reinterpret_cast<const HeadDesc *>(ctx->d_ws), head->w, count, hw_max, stream));
+  else LAUNCH_TRY(launch_head_params(reinterpret_cast<const HeadDesc *>(ctx->d_ws), head->w, count, hw_max, vec, stream));
   DEV_TRY(dev::stream_sync((dev::Stream)stream)); // (the descriptors' staging area belongs to the next call)
   return FGMM_OK;
 }

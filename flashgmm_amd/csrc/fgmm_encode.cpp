@@ -187,7 +187,8 @@ struct EncodeCall {
     if (head) { // the fused head: matrix product + table entries in one kernel, no parameter planes
       bool vec = true;
       for (auto &it : items) vec = vec && (it.hw & 3) == 0 && aligned16(it.x);
-      LAUNCH_TRY(launch_head_symtab(dd, *head, count, M_max, hw_max, mode, items[0].clamp != 0, vec, stream));
+      if (head->arith == FGMM_HEAD_BF16X6) LAUNCH_TRY(launch_head16_symtab(dd, *head, count, M_max, hw_max, mode, items[0].clamp != 0, stream));
+      else LAUNCH_TRY(launch_head_symtab(dd, *head, count, M_max, hw_max, mode, items[0].clamp != 0, vec, stream));
       return ctx->prof_end(0, stream);
     }
     const int vec = vec4 ? (ctx->opt.enc_vec == 1 ? 1 : ctx->opt.enc_vec == 2 ? 2 : vec8 ? 8 : 4) : 1; // option "enc_vec" = 1, 2, 4: A/B narrower loads

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(const EncDesc *__restrict_
   }
   // ---- K loop
   const int n_kt = hw_.n_kt, c_in = hw_.c_in;
-  const float *wp = hw_.wp + (int64_t)cg * n_kt * (kRows * kBK);
+  const float *wp = static_cast<const float *>(hw_.wp) + (int64_t)cg * n_kt * (kRows * kBK);
   // Staging, branch-free (the K loop is ONE basic block, so that the instruction order below is the order issued): a load that would
   // fall outside the features (input channels past c_in in the last tile, positions past hw in the last position tile) reads a valid
   // address instead and is replaced by zero; the packed weights are zero there as well.

@@ -86,10 +86,11 @@ struct DecDesc {
 // ---- the parameter head's last layer on the matrix cores (fgmm_head.hip) ----------------------------------------
 constexpr int kHeadCG = 16; // latent channels per block: the packed weights are laid out in groups of this many
 constexpr int kHeadBK = 32; // input channels per LDS tile
-struct HeadW {              // the PACKED weights of a head (device): see head_pack_kernel
-  const float *wp;          // [n_cg][n_kt][12 * kHeadCG][kHeadBK]
+struct HeadW {              // the PACKED weights of a head (device): see head_pack_kernel / head16_pack_kernel
+  const void *wp;           // exact form: float [n_cg][n_kt][12 * kHeadCG][kHeadBK]; bf16x6: bf16 [n_cg][n_kt][3][12 * kHeadCG][kHeadBK]
   const float *bp;          // [n_cg][12 * kHeadCG]
   int32_t M, c_in, n_cg, n_kt;
+  int32_t arith, pad_;      // 0: binary32 on v_mfma_f32_32x32x2_f32 (fgmm_head.hip); FGMM_HEAD_BF16X6: fgmm_head16.hip
 };
 struct HeadDesc { // one item of the un-fused form
   const float *x; // device [c_in, hw]
@@ -101,6 +102,11 @@ static inline size_t head_packed_floats(int M, int c_in) {
   return n_cg * n_kt * 12 * kHeadCG * kHeadBK + n_cg * 12 * kHeadCG;
 }
 int launch_head_pack(const float *w, const float *bias_or_null, int M, int c_in, float *wp, float *bp, void *stream);
+// the bf16x6 form (fgmm_head16.hip): `packed` holds the three bf16 parts of the weights, then the bias
+size_t head16_packed_bytes(int M, int c_in);
+int launch_head16_pack(const float *w, const float *bias_or_null, int M, int c_in, void *packed, void *stream);
+int launch_head16_params(const HeadDesc *d_descs, const HeadW &w, int count, int64_t hw_max, void *stream);
+int launch_head16_symtab(const EncDesc *d_descs, const HeadW &w, int count, int M_max, int64_t hw_max, int mode, bool clamped, void *stream);
 int launch_head_params(const HeadDesc *d_descs, const HeadW &w, int count, int64_t hw_max, bool vec, void *stream); // vec: every hw % 4 == 0, x 16-byte aligned
 int launch_head_symtab(const EncDesc *d_descs, const HeadW &w, int count, int M_max, int64_t hw_max, int mode, bool clamped, bool vec, void *stream);
 

@@ -158,7 +158,13 @@ class ParameterHead:
     Encoder and decoder then derive identical parameters from identical weights whatever BLAS / MIOpen version either side
     runs - the reference relies on that silently.  The weights are packed once, here."""
 
-    def __init__(self, conv, K: int = 4):
+    def __init__(self, conv, K: int = 4, arithmetic: str = "f32"):
+        # arithmetic: "f32" (the default: binary32 products and sums on v_mfma_f32_32x32x2_f32, bit for bit an fmaf chain) or "bf16x6"
+        # (three bfloat16 parts per operand, six part products on the BF16 matrix cores, binary32 accuracy at a third of the cycles;
+        # deterministic on MI355X, not restatable on a CPU: include/flashgmm_amd.h FGMM_HEAD_BF16X6)
+        if arithmetic not in ("f32", "bf16x6"):
+            raise ValueError(f"arithmetic {arithmetic!r}")
+        self.arithmetic = arithmetic
         w = conv.weight.detach()
         if w.dim() != 4 or w.shape[2:] != (1, 1) or w.shape[0] % (3 * K) or not w.is_cuda:
             raise RuntimeError("expected the weights of a 1x1 nn.Conv2d(c_in, 3*K*M) on a HIP device")
@@ -169,8 +175,8 @@ class ParameterHead:
         b = None if conv.bias is None else conv.bias.detach().to(torch.float32).contiguous()
         out = C.c_void_p()
         stream = torch.cuda.current_stream(w.device).cuda_stream
-        _lib.check(_lib.lib().fgmm_head_create(_lib.ctx(self._dev), stream, w2.data_ptr(), b.data_ptr() if b is not None else None, self.M, self.K,
-                                               self.c_in, C.byref(out)), "ParameterHead")
+        _lib.check(_lib.lib().fgmm_head_create_ex(_lib.ctx(self._dev), stream, w2.data_ptr(), b.data_ptr() if b is not None else None, self.M, self.K,
+                                                  self.c_in, _lib.FGMM_HEAD_BF16X6 if arithmetic == "bf16x6" else 0, C.byref(out)), "ParameterHead")
         self._h = out
 
     def __del__(self):

@@ -290,6 +290,14 @@ typedef struct fgmm_head fgmm_head; /* a head's weights, packed for the kernel, 
 /* weight: device float32 [3*K*M, c_in] row-major (Conv2d.weight [3*K*M, c_in, 1, 1]); bias: device float32 [3*K*M] or NULL.
  * The weights are copied (packed) before the call returns. */
 int fgmm_head_create(fgmm_ctx *ctx, void *stream, const float *weight, const float *bias, int M, int K, int c_in, fgmm_head **out);
+/* ... with flags.  FGMM_HEAD_BF16X6: the same layer on the BF16 matrix cores with binary32 accuracy - weights and features split into
+ * three bfloat16 parts each, six part products per product, accumulated in binary32 (fgmm_head16.hip): within ~2e-7 * sum |w x| of the
+ * exact sum at a third of the matrix-pipe cycles.  Deterministic on gfx950 (the same inputs give the same parameters on every launch,
+ * fused or not), but NOT the fmaf chain of the default form and not restatable bit for bit on a CPU: encoder and decoder must both use
+ * it, on MI355X. */
+#define FGMM_HEAD_BF16X6 1
+int fgmm_head_create_ex(fgmm_ctx *ctx, void *stream, const float *weight, const float *bias, int M, int K, int c_in, int flags,
+                        fgmm_head **out);
 void fgmm_head_destroy(fgmm_head *head);
 /* The parameters as tensors, for the decoder (and for anyone who wants them): item i reads x[i] = device float32 [c_in, hw[i]] and
  * writes out[i] = device float32 [3*K*M, hw[i]] - scales | means | LOGITS, each [K*M, hw] with channel k*M + c: three fgmm_params

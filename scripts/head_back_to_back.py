@@ -12,7 +12,7 @@ from flashgmm_amd import GaussianMixtureConditional, ParameterHead, _lib  # noqa
 from tests.synth import make_head  # noqa: E402
 
 conv, x, y = make_head(5, 192, 640, 32, 24, 48)
-head = ParameterHead(conv)
+head = ParameterHead(conv, arithmetic=os.environ.get("HEAD_ARITH", "f32"))
 gmc = GaussianMixtureConditional(K=4, mode="polya")
 for _ in range(3):
     head.params(x)

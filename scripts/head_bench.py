@@ -23,7 +23,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 c_in = int(sys.argv[3]) if len(sys.argv) > 3 else 640
 N, M, h, w = 2 * images, 192, 32, 24
 conv, x, y = make_head(5, M, c_in, h, w, N)
-head = ParameterHead(conv)
+arith = os.environ.get("HEAD_ARITH", "f32")  # or bf16x6 (FGMM_HEAD_BF16X6: fgmm_head16.hip)
+head = ParameterHead(conv, arithmetic=arith)
 gmc = GaussianMixtureConditional(K=4, mode="polya")
 _lib.set_profiling(0, True)
 flop = 2.0 * 12 * M * c_in * N * h * w
@@ -44,7 +45,7 @@ def torch_params():
         return torch.nn.functional.conv2d(x, conv.weight, conv.bias).chunk(3, 1)
 
 
-out = {"workload": f"{images} Kodak-sized images = {N} halves [1,{M},{h},{w}], head Conv2d({c_in}, {12 * M}, 1)", "gemm_gflop": round(flop / 1e9, 1)}
+out = {"arithmetic": arith, "workload": f"{images} Kodak-sized images = {N} halves [1,{M},{h},{w}], head Conv2d({c_in}, {12 * M}, 1)", "gemm_gflop": round(flop / 1e9, 1)}
 for name, prm in (("torch", torch_params), ("unfused", lambda: head.params(x))):
     for _ in range(3):
         p = prm()

@@ -573,6 +573,10 @@ int launch_softmax_probe(const float *, float *, int64_t, void *) { return kErrU
 // the parameter head (fgmm_head.hip) is a kernel in front of the SAME host pipeline (fgmm_encode.cpp takes its table from it instead of
 // symtab_kernel's): not restated here - its arithmetic is pinned on the GPU against oracle/fgmm_oracle.c fgo_head_params
 int launch_head_pack(const float *, const float *, int, int, float *, float *, void *) { return kErrUnsupported; }
+size_t head16_packed_bytes(int, int) { return 16; }
+int launch_head16_pack(const float *, const float *, int, int, void *, void *) { return kErrUnsupported; }
+int launch_head16_params(const HeadDesc *, const HeadW &, int, int64_t, void *) { return kErrUnsupported; }
+int launch_head16_symtab(const EncDesc *, const HeadW &, int, int, int64_t, int, bool, void *) { return kErrUnsupported; }
 int launch_head_params(const HeadDesc *, const HeadW &, int, int64_t, bool, void *) { return kErrUnsupported; }
 int launch_head_symtab(const EncDesc *, const HeadW &, int, int, int64_t, int, bool, bool, void *) { return kErrUnsupported; }
 int launch_ckbd(const void *, void *, int64_t, int64_t, int64_t, int, int, bool, void *) { return kErrUnsupported; }

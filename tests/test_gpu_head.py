@@ -237,3 +237,30 @@ def test_fuse_head_is_refused_where_it_cannot_apply():
                                     entropy_parameters=torch.nn.Conv2d(64, 12 * 8, 1).cuda(), context_prediction=torch.nn.Conv2d(8, 48, 1).cuda(), fuse_head=True)
     with pytest.raises(RuntimeError):
         codec.compress(torch.zeros((1, 8, 4, 8), device="cuda"), torch.zeros((1, 16, 4, 8), device="cuda"))
+
+
+@pytest.mark.parametrize("M,c_in,h,w", [(192, 640, 32, 24), (24, 40, 5, 7), (16, 64, 16, 16)])
+def test_bf16x6_head_is_accurate_deterministic_and_self_consistent(M, c_in, h, w):
+    """ParameterHead(arithmetic="bf16x6") - FGMM_HEAD_BF16X6, fgmm_head16.hip: three bfloat16 parts per operand, six part products on the
+    BF16 matrix cores.  Within 1e-5 of sum |w x| + |b| of the exact result (in fact ~1e-6: asserted at 2e-6), the same bits on every
+    launch, fused bytes == un-fused bytes fed its own planes, decode(encode(y)) == round(y)."""
+    conv, x, y = make_head(51, M, c_in, h, w, N=3, dead=2)
+    head = ParameterHead(conv, arithmetic="bf16x6")
+    got = torch.cat(head.params(x), 1)
+    with torch.no_grad():
+        xd, wd = x.double(), conv.weight.double()
+        want = torch.nn.functional.conv2d(xd, wd, conv.bias.double())
+        scale = torch.nn.functional.conv2d(xd.abs(), wd.abs(), conv.bias.double().abs())
+    rel = ((got.double() - want).abs() / scale).max().item()
+    assert rel < 2e-6, rel
+    assert torch.equal(torch.cat(head.params(x), 1), got)  # deterministic
+    exact = torch.cat(ParameterHead(conv).params(x), 1)
+    assert ((exact.double() - want).abs() / scale).max().item() < 2e-6 and not torch.equal(exact, got)  # (another arithmetic: other last bits)
+    for mode in MODES:
+        gmc = GaussianMixtureConditional(K=4, mode=mode)
+        fused = gmc.compress_head_batch(y, x, head)
+        s, m, lg = head.params(x)
+        plain = gmc.compress_batch(y, s, m, lg, weights_are_logits=True)
+        assert [bytes(b) for b in fused.strings] == [bytes(b) for b in plain.strings] and fused.abs_maxes == plain.abs_maxes
+        out = gmc.decompress_batch(fused.strings, fused.abs_maxes, fused.zero_bitmaps, s, m, lg, weights_are_logits=True, stacked_output=True)
+        assert torch.equal(out, fused.y_q) and torch.equal(fused.y_q[:, 0], torch.round(y))
