@@ -464,7 +464,37 @@ struct fgmm_head {
   int device = 0;
   float *packed = nullptr; // [wp | bp]
   fgmm::HeadW w{};
+  // bf16x6: the features' split copy of the call in progress (grown on demand; calls are serialised by the context's lock)
+  mutable void *xs = nullptr;
+  mutable size_t xs_cap = 0;
 };
+
+// FGMM_HEAD_BF16X6: split the features of a call's items into their three bf16 parts (fgmm_head16.hip) -> the pointers the kernels'
+// descriptors carry as `x`.  One launch when the items are evenly spaced and of one size (stacked tensors), one per item otherwise.
+static int head16_split(const fgmm_head *head, void *stream, const float *const *x, const int64_t *hw, int count, std::vector<const float *> &out) {
+  out.assign((size_t)count, nullptr);
+  std::vector<size_t> at((size_t)count + 1, 0);
+  for (int i = 0; i < count; ++i) at[(size_t)i + 1] = at[(size_t)i] + head16_split_elems(head->w.c_in, hw[i]);
+  const size_t bytes = at[(size_t)count] * sizeof(uint16_t);
+  if (bytes > head->xs_cap) {
+    if (head->xs) (void)dev::free_device(head->xs);
+    head->xs = nullptr, head->xs_cap = 0;
+    void *p = nullptr;
+    if (dev::malloc_device(&p, bytes + 256) != 0) return fail(FGMM_ERR_NOMEM, "%zu bytes of device memory for the split features", bytes);
+    head->xs = p, head->xs_cap = bytes;
+  }
+  uint16_t *base = static_cast<uint16_t *>(head->xs);
+  for (int i = 0; i < count; ++i) out[(size_t)i] = reinterpret_cast<const float *>(base + at[(size_t)i]);
+  bool even = count > 0;
+  for (int i = 1; i < count && even; ++i) even = hw[i] == hw[0] && x[i] - x[i - 1] == x[1] - x[0];
+  if (even && hw[0] > 0) {
+    LAUNCH_TRY(launch_head16_split(x[0], base, hw[0], head->w.c_in, count, count > 1 ? (int64_t)(x[1] - x[0]) : 0, (int64_t)at[1], stream));
+  } else {
+    for (int i = 0; i < count; ++i)
+      if (hw[i] > 0) LAUNCH_TRY(launch_head16_split(x[i], base + at[(size_t)i], hw[i], head->w.c_in, 1, 0, 0, stream));
+  }
+  return FGMM_OK;
+}
 
 static int compress_batch_impl(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales, const fgmm_head *head,
                                const float *const *x) {
@@ -474,6 +504,16 @@ static int compress_batch_impl(fgmm_ctx *ctx, void *stream, fgmm_item *items, in
   DeviceGuard g(ctx->device);
   if (!g.ok) return fail(FGMM_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
   std::vector<EncItem> v((size_t)count);
+  std::vector<const float *> xsplit;
+  if (head && head->w.arith == FGMM_HEAD_BF16X6 && count) { // the features' three bf16 parts, once for all of the call's blocks
+    std::vector<int64_t> hws((size_t)count);
+    for (int i = 0; i < count; ++i) {
+      if (items[i].hw < 0 || (items[i].M * items[i].hw && !x[i])) return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
+      hws[(size_t)i] = (int64_t)items[i].M * items[i].hw ? items[i].hw : 0;
+    }
+    if (int rc = head16_split(head, stream, x, hws.data(), count, xsplit)) return rc;
+    x = xsplit.data();
+  }
   for (int i = 0; i < count; ++i) {
     const fgmm_item &s = items[i];
     if (s.K != FGMM_K) return fail(FGMM_ERR_INVALID, "K = %d: the reference binds K = 4 only", s.K);
@@ -572,6 +612,7 @@ void fgmm_head_destroy(fgmm_head *h) {
   {
     DeviceGuard g(h->device);
     (void)dev::free_device(h->packed);
+    if (h->xs) (void)dev::free_device(h->xs);
   }
   delete h;
 }
@@ -589,8 +630,14 @@ int fgmm_head_params_batch(fgmm_ctx *ctx, void *stream, const fgmm_head *head, c
   HeadDesc *hd = reinterpret_cast<HeadDesc *>(ctx->h_ws);
   int64_t hw_max = 0;
   bool vec = true;
-  for (int i = 0; i < count; ++i) {
+  for (int i = 0; i < count; ++i)
     if (hw[i] < 0 || (hw[i] && (!x[i] || !out[i]))) return fail(FGMM_ERR_INVALID, "item %d: null tensor / negative size", i);
+  std::vector<const float *> xsplit;
+  if (head->w.arith == FGMM_HEAD_BF16X6) {
+    if ((rc = head16_split(head, stream, x, hw, count, xsplit))) return rc;
+    x = xsplit.data();
+  }
+  for (int i = 0; i < count; ++i) {
     hd[i] = HeadDesc{x[i], out[i], hw[i]};
     hw_max = std::max(hw_max, hw[i]);
     vec = vec && (hw[i] & 3) == 0 && (reinterpret_cast<uintptr_t>(x[i]) & 15) == 0;

@@ -13,9 +13,12 @@
 //
 // Tiling: 256 threads = 4 waves, one block per CU (a wave holds 192 accumulator registers): block = 16 latent channels (192 rows of W) x
 // 256 positions, wave = 192 rows x 64 positions = 6 x 2 accumulator tiles; K tiles of 32 input channels through LDS as bf16 parts:
-// W tile 3 x 192 x 32 from a PRE-SPLIT packed copy (36 KB contiguous per block and tile), x tile split in the kernel on its way from
-// global memory to LDS (stored position-major so that a lane's eight k values are one 16-byte read).  Rows of 40 bf16 (80 bytes): the
-// 16-byte reads and writes of 16 consecutive lanes fall on 64 different banks.  Epilogue and block placement as in fgmm_head.hip.
+// W tile 3 x 192 x 32 from a PRE-SPLIT packed copy (36 KB contiguous per block and tile); the x tile from a pre-split copy of the
+// features as well - head16_split_kernel writes it once per call, [K tile][part][position][32 channels], 1.5 x the features' bytes: the
+// twelve channel-group blocks of a position tile would otherwise each split the same tile (the first cut did: 0.87 ms per Kodak batch,
+// a third of it that arithmetic) - so that staging is sixteen-byte copies only and a lane's eight k values are one 16-byte read.  Rows
+// of 40 bf16 (80 bytes) in LDS: the 16-byte reads and writes of 16 consecutive lanes fall on 64 different banks.  Epilogue and block
+// placement as in fgmm_head.hip.
 #include "fgmm_dev.h"
 
 namespace fgmm {
@@ -70,6 +73,31 @@ __global__ __launch_bounds__(256) void head16_pack_kernel(const float *__restric
   }
 }
 
+// features [c_in, hw] float32 -> three bf16 parts, [K tile][part][position][32 input channels] (channels past c_in: zero).  A thread =
+// (position, group of 8 channels): eight strided loads (64-byte segments per wave), three 16-byte stores (contiguous per wave).
+__global__ __launch_bounds__(256) void head16_split_kernel(const float *__restrict__ x0, uint16_t *__restrict__ xs0, int64_t hw, int c_in, int n_kt, int64_t x_stride,
+                                                           int64_t xs_stride) {
+  const float *x = x0 + (int64_t)blockIdx.z * x_stride;
+  uint16_t *xs = xs0 + (int64_t)blockIdx.z * xs_stride;
+  const int kt = blockIdx.y, g8 = threadIdx.x & 3;
+  const int64_t pos = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (pos >= hw) return;
+  uint16_t parts[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kin = kt * kBK + 8 * g8 + j;
+    const Split3 s = split3(kin < c_in ? ldg<float>(x + (int64_t)kin * hw + pos) : 0.0f);
+    parts[0][j] = s.p[0], parts[1][j] = s.p[1], parts[2][j] = s.p[2];
+  }
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+    u4_t v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (uint32_t)parts[part][2 * e] | ((uint32_t)parts[part][2 * e + 1] << 16);
+    stg<u4_t>(xs + (((int64_t)kt * 3 + part) * hw + pos) * kBK + 8 * g8, v);
+  }
+}
+
 template <int MODE, bool CLAMPED, bool FUSED>
 __global__ __launch_bounds__(256, 1) void head16_kernel(const EncDesc *__restrict__ edescs, const HeadDesc *__restrict__ hdescs, HeadW hw_, int pt_max,
                                                          int cg_max, int total) {
@@ -82,13 +110,13 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(const EncDesc *__restric
   const int item = L / (pt_max * cg_max);
   const int rem = L - item * (pt_max * cg_max);
   const int pt = rem / cg_max, cg = rem - pt * cg_max;
-  const float *x;
+  const uint16_t *xs; // the item's features, split by head16_split_kernel (the descriptor's x points at that copy)
   int64_t hw;
   int M;
   if constexpr (FUSED) {
-    x = edescs[item].x, hw = edescs[item].hw, M = edescs[item].M;
+    xs = reinterpret_cast<const uint16_t *>(edescs[item].x), hw = edescs[item].hw, M = edescs[item].M;
   } else {
-    x = hdescs[item].x, hw = hdescs[item].hw, M = hw_.M;
+    xs = reinterpret_cast<const uint16_t *>(hdescs[item].x), hw = hdescs[item].hw, M = hw_.M;
   }
   const int64_t P0 = (int64_t)pt * kPB;
   if (P0 >= hw || cg * kCG >= M) return;
@@ -148,53 +176,42 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(const EncDesc *__restric
         acc[tl][0][r] = b, acc[tl][1][r] = b;
       }
   }
-  const int n_kt = hw_.n_kt, c_in = hw_.c_in;
+  const int n_kt = hw_.n_kt;
   const uint16_t *wp = static_cast<const uint16_t *>(hw_.wp) + (int64_t)cg * n_kt * 3 * (kRows * kBK);
-  // ---- staging: W parts as they are (nine 16-byte loads per thread and tile); x: thread = position, 32 values of its column
-  u4_t ra[9];
-  float rx[32];
-  const int64_t px = P0 + tid;
-  const bool p_ok = px < hw;
+  // ---- staging: sixteen-byte copies only - nine chunks of the W parts, twelve of the x parts per thread and tile
+  u4_t ra[9], rb[12];
+  unsigned rb_ok = 0; // bit j: chunk j lies inside the features (applied when the tile is written: a select right after the load waits for it)
   auto load_tile = [&](int kt) {
+    rb_ok = 0;
     const u4_t *src = reinterpret_cast<const u4_t *>(wp + (int64_t)kt * 3 * (kRows * kBK));
 #pragma unroll
     for (int j = 0; j < 9; ++j) ra[j] = src[tid + 256 * j];
-    const float *g = x + (p_ok ? px : 0);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      const int kin = kt * kBK + k;
-      rx[k] = ldg<float>(g + (int64_t)(kin < c_in ? kin : c_in - 1) * hw); // (masked when the tile is written: store_tile)
+    for (int j = 0; j < 12; ++j) {
+      const int f = tid + 256 * j, part = f >> 10, r = f & 1023; // 1024 chunks per part: 256 positions x 4 groups of 8 channels
+      const int64_t pos = P0 + (r >> 2);
+      const uint16_t *g = xs + (((int64_t)kt * 3 + part) * hw + (pos < hw ? pos : 0)) * kBK + 8 * (r & 3);
+      rb[j] = ldg<u4_t>(g);
+      rb_ok |= (pos < hw ? 1u : 0u) << j;
     }
   };
-  auto store_tile = [&](int kt) {
+  auto store_tile = [&]() {
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
       const int f = tid + 256 * j, part = f / 768, r768 = f - part * 768;
       *reinterpret_cast<u4_t *>(&sA[(part * kRows + (r768 >> 2)) * kPitch + (r768 & 3) * 8]) = ra[j];
     }
 #pragma unroll
-    for (int g8 = 0; g8 < 4; ++g8) {
-      uint16_t parts[3][8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = 8 * g8 + j;
-        const Split3 s = split3((p_ok && kt * kBK + k < c_in) ? rx[k] : 0.0f);
-        parts[0][j] = s.p[0], parts[1][j] = s.p[1], parts[2][j] = s.p[2];
-      }
-#pragma unroll
-      for (int part = 0; part < 3; ++part) {
-        u4_t v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (uint32_t)parts[part][2 * e] | ((uint32_t)parts[part][2 * e + 1] << 16);
-        *reinterpret_cast<u4_t *>(&sB[(part * kPB + tid) * kPitch + 8 * g8]) = v;
-      }
+    for (int j = 0; j < 12; ++j) {
+      const int f = tid + 256 * j, part = f >> 10, r = f & 1023;
+      *reinterpret_cast<u4_t *>(&sB[(part * kPB + (r >> 2)) * kPitch + 8 * (r & 3)]) = (rb_ok >> j) & 1u ? rb[j] : (u4_t){0u, 0u, 0u, 0u};
     }
   };
   // the fragments of one step of 16 input channels: a lane's eight k values of a row (W) or a position (x) are one 16-byte read
   auto frag = [&](const uint16_t *base) { return __builtin_bit_cast(bf8_t, *reinterpret_cast<const u4_t *>(base)); };
 #define FGMM_FENCE() __builtin_amdgcn_sched_barrier(0)
   load_tile(0);
-  store_tile(0);
+  store_tile();
   __syncthreads();
   for (int kt = 0; kt < n_kt; ++kt) {
     FGMM_FENCE();
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(const EncDesc *__restric
       FGMM_FENCE();
     }
     __syncthreads(); // every wave has read the tile
-    store_tile(kt + 1 < n_kt ? kt + 1 : kt);
+    store_tile();
     __syncthreads();
   }
 #undef FGMM_FENCE
@@ -312,6 +329,17 @@ int launch_head16_pack(const float *w, const float *bias, int M, int c_in, void 
   float *bp = reinterpret_cast<float *>(wp + (size_t)n_cg * n_kt * 3 * kRows * kBK);
   hipLaunchKernelGGL(head16_pack_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, bias, M, c_in, n_cg, n_kt,
                      wp, bp);
+  return (int)hipGetLastError();
+}
+
+size_t head16_split_elems(int c_in, int64_t hw) { return (size_t)((c_in + kBK - 1) / kBK) * 3 * (size_t)hw * kBK; }
+
+// `count` items of one size whose features (x0 + i * x_stride floats) and split copies (xs0 + i * xs_stride bf16) are evenly spaced
+int launch_head16_split(const float *x0, void *xs0, int64_t hw, int c_in, int count, int64_t x_stride, int64_t xs_stride, void *stream) {
+  if (count <= 0 || hw <= 0) return 0;
+  const int n_kt = (c_in + kBK - 1) / kBK;
+  hipLaunchKernelGGL(head16_split_kernel, dim3((unsigned)((hw + 63) / 64), (unsigned)n_kt, (unsigned)count), dim3(256), 0, (hipStream_t)stream, x0,
+                     static_cast<uint16_t *>(xs0), hw, c_in, n_kt, x_stride, xs_stride);
   return (int)hipGetLastError();
 }
 

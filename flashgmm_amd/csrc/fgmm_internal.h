@@ -105,6 +105,10 @@ int launch_head_pack(const float *w, const float *bias_or_null, int M, int c_in,
 // the bf16x6 form (fgmm_head16.hip): `packed` holds the three bf16 parts of the weights, then the bias
 size_t head16_packed_bytes(int M, int c_in);
 int launch_head16_pack(const float *w, const float *bias_or_null, int M, int c_in, void *packed, void *stream);
+// the features' split copy: head16_split_elems bf16 per item, written by launch_head16_split; the kernels' descriptors then carry THAT
+// pointer as `x`
+size_t head16_split_elems(int c_in, int64_t hw);
+int launch_head16_split(const float *x0, void *xs0, int64_t hw, int c_in, int count, int64_t x_stride, int64_t xs_stride, void *stream);
 int launch_head16_params(const HeadDesc *d_descs, const HeadW &w, int count, int64_t hw_max, void *stream);
 int launch_head16_symtab(const EncDesc *d_descs, const HeadW &w, int count, int M_max, int64_t hw_max, int mode, bool clamped, void *stream);
 int launch_head_params(const HeadDesc *d_descs, const HeadW &w, int count, int64_t hw_max, bool vec, void *stream); // vec: every hw % 4 == 0, x 16-byte aligned

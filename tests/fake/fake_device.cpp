@@ -574,6 +574,8 @@ int launch_softmax_probe(const float *, float *, int64_t, void *) { return kErrU
 // symtab_kernel's): not restated here - its arithmetic is pinned on the GPU against oracle/fgmm_oracle.c fgo_head_params
 int launch_head_pack(const float *, const float *, int, int, float *, float *, void *) { return kErrUnsupported; }
 size_t head16_packed_bytes(int, int) { return 16; }
+size_t head16_split_elems(int, int64_t) { return 0; }
+int launch_head16_split(const float *, void *, int64_t, int, int, int64_t, int64_t, void *) { return kErrUnsupported; }
 int launch_head16_pack(const float *, const float *, int, int, void *, void *) { return kErrUnsupported; }
 int launch_head16_params(const HeadDesc *, const HeadW &, int, int64_t, void *) { return kErrUnsupported; }
 int launch_head16_symtab(const EncDesc *, const HeadW &, int, int, int64_t, int, bool, void *) { return kErrUnsupported; }
