@@ -650,6 +650,8 @@ def summary_line(full: dict, detail_path=None) -> dict:
             out["elic4k"]["checkpointed"] = _pick(el["checkpointed"], "value")
     if isinstance(g("head_fused"), dict):
         out["head_fused"] = _pick(g("head_fused"), "value", "mfma_frac", "mfma_frac_back_to_back", "head_ms", "unfused_ms", "bytes_equal_unfused", "error")
+        if isinstance(g("head_fused").get("bf16x6"), dict):
+            out["head_fused"]["bf16x6"] = _pick(g("head_fused")["bf16x6"], "fused_kernel_ms", "head_params_ms_back_to_back", "bytes_equal_unfused", "error")
     rk = g("ranks") or {}
     out["ranks"] = _pick(rk, "backend", "rccl_ranks", "ms_per_step", "host_threads_per_gpu", "result_checked_ranks")
     if isinstance(rk.get("allgather_ms"), dict):
@@ -1028,6 +1030,29 @@ def head_leg(leg: Leg, device: int, reps: int = 8):
     planes = head.params(x)
     plain = gmc.compress_batch(y, *planes, weights_are_logits=True)
     out = gmc.decompress_batch(fused.strings, fused.abs_maxes, fused.zero_bitmaps, *planes, weights_are_logits=True, stacked_output=True)
+    # the OPTION: the same layer on the BF16 matrix cores with binary32 accuracy (FGMM_HEAD_BF16X6, fgmm_head16.hip) - the whole call's GPU
+    # time (the features' split + the fused kernel), its bytes against its own un-fused path, its parameters against the exact form's
+    bf = {}
+    try:
+        head16 = ParameterHead(conv, arithmetic="bf16x6")
+        t16 = []
+        for i in range(reps + 2):
+            ms, fused16 = gpu_ms(lambda: gmc.compress_head_batch(y, x, head16))
+            if i >= 2:
+                t16.append((_lib.kernel_ms(device, 0), ms))
+        p16 = head16.params(x)
+        plain16 = gmc.compress_batch(y, *p16, weights_are_logits=True)
+        warm16 = [gpu_ms(lambda: [head16.params(x) for _ in range(6)])[0] / 6 for _ in range(3)]
+        scale = torch.nn.functional.conv2d(x.abs(), conv.weight.abs(), conv.bias.abs())
+        bf = {"fused_kernel_ms": round(float(np.median([t[0] for t in t16])), 4),
+              "head_params_ms_back_to_back": round(float(np.median(warm16)), 4),
+              "equivalent_tflops_back_to_back": round(flop / float(np.median(warm16)) / 1e9, 1),
+              "bytes_equal_unfused": [bytes(b) for b in fused16.strings] == [bytes(b) for b in plain16.strings],
+              "max_error_over_sum_abs_wx_vs_exact_form": float(((torch.cat(p16, 1) - torch.cat(planes, 1)).abs() / scale).max()),
+              "note": "three bf16 parts per operand, six v_mfma_f32_32x32x16_bf16 per product, binary32 accumulation; deterministic on gfx950, not the "
+                      "fmaf chain of the default form; head_params_ms includes the split of the features (head16_split_kernel)"}
+    except Exception as e:  # pragma: no cover
+        bf = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     k = float(np.median(t_fused))
     return {"value": round(flop / k / 1e9, 1), "unit": "TFLOP/s (f32 MFMA, table epilogue included)", "mfma_frac": round(flop / k / 1e9 / 157.3, 4),
             "mfma_peak_tflops": 157.3, "head_ms": round(k, 4), "unfused_ms": round(float(np.median(t_conv) + np.median(t_sym)), 4),
@@ -1035,6 +1060,7 @@ def head_leg(leg: Leg, device: int, reps: int = 8):
             "head_params_ms_back_to_back": round(float(np.median(warm)), 4), "mfma_frac_back_to_back": round(flop / float(np.median(warm)) / 1e9 / 157.3, 4),
             "bytes_equal_unfused": [bytes(b) for b in fused.strings] == [bytes(b) for b in plain.strings],
             "decode_equals_round_y": bool(torch.equal(out, fused.y_q)),
+            "bf16x6": bf,
             "head": f"Conv2d(640, {12 * M}, 1), random weights; {N} bitstreams of [{M}, {h}, {w}]",
             "detail": "profiles/r06_head_kernel.md"}
 
