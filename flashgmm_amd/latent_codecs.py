@@ -201,7 +201,7 @@ class CheckerboardLatentCodec(nn.Module):
 
     def __init__(self, latent_codec: Optional[Dict[str, nn.Module]] = None, entropy_parameters: Optional[nn.Module] = None,
                  context_prediction: Optional[nn.Module] = None, anchor_parity: str = "even", forward_method: str = "twopass",
-                 fuse_head: bool = False, **kwargs: Any):
+                 fuse_head=False, **kwargs: Any):
         super().__init__()
         if anchor_parity not in ("even", "odd"):
             raise ValueError(f"anchor_parity {anchor_parity!r}")
@@ -209,7 +209,11 @@ class CheckerboardLatentCodec(nn.Module):
         # library (flashgmm_amd.ParameterHead: matrix cores, one fixed summation order, fused with the encode-side CDF kernel; the
         # softmax over K and the sigma clamp with it): encoder and decoder must agree on this switch like on the Phi approximation -
         # the parameters differ from torch's convolution in their last bits
+        # fuse_head: True / "f32" (the exact form) or "bf16x6" (ParameterHead's faster arithmetic: MI355X on both sides)
+        if fuse_head not in (False, True, "f32", "bf16x6"):
+            raise ValueError(f"fuse_head {fuse_head!r}")
         self.fuse_head = bool(fuse_head)
+        self._head_arith = "bf16x6" if fuse_head == "bf16x6" else "f32"
         self._head: Optional[ParameterHead] = None
         self._head_key = None
         if self.fuse_head:
@@ -244,7 +248,7 @@ class CheckerboardLatentCodec(nn.Module):
         body, last = (ep[:-1], ep[-1]) if isinstance(ep, nn.Sequential) else (nn.Identity(), ep)
         key = (last.weight.data_ptr(), last.weight._version, None if last.bias is None else (last.bias.data_ptr(), last.bias._version))
         if self._head is None or self._head_key != key:
-            self._head, self._head_key = ParameterHead(last, K=self.latent_codec["y"].K), key
+            self._head, self._head_key = ParameterHead(last, K=self.latent_codec["y"].K, arithmetic=self._head_arith), key
         return body, self._head
 
     def _ctx(self, y_hat_: Tensor, i: int) -> Tensor:

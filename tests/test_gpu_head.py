@@ -169,7 +169,7 @@ def test_head_c_abi_with_items_of_different_sizes():
         assert torch.equal(outs[i], torch.cat(head.params(xs[i]), 1))
 
 
-def _ckbd_codecs(M, seed, mode="polya"):
+def _ckbd_codecs(M, seed, mode="polya", arithmetic="f32"):
     """two CheckerboardLatentCodecs over the same networks: one with fuse_head, one whose last layer is a module that calls the head's
     un-fused kernel (the same arithmetic, parameter tensors through HBM, fuse_softmax in the GMM codec)"""
     from flashgmm_amd.latent_codecs import CheckerboardLatentCodec, GaussianMixtureConditionalLatentCodec
@@ -192,19 +192,20 @@ def _ckbd_codecs(M, seed, mode="polya"):
             return torch.cat(self.head.params(x), 1)
 
     fused = CheckerboardLatentCodec(latent_codec={"y": GaussianMixtureConditionalLatentCodec(K=4, mode=mode)}, entropy_parameters=ep,
-                                    context_prediction=ctx_net, fuse_head=True)
+                                    context_prediction=ctx_net, fuse_head=True if arithmetic == "f32" else arithmetic)
     plain = CheckerboardLatentCodec(latent_codec={"y": GaussianMixtureConditionalLatentCodec(K=4, mode=mode, fuse_softmax=True)},
-                                    entropy_parameters=torch.nn.Sequential(*ep[:-1], HeadModule(ParameterHead(ep[-1]))), context_prediction=ctx_net)
+                                    entropy_parameters=torch.nn.Sequential(*ep[:-1], HeadModule(ParameterHead(ep[-1], arithmetic=arithmetic))),
+                                    context_prediction=ctx_net)
     return fused, plain
 
 
-@pytest.mark.parametrize("mode", ["polya", "logistic"])
-def test_checkerboard_codec_with_the_fused_head(mode):
+@pytest.mark.parametrize("mode,arithmetic", [("polya", "f32"), ("logistic", "f32"), ("polya", "bf16x6")])
+def test_checkerboard_codec_with_the_fused_head(mode, arithmetic):
     """CheckerboardLatentCodec(fuse_head=True) - the mirror of compressai/latent_codecs/checkerboard.py:275-330 with the last layer of its
     entropy_parameters inside the library: the same strings, shape and y_hat as the codec that runs the head's un-fused kernel as its
     last layer, both halves in one encode call; decompress (stage by stage) gives y_hat back, image by image and stage-major"""
     M, h, w = 32, 16, 24
-    fused, plain = _ckbd_codecs(M, 3, mode)
+    fused, plain = _ckbd_codecs(M, 3, mode, arithmetic)
     rng = np.random.default_rng(9)
     with torch.no_grad():
         outs = []
