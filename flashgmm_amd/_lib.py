@@ -68,6 +68,15 @@ def _item_dtype():
 
 ITEM_DTYPE = _item_dtype()
 
+SINK_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)  # fgmm_sink.alloc(user, item, nbytes) -> address
+
+
+class fgmm_sink(C.Structure):
+    """where a batched compress call puts its bitstreams (include/flashgmm_amd.h); alloc is called on the calling thread, inside
+    the native call (ctypes takes the GIL back for a Python callback by itself)"""
+    _fields_ = [("alloc", SINK_ALLOC), ("user", C.c_void_p)]
+
+
 # every symbol include/flashgmm_amd.h declares: (restype, argtypes)
 _p, _i, _i32, _i64, _sz = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_size_t
 _pp, _psz = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
@@ -94,11 +103,13 @@ SIGNATURES = {
     "fgmm_gmc_decompress": (_i, [_p, _p, _p, _sz, _i32, _p, C.POINTER(fgmm_params), _i, _i, _i64, _i, _i, _p]),
     "fgmm_gmc_compress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
     "fgmm_gmc_decompress_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i]),
+    "fgmm_gmc_compress_batch_to": (_i, [_p, _p, C.POINTER(fgmm_item), _i, _i, _i, C.POINTER(fgmm_sink)]),
     "fgmm_head_create": (_i, [_p, _p, _p, _p, _i, _i, _i, _pp]),
     "fgmm_head_create_ex": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _pp]),
     "fgmm_head_destroy": (None, [_p]),
     "fgmm_head_params_batch": (_i, [_p, _p, _p, _p, _p, _p, _i]),
     "fgmm_gmc_compress_head_batch": (_i, [_p, _p, C.POINTER(fgmm_item), _p, _i, _p, _i, _i]),
+    "fgmm_gmc_compress_head_batch_to": (_i, [_p, _p, C.POINTER(fgmm_item), _p, _i, _p, _i, _i, C.POINTER(fgmm_sink)]),
     "fgmm_gmm_cdf_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p, _p]),
     "fgmm_softmax4_hip": (_i, [_p, _p, _p, _p, _i64]),
     "fgmm_build_symtab_hip": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),

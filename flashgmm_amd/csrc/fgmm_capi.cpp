@@ -497,8 +497,8 @@ static int head16_split(const fgmm_head *head, void *stream, const float *const 
 }
 
 static int compress_batch_impl(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales, const fgmm_head *head,
-                               const float *const *x) {
-  if (!ctx || count < 0 || (count && !items) || !mode_ok(mode)) return fail(FGMM_ERR_INVALID, "bad argument");
+                               const float *const *x, const fgmm_sink *sink = nullptr) {
+  if (!ctx || count < 0 || (count && !items) || !mode_ok(mode) || (sink && !sink->alloc)) return fail(FGMM_ERR_INVALID, "bad argument");
   if (head && (head->device != ctx->device || (count && !x))) return fail(FGMM_ERR_INVALID, "head: made for device %d, context on %d (or x == NULL)", head->device, ctx->device);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
@@ -545,10 +545,11 @@ static int compress_batch_impl(fgmm_ctx *ctx, void *stream, fgmm_item *items, in
       return fail(FGMM_ERR_INVALID, "item %d: ckpt_stride must be 0 or a power of two >= 256, the same for a whole batch", i);
     e.ckpt_stride = s.ckpt_stride;
   }
-  const int rc = encode_batch(ctx, (dev::Stream)stream, v, mode, head ? &head->w : nullptr);
+  const int rc = encode_batch(ctx, (dev::Stream)stream, v, mode, head ? &head->w : nullptr, sink);
   if (rc != FGMM_OK) // a failed call returns no buffer: what the bitstreams that had finished hold is released here, not leaked by a
     for (auto &e : v) { // binding that raises on the status
-      free(e.bytes), free(e.ckpt);
+      if (!sink) free(e.bytes); // (a sink's storage is the caller's)
+      free(e.ckpt);
       e.bytes = nullptr, e.ckpt = nullptr, e.bytes_len = 0, e.n_ckpt = 0;
     }
   for (int i = 0; i < count; ++i) {
@@ -564,6 +565,9 @@ static int compress_batch_impl(fgmm_ctx *ctx, void *stream, fgmm_item *items, in
 
 int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales) {
   return compress_batch_impl(ctx, stream, items, count, mode, clamp_scales, nullptr, nullptr);
+}
+int fgmm_gmc_compress_batch_to(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales, const fgmm_sink *sink) {
+  return compress_batch_impl(ctx, stream, items, count, mode, clamp_scales, nullptr, nullptr, sink);
 }
 
 // ---- the parameter head ---------------------------------------------------------------------------------------
@@ -653,6 +657,11 @@ int fgmm_gmc_compress_head_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, 
                                  int clamp_scales) {
   if (!head) return fail(FGMM_ERR_INVALID, "head == NULL");
   return compress_batch_impl(ctx, stream, items, count, mode, clamp_scales, head, x);
+}
+int fgmm_gmc_compress_head_batch_to(fgmm_ctx *ctx, void *stream, fgmm_item *items, const float *const *x, int count, const fgmm_head *head, int mode,
+                                    int clamp_scales, const fgmm_sink *sink) {
+  if (!head) return fail(FGMM_ERR_INVALID, "head == NULL");
+  return compress_batch_impl(ctx, stream, items, count, mode, clamp_scales, head, x, sink);
 }
 
 int fgmm_gmc_compress(fgmm_ctx *ctx, void *stream, const float *y, const fgmm_params *params, int M, int K,

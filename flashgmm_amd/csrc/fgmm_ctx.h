@@ -417,7 +417,7 @@ struct EncItem {
   int64_t job_n = 0, job_bypass = 0;
   double t_sub = 0, t_start = 0, t_end = 0, t_waited = 0, t_lastland = 0; // job timeline (the call log; trace level 2)
 };
-int encode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<EncItem> &items, int mode, const HeadW *head = nullptr);
+int encode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<EncItem> &items, int mode, const HeadW *head = nullptr, const fgmm_sink *sink = nullptr);
 
 // ---- one bitstream of a batched decode --------------------------------------------------------------------------------------
 struct DecItem {

@@ -6,6 +6,9 @@
 //   enqueue()         descriptors, kernels, the copies and their events
 //   side_info()       per bitstream: abs_max, zero bitmap, bypass count, wide symbols (host, after the kernels)
 //   submit_jobs()     jobs of one bitstream - or of `ways` bitstreams coded in turn - onto the pool
+#include <atomic>
+#include <memory>
+
 #include "fgmm_ctx.h"
 
 namespace fgmm {
@@ -36,12 +39,136 @@ int seg_wait(void *arg, int sg) {
   return ok ? FGMM_OK : FGMM_ERR_HIP;
 }
 
+// The sink's desk (include/flashgmm_amd.h: fgmm_sink).  The caller's alloc() hands out storage of a language runtime - Python `bytes`
+// objects, under the interpreter's lock - so it is called on the CALLING thread, which has nothing else to do while the encoders run:
+// an encoder whose bitstream is complete leaves (item, size) at the desk and waits for the address - a few microseconds of polling,
+// then asleep - the calling thread serves the requests in the order they come and stays awake between requests that follow each
+// other closely (the bitstreams of a call finish within tens of microseconds of each other).  Measured against the alternative, the
+// workers calling alloc() themselves: 48 threads that want the interpreter's lock at once are woken one after the other, 0.1 ms at
+// the end of a Kodak call (profiles/r06_README.md).
+struct SinkDesk {
+  explicit SinkDesk(const fgmm_sink *u, int count) : user(u), need((size_t)count, 0), ans(new Ans[(size_t)count]) {
+    inner.alloc = &SinkDesk::ask;
+    inner.user = this;
+  }
+  struct Ans {
+    std::atomic<int> ready{0};
+    void *p = nullptr;
+  };
+  const fgmm_sink *user;
+  fgmm_sink inner; // what the encoders are given
+  std::mutex m;
+  std::condition_variable cv_req, cv_ans;
+  std::vector<int> asked; // items whose bitstream is complete and waits for its storage
+  std::vector<size_t> need;
+  std::unique_ptr<Ans[]> ans;
+  std::atomic<long> n_asked{0};
+  int jobs_left = 0, sleepers = 0;
+  bool closed = false;
+
+  static double us_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  }
+  // an encoder (a host worker): where do item's nbytes go?  NULL: nowhere, the call fails
+  static void *ask(void *self, int item, size_t nbytes) {
+    SinkDesk *d = static_cast<SinkDesk *>(self);
+    {
+      std::lock_guard<std::mutex> l(d->m);
+      if (d->closed) return nullptr;
+      d->need[(size_t)item] = nbytes;
+      d->asked.push_back(item);
+      d->n_asked.fetch_add(1, std::memory_order_release);
+    }
+    d->cv_req.notify_one();
+    Ans &a = d->ans[(size_t)item];
+    const auto t0 = std::chrono::steady_clock::now();
+    do {
+      for (int k = 0; k < 32; ++k) {
+        if (a.ready.load(std::memory_order_acquire)) return a.p;
+        __builtin_ia32_pause();
+      }
+    } while (us_since(t0) < 25.0);
+    std::unique_lock<std::mutex> l(d->m);
+    ++d->sleepers;
+    d->cv_ans.wait(l, [&] { return a.ready.load(std::memory_order_acquire) != 0; });
+    --d->sleepers;
+    return a.p;
+  }
+  void job_out() { // (before the job is submitted)
+    std::lock_guard<std::mutex> l(m);
+    ++jobs_left;
+  }
+  void job_done() {
+    {
+      std::lock_guard<std::mutex> l(m);
+      --jobs_left;
+    }
+    cv_req.notify_one();
+  }
+  // the calling thread, until every job has ended
+  void serve() {
+    long served = 0;
+    std::unique_lock<std::mutex> l(m);
+    std::vector<int> take;
+    for (;;) {
+      if (asked.empty() && jobs_left > 0) {
+        bool more = false;
+        if (served > 0) { // the next request is a few microseconds away, as a rule: stay awake for it
+          l.unlock();
+          const auto t0 = std::chrono::steady_clock::now();
+          do {
+            for (int k = 0; k < 32 && !more; ++k) {
+              more = n_asked.load(std::memory_order_acquire) != served;
+              __builtin_ia32_pause();
+            }
+          } while (!more && us_since(t0) < 60.0);
+          l.lock();
+        }
+        if (!more) cv_req.wait(l, [&] { return !asked.empty() || jobs_left == 0; });
+      }
+      if (asked.empty()) {
+        if (jobs_left == 0) return;
+        continue;
+      }
+      take.clear();
+      take.swap(asked);
+      l.unlock();
+      for (int item : take) {
+        Ans &a = ans[(size_t)item];
+        a.p = user->alloc(user->user, item, need[(size_t)item]);
+        a.ready.store(1, std::memory_order_release);
+      }
+      served += (long)take.size();
+      l.lock();
+      if (sleepers) cv_ans.notify_all();
+    }
+  }
+  // nobody serves any more (the call is on its way out, perhaps early): whoever asks or has asked gets no storage
+  void close() {
+    {
+      std::lock_guard<std::mutex> l(m);
+      closed = true;
+      for (int item : asked) ans[(size_t)item].ready.store(1, std::memory_order_release); // (p stays NULL)
+      asked.clear();
+    }
+    cv_ans.notify_all();
+  }
+};
+struct DeskCloser {
+  SinkDesk *d;
+  ~DeskCloser() {
+    if (d) d->close();
+  }
+};
+
 struct EncodeCall {
   fgmm_ctx *ctx;
   dev::Stream stream;
   std::vector<EncItem> &items;
   int mode, count;
   const HeadW *head; // the parameters come out of the head's matrix product (fgmm_head.hip) instead of planes
+  const fgmm_sink *sink; // the bitstreams go into the caller's storage (include/flashgmm_amd.h: fgmm_sink)
+  std::unique_ptr<SinkDesk> desk; // ... asked for through the desk when the encoders run on the pool
   Trace tr;
   // plan
   Arena ar;
@@ -62,8 +189,11 @@ struct EncodeCall {
   std::vector<EncItem *> job_items;
   double marks[5] = {0, 0, 0, 0, 0}; // the call log: enqueued | kernels + side information here | jobs out | last table (segment) seen landed | last job done
 
-  EncodeCall(fgmm_ctx *c, dev::Stream s, std::vector<EncItem> &it, int m, const HeadW *h)
-      : ctx(c), stream(s), items(it), mode(m), count((int)it.size()), head(h), tr("encode", (int)c->opt.trace) {}
+  EncodeCall(fgmm_ctx *c, dev::Stream s, std::vector<EncItem> &it, int m, const HeadW *h, const fgmm_sink *k)
+      : ctx(c), stream(s), items(it), mode(m), count((int)it.size()), head(h), sink(k), tr("encode", (int)c->opt.trace) {
+    if (sink && count > 1) desk.reset(new SinkDesk(sink, count)); // (a one-item call codes on the calling thread: it asks the sink itself)
+  }
+  BytesTo to(const EncItem &e) const { return BytesTo{desk ? &desk->inner : sink, (int)(&e - items.data())}; }
 
   size_t table_bytes(const EncItem &it) const { return sizeof(uint32_t) * (size_t)it.M * (size_t)it.hw; }
 
@@ -368,7 +498,7 @@ struct EncodeCall {
     t.arg = arg;
     fgmm_ckpt *ck = nullptr;
     int rc = alloc_ckpt(e, e.ckpt_stride, &ck);
-    if (rc == FGMM_OK) rc = rans_encode_symtab_segs(t, e.job_syms, e.job_n, e.job_bypass, &e.bytes, &e.bytes_len, ck ? e.ckpt_stride : 0, ck);
+    if (rc == FGMM_OK) rc = rans_encode_symtab_segs(t, e.job_syms, e.job_n, e.job_bypass, &e.bytes, &e.bytes_len, ck ? e.ckpt_stride : 0, ck, to(e));
     if (rc != FGMM_OK) drop_ckpt(e);
     e.status = rc;
     e.t_end = tr.ms();
@@ -392,6 +522,7 @@ struct EncodeCall {
     uint8_t **out[kMaxEncWays];
     size_t *len[kMaxEncWays];
     fgmm_ckpt *ck[kMaxEncWays];
+    BytesTo dst[kMaxEncWays];
     const int64_t stride = first[0]->ckpt_stride; // one stride per call (checked at the boundary)
     int rc = FGMM_OK;
     for (int q = 0; q < n_in; ++q) {
@@ -403,10 +534,11 @@ struct EncodeCall {
       nb[q] = e.job_bypass;
       out[q] = &e.bytes;
       len[q] = &e.bytes_len;
+      dst[q] = to(e);
       const int rq = alloc_ckpt(e, stride, &ck[q]);
       if (rq != FGMM_OK) rc = rq;
     }
-    if (rc == FGMM_OK) rc = rans_encode_symtab_ways(n_in, packed, syms, n, nb, out, len, stride, ck);
+    if (rc == FGMM_OK) rc = rans_encode_symtab_ways(n_in, packed, syms, n, nb, out, len, stride, ck, dst);
     const double t_end = tr.ms();
     for (int q = 0; q < n_in; ++q) {
       if (rc != FGMM_OK) drop_ckpt(*first[q]);
@@ -445,7 +577,17 @@ struct EncodeCall {
       } else {
         job = [this, first, n_in] { run_ways(first, n_in); };
       }
-      if (count == 1) job(); else ctx->pool->submit(std::move(job));
+      if (count == 1) {
+        job();
+      } else if (desk) {
+        desk->job_out();
+        ctx->pool->submit([this, job = std::move(job)] {
+          job();
+          desk->job_done();
+        });
+      } else {
+        ctx->pool->submit(std::move(job));
+      }
     }
     return FGMM_OK;
   }
@@ -462,9 +604,11 @@ struct EncodeCall {
     for (auto &it : items) ctx->stat[0] += table_bytes(it);
     {
       PoolDrain drain{ctx->pool}; // on any return: wait for every job before the objects they use go away
+      DeskCloser closer{desk.get()}; // ... which none of them does at a desk nobody serves any more (destroyed first)
       if ((rc = submit_jobs())) return rc;
       tr.mark(segmented ? "jobs out" : "all tables landed, jobs out");
       marks[2] = tr.ms();
+      if (desk) desk->serve();
     }
     // Segmented tables: an encoder waits only for the segments it enters - a bitstream without a coded symbol enters none - so the last
     // copy group may still be in flight here, and the next call writes the pinned workspace it lands in (found on the fake device under
@@ -492,9 +636,9 @@ struct EncodeCall {
 
 } // namespace
 
-int encode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<EncItem> &items, int mode, const HeadW *head) {
+int encode_batch(fgmm_ctx *ctx, dev::Stream stream, std::vector<EncItem> &items, int mode, const HeadW *head, const fgmm_sink *sink) {
   if (items.empty()) return FGMM_OK;
-  EncodeCall call(ctx, stream, items, mode, head);
+  EncodeCall call(ctx, stream, items, mode, head, sink);
   const int rc = call.run();
   if (rc != FGMM_OK) (void)dev::stream_sync(stream); // (an early return: nothing of this call may still be writing the workspace the next one reuses)
   return rc;

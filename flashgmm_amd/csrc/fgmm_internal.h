@@ -248,13 +248,21 @@ int launch_fastmath_selftest(int which, unsigned long long n, unsigned long long
 int launch_saturation_selftest(int mode, unsigned long long *n_bad, void *stream);
 
 // ---- host rANS (fgmm_rans.cpp), integer only --------------------------------------------------------------
+// Where a finished bitstream goes.  Default: a malloc'ed buffer (fgmm_free).  With a sink (include/flashgmm_amd.h: fgmm_sink) the
+// encoder asks it for storage of the stream's exact size once that is known and copies the stream there out of its scratch: the
+// caller's storage (a Python bytes object, say) is filled by the flush, with no buffer of the library's in between.  (The batched
+// encoder gives its workers a sink of its own, which passes the question on to the calling thread: fgmm_encode.cpp, SinkDesk.)
+struct BytesTo {
+  const fgmm_sink *sink = nullptr;
+  int item = 0;
+};
 // returns 0 or an fgmm_status; *out malloc'ed
 int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint,
                        uint8_t **out, size_t *out_len);
 // ... noting a checkpoint (include/flashgmm_amd.h: fgmm_ckpt) every `stride` symbols (a power of two; 0: none):
 // ckpt[(n - 1) / stride] entries, entry k for symbol (k + 1) * stride
 int rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint, uint8_t **out,
-                            size_t *out_len, int64_t stride, fgmm_ckpt *ckpt);
+                            size_t *out_len, int64_t stride, fgmm_ckpt *ckpt, BytesTo to = {});
 // ... from a table that lies in `n_seg` segments of `seg_len` entries (the last one may be shorter): seg[s] holds the entries
 // [s * seg_len, (s + 1) * seg_len).  The walk runs backwards, so the LAST segment is needed first; wait(arg, s) (may be null)
 // returns once segment s may be read (FGMM_OK) - the batched encoder's tables land tail first.
@@ -266,13 +274,13 @@ struct SegTable {
   void *arg;
 };
 int rans_encode_symtab_segs(const SegTable &t, const int32_t *symbols_or_null, int64_t n, int64_t n_bypass_hint, uint8_t **out,
-                            size_t *out_len, int64_t stride, fgmm_ckpt *ckpt);
+                            size_t *out_len, int64_t stride, fgmm_ckpt *ckpt, BytesTo to = {});
 // two streams by one thread, interleaved (each output identical to rans_encode_symtab's)
 constexpr int kMaxEncWays = 4;
 // `ways` (1..4) tables -> bitstreams, coded by the calling thread symbol by symbol in turn
 int rans_encode_symtab_ways(int ways, const uint32_t *const *packed, const int32_t *const *symbols, const int64_t *n,
                             const int64_t *n_bypass_hint, uint8_t ***out, size_t **out_len, int64_t ckpt_stride = 0,
-                            fgmm_ckpt *const *ckpt = nullptr);
+                            fgmm_ckpt *const *ckpt = nullptr, const BytesTo *to = nullptr);
 int rans_encode_symtab2(const uint32_t *const packed[2], const int32_t *const symbols[2], const int64_t n[2],
                         const int64_t n_bypass_hint[2], uint8_t **out[2], size_t *out_len[2]);
 // Decode-side tables as the host decoder sees them: `npiece` pieces in latent order; piece k holds the latents

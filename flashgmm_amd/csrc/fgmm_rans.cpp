@@ -141,12 +141,12 @@ struct CkRec { // while encoding: words emitted so far; finish_ckpt turns that i
 };
 static inline int64_t ckpt_count(int64_t n, int64_t stride) { return stride > 0 && n > 0 ? (n - 1) / stride : 0; }
 
-static int finish_stream(Enc &e, uint32_t *end, uint8_t **out, size_t *out_len) { // Rans64EncFlush + copy out
+static int finish_stream(Enc &e, uint32_t *end, uint8_t **out, size_t *out_len, BytesTo to = {}) { // Rans64EncFlush + copy out
   e.ptr -= 2;
   e.ptr[0] = (uint32_t)(e.x >> 0);
   e.ptr[1] = (uint32_t)(e.x >> 32);
   const size_t nbytes = (size_t)(end - e.ptr) * sizeof(uint32_t);
-  uint8_t *o = (uint8_t *)malloc(nbytes);
+  uint8_t *o = (uint8_t *)(to.sink ? to.sink->alloc(to.sink->user, to.item, nbytes) : malloc(nbytes)); // (the caller's storage: fgmm_sink)
   if (!o) return FGMM_ERR_NOMEM;
   memcpy(o, e.ptr, nbytes);
   *out = o;
@@ -161,7 +161,7 @@ int rans_encode_symtab(const uint32_t *packed, const int32_t *symbols, int64_t n
 
 // the same, noting a checkpoint every `stride` symbols (a power of two; 0: none) into ckpt[ckpt_count(n, stride)]
 int rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols, int64_t n, int64_t n_bypass_hint, uint8_t **out,
-                            size_t *out_len, int64_t stride, fgmm_ckpt *ckpt) {
+                            size_t *out_len, int64_t stride, fgmm_ckpt *ckpt, BytesTo to) {
   std::call_once(g_rcp_once, init_rcp);
   if (n < 0 || !out || !out_len || (n > 0 && !packed) || stride < 0 || (stride & (stride - 1)) || (ckpt_count(n, stride) && !ckpt))
     return FGMM_ERR_INVALID;
@@ -187,13 +187,13 @@ int rans_encode_symtab_ckpt(const uint32_t *packed, const int32_t *symbols, int6
     hi = lo;
   }
   ck.finish(e, end);
-  return finish_stream(e, end, out, out_len);
+  return finish_stream(e, end, out, out_len, to);
 }
 
 // the same from a table in segments (SegTable): the walk is backwards, so it starts in the last segment and asks for each one
 // before it enters it - the batched encoder's tables cross PCIe tail first and the encoders follow the landing
 int rans_encode_symtab_segs(const SegTable &t, const int32_t *symbols, int64_t n, int64_t n_bypass_hint, uint8_t **out, size_t *out_len,
-                            int64_t stride, fgmm_ckpt *ckpt) {
+                            int64_t stride, fgmm_ckpt *ckpt, BytesTo to) {
   std::call_once(g_rcp_once, init_rcp);
   if (n < 0 || !out || !out_len || n_bypass_hint < 0 || stride < 0 || (stride & (stride - 1)) || (ckpt_count(n, stride) && !ckpt) ||
       t.n_seg < 1 || t.n_seg > kEncSegs || t.seg_len < 1 || n > (int64_t)t.n_seg * t.seg_len)
@@ -226,7 +226,7 @@ int rans_encode_symtab_segs(const SegTable &t, const int32_t *symbols, int64_t n
     hi = lo;
   }
   ck.finish(e, end);
-  return finish_stream(e, end, out, out_len);
+  return finish_stream(e, end, out, out_len, to);
 }
 
 // Up to four independent bitstreams coded by one thread, symbol by symbol in turn.  A stream's state update is a chain
@@ -234,7 +234,7 @@ int rans_encode_symtab_segs(const SegTable &t, const int32_t *symbols, int64_t n
 // one stream alone (Zen 5, scripts/enc_ilp.cpp).  Each stream's output is exactly what rans_encode_symtab gives.
 template <int N>
 static int encode_ways(const uint32_t *const *packed, const int32_t *const *symbols, const int64_t *n, const int64_t *n_bypass_hint,
-                       uint8_t ***out, size_t **out_len, int64_t stride, fgmm_ckpt *const *ckpt) {
+                       uint8_t ***out, size_t **out_len, int64_t stride, fgmm_ckpt *const *ckpt, const BytesTo *to) {
   size_t nwords[N], total = 0;
   for (int k = 0; k < N; ++k) {
     if (n[k] < 0 || !out[k] || !out_len[k] || (n[k] > 0 && !packed[k])) return FGMM_ERR_INVALID;
@@ -283,23 +283,23 @@ static int encode_ways(const uint32_t *const *packed, const int32_t *const *symb
   for (int k = 0; k < N; ++k) ck[k].finish(e[k], end[k]);
   int rc = FGMM_OK;
   for (int k = 0; k < N && rc == FGMM_OK; ++k)
-    if ((rc = finish_stream(e[k], end[k], out[k], out_len[k])) != FGMM_OK)
+    if ((rc = finish_stream(e[k], end[k], out[k], out_len[k], to ? to[k] : BytesTo{})) != FGMM_OK)
       for (int q = 0; q < k; ++q) {
-        free(*out[q]);
+        if (!to || !to[q].sink) free(*out[q]); // (a sink's storage is the caller's)
         *out[q] = nullptr;
       }
   return rc;
 }
 
 int rans_encode_symtab_ways(int ways, const uint32_t *const *packed, const int32_t *const *symbols, const int64_t *n,
-                            const int64_t *n_bypass_hint, uint8_t ***out, size_t **out_len, int64_t stride, fgmm_ckpt *const *ckpt) {
+                            const int64_t *n_bypass_hint, uint8_t ***out, size_t **out_len, int64_t stride, fgmm_ckpt *const *ckpt, const BytesTo *to) {
   std::call_once(g_rcp_once, init_rcp);
   if (stride < 0 || (stride & (stride - 1))) return FGMM_ERR_INVALID;
   switch (ways) {
-  case 1: return rans_encode_symtab_ckpt(packed[0], symbols[0], n[0], n_bypass_hint[0], out[0], out_len[0], ckpt && ckpt[0] ? stride : 0, ckpt ? ckpt[0] : nullptr);
-  case 2: return encode_ways<2>(packed, symbols, n, n_bypass_hint, out, out_len, stride, ckpt);
-  case 3: return encode_ways<3>(packed, symbols, n, n_bypass_hint, out, out_len, stride, ckpt);
-  case 4: return encode_ways<4>(packed, symbols, n, n_bypass_hint, out, out_len, stride, ckpt);
+  case 1: return rans_encode_symtab_ckpt(packed[0], symbols[0], n[0], n_bypass_hint[0], out[0], out_len[0], ckpt && ckpt[0] ? stride : 0, ckpt ? ckpt[0] : nullptr, to ? to[0] : BytesTo{});
+  case 2: return encode_ways<2>(packed, symbols, n, n_bypass_hint, out, out_len, stride, ckpt, to);
+  case 3: return encode_ways<3>(packed, symbols, n, n_bypass_hint, out, out_len, stride, ckpt, to);
+  case 4: return encode_ways<4>(packed, symbols, n, n_bypass_hint, out, out_len, stride, ckpt, to);
   default: return FGMM_ERR_INVALID;
   }
 }

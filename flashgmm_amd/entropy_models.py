@@ -39,22 +39,38 @@ class CheckpointedBytes(bytes):
     sequential decode, never a wrong symbol).  Anything that only knows ``bytes`` — the reference's decoder, a file — sees
     the plain stream; ``flashgmm_amd.container`` stores the checkpoints next to it."""
 
+    # _ck = (notes, first, count, address, stride): `notes` is an ndarray of CKPT_DTYPE (first = 0), or the ``bytes`` blob a compiled
+    # compress call filled with the notes of ALL its bitstreams - this one's are records first .. first + count of it, the view is made
+    # when someone asks for ``.ckpt``; address: of the first note (what a decode call hands the library)
     def __new__(cls, data: bytes, ckpt: np.ndarray, stride: int):
         self = super().__new__(cls, data)
         if not (isinstance(ckpt, np.ndarray) and ckpt.dtype == CKPT_DTYPE and ckpt.flags.c_contiguous):
             ckpt = np.ascontiguousarray(ckpt, dtype=CKPT_DTYPE)
-        self.ckpt = ckpt  # [(x: u64, pos: u64)], entry k = before symbol (k + 1) * stride
-        self.ckpt_stride = int(stride)
-        self._ckpt_addr = ckpt.ctypes.data if len(ckpt) else 0  # (ndarray.ctypes is slow: taken once)
+        self._ck = (ckpt, 0, len(ckpt), ckpt.ctypes.data if len(ckpt) else 0, int(stride))  # (ndarray.ctypes is slow: taken once)
         return self
+
+    @property
+    def ckpt(self) -> np.ndarray:
+        """[(x: u64, pos: u64)], entry k = before symbol (k + 1) * stride"""
+        notes, first, count, addr, stride = self._ck
+        if not isinstance(notes, np.ndarray):
+            notes = np.frombuffer(notes, dtype=CKPT_DTYPE, count=count, offset=16 * first) if count else _NO_CKPT
+            self._ck = (notes, 0, count, addr, stride)
+        return notes
+
+    @property
+    def ckpt_stride(self) -> int:
+        return self._ck[4]
+
+    @property
+    def _ckpt_addr(self) -> int:
+        return self._ck[3]
 
     @classmethod
     def _adopt(cls, blank: "CheckpointedBytes", ckpt: np.ndarray, stride: int, addr: int = -1) -> "CheckpointedBytes":
         """attach the notes to an instance whose bytes are already in place (``_lib.take_bytes_many(..., cls=CheckpointedBytes)``:
         the library's workers copied the bitstream into it - no second copy through ``__new__``)"""
-        blank.ckpt = ckpt
-        blank.ckpt_stride = int(stride)
-        blank._ckpt_addr = addr if addr >= 0 else (ckpt.ctypes.data if len(ckpt) else 0)
+        blank._ck = (ckpt, 0, len(ckpt), addr if addr >= 0 else (ckpt.ctypes.data if len(ckpt) else 0), int(stride))
         return blank
 
     def __reduce__(self):
@@ -111,17 +127,6 @@ def _take_ckpts_many(device: int, ptrs, counts):
         else:
             out.append((_NO_CKPT, 0))
     _lib.take_buffers_into(device, dst, src, lens)
-    return out
-
-
-def _adopt_ckpts(strings, blob: bytes, counts, stride: int):
-    """the compiled boundary's checkpoint blob (every bitstream's notes back to back) -> CheckpointedBytes with views into it"""
-    pool = np.frombuffer(blob, dtype=CKPT_DTYPE) if len(blob) else _NO_CKPT
-    base = pool.ctypes.data if len(pool) else 0
-    out, at = [], 0
-    for d, n in zip(strings, counts):
-        out.append(CheckpointedBytes._adopt(d, pool[at:at + n] if n else _NO_CKPT, stride, base + 16 * at if n else 0))
-        at += n
     return out
 
 
@@ -346,12 +351,10 @@ class GaussianMixtureConditional(nn.Module):
             di = dev.index if dev.index is not None else -1
             yq = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
             zb = torch.empty((N, M), dtype=torch.int64)
-            strings, amax, blob, counts = nat.compress_stacked(
+            strings, amax = nat.compress_stacked(
                 _lib.ctx_addr(di), torch.cuda.current_stream(dev).cuda_stream, y.data_ptr(), scales.data_ptr(), means.data_ptr(), weights.data_ptr(),
                 N, M, h * w, s_item, M * sc, sc, _lib.FGMM_F16 if scales.dtype == torch.float16 else _lib.FGMM_F32, flags, self._mode(),
                 int(self.clamp_scales), self.checkpoint_stride, yq.data_ptr(), zb.data_ptr(), CheckpointedBytes if self.checkpoint_stride else None)
-            if self.checkpoint_stride:
-                strings = _adopt_ckpts(strings, blob, counts, self.checkpoint_stride)
             return CompressedBatch(strings, amax, zb, yq)
         items, keep, N, M, h, w, dev = self._stacked_items(y, scales, means, weights, flags)
         if N == 0:
@@ -390,14 +393,11 @@ class GaussianMixtureConditional(nn.Module):
             dev = scales.device
             if not isinstance(strings, list) or not all(type(s_) is bytes or isinstance(s_, bytes) for s_ in strings):
                 strings = [s_ if isinstance(s_, bytes) else bytes(s_) for s_ in strings]
-            ck = None
-            if any(isinstance(d, CheckpointedBytes) for d in strings):
-                ck = [(d._ckpt_addr, len(d.ckpt), d.ckpt_stride) if isinstance(d, CheckpointedBytes) else (0, 0, 0) for d in strings]
             y_hat = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
             nat.decompress_stacked(_lib.ctx_addr(dev.index if dev.index is not None else -1), torch.cuda.current_stream(dev).cuda_stream, strings, abs_maxes,
                                    zb.data_ptr(), zb.stride(0) if N > 1 else M, scales.data_ptr(), means.data_ptr(), weights.data_ptr(), N, M, h * w, s_item,
                                    M * sc, sc, _lib.FGMM_F16 if scales.dtype == torch.float16 else _lib.FGMM_F32, flags, self._mode(), int(self.clamp_scales),
-                                   y_hat.data_ptr(), ck)
+                                   y_hat.data_ptr(), CheckpointedBytes)  # (the out-of-band notes of the bitstreams that carry them: read off the objects)
             return y_hat if stacked_output else list(y_hat.unbind(0))
         items, keep, N, M, h, w, dev = self._stacked_items(None, scales, means, weights, flags)
         if len(strings) != N or len(abs_maxes) != N or len(zero_bitmaps) != N:
@@ -421,7 +421,7 @@ class GaussianMixtureConditional(nn.Module):
         items["bytes"] = np.frombuffer(bufs, dtype=np.uint64)
         items["bytes_len"] = [len(d) for d in data]
         if any(isinstance(d, CheckpointedBytes) for d in data):  # out-of-band checkpoints of the streams that carry them
-            cks = [(d._ckpt_addr, len(d.ckpt), d.ckpt_stride) if isinstance(d, CheckpointedBytes) else (0, 0, 0) for d in data]
+            cks = [(d._ck[3], d._ck[2], d._ck[4]) if isinstance(d, CheckpointedBytes) else (0, 0, 0) for d in data]  # (address, count, stride)
             items["ckpt"], items["n_ckpt"], items["ckpt_stride"] = (np.array(c, dtype=np.uint64) for c in zip(*cks))
         items["abs_max"] = np.asarray(abs_maxes, dtype=np.int64)
         items["yq_out"] = np.uint64(y_hat.data_ptr()) + np.arange(N, dtype=np.uint64) * np.uint64(M * h * w * 4)
@@ -505,12 +505,10 @@ class GaussianMixtureConditional(nn.Module):
         if nat is not None:
             yq = torch.empty((N, 1, M, h, w), dtype=torch.float32, device=dev)
             zb = torch.empty((N, M), dtype=torch.int64)
-            strings, amax, blob, counts = nat.compress_head_stacked(
+            strings, amax = nat.compress_head_stacked(
                 _lib.ctx_addr(dev.index if dev.index is not None else -1), torch.cuda.current_stream(dev).cuda_stream, y.data_ptr(), x.data_ptr(), head._h.value,
                 N, M, head.c_in, h * w, self._mode(), int(self.clamp_scales), self.checkpoint_stride, yq.data_ptr(), zb.data_ptr(),
                 CheckpointedBytes if self.checkpoint_stride else None)
-            if self.checkpoint_stride:
-                strings = _adopt_ckpts(strings, blob, counts, self.checkpoint_stride)
             return CompressedBatch(strings, amax, zb, yq)
         items = np.zeros(N, _lib.ITEM_DTYPE)
         rng = np.arange(N, dtype=np.uint64)
@@ -572,8 +570,8 @@ class GaussianMixtureConditional(nn.Module):
             it.yq_out, it.zero_bitmap = y_hat.data_ptr(), zb.data_ptr()
             it.abs_max = int(abs_maxes[i])
             it.bytes, it.bytes_len = C.cast(buf, C.c_void_p), len(data)
-            if isinstance(data, CheckpointedBytes) and len(data.ckpt):
-                it.ckpt, it.n_ckpt, it.ckpt_stride = data._ckpt_addr, len(data.ckpt), data.ckpt_stride
+            if isinstance(data, CheckpointedBytes) and data._ck[2]:
+                it.ckpt, it.n_ckpt, it.ckpt_stride = data._ck[3], data._ck[2], data._ck[4]
             items[i] = it
             keep += [zb, buf, data]
             outs.append(y_hat)

@@ -38,8 +38,8 @@
 extern "C" {
 #endif
 
-#define FGMM_ABI_VERSION 6 /* 6: + the parameter head (fgmm_head_*, fgmm_gmc_compress_head_batch); FGMM_WORKER_CPUS that cannot be honoured
-                              fails fgmm_ctx_create.  5: + fgmm_ctx_call_log; REMOVED (measured, lost, pruned): options tab_place /
+#define FGMM_ABI_VERSION 6 /* 6: + the parameter head (fgmm_head_*, fgmm_gmc_compress_head_batch); + fgmm_sink and the _to forms of the batched
+                              compress calls; FGMM_WORKER_CPUS that cannot be honoured fails fgmm_ctx_create.  5: + fgmm_ctx_call_log; REMOVED (measured, lost, pruned): options tab_place /
                               tab_spin / copy_engine / dec_pair / dec_group, fgmm_rans_decode_tab2 + fgmm_tab_ref, fgmm_ctx_stat index 6 */
 
 typedef enum {
@@ -275,6 +275,21 @@ typedef struct {
 int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
 int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
 
+/* A sink: the bitstreams of a batched compress call written straight into storage of the caller's (a Python `bytes` object created
+ * at its final size and filled by the flush - what rans_interface.cpp:590-607 does with its py::bytes - instead of a buffer of the
+ * library's that the binding copies once more: 2.5 MB per Kodak batch, 0.1 ms of the calling thread).  When item i's bitstream is
+ * complete and its size known, the library calls alloc(user, i, nbytes) - ONCE per item, ON THE CALLING THREAD (it serves the host
+ * workers' requests while it waits for them: a binding may take its interpreter's lock in alloc without its workers queueing for
+ * it) - and the worker that coded the bitstream copies the nbytes there; items[i].bytes is that address on return, the caller's to
+ * keep: fgmm_free / fgmm_ctx_take_buffers must NOT be given it.  alloc returning NULL fails the call with FGMM_ERR_NOMEM.  A failed
+ * call returns items[i].bytes == NULL as ever; what the sink had handed out by then stays the caller's to release.  Checkpoints
+ * (items[i].ckpt) are returned as without a sink.  sink == NULL: the plain call. */
+typedef struct {
+  void *(*alloc)(void *user, int item, size_t nbytes);
+  void *user;
+} fgmm_sink;
+int fgmm_gmc_compress_batch_to(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales, const fgmm_sink *sink);
+
 /* ------------------------------------------------------------------------------------------------------------
  * 2b. The parameter head's last layer, on the matrix cores.
  *    Replaces: the final 1x1 convolution of `entropy_parameters`, nn.Conv2d(c_in, 3*K*M, 1) (compressai/models/ckbd_gmm.py:115-121;
@@ -311,6 +326,9 @@ int fgmm_head_params_batch(fgmm_ctx *ctx, void *stream, const fgmm_head *head, c
  * FGMM_PARAMS_LOGITS (same arithmetic, same bytes). */
 int fgmm_gmc_compress_head_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, const float *const *x, int count,
                                  const fgmm_head *head, int mode, int clamp_scales);
+/* ... with the bitstreams written into the caller's storage (fgmm_sink, section 2) */
+int fgmm_gmc_compress_head_batch_to(fgmm_ctx *ctx, void *stream, fgmm_item *items, const float *const *x, int count,
+                                    const fgmm_head *head, int mode, int clamp_scales, const fgmm_sink *sink);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 3. Building blocks ("same tables => same bytes" surfaces; also what the parity tests probe).

@@ -7,6 +7,8 @@
 // budget that forces overflow re-runs, an LDS budget that sends items to the generic kernels) and random worker counts; now and then a
 // truncated bitstream, which must be refused, and a corrupted one, which must decode to what the oracle's decoder makes of it.
 //   stress_main [seconds] [seed]
+#include <atomic>
+#include <thread>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -137,6 +139,32 @@ static void coded_rows(const Item &it, std::vector<int32_t> &sym, std::vector<fl
 
 static void set_opt(fgmm_ctx *ctx, const char *name, int64_t v) { CHECK(fgmm_ctx_set_option(ctx, name, v) == FGMM_OK, "option %s=%lld", name, (long long)v); }
 
+// a caller's storage for the bitstreams of one call (fgmm_sink): a malloc of the exact size per item
+struct Sunk {
+  std::vector<void *> slot;
+  std::vector<size_t> len;
+  std::vector<std::atomic<int>> calls;
+  int refuse = -1;
+  std::thread::id owner = std::this_thread::get_id();
+  void reset(int count) {
+    for (void *p : slot) free(p);
+    slot.assign((size_t)count, nullptr);
+    len.assign((size_t)count, 0);
+    calls = std::vector<std::atomic<int>>((size_t)count);
+    refuse = -1;
+  }
+  ~Sunk() {
+    for (void *p : slot) free(p);
+  }
+  static void *alloc(void *user, int item, size_t nbytes) { // (on the calling thread, inside the call)
+    Sunk *s = static_cast<Sunk *>(user);
+    if (item < 0 || (size_t)item >= s->slot.size() || std::this_thread::get_id() != s->owner) abort(); // (a wrong item; not the calling thread)
+    if (s->calls[(size_t)item].fetch_add(1) != 0 || item == s->refuse) return nullptr;
+    s->len[(size_t)item] = nbytes;
+    return s->slot[(size_t)item] = malloc(nbytes ? nbytes : 1);
+  }
+};
+
 int main(int argc, char **argv) {
   const double budget = argc > 1 ? atof(argv[1]) : 20.0;
   if (argc > 2) rng_state ^= (uint64_t)atoll(argv[2]) * 0x9E3779B97F4A7C15ull;
@@ -243,7 +271,27 @@ int main(int argc, char **argv) {
       }
       fprintf(stderr, "\n");
     }
-    CHECK(fgmm_gmc_compress_batch(ctx, nullptr, fi.data(), count, mode, clamp) == FGMM_OK, "compress_batch (count %d)", count);
+    // One round in three through a SINK (fgmm_sink): the bitstreams go into storage handed out by the caller, of their exact size (a
+    // malloc each: the sanitizer sees a byte too many), asked for once per item on the calling thread; now and then the sink
+    // refuses an item first - the call must fail with FGMM_ERR_NOMEM and return no buffer - and the call is made again.
+    Sunk sunk;
+    const bool to_sink = rnd() % 3 == 0;
+    if (to_sink) {
+      sunk.reset(count);
+      const fgmm_sink sink{&Sunk::alloc, &sunk};
+      if (rnd() % 4 == 0) {
+        sunk.refuse = (int)(rnd() % (uint64_t)count);
+        CHECK(fgmm_gmc_compress_batch_to(ctx, nullptr, fi.data(), count, mode, clamp, &sink) == FGMM_ERR_NOMEM, "a sink that refuses item %d: the call went through", sunk.refuse);
+        for (int i = 0; i < count; ++i) CHECK(!fi[(size_t)i].bytes && !fi[(size_t)i].ckpt, "a failed call returned a buffer (item %d)", i);
+        sunk.reset(count);
+      }
+      CHECK(fgmm_gmc_compress_batch_to(ctx, nullptr, fi.data(), count, mode, clamp, &sink) == FGMM_OK, "compress_batch_to (count %d)", count);
+      for (int i = 0; i < count; ++i)
+        CHECK(sunk.calls[(size_t)i].load() == 1 && fi[(size_t)i].bytes == sunk.slot[(size_t)i] && fi[(size_t)i].bytes_len == sunk.len[(size_t)i],
+              "sink: item %d asked %d times / bytes not where the sink said", i, sunk.calls[(size_t)i].load());
+    } else {
+      CHECK(fgmm_gmc_compress_batch(ctx, nullptr, fi.data(), count, mode, clamp) == FGMM_OK, "compress_batch (count %d)", count);
+    }
     // ---- every bitstream against the oracle's encoder
     for (int i = 0; i < count; ++i) {
       Item &it = its[(size_t)i];
@@ -338,7 +386,7 @@ int main(int argc, char **argv) {
       if (pick_.hw > 0) raw_boundary(ctx, pick_, mode);
     }
     // ---- buffers handed over in one native call (a binding that wants to own the bytes), the call log, trimming the context
-    if (rnd() % 4 == 0) {
+    if (!to_sink && rnd() % 4 == 0) {
       std::vector<std::vector<uint8_t>> own((size_t)count);
       std::vector<void *> dst((size_t)count), src((size_t)count);
       std::vector<size_t> len((size_t)count);
@@ -359,7 +407,10 @@ int main(int argc, char **argv) {
       for (int k = 0; k < n_log; ++k) CHECK(log[k].count >= 1 && log[k].ms[5] >= log[k].ms[0] && log[k].ms[0] >= 0, "call log entry %d", k);
       if (rnd() % 2) CHECK(fgmm_ctx_trim(ctx) == FGMM_OK, "trim");
     }
-    for (auto &f : fi) fgmm_free(f.bytes), fgmm_free(f.ckpt);
+    for (auto &f : fi) {
+      if (!to_sink) fgmm_free(f.bytes); // (a sink's storage is the caller's: released with `sunk`)
+      fgmm_free(f.ckpt);
+    }
     ++rounds;
   }
   fgmm_ctx_destroy(ctx);

@@ -555,6 +555,68 @@ def test_compiled_and_ctypes_bindings_agree(monkeypatch, stride):
         assert torch.equal(out_nat[s], nat.y_q[s::2]) and torch.equal(out_cty[s], nat.y_q[s::2])
 
 
+def test_sink_puts_the_bitstreams_into_the_callers_storage(monkeypatch):
+    """include/flashgmm_amd.h: fgmm_sink.  fgmm_gmc_compress_batch_to asks the sink once per item, on the calling thread, for
+    storage of the bitstream's exact size and the worker that coded it writes it there (what rans_interface.cpp:590-607 does with its py::bytes): the same
+    bytes as the plain call's buffers; a sink that refuses an item fails the call with FGMM_ERR_NOMEM and returns no buffer.  The
+    compiled module's `bytes` objects are made that way: they hash, compare and slice like any other."""
+    import ctypes as C
+    import threading
+
+    L = _lib.lib()
+    gmc = GaussianMixtureConditional(K=4, mode="polya")
+    lat = [T.make_latent(4300 + i, M=32 + 8 * (i % 2), h=16, w=8 + 4 * (i % 3), clamp=False, zero_frac=0.25 if i != 3 else 1.0) for i in range(7)]
+    dev_t = [[torch.from_numpy(l[k]).to("cuda:0") for k in range(4)] for l in lat]
+    plain = gmc.compress_batch(*[[t[k] for t in dev_t] for k in range(4)])
+    items = (_lib.fgmm_item * 7)()
+    keep = []
+    for i, t in enumerate(dev_t):
+        it, M, hw, _ = gmc._item(t[0], t[1], t[2], t[3], keep)
+        yq, zb = torch.empty_like(t[0]), torch.empty(M, dtype=torch.int64)
+        it.yq_out, it.zero_bitmap = yq.data_ptr(), zb.data_ptr()
+        items[i] = it
+        keep += [yq, zb]
+    store, asked, threads = {}, [], set()
+
+    def alloc(user, item, nbytes, refuse=-1):
+        asked.append(item)
+        threads.add(threading.get_ident())
+        if item == refuse:
+            return None
+        store[item] = C.create_string_buffer(nbytes)
+        return C.addressof(store[item])
+
+    sink = _lib.fgmm_sink(_lib.SINK_ALLOC(alloc), None)
+    rc = L.fgmm_gmc_compress_batch_to(_lib.ctx(0), torch.cuda.current_stream().cuda_stream, items, 7, 0, 1, C.byref(sink))
+    assert rc == 0, L.fgmm_last_error()
+    assert sorted(asked) == list(range(7)), asked  # once per item
+    assert threads == {threading.get_ident()}      # ... on the calling thread (which serves its workers' requests inside the call)
+    for i in range(7):
+        assert items[i].bytes == C.addressof(store[i]) and items[i].bytes_len == len(store[i].raw)
+        assert store[i].raw == plain[i][0][0] and items[i].abs_max == plain[i][0][1]
+    # a sink that refuses item 4
+    store.clear(), asked.clear()
+    sink2 = _lib.fgmm_sink(_lib.SINK_ALLOC(lambda u, i, n: alloc(u, i, n, refuse=4)), None)
+    rc = L.fgmm_gmc_compress_batch_to(_lib.ctx(0), torch.cuda.current_stream().cuda_stream, items, 7, 0, 1, C.byref(sink2))
+    assert rc == 4 and sorted(asked) == list(range(7))  # FGMM_ERR_NOMEM; the other items' encoders ran to their end
+    assert all(not items[i].bytes and not items[i].ckpt for i in range(7))
+    # a one-item call (coded on the calling thread itself)
+    threads.clear(), asked.clear()
+    rc = L.fgmm_gmc_compress_batch_to(_lib.ctx(0), torch.cuda.current_stream().cuda_stream, items, 1, 0, 1, C.byref(sink))
+    assert rc == 0 and asked == [0] and threads == {threading.get_ident()} and store[0].raw == plain[0][0][0]
+    # the compiled module's objects (stacked inputs go through it)
+    ys, ss, ms, ws = (torch.cat([dev_t[i][k] for i in (0, 6)]) for k in range(4))
+    for stride in (0, 256):
+        g = GaussianMixtureConditional(K=4, mode="polya", checkpoint_stride=stride)
+        res = g.compress_batch(ys, ss, ms, ws)
+        assert _lib.native() is not None
+        for j, i in enumerate((0, 6)):
+            b = res.strings[j]
+            assert type(b) is (CheckpointedBytes if stride else bytes) and b == plain[i][0][0] and hash(b) == hash(plain[i][0][0])
+            assert b[:8] == plain[i][0][0][:8] and len(b) == len(plain[i][0][0]) and bytes(b) + b"x" == plain[i][0][0] + b"x"
+            assert {b: 1}[plain[i][0][0]] == 1
+
+
 @pytest.fixture
 def ctx_options():
     """set options of the process-wide context for one test and restore them afterwards"""
