@@ -63,7 +63,8 @@ struct SinkDesk {
   std::vector<size_t> need;
   std::unique_ptr<Ans[]> ans;
   std::atomic<long> n_asked{0};
-  int jobs_left = 0, sleepers = 0;
+  std::atomic<int> jobs_left{0}; // (written under the lock; read without it by the calling thread's polling)
+  int sleepers = 0;
   bool closed = false;
 
   static double us_since(std::chrono::steady_clock::time_point t0) {
@@ -118,7 +119,7 @@ struct SinkDesk {
           const auto t0 = std::chrono::steady_clock::now();
           do {
             for (int k = 0; k < 32 && !more; ++k) {
-              more = n_asked.load(std::memory_order_acquire) != served;
+              more = n_asked.load(std::memory_order_acquire) != served || jobs_left.load(std::memory_order_acquire) == 0;
               __builtin_ia32_pause();
             }
           } while (!more && us_since(t0) < 60.0);
