@@ -65,7 +65,8 @@ struct DecodeCall {
   bool clamped = false, f16 = false, spin = false;
   uint32_t ef_min = kTabNoEf;
   int64_t streams_of_work = 0;
-  bool lead_small = false; // plan_pieces: two pieces, an eighth and the rest (a call with one decoder)
+  bool lead_small = false; // plan_pieces: a call with one decoder - a small first piece, then pieces that grow (lead_cum)
+  double lead_cum[kMaxPieces + 1] = {0}; // ... the share of the bitstream's blocks before piece p
   // ---- plan
   std::vector<int> fast, generic;
   std::vector<Unit> units;
@@ -158,17 +159,28 @@ struct DecodeCall {
     np = 8;
     while (np < kAutoPiecesMax && (int64_t)np * (np + 1) / 2 * 4096 < lat_max) ++np;
     if (lat < 65536) np = 1;                 // pieces only pay for rows that take a while to cross
-    // one decoder (one image's half, the latency case): it is the bottleneck (1.2 ms for a Kodak half against 0.14 ms of tables on the
-    // bus), so pieces only let it START early - a small first piece (an eighth: it lands 0.09 ms sooner than the half that
-    // "3, 2, 1" made it, and its 0.15 ms of decoding cover the arrival of the rest), then everything else in one
-    if (decoders == 1) np = std::min(np, 2);
+    // One decoder (one image's half, the latency case): it is the bottleneck - 1.2 ms for a Kodak half against 0.14 ms of tables on the
+    // bus, a latent takes 9-10 ns to decode and 1.0-1.3 ns to cross - so pieces only have to let it START early and never run dry: a small
+    // first piece (an eighth of a Kodak half lands 0.09 ms sooner than the half that "3, 2, 1" made it), then pieces that grow FOURFOLD
+    // (cumulatively): the next piece - three times what has landed so far - crosses in 3.1-3.9 ns per latent already here plus a round
+    // trip of this thread (~60 us: launch, counter, copy), the decoder needs 7.2 ns for each of them: it never waits from 16 k latents
+    // on.  Kodak half: 1/8, 3/8, 1/2 (two pieces - an eighth, the rest - left the decoder waiting 0.08-0.1 ms for the second: one image
+    // 3.43 -> 3.28 ms, profiles/r06_README.md); an ELIC-4K stage of 3.5 M latents: 24 k, 72 k, 288 k, 1.2 M, the rest.
+    if (decoders == 1 && np > 1) {
+      lead_small = true;
+      const double first = std::min<double>(std::max<double>((double)lat_max / 8, 16384), 24576);
+      int k = 0;
+      for (double cum = first; k + 1 < kAutoPiecesMax && cum < 0.6 * (double)lat_max; cum *= 4) lead_cum[++k] = cum / (double)lat_max;
+      np = k + 1;
+      lead_cum[np] = 1.0;
+      return;
+    }
     // every round costs this thread ~60 us of launch / counter / copy round trips: no more rounds than the tables' time on the bus
-    // is worth (a lone Kodak half: 7.7 MB = 0.14 ms -> 2 pieces; measured 0.45 ms per call against 0.72 with 8)
+    // is worth
     np = (int)std::min<int64_t>(np, std::max<int64_t>(1, lat * 58 / 55700 / 60)); // lat * 58 B / 55.7 GB/s in units of 60 us
-    lead_small = decoders == 1 && np == 2;
   }
   int64_t piece_bound(int64_t nblk, int p) const { // first block of piece p: weights np, np-1 ... 1
-    if (lead_small) return p <= 0 ? 0 : p == 1 ? nblk / 8 : nblk;
+    if (lead_small) return p <= 0 ? 0 : p >= np ? nblk : std::min<int64_t>((int64_t)((double)nblk * lead_cum[p]), nblk);
     const int64_t tot = (int64_t)np * (np + 1) / 2, cum = (int64_t)p * (2 * np - p + 1) / 2;
     return (int64_t)((__int128)nblk * cum / tot);
   }

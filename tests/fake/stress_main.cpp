@@ -220,7 +220,7 @@ int main(int argc, char **argv) {
   while (std::chrono::steady_clock::now() < t_end) {
     // The first three rounds of every run are LARGE bitstreams under the AUTOMATIC piece plan (pieces = 0), which the random
     // items below - all under 65 536 latents, one piece - never reach: one bitstream of 131 072 latents on a pool of one worker and
-    // on a pool of eight (one decoder: two pieces, an eighth first - plan_pieces' lead_small), then two such bitstreams (the
+    // on a pool of eight (one decoder: a small first piece, then growing ones - plan_pieces' lead_small), then two such bitstreams (the
     // general multi-piece plan, shrinking pieces).
     const bool big = rounds < 3;
     CHECK(fgmm_ctx_set_threads(ctx, big ? (rounds == 0 ? 1 : 8) : kThreads[rnd() % 6]) == FGMM_OK, "threads");
