@@ -1292,6 +1292,14 @@ def main(argv=None):
                 return (time.perf_counter() - t0) * 1e3
 
             reps = 30 if a.workload == "kodak24" else 3
+            _lib.set_profiling(local_rank, False)  # (no timing events around the kernels of these calls: nothing reads them; on again below)
+            wide = None
+            if env.l3_cpus:  # the calling thread on its own L3 domain, as in the timed regions (Leg.timed); opened again below
+                try:
+                    wide = os.sched_getaffinity(0)
+                    os.sched_setaffinity(0, env.l3_cpus)
+                except OSError:
+                    wide = None
             for codec in (True, False):
                 one_image(codec)
             extras["latency_ms"] = {"images": 1, "streams": spi,
@@ -1315,6 +1323,10 @@ def main(argv=None):
                 one_image(True)
                 extras["latency_ms"]["as_codec_checkpointed_stride_256"] = round(float(np.median([one_image(True) for _ in range(reps)])), 3)
                 extras["latency_ms"]["checkpoint_bytes_stride_256"] = int(sum(16 * len(x[0][0].ckpt) for x in r_256))
+            extras["latency_ms"]["calling_thread_on_its_l3_domain"] = wide is not None  # (as in the timed regions: plan_l3)
+            if wide is not None:
+                os.sched_setaffinity(0, wide)
+            _lib.set_profiling(local_rank, True)
             if a.diag and a.diag_steps > 0:
                 threads = _lib.lib().fgmm_ctx_threads(_lib.ctx(local_rank))
                 if a.diag_pools:

@@ -20,7 +20,7 @@ print(note)
 host, devt, pix = B.make_workload(0, 1, dev, "kodak24", False)
 gmc = GaussianMixtureConditional(K=4, mode="polya")
 ys, ss, ms, ws = (torch.cat([t[k] for t in devt]) for k in range(4))
-if mine:
+if mine and os.environ.get("LATENCY_NO_PIN") != "1":  # (LATENCY_NO_PIN=1: the calling thread stays on the process's CPUs)
     os.sched_setaffinity(0, mine)
 import gc
 
