@@ -193,10 +193,11 @@ public:
   Pool(int n, const WorkerCpus &where, char tag = 'w') : slot_((size_t)n), lifo_(getenv("FGMM_POOL_FIFO") == nullptr) {
     for (int i = 0; i < n; ++i)
       th_.emplace_back([this, i, where, tag] {
+        // (the affinity first: whoever finds a thread of this name in /proc/<pid>/task - bench.py's step_diag, the tests - sees its final mask)
+        if (where.restricted) (void)sched_setaffinity(0, sizeof where.set, &where.set); // (refused by the kernel: the inherited mask)
         char name[16];
         snprintf(name, sizeof name, "fgmm-%c%d", tag, i); // fgmm-w*: the context's pool (encode, copies); fgmm-d*: the decode calls' pool // (/proc/<pid>/task/<tid>/comm: bench.py's step_diag names the threads that waited for a CPU)
         pthread_setname_np(pthread_self(), name);
-        if (where.restricted) (void)sched_setaffinity(0, sizeof where.set, &where.set); // (refused by the kernel: the inherited mask)
         run(i);
       });
   }
