@@ -185,32 +185,38 @@ int main(int argc, char **argv) {
     char got[4096];
     CHECK(fgmm_ctx_worker_cpus(ctx, got, sizeof got) == FGMM_OK && !strcmp(got, want), "worker CPUs '%s', expected '%s'", got, want);
     CHECK(fgmm_ctx_set_threads(ctx, 6) == FGMM_OK, "threads"); // (a resized pool keeps the context's decision)
+    // (the pool's threads name themselves when they start, after they have taken their mask: look until all six are there)
     int seen = 0;
-    DIR *tasks = *want ? opendir("/proc/self/task") : nullptr;
-    for (struct dirent *de; tasks && (de = readdir(tasks));) {
-      const int tid = atoi(de->d_name);
-      if (tid <= 0) continue;
-      char path[64], line[256];
-      snprintf(path, sizeof path, "/proc/self/task/%d/comm", tid);
-      FILE *f = fopen(path, "r");
-      if (!f) continue;
-      const bool worker = fgets(line, sizeof line, f) && !strncmp(line, "fgmm-w", 6);
-      fclose(f);
-      if (!worker) continue;
-      snprintf(path, sizeof path, "/proc/self/task/%d/status", tid);
-      f = fopen(path, "r");
-      CHECK(f != nullptr, "status of thread %d", tid);
-      while (fgets(line, sizeof line, f))
-        if (!strncmp(line, "Cpus_allowed_list:", 18)) {
-          char *v = line + 18;
-          while (*v == ' ' || *v == '\t') ++v;
-          v[strcspn(v, "\n")] = 0;
-          CHECK(!strcmp(v, want), "worker thread %d may run on '%s', expected '%s'", tid, v, want);
-          ++seen;
-        }
-      fclose(f);
+    for (int attempt = 0; attempt < 400 && *want; ++attempt) {
+      seen = 0;
+      DIR *tasks = opendir("/proc/self/task");
+      for (struct dirent *de; tasks && (de = readdir(tasks));) {
+        const int tid = atoi(de->d_name);
+        if (tid <= 0) continue;
+        char path[64], line[256];
+        snprintf(path, sizeof path, "/proc/self/task/%d/comm", tid);
+        FILE *f = fopen(path, "r");
+        if (!f) continue;
+        const bool worker = fgets(line, sizeof line, f) && !strncmp(line, "fgmm-w", 6);
+        fclose(f);
+        if (!worker) continue;
+        snprintf(path, sizeof path, "/proc/self/task/%d/status", tid);
+        f = fopen(path, "r");
+        CHECK(f != nullptr, "status of thread %d", tid);
+        while (fgets(line, sizeof line, f))
+          if (!strncmp(line, "Cpus_allowed_list:", 18)) {
+            char *v = line + 18;
+            while (*v == ' ' || *v == '\t') ++v;
+            v[strcspn(v, "\n")] = 0;
+            CHECK(!strcmp(v, want), "worker thread %d may run on '%s', expected '%s'", tid, v, want);
+            ++seen;
+          }
+        fclose(f);
+      }
+      if (tasks) closedir(tasks);
+      if (seen == 6) break;
+      usleep(5000);
     }
-    if (tasks) closedir(tasks);
     CHECK(!*want || seen == 6, "%d worker threads found, expected 6", seen);
     printf("worker CPUs: '%s' (%d threads checked)\n", got, seen);
   }
