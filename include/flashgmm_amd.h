@@ -276,7 +276,7 @@ int fgmm_gmc_compress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int c
 int fgmm_gmc_decompress_batch(fgmm_ctx *ctx, void *stream, fgmm_item *items, int count, int mode, int clamp_scales);
 
 /* A sink: the bitstreams of a batched compress call written straight into storage of the caller's (a Python `bytes` object created
- * at its final size and filled by the flush - what rans_interface.cpp:590-607 does with its py::bytes - instead of a buffer of the
+ * at its final size and filled by the flush - what rans_interface.cpp:557-585 does with its py::bytes - instead of a buffer of the
  * library's that the binding copies once more: 2.5 MB per Kodak batch, 0.1 ms of the calling thread).  When item i's bitstream is
  * complete and its size known, the library calls alloc(user, i, nbytes) - ONCE per item, ON THE CALLING THREAD (it serves the host
  * workers' requests while it waits for them: a binding may take its interpreter's lock in alloc without its workers queueing for

@@ -557,7 +557,7 @@ def test_compiled_and_ctypes_bindings_agree(monkeypatch, stride):
 
 def test_sink_puts_the_bitstreams_into_the_callers_storage(monkeypatch):
     """include/flashgmm_amd.h: fgmm_sink.  fgmm_gmc_compress_batch_to asks the sink once per item, on the calling thread, for
-    storage of the bitstream's exact size and the worker that coded it writes it there (what rans_interface.cpp:590-607 does with its py::bytes): the same
+    storage of the bitstream's exact size and the worker that coded it writes it there (what rans_interface.cpp:557-585 does with its py::bytes): the same
     bytes as the plain call's buffers; a sink that refuses an item fails the call with FGMM_ERR_NOMEM and returns no buffer.  The
     compiled module's `bytes` objects are made that way: they hash, compare and slice like any other."""
     import ctypes as C
