@@ -240,6 +240,80 @@ void decompress_stacked(uintptr_t ctx_, uintptr_t stream, py::sequence strings, 
   if (rc) raise("GaussianMixtureConditional.decompress", rc);
 }
 
+// ---- items of any mix of shapes (the sequence form of compress_batch / decompress_batch: ELIC's ten groups per image) --------------
+// one item = a tuple of integers; compress: (y, scales, means, weights, M, hw, stride_k, stride_c, yq, zero_bitmap),
+// decompress: (scales, means, weights, M, hw, stride_k, stride_c, y_hat, zero_bitmap): device addresses, HOST zero bitmap
+void item_common(fgmm_item &f, const py::tuple &t, size_t at, int dtype, int flags) {
+  std::memset(&f, 0, sizeof f);
+  f.params.scales = ptr<const void>(py::cast<uintptr_t>(t[at]));
+  f.params.means = ptr<const void>(py::cast<uintptr_t>(t[at + 1]));
+  f.params.weights = ptr<const void>(py::cast<uintptr_t>(t[at + 2]));
+  f.M = py::cast<int32_t>(t[at + 3]), f.K = FGMM_K, f.hw = py::cast<int64_t>(t[at + 4]);
+  f.params.stride_k = py::cast<int64_t>(t[at + 5]), f.params.stride_c = py::cast<int64_t>(t[at + 6]);
+  f.params.dtype = dtype, f.params.flags = flags;
+  f.yq_out = ptr<float>(py::cast<uintptr_t>(t[at + 7]));
+  f.zero_bitmap = ptr<int64_t>(py::cast<uintptr_t>(t[at + 8]));
+}
+
+py::tuple compress_items(uintptr_t ctx_, uintptr_t stream, py::sequence items, int dtype, int flags, int mode, int clamp_scales, int ckpt_stride,
+                         py::object bytes_cls) {
+  fgmm_ctx *ctx = ptr<fgmm_ctx>(ctx_);
+  const size_t n = py::len(items);
+  std::vector<fgmm_item> it(n);
+  for (size_t i = 0; i < n; ++i) {
+    py::tuple t = py::cast<py::tuple>(items[i]);
+    if (t.size() != 10) throw std::runtime_error("compress_items: an item is (y, scales, means, weights, M, hw, stride_k, stride_c, yq, zero_bitmap)");
+    item_common(it[i], t, 1, dtype, flags);
+    it[i].y = ptr<const float>(py::cast<uintptr_t>(t[0]));
+    it[i].ckpt_stride = ckpt_stride;
+  }
+  py::list strings(n);
+  PySink to(strings, bytes_cls);
+  int rc;
+  {
+    py::gil_scoped_release nogil;
+    rc = fgmm_gmc_compress_batch_to(ctx, ptr<void>(stream), it.data(), (int)n, mode, clamp_scales, &to.sink);
+  }
+  if (rc) raise("GaussianMixtureConditional.compress", rc);
+  return finish_compress(ctx, it, ckpt_stride, strings);
+}
+
+void decompress_items(uintptr_t ctx_, uintptr_t stream, py::sequence strings, py::sequence abs_maxes, py::sequence items, int dtype, int flags, int mode,
+                      int clamp_scales, py::object ckpt_cls) {
+  fgmm_ctx *ctx = ptr<fgmm_ctx>(ctx_);
+  const size_t n = py::len(items);
+  if (py::len(strings) != n || py::len(abs_maxes) != n) throw std::runtime_error("decompress: " + std::to_string(n) + " items, " + std::to_string(py::len(strings)) + " bitstreams");
+  std::vector<fgmm_item> it(n);
+  PyTypeObject *cls = ckpt_cls.is_none() ? nullptr : reinterpret_cast<PyTypeObject *>(ckpt_cls.ptr());
+  static PyObject *ck_name = PyUnicode_InternFromString("_ck");
+  for (size_t i = 0; i < n; ++i) {
+    py::tuple t = py::cast<py::tuple>(items[i]);
+    if (t.size() != 9) throw std::runtime_error("decompress_items: an item is (scales, means, weights, M, hw, stride_k, stride_c, y_hat, zero_bitmap)");
+    fgmm_item &f = it[i];
+    item_common(f, t, 0, dtype, flags);
+    py::object b = strings[i];
+    if (!PyBytes_Check(b.ptr())) throw std::runtime_error("decompress: bitstream " + std::to_string(i) + " is not a bytes object");
+    f.bytes = reinterpret_cast<uint8_t *>(PyBytes_AS_STRING(b.ptr()));
+    f.bytes_len = (size_t)PyBytes_GET_SIZE(b.ptr());
+    f.abs_max = py::cast<int32_t>(abs_maxes[i]);
+    if (cls && PyObject_TypeCheck(b.ptr(), cls)) {
+      PyObject *rec = PyObject_GetAttr(b.ptr(), ck_name);
+      if (!rec) throw py::error_already_set();
+      py::tuple c = py::cast<py::tuple>(py::reinterpret_steal<py::object>(rec));
+      if (c.size() != 5) throw std::runtime_error("decompress: bitstream " + std::to_string(i) + ": malformed checkpoint record");
+      f.n_ckpt = py::cast<int64_t>(c[2]);
+      f.ckpt = ptr<fgmm_ckpt>(py::cast<uintptr_t>(c[3]));
+      f.ckpt_stride = py::cast<int32_t>(c[4]);
+    }
+  }
+  int rc;
+  {
+    py::gil_scoped_release nogil;
+    rc = fgmm_gmc_decompress_batch(ctx, ptr<void>(stream), it.data(), (int)n, mode, clamp_scales);
+  }
+  if (rc) raise("GaussianMixtureConditional.decompress", rc);
+}
+
 } // namespace
 
 PYBIND11_MODULE(_native, m) {
@@ -250,6 +324,9 @@ PYBIND11_MODULE(_native, m) {
         "stride_c"_a, "dtype"_a, "flags"_a, "mode"_a, "clamp_scales"_a, "ckpt_stride"_a, "yq"_a, "zero_bitmap"_a, "bytes_cls"_a = py::none());
   m.def("compress_head_stacked", &compress_head_stacked, "ctx"_a, "stream"_a, "y"_a, "x"_a, "head"_a, "N"_a, "M"_a, "c_in"_a, "hw"_a, "mode"_a, "clamp_scales"_a,
         "ckpt_stride"_a, "yq"_a, "zero_bitmap"_a, "bytes_cls"_a = py::none());
+  m.def("compress_items", &compress_items, "ctx"_a, "stream"_a, "items"_a, "dtype"_a, "flags"_a, "mode"_a, "clamp_scales"_a, "ckpt_stride"_a, "bytes_cls"_a = py::none());
+  m.def("decompress_items", &decompress_items, "ctx"_a, "stream"_a, "strings"_a, "abs_maxes"_a, "items"_a, "dtype"_a, "flags"_a, "mode"_a, "clamp_scales"_a,
+        "ckpt_cls"_a = py::none());
   m.def("decompress_stacked", &decompress_stacked, "ctx"_a, "stream"_a, "strings"_a, "abs_maxes"_a, "zero_bitmap"_a, "zb_row_stride"_a, "scales"_a, "means"_a,
         "weights"_a, "N"_a, "M"_a, "hw"_a, "item_stride"_a, "stride_k"_a, "stride_c"_a, "dtype"_a, "flags"_a, "mode"_a, "clamp_scales"_a, "y_hat"_a,
         "ckpt_cls"_a = py::none());

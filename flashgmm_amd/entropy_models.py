@@ -278,6 +278,40 @@ class GaussianMixtureConditional(nn.Module):
             keep.append(yc)
         return it, M, hw, s.device
 
+    def _item_ints(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor, keep: list):
+        """one item of the sequence form for the compiled boundary -> (pointers and strides as integers, M, hw, device, dtype); the
+        tensors whose storage the pointers name are appended to ``keep``"""
+        if not scales.is_cuda:
+            raise RuntimeError(
+                "flashgmm_amd runs the GMM entropy-coding path on the GPU only: tensors must be on a HIP device "
+                "(there is deliberately no CPU fallback)")
+        s, sk, sc = _plane_view(scales, self.K)
+        m, mk, mc = _plane_view(means, self.K)
+        w, wk, wc = _plane_view(weights, self.K)
+        if (mk, mc) != (sk, sc) or (wk, wc) != (sk, sc) or m.shape != s.shape or w.shape != s.shape:
+            if m.shape != s.shape or w.shape != s.shape:
+                raise RuntimeError("scales, means and weights must have one shape")
+            s, m, w = s.contiguous(), m.contiguous(), w.contiguous()
+            hw_ = s.size(2) * s.size(3)
+            sc, sk = hw_, (s.size(1) // self.K) * hw_
+        if not (s.dtype == m.dtype == w.dtype):
+            raise RuntimeError("scales, means and weights must share one dtype")
+        shp = s.shape
+        M = shp[1] // self.K
+        hw = shp[2] * shp[3]
+        keep += [s, m, w]
+        yp = 0
+        if y is not None:
+            ys_ = y.shape
+            if len(ys_) != 4 or ys_[0] != 1 or ys_[1] != M or ys_[2] * ys_[3] != hw:
+                raise RuntimeError(f"y must be [1, {M}, h, w] matching the parameters; got {tuple(ys_)}")
+            if y.dtype != torch.float32 or y.device != s.device:  # latents stay float32 (32 B/symbol with fp16 planes)
+                raise RuntimeError("y must be float32 on the parameters' device")
+            yc = y.contiguous()
+            yp = yc.data_ptr()
+            keep.append(yc)
+        return yp, s.data_ptr(), m.data_ptr(), w.data_ptr(), M, hw, sk, sc, s.device, s.dtype
+
     def _stacked_items(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor, flags: int = 0):
         """``fgmm_item[N]`` (as a numpy record array) for N items given as ONE tensor each: y ``[N, M, h, w]``,
         parameters ``[N, K*M, h, w]``.  One validation and one set of strides for the whole batch; the item
@@ -451,6 +485,33 @@ class GaussianMixtureConditional(nn.Module):
         if isinstance(ys, Tensor):
             return self._compress_stacked(ys, scales, means, weights, flags)
         n_items = len(ys)
+        nat = _lib.native()
+        if nat is not None and n_items > 0:  # the compiled boundary: items as tuples of integers, the bitstreams made by the call (fgmm_sink)
+            keep = []
+            tuples, outs, dev, dt = [], [], None, None
+            ms = []
+            for i in range(n_items):
+                yp, sp, mp, wp, M, hw, sk, sc, d, dti = self._item_ints(ys[i], scales[i], means[i], weights[i], keep)
+                dev, dt = dev or d, dt or dti
+                if d != dev:
+                    raise RuntimeError("all items of a batch must be on one device")
+                if dti != dt:
+                    raise RuntimeError("all items of a batch must have parameters of one dtype")
+                yq = torch.empty_like(keep[-1])
+                outs.append(yq)
+                ms.append(M)
+                tuples.append([yp, sp, mp, wp, M, hw, sk, sc, yq.data_ptr(), 0])
+            zb_all = torch.empty(sum(ms), dtype=torch.int64)  # the zero bitmaps of all items: one allocation, a view per item
+            at, base = 0, zb_all.data_ptr()
+            for t, M in zip(tuples, ms):
+                t[9] = base + 8 * at
+                at += M
+            di = dev.index if dev.index is not None else -1
+            strings, amax = nat.compress_items(_lib.ctx_addr(di), torch.cuda.current_stream(dev).cuda_stream, [tuple(t) for t in tuples],
+                                               _lib.FGMM_F16 if dt == torch.float16 else _lib.FGMM_F32, flags, self._mode(), int(self.clamp_scales),
+                                               self.checkpoint_stride, CheckpointedBytes if self.checkpoint_stride else None)
+            bitmaps = zb_all.split(ms)
+            return [((strings[i], amax[i], bitmaps[i]), outs[i].view_as(ys[i])) for i in range(n_items)]
         items = (_lib.fgmm_item * n_items)()
         keep: list = []
         outs, bitmaps = [], []
@@ -549,6 +610,32 @@ class GaussianMixtureConditional(nn.Module):
         if stacked_output:
             raise RuntimeError("stacked_output needs stacked parameters ([N, K*M, h, w] tensors)")
         n_items = len(strings)
+        nat = _lib.native()
+        if nat is not None and n_items > 0:
+            keep = []
+            tuples, outs, dev, dt = [], [], None, None
+            for i in range(n_items):
+                _, sp, mp, wp, M, hw, sk, sc, d, dti = self._item_ints(None, scales[i], means[i], weights[i], keep)
+                dev, dt = dev or d, dt or dti
+                if d != dev:
+                    raise RuntimeError("all items of a batch must be on one device")
+                if dti != dt:
+                    raise RuntimeError("all items of a batch must have parameters of one dtype")
+                zb = zero_bitmaps[i]
+                if zb.device.type != "cpu" or zb.dtype != torch.int64 or not zb.is_contiguous():
+                    zb = zb.to("cpu", torch.int64).contiguous()
+                if zb.numel() != M:
+                    raise RuntimeError(f"zero_bitmap has {zb.numel()} entries, expected {M}")
+                shp = scales[i].shape
+                y_hat = torch.empty((1, M, shp[2], shp[3]), dtype=torch.float32, device=d)
+                keep.append(zb)
+                outs.append(y_hat)
+                tuples.append((sp, mp, wp, M, hw, sk, sc, y_hat.data_ptr(), zb.data_ptr()))
+            data = strings if isinstance(strings, list) and all(isinstance(s_, bytes) for s_ in strings) else [s_ if isinstance(s_, bytes) else bytes(s_) for s_ in strings]
+            nat.decompress_items(_lib.ctx_addr(dev.index if dev.index is not None else -1), torch.cuda.current_stream(dev).cuda_stream, data,
+                                 [int(a) for a in abs_maxes], tuples, _lib.FGMM_F16 if dt == torch.float16 else _lib.FGMM_F32, flags, self._mode(),
+                                 int(self.clamp_scales), CheckpointedBytes)
+            return outs
         items = (_lib.fgmm_item * n_items)()
         keep: list = []
         outs = []

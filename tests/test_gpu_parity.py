@@ -541,8 +541,23 @@ def test_compiled_and_ctypes_bindings_agree(monkeypatch, stride):
     ys, ss, ms, ws = (torch.stack([torch.from_numpy(l[k][0]) for l in lat]).to("cuda:0") for k in range(4))
     nat = gmc.compress_batch(ys, ss, ms, ws)
     out_nat = [gmc.decompress_batch(nat.strings[s::2], nat.abs_maxes[s::2], nat.zero_bitmaps[s::2], ss[s::2], ms[s::2], ws[s::2], stacked_output=True) for s in range(2)]
+    # the sequence form (items of any mix of shapes: compress_items / decompress_items of the module)
+    mixed = [T.make_latent(4250 + i, M=(24, 40, 8)[i % 3], h=(8, 16, 4)[i % 3], w=(12, 8, 20)[i % 3], clamp=False, zero_frac=0.2 if i != 4 else 1.0) for i in range(7)]
+    mixed = [[torch.from_numpy(l[k]).to("cuda:0") for k in range(4)] for l in mixed]
+    cols = [[t[k] for t in mixed] for k in range(4)]
+    nat_l = gmc.compress_batch(*cols)
+    out_nat_l = gmc.decompress_batch([r[0][0] for r in nat_l], [r[0][1] for r in nat_l], [r[0][2] for r in nat_l], *cols[1:])
     monkeypatch.setattr(_lib, "_native", False)
     assert _lib.native() is None
+    cty_l = gmc.compress_batch(*cols)
+    out_cty_l = gmc.decompress_batch([r[0][0] for r in nat_l], [r[0][1] for r in nat_l], [r[0][2] for r in nat_l], *cols[1:])
+    for i in range(7):
+        (bn, an, zn), yn = nat_l[i]
+        (bc, ac, zc), yc = cty_l[i]
+        assert type(bn) is type(bc) is (CheckpointedBytes if stride else bytes) and bytes(bn) == bytes(bc) and an == ac and torch.equal(zn, zc) and torch.equal(yn, yc)
+        assert yn.shape == mixed[i][0].shape and torch.equal(yn, torch.round(mixed[i][0])) and torch.equal(out_nat_l[i], yn) and torch.equal(out_cty_l[i], yn)
+        if stride:
+            assert bn.ckpt_stride == stride and np.array_equal(bn.ckpt, bc.ckpt)
     cty = gmc.compress_batch(ys, ss, ms, ws)
     out_cty = [gmc.decompress_batch(nat.strings[s::2], nat.abs_maxes[s::2], nat.zero_bitmaps[s::2], ss[s::2], ms[s::2], ws[s::2], stacked_output=True) for s in range(2)]
     assert type(nat.strings[0]) is (CheckpointedBytes if stride else bytes) and type(cty.strings[0]) is type(nat.strings[0])
