@@ -178,10 +178,12 @@ struct EncodeCall {
   int64_t hw_max = 0;
   std::vector<int> order; // the bitstreams LARGEST FIRST (equal sizes: as given)
   int enc_T = 1, enc_ways = 1;
-  bool segmented = false;
+  bool segmented = false; // every table lies in segments (a worker per bitstream)
+  int n_segd = 0;         // tables that do: all of them, or - more bitstreams than workers - those of the bitstreams that are a job of their own
+  bool segd(const EncItem &it) const { return it.n_seg > 0; }
   // copies
   std::vector<int> group_of;
-  int n_groups = 0;
+  int n_groups = 0, n_seg_groups = 0; // of whole tables (ctx->events, waited for by the calling thread) / of segments (ctx->sleep_events, by the encoders)
   size_t ev_meta = 0;
   // host side
   std::vector<std::vector<int32_t>> wide_syms; // only for bypass symbols beyond int16 (rare)
@@ -233,13 +235,27 @@ struct EncodeCall {
       segmented = segmented && it.latent && !it.symbuf && it.M >= 2 * kEncSegs && it.hw > 0;
     }
     segmented = segmented && (tables >= ((size_t)4 << 20) || ctx->opt.enc_segs == 2); // (smaller calls: the transfer is not what they wait for; 2: tests)
-    if (!segmented) {
-      for (int i : order) items[i].o_packed = ar.take(table_bytes(items[i]) + 64);
-    } else {
-      for (auto &it : items) {
-        it.cps = (it.M + kEncSegs - 1) / kEncSegs;
-        it.n_seg = (it.M + it.cps - 1) / it.cps;
-      }
+    auto in_segments = [&](EncItem &it) {
+      it.cps = (it.M + kEncSegs - 1) / kEncSegs;
+      it.n_seg = (it.M + it.cps - 1) / it.cps;
+      ++n_segd;
+    };
+    if (segmented) {
+      for (auto &it : items) in_segments(it);
+    } else if (ctx->opt.enc_segs != 0 && ctx->opt.enc_ways == 0 && count > enc_T) {
+      // More bitstreams than workers (ELIC: 160 per call of sixteen 4K images, the largest sixteen 3.5 M symbols = 12 ms of encoding
+      // each): the bitstreams that are a worker's fair share by themselves (plan_jobs: jobs of their own) are the call's critical path -
+      // the last of their whole tables landed 6 ms into the call.  Their tables go in segments too, tail first across all of them and
+      // before every other table: their encoders start after a quarter of their transfer and follow the landing.
+      int64_t n_total = 0;
+      for (auto &it : items) n_total += (int64_t)it.M * it.hw;
+      const int64_t big = n_total / (2 * (int64_t)enc_T) + 1;
+      for (auto &it : items)
+        if (it.latent && !it.symbuf && it.M >= 2 * kEncSegs && it.hw > 0 && (int64_t)it.M * it.hw >= big &&
+            (table_bytes(it) >= ((size_t)1 << 20) || ctx->opt.enc_segs == 2))
+          in_segments(it);
+    }
+    if (n_segd) {
       for (int sg = kEncSegs - 1; sg >= 0; --sg)
         for (int i : order) {
           EncItem &it = items[i];
@@ -247,8 +263,11 @@ struct EncodeCall {
           const int32_t ch = std::min(it.M, (sg + 1) * it.cps) - sg * it.cps;
           it.o_seg[sg] = ar.take(sizeof(uint32_t) * (size_t)ch * (size_t)it.hw + 64);
         }
-      for (auto &it : items) it.o_packed = it.o_seg[0];
+      for (auto &it : items)
+        if (segd(it)) it.o_packed = it.o_seg[0];
     }
+    for (int i : order)
+      if (!segd(items[i])) items[i].o_packed = ar.take(table_bytes(items[i]) + 64);
     int rc;
     if ((rc = ctx->ensure_device(ar.off)) || (rc = ctx->ensure_host(ar.off)) || (rc = ctx->ensure_events((size_t)count + 17, 16))) return rc;
     ev_meta = (size_t)count + 16; // (the copy groups of the tables use the events before it: at most count, or nine)
@@ -280,7 +299,7 @@ struct EncodeCall {
     d.packed = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_packed);
     d.seg_b[0] = d.seg_b[1] = d.seg_b[2] = INT32_MAX;
     d.packed_seg[0] = d.packed;
-    if (segmented) {
+    if (segd(it)) {
       d.cps = it.cps;
       for (int sg = 0; sg < it.n_seg; ++sg) {
         d.packed_seg[sg] = reinterpret_cast<uint32_t *>(ctx->d_ws + it.o_seg[sg]);
@@ -338,8 +357,8 @@ struct EncodeCall {
     DEV_TRY(dev::copy_async(ctx->h_ws + o_small, ctx->d_ws + o_small, small_bytes, dev::kD2H, stream));
     DEV_TRY(dev::event_record(ctx->events[ev_meta], stream));
     group_of.assign((size_t)count, 0);
-    if (segmented) {
-      // the segments in the order they were laid out (tails of all bitstreams first), in about eight copies
+    if (n_segd) {
+      // the segments in the order they were laid out (tails of all segmented bitstreams first), in about eight copies
       struct Chunk {
         int item, sg;
         size_t beg, end;
@@ -355,7 +374,7 @@ struct EncodeCall {
           bytes += chunks.back().end - chunks.back().beg;
         }
       const size_t per_group = bytes / 8 + 1;
-      for (size_t c0 = 0; c0 < chunks.size(); ++n_groups) {
+      for (size_t c0 = 0; c0 < chunks.size(); ++n_seg_groups) {
         size_t c1 = c0, got = 0;
         do {
           got += chunks[c1].end - chunks[c1].beg;
@@ -363,27 +382,30 @@ struct EncodeCall {
         } while (c1 < chunks.size() && got < per_group);
         const size_t beg = chunks[c0].beg, end = chunks[c1 - 1].end; // (laid out in this order: one contiguous range)
         if (end > beg) DEV_TRY(dev::copy_async(ctx->h_ws + beg, ctx->d_ws + beg, end - beg, dev::kD2H, stream));
-        DEV_TRY(dev::event_record(ctx->sleep_events[(size_t)n_groups], stream));
-        for (size_t c = c0; c < c1; ++c) items[chunks[c].item].seg_group[chunks[c].sg] = n_groups;
+        DEV_TRY(dev::event_record(ctx->sleep_events[(size_t)n_seg_groups], stream));
+        for (size_t c = c0; c < c1; ++c) items[chunks[c].item].seg_group[chunks[c].sg] = n_seg_groups;
         c0 = c1;
       }
-      return FGMM_OK;
     }
+    // the whole tables, in their order (after the segments)
+    std::vector<int> rest;
     size_t tables = 0;
-    for (auto &it : items) tables += table_bytes(it);
-    const size_t per_group = count >= 16 ? tables / 6 + 1 : 0; // (fewer than 16 bitstreams: a copy each)
-    for (int p0 = 0; p0 < count; ++n_groups) {
+    for (int i : order)
+      if (!segd(items[i])) rest.push_back(i), tables += table_bytes(items[i]);
+    const int n_rest = (int)rest.size();
+    const size_t per_group = n_rest >= 16 ? tables / 6 + 1 : 0; // (fewer than 16 bitstreams: a copy each)
+    for (int p0 = 0; p0 < n_rest; ++n_groups) {
       int p1 = p0;
       size_t got = 0;
       do {
-        got += table_bytes(items[order[(size_t)p1]]);
+        got += table_bytes(items[rest[(size_t)p1]]);
         ++p1;
-      } while (p1 < count && got < per_group);
-      const EncItem &a = items[order[(size_t)p0]], &b = items[order[(size_t)p1 - 1]];
+      } while (p1 < n_rest && got < per_group);
+      const EncItem &a = items[rest[(size_t)p0]], &b = items[rest[(size_t)p1 - 1]];
       const size_t beg = a.o_packed, end = b.o_packed + table_bytes(b);
       if (end > beg) DEV_TRY(dev::copy_async(ctx->h_ws + beg, ctx->d_ws + beg, end - beg, dev::kD2H, stream));
       DEV_TRY(dev::event_record(ctx->events[(size_t)n_groups], stream));
-      for (int p = p0; p < p1; ++p) group_of[(size_t)order[(size_t)p]] = n_groups;
+      for (int p = p0; p < p1; ++p) group_of[(size_t)rest[(size_t)p]] = n_groups;
       p0 = p1;
     }
     return FGMM_OK;
@@ -459,7 +481,7 @@ struct EncodeCall {
     const int first_single = tail <= enc_T ? count - tail : count;
     auto small = [&](int pos) {
       const EncItem &e = items[order[(size_t)pos]];
-      return !e.symbuf && (int64_t)e.M * e.hw < big;
+      return !e.symbuf && !segd(e) && (int64_t)e.M * e.hw < big;
     };
     for (int p = 0; p < count;) {
       int q = p + 1;
@@ -561,7 +583,7 @@ struct EncodeCall {
       // share a core: 1.5 instead of 2.4 ns/symbol.  The job is submitted with its last member (the later copies hold the smaller tables)
       if (pos < job_last[(size_t)pos]) continue;
       const int g_begin = job_first[(size_t)pos], n_in = pos - g_begin + 1;
-      if (!segmented) {
+      if (!segd(items[i])) {
         int last_group = 0;
         for (int r = g_begin; r <= pos; ++r) last_group = std::max(last_group, group_of[(size_t)order[(size_t)r]]);
         DEV_TRY(dev::event_sync(ctx->events[(size_t)last_group])); // copies complete in the order they were queued
@@ -571,7 +593,7 @@ struct EncodeCall {
       const double t_sub = tr.ms();
       for (int q = 0; q < n_in; ++q) first[q]->t_sub = t_sub;
       std::function<void()> job;
-      if (segmented) {
+      if (segd(items[i])) { // (a job of its own: plan_jobs)
         seg_args[(size_t)i] = SegWaitArg{ctx->sleep_events.data(), items[i].seg_group, &tr, 0.0, 0.0};
         SegWaitArg *arg = &seg_args[(size_t)i];
         job = [this, first, arg] { run_segmented(*first[0], arg); };
@@ -597,6 +619,7 @@ struct EncodeCall {
     int rc;
     if ((rc = plan()) || (rc = enqueue_kernels()) || (rc = enqueue_copies())) return rc;
     tr.mark("enqueued");
+    if (tr.level > 0 && n_segd && !segmented) fprintf(stderr, "[fgmm encode]   %d of the %d tables in segments (the bitstreams that are jobs of their own)\n", n_segd, count);
     marks[0] = tr.ms();
     DEV_TRY(dev::event_sync(ctx->events[ev_meta]));
     tr.mark("kernels + meta landed");
@@ -615,7 +638,7 @@ struct EncodeCall {
     // copy group may still be in flight here, and the next call writes the pinned workspace it lands in (found on the fake device under
     // AddressSanitizer, round 5: descriptors of the following decode call overwritten by a stale table copy).  Copies complete in the
     // order they were queued: the last group's event covers them all; normally it has long fired.
-    if (segmented && n_groups > 0) DEV_TRY(dev::event_sync(ctx->sleep_events[(size_t)n_groups - 1]));
+    if (n_seg_groups > 0) DEV_TRY(dev::event_sync(ctx->sleep_events[(size_t)n_seg_groups - 1]));
     tr.mark("host rANS done");
     double busy = 0, wait = 0;
     for (auto &it : items) {

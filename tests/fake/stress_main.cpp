@@ -242,9 +242,17 @@ int main(int argc, char **argv) {
     set_opt(ctx, "stage_max_mb", !big && rnd() % 4 == 0 ? 1 : 0); // a tiny staging budget: launches overflow and are re-run
     set_opt(ctx, "tab_cap_e", !big && rnd() % 5 == 0 ? 256 : 12288); // a tiny LDS budget: items take the generic two-pass kernels
     set_opt(ctx, "spin_lat", rnd() % 3 == 0 ? -1 : 400000);
+    // one round in six: more bitstreams than workers under the automatic job plan with segments forced - the tables of the bitstreams
+    // that are jobs of their own go in segments, the others whole (fgmm_encode.cpp: plan)
+    const bool mixed_segs = !big && rounds % 6 == 5;
+    if (mixed_segs) {
+      CHECK(fgmm_ctx_set_threads(ctx, (int)pick(1, 3)) == FGMM_OK, "threads");
+      set_opt(ctx, "enc_ways", 0);
+      set_opt(ctx, "enc_segs", 2);
+    }
     const int mode = (int)(rnd() % 3), clamp = 1;
     const int32_t stride = !big && rnd() % 2 ? (int32_t)(256 << (rnd() % 3)) : 0; // checkpointed streams
-    const int count = big ? (rounds == 2 ? 2 : 1) : (int)pick(1, 12);
+    const int count = big ? (rounds == 2 ? 2 : 1) : mixed_segs ? (int)pick(5, 12) : (int)pick(1, 12);
     std::vector<Item> its((size_t)count);
     std::vector<fgmm_item> fi((size_t)count);
     for (int i = 0; i < count; ++i) {
