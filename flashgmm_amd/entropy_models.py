@@ -244,39 +244,14 @@ class GaussianMixtureConditional(nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def _item(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor, keep: list, flags: int = 0):
-        if not scales.is_cuda:
-            raise RuntimeError(
-                "flashgmm_amd runs the GMM entropy-coding path on the GPU only: tensors must be on a HIP device "
-                "(there is deliberately no CPU fallback)")
-        s, sk, sc = _plane_view(scales, self.K)
-        m, mk, mc = _plane_view(means, self.K)
-        w, wk, wc = _plane_view(weights, self.K)
-        if (mk, mc) != (sk, sc) or (wk, wc) != (sk, sc) or m.shape != s.shape or w.shape != s.shape:
-            if m.shape != s.shape or w.shape != s.shape:
-                raise RuntimeError("scales, means and weights must have one shape")
-            s, m, w = s.contiguous(), m.contiguous(), w.contiguous()
-            hw_ = s.size(2) * s.size(3)
-            sc, sk = hw_, (s.size(1) // self.K) * hw_
-        shp = s.shape
-        M = shp[1] // self.K
-        hw = shp[2] * shp[3]
+        """one item of the sequence form as an ``fgmm_item`` (the ctypes binding) -> (item, M, hw, device)"""
+        yp, sp, mp, wp, M, hw, sk, sc, dev, dt = self._item_ints(y, scales, means, weights, keep)
         it = _lib.fgmm_item()
-        if not (s.dtype == m.dtype == w.dtype):
-            raise RuntimeError("scales, means and weights must share one dtype")
-        it.params = _lib.fgmm_params(s.data_ptr(), m.data_ptr(), w.data_ptr(), sk, sc,
-                                     _lib.FGMM_F16 if s.dtype == torch.float16 else _lib.FGMM_F32, flags)
+        it.params = _lib.fgmm_params(sp, mp, wp, sk, sc, _lib.FGMM_F16 if dt == torch.float16 else _lib.FGMM_F32, flags)
         it.M, it.K, it.hw = M, self.K, hw
-        keep += [s, m, w]
         if y is not None:
-            ys_ = y.shape
-            if len(ys_) != 4 or ys_[0] != 1 or ys_[1] != M or ys_[2] * ys_[3] != hw:
-                raise RuntimeError(f"y must be [1, {M}, h, w] matching the parameters; got {tuple(ys_)}")
-            if y.dtype != torch.float32 or y.device != s.device:  # latents stay float32 (32 B/symbol with fp16 planes)
-                raise RuntimeError("y must be float32 on the parameters' device")
-            yc = y.contiguous()
-            it.y = yc.data_ptr()
-            keep.append(yc)
-        return it, M, hw, s.device
+            it.y = yp
+        return it, M, hw, dev
 
     def _item_ints(self, y: Optional[Tensor], scales: Tensor, means: Tensor, weights: Tensor, keep: list):
         """one item of the sequence form for the compiled boundary -> (pointers and strides as integers, M, hw, device, dtype); the
