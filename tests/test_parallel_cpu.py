@@ -211,3 +211,33 @@ def test_numa_binding_is_confirmed_against_the_runtimes_own_address(monkeypatch)
     assert calls == ["0000:5d:00.0"] and out.startswith("gpu 0 (0000:5d:00.0)") and "rebound" in out and "0000:1a:00.0" in out
     monkeypatch.setattr(P, "runtime_pci_address", lambda i: (_ for _ in ()).throw(RuntimeError("no device")))
     assert "not confirmed" in P.confirm_numa_binding(0, early)
+
+
+def test_checkpointed_bytes_is_a_bytes_object_with_its_notes():
+    """CheckpointedBytes (flashgmm_amd/entropy_models.py): the reference's stream as ``bytes`` (equal, hashable, sliceable, picklable)
+    plus the encoder's notes - given as an array, or (the compiled boundary, csrc/fgmm_pybind.cpp: adopt_ckpts) as a place in the
+    blob that holds the notes of all the bitstreams of a call, the view made when somebody asks for it"""
+    import pickle
+
+    import numpy as np
+
+    from flashgmm_amd import CheckpointedBytes
+    from flashgmm_amd.entropy_models import CKPT_DTYPE
+
+    data = bytes(range(200)) * 3
+    ck = np.zeros(3, CKPT_DTYPE)
+    ck["x"], ck["pos"] = [1 << 40, 1 << 41, 1 << 42], [5, 9, 14]
+    a = CheckpointedBytes(data, ck, 512)
+    assert a == data and hash(a) == hash(data) and a[3:9] == data[3:9] and isinstance(a, bytes) and {a: 1}[data] == 1
+    assert a.ckpt_stride == 512 and np.array_equal(a.ckpt, ck) and a._ckpt_addr == a.ckpt.ctypes.data and a._ck[2] == 3
+    b = pickle.loads(pickle.dumps(a))
+    assert type(b) is CheckpointedBytes and b == data and b.ckpt_stride == 512 and np.array_equal(b.ckpt, ck)
+    # as the module attaches them: (blob, first record, records, address of the first, stride)
+    blob = np.concatenate([np.zeros(2, CKPT_DTYPE), ck, np.zeros(4, CKPT_DTYPE)]).tobytes()
+    c = CheckpointedBytes.__new__(CheckpointedBytes, data, np.zeros(0, CKPT_DTYPE), 0)
+    c._ck = (blob, 2, 3, 12345, 512)
+    assert c.ckpt_stride == 512 and c._ckpt_addr == 12345 and np.array_equal(c.ckpt, ck) and isinstance(c._ck[0], np.ndarray)  # (the view is kept)
+    e = CheckpointedBytes(data, np.zeros(0, CKPT_DTYPE), 256)  # a stream too short for a note
+    assert len(e.ckpt) == 0 and e._ckpt_addr == 0 and e.ckpt_stride == 256
+    e._ck = (blob, 9, 0, 0, 256)
+    assert len(e.ckpt) == 0
