@@ -25,7 +25,7 @@ while time.time() < t_end:
     opts = dict(pieces=int(rng.integers(0, 33)), dec_first=int(rng.integers(1, 10)),
                 ef_min=int(rng.choice([14, 33, 49, 200])), ef_rows=int(rng.integers(0, 3)),
                 enc_ways=int(rng.integers(0, 5)), ckpt_decode=int(rng.integers(0, 3)), gpu_decode=int(rng.choice([0, 2])),
-                enc_segs=int(rng.integers(0, 2)), scatter_rounds=int(rng.integers(0, 2)))
+                enc_segs=int(rng.integers(0, 3)), scatter_rounds=int(rng.integers(0, 2)))
     ck_stride = int(rng.choice([0, 0, 256, 1024, 4096]))  # checkpointed streams: segments on the workers
     for k, v in opts.items(): _lib.set_option(0, k, v)
     for mode in ("polya", "as", "logistic"):
